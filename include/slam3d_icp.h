@@ -1,0 +1,174 @@
+/*
+ * slam3d_icp.h -- C-ABI of the MI355X-native plane-ICP registration path.
+ *
+ * This is the drop-in boundary for the per-frame alignment of gaoxiang12/slam3d_gx:
+ * the reference's seam is the virtual method
+ *     RESULT_OF_MULTIPNP GraphicEnd::multiPnP(vector<PLANE>&, vector<PLANE>&, bool, int, int)
+ *         src/GraphicEnd.h:134, src/GraphicEnd.cpp:557-659   (callers :168,:187,:195,:700,:736,:813,:892)
+ * and the frame producer GraphicEnd::readimage() src/GraphicEnd.cpp:266-302.  A subclass in the
+ * style of GraphicEnd2 (src/GraphicEnd.h:262-275) overrides those two and forwards to the entry
+ * points below (INTEGRATION.md shows the binding).  Plain C structs, fixed-width integers,
+ * caller-owned host memory, no C++/torch types.
+ *
+ * Conventions kept from the reference:
+ *   - pose direction: X_target(present) = T * X_source(keyframe)        (src/GraphicEnd.cpp:169-170,589-590)
+ *   - norm = |min(angle, 2pi-angle)| + 0.9*||t||                        (src/GraphicEnd.cpp:618)
+ *   - failure is signalled by T == Identity                             (src/GraphicEnd.cpp:173)
+ *   - thresholds minimum_inliers / error_threshold                      (src/GraphicEnd.cpp:599,:621)
+ *   - never throws; returns int status
+ * T is ROW-MAJOR double[16] here (Eigen::Isometry3d of RESULT_OF_MULTIPNP, src/GraphicEnd.h:59-69,
+ * is column-major: transpose when copying into .matrix().data()).
+ */
+#ifndef SLAM3D_ICP_H
+#define SLAM3D_ICP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAM3D_ICP_ABI_VERSION 1
+#define SLAM3D_ICP_NSUMS 29   /* 21 upper-tri AtA + 6 Atb + count + sum r^2 */
+
+/* return codes: 0 ok; >0 algorithmic (result.T == Identity); <0 usage / runtime errors */
+enum {
+    SLAM3D_OK = 0,
+    SLAM3D_TOO_FEW_INLIERS = 1,     /* inliers < min_inliers        src/GraphicEnd.cpp:599 */
+    SLAM3D_NORM_EXCEEDED = 2,       /* norm > error_threshold       src/GraphicEnd.cpp:621 */
+    SLAM3D_DEGENERATE = 3,          /* normal equations needed damping (planes do not span R^3) */
+    SLAM3D_E_INVALID = -1,          /* bad argument */
+    SLAM3D_E_HIP = -2,              /* HIP runtime error (see slam3d_last_error) */
+    SLAM3D_E_NOMEM = -3,
+    SLAM3D_E_NODEVICE = -4,         /* no gfx950 device visible */
+    SLAM3D_E_STATE = -5             /* call order violated (e.g. fetch before run) */
+};
+
+enum { SLAM3D_EST_POINT2PLANE = 0, SLAM3D_EST_SVD = 1 };
+/* NN search variants: all return bit-identical correspondences */
+enum { SLAM3D_NN_AUTO = 0, SLAM3D_NN_BRUTE_VALU = 1, SLAM3D_NN_BRUTE_MFMA = 2 };
+
+typedef struct slam3d_icp_params {
+    int32_t width, height;          /* organized cloud size (640x480 Kinect)                         */
+    double  fx, fy, cx, cy;         /* pinhole intrinsics, parameters.yaml camera_* (:82-86)         */
+    double  depth_factor;           /* parameters.yaml camera_factor                                 */
+    double  z_filter;               /* validity 0 < z <= z_filter, parameters.yaml:65                */
+    int32_t iterations;             /* icp_iterations (20); fixed count, no early exit               */
+    double  max_corr_dist;          /* icp_max_corr_dist (0.10 m)                                    */
+    int32_t estimator;              /* SLAM3D_EST_*                                                  */
+    int32_t normal_window;          /* 7   (src/planarFeatures.cpp:92)                               */
+    int32_t normal_min_inliers;     /* 41  (src/planarFeatures.cpp:128, "> 40")                      */
+    double  normal_inlier_dist;     /* 0.01 (src/planarFeatures.cpp:123)                             */
+    int32_t min_inliers;            /* 12  (multiPnP default, src/GraphicEnd.h:134)                  */
+    double  error_threshold;        /* 1.0 (parameters.yaml:39)                                      */
+    int32_t max_batch;              /* frame pairs resident per handle                               */
+    int32_t device;                 /* HIP device ordinal                                            */
+    int32_t nn_mode;                /* SLAM3D_NN_*                                                   */
+} slam3d_icp_params;
+
+/* a borrowed view of an organized cloud: `data` points at width*height records of
+ * `stride_bytes` each whose first 12 bytes are float x,y,z (pcl::PointXYZRGBA is 32 B,
+ * src/GraphicEnd.h:71-72; a packed float4 cloud is 16 B).  Invalid = NaN or z <= 0. */
+typedef struct slam3d_cloud_view {
+    const void *data;
+    int32_t stride_bytes;
+    int32_t width, height;
+} slam3d_cloud_view;
+
+/* mirrors RESULT_OF_MULTIPNP {T, norm, inliers} (src/GraphicEnd.h:59-69) + diagnostics */
+typedef struct slam3d_icp_result {
+    double  T[16];                  /* row-major; Identity unless status == SLAM3D_OK               */
+    double  norm;
+    int32_t inliers;
+    int32_t status;                 /* SLAM3D_OK / TOO_FEW_INLIERS / NORM_EXCEEDED / DEGENERATE     */
+    int32_t iterations;
+    int32_t n_src, n_tgt;           /* valid source points / valid target points searched           */
+    int32_t _pad;
+    double  rmse;                   /* sqrt(sum r^2 / inliers) at the last iteration                */
+    double  T_raw[16];              /* the converged estimate even when status != OK                */
+} slam3d_icp_result;
+
+/* plane of PLANE::coff (src/GraphicEnd.h:43): a,b,c,d with unit normal, d >= 0 (src/GraphicEnd.cpp:383-387) */
+typedef struct slam3d_plane {
+    float   coeff[4];
+    int32_t count;
+    float   centroid[3];
+} slam3d_plane;
+
+typedef struct slam3d_icp_handle slam3d_icp_handle;
+
+/* ---- lifecycle --------------------------------------------------------------------------- */
+void        slam3d_icp_default_params(slam3d_icp_params *p);
+int         slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle **out);
+void        slam3d_icp_destroy(slam3d_icp_handle *h);
+const char *slam3d_strerror(int code);
+const char *slam3d_last_error(const slam3d_icp_handle *h);   /* text of the last HIP failure */
+int         slam3d_icp_abi_version(void);
+
+/* ---- one-call pose API (replaces multiPnP, src/GraphicEnd.cpp:557-659) ------------------- */
+/* source = keyframe cloud, target = present cloud; T_init nullable (Identity). */
+int slam3d_icp_align(slam3d_icp_handle *h, const slam3d_cloud_view *src, const slam3d_cloud_view *tgt,
+                     const double *T_init, slam3d_icp_result *out);
+/* B independent pairs (loop-closure candidates, src/GraphicEnd.cpp:685-762, are such a batch). */
+int slam3d_icp_align_batch(slam3d_icp_handle *h, int32_t B, const slam3d_cloud_view *src,
+                           const slam3d_cloud_view *tgt, const double *T_init /* B*16 or NULL */,
+                           slam3d_icp_result *out /* B */);
+/* same, from raw 16-bit depth images (readimage + back-projection, src/GraphicEnd.cpp:266-302,
+ * src/convert2PCD.cpp:54-72) */
+int slam3d_icp_align_depth_batch(slam3d_icp_handle *h, int32_t B, const uint16_t *const *src_depth,
+                                 const uint16_t *const *tgt_depth, const double *T_init,
+                                 slam3d_icp_result *out);
+
+/* ---- staged API (inputs resident in HBM; no host sync between set/run/fetch) ------------- */
+int slam3d_icp_set_clouds_host(slam3d_icp_handle *h, int32_t slot, const slam3d_cloud_view *src,
+                               const slam3d_cloud_view *tgt);
+int slam3d_icp_set_depth_host(slam3d_icp_handle *h, int32_t slot, const uint16_t *src_depth,
+                              const uint16_t *tgt_depth);
+/* device pointers to organized float4 {x,y,z,-} clouds of width*height points; borrowed until
+ * the next set_* on that slot. */
+int slam3d_icp_set_clouds_device(slam3d_icp_handle *h, int32_t slot, const void *d_src_xyz4,
+                                 const void *d_tgt_xyz4);
+/* device pointers to u16 depth images; back-projected on the device into the handle's clouds. */
+int slam3d_icp_set_depth_device(slam3d_icp_handle *h, int32_t slot, const void *d_src_depth,
+                                const void *d_tgt_depth);
+/* enqueue preprocessing (normals, compaction) + `iterations` ICP iterations for slots [0,B) on
+ * `stream` (hipStream_t, NULL = the handle's own stream).  Asynchronous. */
+int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_init, void *stream);
+/* wait for the run and produce results (norm / thresholds evaluated on the host). */
+int slam3d_icp_fetch_results(slam3d_icp_handle *h, int32_t B, slam3d_icp_result *out);
+
+/* ---- introspection for parity tests ------------------------------------------------------ */
+/* correspondences of the LAST iteration: idx[N] original linear target index or -1, d2[N] (inf) */
+int slam3d_icp_get_correspondences(slam3d_icp_handle *h, int32_t slot, int32_t *idx, float *d2);
+/* T_trace[(iterations+1)*16], sums_trace[iterations*29] (either nullable) */
+int slam3d_icp_get_trace(slam3d_icp_handle *h, int32_t slot, double *T_trace, double *sums_trace);
+/* organized float4 clouds / target normals as the device holds them (each N*4 floats, nullable) */
+int slam3d_icp_get_clouds(slam3d_icp_handle *h, int32_t slot, float *src_xyz4, float *tgt_xyz4,
+                          float *tgt_nrm4);
+/* kernel time of the last run, by bucket (ms): [0] preprocess [1] nn [2] accumulate+solve [3] total */
+int slam3d_icp_get_timings(slam3d_icp_handle *h, float ms[4]);
+
+/* ---- building blocks (rows a5, a6 of the scope table) ------------------------------------ */
+/* u16 depth (host) -> organized float4 cloud (host); src/convert2PCD.cpp:54-72 */
+int slam3d_backproject_u16(slam3d_icp_handle *h, const uint16_t *depth, float *xyz4);
+/* per-plane LS fit from labels (PCL's optimizeCoefficients inside SACSegmentation::segment,
+ * src/GraphicEnd.cpp:360-375; sign rule :383-387).  labels[N] in {-1, 0..nplanes-1}. */
+int slam3d_fit_planes(slam3d_icp_handle *h, const slam3d_cloud_view *cloud, const int32_t *labels,
+                      int32_t nplanes, slam3d_plane *planes);
+
+/* ---- dense (single pair sharded over ranks) building blocks, one exchange per iteration -- */
+/* restrict the source rows this handle works on to [row_begin,row_end) of slot 0 */
+int slam3d_icp_dense_set_rows(slam3d_icp_handle *h, int32_t row_begin, int32_t row_end);
+/* preprocess slot 0 (normals, compaction) and reset T to T_init */
+int slam3d_icp_dense_begin(slam3d_icp_handle *h, const double *T_init, void *stream);
+/* one NN + accumulate pass over the local rows: 29 partial sums on the host */
+int slam3d_icp_dense_partial(slam3d_icp_handle *h, double sums[SLAM3D_ICP_NSUMS], void *stream);
+/* solve with the (all-reduced) sums and update T on every rank identically */
+int slam3d_icp_dense_update(slam3d_icp_handle *h, const double sums[SLAM3D_ICP_NSUMS], void *stream);
+int slam3d_icp_dense_finish(slam3d_icp_handle *h, const double last_sums[SLAM3D_ICP_NSUMS],
+                            slam3d_icp_result *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAM3D_ICP_H */

@@ -1,0 +1,772 @@
+/*
+ * icp_oracle.c -- CPU ORACLE (test infrastructure, see icp_oracle.h header note).
+ *
+ * Plain C restatement of the plane-ICP path, DESIGN.md section 3 ("normative
+ * spec", stages S1..S6).  PARITY UNPINNED except S1 (see icp_oracle.h).
+ *
+ * Build: gcc -O2 -mfma -ffp-contract=off -fno-fast-math -fopenmp  (oracle/Makefile)
+ * -ffp-contract=off + explicit fmaf() where the spec says so makes every float /
+ * double operation here an individually rounded IEEE op in a fixed order, which
+ * is what the HIP kernels reproduce.
+ */
+#include "icp_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ params */
+void orc_default_params(orc_params *p)
+{
+    memset(p, 0, sizeof(*p));
+    p->width = 640; p->height = 480;
+    /* src/convert2PCD.cpp:19-23 -- the intrinsics the committed fixtures were made with */
+    p->fx = 525.0; p->fy = 525.0; p->cx = 319.5; p->cy = 235.5; p->depth_factor = 1000.0;
+    p->z_filter = 7.0;                 /* parameters.yaml:65 */
+    p->iterations = 20;
+    p->max_corr_dist = 0.10;
+    p->estimator = ORC_EST_POINT2PLANE;
+    p->normal_window = 7;              /* src/planarFeatures.cpp:92 */
+    p->normal_min_inliers = 41;        /* src/planarFeatures.cpp:128  (> 40) */
+    p->normal_inlier_dist = 0.01;      /* src/planarFeatures.cpp:123 */
+    p->min_inliers = 12;               /* src/GraphicEnd.h:134 default arg */
+    p->error_threshold = 1.0;          /* parameters.yaml:39 */
+    p->nn_method = ORC_NN_KDTREE;
+    p->threads = 0;
+}
+
+static int n_threads(const orc_params *p)
+{
+#ifdef _OPENMP
+    return p->threads > 0 ? p->threads : omp_get_max_threads();
+#else
+    (void)p; return 1;
+#endif
+}
+
+/* ------------------------------------------------------------ S1 backproject
+ * src/convert2PCD.cpp:65-69: z = d/factor; x = (n-cx)*z/fx; y = (m-cy)*z/fy in
+ * double, stored to float.  d==0 is dropped there (:61); the PassThrough of
+ * src/GraphicEnd.cpp:283-285 (z in [0, z_filter]) becomes part of the mask. */
+void orc_backproject(const uint16_t *depth, const orc_params *p, float *xyz4)
+{
+    const int W = p->width, H = p->height;
+    for (int v = 0; v < H; ++v)
+        for (int u = 0; u < W; ++u) {
+            const int i = v * W + u;
+            const uint16_t d = depth[i];
+            double z = (double)d / p->depth_factor;
+            float *o = xyz4 + 4 * (size_t)i;
+            if (d == 0 || !(z <= p->z_filter)) {
+                o[0] = o[1] = o[2] = NAN; o[3] = 0.0f;
+                continue;
+            }
+            double x = ((double)u - p->cx) * z / p->fx;
+            double y = ((double)v - p->cy) * z / p->fy;
+            o[0] = (float)x; o[1] = (float)y; o[2] = (float)z; o[3] = 1.0f;
+        }
+}
+
+static inline int point_valid(const float *q, float zmax)
+{
+    return isfinite(q[0]) && isfinite(q[1]) && isfinite(q[2]) && q[2] > 0.0f && q[2] <= zmax;
+}
+
+/* ------------------------------------------------------- 3x3 Jacobi eigen
+ * cyclic Jacobi, fixed 8 sweeps, rotation order (0,1),(0,2),(1,2). */
+void orc_eig3(const double A[6], double evals[3], double V[9])
+{
+    double a[3][3] = { { A[0], A[1], A[2] }, { A[1], A[3], A[4] }, { A[2], A[4], A[5] } };
+    double v[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
+    static const int PP[3] = { 0, 0, 1 }, QQ[3] = { 1, 2, 2 }, RR[3] = { 2, 1, 0 };
+    for (int sweep = 0; sweep < 8; ++sweep)
+        for (int k = 0; k < 3; ++k) {
+            const int p = PP[k], q = QQ[k], r = RR[k];
+            const double apq = a[p][q];
+            if (apq == 0.0) continue;
+            const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+            double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+            if (theta < 0.0) t = -t;
+            const double c = 1.0 / sqrt(t * t + 1.0);
+            const double s = t * c;
+            a[p][p] = a[p][p] - t * apq;
+            a[q][q] = a[q][q] + t * apq;
+            a[p][q] = a[q][p] = 0.0;
+            const double arp = a[r][p], arq = a[r][q];
+            a[r][p] = a[p][r] = c * arp - s * arq;
+            a[r][q] = a[q][r] = s * arp + c * arq;
+            for (int m = 0; m < 3; ++m) {
+                const double vmp = v[m][p], vmq = v[m][q];
+                v[m][p] = c * vmp - s * vmq;
+                v[m][q] = s * vmp + c * vmq;
+            }
+        }
+    for (int k = 0; k < 3; ++k) evals[k] = a[k][k];
+    for (int m = 0; m < 3; ++m) for (int k = 0; k < 3; ++k) V[m * 3 + k] = v[m][k]; /* column k = evec k */
+}
+
+/* ------------------------------------------------------------- S2 normals */
+static void normal_at(const float *xyz4, int W, int H, int u, int v, int r,
+                      float zmax, int min_in, double in_dist, float *out)
+{
+    out[0] = out[1] = out[2] = out[3] = 0.0f;
+    const float *c0 = xyz4 + 4 * ((size_t)v * W + u);
+    if (!point_valid(c0, zmax)) return;
+    const double cx0 = c0[0], cy0 = c0[1], cz0 = c0[2];
+    int n = 0;
+    double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+    for (int dv = -r; dv <= r; ++dv)
+        for (int du = -r; du <= r; ++du) {
+            const int uu = u + du, vv = v + dv;
+            if (uu < 0 || uu >= W || vv < 0 || vv >= H) continue;
+            const float *q = xyz4 + 4 * ((size_t)vv * W + uu);
+            if (!point_valid(q, zmax)) continue;
+            const double dx = (double)q[0] - cx0, dy = (double)q[1] - cy0, dz = (double)q[2] - cz0;
+            ++n;
+            sx += dx; sy += dy; sz += dz;
+            sxx += dx * dx; sxy += dx * dy; sxz += dx * dz;
+            syy += dy * dy; syz += dy * dz; szz += dz * dz;
+        }
+    if (n < min_in) return;
+    const double inv = 1.0 / (double)n;
+    const double mx = sx * inv, my = sy * inv, mz = sz * inv;
+    double C[6];
+    C[0] = sxx * inv - mx * mx; C[1] = sxy * inv - mx * my; C[2] = sxz * inv - mx * mz;
+    C[3] = syy * inv - my * my; C[4] = syz * inv - my * mz; C[5] = szz * inv - mz * mz;
+    double ev[3], V[9];
+    orc_eig3(C, ev, V);
+    int k = 0;
+    if (ev[1] < ev[k]) k = 1;
+    if (ev[2] < ev[k]) k = 2;
+    double nx = V[0 + k], ny = V[3 + k], nz = V[6 + k];
+    const double len = sqrt(nx * nx + ny * ny + nz * nz);
+    nx = nx / len; ny = ny / len; nz = nz / len;
+    if (nx * cx0 + ny * cy0 + nz * cz0 > 0.0) { nx = -nx; ny = -ny; nz = -nz; } /* toward camera */
+    int cnt = 0;
+    for (int dv = -r; dv <= r; ++dv)
+        for (int du = -r; du <= r; ++du) {
+            const int uu = u + du, vv = v + dv;
+            if (uu < 0 || uu >= W || vv < 0 || vv >= H) continue;
+            const float *q = xyz4 + 4 * ((size_t)vv * W + uu);
+            if (!point_valid(q, zmax)) continue;
+            const double dx = (double)q[0] - cx0, dy = (double)q[1] - cy0, dz = (double)q[2] - cz0;
+            const double e = nx * (dx - mx) + ny * (dy - my) + nz * (dz - mz);
+            if (fabs(e) <= in_dist) ++cnt;
+        }
+    if (cnt < min_in) return;
+    out[0] = (float)nx; out[1] = (float)ny; out[2] = (float)nz; out[3] = 1.0f;
+}
+
+void orc_normals(const float *xyz4, const orc_params *p, float *nrm4)
+{
+    const int W = p->width, H = p->height, r = p->normal_window / 2;
+    const float zmax = (float)p->z_filter;
+    const int nt = n_threads(p);
+    (void)nt;
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (int v = 0; v < H; ++v)
+        for (int u = 0; u < W; ++u)
+            normal_at(xyz4, W, H, u, v, r, zmax, p->normal_min_inliers, p->normal_inlier_dist,
+                      nrm4 + 4 * ((size_t)v * W + u));
+}
+
+/* ------------------------------------------------------------ spec sincos
+ * Deterministic sin/cos from +,-,*,floor only (libm's differ between CPU and GPU):
+ * k = floor(x*2/pi + 0.5); r = (x - k*PIO2_HI) - k*PIO2_LO; Taylor in r*r (Horner). */
+void orc_sincos(double x, double *s, double *c)
+{
+    const double kf = floor(x * 0.63661977236758134308 + 0.5);
+    const double r = (x - kf * 1.57079632673412561417e+00) - kf * 6.07710050650619224932e-11;
+    const double z = r * r;
+    /* sin r = r*(1 - z/3! + z^2/5! - ... - z^7/15! + z^8/17!) */
+    double ps = 1.0 / 355687428096000.0;             /* 1/17! */
+    ps = ps * z - 1.0 / 1307674368000.0;             /* 1/15! */
+    ps = ps * z + 1.0 / 6227020800.0;                /* 1/13! */
+    ps = ps * z - 1.0 / 39916800.0;                  /* 1/11! */
+    ps = ps * z + 1.0 / 362880.0;                    /* 1/9!  */
+    ps = ps * z - 1.0 / 5040.0;                      /* 1/7!  */
+    ps = ps * z + 1.0 / 120.0;                       /* 1/5!  */
+    ps = ps * z - 1.0 / 6.0;                         /* 1/3!  */
+    const double sr = r + r * (z * ps);
+    /* cos r = 1 - z/2! + z^2/4! - ... + z^8/16! - z^9/18! */
+    double pc = -1.0 / 6402373705728000.0;           /* 1/18! */
+    pc = pc * z + 1.0 / 20922789888000.0;            /* 1/16! */
+    pc = pc * z - 1.0 / 87178291200.0;               /* 1/14! */
+    pc = pc * z + 1.0 / 479001600.0;                 /* 1/12! */
+    pc = pc * z - 1.0 / 3628800.0;                   /* 1/10! */
+    pc = pc * z + 1.0 / 40320.0;                     /* 1/8!  */
+    pc = pc * z - 1.0 / 720.0;                       /* 1/6!  */
+    pc = pc * z + 1.0 / 24.0;                        /* 1/4!  */
+    pc = pc * z - 0.5;                               /* 1/2!  */
+    const double cr = 1.0 + z * pc;
+    long long k = (long long)kf;
+    int quad = (int)(((k % 4) + 4) % 4);
+    switch (quad) {
+    case 0: *s = sr;  *c = cr;  break;
+    case 1: *s = cr;  *c = -sr; break;
+    case 2: *s = -sr; *c = -cr; break;
+    default: *s = -cr; *c = sr; break;
+    }
+}
+
+/* --------------------------------------------------------- 6x6 LDL^T solve */
+static int ldl6(const double A[6][6], const double b[6], double tr, double x[6])
+{
+    double L[6][6], D[6], y[6];
+    const double floor_piv = 1e-12 * tr / 6.0;
+    memset(L, 0, sizeof(L));
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j][j];
+        for (int k = 0; k < j; ++k) d -= (L[j][k] * L[j][k]) * D[k];
+        if (!(d > floor_piv)) return 0;
+        D[j] = d;
+        for (int i = j + 1; i < 6; ++i) {
+            double v = A[i][j];
+            for (int k = 0; k < j; ++k) v -= (L[i][k] * L[j][k]) * D[k];
+            L[i][j] = v / d;
+        }
+    }
+    for (int i = 0; i < 6; ++i) {
+        double v = b[i];
+        for (int k = 0; k < i; ++k) v -= L[i][k] * y[k];
+        y[i] = v;
+    }
+    for (int i = 0; i < 6; ++i) y[i] = y[i] / D[i];
+    for (int i = 5; i >= 0; --i) {
+        double v = y[i];
+        for (int k = i + 1; k < 6; ++k) v -= L[k][i] * x[k];
+        x[i] = v;
+    }
+    return 1;
+}
+
+/* returns 1 = solved, 2 = solved after Tikhonov damping (degenerate), 0 = failed */
+int orc_solve6(const double U[21], const double Atb[6], double x[6])
+{
+    double A[6][6];
+    int k = 0;
+    for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c) { A[r][c] = A[c][r] = U[k]; ++k; }
+    double tr = 0.0;
+    for (int r = 0; r < 6; ++r) tr += A[r][r];
+    if (!(tr > 0.0)) return 0;
+    if (ldl6(A, Atb, tr, x)) return 1;
+    const double lam = 1e-9 * tr / 6.0;
+    for (int r = 0; r < 6; ++r) A[r][r] = A[r][r] + lam;
+    if (ldl6(A, Atb, tr, x)) return 2;
+    return 0;
+}
+
+/* ----------------------------------------------------- 3x3 SVD -> rotation
+ * one-sided (Hestenes) Jacobi on the columns of H, 12 fixed sweeps; R = V U^T
+ * with the smallest-singular-value pair replaced by cross products (det = +1). */
+void orc_svd3_rotation(const double H[9], double R[9])
+{
+    double g[3][3], v[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } }; /* [row][col] */
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) g[r][c] = H[r * 3 + c];
+    static const int PP[3] = { 0, 0, 1 }, QQ[3] = { 1, 2, 2 };
+    for (int sweep = 0; sweep < 12; ++sweep)
+        for (int k = 0; k < 3; ++k) {
+            const int p = PP[k], q = QQ[k];
+            const double al = (g[0][p] * g[0][p] + g[1][p] * g[1][p]) + g[2][p] * g[2][p];
+            const double be = (g[0][q] * g[0][q] + g[1][q] * g[1][q]) + g[2][q] * g[2][q];
+            const double ga = (g[0][p] * g[0][q] + g[1][p] * g[1][q]) + g[2][p] * g[2][q];
+            if (ga == 0.0) continue;
+            const double zeta = (be - al) / (2.0 * ga);
+            double t = 1.0 / (fabs(zeta) + sqrt(zeta * zeta + 1.0));
+            if (zeta < 0.0) t = -t;
+            const double c = 1.0 / sqrt(t * t + 1.0);
+            const double s = c * t;
+            for (int m = 0; m < 3; ++m) {
+                const double gp = g[m][p], gq = g[m][q];
+                g[m][p] = c * gp - s * gq;
+                g[m][q] = s * gp + c * gq;
+                const double vp = v[m][p], vq = v[m][q];
+                v[m][p] = c * vp - s * vq;
+                v[m][q] = s * vp + c * vq;
+            }
+        }
+    double sg[3];
+    for (int k = 0; k < 3; ++k)
+        sg[k] = sqrt((g[0][k] * g[0][k] + g[1][k] * g[1][k]) + g[2][k] * g[2][k]);
+    int i0 = 0, i1 = 1, i2 = 2, tmp;
+    /* stable descending sort of 3 */
+    if (sg[i1] > sg[i0]) { tmp = i0; i0 = i1; i1 = tmp; }
+    if (sg[i2] > sg[i1]) { tmp = i1; i1 = i2; i2 = tmp; }
+    if (sg[i1] > sg[i0]) { tmp = i0; i0 = i1; i1 = tmp; }
+    (void)i2;
+    for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    if (!(sg[i0] > 0.0) || !(sg[i1] > 1e-14 * sg[i0])) return; /* rank < 2: identity */
+    double u0[3], u1[3], u2[3], v0[3], v1[3], v2[3];
+    for (int m = 0; m < 3; ++m) {
+        u0[m] = g[m][i0] / sg[i0]; u1[m] = g[m][i1] / sg[i1];
+        v0[m] = v[m][i0];          v1[m] = v[m][i1];
+    }
+    u2[0] = u0[1] * u1[2] - u0[2] * u1[1]; u2[1] = u0[2] * u1[0] - u0[0] * u1[2]; u2[2] = u0[0] * u1[1] - u0[1] * u1[0];
+    v2[0] = v0[1] * v1[2] - v0[2] * v1[1]; v2[1] = v0[2] * v1[0] - v0[0] * v1[2]; v2[2] = v0[0] * v1[1] - v0[1] * v1[0];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            R[r * 3 + c] = (v0[r] * u0[c] + v1[r] * u1[c]) + v2[r] * u2[c];
+}
+
+/* ---------------------------------------------------------- compaction S3 */
+typedef struct {
+    int n;
+    float *x, *y, *z;      /* SoA coordinates of the compacted list */
+    float *nx, *ny, *nz;   /* normals (targets only)                */
+    int32_t *orig;         /* original linear index                 */
+} clist;
+
+static void clist_free(clist *c)
+{
+    free(c->x); free(c->y); free(c->z); free(c->nx); free(c->ny); free(c->nz); free(c->orig);
+    memset(c, 0, sizeof(*c));
+}
+
+static void clist_build(clist *c, const float *xyz4, const float *nrm4, int N, float zmax)
+{
+    memset(c, 0, sizeof(*c));
+    c->x = malloc(sizeof(float) * (size_t)(N + 8)); c->y = malloc(sizeof(float) * (size_t)(N + 8));
+    c->z = malloc(sizeof(float) * (size_t)(N + 8)); c->orig = malloc(sizeof(int32_t) * (size_t)(N + 8));
+    if (nrm4) {
+        c->nx = malloc(sizeof(float) * (size_t)(N + 8)); c->ny = malloc(sizeof(float) * (size_t)(N + 8));
+        c->nz = malloc(sizeof(float) * (size_t)(N + 8));
+    }
+    int n = 0;
+    for (int i = 0; i < N; ++i) {
+        const float *q = xyz4 + 4 * (size_t)i;
+        if (!point_valid(q, zmax)) continue;
+        if (nrm4 && !(nrm4[4 * (size_t)i + 3] > 0.5f)) continue;
+        c->x[n] = q[0]; c->y[n] = q[1]; c->z[n] = q[2]; c->orig[n] = i;
+        if (nrm4) { c->nx[n] = nrm4[4 * (size_t)i]; c->ny[n] = nrm4[4 * (size_t)i + 1]; c->nz[n] = nrm4[4 * (size_t)i + 2]; }
+        ++n;
+    }
+    c->n = n;
+}
+
+/* ------------------------------------------------------------- kd-tree NN
+ * exact; same (d2, index) lexicographic minimum as the brute-force scan.
+ * Pruning uses fl(ds*ds) > best, which is a valid lower bound of the canonical
+ * d2 = fmaf(dz,dz,fmaf(dy,dy,dx*dx)) because every partial of that chain is
+ * monotone non-decreasing under round-to-nearest. */
+typedef struct { float split; int axis; int left, right; int lo, hi; } kdnode; /* leaf: axis=-1, [lo,hi) */
+typedef struct { kdnode *nodes; int n_nodes, cap; int *perm; const clist *pts; } kdtree;
+
+static int kd_cmp_axis; static const clist *kd_cmp_pts;
+static int kd_cmp(const void *a, const void *b)
+{
+    const int ia = *(const int *)a, ib = *(const int *)b;
+    const float *arr = kd_cmp_axis == 0 ? kd_cmp_pts->x : (kd_cmp_axis == 1 ? kd_cmp_pts->y : kd_cmp_pts->z);
+    if (arr[ia] < arr[ib]) return -1;
+    if (arr[ia] > arr[ib]) return 1;
+    return (ia > ib) - (ia < ib);
+}
+
+static int kd_build_rec(kdtree *t, int lo, int hi)
+{
+    if (t->n_nodes == t->cap) { t->cap *= 2; t->nodes = realloc(t->nodes, sizeof(kdnode) * (size_t)t->cap); }
+    const int id = t->n_nodes++;
+    if (hi - lo <= 12) {
+        kdnode nd = { 0.0f, -1, -1, -1, lo, hi };
+        t->nodes[id] = nd;
+        return id;
+    }
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int k = lo; k < hi; ++k) {
+        const int i = t->perm[k];
+        const float c[3] = { t->pts->x[i], t->pts->y[i], t->pts->z[i] };
+        for (int a = 0; a < 3; ++a) { if (c[a] < mn[a]) mn[a] = c[a]; if (c[a] > mx[a]) mx[a] = c[a]; }
+    }
+    int axis = 0;
+    if (mx[1] - mn[1] > mx[axis] - mn[axis]) axis = 1;
+    if (mx[2] - mn[2] > mx[axis] - mn[axis]) axis = 2;
+    kd_cmp_axis = axis; kd_cmp_pts = t->pts;
+    qsort(t->perm + lo, (size_t)(hi - lo), sizeof(int), kd_cmp);
+    const int mid = (lo + hi) / 2;
+    const float *arr = axis == 0 ? t->pts->x : (axis == 1 ? t->pts->y : t->pts->z);
+    const float split = arr[t->perm[mid]];
+    const int l = kd_build_rec(t, lo, mid);
+    const int r = kd_build_rec(t, mid, hi);
+    kdnode nd = { split, axis, l, r, lo, hi };
+    t->nodes[id] = nd;
+    return id;
+}
+
+static void kd_build(kdtree *t, const clist *pts)
+{
+    t->pts = pts; t->cap = 1024; t->n_nodes = 0;
+    t->nodes = malloc(sizeof(kdnode) * (size_t)t->cap);
+    t->perm = malloc(sizeof(int) * (size_t)(pts->n + 1));
+    for (int i = 0; i < pts->n; ++i) t->perm[i] = i;
+    if (pts->n > 0) kd_build_rec(t, 0, pts->n);
+}
+
+static void kd_free(kdtree *t) { free(t->nodes); free(t->perm); }
+
+static inline float canon_d2(float px, float py, float pz, float qx, float qy, float qz)
+{
+    const float dx = qx - px, dy = qy - py, dz = qz - pz;
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+static void kd_query(const kdtree *t, float px, float py, float pz, float gate2, float *best_d2, int *best_j)
+{
+    if (t->n_nodes == 0) return;
+    int stack[128]; float lbs[128]; int sp = 0;
+    stack[sp] = 0; lbs[sp] = 0.0f; ++sp;
+    const clist *c = t->pts;
+    while (sp > 0) {
+        --sp;
+        const int id = stack[sp];
+        const float lb = lbs[sp];
+        if (lb > *best_d2 || lb > gate2) continue;
+        const kdnode *nd = &t->nodes[id];
+        if (nd->axis < 0) {
+            for (int k = nd->lo; k < nd->hi; ++k) {
+                const int j = t->perm[k];
+                const float d2 = canon_d2(px, py, pz, c->x[j], c->y[j], c->z[j]);
+                if (d2 < *best_d2 || (d2 == *best_d2 && j < *best_j)) { *best_d2 = d2; *best_j = j; }
+            }
+            continue;
+        }
+        const float pa = nd->axis == 0 ? px : (nd->axis == 1 ? py : pz);
+        const float ds = nd->split - pa;
+        const float far_lb = ds * ds;
+        int nearc, farc;
+        if (pa <= nd->split) { nearc = nd->left; farc = nd->right; } else { nearc = nd->right; farc = nd->left; }
+        /* children of the left subtree have coordinate <= split, right >= split */
+        stack[sp] = farc; lbs[sp] = far_lb > lb ? far_lb : lb; ++sp;
+        stack[sp] = nearc; lbs[sp] = lb; ++sp;
+    }
+}
+
+/* ---------------------------------------------------------------- S4 NN */
+static void transform_f(const double *T, float Rf[9], float tf[3])
+{
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) Rf[r * 3 + c] = (float)T[r * 4 + c];
+        tf[r] = (float)T[r * 4 + 3];
+    }
+}
+
+static inline void xform_pt(const float Rf[9], const float tf[3], float x, float y, float z, float *o)
+{
+    o[0] = fmaf(Rf[2], z, fmaf(Rf[1], y, Rf[0] * x)) + tf[0];
+    o[1] = fmaf(Rf[5], z, fmaf(Rf[4], y, Rf[3] * x)) + tf[1];
+    o[2] = fmaf(Rf[8], z, fmaf(Rf[7], y, Rf[6] * x)) + tf[2];
+}
+
+/* corr[i] = compact target position or -1, d2c[i] = canonical d2 or +inf */
+static void nn_pass(const clist *src, const clist *tgt, const kdtree *kd, const double *T,
+                    float gate2, int method, int nt, int *corr, float *d2c)
+{
+    float Rf[9], tf[3];
+    transform_f(T, Rf, tf);
+    (void)nt;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(nt)
+    for (int i = 0; i < src->n; ++i) {
+        float p[3];
+        xform_pt(Rf, tf, src->x[i], src->y[i], src->z[i], p);
+        float best = INFINITY; int bj = -1;
+        if (method == ORC_NN_BRUTE) {
+            for (int j = 0; j < tgt->n; ++j) {
+                const float d2 = canon_d2(p[0], p[1], p[2], tgt->x[j], tgt->y[j], tgt->z[j]);
+                if (d2 < best) { best = d2; bj = j; }   /* ascending j: ties keep the smallest */
+            }
+        } else {
+            kd_query(kd, p[0], p[1], p[2], gate2, &best, &bj);
+        }
+        if (bj >= 0 && best <= gate2) { corr[i] = bj; d2c[i] = best; }
+        else { corr[i] = -1; d2c[i] = INFINITY; }
+    }
+}
+
+/* ------------------------------------------------ S4 rows + tree reduction */
+static void row_sums(const clist *src, const clist *tgt, const float Rf[9], const float tf[3],
+                     int estimator, int i, int j, double *s /*29*/)
+{
+    for (int k = 0; k < ORC_NSUMS; ++k) s[k] = 0.0;
+    if (j < 0) return;
+    float pf[3];
+    xform_pt(Rf, tf, src->x[i], src->y[i], src->z[i], pf);
+    const double px = pf[0], py = pf[1], pz = pf[2];
+    const double qx = tgt->x[j], qy = tgt->y[j], qz = tgt->z[j];
+    const double dx = qx - px, dy = qy - py, dz = qz - pz;
+    if (estimator == ORC_EST_POINT2PLANE) {
+        const double nx = tgt->nx[j], ny = tgt->ny[j], nz = tgt->nz[j];
+        double a[6];
+        a[0] = py * nz - pz * ny; a[1] = pz * nx - px * nz; a[2] = px * ny - py * nx;
+        a[3] = nx; a[4] = ny; a[5] = nz;
+        const double b = (nx * dx + ny * dy) + nz * dz;
+        int k = 0;
+        for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) s[k++] = a[r] * a[c];
+        for (int r = 0; r < 6; ++r) s[21 + r] = a[r] * b;
+        s[27] = 1.0; s[28] = b * b;
+    } else {
+        s[0] = px; s[1] = py; s[2] = pz; s[3] = qx; s[4] = qy; s[5] = qz;
+        s[6] = px * qx; s[7] = px * qy; s[8] = px * qz;
+        s[9] = py * qx; s[10] = py * qy; s[11] = py * qz;
+        s[12] = pz * qx; s[13] = pz * qy; s[14] = pz * qz;
+        s[27] = 1.0; s[28] = (dx * dx + dy * dy) + dz * dz;
+    }
+}
+
+static void tree256(double (*v)[ORC_NSUMS])   /* v[256][29] -> v[0] */
+{
+    for (int s = ORC_CHUNK / 2; s >= 1; s >>= 1)
+        for (int i = 0; i < s; ++i)
+            for (int k = 0; k < ORC_NSUMS; ++k) v[i][k] += v[i + s][k];
+}
+
+static void accumulate(const clist *src, const clist *tgt, const double *T, int estimator,
+                       const int *corr, int nt, double *total /*29*/)
+{
+    float Rf[9], tf[3];
+    transform_f(T, Rf, tf);
+    const int nchunks = (src->n + ORC_CHUNK - 1) / ORC_CHUNK;
+    const int ngroups = (nchunks + ORC_CHUNK - 1) / ORC_CHUNK;
+    double (*P1)[ORC_NSUMS] = calloc((size_t)(ngroups * ORC_CHUNK + 1), sizeof(*P1));
+    (void)nt;
+#pragma omp parallel num_threads(nt)
+    {
+        double (*v)[ORC_NSUMS] = malloc(sizeof(*v) * ORC_CHUNK);
+#pragma omp for schedule(static)
+        for (int c = 0; c < nchunks; ++c) {
+            for (int l = 0; l < ORC_CHUNK; ++l) {
+                const int i = c * ORC_CHUNK + l;
+                if (i < src->n) row_sums(src, tgt, Rf, tf, estimator, i, corr[i], v[l]);
+                else for (int k = 0; k < ORC_NSUMS; ++k) v[l][k] = 0.0;
+            }
+            tree256(v);
+            memcpy(P1[c], v[0], sizeof(double) * ORC_NSUMS);
+        }
+        free(v);
+    }
+    for (int k = 0; k < ORC_NSUMS; ++k) total[k] = 0.0;
+    for (int g = 0; g < ngroups; ++g) {
+        tree256(P1 + (size_t)g * ORC_CHUNK);
+        if (g == 0) memcpy(total, P1[0], sizeof(double) * ORC_NSUMS);
+        else for (int k = 0; k < ORC_NSUMS; ++k) total[k] += P1[(size_t)g * ORC_CHUNK][k];
+    }
+    free(P1);
+}
+
+/* ------------------------------------------------------------- S5 update */
+static void compose(const double dR[9], const double dt[3], double *T)
+{
+    double Tn[16];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c)
+            Tn[r * 4 + c] = (dR[r * 3 + 0] * T[0 * 4 + c] + dR[r * 3 + 1] * T[1 * 4 + c]) + dR[r * 3 + 2] * T[2 * 4 + c];
+        Tn[r * 4 + 3] = ((dR[r * 3 + 0] * T[3] + dR[r * 3 + 1] * T[7]) + dR[r * 3 + 2] * T[11]) + dt[r];
+    }
+    Tn[12] = 0.0; Tn[13] = 0.0; Tn[14] = 0.0; Tn[15] = 1.0;
+    memcpy(T, Tn, sizeof(Tn));
+}
+
+/* returns 1 ok, 2 ok-but-degenerate, 0 failed (T unchanged) */
+static int solve_update(const double *sums, int estimator, double *T)
+{
+    double dR[9], dt[3];
+    if (estimator == ORC_EST_POINT2PLANE) {
+        if (sums[27] < 6.0) return 0;
+        double x[6];
+        const int rc = orc_solve6(sums, sums + 21, x);
+        if (!rc) return 0;
+        double sa, ca, sb, cb, sg, cg;
+        orc_sincos(x[0], &sa, &ca); orc_sincos(x[1], &sb, &cb); orc_sincos(x[2], &sg, &cg);
+        dR[0] = cg * cb; dR[1] = (cg * sb) * sa - sg * ca; dR[2] = (cg * sb) * ca + sg * sa;
+        dR[3] = sg * cb; dR[4] = (sg * sb) * sa + cg * ca; dR[5] = (sg * sb) * ca - cg * sa;
+        dR[6] = -sb;     dR[7] = cb * sa;                  dR[8] = cb * ca;
+        dt[0] = x[3]; dt[1] = x[4]; dt[2] = x[5];
+        compose(dR, dt, T);
+        return rc;
+    }
+    const double n = sums[27];
+    if (n < 3.0) return 0;
+    const double pm[3] = { sums[0] / n, sums[1] / n, sums[2] / n };
+    const double qm[3] = { sums[3] / n, sums[4] / n, sums[5] / n };
+    double H[9];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) H[r * 3 + c] = sums[6 + r * 3 + c] - (n * pm[r]) * qm[c];
+    orc_svd3_rotation(H, dR);
+    for (int r = 0; r < 3; ++r)
+        dt[r] = qm[r] - ((dR[r * 3 + 0] * pm[0] + dR[r * 3 + 1] * pm[1]) + dR[r * 3 + 2] * pm[2]);
+    compose(dR, dt, T);
+    return 1;
+}
+
+/* ------------------------------------------------------------ S6 result */
+static void finish_result(const double *T, const double *last_sums, int degenerate,
+                          const orc_params *p, orc_result *res)
+{
+    memcpy(res->T, T, sizeof(double) * 16);
+    const double tr = T[0] + T[5] + T[10];
+    double ca = (tr - 1.0) / 2.0;
+    if (ca > 1.0) ca = 1.0;
+    if (ca < -1.0) ca = -1.0;
+    const double ang = acos(ca);
+    const double tn = sqrt(T[3] * T[3] + T[7] * T[7] + T[11] * T[11]);
+    /* src/GraphicEnd.cpp:618 */
+    res->norm = fabs(fmin(ang, 2.0 * M_PI - ang)) + 0.9 * fabs(tn);
+    res->inliers = last_sums ? (int)last_sums[27] : 0;
+    res->rmse = (last_sums && last_sums[27] > 0.0) ? sqrt(last_sums[28] / last_sums[27]) : 0.0;
+    res->status = ORC_OK;
+    if (res->inliers < p->min_inliers) res->status = ORC_TOO_FEW_INLIERS;      /* :599 */
+    else if (degenerate) res->status = ORC_DEGENERATE;
+    else if (res->norm > p->error_threshold) res->status = ORC_NORM_EXCEEDED;  /* :621 */
+    if (res->status != ORC_OK)
+        for (int k = 0; k < 16; ++k) res->T[k] = (k % 5 == 0) ? 1.0 : 0.0;     /* failure == Identity, :173 */
+}
+
+static float gate2_of(const orc_params *p) { return (float)(p->max_corr_dist * p->max_corr_dist); }
+
+int orc_icp(const float *src4, const float *tgt4, const orc_params *p, const double *T_init,
+            orc_result *res, int32_t *idx_out, float *d2_out, double *T_trace, double *sums_trace)
+{
+    const int N = p->width * p->height;
+    const float zmax = (float)p->z_filter;
+    const int nt = n_threads(p);
+    float *nrm4 = NULL;
+    if (p->estimator == ORC_EST_POINT2PLANE) {
+        nrm4 = malloc(sizeof(float) * 4 * (size_t)N);
+        orc_normals(tgt4, p, nrm4);
+    }
+    clist src, tgt;
+    clist_build(&src, src4, NULL, N, zmax);
+    clist_build(&tgt, tgt4, nrm4, N, zmax);
+    kdtree kd; memset(&kd, 0, sizeof(kd));
+    if (p->nn_method == ORC_NN_KDTREE) kd_build(&kd, &tgt);
+
+    double T[16];
+    if (T_init) memcpy(T, T_init, sizeof(T));
+    else for (int k = 0; k < 16; ++k) T[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    int *corr = malloc(sizeof(int) * (size_t)(src.n + 1));
+    float *d2c = malloc(sizeof(float) * (size_t)(src.n + 1));
+    double sums[ORC_NSUMS];
+    int degenerate = 0, have_sums = 0;
+    const float g2 = gate2_of(p);
+    if (T_trace) memcpy(T_trace, T, sizeof(T));
+    for (int it = 0; it < p->iterations; ++it) {
+        nn_pass(&src, &tgt, &kd, T, g2, p->nn_method, nt, corr, d2c);
+        accumulate(&src, &tgt, T, p->estimator, corr, nt, sums);
+        have_sums = 1;
+        if (sums_trace) memcpy(sums_trace + (size_t)it * ORC_NSUMS, sums, sizeof(sums));
+        const int rc = solve_update(sums, p->estimator, T);
+        if (rc == 2) degenerate = 1;
+        if (T_trace) memcpy(T_trace + (size_t)(it + 1) * 16, T, sizeof(T));
+    }
+    if (idx_out) {
+        for (int i = 0; i < N; ++i) idx_out[i] = -1;
+        if (p->iterations > 0)
+            for (int i = 0; i < src.n; ++i) idx_out[src.orig[i]] = corr[i] >= 0 ? tgt.orig[corr[i]] : -1;
+    }
+    if (d2_out) {
+        for (int i = 0; i < N; ++i) d2_out[i] = INFINITY;
+        if (p->iterations > 0)
+            for (int i = 0; i < src.n; ++i) d2_out[src.orig[i]] = d2c[i];
+    }
+    finish_result(T, have_sums ? sums : NULL, degenerate, p, res);
+    res->iterations = p->iterations;
+    res->n_src = src.n; res->n_tgt = tgt.n;
+    if (p->nn_method == ORC_NN_KDTREE) kd_free(&kd);
+    free(corr); free(d2c); free(nrm4);
+    clist_free(&src); clist_free(&tgt);
+    return res->status;
+}
+
+int orc_nn_once(const float *src4, const float *tgt4, const orc_params *p, const double *T,
+                int use_normals, int32_t *idx_out, float *d2_out)
+{
+    const int N = p->width * p->height;
+    const float zmax = (float)p->z_filter;
+    float *nrm4 = NULL;
+    if (use_normals) { nrm4 = malloc(sizeof(float) * 4 * (size_t)N); orc_normals(tgt4, p, nrm4); }
+    clist src, tgt;
+    clist_build(&src, src4, NULL, N, zmax);
+    clist_build(&tgt, tgt4, nrm4, N, zmax);
+    kdtree kd; memset(&kd, 0, sizeof(kd));
+    if (p->nn_method == ORC_NN_KDTREE) kd_build(&kd, &tgt);
+    int *corr = malloc(sizeof(int) * (size_t)(src.n + 1));
+    float *d2c = malloc(sizeof(float) * (size_t)(src.n + 1));
+    double Tid[16];
+    for (int k = 0; k < 16; ++k) Tid[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    nn_pass(&src, &tgt, &kd, T ? T : Tid, gate2_of(p), p->nn_method, n_threads(p), corr, d2c);
+    for (int i = 0; i < N; ++i) { if (idx_out) idx_out[i] = -1; if (d2_out) d2_out[i] = INFINITY; }
+    for (int i = 0; i < src.n; ++i) {
+        if (idx_out) idx_out[src.orig[i]] = corr[i] >= 0 ? tgt.orig[corr[i]] : -1;
+        if (d2_out) d2_out[src.orig[i]] = d2c[i];
+    }
+    const int ns = src.n;
+    if (p->nn_method == ORC_NN_KDTREE) kd_free(&kd);
+    free(corr); free(d2c); free(nrm4);
+    clist_free(&src); clist_free(&tgt);
+    return ns;
+}
+
+/* --------------------------------------------------- per-plane fit (row a6)
+ * PCL's LS refinement inside SACSegmentation::segment (setOptimizeCoefficients,
+ * src/GraphicEnd.cpp:363): mean + covariance of the inliers -> eigenvector of the
+ * smallest eigenvalue, d = -n.c; sign normalised so d >= 0 (src/GraphicEnd.cpp:383-387). */
+void orc_fit_planes(const float *xyz4, const int32_t *labels, int n, int nplanes,
+                    float *planes, int32_t *counts)
+{
+    for (int pl = 0; pl < nplanes; ++pl) {
+        /* sums relative to the first labelled point, in index order, 256-chunk tree like S4 */
+        int first = -1;
+        for (int i = 0; i < n; ++i) if (labels[i] == pl) { first = i; break; }
+        planes[4 * pl] = planes[4 * pl + 1] = planes[4 * pl + 2] = planes[4 * pl + 3] = 0.0f;
+        counts[pl] = 0;
+        if (first < 0) continue;
+        const double ox = xyz4[4 * (size_t)first], oy = xyz4[4 * (size_t)first + 1], oz = xyz4[4 * (size_t)first + 2];
+        double s[10] = { 0 };
+        for (int i = 0; i < n; ++i) {
+            if (labels[i] != pl) continue;
+            const double dx = (double)xyz4[4 * (size_t)i] - ox, dy = (double)xyz4[4 * (size_t)i + 1] - oy,
+                         dz = (double)xyz4[4 * (size_t)i + 2] - oz;
+            s[0] += 1.0; s[1] += dx; s[2] += dy; s[3] += dz;
+            s[4] += dx * dx; s[5] += dx * dy; s[6] += dx * dz; s[7] += dy * dy; s[8] += dy * dz; s[9] += dz * dz;
+        }
+        counts[pl] = (int32_t)s[0];
+        if (s[0] < 3.0) continue;
+        const double inv = 1.0 / s[0];
+        const double mx = s[1] * inv, my = s[2] * inv, mz = s[3] * inv;
+        double C[6] = { s[4] * inv - mx * mx, s[5] * inv - mx * my, s[6] * inv - mx * mz,
+                        s[7] * inv - my * my, s[8] * inv - my * mz, s[9] * inv - mz * mz };
+        double ev[3], V[9];
+        orc_eig3(C, ev, V);
+        int k = 0;
+        if (ev[1] < ev[k]) k = 1;
+        if (ev[2] < ev[k]) k = 2;
+        double nx = V[0 + k], ny = V[3 + k], nz = V[6 + k];
+        const double len = sqrt(nx * nx + ny * ny + nz * nz);
+        nx /= len; ny /= len; nz /= len;
+        double d = -(nx * (ox + mx) + ny * (oy + my) + nz * (oz + mz));
+        if (d < 0.0) { nx = -nx; ny = -ny; nz = -nz; d = -d; }
+        planes[4 * pl] = (float)nx; planes[4 * pl + 1] = (float)ny; planes[4 * pl + 2] = (float)nz; planes[4 * pl + 3] = (float)d;
+    }
+}
+
+/* ------------------------------------------------------- pose error (a14)
+ * src/exp1/exp1_2.cpp:167-171,285-289 ; tools/evaluate_rpe.py:138-173 */
+void orc_pose_error(const double *Tref, const double *T, double *rot_err, double *trans_err)
+{
+    /* Tref^-1 = [R^T, -R^T t] */
+    double E[16];
+    double Ri[9], ti[3];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Ri[r * 3 + c] = Tref[c * 4 + r];
+    for (int r = 0; r < 3; ++r) ti[r] = -(Ri[r * 3] * Tref[3] + Ri[r * 3 + 1] * Tref[7] + Ri[r * 3 + 2] * Tref[11]);
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c)
+            E[r * 4 + c] = Ri[r * 3] * T[c] + Ri[r * 3 + 1] * T[4 + c] + Ri[r * 3 + 2] * T[8 + c];
+        E[r * 4 + 3] = Ri[r * 3] * T[3] + Ri[r * 3 + 1] * T[7] + Ri[r * 3 + 2] * T[11] + ti[r];
+    }
+    *trans_err = sqrt(E[3] * E[3] + E[7] * E[7] + E[11] * E[11]);
+    double ca = (E[0] + E[5] + E[10] - 1.0) / 2.0;
+    if (ca > 1.0) ca = 1.0;
+    if (ca < -1.0) ca = -1.0;
+    *rot_err = acos(ca);
+}

@@ -1,0 +1,107 @@
+/*
+ * icp_oracle.h -- CPU ORACLE for the plane-ICP registration path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (slam3d_gx_amd/,
+ * include/) may include, link or call this.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg use it, and only as the checker / CPU baseline.
+ *
+ * PARITY UNPINNED: the reference (gaoxiang12/slam3d_gx) contains no ICP of its
+ * own and its PCL/OpenCV dependencies cannot be built
+ * here (F3), so no golden vector of the reference pins this oracle.  What IS
+ * pinned against reference artefacts:
+ *   - orc_backproject vs data/exp1/pcd/{1,2}.pcd (written by the reference's
+ *     src/convert2PCD.cpp:54-72) -- tests/test_oracle_reference_fixtures.py
+ * Everything else follows the normative restatement in DESIGN.md section 3
+ * (SURVEY.md App. C), which re-uses the reference's conventions:
+ *   - pinhole back-projection         src/convert2PCD.cpp:65-69,
+ *                                     src/GraphicEnd.cpp:452-455,
+ *                                     src/planarFeatures.cpp:108-111
+ *   - PassThrough z in (0, z_filter]  src/GraphicEnd.cpp:283-285
+ *   - 7x7 organized patch, ">40" planar inliers at 0.01 m
+ *                                     src/planarFeatures.cpp:92,118-128
+ *   - pose direction / norm / thresholds of multiPnP
+ *                                     src/GraphicEnd.cpp:557-659 (:599,:618,:621)
+ *   - pose-error metric               src/exp1/exp1_2.cpp:167-171,285-289
+ */
+#ifndef ICP_ORACLE_H
+#define ICP_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_NSUMS 29          /* 21 upper-tri AtA + 6 Atb + count + sum r^2   */
+#define ORC_CHUNK 256         /* reduction chunk of the deterministic tree    */
+
+enum { ORC_EST_POINT2PLANE = 0, ORC_EST_SVD = 1 };
+enum { ORC_NN_BRUTE = 0, ORC_NN_KDTREE = 1 };
+enum { ORC_OK = 0, ORC_TOO_FEW_INLIERS = 1, ORC_NORM_EXCEEDED = 2, ORC_DEGENERATE = 3 };
+
+typedef struct orc_params {
+    int    width, height;
+    double fx, fy, cx, cy, depth_factor;  /* back-projection intrinsics            */
+    double z_filter;                      /* validity: 0 < z <= z_filter           */
+    int    iterations;                    /* fixed count, no early exit            */
+    double max_corr_dist;                 /* gate on the NN distance (metres)      */
+    int    estimator;                     /* ORC_EST_*                             */
+    int    normal_window;                 /* odd, 7 in the reference's isPlanar    */
+    int    normal_min_inliers;            /* 41  (= "> 40")                        */
+    double normal_inlier_dist;            /* 0.01 m                                */
+    int    min_inliers;                   /* 12, multiPnP default                  */
+    double error_threshold;               /* 1.0, parameters.yaml:39               */
+    int    nn_method;                     /* ORC_NN_*  (identical results)         */
+    int    threads;                       /* OpenMP threads, <=0 -> all            */
+} orc_params;
+
+typedef struct orc_result {
+    double T[16];        /* row-major 4x4, X_target = T * X_source */
+    double norm;         /* |min(a, 2pi-a)| + 0.9*||t||            */
+    double rmse;         /* sqrt(sum r^2 / count) at last iteration */
+    int    inliers;      /* gated correspondences at last iteration */
+    int    status;       /* ORC_*                                   */
+    int    iterations;   /* iterations actually executed            */
+    int    n_src, n_tgt; /* compacted list sizes                    */
+} orc_result;
+
+void orc_default_params(orc_params *p);
+
+/* S1: u16 depth -> organized float4 cloud {x,y,z,1}; invalid pixels = NaN,NaN,NaN,0 */
+void orc_backproject(const uint16_t *depth, const orc_params *p, float *xyz4);
+
+/* S2: per-pixel normals of an organized cloud; out {nx,ny,nz,1} or {0,0,0,0} */
+void orc_normals(const float *xyz4, const orc_params *p, float *nrm4);
+
+/* S3..S6: full ICP.  src4/tgt4 organized float4 clouds (w ignored).
+ * idx_out[N] (original linear indices, -1 none) / d2_out[N] of the LAST iteration,
+ * T_trace[(iterations+1)*16], sums_trace[iterations*29] -- all nullable. */
+int orc_icp(const float *src4, const float *tgt4, const orc_params *p,
+            const double *T_init, orc_result *res,
+            int32_t *idx_out, float *d2_out,
+            double *T_trace, double *sums_trace);
+
+/* one NN pass only (for index-parity tests / CPU baseline timing):
+ * T (row-major 4x4 double) applied to src, search in tgt (point validity only when
+ * use_normals==0, else tgt normal validity too). */
+int orc_nn_once(const float *src4, const float *tgt4, const orc_params *p,
+                const double *T, int use_normals, int32_t *idx_out, float *d2_out);
+
+/* per-plane fit (row a6): labels[N] in {-1,0..nplanes-1}; out planes[nplanes*4]=(a,b,c,d), d>=0
+ * counts[nplanes] */
+void orc_fit_planes(const float *xyz4, const int32_t *labels, int n, int nplanes,
+                    float *planes, int32_t *counts);
+
+/* pose error metric a14: E = Tref^-1 * T ; trans = ||E_t||, rot = acos(clamp((tr-1)/2)) */
+void orc_pose_error(const double *Tref, const double *T, double *rot_err, double *trans_err);
+
+/* small solvers exposed for property tests */
+void orc_eig3(const double A[6] /*xx,xy,xz,yy,yz,zz*/, double evals[3], double evecs[9] /*cols*/);
+int  orc_solve6(const double AtA21[21], const double Atb[6], double x[6]);
+void orc_svd3_rotation(const double H[9], double R[9]);
+void orc_sincos(double x, double *s, double *c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

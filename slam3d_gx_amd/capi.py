@@ -1,0 +1,272 @@
+"""ctypes binding of the C-ABI in include/slam3d_icp.h (libslam3d_icp.so, HIP/gfx950).
+
+Plumbing only: the product is the shared library.  There is NO CPU fallback -- if the
+library is missing or no MI355X is visible, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import build as _build
+
+NSUMS = 29
+EST_POINT2PLANE, EST_SVD = 0, 1
+NN_AUTO, NN_BRUTE_VALU, NN_BRUTE_MFMA = 0, 1, 2
+
+EXPORTED_SYMBOLS = [
+    "slam3d_icp_default_params", "slam3d_icp_create", "slam3d_icp_destroy", "slam3d_strerror",
+    "slam3d_last_error", "slam3d_icp_abi_version", "slam3d_icp_align", "slam3d_icp_align_batch",
+    "slam3d_icp_align_depth_batch", "slam3d_icp_set_clouds_host", "slam3d_icp_set_depth_host",
+    "slam3d_icp_set_clouds_device", "slam3d_icp_set_depth_device", "slam3d_icp_run",
+    "slam3d_icp_fetch_results", "slam3d_icp_get_correspondences", "slam3d_icp_get_trace",
+    "slam3d_icp_get_clouds", "slam3d_icp_get_timings", "slam3d_backproject_u16", "slam3d_fit_planes",
+    "slam3d_icp_dense_set_rows", "slam3d_icp_dense_begin", "slam3d_icp_dense_partial",
+    "slam3d_icp_dense_update", "slam3d_icp_dense_finish",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+        ("depth_factor", C.c_double), ("z_filter", C.c_double),
+        ("iterations", C.c_int32), ("max_corr_dist", C.c_double), ("estimator", C.c_int32),
+        ("normal_window", C.c_int32), ("normal_min_inliers", C.c_int32), ("normal_inlier_dist", C.c_double),
+        ("min_inliers", C.c_int32), ("error_threshold", C.c_double),
+        ("max_batch", C.c_int32), ("device", C.c_int32), ("nn_mode", C.c_int32),
+    ]
+
+
+class CloudView(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("stride_bytes", C.c_int32), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("T", C.c_double * 16), ("norm", C.c_double), ("inliers", C.c_int32), ("status", C.c_int32),
+        ("iterations", C.c_int32), ("n_src", C.c_int32), ("n_tgt", C.c_int32), ("_pad", C.c_int32),
+        ("rmse", C.c_double), ("T_raw", C.c_double * 16),
+    ]
+
+    def as_dict(self):
+        return dict(T=np.array(self.T).reshape(4, 4), T_raw=np.array(self.T_raw).reshape(4, 4), norm=self.norm,
+                    inliers=self.inliers, status=self.status, iterations=self.iterations, n_src=self.n_src,
+                    n_tgt=self.n_tgt, rmse=self.rmse)
+
+
+class Plane(C.Structure):
+    _fields_ = [("coeff", C.c_float * 4), ("count", C.c_int32), ("centroid", C.c_float * 3)]
+
+
+class Slam3dError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"slam3d_icp error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen the in-tree HIP library; raises if it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    so = path or _build.LIB
+    if not os.path.exists(so):
+        raise FileNotFoundError(
+            f"{so} not found: build it with `python -m slam3d_gx_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the ICP path.")
+    lib = C.CDLL(so)
+    lib.slam3d_strerror.restype = C.c_char_p
+    lib.slam3d_last_error.restype = C.c_char_p
+    lib.slam3d_last_error.argtypes = [C.c_void_p]
+    lib.slam3d_icp_create.argtypes = [C.POINTER(Params), C.POINTER(C.c_void_p)]
+    lib.slam3d_icp_destroy.argtypes = [C.c_void_p]
+    lib.slam3d_icp_destroy.restype = None
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("slam3d_strerror", "slam3d_last_error", "slam3d_icp_destroy", "slam3d_icp_default_params"):
+            fn.restype = C.c_int
+    lib.slam3d_icp_default_params.restype = None
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def default_params(intr=None, **kw) -> Params:
+    p = Params()
+    load_library().slam3d_icp_default_params(C.byref(p))
+    if intr is not None:
+        p.width, p.height = intr.width, intr.height
+        p.fx, p.fy, p.cx, p.cy, p.depth_factor = intr.fx, intr.fy, intr.cx, intr.cy, intr.depth_factor
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _vp(a: Optional[np.ndarray]):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _cloud_view(a: np.ndarray, w: int, h: int) -> CloudView:
+    """a: (H, W, k) float32 array with k*4-byte records (k >= 3), C-contiguous."""
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and a.shape[0] == h and a.shape[1] == w
+    return CloudView(a.ctypes.data, a.shape[2] * 4, w, h)
+
+
+class IcpHandle:
+    """RAII wrapper of slam3d_icp_handle."""
+
+    def __init__(self, params: Params):
+        self.lib = load_library()
+        self.params = params
+        self._h = C.c_void_p()
+        rc = self.lib.slam3d_icp_create(C.byref(params), C.byref(self._h))
+        if rc != 0:
+            raise Slam3dError(rc, self.lib.slam3d_strerror(rc).decode())
+        self.N = params.width * params.height
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.slam3d_icp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc: int, allow_algorithmic: bool = True):
+        if rc < 0 or (rc > 0 and not allow_algorithmic):
+            detail = self.lib.slam3d_last_error(self._h).decode()
+            raise Slam3dError(rc, self.lib.slam3d_strerror(rc).decode() + (": " + detail if detail else ""))
+        return rc
+
+    # ---- one-call API ------------------------------------------------------------------
+    def align(self, src: np.ndarray, tgt: np.ndarray, T_init=None) -> dict:
+        return self.align_batch([src], [tgt], None if T_init is None else [T_init])[0]
+
+    def align_batch(self, src: Sequence[np.ndarray], tgt: Sequence[np.ndarray], T_init=None) -> list:
+        B = len(src)
+        W, H = self.params.width, self.params.height
+        sv = (CloudView * B)(*[_cloud_view(np.ascontiguousarray(a, dtype=np.float32), W, H) for a in src])
+        tv = (CloudView * B)(*[_cloud_view(np.ascontiguousarray(a, dtype=np.float32), W, H) for a in tgt])
+        self._keep = (src, tgt)
+        Ti = None if T_init is None else np.ascontiguousarray(np.stack(T_init), dtype=np.float64).reshape(B, 16)
+        out = (Result * B)()
+        self._check(self.lib.slam3d_icp_align_batch(self._h, C.c_int32(B), sv, tv, _vp(Ti), out))
+        return [r.as_dict() for r in out]
+
+    def align_depth_batch(self, src_depth: Sequence[np.ndarray], tgt_depth: Sequence[np.ndarray], T_init=None) -> list:
+        B = len(src_depth)
+        sd = [np.ascontiguousarray(d, dtype=np.uint16) for d in src_depth]
+        td = [np.ascontiguousarray(d, dtype=np.uint16) for d in tgt_depth]
+        sp = (C.c_void_p * B)(*[d.ctypes.data for d in sd])
+        tp = (C.c_void_p * B)(*[d.ctypes.data for d in td])
+        Ti = None if T_init is None else np.ascontiguousarray(np.stack(T_init), dtype=np.float64).reshape(B, 16)
+        out = (Result * B)()
+        self._check(self.lib.slam3d_icp_align_depth_batch(self._h, C.c_int32(B), sp, tp, _vp(Ti), out))
+        return [r.as_dict() for r in out]
+
+    # ---- staged API --------------------------------------------------------------------
+    def set_depth_host(self, slot: int, src_depth: np.ndarray, tgt_depth: np.ndarray):
+        sd = np.ascontiguousarray(src_depth, dtype=np.uint16)
+        td = np.ascontiguousarray(tgt_depth, dtype=np.uint16)
+        self._check(self.lib.slam3d_icp_set_depth_host(self._h, C.c_int32(slot), _vp(sd), _vp(td)), False)
+
+    def set_clouds_host(self, slot: int, src: np.ndarray, tgt: np.ndarray):
+        W, H = self.params.width, self.params.height
+        s = np.ascontiguousarray(src, dtype=np.float32); t = np.ascontiguousarray(tgt, dtype=np.float32)
+        sv, tv = _cloud_view(s, W, H), _cloud_view(t, W, H)
+        self._check(self.lib.slam3d_icp_set_clouds_host(self._h, C.c_int32(slot), C.byref(sv), C.byref(tv)), False)
+
+    def set_clouds_device(self, slot: int, d_src_ptr: int, d_tgt_ptr: int):
+        self._check(self.lib.slam3d_icp_set_clouds_device(self._h, C.c_int32(slot), C.c_void_p(d_src_ptr), C.c_void_p(d_tgt_ptr)), False)
+
+    def set_depth_device(self, slot: int, d_src_ptr: int, d_tgt_ptr: int):
+        self._check(self.lib.slam3d_icp_set_depth_device(self._h, C.c_int32(slot), C.c_void_p(d_src_ptr), C.c_void_p(d_tgt_ptr)), False)
+
+    def run(self, B: int, T_init=None, stream: int = 0):
+        Ti = None if T_init is None else np.ascontiguousarray(T_init, dtype=np.float64).reshape(B, 16)
+        self._check(self.lib.slam3d_icp_run(self._h, C.c_int32(B), _vp(Ti), C.c_void_p(stream)), False)
+
+    def fetch_results(self, B: int) -> list:
+        out = (Result * B)()
+        self._check(self.lib.slam3d_icp_fetch_results(self._h, C.c_int32(B), out), False)
+        return [r.as_dict() for r in out]
+
+    # ---- introspection -----------------------------------------------------------------
+    def get_correspondences(self, slot: int = 0):
+        idx = np.empty(self.N, dtype=np.int32); d2 = np.empty(self.N, dtype=np.float32)
+        self._check(self.lib.slam3d_icp_get_correspondences(self._h, C.c_int32(slot), _vp(idx), _vp(d2)), False)
+        return idx, d2
+
+    def get_trace(self, slot: int = 0):
+        it = self.params.iterations
+        Tt = np.zeros((it + 1, 16), dtype=np.float64); St = np.zeros((max(it, 1), NSUMS), dtype=np.float64)
+        self._check(self.lib.slam3d_icp_get_trace(self._h, C.c_int32(slot), _vp(Tt), _vp(St)), False)
+        return Tt.reshape(-1, 4, 4), St[:it]
+
+    def get_clouds(self, slot: int = 0, normals: bool = True):
+        H, W = self.params.height, self.params.width
+        s = np.empty((H, W, 4), dtype=np.float32); t = np.empty((H, W, 4), dtype=np.float32)
+        n = np.empty((H, W, 4), dtype=np.float32) if normals else None
+        self._check(self.lib.slam3d_icp_get_clouds(self._h, C.c_int32(slot), _vp(s), _vp(t), _vp(n)), False)
+        return s, t, n
+
+    def get_timings(self):
+        ms = (C.c_float * 4)()
+        self._check(self.lib.slam3d_icp_get_timings(self._h, ms), False)
+        return dict(preprocess_ms=ms[0], nn_ms=ms[1], accumulate_solve_ms=ms[2], total_ms=ms[3])
+
+    # ---- building blocks ---------------------------------------------------------------
+    def backproject_u16(self, depth: np.ndarray) -> np.ndarray:
+        d = np.ascontiguousarray(depth, dtype=np.uint16)
+        out = np.empty((self.params.height, self.params.width, 4), dtype=np.float32)
+        self._check(self.lib.slam3d_backproject_u16(self._h, _vp(d), _vp(out)), False)
+        return out
+
+    def fit_planes(self, cloud: np.ndarray, labels: np.ndarray, nplanes: int):
+        c = np.ascontiguousarray(cloud, dtype=np.float32)
+        cv = _cloud_view(c, self.params.width, self.params.height)
+        lab = np.ascontiguousarray(labels, dtype=np.int32).reshape(-1)
+        planes = (Plane * nplanes)()
+        self._check(self.lib.slam3d_fit_planes(self._h, C.byref(cv), _vp(lab), C.c_int32(nplanes), planes), False)
+        return [dict(coeff=np.array(p.coeff), count=p.count, centroid=np.array(p.centroid)) for p in planes]
+
+    # ---- dense mode --------------------------------------------------------------------
+    def dense_set_rows(self, r0: int, r1: int):
+        self._check(self.lib.slam3d_icp_dense_set_rows(self._h, C.c_int32(r0), C.c_int32(r1)), False)
+
+    def dense_begin(self, T_init=None, stream: int = 0):
+        Ti = None if T_init is None else np.ascontiguousarray(T_init, dtype=np.float64).reshape(16)
+        self._check(self.lib.slam3d_icp_dense_begin(self._h, _vp(Ti), C.c_void_p(stream)), False)
+
+    def dense_partial(self, stream: int = 0) -> np.ndarray:
+        s = np.zeros(NSUMS, dtype=np.float64)
+        self._check(self.lib.slam3d_icp_dense_partial(self._h, _vp(s), C.c_void_p(stream)), False)
+        return s
+
+    def dense_update(self, sums: np.ndarray, stream: int = 0):
+        s = np.ascontiguousarray(sums, dtype=np.float64).reshape(NSUMS)
+        self._check(self.lib.slam3d_icp_dense_update(self._h, _vp(s), C.c_void_p(stream)), False)
+
+    def dense_finish(self, last_sums: np.ndarray) -> dict:
+        s = np.ascontiguousarray(last_sums, dtype=np.float64).reshape(NSUMS)
+        out = Result()
+        self._check(self.lib.slam3d_icp_dense_finish(self._h, _vp(s), C.byref(out)), False)
+        return out.as_dict()

@@ -1,0 +1,670 @@
+// icp_capi.hip -- C-ABI (include/slam3d_icp.h) over the HIP kernels in icp_kernels.hpp.
+//
+// Replaces, behind the same pose semantics, GraphicEnd::multiPnP (src/GraphicEnd.cpp:557-659) and
+// the cloud half of GraphicEnd::readimage (src/GraphicEnd.cpp:266-302).  No CPU fallback exists:
+// every entry point that computes runs HIP kernels on a gfx950 device or returns an error.
+#include "../../include/slam3d_icp.h"
+#include "icp_kernels.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace s3d;
+
+struct slam3d_icp_handle {
+    slam3d_icp_params p;
+    Geometry g;
+    int N = 0, maxB = 0, max_chunks = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t run_stream = nullptr;
+    // device buffers
+    float4 *own_src = nullptr, *own_tgt = nullptr, *nrm = nullptr, *src_c = nullptr, *tgt_c = nullptr, *tgt_cn = nullptr;
+    int *counts = nullptr, *corr = nullptr, *flags = nullptr;
+    unsigned long long *best = nullptr;
+    float *cd2 = nullptr;
+    double *partials = nullptr, *sums = nullptr, *Tcur = nullptr, *trace_T = nullptr, *trace_S = nullptr, *d_Tinit = nullptr;
+    SlotPtrs *d_slots = nullptr;
+    unsigned char *d_raw = nullptr; size_t raw_bytes = 0;
+    uint16_t *d_depth = nullptr;
+    int *d_idx = nullptr; float *d_d2 = nullptr;
+    float4 *d_scratch4 = nullptr;
+    // host
+    std::vector<SlotPtrs> h_slots;
+    SlotPtrs *pin_slots = nullptr;
+    double *pin_T = nullptr;      // maxB*16
+    double *pin_out = nullptr;    // maxB*(16+29)
+    int *pin_int = nullptr;       // maxB*5
+    std::vector<hipEvent_t> ev;   // 0 start, 1 after preprocess, 2 end, then (nn0,nn1) per iteration
+    bool ran = false; int last_B = 0;
+    int row0 = 0, row1 = 0; int dense_it = 0;
+    std::string err;
+};
+
+#define HIPCHK(h, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            char buf__[512];                                                                    \
+            snprintf(buf__, sizeof buf__, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            if (h) (h)->err = buf__;                                                            \
+            return SLAM3D_E_HIP;                                                                \
+        }                                                                                       \
+    } while (0)
+
+static inline void identity16(double *T) { for (int k = 0; k < 16; ++k) T[k] = (k % 5 == 0) ? 1.0 : 0.0; }
+
+extern "C" int slam3d_icp_abi_version(void) { return SLAM3D_ICP_ABI_VERSION; }
+
+extern "C" void slam3d_icp_default_params(slam3d_icp_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->width = 640; p->height = 480;
+    p->fx = 525.0; p->fy = 525.0; p->cx = 319.5; p->cy = 235.5; p->depth_factor = 1000.0; // src/convert2PCD.cpp:19-23
+    p->z_filter = 7.0;
+    p->iterations = 20;
+    p->max_corr_dist = 0.10;
+    p->estimator = SLAM3D_EST_POINT2PLANE;
+    p->normal_window = 7; p->normal_min_inliers = 41; p->normal_inlier_dist = 0.01;
+    p->min_inliers = 12; p->error_threshold = 1.0;
+    p->max_batch = 1; p->device = 0; p->nn_mode = SLAM3D_NN_AUTO;
+}
+
+extern "C" const char *slam3d_strerror(int code)
+{
+    switch (code) {
+    case SLAM3D_OK: return "ok";
+    case SLAM3D_TOO_FEW_INLIERS: return "too few inliers (T = Identity)";
+    case SLAM3D_NORM_EXCEEDED: return "norm of transform above error_threshold (T = Identity)";
+    case SLAM3D_DEGENERATE: return "degenerate geometry: normal equations needed damping (T = Identity)";
+    case SLAM3D_E_INVALID: return "invalid argument";
+    case SLAM3D_E_HIP: return "HIP runtime error";
+    case SLAM3D_E_NOMEM: return "out of memory";
+    case SLAM3D_E_NODEVICE: return "no gfx950 (MI355X) device visible; this library has no CPU fallback";
+    case SLAM3D_E_STATE: return "call order violated";
+    default: return "unknown status";
+    }
+}
+
+extern "C" const char *slam3d_last_error(const slam3d_icp_handle *h) { return h ? h->err.c_str() : ""; }
+
+static void free_all(slam3d_icp_handle *h)
+{
+    auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    F(h->own_src); F(h->own_tgt); F(h->nrm); F(h->src_c); F(h->tgt_c); F(h->tgt_cn); F(h->counts); F(h->corr);
+    F(h->flags); F(h->best); F(h->cd2); F(h->partials); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
+    F(h->d_Tinit); F(h->d_slots); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4);
+    if (h->pin_slots) (void)hipHostFree(h->pin_slots);
+    if (h->pin_T) (void)hipHostFree(h->pin_T);
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
+    if (h->pin_int) (void)hipHostFree(h->pin_int);
+    for (auto e : h->ev) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+}
+
+extern "C" void slam3d_icp_destroy(slam3d_icp_handle *h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->p.device);
+    (void)hipDeviceSynchronize();
+    free_all(h);
+    delete h;
+}
+
+template <class T> static hipError_t dalloc(T *&p, size_t n) { return hipMalloc((void **)&p, n * sizeof(T)); }
+
+extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle **out)
+{
+    if (!p || !out) return SLAM3D_E_INVALID;
+    *out = nullptr;
+    if (p->width <= 0 || p->height <= 0 || p->max_batch <= 0 || p->iterations < 0) return SLAM3D_E_INVALID;
+    if (p->normal_window < 1 || (p->normal_window & 1) == 0 || p->normal_window / 2 > NRM_RMAX) return SLAM3D_E_INVALID;
+    if (p->estimator != SLAM3D_EST_POINT2PLANE && p->estimator != SLAM3D_EST_SVD) return SLAM3D_E_INVALID;
+    if (!(p->max_corr_dist > 0.0) || !(p->z_filter > 0.0)) return SLAM3D_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device < 0 || p->device >= ndev) return SLAM3D_E_NODEVICE;
+    auto *h = new slam3d_icp_handle();
+    h->p = *p;
+    if (hipSetDevice(p->device) != hipSuccess) { delete h; return SLAM3D_E_NODEVICE; }
+    h->N = p->width * p->height;
+    h->maxB = p->max_batch;
+    h->max_chunks = (h->N + CHUNK - 1) / CHUNK;
+    Geometry &g = h->g;
+    g.W = p->width; g.H = p->height; g.N = h->N;
+    g.zmax = (float)p->z_filter;
+    g.win_r = p->normal_window / 2; g.min_in = p->normal_min_inliers; g.in_dist = p->normal_inlier_dist;
+    g.gate2 = (float)(p->max_corr_dist * p->max_corr_dist);
+    g.estimator = p->estimator;
+    g.fx = p->fx; g.fy = p->fy; g.cx = p->cx; g.cy = p->cy; g.factor = p->depth_factor; g.zf = p->z_filter;
+    h->row0 = 0; h->row1 = p->height;
+    const size_t BN = (size_t)h->maxB * h->N;
+    const int iters = p->iterations > 0 ? p->iterations : 1;
+    hipError_t e = hipSuccess;
+    auto A = [&](hipError_t r) { if (e == hipSuccess && r != hipSuccess) e = r; };
+    A(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    A(dalloc(h->own_src, BN)); A(dalloc(h->own_tgt, BN)); A(dalloc(h->nrm, BN));
+    A(dalloc(h->src_c, BN)); A(dalloc(h->tgt_c, BN)); A(dalloc(h->tgt_cn, BN));
+    A(dalloc(h->counts, (size_t)h->maxB * 4)); A(dalloc(h->corr, BN)); A(dalloc(h->flags, (size_t)h->maxB));
+    A(dalloc(h->best, BN)); A(dalloc(h->cd2, BN));
+    A(dalloc(h->partials, (size_t)h->maxB * h->max_chunks * NSUMS));
+    A(dalloc(h->sums, (size_t)h->maxB * NSUMS)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
+    A(dalloc(h->trace_T, (size_t)h->maxB * (iters + 1) * 16)); A(dalloc(h->trace_S, (size_t)h->maxB * iters * NSUMS));
+    A(dalloc(h->d_Tinit, (size_t)h->maxB * 16)); A(dalloc(h->d_slots, (size_t)h->maxB));
+    A(dalloc(h->d_depth, (size_t)2 * h->N)); A(dalloc(h->d_idx, (size_t)h->N)); A(dalloc(h->d_d2, (size_t)h->N));
+    A(dalloc(h->d_scratch4, (size_t)h->N));
+    A(hipHostMalloc((void **)&h->pin_slots, sizeof(SlotPtrs) * h->maxB, hipHostMallocDefault));
+    A(hipHostMalloc((void **)&h->pin_T, sizeof(double) * 16 * h->maxB, hipHostMallocDefault));
+    A(hipHostMalloc((void **)&h->pin_out, sizeof(double) * (16 + NSUMS) * h->maxB, hipHostMallocDefault));
+    A(hipHostMalloc((void **)&h->pin_int, sizeof(int) * 5 * h->maxB, hipHostMallocDefault));
+    h->ev.resize(3 + 2 * (size_t)iters);
+    for (auto &evx : h->ev) A(hipEventCreate(&evx));
+    if (e != hipSuccess) {
+        free_all(h);
+        const bool oom = (e == hipErrorOutOfMemory);
+        delete h;
+        return oom ? SLAM3D_E_NOMEM : SLAM3D_E_HIP;
+    }
+    h->h_slots.assign(h->maxB, SlotPtrs{ nullptr, nullptr });
+    (void)hipMemsetAsync(h->counts, 0, sizeof(int) * 4 * h->maxB, h->stream);
+    *out = h;
+    return SLAM3D_OK;
+}
+
+// ------------------------------------------------------------------------------ inputs
+static int upload_cloud(slam3d_icp_handle *h, const slam3d_cloud_view *v, float4 *dst)
+{
+    if (!v || !v->data || v->width != h->p.width || v->height != h->p.height || v->stride_bytes < 12) return SLAM3D_E_INVALID;
+    const size_t N = h->N;
+    if (v->stride_bytes == 16) {
+        HIPCHK(h, hipMemcpyAsync(dst, v->data, N * 16, hipMemcpyHostToDevice, h->stream));
+        return SLAM3D_OK;
+    }
+    const size_t need = N * (size_t)v->stride_bytes;
+    if (need > h->raw_bytes) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->d_raw) { HIPCHK(h, hipFree(h->d_raw)); h->d_raw = nullptr; }
+        HIPCHK(h, hipMalloc((void **)&h->d_raw, need));
+        h->raw_bytes = need;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_raw, v->data, need, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_repack, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, h->d_raw, v->stride_bytes, dst, (int)N);
+    HIPCHK(h, hipGetLastError());
+    // d_raw is reused by the next upload: keep stream order, the copy above is stream-ordered too
+    return SLAM3D_OK;
+}
+
+static inline bool slot_ok(const slam3d_icp_handle *h, int slot) { return h && slot >= 0 && slot < h->maxB; }
+
+extern "C" int slam3d_icp_set_clouds_host(slam3d_icp_handle *h, int32_t slot, const slam3d_cloud_view *src,
+                                          const slam3d_cloud_view *tgt)
+{
+    if (!slot_ok(h, slot)) return SLAM3D_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    float4 *ds = h->own_src + (size_t)slot * h->N, *dt = h->own_tgt + (size_t)slot * h->N;
+    int rc = upload_cloud(h, src, ds);
+    if (rc) return rc;
+    rc = upload_cloud(h, tgt, dt);
+    if (rc) return rc;
+    h->h_slots[slot] = SlotPtrs{ ds, dt };
+    return SLAM3D_OK;
+}
+
+static int backproject_dev(slam3d_icp_handle *h, const uint16_t *d_depth, float4 *dst)
+{
+    hipLaunchKernelGGL(k_backproject, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, d_depth, dst, h->g);
+    HIPCHK(h, hipGetLastError());
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_set_depth_host(slam3d_icp_handle *h, int32_t slot, const uint16_t *src_depth,
+                                         const uint16_t *tgt_depth)
+{
+    if (!slot_ok(h, slot) || !src_depth || !tgt_depth) return SLAM3D_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    float4 *ds = h->own_src + (size_t)slot * h->N, *dt = h->own_tgt + (size_t)slot * h->N;
+    HIPCHK(h, hipMemcpyAsync(h->d_depth, src_depth, sizeof(uint16_t) * h->N, hipMemcpyHostToDevice, h->stream));
+    int rc = backproject_dev(h, h->d_depth, ds);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_depth + h->N, tgt_depth, sizeof(uint16_t) * h->N, hipMemcpyHostToDevice, h->stream));
+    rc = backproject_dev(h, h->d_depth + h->N, dt);
+    if (rc) return rc;
+    h->h_slots[slot] = SlotPtrs{ ds, dt };
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_set_clouds_device(slam3d_icp_handle *h, int32_t slot, const void *d_src_xyz4, const void *d_tgt_xyz4)
+{
+    if (!slot_ok(h, slot) || !d_src_xyz4 || !d_tgt_xyz4) return SLAM3D_E_INVALID;
+    h->h_slots[slot] = SlotPtrs{ (const float4 *)d_src_xyz4, (const float4 *)d_tgt_xyz4 };
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_set_depth_device(slam3d_icp_handle *h, int32_t slot, const void *d_src_depth, const void *d_tgt_depth)
+{
+    if (!slot_ok(h, slot) || !d_src_depth || !d_tgt_depth) return SLAM3D_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    float4 *ds = h->own_src + (size_t)slot * h->N, *dt = h->own_tgt + (size_t)slot * h->N;
+    int rc = backproject_dev(h, (const uint16_t *)d_src_depth, ds);
+    if (rc) return rc;
+    rc = backproject_dev(h, (const uint16_t *)d_tgt_depth, dt);
+    if (rc) return rc;
+    h->h_slots[slot] = SlotPtrs{ ds, dt };
+    return SLAM3D_OK;
+}
+
+// ------------------------------------------------------------------------------ run
+static int pick_nsplit(const slam3d_icp_handle *h, int B)
+{
+    // enough workgroups for 256 CUs: aim at >= ~2048 blocks (query blocks are sized for ~75 % valid)
+    const int qblocks = ((h->N * 3) / 4 + NN_BLOCK * NN_QPT - 1) / (NN_BLOCK * NN_QPT);
+    int ns = (2048 + qblocks * B - 1) / (qblocks * B);
+    if (ns < 1) ns = 1;
+    if (ns > 16) ns = 16;
+    return ns;
+}
+
+static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init, hipStream_t s)
+{
+    const Geometry &g = h->g;
+    for (int b = 0; b < B; ++b) {
+        if (!h->h_slots[b].src || !h->h_slots[b].tgt) return SLAM3D_E_STATE;
+        h->pin_slots[b] = h->h_slots[b];
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_slots, h->pin_slots, sizeof(SlotPtrs) * B, hipMemcpyHostToDevice, s));
+    const double *dT = nullptr;
+    if (T_init) {
+        memcpy(h->pin_T, T_init, sizeof(double) * 16 * B);
+        HIPCHK(h, hipMemcpyAsync(h->d_Tinit, h->pin_T, sizeof(double) * 16 * B, hipMemcpyHostToDevice, s));
+        dT = h->d_Tinit;
+    }
+    HIPCHK(h, hipMemsetAsync(h->best, 0xFF, sizeof(unsigned long long) * (size_t)B * h->N, s));
+    const int use_normals = h->p.estimator == SLAM3D_EST_POINT2PLANE ? 1 : 0;
+    if (use_normals) {
+        dim3 grid((g.W + NRM_BX - 1) / NRM_BX, (g.H + NRM_BY - 1) / NRM_BY, B);
+        hipLaunchKernelGGL(k_normals, grid, dim3(NRM_BX, NRM_BY), 0, s, h->d_slots, h->nrm, g);
+    }
+    hipLaunchKernelGGL(k_compact, dim3(2, B), dim3(1024), 0, s, h->d_slots, h->nrm, h->src_c, h->tgt_c, h->tgt_cn,
+                       h->counts, g, use_normals, h->row0, h->row1);
+    const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
+    hipLaunchKernelGGL(k_init_T, dim3((B + 63) / 64), dim3(64), 0, s, dT, h->Tcur, h->trace_T, h->flags, B, iters);
+    HIPCHK(h, hipGetLastError());
+    return SLAM3D_OK;
+}
+
+static int enqueue_nn_accumulate(slam3d_icp_handle *h, int B, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
+{
+    const int nsplit = pick_nsplit(h, B);
+    const int qblocks = (h->N + NN_BLOCK * NN_QPT - 1) / (NN_BLOCK * NN_QPT);
+    if (e0) HIPCHK(h, hipEventRecord(e0, s));
+    hipLaunchKernelGGL(k_nn_valu, dim3(qblocks, nsplit, B), dim3(NN_BLOCK), 0, s, h->src_c, h->tgt_c, h->counts, h->Tcur,
+                       h->best, h->N, nsplit);
+    if (e1) HIPCHK(h, hipEventRecord(e1, s));
+    hipLaunchKernelGGL(k_accumulate, dim3(h->max_chunks, B), dim3(CHUNK), 0, s, h->src_c, h->tgt_c, h->tgt_cn, h->counts,
+                       h->Tcur, h->best, h->corr, h->cd2, h->partials, h->N, h->max_chunks, h->g.gate2, h->p.estimator);
+    hipLaunchKernelGGL(k_reduce, dim3(B), dim3(CHUNK), 0, s, h->partials, h->counts, h->sums, h->max_chunks);
+    HIPCHK(h, hipGetLastError());
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_init, void *stream)
+{
+    if (!h || B <= 0 || B > h->maxB) return SLAM3D_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    if (s != h->stream) {   // inputs were staged on the handle's stream
+        HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+        HIPCHK(h, hipStreamWaitEvent(s, h->ev[0], 0));
+    }
+    HIPCHK(h, hipEventRecord(h->ev[0], s));
+    int rc = enqueue_preprocess(h, B, T_init, s);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[1], s));
+    const int iters = h->p.iterations;
+    for (int it = 0; it < iters; ++it) {
+        rc = enqueue_nn_accumulate(h, B, s, h->ev[3 + 2 * it], h->ev[4 + 2 * it]);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_solve, dim3((B + 63) / 64), dim3(64), 0, s, h->sums, h->Tcur, h->trace_T, h->trace_S, h->flags,
+                           B, it, iters > 0 ? iters : 1, h->p.estimator);
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->ev[2], s));
+    h->run_stream = s;
+    h->ran = true;
+    h->last_B = B;
+    return SLAM3D_OK;
+}
+
+// S6 on the host: norm, thresholds, failure == Identity (src/GraphicEnd.cpp:599,618,621,173)
+static void finish_result(const slam3d_icp_params &p, const double *T, const double *last_sums, int degenerate,
+                          int n_src, int n_tgt, slam3d_icp_result *r)
+{
+    memcpy(r->T, T, sizeof(double) * 16);
+    memcpy(r->T_raw, T, sizeof(double) * 16);
+    const double tr = T[0] + T[5] + T[10];
+    double ca = (tr - 1.0) / 2.0;
+    if (ca > 1.0) ca = 1.0;
+    if (ca < -1.0) ca = -1.0;
+    const double ang = acos(ca);
+    const double tn = sqrt(T[3] * T[3] + T[7] * T[7] + T[11] * T[11]);
+    r->norm = fabs(fmin(ang, 2.0 * M_PI - ang)) + 0.9 * fabs(tn);
+    r->inliers = last_sums ? (int)last_sums[27] : 0;
+    r->rmse = (last_sums && last_sums[27] > 0.0) ? sqrt(last_sums[28] / last_sums[27]) : 0.0;
+    r->iterations = p.iterations;
+    r->n_src = n_src; r->n_tgt = n_tgt; r->_pad = 0;
+    r->status = SLAM3D_OK;
+    if (r->inliers < p.min_inliers) r->status = SLAM3D_TOO_FEW_INLIERS;
+    else if (degenerate) r->status = SLAM3D_DEGENERATE;
+    else if (r->norm > p.error_threshold) r->status = SLAM3D_NORM_EXCEEDED;
+    if (r->status != SLAM3D_OK) identity16(r->T);
+}
+
+extern "C" int slam3d_icp_fetch_results(slam3d_icp_handle *h, int32_t B, slam3d_icp_result *out)
+{
+    if (!h || !out || B <= 0 || B > h->maxB) return SLAM3D_E_INVALID;
+    if (!h->ran || B > h->last_B) return SLAM3D_E_STATE;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    hipStream_t s = h->run_stream;
+    const int iters = h->p.iterations;
+    HIPCHK(h, hipMemcpyAsync(h->pin_out, h->Tcur, sizeof(double) * 16 * B, hipMemcpyDeviceToHost, s));
+    double *ps = h->pin_out + 16 * (size_t)h->maxB;
+    if (iters > 0)
+        for (int b = 0; b < B; ++b)
+            HIPCHK(h, hipMemcpyAsync(ps + (size_t)b * NSUMS, h->trace_S + ((size_t)b * iters + (iters - 1)) * NSUMS,
+                                     sizeof(double) * NSUMS, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->pin_int, h->counts, sizeof(int) * 4 * B, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->pin_int + 4 * (size_t)h->maxB, h->flags, sizeof(int) * B, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    for (int b = 0; b < B; ++b)
+        finish_result(h->p, h->pin_out + 16 * (size_t)b, iters > 0 ? ps + (size_t)b * NSUMS : nullptr,
+                      h->pin_int[4 * (size_t)h->maxB + b], h->pin_int[4 * b], h->pin_int[4 * b + 1], out + b);
+    return SLAM3D_OK;
+}
+
+// ------------------------------------------------------------------------------ one-call API
+static int first_bad_status(const slam3d_icp_result *out, int B)
+{
+    for (int b = 0; b < B; ++b) if (out[b].status != SLAM3D_OK) return out[b].status;
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_align_batch(slam3d_icp_handle *h, int32_t B, const slam3d_cloud_view *src,
+                                      const slam3d_cloud_view *tgt, const double *T_init, slam3d_icp_result *out)
+{
+    if (!h || !src || !tgt || !out || B <= 0 || B > h->maxB) return SLAM3D_E_INVALID;
+    for (int b = 0; b < B; ++b) {
+        const int rc = slam3d_icp_set_clouds_host(h, b, src + b, tgt + b);
+        if (rc) return rc;
+    }
+    int rc = slam3d_icp_run(h, B, T_init, nullptr);
+    if (rc) return rc;
+    rc = slam3d_icp_fetch_results(h, B, out);
+    if (rc) return rc;
+    return B == 1 ? out[0].status : (first_bad_status(out, B) ? first_bad_status(out, B) : SLAM3D_OK);
+}
+
+extern "C" int slam3d_icp_align(slam3d_icp_handle *h, const slam3d_cloud_view *src, const slam3d_cloud_view *tgt,
+                                const double *T_init, slam3d_icp_result *out)
+{
+    return slam3d_icp_align_batch(h, 1, src, tgt, T_init, out);
+}
+
+extern "C" int slam3d_icp_align_depth_batch(slam3d_icp_handle *h, int32_t B, const uint16_t *const *src_depth,
+                                            const uint16_t *const *tgt_depth, const double *T_init,
+                                            slam3d_icp_result *out)
+{
+    if (!h || !src_depth || !tgt_depth || !out || B <= 0 || B > h->maxB) return SLAM3D_E_INVALID;
+    for (int b = 0; b < B; ++b) {
+        const int rc = slam3d_icp_set_depth_host(h, b, src_depth[b], tgt_depth[b]);
+        if (rc) return rc;
+    }
+    int rc = slam3d_icp_run(h, B, T_init, nullptr);
+    if (rc) return rc;
+    rc = slam3d_icp_fetch_results(h, B, out);
+    if (rc) return rc;
+    return first_bad_status(out, B);
+}
+
+// ------------------------------------------------------------------------------ introspection
+extern "C" int slam3d_icp_get_correspondences(slam3d_icp_handle *h, int32_t slot, int32_t *idx, float *d2)
+{
+    if (!slot_ok(h, slot)) return SLAM3D_E_INVALID;
+    if (!h->ran || slot >= h->last_B) return SLAM3D_E_STATE;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    hipStream_t s = h->run_stream;
+    const int N = h->N;
+    hipLaunchKernelGGL(k_fill_corr, dim3((N + 255) / 256), dim3(256), 0, s, h->d_idx, h->d_d2, N);
+    if (h->p.iterations > 0)
+        hipLaunchKernelGGL(k_scatter_corr, dim3((N + 255) / 256), dim3(256), 0, s, h->src_c, h->tgt_c, h->corr, h->cd2,
+                           h->counts, slot, N, h->d_idx, h->d_d2);
+    HIPCHK(h, hipGetLastError());
+    if (idx) HIPCHK(h, hipMemcpyAsync(idx, h->d_idx, sizeof(int) * N, hipMemcpyDeviceToHost, s));
+    if (d2) HIPCHK(h, hipMemcpyAsync(d2, h->d_d2, sizeof(float) * N, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_get_trace(slam3d_icp_handle *h, int32_t slot, double *T_trace, double *sums_trace)
+{
+    if (!slot_ok(h, slot)) return SLAM3D_E_INVALID;
+    if (!h->ran || slot >= h->last_B) return SLAM3D_E_STATE;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    hipStream_t s = h->run_stream;
+    const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
+    if (T_trace)
+        HIPCHK(h, hipMemcpyAsync(T_trace, h->trace_T + (size_t)slot * (iters + 1) * 16,
+                                 sizeof(double) * 16 * (h->p.iterations + 1), hipMemcpyDeviceToHost, s));
+    if (sums_trace && h->p.iterations > 0)
+        HIPCHK(h, hipMemcpyAsync(sums_trace, h->trace_S + (size_t)slot * iters * NSUMS,
+                                 sizeof(double) * NSUMS * h->p.iterations, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_get_clouds(slam3d_icp_handle *h, int32_t slot, float *src_xyz4, float *tgt_xyz4, float *tgt_nrm4)
+{
+    if (!slot_ok(h, slot) || !h->h_slots[slot].src) return SLAM3D_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    hipStream_t s = h->ran ? h->run_stream : h->stream;
+    const size_t bytes = sizeof(float) * 4 * (size_t)h->N;
+    if (s != h->stream) HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (src_xyz4) HIPCHK(h, hipMemcpyAsync(src_xyz4, h->h_slots[slot].src, bytes, hipMemcpyDeviceToHost, s));
+    if (tgt_xyz4) HIPCHK(h, hipMemcpyAsync(tgt_xyz4, h->h_slots[slot].tgt, bytes, hipMemcpyDeviceToHost, s));
+    if (tgt_nrm4) {
+        if (!h->ran || h->p.estimator != SLAM3D_EST_POINT2PLANE) return SLAM3D_E_STATE;
+        HIPCHK(h, hipMemcpyAsync(tgt_nrm4, h->nrm + (size_t)slot * h->N, bytes, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(h, hipStreamSynchronize(s));
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_get_timings(slam3d_icp_handle *h, float ms[4])
+{
+    if (!h || !ms) return SLAM3D_E_INVALID;
+    if (!h->ran) return SLAM3D_E_STATE;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    HIPCHK(h, hipEventSynchronize(h->ev[2]));
+    float pre = 0, tot = 0, nn = 0;
+    HIPCHK(h, hipEventElapsedTime(&pre, h->ev[0], h->ev[1]));
+    HIPCHK(h, hipEventElapsedTime(&tot, h->ev[0], h->ev[2]));
+    for (int it = 0; it < h->p.iterations; ++it) {
+        float t = 0;
+        HIPCHK(h, hipEventElapsedTime(&t, h->ev[3 + 2 * it], h->ev[4 + 2 * it]));
+        nn += t;
+    }
+    ms[0] = pre; ms[1] = nn; ms[2] = tot - pre - nn; ms[3] = tot;
+    return SLAM3D_OK;
+}
+
+// ------------------------------------------------------------------------------ building blocks
+extern "C" int slam3d_backproject_u16(slam3d_icp_handle *h, const uint16_t *depth, float *xyz4)
+{
+    if (!h || !depth || !xyz4) return SLAM3D_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    HIPCHK(h, hipMemcpyAsync(h->d_depth, depth, sizeof(uint16_t) * h->N, hipMemcpyHostToDevice, h->stream));
+    const int rc = backproject_dev(h, h->d_depth, h->d_scratch4);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(xyz4, h->d_scratch4, sizeof(float) * 4 * (size_t)h->N, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return SLAM3D_OK;
+}
+
+// host twin of the device Jacobi (same operation order) for the handful of per-plane solves
+static void host_eig3_smallest(double a00, double a01, double a02, double a11, double a12, double a22,
+                               double &nx, double &ny, double &nz)
+{
+    double a[3][3] = { { a00, a01, a02 }, { a01, a11, a12 }, { a02, a12, a22 } };
+    double v[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
+    const int PP[3] = { 0, 0, 1 }, QQ[3] = { 1, 2, 2 }, RR[3] = { 2, 1, 0 };
+    for (int sweep = 0; sweep < 8; ++sweep)
+        for (int k = 0; k < 3; ++k) {
+            const int p = PP[k], q = QQ[k], r = RR[k];
+            const double apq = a[p][q];
+            if (apq == 0.0) continue;
+            const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+            double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+            if (theta < 0.0) t = -t;
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            a[p][p] -= t * apq; a[q][q] += t * apq; a[p][q] = a[q][p] = 0.0;
+            const double arp = a[r][p], arq = a[r][q];
+            a[r][p] = a[p][r] = c * arp - s * arq;
+            a[r][q] = a[q][r] = s * arp + c * arq;
+            for (int m = 0; m < 3; ++m) {
+                const double vp = v[m][p], vq = v[m][q];
+                v[m][p] = c * vp - s * vq; v[m][q] = s * vp + c * vq;
+            }
+        }
+    int k = 0;
+    if (a[1][1] < a[k][k]) k = 1;
+    if (a[2][2] < a[k][k]) k = 2;
+    nx = v[0][k]; ny = v[1][k]; nz = v[2][k];
+    const double len = sqrt(nx * nx + ny * ny + nz * nz);
+    nx /= len; ny /= len; nz /= len;
+}
+
+extern "C" int slam3d_fit_planes(slam3d_icp_handle *h, const slam3d_cloud_view *cloud, const int32_t *labels,
+                                 int32_t nplanes, slam3d_plane *planes)
+{
+    if (!h || !cloud || !labels || !planes || nplanes <= 0 || nplanes > 16) return SLAM3D_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    const int N = h->N;
+    int rc = upload_cloud(h, cloud, h->d_scratch4);
+    if (rc) return rc;
+    // origin of each plane's moments = its first labelled point (keeps the sums well conditioned)
+    std::vector<double> origin(3 * (size_t)nplanes, 0.0);
+    std::vector<int> first(nplanes, -1);
+    int found = 0;
+    for (int i = 0; i < N && found < nplanes; ++i) {
+        const int l = labels[i];
+        if (l >= 0 && l < nplanes && first[l] < 0) {
+            first[l] = i; ++found;
+            const float *q = reinterpret_cast<const float *>((const unsigned char *)cloud->data + (size_t)i * cloud->stride_bytes);
+            origin[3 * l] = q[0]; origin[3 * l + 1] = q[1]; origin[3 * l + 2] = q[2];
+        }
+    }
+    const int chunks = (N + CHUNK - 1) / CHUNK;
+    double *d_origin = nullptr, *d_part = nullptr;
+    HIPCHK(h, hipMalloc((void **)&d_origin, sizeof(double) * 3 * nplanes));
+    HIPCHK(h, hipMalloc((void **)&d_part, sizeof(double) * 10 * (size_t)nplanes * chunks));
+    HIPCHK(h, hipMemcpyAsync(d_origin, origin.data(), sizeof(double) * 3 * nplanes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_idx, labels, sizeof(int) * N, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_plane_sums, dim3(chunks), dim3(CHUNK), 0, h->stream, h->d_scratch4, h->d_idx, N, nplanes, d_origin, d_part);
+    HIPCHK(h, hipGetLastError());
+    std::vector<double> part(10 * (size_t)nplanes * chunks);
+    HIPCHK(h, hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(d_origin); (void)hipFree(d_part);
+    for (int pl = 0; pl < nplanes; ++pl) {
+        double s[10] = { 0 };
+        for (int c = 0; c < chunks; ++c)
+            for (int k = 0; k < 10; ++k) s[k] += part[((size_t)c * nplanes + pl) * 10 + k];
+        slam3d_plane &P = planes[pl];
+        memset(&P, 0, sizeof P);
+        P.count = (int)s[0];
+        if (s[0] < 3.0) continue;
+        const double inv = 1.0 / s[0];
+        const double mx = s[1] * inv, my = s[2] * inv, mz = s[3] * inv;
+        double nx, ny, nz;
+        host_eig3_smallest(s[4] * inv - mx * mx, s[5] * inv - mx * my, s[6] * inv - mx * mz,
+                           s[7] * inv - my * my, s[8] * inv - my * mz, s[9] * inv - mz * mz, nx, ny, nz);
+        const double cx = origin[3 * pl] + mx, cy = origin[3 * pl + 1] + my, cz = origin[3 * pl + 2] + mz;
+        double d = -(nx * cx + ny * cy + nz * cz);
+        if (d < 0.0) { nx = -nx; ny = -ny; nz = -nz; d = -d; }     // src/GraphicEnd.cpp:383-387
+        P.coeff[0] = (float)nx; P.coeff[1] = (float)ny; P.coeff[2] = (float)nz; P.coeff[3] = (float)d;
+        P.centroid[0] = (float)cx; P.centroid[1] = (float)cy; P.centroid[2] = (float)cz;
+    }
+    return SLAM3D_OK;
+}
+
+// ------------------------------------------------------------------------------ dense mode
+extern "C" int slam3d_icp_dense_set_rows(slam3d_icp_handle *h, int32_t row_begin, int32_t row_end)
+{
+    if (!h || row_begin < 0 || row_end > h->p.height || row_begin > row_end) return SLAM3D_E_INVALID;
+    h->row0 = row_begin; h->row1 = row_end;
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_dense_begin(slam3d_icp_handle *h, const double *T_init, void *stream)
+{
+    if (!h) return SLAM3D_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    if (s != h->stream) {
+        HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+        HIPCHK(h, hipStreamWaitEvent(s, h->ev[0], 0));
+    }
+    const int rc = enqueue_preprocess(h, 1, T_init, s);
+    if (rc) return rc;
+    h->dense_it = 0;
+    h->run_stream = s; h->ran = true; h->last_B = 1;
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_dense_partial(slam3d_icp_handle *h, double sums[SLAM3D_ICP_NSUMS], void *stream)
+{
+    if (!h || !sums) return SLAM3D_E_INVALID;
+    if (!h->ran) return SLAM3D_E_STATE;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
+    const int rc = enqueue_nn_accumulate(h, 1, s, nullptr, nullptr);
+    if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->pin_out, h->sums, sizeof(double) * NSUMS, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    memcpy(sums, h->pin_out, sizeof(double) * NSUMS);
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_dense_update(slam3d_icp_handle *h, const double sums[SLAM3D_ICP_NSUMS], void *stream)
+{
+    if (!h || !sums) return SLAM3D_E_INVALID;
+    if (!h->ran || h->dense_it >= (h->p.iterations > 0 ? h->p.iterations : 1)) return SLAM3D_E_STATE;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
+    memcpy(h->pin_T, sums, sizeof(double) * NSUMS);
+    HIPCHK(h, hipMemcpyAsync(h->sums, h->pin_T, sizeof(double) * NSUMS, hipMemcpyHostToDevice, s));
+    const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, s, h->sums, h->Tcur, h->trace_T, h->trace_S, h->flags, 1, h->dense_it,
+                       iters, h->p.estimator);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(s));   // pin_T is reused by the next call
+    h->dense_it++;
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_dense_finish(slam3d_icp_handle *h, const double last_sums[SLAM3D_ICP_NSUMS], slam3d_icp_result *out)
+{
+    if (!h || !out) return SLAM3D_E_INVALID;
+    if (!h->ran) return SLAM3D_E_STATE;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    hipStream_t s = h->run_stream;
+    HIPCHK(h, hipMemcpyAsync(h->pin_out, h->Tcur, sizeof(double) * 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->pin_int, h->counts, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->pin_int + 4, h->flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    finish_result(h->p, h->pin_out, last_sums, h->pin_int[4], h->pin_int[0], h->pin_int[1], out);
+    out->iterations = h->dense_it;
+    return SLAM3D_OK;
+}

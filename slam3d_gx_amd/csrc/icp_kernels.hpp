@@ -1,0 +1,703 @@
+// icp_kernels.hpp -- hand-written HIP kernels (gfx950 / CDNA4) of the plane-ICP path.
+//
+// Stage map (DESIGN.md section 3 / SURVEY.md section 8a):
+//   S1 k_backproject      u16 depth -> organized float4 cloud      src/convert2PCD.cpp:54-72
+//   S2 k_normals          7x7 window covariance -> normal          src/planarFeatures.cpp:88-136 (a7)
+//   S3 k_compact          valid points -> dense raster-ordered lists (stable)
+//   S4 k_nn_*             exact brute-force 1-NN (replaces FLANN matching, src/GraphicEnd.cpp:486-520)
+//      k_accumulate       point-to-plane / Kabsch normal equations, deterministic 256-chunk tree
+//   S5 k_reduce, k_solve  29-double reduction, 6x6 LDL^T or 3x3 SVD, SE(3) update on device
+//   a6 k_plane_sums       per-plane {sum p, sum pp^T, n} -> (n,d)   src/GraphicEnd.cpp:360-387
+//
+// Numerics contract: compiled with -ffp-contract=off; every float/double operation is an
+// individually rounded IEEE op in the order written (explicit __fmaf_rn where the spec has an
+// fma), so results are bit-identical to the CPU oracle's restatement of the same spec.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace s3d {
+
+constexpr int NSUMS = 29;
+constexpr int CHUNK = 256;
+constexpr int NN_TILE = 1024;      // targets staged in LDS per tile
+constexpr int NN_QPT = 4;          // queries per thread (VALU kernel)
+constexpr int NN_BLOCK = 256;
+
+struct SlotPtrs {                  // per frame-pair device pointers (organized float4 clouds)
+    const float4 *src;
+    const float4 *tgt;
+};
+
+struct Geometry {
+    int W, H, N;
+    float zmax;
+    int win_r, min_in;
+    double in_dist;
+    float gate2;
+    int estimator;
+    double fx, fy, cx, cy, factor, zf;
+};
+
+__device__ __forceinline__ bool pt_valid(float x, float y, float z, float zmax)
+{
+    return isfinite(x) && isfinite(y) && isfinite(z) && z > 0.0f && z <= zmax;
+}
+
+// ------------------------------------------------------------------------------------ S1
+__global__ __launch_bounds__(256) void k_backproject(const uint16_t *__restrict__ depth, float4 *__restrict__ out,
+                                                      Geometry g)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.N) return;
+    const int v = i / g.W, u = i - v * g.W;
+    const uint16_t d = depth[i];
+    const double z = (double)d / g.factor;
+    float4 o;
+    if (d == 0 || !(z <= g.zf)) {
+        const float qnan = __int_as_float(0x7fc00000);
+        o = make_float4(qnan, qnan, qnan, 0.0f);
+    } else {
+        const double x = ((double)u - g.cx) * z / g.fx;
+        const double y = ((double)v - g.cy) * z / g.fy;
+        o = make_float4((float)x, (float)y, (float)z, 1.0f);
+    }
+    out[i] = o;
+}
+
+// records of arbitrary stride (pcl::PointXYZRGBA = 32 B) -> packed float4
+__global__ __launch_bounds__(256) void k_repack(const unsigned char *__restrict__ raw, int stride,
+                                                 float4 *__restrict__ out, int N)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float *p = reinterpret_cast<const float *>(raw + (size_t)i * stride);
+    out[i] = make_float4(p[0], p[1], p[2], 1.0f);
+}
+
+// --------------------------------------------------------------------- 3x3 Jacobi eigen
+struct Sym3 { double a00, a01, a02, a11, a12, a22; };
+struct Mat3 { double m00, m01, m02, m10, m11, m12, m20, m21, m22; };
+
+__device__ __forceinline__ void jrot(double &app, double &aqq, double &apq, double &arp, double &arq,
+                                     double &v0p, double &v0q, double &v1p, double &v1q, double &v2p, double &v2q)
+{
+    if (apq == 0.0) return;
+    const double theta = (aqq - app) / (2.0 * apq);
+    double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
+    if (theta < 0.0) t = -t;
+    const double c = 1.0 / sqrt(t * t + 1.0);
+    const double s = t * c;
+    app = app - t * apq;
+    aqq = aqq + t * apq;
+    apq = 0.0;
+    const double rp = arp, rq = arq;
+    arp = c * rp - s * rq;
+    arq = s * rp + c * rq;
+    double a = v0p, b = v0q; v0p = c * a - s * b; v0q = s * a + c * b;
+    a = v1p; b = v1q;        v1p = c * a - s * b; v1q = s * a + c * b;
+    a = v2p; b = v2q;        v2p = c * a - s * b; v2q = s * a + c * b;
+}
+
+// eigenvector (unit) of the smallest eigenvalue; cyclic Jacobi, 8 sweeps, order (0,1),(0,2),(1,2)
+__device__ __forceinline__ void eig3_smallest(Sym3 A, double &nx, double &ny, double &nz)
+{
+    Mat3 V = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+#pragma unroll 1
+    for (int sweep = 0; sweep < 8; ++sweep) {
+        jrot(A.a00, A.a11, A.a01, A.a02, A.a12, V.m00, V.m01, V.m10, V.m11, V.m20, V.m21); // (0,1) r=2
+        jrot(A.a00, A.a22, A.a02, A.a01, A.a12, V.m00, V.m02, V.m10, V.m12, V.m20, V.m22); // (0,2) r=1
+        jrot(A.a11, A.a22, A.a12, A.a01, A.a02, V.m01, V.m02, V.m11, V.m12, V.m21, V.m22); // (1,2) r=0
+    }
+    double e = A.a00; nx = V.m00; ny = V.m10; nz = V.m20;
+    if (A.a11 < e) { e = A.a11; nx = V.m01; ny = V.m11; nz = V.m21; }
+    if (A.a22 < e) { e = A.a22; nx = V.m02; ny = V.m12; nz = V.m22; }
+    const double len = sqrt(nx * nx + ny * ny + nz * nz);
+    nx = nx / len; ny = ny / len; nz = nz / len;
+}
+
+// ------------------------------------------------------------------------------------ S2
+// one thread per target pixel; the (32+2r)x(8+2r) neighbourhood of a 32x8 pixel block is staged
+// in LDS once (coalesced float4 rows), then each thread walks its window twice (moments, inliers).
+constexpr int NRM_BX = 32, NRM_BY = 8, NRM_RMAX = 4;
+
+__global__ __launch_bounds__(NRM_BX * NRM_BY) void k_normals(const SlotPtrs *__restrict__ slots,
+                                                             float4 *__restrict__ nrm_all, Geometry g)
+{
+    __shared__ float4 tile[(NRM_BY + 2 * NRM_RMAX) * (NRM_BX + 2 * NRM_RMAX)];
+    const int b = blockIdx.z;
+    const float4 *__restrict__ cloud = slots[b].tgt;
+    float4 *__restrict__ nrm = nrm_all + (size_t)b * g.N;
+    const int r = g.win_r;
+    const int tw = NRM_BX + 2 * r, th = NRM_BY + 2 * r;
+    const int u0 = blockIdx.x * NRM_BX - r, v0 = blockIdx.y * NRM_BY - r;
+    const int tid = threadIdx.y * NRM_BX + threadIdx.x;
+    const float qnan = __int_as_float(0x7fc00000);
+    for (int k = tid; k < tw * th; k += NRM_BX * NRM_BY) {
+        const int ty = k / tw, tx = k - ty * tw;
+        const int uu = u0 + tx, vv = v0 + ty;
+        float4 q = make_float4(qnan, qnan, qnan, 0.0f);
+        if (uu >= 0 && uu < g.W && vv >= 0 && vv < g.H) q = cloud[(size_t)vv * g.W + uu];
+        q.w = pt_valid(q.x, q.y, q.z, g.zmax) ? 1.0f : 0.0f;
+        tile[k] = q;
+    }
+    __syncthreads();
+    const int u = blockIdx.x * NRM_BX + threadIdx.x, v = blockIdx.y * NRM_BY + threadIdx.y;
+    if (u >= g.W || v >= g.H) return;
+    float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 c0 = tile[(threadIdx.y + r) * tw + threadIdx.x + r];
+    if (c0.w > 0.5f) {
+        const double cx0 = c0.x, cy0 = c0.y, cz0 = c0.z;
+        int n = 0;
+        double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+        for (int dv = 0; dv <= 2 * r; ++dv)
+            for (int du = 0; du <= 2 * r; ++du) {
+                const float4 q = tile[(threadIdx.y + dv) * tw + threadIdx.x + du];
+                if (!(q.w > 0.5f)) continue;
+                const double dx = (double)q.x - cx0, dy = (double)q.y - cy0, dz = (double)q.z - cz0;
+                ++n;
+                sx += dx; sy += dy; sz += dz;
+                sxx += dx * dx; sxy += dx * dy; sxz += dx * dz;
+                syy += dy * dy; syz += dy * dz; szz += dz * dz;
+            }
+        if (n >= g.min_in) {
+            const double inv = 1.0 / (double)n;
+            const double mx = sx * inv, my = sy * inv, mz = sz * inv;
+            Sym3 C;
+            C.a00 = sxx * inv - mx * mx; C.a01 = sxy * inv - mx * my; C.a02 = sxz * inv - mx * mz;
+            C.a11 = syy * inv - my * my; C.a12 = syz * inv - my * mz; C.a22 = szz * inv - mz * mz;
+            double nx, ny, nz;
+            eig3_smallest(C, nx, ny, nz);
+            if (nx * cx0 + ny * cy0 + nz * cz0 > 0.0) { nx = -nx; ny = -ny; nz = -nz; }
+            int cnt = 0;
+            for (int dv = 0; dv <= 2 * r; ++dv)
+                for (int du = 0; du <= 2 * r; ++du) {
+                    const float4 q = tile[(threadIdx.y + dv) * tw + threadIdx.x + du];
+                    if (!(q.w > 0.5f)) continue;
+                    const double dx = (double)q.x - cx0, dy = (double)q.y - cy0, dz = (double)q.z - cz0;
+                    const double e = nx * (dx - mx) + ny * (dy - my) + nz * (dz - mz);
+                    if (fabs(e) <= g.in_dist) ++cnt;
+                }
+            if (cnt >= g.min_in) out = make_float4((float)nx, (float)ny, (float)nz, 1.0f);
+        }
+    }
+    nrm[(size_t)v * g.W + u] = out;
+}
+
+// ------------------------------------------------------------------------------------ S3
+// stable stream compaction, one 1024-thread block per (pair, src|tgt); w of the compacted
+// float4 carries the original linear index (int bits).  Source rows can be restricted
+// (dense multi-GPU mode) to [row0,row1).
+__global__ __launch_bounds__(1024) void k_compact(const SlotPtrs *__restrict__ slots,
+                                                  const float4 *__restrict__ nrm_all,
+                                                  float4 *__restrict__ src_c, float4 *__restrict__ tgt_c,
+                                                  float4 *__restrict__ tgt_cn, int *__restrict__ counts,
+                                                  Geometry g, int use_normals, int row0, int row1)
+{
+    __shared__ int wave_tot[16];
+    const int which = blockIdx.x, b = blockIdx.y;
+    const float4 *__restrict__ cloud = which == 0 ? slots[b].src : slots[b].tgt;
+    const float4 *__restrict__ nrm = nrm_all + (size_t)b * g.N;
+    float4 *__restrict__ outp = (which == 0 ? src_c : tgt_c) + (size_t)b * g.N;
+    float4 *__restrict__ outn = tgt_cn + (size_t)b * g.N;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i_begin = which == 0 ? row0 * g.W : 0;
+    const int i_end = which == 0 ? row1 * g.W : g.N;
+    int base = 0;
+    for (int t0 = i_begin; t0 < i_end; t0 += 1024) {
+        const int i = t0 + tid;
+        float4 q = make_float4(0, 0, 0, 0), nn = make_float4(0, 0, 0, 0);
+        bool ok = false;
+        if (i < i_end) {
+            q = cloud[i];
+            ok = pt_valid(q.x, q.y, q.z, g.zmax);
+            if (ok && which == 1 && use_normals) { nn = nrm[i]; ok = nn.w > 0.5f; }
+        }
+        const unsigned long long m = __ballot(ok);
+        const int prefix = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[w] = __popcll(m);
+        __syncthreads();
+        int woff = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int c = wave_tot[k]; if (k < w) woff += c; total += c; }
+        if (ok) {
+            const int pos = base + woff + prefix;
+            outp[pos] = make_float4(q.x, q.y, q.z, __int_as_float(i));
+            if (which == 1 && use_normals) outn[pos] = make_float4(nn.x, nn.y, nn.z, 0.0f);
+        }
+        base += total;
+        __syncthreads();
+    }
+    if (tid == 0) counts[b * 4 + which] = base;
+}
+
+// ------------------------------------------------------------------------------------ S4
+struct Rt { float r00, r01, r02, r10, r11, r12, r20, r21, r22, t0, t1, t2; };
+
+__device__ __forceinline__ Rt load_rt(const double *__restrict__ T)
+{
+    Rt m;
+    m.r00 = (float)T[0]; m.r01 = (float)T[1]; m.r02 = (float)T[2];  m.t0 = (float)T[3];
+    m.r10 = (float)T[4]; m.r11 = (float)T[5]; m.r12 = (float)T[6];  m.t1 = (float)T[7];
+    m.r20 = (float)T[8]; m.r21 = (float)T[9]; m.r22 = (float)T[10]; m.t2 = (float)T[11];
+    return m;
+}
+
+__device__ __forceinline__ void xform(const Rt &m, float x, float y, float z, float &ox, float &oy, float &oz)
+{
+    ox = __fmaf_rn(m.r02, z, __fmaf_rn(m.r01, y, m.r00 * x)) + m.t0;
+    oy = __fmaf_rn(m.r12, z, __fmaf_rn(m.r11, y, m.r10 * x)) + m.t1;
+    oz = __fmaf_rn(m.r22, z, __fmaf_rn(m.r21, y, m.r20 * x)) + m.t2;
+}
+
+__device__ __forceinline__ float canon_d2(float px, float py, float pz, float qx, float qy, float qz)
+{
+    const float dx = qx - px, dy = qy - py, dz = qz - pz;
+    return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
+}
+
+// exact brute force on the VALU.  grid = (query blocks, target splits, pairs).  Each thread owns
+// NN_QPT queries (registers); target tiles of NN_TILE points are staged in LDS and read with
+// broadcast ds_read_b128.  Splits merge through a 64-bit atomicMin on (d2 bits << 32 | j): the
+// float bits of a non-negative d2 order like unsigned ints, so the minimum is the smallest d2 and,
+// among equal d2, the smallest j -- the spec's tie-break, independent of scheduling.
+__global__ __launch_bounds__(NN_BLOCK) void k_nn_valu(const float4 *__restrict__ src_c,
+                                                      const float4 *__restrict__ tgt_c,
+                                                      const int *__restrict__ counts,
+                                                      const double *__restrict__ Tcur,
+                                                      unsigned long long *__restrict__ best, int N, int nsplit)
+{
+    __shared__ float4 tile[NN_TILE];
+    const int b = blockIdx.z;
+    const int ns = counts[b * 4 + 0], nt = counts[b * 4 + 1];
+    const int q0 = blockIdx.x * (NN_BLOCK * NN_QPT);
+    if (q0 >= ns) return;
+    const int ntiles = (nt + NN_TILE - 1) / NN_TILE;
+    const int tile_begin = (int)(((long long)blockIdx.y * ntiles) / nsplit);
+    const int tile_end = (int)(((long long)(blockIdx.y + 1) * ntiles) / nsplit);
+    if (tile_begin >= tile_end) return;
+    const float4 *__restrict__ S = src_c + (size_t)b * N;
+    const float4 *__restrict__ Q = tgt_c + (size_t)b * N;
+    const Rt m = load_rt(Tcur + b * 16);
+    float px[NN_QPT], py[NN_QPT], pz[NN_QPT], bd[NN_QPT];
+    int bj[NN_QPT];
+    const float inf = __int_as_float(0x7f800000);
+#pragma unroll
+    for (int k = 0; k < NN_QPT; ++k) {
+        const int i = q0 + k * NN_BLOCK + threadIdx.x;
+        float4 s = make_float4(0, 0, 0, 0);
+        if (i < ns) s = S[i];
+        xform(m, s.x, s.y, s.z, px[k], py[k], pz[k]);
+        bd[k] = inf; bj[k] = -1;
+    }
+    for (int t = tile_begin; t < tile_end; ++t) {
+        const int j0 = t * NN_TILE;
+        __syncthreads();
+        for (int k = threadIdx.x; k < NN_TILE; k += NN_BLOCK) {
+            const int j = j0 + k;
+            float4 q = make_float4(inf, inf, inf, 0.0f);
+            if (j < nt) q = Q[j];
+            tile[k] = q;
+        }
+        __syncthreads();
+        const int cnt = min(NN_TILE, nt - j0);
+#pragma unroll 4
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float4 c = tile[jj];
+#pragma unroll
+            for (int k = 0; k < NN_QPT; ++k) {
+                const float d2 = canon_d2(px[k], py[k], pz[k], c.x, c.y, c.z);
+                const bool lt = d2 < bd[k];
+                bd[k] = lt ? d2 : bd[k];
+                bj[k] = lt ? j0 + jj : bj[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NN_QPT; ++k) {
+        const int i = q0 + k * NN_BLOCK + threadIdx.x;
+        if (i < ns && bj[k] >= 0) {
+            const unsigned long long key =
+                ((unsigned long long)(unsigned int)__float_as_int(bd[k]) << 32) | (unsigned int)bj[k];
+            atomicMin(best + (size_t)b * N + i, key);
+        }
+    }
+}
+
+// rows of the normal equations for compact source i matched to compact target j (spec S4)
+__device__ __forceinline__ void row_sums(int estimator, float pxf, float pyf, float pzf, const float4 q4,
+                                         const float4 n4, double *__restrict__ s)
+{
+    const double px = pxf, py = pyf, pz = pzf;
+    const double qx = q4.x, qy = q4.y, qz = q4.z;
+    const double dx = qx - px, dy = qy - py, dz = qz - pz;
+    if (estimator == 0) {
+        const double nx = n4.x, ny = n4.y, nz = n4.z;
+        double a[6];
+        a[0] = py * nz - pz * ny; a[1] = pz * nx - px * nz; a[2] = px * ny - py * nx;
+        a[3] = nx; a[4] = ny; a[5] = nz;
+        const double bb = (nx * dx + ny * dy) + nz * dz;
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = r; c < 6; ++c) s[k++] = a[r] * a[c];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) s[21 + r] = a[r] * bb;
+        s[27] = 1.0; s[28] = bb * bb;
+    } else {
+        s[0] = px; s[1] = py; s[2] = pz; s[3] = qx; s[4] = qy; s[5] = qz;
+        s[6] = px * qx; s[7] = px * qy; s[8] = px * qz;
+        s[9] = py * qx; s[10] = py * qy; s[11] = py * qz;
+        s[12] = pz * qx; s[13] = pz * qy; s[14] = pz * qz;
+        s[27] = 1.0; s[28] = (dx * dx + dy * dy) + dz * dz;
+    }
+}
+
+// block tree: sh[k*256 + i] += sh[k*256 + i + s] for s = 128..1 -- the spec's association order.
+// The s*29 independent adds of a level are spread over all 256 threads.
+__device__ __forceinline__ void tree256(double *__restrict__ sh, int tid)
+{
+    for (int s = CHUNK / 2; s >= 1; s >>= 1) {
+        __syncthreads();
+        for (int w = tid; w < s * NSUMS; w += CHUNK) {
+            const int k = w / s, i = w - k * s;
+            sh[k * CHUNK + i] += sh[k * CHUNK + i + s];
+        }
+    }
+    __syncthreads();
+}
+
+// grid = (chunks, pairs); decodes + resets the packed NN keys, writes corr/d2 (compact order),
+// forms the 29 row products per correspondence and tree-reduces the chunk.
+__global__ __launch_bounds__(CHUNK) void k_accumulate(const float4 *__restrict__ src_c,
+                                                      const float4 *__restrict__ tgt_c,
+                                                      const float4 *__restrict__ tgt_cn,
+                                                      const int *__restrict__ counts,
+                                                      const double *__restrict__ Tcur,
+                                                      unsigned long long *__restrict__ best,
+                                                      int *__restrict__ corr, float *__restrict__ cd2,
+                                                      double *__restrict__ partials, int N, int max_chunks,
+                                                      float gate2, int estimator)
+{
+    __shared__ double sh[NSUMS * CHUNK];
+    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const int ns = counts[b * 4 + 0];
+    if (c * CHUNK >= ns) return;
+    const int i = c * CHUNK + tid;
+    double s[NSUMS];
+#pragma unroll
+    for (int k = 0; k < NSUMS; ++k) s[k] = 0.0;
+    if (i < ns) {
+        const size_t gi = (size_t)b * N + i;
+        const unsigned long long key = best[gi];
+        best[gi] = ~0ull;
+        const int j = (int)(unsigned int)(key & 0xffffffffull);
+        const float d2 = __int_as_float((int)(unsigned int)(key >> 32));
+        const bool ok = (j >= 0) && (d2 <= gate2);
+        corr[gi] = ok ? j : -1;
+        cd2[gi] = ok ? d2 : __int_as_float(0x7f800000);
+        if (ok) {
+            const Rt m = load_rt(Tcur + b * 16);
+            const float4 sp = src_c[gi];
+            float px, py, pz;
+            xform(m, sp.x, sp.y, sp.z, px, py, pz);
+            const float4 q4 = tgt_c[(size_t)b * N + j];
+            float4 n4 = make_float4(0, 0, 0, 0);
+            if (estimator == 0) n4 = tgt_cn[(size_t)b * N + j];
+            row_sums(estimator, px, py, pz, q4, n4, s);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NSUMS; ++k) sh[k * CHUNK + tid] = s[k];
+    tree256(sh, tid);
+    if (tid < NSUMS) partials[((size_t)b * max_chunks + c) * NSUMS + tid] = sh[tid * CHUNK];
+}
+
+// ------------------------------------------------------------------------------------ S5
+// level 2/3 of the reduction: groups of 256 chunk partials -> tree, groups summed in order.
+__global__ __launch_bounds__(CHUNK) void k_reduce(const double *__restrict__ partials,
+                                                  const int *__restrict__ counts, double *__restrict__ sums,
+                                                  int max_chunks)
+{
+    __shared__ double sh[NSUMS * CHUNK];
+    __shared__ double tot[NSUMS];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int ns = counts[b * 4 + 0];
+    const int nchunks = (ns + CHUNK - 1) / CHUNK;
+    const int ngroups = (nchunks + CHUNK - 1) / CHUNK;
+    if (tid < NSUMS) tot[tid] = 0.0;
+    for (int g = 0; g < ngroups; ++g) {
+        const int c = g * CHUNK + tid;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NSUMS; ++k)
+            sh[k * CHUNK + tid] = c < nchunks ? partials[((size_t)b * max_chunks + c) * NSUMS + k] : 0.0;
+        tree256(sh, tid);
+        if (tid < NSUMS) tot[tid] = g == 0 ? sh[tid * CHUNK] : tot[tid] + sh[tid * CHUNK];
+    }
+    __syncthreads();
+    if (tid < NSUMS) sums[b * NSUMS + tid] = tot[tid];
+}
+
+// deterministic sin/cos (spec): Cody-Waite reduction by pi/2 + Taylor/Horner, basic ops only
+__device__ inline void spec_sincos(double x, double &s, double &c)
+{
+    const double kf = floor(x * 0.63661977236758134308 + 0.5);
+    const double r = (x - kf * 1.57079632673412561417e+00) - kf * 6.07710050650619224932e-11;
+    const double z = r * r;
+    double ps = 1.0 / 355687428096000.0;
+    ps = ps * z - 1.0 / 1307674368000.0;
+    ps = ps * z + 1.0 / 6227020800.0;
+    ps = ps * z - 1.0 / 39916800.0;
+    ps = ps * z + 1.0 / 362880.0;
+    ps = ps * z - 1.0 / 5040.0;
+    ps = ps * z + 1.0 / 120.0;
+    ps = ps * z - 1.0 / 6.0;
+    const double sr = r + r * (z * ps);
+    double pc = -1.0 / 6402373705728000.0;
+    pc = pc * z + 1.0 / 20922789888000.0;
+    pc = pc * z - 1.0 / 87178291200.0;
+    pc = pc * z + 1.0 / 479001600.0;
+    pc = pc * z - 1.0 / 3628800.0;
+    pc = pc * z + 1.0 / 40320.0;
+    pc = pc * z - 1.0 / 720.0;
+    pc = pc * z + 1.0 / 24.0;
+    pc = pc * z - 0.5;
+    const double cr = 1.0 + z * pc;
+    const long long k = (long long)kf;
+    const int quad = (int)(((k % 4) + 4) % 4);
+    if (quad == 0) { s = sr; c = cr; }
+    else if (quad == 1) { s = cr; c = -sr; }
+    else if (quad == 2) { s = -sr; c = -cr; }
+    else { s = -cr; c = sr; }
+}
+
+__device__ inline bool ldl6(const double (*A)[6], const double *b, double tr, double *x)
+{
+    double L[6][6], D[6], y[6];
+    const double floor_piv = 1e-12 * tr / 6.0;
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j][j];
+        for (int k = 0; k < j; ++k) d -= (L[j][k] * L[j][k]) * D[k];
+        if (!(d > floor_piv)) return false;
+        D[j] = d;
+        for (int i = j + 1; i < 6; ++i) {
+            double v = A[i][j];
+            for (int k = 0; k < j; ++k) v -= (L[i][k] * L[j][k]) * D[k];
+            L[i][j] = v / d;
+        }
+    }
+    for (int i = 0; i < 6; ++i) {
+        double v = b[i];
+        for (int k = 0; k < i; ++k) v -= L[i][k] * y[k];
+        y[i] = v;
+    }
+    for (int i = 0; i < 6; ++i) y[i] = y[i] / D[i];
+    for (int i = 5; i >= 0; --i) {
+        double v = y[i];
+        for (int k = i + 1; k < 6; ++k) v -= L[k][i] * x[k];
+        x[i] = v;
+    }
+    return true;
+}
+
+// 1 solved, 2 solved after damping, 0 failed
+__device__ inline int solve6(const double *U, const double *Atb, double *x)
+{
+    double A[6][6];
+    int k = 0;
+    for (int r = 0; r < 6; ++r)
+        for (int c = r; c < 6; ++c) { A[r][c] = U[k]; A[c][r] = U[k]; ++k; }
+    double tr = 0.0;
+    for (int r = 0; r < 6; ++r) tr += A[r][r];
+    if (!(tr > 0.0)) return 0;
+    if (ldl6(A, Atb, tr, x)) return 1;
+    const double lam = 1e-9 * tr / 6.0;
+    for (int r = 0; r < 6; ++r) A[r][r] = A[r][r] + lam;
+    if (ldl6(A, Atb, tr, x)) return 2;
+    return 0;
+}
+
+// one-sided Jacobi SVD of H (12 sweeps) -> R = V U^T with det +1 (spec S5, Kabsch)
+__device__ inline void svd3_rotation(const double *H, double *R)
+{
+    double g[3][3], v[3][3];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) { g[r][c] = H[r * 3 + c]; v[r][c] = r == c ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 12; ++sweep)
+        for (int k = 0; k < 3; ++k) {
+            const int p = k == 2 ? 1 : 0, q = k == 0 ? 1 : 2;
+            const double al = (g[0][p] * g[0][p] + g[1][p] * g[1][p]) + g[2][p] * g[2][p];
+            const double be = (g[0][q] * g[0][q] + g[1][q] * g[1][q]) + g[2][q] * g[2][q];
+            const double ga = (g[0][p] * g[0][q] + g[1][p] * g[1][q]) + g[2][p] * g[2][q];
+            if (ga == 0.0) continue;
+            const double zeta = (be - al) / (2.0 * ga);
+            double t = 1.0 / (fabs(zeta) + sqrt(zeta * zeta + 1.0));
+            if (zeta < 0.0) t = -t;
+            const double c = 1.0 / sqrt(t * t + 1.0);
+            const double s = c * t;
+            for (int m = 0; m < 3; ++m) {
+                const double gp = g[m][p], gq = g[m][q];
+                g[m][p] = c * gp - s * gq;
+                g[m][q] = s * gp + c * gq;
+                const double vp = v[m][p], vq = v[m][q];
+                v[m][p] = c * vp - s * vq;
+                v[m][q] = s * vp + c * vq;
+            }
+        }
+    double sg[3];
+    for (int k = 0; k < 3; ++k) sg[k] = sqrt((g[0][k] * g[0][k] + g[1][k] * g[1][k]) + g[2][k] * g[2][k]);
+    int i0 = 0, i1 = 1, i2 = 2, tmp;
+    if (sg[i1] > sg[i0]) { tmp = i0; i0 = i1; i1 = tmp; }
+    if (sg[i2] > sg[i1]) { tmp = i1; i1 = i2; i2 = tmp; }
+    if (sg[i1] > sg[i0]) { tmp = i0; i0 = i1; i1 = tmp; }
+    for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    if (!(sg[i0] > 0.0) || !(sg[i1] > 1e-14 * sg[i0])) return;
+    double u0[3], u1[3], u2[3], v0[3], v1[3], v2[3];
+    for (int m = 0; m < 3; ++m) {
+        u0[m] = g[m][i0] / sg[i0]; u1[m] = g[m][i1] / sg[i1];
+        v0[m] = v[m][i0];          v1[m] = v[m][i1];
+    }
+    u2[0] = u0[1] * u1[2] - u0[2] * u1[1]; u2[1] = u0[2] * u1[0] - u0[0] * u1[2]; u2[2] = u0[0] * u1[1] - u0[1] * u1[0];
+    v2[0] = v0[1] * v1[2] - v0[2] * v1[1]; v2[1] = v0[2] * v1[0] - v0[0] * v1[2]; v2[2] = v0[0] * v1[1] - v0[1] * v1[0];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) R[r * 3 + c] = (v0[r] * u0[c] + v1[r] * u1[c]) + v2[r] * u2[c];
+}
+
+__device__ inline void compose(const double *dR, const double *dt, double *T)
+{
+    double Tn[16];
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c)
+            Tn[r * 4 + c] = (dR[r * 3 + 0] * T[0 * 4 + c] + dR[r * 3 + 1] * T[1 * 4 + c]) + dR[r * 3 + 2] * T[2 * 4 + c];
+        Tn[r * 4 + 3] = ((dR[r * 3 + 0] * T[3] + dR[r * 3 + 1] * T[7]) + dR[r * 3 + 2] * T[11]) + dt[r];
+    }
+    Tn[12] = 0.0; Tn[13] = 0.0; Tn[14] = 0.0; Tn[15] = 1.0;
+    for (int k = 0; k < 16; ++k) T[k] = Tn[k];
+}
+
+// one thread per pair: solve + SE(3) update, trace bookkeeping.  (The data-parallel work is in
+// k_accumulate/k_reduce; this is ~1e3 dependent fp64 ops.)
+__global__ void k_solve(const double *__restrict__ sums_all, double *__restrict__ Tcur,
+                        double *__restrict__ trace_T, double *__restrict__ trace_S,
+                        int *__restrict__ flags, int B, int it, int iters, int estimator)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double sums[NSUMS], T[16];
+    for (int k = 0; k < NSUMS; ++k) sums[k] = sums_all[b * NSUMS + k];
+    for (int k = 0; k < 16; ++k) T[k] = Tcur[b * 16 + k];
+    for (int k = 0; k < NSUMS; ++k) trace_S[((size_t)b * iters + it) * NSUMS + k] = sums[k];
+    int rc = 0;
+    double dR[9], dt[3];
+    if (estimator == 0) {
+        if (!(sums[27] < 6.0)) {
+            double x[6];
+            rc = solve6(sums, sums + 21, x);
+            if (rc) {
+                double sa, ca, sb, cb, sg, cg;
+                spec_sincos(x[0], sa, ca); spec_sincos(x[1], sb, cb); spec_sincos(x[2], sg, cg);
+                dR[0] = cg * cb; dR[1] = (cg * sb) * sa - sg * ca; dR[2] = (cg * sb) * ca + sg * sa;
+                dR[3] = sg * cb; dR[4] = (sg * sb) * sa + cg * ca; dR[5] = (sg * sb) * ca - cg * sa;
+                dR[6] = -sb;     dR[7] = cb * sa;                  dR[8] = cb * ca;
+                dt[0] = x[3]; dt[1] = x[4]; dt[2] = x[5];
+            }
+        }
+    } else {
+        const double n = sums[27];
+        if (!(n < 3.0)) {
+            const double pm[3] = { sums[0] / n, sums[1] / n, sums[2] / n };
+            const double qm[3] = { sums[3] / n, sums[4] / n, sums[5] / n };
+            double H[9];
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) H[r * 3 + c] = sums[6 + r * 3 + c] - (n * pm[r]) * qm[c];
+            svd3_rotation(H, dR);
+            for (int r = 0; r < 3; ++r)
+                dt[r] = qm[r] - ((dR[r * 3 + 0] * pm[0] + dR[r * 3 + 1] * pm[1]) + dR[r * 3 + 2] * pm[2]);
+            rc = 1;
+        }
+    }
+    if (rc) {
+        compose(dR, dt, T);
+        for (int k = 0; k < 16; ++k) Tcur[b * 16 + k] = T[k];
+        if (rc == 2) flags[b] = 1;
+    }
+    for (int k = 0; k < 16; ++k) trace_T[((size_t)b * (iters + 1) + it + 1) * 16 + k] = T[k];
+}
+
+__global__ void k_init_T(const double *__restrict__ T_init, double *__restrict__ Tcur,
+                         double *__restrict__ trace_T, int *__restrict__ flags, int B, int iters)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    for (int k = 0; k < 16; ++k) {
+        const double v = T_init ? T_init[b * 16 + k] : ((k % 5 == 0) ? 1.0 : 0.0);
+        Tcur[b * 16 + k] = v;
+        trace_T[((size_t)b * (iters + 1)) * 16 + k] = v;
+    }
+    flags[b] = 0;
+}
+
+// compact-order correspondences -> original linear indices (for get_correspondences)
+__global__ __launch_bounds__(256) void k_fill_corr(int *__restrict__ idx, float *__restrict__ d2, int N)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < N) { idx[i] = -1; d2[i] = __int_as_float(0x7f800000); }
+}
+
+__global__ __launch_bounds__(256) void k_scatter_corr(const float4 *__restrict__ src_c,
+                                                      const float4 *__restrict__ tgt_c,
+                                                      const int *__restrict__ corr, const float *__restrict__ cd2,
+                                                      const int *__restrict__ counts, int b, int N,
+                                                      int *__restrict__ idx, float *__restrict__ d2)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= counts[b * 4 + 0]) return;
+    const size_t gi = (size_t)b * N + i;
+    const int oi = __float_as_int(src_c[gi].w);
+    const int j = corr[gi];
+    idx[oi] = j >= 0 ? __float_as_int(tgt_c[(size_t)b * N + j].w) : -1;
+    d2[oi] = cd2[gi];
+}
+
+// ------------------------------------------------------------------------------------ a6
+// per-plane moments relative to an origin point, sequential-in-index semantics are not needed
+// here: sums are accumulated per plane with the same 256-chunk tree over the raster order.
+__global__ __launch_bounds__(CHUNK) void k_plane_sums(const float4 *__restrict__ cloud,
+                                                      const int *__restrict__ labels, int N, int nplanes,
+                                                      const double *__restrict__ origin /* nplanes*3 */,
+                                                      double *__restrict__ partials /* chunks*nplanes*10 */)
+{
+    __shared__ double sh[NSUMS * CHUNK];
+    const int c = blockIdx.x, tid = threadIdx.x, i = c * CHUNK + tid;
+    const int lab = i < N ? labels[i] : -1;
+    float4 q = make_float4(0, 0, 0, 0);
+    if (i < N) q = cloud[i];
+    for (int pl = 0; pl < nplanes; ++pl) {
+        double s[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) s[k] = 0.0;
+        if (lab == pl) {
+            const double dx = (double)q.x - origin[pl * 3], dy = (double)q.y - origin[pl * 3 + 1],
+                         dz = (double)q.z - origin[pl * 3 + 2];
+            s[0] = 1.0; s[1] = dx; s[2] = dy; s[3] = dz;
+            s[4] = dx * dx; s[5] = dx * dy; s[6] = dx * dz; s[7] = dy * dy; s[8] = dy * dz; s[9] = dz * dz;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 10; ++k) sh[k * CHUNK + tid] = s[k];
+        for (int st = CHUNK / 2; st >= 1; st >>= 1) {
+            __syncthreads();
+            for (int w = tid; w < st * 10; w += CHUNK) {
+                const int k = w / st, ii = w - k * st;
+                sh[k * CHUNK + ii] += sh[k * CHUNK + ii + st];
+            }
+        }
+        __syncthreads();
+        if (tid < 10) partials[((size_t)c * nplanes + pl) * 10 + tid] = sh[tid * CHUNK];
+    }
+}
+
+} // namespace s3d

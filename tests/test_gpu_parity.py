@@ -1,0 +1,146 @@
+"""HIP path vs CPU oracle, through the C-ABI (include/slam3d_icp.h).
+
+Bar (BASELINE.json north_star): correspondence indices bit-exact; pose within 1e-4 rad / 1e-4 m.
+The implementation is designed to be bit-identical in T as well; the tests
+assert the contractual tolerance and additionally report/guard the stronger property.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from slam3d_gx_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+ROT_TOL = 1e-4   # rad
+TRANS_TOL = 1e-4  # m
+
+
+def _pair(seed, w, h, **kw):
+    pr = synth.make_pair(seed, w, h, **kw)
+    s4 = synth.backproject_numpy(pr.depth_src, pr.intr)
+    t4 = synth.backproject_numpy(pr.depth_tgt, pr.intr)
+    return pr, s4, t4
+
+
+def _run_both(pr, s4, t4, estimator, iterations, nn_method=1, **kw):
+    po = O.params(pr.intr, estimator=estimator, iterations=iterations, nn_method=nn_method, **kw)
+    ro = O.icp(s4, t4, po)
+    pg = capi.default_params(pr.intr, estimator=estimator, iterations=iterations, max_batch=1, **kw)
+    with capi.IcpHandle(pg) as h:
+        rg = h.align(s4, t4)
+        idx, d2 = h.get_correspondences(0)
+        Tt, St = h.get_trace(0)
+        _, _, nrm = h.get_clouds(0, normals=(estimator == 0))
+    return ro, rg, idx, d2, Tt, St, nrm
+
+
+@pytest.mark.parametrize("estimator", [0, 1])
+@pytest.mark.parametrize("size", [(160, 120), (320, 240)])
+def test_small_vs_bruteforce_oracle(gpu_lib, estimator, size):
+    pr, s4, t4 = _pair(1000, *size)
+    ro, rg, idx, d2, Tt, St, nrm = _run_both(pr, s4, t4, estimator, 5, nn_method=0)
+    assert rg["n_src"] == ro["n_src"] and rg["n_tgt"] == ro["n_tgt"]
+    assert np.array_equal(idx, ro["idx"]), f"{(idx != ro['idx']).sum()} index mismatches"
+    assert np.array_equal(d2, ro["d2"])
+    rot, tr = O.pose_error(ro["T_trace"][-1], Tt[-1])
+    assert rot <= ROT_TOL and tr <= TRANS_TOL
+    assert rg["inliers"] == ro["inliers"] and rg["status"] == ro["status"]
+    assert abs(rg["norm"] - ro["norm"]) < 1e-9
+    # stronger, by design: every iterate and every 29-sum block identical
+    assert np.array_equal(St, ro["sums_trace"])
+    assert np.array_equal(Tt, ro["T_trace"])
+
+
+def test_normals_bitexact(gpu_lib):
+    pr, s4, t4 = _pair(1001, 320, 240)
+    po = O.params(pr.intr)
+    n_or = O.normals(t4, po)
+    pg = capi.default_params(pr.intr, iterations=1)
+    with capi.IcpHandle(pg) as h:
+        h.align(s4, t4)
+        _, _, n_gpu = h.get_clouds(0, normals=True)
+    assert np.array_equal(n_gpu[..., 3], n_or[..., 3])
+    assert np.array_equal(n_gpu, n_or)
+
+
+def test_backproject_bitexact(gpu_lib):
+    pr = synth.make_pair(1002, 640, 480)
+    po = O.params(pr.intr)
+    ref = O.backproject(pr.depth_src, po)
+    with capi.IcpHandle(capi.default_params(pr.intr)) as h:
+        got = h.backproject_u16(pr.depth_src)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.array_equal(np.nan_to_num(got), np.nan_to_num(ref))
+
+
+@pytest.mark.parametrize("estimator", [0, 1])
+def test_full_640x480_config2(gpu_lib, estimator):
+    """BASELINE config 2: single 640x480 pair, 20 iterations (oracle NN via exact kd-tree)."""
+    pr, s4, t4 = _pair(1000, 640, 480)
+    ro, rg, idx, d2, Tt, St, nrm = _run_both(pr, s4, t4, estimator, 20, nn_method=1)
+    assert np.array_equal(idx, ro["idx"]), f"{(idx != ro['idx']).sum()} index mismatches"
+    assert np.array_equal(d2, ro["d2"])
+    rot, tr = O.pose_error(ro["T_trace"][-1], Tt[-1])
+    assert rot <= ROT_TOL and tr <= TRANS_TOL
+    assert rg["inliers"] == ro["inliers"] and rg["status"] == ro["status"] == 0
+    assert np.array_equal(Tt, ro["T_trace"])
+    if estimator == 0:   # converges to the analytic pose within the noise floor
+        rot_gt, tr_gt = O.pose_error(pr.T_gt, rg["T"])
+        assert rot_gt < 2e-3 and tr_gt < 5e-3
+
+
+def test_batch_equals_single(gpu_lib):
+    """Batch mode (config 3 shape, reduced): every pair of a batch equals its single-pair run."""
+    seeds = [1000, 1001, 1002, 1003]
+    prs = [_pair(s, 320, 240) for s in seeds]
+    intr = prs[0][0].intr
+    pg = capi.default_params(intr, iterations=6, max_batch=len(seeds))
+    with capi.IcpHandle(pg) as h:
+        rb = h.align_batch([p[1] for p in prs], [p[2] for p in prs])
+        idxb = [h.get_correspondences(b)[0] for b in range(len(seeds))]
+    for b, (pr, s4, t4) in enumerate(prs):
+        ro = O.icp(s4, t4, O.params(intr, iterations=6, nn_method=1))
+        assert np.array_equal(idxb[b], ro["idx"])
+        assert np.array_equal(rb[b]["T_raw"], ro["T_trace"][-1])
+
+
+def test_depth_entry_and_strided_clouds(gpu_lib):
+    """align_depth_batch and 32-byte (pcl::PointXYZRGBA-like) records give the same answer."""
+    pr, s4, t4 = _pair(1003, 320, 240)
+    pg = capi.default_params(pr.intr, iterations=4)
+    with capi.IcpHandle(pg) as h:
+        r_cloud = h.align(s4, t4)
+        r_depth = h.align_depth_batch([pr.depth_src], [pr.depth_tgt])[0]
+        s8 = np.zeros(s4.shape[:2] + (8,), dtype=np.float32); s8[..., :3] = s4[..., :3]
+        t8 = np.zeros(t4.shape[:2] + (8,), dtype=np.float32); t8[..., :3] = t4[..., :3]
+        r_strided = h.align(s8, t8)
+    assert np.array_equal(r_cloud["T_raw"], r_depth["T_raw"])
+    assert np.array_equal(r_cloud["T_raw"], r_strided["T_raw"])
+
+
+def test_failure_convention_identity(gpu_lib):
+    """Empty target => too few inliers => status 1 and T exactly Identity (src/GraphicEnd.cpp:173,599)."""
+    pr, s4, t4 = _pair(1000, 160, 120)
+    t_empty = np.full_like(t4, np.nan)
+    with capi.IcpHandle(capi.default_params(pr.intr, iterations=3)) as h:
+        r = h.align(s4, t_empty)
+    ro = O.icp(s4, t_empty, O.params(pr.intr, iterations=3))
+    assert r["status"] == ro["status"] == 1
+    assert np.array_equal(r["T"], np.eye(4))
+    assert r["inliers"] == 0
+
+
+def test_T_init_and_roundtrip_property(gpu_lib):
+    """Size-independent property: aligning (A->B) from identity and (A->B) from the converged pose agree,
+    and swapping source/target yields the inverse transform to ICP accuracy."""
+    pr, s4, t4 = _pair(1001, 320, 240, noise=False, holes=False)
+    with capi.IcpHandle(capi.default_params(pr.intr, iterations=20)) as h:
+        r_ab = h.align(s4, t4)
+        r_ba = h.align(t4, s4)
+        r_warm = h.align(s4, t4, T_init=r_ab["T_raw"])
+    E = r_ab["T_raw"] @ r_ba["T_raw"]
+    rot, tr = O.pose_error(np.eye(4), E)
+    assert rot < 2e-3 and tr < 5e-3
+    rot, tr = O.pose_error(r_ab["T_raw"], r_warm["T_raw"])
+    assert rot < 1e-4 and tr < 1e-4
