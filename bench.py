@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- ICP iterations/s of the MI355X plane-ICP path (BASELINE.json metric).
+
+A *step* is one pass of the hot path over one batch of synthetic frame pairs that are already
+resident in HBM: preprocessing (normals, compaction) + `iterations` ICP iterations + the pose
+records back on the host.  Workload at N=1: BASELINE config 2 (single 640x480 pair, seed 1000,
+20 iterations, point-to-plane); `--pairs P` batches P pairs per GPU (config 3 = 64).
+For N>1 every rank processes its own pairs (seed 1000 + rank*P + i) -- the path has no data-path
+collective -- and the SE(3) pose records are all-gathered over RCCL once per step (weak scaling).
+
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (the NN search):
+achieved = algorithmic flops per launch (8 * n_src * n_tgt summed over the launch's pairs,
+SURVEY.md 8(d)) / mean launch duration measured with HIP events on the launch stream.
+`cpu_baseline` times the CPU oracle (exact kd-tree NN, OpenMP) on the same pair on the host.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md:40-41 (vector == f32-MFMA peak)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=1, help="frame pairs per GPU per step (config 3: 64)")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--iterations", type=int, default=20)
+    ap.add_argument("--estimator", choices=["point2plane", "svd"], default="point2plane")
+    ap.add_argument("--nn-mode", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed0", type=int, default=1000)
+    return ap.parse_args()
+
+
+def cpu_baseline_leg(pair, s4, t4, args, gpu_result, gpu_idx):
+    """Times the CPU oracle on the same pair and checks the GPU result against it.
+    (oracle use is confined to this leg: checker + CPU baseline, never the measured path)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    est = 0 if args.estimator == "point2plane" else 1
+    cores = os.cpu_count() or 1
+    p_all = O.params(pair.intr, estimator=est, iterations=args.iterations, nn_method=1, threads=0)
+    times = []
+    ro = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        ro = O.icp(s4, t4, p_all, trace=True)
+        times.append(time.perf_counter() - t0)
+    t_all = statistics.median(times)
+    # PCL's ICP is single-threaded: time one thread on a bounded sample (4 iterations)
+    it1 = min(4, args.iterations)
+    p_one = O.params(pair.intr, estimator=est, iterations=it1, nn_method=1, threads=1)
+    t0 = time.perf_counter()
+    O.icp(s4, t4, p_one, trace=False)
+    t_one = time.perf_counter() - t0
+    rot, tr = O.pose_error(ro["T_trace"][-1], gpu_result["T_raw"])
+    out = {
+        "value": args.iterations / t_all, "unit": "ICP iterations/s", "cores": cores, "kind": "port",
+        "sample": f"oracle/ (exact kd-tree NN + same estimator, OpenMP all cores), 1 pair seed {pair.seed} x "
+                  f"{args.iterations} iterations incl. normals+kd-tree build, median of 3",
+        "single_thread_value": it1 / t_one,
+        "single_thread_sample": f"same, 1 thread, {it1} iterations (PCL's ICP is single-threaded)",
+    }
+    parity = {
+        "rot_err_rad": rot, "trans_err_m": tr,
+        "idx_mismatches": int((gpu_idx != ro["idx"]).sum()),
+        "T_bit_identical": bool(np.array_equal(ro["T_trace"][-1], gpu_result["T_raw"])),
+    }
+    return out, parity
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from slam3d_gx_amd import capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the ICP path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    P = args.pairs
+    est = capi.EST_POINT2PLANE if args.estimator == "point2plane" else capi.EST_SVD
+    # ---- synthetic inputs, uploaded once: the timed region starts with clouds resident in HBM
+    pairs = [synth.make_pair(args.seed0 + rank * P + i, args.width, args.height) for i in range(P)]
+    intr = pairs[0].intr
+    src_host = [synth.backproject_numpy(p.depth_src, intr) for p in pairs]
+    tgt_host = [synth.backproject_numpy(p.depth_tgt, intr) for p in pairs]
+    d_src = torch.from_numpy(np.stack(src_host)).to(dev)
+    d_tgt = torch.from_numpy(np.stack(tgt_host)).to(dev)
+    params = capi.default_params(intr, estimator=est, iterations=args.iterations, max_batch=P,
+                                 device=local_rank, nn_mode=args.nn_mode)
+    h = capi.IcpHandle(params)
+    rec_bytes = 4 * args.width * args.height * 4
+    for i in range(P):
+        h.set_clouds_device(i, d_src.data_ptr() + i * rec_bytes, d_tgt.data_ptr() + i * rec_bytes)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    pose_dev = torch.zeros((P, 20), dtype=torch.float64, device=dev)
+    gathered = [torch.zeros_like(pose_dev) for _ in range(world)] if world > 1 else None
+
+    def step():
+        h.run(P, None, stream)
+        res = h.fetch_results(P)
+        if world > 1:   # RCCL all-gather of the 160-byte pose records (T, norm, inliers, status, rmse)
+            rec = np.zeros((P, 20))
+            for i, r in enumerate(res):
+                rec[i, :16] = r["T"].reshape(16); rec[i, 16] = r["norm"]; rec[i, 17] = r["inliers"]
+                rec[i, 18] = r["status"]; rec[i, 19] = r["rmse"]
+            pose_dev.copy_(torch.from_numpy(rec))
+            dist.all_gather(gathered, pose_dev)
+        return res
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    nn_ms, tot_ms, pre_ms = [], [], []
+    fence()
+    t0 = time.perf_counter()
+    res = None
+    for _ in range(args.steps):
+        res = step()
+        tm = h.get_timings()
+        nn_ms.append(tm["nn_ms"]); tot_ms.append(tm["total_ms"]); pre_ms.append(tm["preprocess_ms"])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    total_iters = world * P * args.iterations * args.steps
+    value = total_iters / elapsed
+    # ---- roofline of the dominant kernel (NN search): one launch = one iteration over P pairs
+    flops_per_launch = sum(8.0 * r["n_src"] * r["n_tgt"] for r in res)
+    launch_ms = statistics.mean(nn_ms) / max(args.iterations, 1)
+    achieved = flops_per_launch / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
+    alg_bytes = sum((12 + 4) * r["n_src"] + (12 + (12 if est == 0 else 0)) * r["n_tgt"] for r in res)
+    out = {
+        "metric": "ICP iterations/sec on 640x480 clouds" if (args.width, args.height) == (640, 480)
+                  else f"ICP iterations/sec on {args.width}x{args.height} clouds",
+        "value": value, "unit": "ICP iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": (f"BASELINE config {'2' if P == 1 else '3-style'}: {P} frame pair(s)/GPU of "
+                         f"{args.width}x{args.height}, {args.iterations} ICP iterations, {args.estimator}, "
+                         f"exact brute-force NN, seeds {args.seed0}+"),
+            "pairs_per_gpu": P, "iterations": args.iterations, "estimator": args.estimator,
+            "n_src": [r["n_src"] for r in res][:4], "n_tgt": [r["n_tgt"] for r in res][:4],
+            "parallelism": f"pairs sharded 1 process/GPU x{world}, RCCL all-gather of pose records",
+        },
+        "roofline": {
+            "kernel": "k_nn (exact brute-force 1-NN)", "bound": "mfma", "achieved": achieved,
+            "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
+            "launch_ms": launch_ms, "flops_per_launch": flops_per_launch,
+            "note": "fp32 distance contraction; peak = fp32 vector == f32-MFMA dense peak",
+            "hbm_algorithmic_bytes_per_launch": alg_bytes,
+            "hbm_achieved_GBps": alg_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0,
+        },
+        "kernel_ms_per_step": {"preprocess": statistics.mean(pre_ms), "nn": statistics.mean(nn_ms),
+                               "total": statistics.mean(tot_ms)},
+        "status": [r["status"] for r in res][:8],
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            idx, _ = h.get_correspondences(0)
+            cb, parity = cpu_baseline_leg(pairs[0], src_host[0], tgt_host[0], args, res[0], idx)
+            out["cpu_baseline"] = cb
+            out["parity_vs_oracle"] = parity
+        print(json.dumps(out))
+    h.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
