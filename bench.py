@@ -87,7 +87,7 @@ def main():
     args = parse_args()
     import torch
     import torch.distributed as dist
-    from slam3d_gx_amd import capi, synth
+    from slam3d_gx_amd import capi, shard, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -119,19 +119,13 @@ def main():
         h.set_clouds_device(i, d_src.data_ptr() + i * rec_bytes, d_tgt.data_ptr() + i * rec_bytes)
     stream = torch.cuda.current_stream().cuda_stream
 
-    pose_dev = torch.zeros((P, 20), dtype=torch.float64, device=dev)
-    gathered = [torch.zeros_like(pose_dev) for _ in range(world)] if world > 1 else None
+    table = {}
 
     def step():
         h.run(P, None, stream)
         res = h.fetch_results(P)
         if world > 1:   # RCCL all-gather of the 160-byte pose records (T, norm, inliers, status, rmse)
-            rec = np.zeros((P, 20))
-            for i, r in enumerate(res):
-                rec[i, :16] = r["T"].reshape(16); rec[i, 16] = r["norm"]; rec[i, 17] = r["inliers"]
-                rec[i, 18] = r["status"]; rec[i, 19] = r["rmse"]
-            pose_dev.copy_(torch.from_numpy(rec))
-            dist.all_gather(gathered, pose_dev)
+            table["poses"] = shard.gather_records(shard.pack_records(res), world * P, device=dev)
         return res
 
     def fence():

@@ -103,18 +103,22 @@ _BOXES = [  # (xmin, xmax, ymin, ymax, zmin, zmax) resting on the floor
 ]
 
 
-def _raycast(o: np.ndarray, d: np.ndarray) -> np.ndarray:
-    """o (3,), d (n,3) world rays -> smallest positive hit parameter t (n,)."""
+def _raycast(o: np.ndarray, d: np.ndarray, want_ids: bool = False):
+    """o (3,), d (n,3) world rays -> smallest positive hit parameter t (n,)
+    (and, with want_ids, the surface id: 0 floor, 1 left wall, 2 back wall, -1 anything else)."""
     n = d.shape[0]
     t_best = np.full(n, np.inf)
+    ids = np.full(n, -1, dtype=np.int32)
     with np.errstate(divide="ignore", invalid="ignore"):
         # floor y = FLOOR_Y
         t = (_FLOOR_Y - o[1]) / d[:, 1]
         ok = (d[:, 1] > 0) & (t > 0)
+        ids = np.where(ok & (t < t_best), 0, ids)
         t_best = np.where(ok & (t < t_best), t, t_best)
         # left wall x = LEFT_X
         t = (_LEFT_X - o[0]) / d[:, 0]
         ok = (d[:, 0] < 0) & (t > 0)
+        ids = np.where(ok & (t < t_best), 1, ids)
         t_best = np.where(ok & (t < t_best), t, t_best)
         # back wall z = BACK_Z with doorway
         t = (_BACK_Z - o[2]) / d[:, 2]
@@ -122,10 +126,12 @@ def _raycast(o: np.ndarray, d: np.ndarray) -> np.ndarray:
         hy = o[1] + t * d[:, 1]
         door = (hx > _DOOR[0]) & (hx < _DOOR[1]) & (hy > _DOOR[2]) & (hy < _DOOR[3])
         ok = (d[:, 2] > 0) & (t > 0) & ~door
+        ids = np.where(ok & (t < t_best), 2, ids)
         t_best = np.where(ok & (t < t_best), t, t_best)
         # far wall behind the doorway
         t = (_FAR_Z - o[2]) / d[:, 2]
         ok = (d[:, 2] > 0) & (t > 0)
+        ids = np.where(ok & (t < t_best), -1, ids)
         t_best = np.where(ok & (t < t_best), t, t_best)
         # boxes (slab test)
         for b in _BOXES:
@@ -136,13 +142,17 @@ def _raycast(o: np.ndarray, d: np.ndarray) -> np.ndarray:
             tn = np.minimum(t0, t1).max(axis=1)
             tf = np.maximum(t0, t1).min(axis=1)
             ok = (tn <= tf) & (tn > 0)
+            ids = np.where(ok & (tn < t_best), -1, ids)
             t_best = np.where(ok & (tn < t_best), tn, t_best)
+    if want_ids:
+        return t_best, ids
     return t_best
 
 
 def render_depth(T_cam_from_world: np.ndarray, intr: Intrinsics, seed: int, stream: int,
                  noise: bool = True, holes: bool = True, z_min: float = 0.7, z_max: float = 7.0,
-                 hole_block: int = 32, hole_prob: float = 0.2, noise_sigma: float = 0.0002) -> np.ndarray:
+                 hole_block: int = 32, hole_prob: float = 0.2, noise_sigma: float = 0.0002,
+                 want_labels: bool = False):
     """Depth image (uint16, millimetres for depth_factor 1000) seen by a camera whose pose
     maps world -> camera coordinates as X_cam = T . X_world."""
     W, H = intr.width, intr.height
@@ -153,7 +163,7 @@ def render_depth(T_cam_from_world: np.ndarray, intr: Intrinsics, seed: int, stre
     uu, vv = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
     dc = np.stack([(uu - intr.cx) / intr.fx, (vv - intr.cy) / intr.fy, np.ones_like(uu)], axis=-1).reshape(-1, 3)
     dw = np.stack([dc[:, 0] * R[0, k] + dc[:, 1] * R[1, k] + dc[:, 2] * R[2, k] for k in range(3)], axis=-1)  # R^T . dc
-    z = _raycast(o, dw)                # camera-frame z because dc_z == 1
+    z, ids = _raycast(o, dw, want_ids=True)   # camera-frame z because dc_z == 1
     if noise:
         z = z + noise_sigma * z * z * _gauss(seed, stream * 4 + 1, W * H)
     bad = ~np.isfinite(z) | (z <= z_min) | (z > z_max)
@@ -164,7 +174,10 @@ def render_depth(T_cam_from_world: np.ndarray, intr: Intrinsics, seed: int, stre
         bad |= drop
     d = np.floor(np.where(bad, 0.0, z) * intr.depth_factor + 0.5)
     d = np.where(bad, 0.0, np.clip(d, 0.0, 65535.0))
-    return d.astype(np.uint16).reshape(H, W)
+    d = d.astype(np.uint16).reshape(H, W)
+    if want_labels:   # plane labels of the valid pixels (floor / left wall / back wall), -1 elsewhere
+        return d, np.where(bad, -1, ids).astype(np.int32).reshape(H, W)
+    return d
 
 
 @dataclass

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.json from the CPU oracle (run in the authoring container).
+
+  synthetic_golden.json   oracle outputs for deterministic synthetic pairs (inputs are regenerated
+                          by slam3d_gx_amd.synth anywhere; their SHA-256 is stored)
+  reference_golden.json   DERIVED outputs only (hashes, poses, counts) of the oracle run on the
+                          reference's real fixtures data/exp1/dep/{1,2}.png and bin/dep_1.png, read from
+                          /root/reference.  No reference data or source is copied (GPLv3).
+Floats are stored as C99 hex strings (bit-exact round trip).
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O  # noqa: E402
+from slam3d_gx_amd import synth  # noqa: E402
+
+REF = "/root/reference"
+
+
+def hx(a):
+    return [float(x).hex() for x in np.asarray(a, dtype=np.float64).reshape(-1)]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def summarize(r, p):
+    valid = np.nonzero(r["idx"] >= 0)[0]
+    return dict(
+        n_src=r["n_src"], n_tgt=r["n_tgt"], inliers=r["inliers"], status=r["status"], norm=float(r["norm"]).hex(),
+        rmse=float(r["rmse"]).hex(), T_final=hx(r["T_trace"][-1]), T_iter1=hx(r["T_trace"][1]),
+        sums_first=hx(r["sums_trace"][0]), sums_last=hx(r["sums_trace"][-1]),
+        idx_sha256=sha(r["idx"]), d2_sha256=sha(r["d2"]), n_corr=int(valid.size),
+        idx_first64=[[int(i), int(r["idx"][i])] for i in valid[:64]],
+        idx_last64=[[int(i), int(r["idx"][i])] for i in valid[-64:]],
+        iterations=p.iterations, estimator=p.estimator)
+
+
+def synthetic():
+    cases = []
+    for (w, h, seeds, iters, method) in ((160, 120, (1000, 1001, 1002, 1003), 5, 0), (640, 480, (1000,), 20, 1)):
+        for seed in seeds:
+            pr = synth.make_pair(seed, w, h)
+            s4 = synth.backproject_numpy(pr.depth_src, pr.intr)
+            t4 = synth.backproject_numpy(pr.depth_tgt, pr.intr)
+            for est in (0, 1):
+                p = O.params(pr.intr, estimator=est, iterations=iters, nn_method=method)
+                r = O.icp(s4, t4, p)
+                c = dict(seed=seed, width=w, height=h, depth_sha256=pr.sha256(), T_gt=hx(pr.T_gt))
+                c.update(summarize(r, p))
+                if est == 0:
+                    c["normals_sha256"] = sha(O.normals(t4, p))
+                cases.append(c)
+                print("synthetic", w, h, seed, est, c["inliers"], c["status"])
+    json.dump(dict(generator="tests/golden/make_golden.py", cases=cases), open(os.path.join(HERE, "synthetic_golden.json"), "w"), indent=1)
+
+
+def read_png16(path):
+    from PIL import Image
+    a = np.array(Image.open(path))
+    assert a.dtype in (np.uint16, np.int32), a.dtype
+    return a.astype(np.uint16)
+
+
+def reference():
+    if not os.path.isdir(REF):
+        print("no /root/reference: skipping reference_golden.json")
+        return
+    intr = synth.Intrinsics()    # src/convert2PCD.cpp:19-23 -- the intrinsics the fixtures were made with
+    d1 = read_png16(os.path.join(REF, "data/exp1/dep/1.png"))
+    d2 = read_png16(os.path.join(REF, "data/exp1/dep/2.png"))
+    db = read_png16(os.path.join(REF, "bin/dep_1.png"))
+    out = dict(generator="tests/golden/make_golden.py", note="derived outputs only; inputs are read from /root/reference",
+               inputs={k: dict(sha256_prefix=hashlib.sha256(open(os.path.join(REF, f), "rb").read()).hexdigest()[:16],
+                               nonzero=int((d > 0).sum()))
+                       for k, f, d in (("dep1", "data/exp1/dep/1.png", d1), ("dep2", "data/exp1/dep/2.png", d2), ("bin_dep_1", "bin/dep_1.png", db))})
+    p = O.params(intr)
+    c1, c2, cb = (O.backproject(d, p) for d in (d1, d2, db))
+    out["backproject_sha256"] = dict(dep1=sha(c1), dep2=sha(c2), bin_dep_1=sha(cb))
+    # config 1 plumbing: organized normals / planarity on bin/dep_1.png (row a7)
+    nb = O.normals(cb, p)
+    out["config1_bin_dep_1"] = dict(valid_points=int(np.isfinite(cb[..., 2]).sum()), planar_pixels=int((nb[..., 3] > 0).sum()),
+                                    normals_sha256=sha(nb))
+    # wide-baseline real pair: GPU == oracle equality test only (SURVEY.md App. D caveat)
+    pairs = {}
+    for est in (0, 1):
+        pp = O.params(intr, estimator=est, iterations=10, nn_method=1)
+        r = O.icp(c1, c2, pp)
+        pairs[str(est)] = summarize(r, pp)
+        print("real pair est", est, r["inliers"], r["status"], r["norm"])
+    out["real_pair_dep1_to_dep2"] = pairs
+    json.dump(out, open(os.path.join(HERE, "reference_golden.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    synthetic()
+    reference()

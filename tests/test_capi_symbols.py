@@ -1,0 +1,63 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/slam3d_icp.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from slam3d_gx_amd import build, capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "slam3d_icp.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(slam3d_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    so = build.build_lib()
+    lib = ctypes.CDLL(so)
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/slam3d_icp.h but not exported"
+    assert sorted(capi.EXPORTED_SYMBOLS) == declared
+
+
+def test_abi_version_and_strerror_without_gpu():
+    lib = capi.load_library()
+    assert lib.slam3d_icp_abi_version() == 1
+    assert b"no gfx950" in lib.slam3d_strerror(-4)
+    assert lib.slam3d_strerror(0) == b"ok"
+
+
+def test_struct_layouts_match_header_sizes(tmp_path):
+    """Compile the public header with plain gcc (it must be valid C) and compare struct sizes/offsets
+    with the ctypes mirror used by tests and bench."""
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "slam3d_icp.h"\n'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(slam3d_icp_params), sizeof(slam3d_icp_result),'
+        ' sizeof(slam3d_cloud_view), sizeof(slam3d_plane), offsetof(slam3d_icp_params, nn_mode),'
+        ' offsetof(slam3d_icp_result, rmse), offsetof(slam3d_icp_result, T_raw));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got == [ctypes.sizeof(capi.Params), ctypes.sizeof(capi.Result), ctypes.sizeof(capi.CloudView),
+                   ctypes.sizeof(capi.Plane), capi.Params.nn_mode.offset, capi.Result.rmse.offset, capi.Result.T_raw.offset]
+
+
+def test_create_fails_loudly_without_device_or_with_bad_params():
+    import torch
+    p = capi.default_params()
+    if not torch.cuda.is_available():
+        with pytest.raises(capi.Slam3dError) as e:
+            capi.IcpHandle(p)
+        assert e.value.code == -4          # SLAM3D_E_NODEVICE: no CPU fallback
+    p.normal_window = 4
+    with pytest.raises(capi.Slam3dError) as e:
+        capi.IcpHandle(p)
+    assert e.value.code == -1

@@ -1,0 +1,99 @@
+"""Property tests of the oracle's small solvers against numpy/scipy."""
+import math
+
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+import oracle_lib as O
+
+rng = np.random.default_rng(7)
+
+
+def _sym6(M):
+    return np.array([M[0, 0], M[0, 1], M[0, 2], M[1, 1], M[1, 2], M[2, 2]])
+
+
+def test_eig3_vs_numpy_100_cases():
+    for k in range(100):
+        A = rng.normal(size=(3, 3)) * 10.0 ** rng.integers(-6, 3)
+        S = A @ A.T if k % 2 == 0 else (A + A.T)
+        ev, V = O.eig3(_sym6(S))
+        w = np.linalg.eigvalsh(S)
+        scale = max(1e-300, np.abs(w).max())
+        assert np.allclose(np.sort(ev), w, atol=1e-12 * scale)
+        assert np.allclose(V.T @ V, np.eye(3), atol=1e-12)
+        assert np.allclose(S @ V, V * ev[None, :], atol=1e-11 * scale)
+
+
+def test_eig3_degenerate_inputs():
+    ev, V = O.eig3(np.zeros(6))
+    assert np.array_equal(ev, np.zeros(3)) and np.array_equal(V, np.eye(3))
+    ev, V = O.eig3(np.array([2.0, 0, 0, 2.0, 0, 2.0]))
+    assert np.array_equal(ev, [2, 2, 2])
+    ev, V = O.eig3(np.array([1.0, 1e-300, 0, 1.0, 0, 3.0]))   # huge theta -> no NaN
+    assert np.all(np.isfinite(ev)) and np.all(np.isfinite(V))
+
+
+def test_solve6_vs_numpy_100_cases():
+    for _ in range(100):
+        J = rng.normal(size=(40, 6))
+        A = J.T @ J
+        b = rng.normal(size=6)
+        U = np.array([A[r, c] for r in range(6) for c in range(r, 6)])
+        rc, x = O.solve6(U, b)
+        assert rc == 1
+        assert np.allclose(x, np.linalg.solve(A, b), rtol=1e-9, atol=1e-12)
+
+
+def test_solve6_rank_deficient_is_damped_or_fails():
+    J = rng.normal(size=(40, 6)); J[:, 5] = J[:, 4]          # two identical columns -> singular
+    A = J.T @ J
+    U = np.array([A[r, c] for r in range(6) for c in range(r, 6)])
+    rc, x = O.solve6(U, rng.normal(size=6))
+    assert rc in (0, 2)
+    assert O.solve6(np.zeros(21), np.zeros(6))[0] == 0
+
+
+def test_svd3_rotation_vs_numpy_kabsch():
+    for k in range(100):
+        P = rng.normal(size=(50, 3))
+        ang = rng.uniform(0, math.pi)
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        Rt = np.eye(3) + math.sin(ang) * K + (1 - math.cos(ang)) * K @ K
+        if k % 3 == 0:
+            P[:, 2] = 0.0                                      # planar data: rank-2 H, reflection fix must hold
+        Q = P @ Rt.T + 0.01 * rng.normal(size=P.shape)
+        Pc, Qc = P - P.mean(0), Q - Q.mean(0)
+        H = Pc.T @ Qc
+        R = O.svd3_rotation(H)
+        U, S, Vt = np.linalg.svd(H)
+        D = np.diag([1, 1, np.sign(np.linalg.det(Vt.T @ U.T))])
+        Rn = Vt.T @ D @ U.T
+        assert abs(np.linalg.det(R) - 1) < 1e-12
+        assert np.allclose(R, Rn, atol=1e-9)
+
+
+def test_svd3_rank_deficient_returns_identity():
+    assert np.array_equal(O.svd3_rotation(np.zeros(9)), np.eye(3))
+    H = np.outer([1.0, 2, 3], [3.0, 2, 1])                     # rank 1
+    assert np.array_equal(O.svd3_rotation(H), np.eye(3))
+
+
+@settings(max_examples=200, deadline=None)
+@given(st.floats(min_value=-50.0, max_value=50.0, allow_nan=False))
+def test_spec_sincos_matches_libm(x):
+    s, c = O.sincos(x)
+    assert abs(s - math.sin(x)) < 2e-15 and abs(c - math.cos(x)) < 2e-15
+
+
+def test_pose_error_metric():
+    T = np.eye(4); T[:3, 3] = [0.3, 0.0, 0.4]
+    r, t = O.pose_error(np.eye(4), T)
+    assert abs(t - 0.5) < 1e-15 and r == 0.0
+    a = 0.3
+    T = np.eye(4); T[:2, :2] = [[math.cos(a), -math.sin(a)], [math.sin(a), math.cos(a)]]
+    r, t = O.pose_error(np.eye(4), T)
+    assert abs(r - a) < 1e-12 and t == 0.0
+    r, t = O.pose_error(T, T)
+    assert r < 1e-7 and t == 0.0
