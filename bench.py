@@ -183,6 +183,7 @@ def main():
         "kernel_ms_per_step": {"preprocess": statistics.mean(pre_ms), "nn": statistics.mean(nn_ms),
                                "total": statistics.mean(tot_ms)},
         "status": [r["status"] for r in res][:8],
+        "nn_ms_per_iteration": [round(float(x), 4) for x in h.get_iteration_timings()],
     }
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:

@@ -45,8 +45,12 @@ enum {
 };
 
 enum { SLAM3D_EST_POINT2PLANE = 0, SLAM3D_EST_SVD = 1 };
-/* NN search variants: all return bit-identical correspondences */
-enum { SLAM3D_NN_AUTO = 0, SLAM3D_NN_BRUTE_VALU = 1, SLAM3D_NN_BRUTE_MFMA = 2 };
+/* NN search variants: all return bit-identical correspondences.
+ *   BRUTE_VALU  every source x every target, LDS-tiled, fp32 VALU
+ *   BRUTE_MFMA  same scan, distance contraction on the f32 MFMA pipe as a conservative filter
+ *   TILES       exact search restricted to the 8x8-pixel target tiles whose bounding box can hold
+ *               a winner (AABB culling against a per-query upper bound); AUTO selects this */
+enum { SLAM3D_NN_AUTO = 0, SLAM3D_NN_BRUTE_VALU = 1, SLAM3D_NN_BRUTE_MFMA = 2, SLAM3D_NN_TILES = 3 };
 
 typedef struct slam3d_icp_params {
     int32_t width, height;          /* organized cloud size (640x480 Kinect)                         */
@@ -147,6 +151,8 @@ int slam3d_icp_get_clouds(slam3d_icp_handle *h, int32_t slot, float *src_xyz4, f
                           float *tgt_nrm4);
 /* kernel time of the last run, by bucket (ms): [0] preprocess [1] nn [2] accumulate+solve [3] total */
 int slam3d_icp_get_timings(slam3d_icp_handle *h, float ms[4]);
+/* duration of each iteration's NN launch of the last run (ms), nn_ms[iterations] */
+int slam3d_icp_get_iteration_timings(slam3d_icp_handle *h, float *nn_ms);
 
 /* ---- building blocks (rows a5, a6 of the scope table) ------------------------------------ */
 /* u16 depth (host) -> organized float4 cloud (host); src/convert2PCD.cpp:54-72 */

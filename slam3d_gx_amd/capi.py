@@ -15,7 +15,7 @@ from . import build as _build
 
 NSUMS = 29
 EST_POINT2PLANE, EST_SVD = 0, 1
-NN_AUTO, NN_BRUTE_VALU, NN_BRUTE_MFMA = 0, 1, 2
+NN_AUTO, NN_BRUTE_VALU, NN_BRUTE_MFMA, NN_TILES = 0, 1, 2, 3
 
 EXPORTED_SYMBOLS = [
     "slam3d_icp_default_params", "slam3d_icp_create", "slam3d_icp_destroy", "slam3d_strerror",
@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "slam3d_icp_align_depth_batch", "slam3d_icp_set_clouds_host", "slam3d_icp_set_depth_host",
     "slam3d_icp_set_clouds_device", "slam3d_icp_set_depth_device", "slam3d_icp_run",
     "slam3d_icp_fetch_results", "slam3d_icp_get_correspondences", "slam3d_icp_get_trace",
-    "slam3d_icp_get_clouds", "slam3d_icp_get_timings", "slam3d_backproject_u16", "slam3d_fit_planes",
+    "slam3d_icp_get_clouds", "slam3d_icp_get_timings", "slam3d_icp_get_iteration_timings", "slam3d_backproject_u16", "slam3d_fit_planes",
     "slam3d_icp_dense_set_rows", "slam3d_icp_dense_begin", "slam3d_icp_dense_partial",
     "slam3d_icp_dense_update", "slam3d_icp_dense_finish",
 ]
@@ -232,6 +232,11 @@ class IcpHandle:
         ms = (C.c_float * 4)()
         self._check(self.lib.slam3d_icp_get_timings(self._h, ms), False)
         return dict(preprocess_ms=ms[0], nn_ms=ms[1], accumulate_solve_ms=ms[2], total_ms=ms[3])
+
+    def get_iteration_timings(self) -> np.ndarray:
+        ms = np.zeros(max(self.params.iterations, 1), dtype=np.float32)
+        self._check(self.lib.slam3d_icp_get_iteration_timings(self._h, _vp(ms)), False)
+        return ms[: self.params.iterations]
 
     # ---- building blocks ---------------------------------------------------------------
     def backproject_u16(self, depth: np.ndarray) -> np.ndarray:

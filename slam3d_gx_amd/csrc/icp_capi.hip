@@ -32,6 +32,10 @@ struct slam3d_icp_handle {
     uint16_t *d_depth = nullptr;
     int *d_idx = nullptr; float *d_d2 = nullptr;
     float4 *d_scratch4 = nullptr;
+    // tile-pruned NN (8x8-pixel tiles)
+    TileGrid tg;
+    int *pos_src = nullptr, *pos_tgt = nullptr;
+    float4 *srcT = nullptr, *tgtT = nullptr, *tbox = nullptr, *cbox = nullptr;
     // host
     std::vector<SlotPtrs> h_slots;
     SlotPtrs *pin_slots = nullptr;
@@ -98,6 +102,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->own_src); F(h->own_tgt); F(h->nrm); F(h->src_c); F(h->tgt_c); F(h->tgt_cn); F(h->counts); F(h->corr);
     F(h->flags); F(h->best); F(h->cd2); F(h->partials); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
     F(h->d_Tinit); F(h->d_slots); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4);
+    F(h->pos_src); F(h->pos_tgt); F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox);
     if (h->pin_slots) (void)hipHostFree(h->pin_slots);
     if (h->pin_T) (void)hipHostFree(h->pin_T);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -124,6 +129,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     if (p->width <= 0 || p->height <= 0 || p->max_batch <= 0 || p->iterations < 0) return SLAM3D_E_INVALID;
     if (p->normal_window < 1 || (p->normal_window & 1) == 0 || p->normal_window / 2 > NRM_RMAX) return SLAM3D_E_INVALID;
     if (p->estimator != SLAM3D_EST_POINT2PLANE && p->estimator != SLAM3D_EST_SVD) return SLAM3D_E_INVALID;
+    if (p->nn_mode < SLAM3D_NN_AUTO || p->nn_mode > SLAM3D_NN_TILES) return SLAM3D_E_INVALID;
     if (!(p->max_corr_dist > 0.0) || !(p->z_filter > 0.0)) return SLAM3D_E_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device < 0 || p->device >= ndev) return SLAM3D_E_NODEVICE;
@@ -141,6 +147,11 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     g.estimator = p->estimator;
     g.fx = p->fx; g.fy = p->fy; g.cx = p->cx; g.cy = p->cy; g.factor = p->depth_factor; g.zf = p->z_filter;
     h->row0 = 0; h->row1 = p->height;
+    TileGrid &tg = h->tg;
+    tg.ntx = (p->width + TILE_PX - 1) / TILE_PX; tg.nty = (p->height + TILE_PX - 1) / TILE_PX;
+    tg.ntiles = tg.ntx * tg.nty;
+    tg.ncx = (tg.ntx + COARSE_TILES - 1) / COARSE_TILES; tg.ncy = (tg.nty + COARSE_TILES - 1) / COARSE_TILES;
+    tg.ncoarse = tg.ncx * tg.ncy;
     const size_t BN = (size_t)h->maxB * h->N;
     const int iters = p->iterations > 0 ? p->iterations : 1;
     hipError_t e = hipSuccess;
@@ -156,6 +167,9 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     A(dalloc(h->d_Tinit, (size_t)h->maxB * 16)); A(dalloc(h->d_slots, (size_t)h->maxB));
     A(dalloc(h->d_depth, (size_t)2 * h->N)); A(dalloc(h->d_idx, (size_t)h->N)); A(dalloc(h->d_d2, (size_t)h->N));
     A(dalloc(h->d_scratch4, (size_t)h->N));
+    A(dalloc(h->pos_src, BN)); A(dalloc(h->pos_tgt, BN));
+    A(dalloc(h->srcT, (size_t)h->maxB * tg.ntiles * TILE_SLOTS)); A(dalloc(h->tgtT, (size_t)h->maxB * tg.ntiles * TILE_SLOTS));
+    A(dalloc(h->tbox, (size_t)h->maxB * tg.ntiles * 2)); A(dalloc(h->cbox, (size_t)h->maxB * tg.ncoarse * 2));
     A(hipHostMalloc((void **)&h->pin_slots, sizeof(SlotPtrs) * h->maxB, hipHostMallocDefault));
     A(hipHostMalloc((void **)&h->pin_T, sizeof(double) * 16 * h->maxB, hipHostMallocDefault));
     A(hipHostMalloc((void **)&h->pin_out, sizeof(double) * (16 + NSUMS) * h->maxB, hipHostMallocDefault));
@@ -257,6 +271,11 @@ extern "C" int slam3d_icp_set_depth_device(slam3d_icp_handle *h, int32_t slot, c
 }
 
 // ------------------------------------------------------------------------------ run
+static inline int nn_mode_of(const slam3d_icp_handle *h)
+{
+    return h->p.nn_mode == SLAM3D_NN_AUTO ? SLAM3D_NN_TILES : h->p.nn_mode;
+}
+
 static int pick_nsplit(const slam3d_icp_handle *h, int B)
 {
     // enough workgroups for 256 CUs: aim at >= ~2048 blocks (query blocks are sized for ~75 % valid)
@@ -288,7 +307,13 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         hipLaunchKernelGGL(k_normals, grid, dim3(NRM_BX, NRM_BY), 0, s, h->d_slots, h->nrm, g);
     }
     hipLaunchKernelGGL(k_compact, dim3(2, B), dim3(1024), 0, s, h->d_slots, h->nrm, h->src_c, h->tgt_c, h->tgt_cn,
-                       h->counts, g, use_normals, h->row0, h->row1);
+                       h->counts, h->pos_src, h->pos_tgt, g, use_normals, h->row0, h->row1);
+    HIPCHK(h, hipMemsetAsync(h->corr, 0xFF, sizeof(int) * (size_t)B * h->N, s));   // no previous match yet
+    if (nn_mode_of(h) == SLAM3D_NN_TILES) {
+        hipLaunchKernelGGL(k_build_tiles, dim3(h->tg.ntiles, 2, B), dim3(64), 0, s, h->d_slots, h->pos_src, h->pos_tgt,
+                           h->srcT, h->tgtT, h->tbox, g, h->tg);
+        hipLaunchKernelGGL(k_coarse_boxes, dim3(h->tg.ncoarse, B), dim3(64), 0, s, h->tbox, h->cbox, h->tg);
+    }
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
     hipLaunchKernelGGL(k_init_T, dim3((B + 63) / 64), dim3(64), 0, s, dT, h->Tcur, h->trace_T, h->flags, B, iters);
     HIPCHK(h, hipGetLastError());
@@ -300,8 +325,12 @@ static int enqueue_nn_accumulate(slam3d_icp_handle *h, int B, hipStream_t s, hip
     const int nsplit = pick_nsplit(h, B);
     const int qblocks = (h->N + NN_BLOCK * NN_QPT - 1) / (NN_BLOCK * NN_QPT);
     if (e0) HIPCHK(h, hipEventRecord(e0, s));
-    hipLaunchKernelGGL(k_nn_valu, dim3(qblocks, nsplit, B), dim3(NN_BLOCK), 0, s, h->src_c, h->tgt_c, h->counts, h->Tcur,
-                       h->best, h->N, nsplit);
+    if (nn_mode_of(h) == SLAM3D_NN_TILES)
+        hipLaunchKernelGGL(k_nn_tiles, dim3((h->tg.ntiles + NNT_WAVES - 1) / NNT_WAVES, B), dim3(64 * NNT_WAVES), 0, s,
+                           h->srcT, h->tgtT, h->tbox, h->cbox, h->tgt_c, h->pos_tgt, h->corr, h->Tcur, h->best, h->g, h->tg);
+    else
+        hipLaunchKernelGGL(k_nn_valu, dim3(qblocks, nsplit, B), dim3(NN_BLOCK), 0, s, h->src_c, h->tgt_c, h->counts, h->Tcur,
+                           h->best, h->N, nsplit);
     if (e1) HIPCHK(h, hipEventRecord(e1, s));
     hipLaunchKernelGGL(k_accumulate, dim3(h->max_chunks, B), dim3(CHUNK), 0, s, h->src_c, h->tgt_c, h->tgt_cn, h->counts,
                        h->Tcur, h->best, h->corr, h->cd2, h->partials, h->N, h->max_chunks, h->g.gate2, h->p.estimator);
@@ -496,6 +525,17 @@ extern "C" int slam3d_icp_get_timings(slam3d_icp_handle *h, float ms[4])
         nn += t;
     }
     ms[0] = pre; ms[1] = nn; ms[2] = tot - pre - nn; ms[3] = tot;
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_get_iteration_timings(slam3d_icp_handle *h, float *nn_ms)
+{
+    if (!h || !nn_ms) return SLAM3D_E_INVALID;
+    if (!h->ran) return SLAM3D_E_STATE;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    HIPCHK(h, hipEventSynchronize(h->ev[2]));
+    for (int it = 0; it < h->p.iterations; ++it)
+        HIPCHK(h, hipEventElapsedTime(&nn_ms[it], h->ev[3 + 2 * it], h->ev[4 + 2 * it]));
     return SLAM3D_OK;
 }
 

@@ -193,10 +193,15 @@ __global__ __launch_bounds__(1024) void k_compact(const SlotPtrs *__restrict__ s
                                                   const float4 *__restrict__ nrm_all,
                                                   float4 *__restrict__ src_c, float4 *__restrict__ tgt_c,
                                                   float4 *__restrict__ tgt_cn, int *__restrict__ counts,
+                                                  int *__restrict__ pos_src, int *__restrict__ pos_tgt,
                                                   Geometry g, int use_normals, int row0, int row1)
 {
     __shared__ int wave_tot[16];
     const int which = blockIdx.x, b = blockIdx.y;
+    int *__restrict__ posmap = (which == 0 ? pos_src : pos_tgt) + (size_t)b * g.N;
+    if (which == 0)   // rows outside the (dense-mode) source range hold no source point
+        for (int i = threadIdx.x; i < g.N; i += 1024)
+            if (i < row0 * g.W || i >= row1 * g.W) posmap[i] = -1;
     const float4 *__restrict__ cloud = which == 0 ? slots[b].src : slots[b].tgt;
     const float4 *__restrict__ nrm = nrm_all + (size_t)b * g.N;
     float4 *__restrict__ outp = (which == 0 ? src_c : tgt_c) + (size_t)b * g.N;
@@ -225,6 +230,9 @@ __global__ __launch_bounds__(1024) void k_compact(const SlotPtrs *__restrict__ s
             const int pos = base + woff + prefix;
             outp[pos] = make_float4(q.x, q.y, q.z, __int_as_float(i));
             if (which == 1 && use_normals) outn[pos] = make_float4(nn.x, nn.y, nn.z, 0.0f);
+            posmap[i] = pos;
+        } else if (i < i_end) {
+            posmap[i] = -1;
         }
         base += total;
         __syncthreads();
@@ -323,6 +331,211 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_valu(const float4 *__restrict__
             atomicMin(best + (size_t)b * N + i, key);
         }
     }
+}
+
+// ------------------------------------------------------------------ S4, tile-pruned exact NN
+// Both organized clouds are cut into 8x8-pixel tiles (one wavefront = one tile = 64 slots).  A tile
+// of an organized depth image is a small 3-D patch, so its axis-aligned bounding box (AABB, taken
+// from the DATA, no camera model assumed) is tight.  For a source tile the wave knows an upper bound
+// U_i >= d2(i, NN(i)) for every query (distance to the previous iteration's match, else to the target
+// at the same pixel, else the max_corr_dist gate), hence every candidate that can win or tie lies in
+// a target tile whose AABB is within sqrt(max U) of the queries' AABB.  Only those tiles are scanned
+// -- exhaustively, with the canonical distance and the (d2, j) lexicographic minimum -- so the result
+// is bit-identical to the full brute-force scan.  Two-level culling: 64x64-pixel coarse boxes, then
+// their 8x8 child tiles; survivors are found with ballots, candidates are wave-uniform (scalar loads).
+constexpr int TILE_PX = 8;                 // tile edge in pixels
+constexpr int TILE_SLOTS = 64;             // = one wavefront
+constexpr int COARSE_TILES = 8;            // coarse box edge in tiles (64 px)
+
+struct TileGrid { int ntx, nty, ntiles, ncx, ncy, ncoarse; };
+
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// grid (ntiles, 2, B), block 64.  Slot w = raster-compact index (int bits), -1 = empty.
+// Target tiles are compacted inside the tile (valid slots first) and get an AABB:
+// box[2*t] = (minx, miny, minz, count), box[2*t+1] = (maxx, maxy, maxz, 0).
+__global__ __launch_bounds__(64) void k_build_tiles(const SlotPtrs *__restrict__ slots,
+                                                    const int *__restrict__ pos_src, const int *__restrict__ pos_tgt,
+                                                    float4 *__restrict__ srcT, float4 *__restrict__ tgtT,
+                                                    float4 *__restrict__ tbox, Geometry g, TileGrid tg)
+{
+    const int t = blockIdx.x, which = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    const int tx = t % tg.ntx, ty = t / tg.ntx;
+    const int u = tx * TILE_PX + (lane & 7), v = ty * TILE_PX + (lane >> 3);
+    const float inf = __int_as_float(0x7f800000);
+    float4 q = make_float4(inf, inf, inf, __int_as_float(-1));
+    bool ok = false;
+    if (u < g.W && v < g.H) {
+        const int pix = v * g.W + u;
+        const int pos = (which == 0 ? pos_src : pos_tgt)[(size_t)b * g.N + pix];
+        if (pos >= 0) {
+            const float4 c = (which == 0 ? slots[b].src : slots[b].tgt)[pix];
+            q = make_float4(c.x, c.y, c.z, __int_as_float(pos));
+            ok = true;
+        }
+    }
+    const size_t base = ((size_t)b * tg.ntiles + t) * TILE_SLOTS;
+    if (which == 0) { srcT[base + lane] = q; return; }
+    const unsigned long long m = __ballot(ok);
+    const int cnt = __popcll(m);
+    const int slot = ok ? __popcll(m & ((1ull << lane) - 1ull)) : cnt + __popcll(~m & ((1ull << lane) - 1ull));
+    tgtT[base + slot] = q;
+    const float mnx = wave_min(ok ? q.x : inf), mny = wave_min(ok ? q.y : inf), mnz = wave_min(ok ? q.z : inf);
+    const float mxx = wave_max(ok ? q.x : -inf), mxy = wave_max(ok ? q.y : -inf), mxz = wave_max(ok ? q.z : -inf);
+    if (lane == 0) {
+        tbox[((size_t)b * tg.ntiles + t) * 2] = make_float4(mnx, mny, mnz, __int_as_float(cnt));
+        tbox[((size_t)b * tg.ntiles + t) * 2 + 1] = make_float4(mxx, mxy, mxz, 0.0f);
+    }
+}
+
+// grid (ncoarse, B), block 64: AABB of the 8x8 child tiles
+__global__ __launch_bounds__(64) void k_coarse_boxes(const float4 *__restrict__ tbox, float4 *__restrict__ cbox, TileGrid tg)
+{
+    const int c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int tx = (c % tg.ncx) * COARSE_TILES + (lane & 7), ty = (c / tg.ncx) * COARSE_TILES + (lane >> 3);
+    const float inf = __int_as_float(0x7f800000);
+    float4 lo = make_float4(inf, inf, inf, 0.0f), hi = make_float4(-inf, -inf, -inf, 0.0f);
+    if (tx < tg.ntx && ty < tg.nty) {
+        const size_t t = (size_t)b * tg.ntiles + (size_t)ty * tg.ntx + tx;
+        lo = tbox[t * 2]; hi = tbox[t * 2 + 1];
+    }
+    const float mnx = wave_min(lo.x), mny = wave_min(lo.y), mnz = wave_min(lo.z);
+    const float mxx = wave_max(hi.x), mxy = wave_max(hi.y), mxz = wave_max(hi.z);
+    if (lane == 0) {
+        cbox[((size_t)b * tg.ncoarse + c) * 2] = make_float4(mnx, mny, mnz, 0.0f);
+        cbox[((size_t)b * tg.ncoarse + c) * 2 + 1] = make_float4(mxx, mxy, mxz, 0.0f);
+    }
+}
+
+__device__ __forceinline__ float box_gap2(const float4 lo, const float4 hi, float qminx, float qminy, float qminz,
+                                          float qmaxx, float qmaxy, float qmaxz)
+{
+    const float gx = fmaxf(0.0f, fmaxf(lo.x - qmaxx, qminx - hi.x));
+    const float gy = fmaxf(0.0f, fmaxf(lo.y - qmaxy, qminy - hi.y));
+    const float gz = fmaxf(0.0f, fmaxf(lo.z - qmaxz, qminz - hi.z));
+    return gx * gx + gy * gy + gz * gz;      // empty boxes (lo=+inf, hi=-inf) give +inf
+}
+
+constexpr int NNT_WAVES = 4;
+
+// grid (ceil(ntiles/4), B), block 256 = 4 independent waves, one source tile each.
+__global__ __launch_bounds__(64 * NNT_WAVES) void k_nn_tiles(const float4 *__restrict__ srcT,
+                                                             const float4 *__restrict__ tgtT,
+                                                             const float4 *__restrict__ tbox,
+                                                             const float4 *__restrict__ cbox,
+                                                             const float4 *__restrict__ tgt_c,
+                                                             const int *__restrict__ pos_tgt,
+                                                             const int *__restrict__ corr,
+                                                             const double *__restrict__ Tcur,
+                                                             unsigned long long *__restrict__ best,
+                                                             Geometry g, TileGrid tg)
+{
+    const int lane = threadIdx.x & 63;
+    const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * NNT_WAVES + (threadIdx.x >> 6));
+    const int b = blockIdx.y;
+    if (t >= tg.ntiles) return;
+    const int N = g.N;
+    const float inf = __int_as_float(0x7f800000);
+    const float4 s = srcT[((size_t)b * tg.ntiles + t) * TILE_SLOTS + lane];
+    const int i = __float_as_int(s.w);
+    const bool valid = i >= 0;
+    if (__ballot(valid) == 0ull) return;
+    const Rt m = load_rt(Tcur + b * 16);
+    float px, py, pz;
+    xform(m, s.x, s.y, s.z, px, py, pz);
+    // ---- upper bound: previous match, else the target at the same pixel, else the gate
+    int jg = -1;
+    if (valid) {
+        jg = corr[(size_t)b * N + i];
+        if (jg < 0) {
+            const int u = (t % tg.ntx) * TILE_PX + (lane & 7), v = (t / tg.ntx) * TILE_PX + (lane >> 3);
+            jg = pos_tgt[(size_t)b * N + v * g.W + u];
+        }
+    }
+    float bd = g.gate2;
+    unsigned int bj = 0xffffffffu;
+    if (jg >= 0) {
+        const float4 q = tgt_c[(size_t)b * N + jg];
+        const float d2g = canon_d2(px, py, pz, q.x, q.y, q.z);
+        if (d2g <= g.gate2) { bd = d2g; bj = (unsigned int)jg; }
+    }
+    unsigned long long bkey = ((unsigned long long)(unsigned int)__float_as_int(bd) << 32) | bj;
+    const float4 *__restrict__ TB = tbox + (size_t)b * tg.ntiles * 2;
+    const float4 *__restrict__ CB = cbox + (size_t)b * tg.ncoarse * 2;
+    const float4 *__restrict__ TT = tgtT + (size_t)b * tg.ntiles * TILE_SLOTS;
+    // scan one target tile (wave-uniform tt) if some lane can still improve/tie inside its box
+    auto scan_tile = [&](int tt) {
+        const float4 lo = TB[2 * tt], hi = TB[2 * tt + 1];              // uniform -> scalar loads
+        const float cur = __int_as_float((int)(unsigned int)(bkey >> 32));
+        const float gx = fmaxf(0.0f, fmaxf(lo.x - px, px - hi.x));
+        const float gy = fmaxf(0.0f, fmaxf(lo.y - py, py - hi.y));
+        const float gz = fmaxf(0.0f, fmaxf(lo.z - pz, pz - hi.z));
+        const bool need = valid && (gx * gx + gy * gy + gz * gz) <= cur * 1.00001f + 1e-30f;
+        if (__ballot(need) == 0ull) return;
+        const int cnt = __builtin_amdgcn_readfirstlane(__float_as_int(lo.w));
+        const float4 *__restrict__ cand = TT + (size_t)tt * TILE_SLOTS;
+#pragma unroll 4
+        for (int k = 0; k < cnt; ++k) {
+            const float4 q = cand[k];                                   // wave-uniform address
+            const float d2 = canon_d2(px, py, pz, q.x, q.y, q.z);
+            const unsigned long long key =
+                ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(q.w);
+            bkey = key < bkey ? key : bkey;
+        }
+    };
+    // ---- phase A: the 3x3 tiles around the same image location first (centre, then ring): this is
+    // where the neighbours are for frame-to-frame motion, so the bounds shrink before the wide search
+    const int tx0 = t % tg.ntx, ty0 = t / tg.ntx;
+    {
+        const int ox[9] = { 0, -1, 1, 0, 0, -1, 1, -1, 1 }, oy[9] = { 0, 0, 0, -1, 1, -1, -1, 1, 1 };
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const int tx = tx0 + ox[k], ty = ty0 + oy[k];
+            if (tx >= 0 && tx < tg.ntx && ty >= 0 && ty < tg.nty) scan_tile(ty * tg.ntx + tx);
+        }
+    }
+    // ---- phase B: every other tile whose box is within reach of the (shrunken) bounds
+    const float qminx = wave_min(valid ? px : inf), qminy = wave_min(valid ? py : inf), qminz = wave_min(valid ? pz : inf);
+    const float qmaxx = wave_max(valid ? px : -inf), qmaxy = wave_max(valid ? py : -inf), qmaxz = wave_max(valid ? pz : -inf);
+    for (int c0 = 0; c0 < tg.ncoarse; c0 += 64) {
+        float umax = wave_max(valid ? __int_as_float((int)(unsigned int)(bkey >> 32)) : 0.0f);
+        float thr = umax * 1.00001f + 1e-30f;        // covers the rounding of box_gap2 and of canon_d2
+        const int c = c0 + lane;
+        bool hit = false;
+        if (c < tg.ncoarse) hit = box_gap2(CB[2 * c], CB[2 * c + 1], qminx, qminy, qminz, qmaxx, qmaxy, qmaxz) <= thr;
+        unsigned long long cm = __ballot(hit);
+        while (cm) {
+            const int cc = c0 + __builtin_ctzll(cm);
+            cm &= cm - 1;
+            const int ctx = (cc % tg.ncx) * COARSE_TILES, cty = (cc / tg.ncx) * COARSE_TILES;
+            const int tx = ctx + (lane & 7), ty = cty + (lane >> 3);
+            umax = wave_max(valid ? __int_as_float((int)(unsigned int)(bkey >> 32)) : 0.0f);
+            thr = umax * 1.00001f + 1e-30f;
+            bool hit2 = false;
+            if (tx < tg.ntx && ty < tg.nty && !(abs(tx - tx0) <= 1 && abs(ty - ty0) <= 1)) {
+                const int tt = ty * tg.ntx + tx;
+                hit2 = box_gap2(TB[2 * tt], TB[2 * tt + 1], qminx, qminy, qminz, qmaxx, qmaxy, qmaxz) <= thr;
+            }
+            unsigned long long tm = __ballot(hit2);
+            while (tm) {
+                const int k2 = __builtin_ctzll(tm);
+                tm &= tm - 1;
+                scan_tile((cty + (k2 >> 3)) * tg.ntx + ctx + (k2 & 7));
+            }
+        }
+    }
+    if (valid) best[(size_t)b * N + i] = bkey;
 }
 
 // rows of the normal equations for compact source i matched to compact target j (spec S4)

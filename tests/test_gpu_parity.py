@@ -144,3 +144,33 @@ def test_T_init_and_roundtrip_property(gpu_lib):
     assert rot < 2e-3 and tr < 5e-3
     rot, tr = O.pose_error(r_ab["T_raw"], r_warm["T_raw"])
     assert rot < 1e-4 and tr < 1e-4
+
+
+@pytest.mark.parametrize("nn_mode", [capi.NN_BRUTE_VALU, capi.NN_TILES])
+@pytest.mark.parametrize("estimator", [0, 1])
+def test_every_nn_mode_is_bit_identical(gpu_lib, nn_mode, estimator):
+    """All NN variants (full brute force, tile-pruned) must return the same indices / d2 / poses as the
+    brute-force oracle, including with a poor initial guess (large culling radius) and max_corr_dist gates."""
+    pr, s4, t4 = _pair(1002, 320, 240)
+    for max_corr, T0 in ((0.10, None), (0.03, None), (0.25, synth.pose_from_seed(77, 6.0, 0.10))):
+        po = O.params(pr.intr, estimator=estimator, iterations=4, nn_method=0, max_corr_dist=max_corr)
+        ro = O.icp(s4, t4, po, T_init=T0)
+        pg = capi.default_params(pr.intr, estimator=estimator, iterations=4, nn_mode=nn_mode, max_corr_dist=max_corr)
+        with capi.IcpHandle(pg) as h:
+            rg = h.align(s4, t4, T_init=T0)
+            idx, d2 = h.get_correspondences(0)
+            Tt, St = h.get_trace(0)
+        assert np.array_equal(idx, ro["idx"]), f"mode {nn_mode} gate {max_corr}: {(idx != ro['idx']).sum()} mismatches"
+        assert np.array_equal(d2, ro["d2"])
+        assert np.array_equal(St, ro["sums_trace"]) and np.array_equal(Tt, ro["T_trace"])
+
+
+def test_odd_image_size_not_multiple_of_tile(gpu_lib):
+    """Ragged tiles: width/height not multiples of 8 (tile) or 64 (coarse box)."""
+    pr, s4, t4 = _pair(1001, 200, 150)
+    ro = O.icp(s4, t4, O.params(pr.intr, iterations=3, nn_method=0))
+    with capi.IcpHandle(capi.default_params(pr.intr, iterations=3)) as h:
+        h.align(s4, t4)
+        idx, d2 = h.get_correspondences(0)
+        Tt, _ = h.get_trace(0)
+    assert np.array_equal(idx, ro["idx"]) and np.array_equal(Tt, ro["T_trace"])
