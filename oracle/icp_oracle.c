@@ -521,13 +521,25 @@ static void tree256(double (*v)[ORC_NSUMS])   /* v[256][29] -> v[0] */
             for (int k = 0; k < ORC_NSUMS; ++k) v[i][k] += v[i + s][k];
 }
 
+/* Summation order (spec S4): sources are enumerated by SLOT, tile-major over 8x8-pixel tiles
+ * (tile t = ty*ntx + tx, slot = t*64 + (v%8)*8 + (u%8); the image is padded to whole tiles and
+ * the tile count to whole chunks).  A slot without a valid source point or without a gated
+ * correspondence contributes zeros.  Chunks of 256 slots (= 4 consecutive tiles) are reduced by
+ * tree256, groups of 256 chunk results again by tree256, group results summed in order. */
+#define ORC_TILE 8
 static void accumulate(const clist *src, const clist *tgt, const double *T, int estimator,
-                       const int *corr, int nt, double *total /*29*/)
+                       const int *corr, int W, int H, int nt, double *total /*29*/)
 {
     float Rf[9], tf[3];
     transform_f(T, Rf, tf);
-    const int nchunks = (src->n + ORC_CHUNK - 1) / ORC_CHUNK;
+    const int ntx = (W + ORC_TILE - 1) / ORC_TILE, nty = (H + ORC_TILE - 1) / ORC_TILE;
+    const int ntiles = ntx * nty;
+    const int nchunks = (ntiles * 64 + ORC_CHUNK - 1) / ORC_CHUNK;
     const int ngroups = (nchunks + ORC_CHUNK - 1) / ORC_CHUNK;
+    /* pixel -> compact source index */
+    int *cidx = malloc(sizeof(int) * (size_t)(W * H));
+    for (int i = 0; i < W * H; ++i) cidx[i] = -1;
+    for (int i = 0; i < src->n; ++i) cidx[src->orig[i]] = i;
     double (*P1)[ORC_NSUMS] = calloc((size_t)(ngroups * ORC_CHUNK + 1), sizeof(*P1));
     (void)nt;
 #pragma omp parallel num_threads(nt)
@@ -536,8 +548,14 @@ static void accumulate(const clist *src, const clist *tgt, const double *T, int 
 #pragma omp for schedule(static)
         for (int c = 0; c < nchunks; ++c) {
             for (int l = 0; l < ORC_CHUNK; ++l) {
-                const int i = c * ORC_CHUNK + l;
-                if (i < src->n) row_sums(src, tgt, Rf, tf, estimator, i, corr[i], v[l]);
+                const int slot = c * ORC_CHUNK + l;
+                const int t = slot / 64, ln = slot % 64;
+                int i = -1;
+                if (t < ntiles) {
+                    const int u = (t % ntx) * ORC_TILE + (ln & 7), vv = (t / ntx) * ORC_TILE + (ln >> 3);
+                    if (u < W && vv < H) i = cidx[vv * W + u];
+                }
+                if (i >= 0) row_sums(src, tgt, Rf, tf, estimator, i, corr[i], v[l]);
                 else for (int k = 0; k < ORC_NSUMS; ++k) v[l][k] = 0.0;
             }
             tree256(v);
@@ -551,7 +569,7 @@ static void accumulate(const clist *src, const clist *tgt, const double *T, int 
         if (g == 0) memcpy(total, P1[0], sizeof(double) * ORC_NSUMS);
         else for (int k = 0; k < ORC_NSUMS; ++k) total[k] += P1[(size_t)g * ORC_CHUNK][k];
     }
-    free(P1);
+    free(P1); free(cidx);
 }
 
 /* ------------------------------------------------------------- S5 update */
@@ -652,7 +670,7 @@ int orc_icp(const float *src4, const float *tgt4, const orc_params *p, const dou
     if (T_trace) memcpy(T_trace, T, sizeof(T));
     for (int it = 0; it < p->iterations; ++it) {
         nn_pass(&src, &tgt, &kd, T, g2, p->nn_method, nt, corr, d2c);
-        accumulate(&src, &tgt, T, p->estimator, corr, nt, sums);
+        accumulate(&src, &tgt, T, p->estimator, corr, p->width, p->height, nt, sums);
         have_sums = 1;
         if (sums_trace) memcpy(sums_trace + (size_t)it * ORC_NSUMS, sums, sizeof(sums));
         const int rc = solve_update(sums, p->estimator, T);

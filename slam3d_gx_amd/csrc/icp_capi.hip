@@ -18,12 +18,12 @@ using namespace s3d;
 struct slam3d_icp_handle {
     slam3d_icp_params p;
     Geometry g;
-    int N = 0, maxB = 0, max_chunks = 0;
+    int N = 0, maxB = 0;
     hipStream_t stream = nullptr;
     hipStream_t run_stream = nullptr;
     // device buffers
-    float4 *own_src = nullptr, *own_tgt = nullptr, *nrm = nullptr, *src_c = nullptr, *tgt_c = nullptr, *tgt_cn = nullptr;
-    int *counts = nullptr, *corr = nullptr, *flags = nullptr;
+    float4 *own_src = nullptr, *own_tgt = nullptr, *nrm = nullptr, *src_c = nullptr, *tgt_c = nullptr;
+    int *counts = nullptr, *ccounts = nullptr, *corr = nullptr, *flags = nullptr;
     unsigned long long *best = nullptr;
     float *cd2 = nullptr;
     double *partials = nullptr, *sums = nullptr, *Tcur = nullptr, *trace_T = nullptr, *trace_S = nullptr, *d_Tinit = nullptr;
@@ -32,9 +32,8 @@ struct slam3d_icp_handle {
     uint16_t *d_depth = nullptr;
     int *d_idx = nullptr; float *d_d2 = nullptr;
     float4 *d_scratch4 = nullptr;
-    // tile-pruned NN (8x8-pixel tiles)
+    // 8x8-pixel tiles (slot order of the sums; target tiles + boxes for the pruned NN)
     TileGrid tg;
-    int *pos_src = nullptr, *pos_tgt = nullptr;
     float4 *srcT = nullptr, *tgtT = nullptr, *tbox = nullptr, *cbox = nullptr;
     // host
     std::vector<SlotPtrs> h_slots;
@@ -58,6 +57,11 @@ struct slam3d_icp_handle {
             return SLAM3D_E_HIP;                                                                \
         }                                                                                       \
     } while (0)
+
+static inline int nn_mode_of(const slam3d_icp_handle *h)
+{
+    return h->p.nn_mode == SLAM3D_NN_AUTO ? SLAM3D_NN_TILES : h->p.nn_mode;
+}
 
 static inline void identity16(double *T) { for (int k = 0; k < 16; ++k) T[k] = (k % 5 == 0) ? 1.0 : 0.0; }
 
@@ -99,10 +103,10 @@ extern "C" const char *slam3d_last_error(const slam3d_icp_handle *h) { return h 
 static void free_all(slam3d_icp_handle *h)
 {
     auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    F(h->own_src); F(h->own_tgt); F(h->nrm); F(h->src_c); F(h->tgt_c); F(h->tgt_cn); F(h->counts); F(h->corr);
+    F(h->own_src); F(h->own_tgt); F(h->nrm); F(h->src_c); F(h->tgt_c); F(h->counts); F(h->ccounts); F(h->corr);
     F(h->flags); F(h->best); F(h->cd2); F(h->partials); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
     F(h->d_Tinit); F(h->d_slots); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4);
-    F(h->pos_src); F(h->pos_tgt); F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox);
+    F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox);
     if (h->pin_slots) (void)hipHostFree(h->pin_slots);
     if (h->pin_T) (void)hipHostFree(h->pin_T);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -129,7 +133,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     if (p->width <= 0 || p->height <= 0 || p->max_batch <= 0 || p->iterations < 0) return SLAM3D_E_INVALID;
     if (p->normal_window < 1 || (p->normal_window & 1) == 0 || p->normal_window / 2 > NRM_RMAX) return SLAM3D_E_INVALID;
     if (p->estimator != SLAM3D_EST_POINT2PLANE && p->estimator != SLAM3D_EST_SVD) return SLAM3D_E_INVALID;
-    if (p->nn_mode < SLAM3D_NN_AUTO || p->nn_mode > SLAM3D_NN_TILES) return SLAM3D_E_INVALID;
+    if (p->nn_mode < SLAM3D_NN_AUTO || p->nn_mode > SLAM3D_NN_TILES || p->nn_mode == SLAM3D_NN_BRUTE_MFMA) return SLAM3D_E_INVALID;
     if (!(p->max_corr_dist > 0.0) || !(p->z_filter > 0.0)) return SLAM3D_E_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device < 0 || p->device >= ndev) return SLAM3D_E_NODEVICE;
@@ -138,7 +142,6 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     if (hipSetDevice(p->device) != hipSuccess) { delete h; return SLAM3D_E_NODEVICE; }
     h->N = p->width * p->height;
     h->maxB = p->max_batch;
-    h->max_chunks = (h->N + CHUNK - 1) / CHUNK;
     Geometry &g = h->g;
     g.W = p->width; g.H = p->height; g.N = h->N;
     g.zmax = (float)p->z_filter;
@@ -152,22 +155,26 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     tg.ntiles = tg.ntx * tg.nty;
     tg.ncx = (tg.ntx + COARSE_TILES - 1) / COARSE_TILES; tg.ncy = (tg.nty + COARSE_TILES - 1) / COARSE_TILES;
     tg.ncoarse = tg.ncx * tg.ncy;
+    tg.nchunks = (tg.ntiles + TILES_PER_CHUNK - 1) / TILES_PER_CHUNK;
+    tg.nslots = tg.nchunks * CHUNK;
+    if ((tg.nchunks + CHUNK - 1) / CHUNK > RS_MAXGROUPS) { delete h; return SLAM3D_E_INVALID; }
     const size_t BN = (size_t)h->maxB * h->N;
+    const size_t BS = (size_t)h->maxB * tg.nslots;
+    const bool brute = nn_mode_of(h) != SLAM3D_NN_TILES;
     const int iters = p->iterations > 0 ? p->iterations : 1;
     hipError_t e = hipSuccess;
     auto A = [&](hipError_t r) { if (e == hipSuccess && r != hipSuccess) e = r; };
     A(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     A(dalloc(h->own_src, BN)); A(dalloc(h->own_tgt, BN)); A(dalloc(h->nrm, BN));
-    A(dalloc(h->src_c, BN)); A(dalloc(h->tgt_c, BN)); A(dalloc(h->tgt_cn, BN));
-    A(dalloc(h->counts, (size_t)h->maxB * 4)); A(dalloc(h->corr, BN)); A(dalloc(h->flags, (size_t)h->maxB));
-    A(dalloc(h->best, BN)); A(dalloc(h->cd2, BN));
-    A(dalloc(h->partials, (size_t)h->maxB * h->max_chunks * NSUMS));
+    if (brute) { A(dalloc(h->src_c, BN)); A(dalloc(h->tgt_c, BN)); A(dalloc(h->best, BS)); }
+    A(dalloc(h->counts, (size_t)h->maxB * 4)); A(dalloc(h->ccounts, (size_t)h->maxB * 4));
+    A(dalloc(h->corr, BS)); A(dalloc(h->flags, (size_t)h->maxB)); A(dalloc(h->cd2, BS));
+    A(dalloc(h->partials, (size_t)h->maxB * tg.nchunks * NSUMS));
     A(dalloc(h->sums, (size_t)h->maxB * NSUMS)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
     A(dalloc(h->trace_T, (size_t)h->maxB * (iters + 1) * 16)); A(dalloc(h->trace_S, (size_t)h->maxB * iters * NSUMS));
     A(dalloc(h->d_Tinit, (size_t)h->maxB * 16)); A(dalloc(h->d_slots, (size_t)h->maxB));
     A(dalloc(h->d_depth, (size_t)2 * h->N)); A(dalloc(h->d_idx, (size_t)h->N)); A(dalloc(h->d_d2, (size_t)h->N));
     A(dalloc(h->d_scratch4, (size_t)h->N));
-    A(dalloc(h->pos_src, BN)); A(dalloc(h->pos_tgt, BN));
     A(dalloc(h->srcT, (size_t)h->maxB * tg.ntiles * TILE_SLOTS)); A(dalloc(h->tgtT, (size_t)h->maxB * tg.ntiles * TILE_SLOTS));
     A(dalloc(h->tbox, (size_t)h->maxB * tg.ntiles * 2)); A(dalloc(h->cbox, (size_t)h->maxB * tg.ncoarse * 2));
     A(hipHostMalloc((void **)&h->pin_slots, sizeof(SlotPtrs) * h->maxB, hipHostMallocDefault));
@@ -271,11 +278,6 @@ extern "C" int slam3d_icp_set_depth_device(slam3d_icp_handle *h, int32_t slot, c
 }
 
 // ------------------------------------------------------------------------------ run
-static inline int nn_mode_of(const slam3d_icp_handle *h)
-{
-    return h->p.nn_mode == SLAM3D_NN_AUTO ? SLAM3D_NN_TILES : h->p.nn_mode;
-}
-
 static int pick_nsplit(const slam3d_icp_handle *h, int B)
 {
     // enough workgroups for 256 CUs: aim at >= ~2048 blocks (query blocks are sized for ~75 % valid)
@@ -300,19 +302,23 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         HIPCHK(h, hipMemcpyAsync(h->d_Tinit, h->pin_T, sizeof(double) * 16 * B, hipMemcpyHostToDevice, s));
         dT = h->d_Tinit;
     }
-    HIPCHK(h, hipMemsetAsync(h->best, 0xFF, sizeof(unsigned long long) * (size_t)B * h->N, s));
+    const bool brute = nn_mode_of(h) != SLAM3D_NN_TILES;
+    const TileGrid &tg = h->tg;
+    HIPCHK(h, hipMemsetAsync(h->counts, 0, sizeof(int) * 4 * (size_t)B, s));
+    HIPCHK(h, hipMemsetAsync(h->corr, 0xFF, sizeof(int) * (size_t)B * tg.nslots, s));   // no previous match yet
     const int use_normals = h->p.estimator == SLAM3D_EST_POINT2PLANE ? 1 : 0;
     if (use_normals) {
         dim3 grid((g.W + NRM_BX - 1) / NRM_BX, (g.H + NRM_BY - 1) / NRM_BY, B);
         hipLaunchKernelGGL(k_normals, grid, dim3(NRM_BX, NRM_BY), 0, s, h->d_slots, h->nrm, g);
     }
-    hipLaunchKernelGGL(k_compact, dim3(2, B), dim3(1024), 0, s, h->d_slots, h->nrm, h->src_c, h->tgt_c, h->tgt_cn,
-                       h->counts, h->pos_src, h->pos_tgt, g, use_normals, h->row0, h->row1);
-    HIPCHK(h, hipMemsetAsync(h->corr, 0xFF, sizeof(int) * (size_t)B * h->N, s));   // no previous match yet
-    if (nn_mode_of(h) == SLAM3D_NN_TILES) {
-        hipLaunchKernelGGL(k_build_tiles, dim3(h->tg.ntiles, 2, B), dim3(64), 0, s, h->d_slots, h->pos_src, h->pos_tgt,
-                           h->srcT, h->tgtT, h->tbox, g, h->tg);
-        hipLaunchKernelGGL(k_coarse_boxes, dim3(h->tg.ncoarse, B), dim3(64), 0, s, h->tbox, h->cbox, h->tg);
+    hipLaunchKernelGGL(k_build_tiles, dim3(tg.ntiles, 2, B), dim3(64), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT, h->tbox,
+                       h->counts, g, tg, use_normals, h->row0, h->row1);
+    if (brute) {
+        HIPCHK(h, hipMemsetAsync(h->best, 0xFF, sizeof(unsigned long long) * (size_t)B * tg.nslots, s));
+        hipLaunchKernelGGL(k_compact, dim3(2, B), dim3(1024), 0, s, h->d_slots, h->nrm, h->src_c, h->tgt_c, h->ccounts, g, tg,
+                           use_normals, h->row0, h->row1);
+    } else {
+        hipLaunchKernelGGL(k_coarse_boxes, dim3(tg.ncoarse, B), dim3(64), 0, s, h->tbox, h->cbox, tg);
     }
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
     hipLaunchKernelGGL(k_init_T, dim3((B + 63) / 64), dim3(64), 0, s, dT, h->Tcur, h->trace_T, h->flags, B, iters);
@@ -320,21 +326,28 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
     return SLAM3D_OK;
 }
 
-static int enqueue_nn_accumulate(slam3d_icp_handle *h, int B, hipStream_t s, hipEvent_t e0, hipEvent_t e1)
+// one iteration's data-parallel part: NN search + normal-equation chunks, then the 29-sum reduction
+// (+ solve and SE(3) update when do_solve)
+static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int it, int do_solve)
 {
-    const int nsplit = pick_nsplit(h, B);
-    const int qblocks = (h->N + NN_BLOCK * NN_QPT - 1) / (NN_BLOCK * NN_QPT);
+    const TileGrid &tg = h->tg;
+    const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
     if (e0) HIPCHK(h, hipEventRecord(e0, s));
-    if (nn_mode_of(h) == SLAM3D_NN_TILES)
-        hipLaunchKernelGGL(k_nn_tiles, dim3((h->tg.ntiles + NNT_WAVES - 1) / NNT_WAVES, B), dim3(64 * NNT_WAVES), 0, s,
-                           h->srcT, h->tgtT, h->tbox, h->cbox, h->tgt_c, h->pos_tgt, h->corr, h->Tcur, h->best, h->g, h->tg);
-    else
-        hipLaunchKernelGGL(k_nn_valu, dim3(qblocks, nsplit, B), dim3(NN_BLOCK), 0, s, h->src_c, h->tgt_c, h->counts, h->Tcur,
-                           h->best, h->N, nsplit);
-    if (e1) HIPCHK(h, hipEventRecord(e1, s));
-    hipLaunchKernelGGL(k_accumulate, dim3(h->max_chunks, B), dim3(CHUNK), 0, s, h->src_c, h->tgt_c, h->tgt_cn, h->counts,
-                       h->Tcur, h->best, h->corr, h->cd2, h->partials, h->N, h->max_chunks, h->g.gate2, h->p.estimator);
-    hipLaunchKernelGGL(k_reduce, dim3(B), dim3(CHUNK), 0, s, h->partials, h->counts, h->sums, h->max_chunks);
+    if (nn_mode_of(h) == SLAM3D_NN_TILES) {
+        hipLaunchKernelGGL(k_nn_tiles_acc, dim3(tg.nchunks, B), dim3(CHUNK), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
+                           h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->partials, h->g, tg);
+        if (e1) HIPCHK(h, hipEventRecord(e1, s));
+    } else {
+        const int nsplit = pick_nsplit(h, B);
+        const int qblocks = (h->N + NN_BLOCK * NN_QPT - 1) / (NN_BLOCK * NN_QPT);
+        hipLaunchKernelGGL(k_nn_valu, dim3(qblocks, nsplit, B), dim3(NN_BLOCK), 0, s, h->src_c, h->tgt_c, h->ccounts, h->Tcur,
+                           h->best, h->N, tg.nslots, nsplit);
+        if (e1) HIPCHK(h, hipEventRecord(e1, s));
+        hipLaunchKernelGGL(k_accumulate, dim3(tg.nchunks, B), dim3(CHUNK), 0, s, h->d_slots, h->nrm, h->srcT, h->Tcur, h->best,
+                           h->corr, h->cd2, h->partials, h->g, tg);
+    }
+    hipLaunchKernelGGL(k_reduce_solve, dim3(B), dim3(RS_THREADS), 0, s, h->partials, h->sums, h->Tcur, h->trace_T, h->trace_S,
+                       h->flags, tg, it, iters, h->p.estimator, do_solve);
     HIPCHK(h, hipGetLastError());
     return SLAM3D_OK;
 }
@@ -354,10 +367,8 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
     HIPCHK(h, hipEventRecord(h->ev[1], s));
     const int iters = h->p.iterations;
     for (int it = 0; it < iters; ++it) {
-        rc = enqueue_nn_accumulate(h, B, s, h->ev[3 + 2 * it], h->ev[4 + 2 * it]);
+        rc = enqueue_iteration(h, B, s, h->ev[3 + 2 * it], h->ev[4 + 2 * it], it, 1);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_solve, dim3((B + 63) / 64), dim3(64), 0, s, h->sums, h->Tcur, h->trace_T, h->trace_S, h->flags,
-                           B, it, iters > 0 ? iters : 1, h->p.estimator);
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev[2], s));
@@ -467,8 +478,8 @@ extern "C" int slam3d_icp_get_correspondences(slam3d_icp_handle *h, int32_t slot
     const int N = h->N;
     hipLaunchKernelGGL(k_fill_corr, dim3((N + 255) / 256), dim3(256), 0, s, h->d_idx, h->d_d2, N);
     if (h->p.iterations > 0)
-        hipLaunchKernelGGL(k_scatter_corr, dim3((N + 255) / 256), dim3(256), 0, s, h->src_c, h->tgt_c, h->corr, h->cd2,
-                           h->counts, slot, N, h->d_idx, h->d_d2);
+        hipLaunchKernelGGL(k_scatter_corr, dim3((h->tg.nslots + 255) / 256), dim3(256), 0, s, h->srcT, h->corr, h->cd2,
+                           slot, h->tg, h->d_idx, h->d_d2);
     HIPCHK(h, hipGetLastError());
     if (idx) HIPCHK(h, hipMemcpyAsync(idx, h->d_idx, sizeof(int) * N, hipMemcpyDeviceToHost, s));
     if (d2) HIPCHK(h, hipMemcpyAsync(d2, h->d_d2, sizeof(float) * N, hipMemcpyDeviceToHost, s));
@@ -669,7 +680,7 @@ extern "C" int slam3d_icp_dense_partial(slam3d_icp_handle *h, double sums[SLAM3D
     if (!h->ran) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
-    const int rc = enqueue_nn_accumulate(h, 1, s, nullptr, nullptr);
+    const int rc = enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0);
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(h->pin_out, h->sums, sizeof(double) * NSUMS, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));

@@ -3,10 +3,12 @@
 // Stage map (DESIGN.md section 3 / SURVEY.md section 8a):
 //   S1 k_backproject      u16 depth -> organized float4 cloud      src/convert2PCD.cpp:54-72
 //   S2 k_normals          7x7 window covariance -> normal          src/planarFeatures.cpp:88-136 (a7)
-//   S3 k_compact          valid points -> dense raster-ordered lists (stable)
-//   S4 k_nn_*             exact brute-force 1-NN (replaces FLANN matching, src/GraphicEnd.cpp:486-520)
-//      k_accumulate       point-to-plane / Kabsch normal equations, deterministic 256-chunk tree
-//   S5 k_reduce, k_solve  29-double reduction, 6x6 LDL^T or 3x3 SVD, SE(3) update on device
+//   S3 k_build_tiles      8x8-pixel tiles (one wavefront each) of source / target + target AABBs
+//      k_compact          raster-ordered dense lists (only the full brute-force modes need them)
+//   S4 k_nn_tiles_acc     exact tile-pruned 1-NN fused with the normal-equation accumulation
+//      k_nn_valu          exact full brute-force 1-NN (replaces FLANN matching, src/GraphicEnd.cpp:486-520)
+//      k_accumulate       point-to-plane / Kabsch normal equations, deterministic 256-slot chunk tree
+//   S5 k_reduce_solve     29-double reduction, 6x6 LDL^T or 3x3 SVD, SE(3) update on device
 //   a6 k_plane_sums       per-plane {sum p, sum pp^T, n} -> (n,d)   src/GraphicEnd.cpp:360-387
 //
 // Numerics contract: compiled with -ffp-contract=off; every float/double operation is an
@@ -21,8 +23,8 @@ namespace s3d {
 
 constexpr int NSUMS = 29;
 constexpr int CHUNK = 256;
-constexpr int NN_TILE = 1024;      // targets staged in LDS per tile
-constexpr int NN_QPT = 4;          // queries per thread (VALU kernel)
+constexpr int NN_TILE = 1024;      // targets staged in LDS per tile (brute-force kernel)
+constexpr int NN_QPT = 4;          // queries per thread (brute-force VALU kernel)
 constexpr int NN_BLOCK = 256;
 
 struct SlotPtrs {                  // per frame-pair device pointers (organized float4 clouds)
@@ -186,168 +188,15 @@ __global__ __launch_bounds__(NRM_BX * NRM_BY) void k_normals(const SlotPtrs *__r
 }
 
 // ------------------------------------------------------------------------------------ S3
-// stable stream compaction, one 1024-thread block per (pair, src|tgt); w of the compacted
-// float4 carries the original linear index (int bits).  Source rows can be restricted
-// (dense multi-GPU mode) to [row0,row1).
-__global__ __launch_bounds__(1024) void k_compact(const SlotPtrs *__restrict__ slots,
-                                                  const float4 *__restrict__ nrm_all,
-                                                  float4 *__restrict__ src_c, float4 *__restrict__ tgt_c,
-                                                  float4 *__restrict__ tgt_cn, int *__restrict__ counts,
-                                                  int *__restrict__ pos_src, int *__restrict__ pos_tgt,
-                                                  Geometry g, int use_normals, int row0, int row1)
-{
-    __shared__ int wave_tot[16];
-    const int which = blockIdx.x, b = blockIdx.y;
-    int *__restrict__ posmap = (which == 0 ? pos_src : pos_tgt) + (size_t)b * g.N;
-    if (which == 0)   // rows outside the (dense-mode) source range hold no source point
-        for (int i = threadIdx.x; i < g.N; i += 1024)
-            if (i < row0 * g.W || i >= row1 * g.W) posmap[i] = -1;
-    const float4 *__restrict__ cloud = which == 0 ? slots[b].src : slots[b].tgt;
-    const float4 *__restrict__ nrm = nrm_all + (size_t)b * g.N;
-    float4 *__restrict__ outp = (which == 0 ? src_c : tgt_c) + (size_t)b * g.N;
-    float4 *__restrict__ outn = tgt_cn + (size_t)b * g.N;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int i_begin = which == 0 ? row0 * g.W : 0;
-    const int i_end = which == 0 ? row1 * g.W : g.N;
-    int base = 0;
-    for (int t0 = i_begin; t0 < i_end; t0 += 1024) {
-        const int i = t0 + tid;
-        float4 q = make_float4(0, 0, 0, 0), nn = make_float4(0, 0, 0, 0);
-        bool ok = false;
-        if (i < i_end) {
-            q = cloud[i];
-            ok = pt_valid(q.x, q.y, q.z, g.zmax);
-            if (ok && which == 1 && use_normals) { nn = nrm[i]; ok = nn.w > 0.5f; }
-        }
-        const unsigned long long m = __ballot(ok);
-        const int prefix = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_tot[w] = __popcll(m);
-        __syncthreads();
-        int woff = 0, total = 0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { const int c = wave_tot[k]; if (k < w) woff += c; total += c; }
-        if (ok) {
-            const int pos = base + woff + prefix;
-            outp[pos] = make_float4(q.x, q.y, q.z, __int_as_float(i));
-            if (which == 1 && use_normals) outn[pos] = make_float4(nn.x, nn.y, nn.z, 0.0f);
-            posmap[i] = pos;
-        } else if (i < i_end) {
-            posmap[i] = -1;
-        }
-        base += total;
-        __syncthreads();
-    }
-    if (tid == 0) counts[b * 4 + which] = base;
-}
-
-// ------------------------------------------------------------------------------------ S4
-struct Rt { float r00, r01, r02, r10, r11, r12, r20, r21, r22, t0, t1, t2; };
-
-__device__ __forceinline__ Rt load_rt(const double *__restrict__ T)
-{
-    Rt m;
-    m.r00 = (float)T[0]; m.r01 = (float)T[1]; m.r02 = (float)T[2];  m.t0 = (float)T[3];
-    m.r10 = (float)T[4]; m.r11 = (float)T[5]; m.r12 = (float)T[6];  m.t1 = (float)T[7];
-    m.r20 = (float)T[8]; m.r21 = (float)T[9]; m.r22 = (float)T[10]; m.t2 = (float)T[11];
-    return m;
-}
-
-__device__ __forceinline__ void xform(const Rt &m, float x, float y, float z, float &ox, float &oy, float &oz)
-{
-    ox = __fmaf_rn(m.r02, z, __fmaf_rn(m.r01, y, m.r00 * x)) + m.t0;
-    oy = __fmaf_rn(m.r12, z, __fmaf_rn(m.r11, y, m.r10 * x)) + m.t1;
-    oz = __fmaf_rn(m.r22, z, __fmaf_rn(m.r21, y, m.r20 * x)) + m.t2;
-}
-
-__device__ __forceinline__ float canon_d2(float px, float py, float pz, float qx, float qy, float qz)
-{
-    const float dx = qx - px, dy = qy - py, dz = qz - pz;
-    return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
-}
-
-// exact brute force on the VALU.  grid = (query blocks, target splits, pairs).  Each thread owns
-// NN_QPT queries (registers); target tiles of NN_TILE points are staged in LDS and read with
-// broadcast ds_read_b128.  Splits merge through a 64-bit atomicMin on (d2 bits << 32 | j): the
-// float bits of a non-negative d2 order like unsigned ints, so the minimum is the smallest d2 and,
-// among equal d2, the smallest j -- the spec's tie-break, independent of scheduling.
-__global__ __launch_bounds__(NN_BLOCK) void k_nn_valu(const float4 *__restrict__ src_c,
-                                                      const float4 *__restrict__ tgt_c,
-                                                      const int *__restrict__ counts,
-                                                      const double *__restrict__ Tcur,
-                                                      unsigned long long *__restrict__ best, int N, int nsplit)
-{
-    __shared__ float4 tile[NN_TILE];
-    const int b = blockIdx.z;
-    const int ns = counts[b * 4 + 0], nt = counts[b * 4 + 1];
-    const int q0 = blockIdx.x * (NN_BLOCK * NN_QPT);
-    if (q0 >= ns) return;
-    const int ntiles = (nt + NN_TILE - 1) / NN_TILE;
-    const int tile_begin = (int)(((long long)blockIdx.y * ntiles) / nsplit);
-    const int tile_end = (int)(((long long)(blockIdx.y + 1) * ntiles) / nsplit);
-    if (tile_begin >= tile_end) return;
-    const float4 *__restrict__ S = src_c + (size_t)b * N;
-    const float4 *__restrict__ Q = tgt_c + (size_t)b * N;
-    const Rt m = load_rt(Tcur + b * 16);
-    float px[NN_QPT], py[NN_QPT], pz[NN_QPT], bd[NN_QPT];
-    int bj[NN_QPT];
-    const float inf = __int_as_float(0x7f800000);
-#pragma unroll
-    for (int k = 0; k < NN_QPT; ++k) {
-        const int i = q0 + k * NN_BLOCK + threadIdx.x;
-        float4 s = make_float4(0, 0, 0, 0);
-        if (i < ns) s = S[i];
-        xform(m, s.x, s.y, s.z, px[k], py[k], pz[k]);
-        bd[k] = inf; bj[k] = -1;
-    }
-    for (int t = tile_begin; t < tile_end; ++t) {
-        const int j0 = t * NN_TILE;
-        __syncthreads();
-        for (int k = threadIdx.x; k < NN_TILE; k += NN_BLOCK) {
-            const int j = j0 + k;
-            float4 q = make_float4(inf, inf, inf, 0.0f);
-            if (j < nt) q = Q[j];
-            tile[k] = q;
-        }
-        __syncthreads();
-        const int cnt = min(NN_TILE, nt - j0);
-#pragma unroll 4
-        for (int jj = 0; jj < cnt; ++jj) {
-            const float4 c = tile[jj];
-#pragma unroll
-            for (int k = 0; k < NN_QPT; ++k) {
-                const float d2 = canon_d2(px[k], py[k], pz[k], c.x, c.y, c.z);
-                const bool lt = d2 < bd[k];
-                bd[k] = lt ? d2 : bd[k];
-                bj[k] = lt ? j0 + jj : bj[k];
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NN_QPT; ++k) {
-        const int i = q0 + k * NN_BLOCK + threadIdx.x;
-        if (i < ns && bj[k] >= 0) {
-            const unsigned long long key =
-                ((unsigned long long)(unsigned int)__float_as_int(bd[k]) << 32) | (unsigned int)bj[k];
-            atomicMin(best + (size_t)b * N + i, key);
-        }
-    }
-}
-
-// ------------------------------------------------------------------ S4, tile-pruned exact NN
-// Both organized clouds are cut into 8x8-pixel tiles (one wavefront = one tile = 64 slots).  A tile
-// of an organized depth image is a small 3-D patch, so its axis-aligned bounding box (AABB, taken
-// from the DATA, no camera model assumed) is tight.  For a source tile the wave knows an upper bound
-// U_i >= d2(i, NN(i)) for every query (distance to the previous iteration's match, else to the target
-// at the same pixel, else the max_corr_dist gate), hence every candidate that can win or tie lies in
-// a target tile whose AABB is within sqrt(max U) of the queries' AABB.  Only those tiles are scanned
-// -- exhaustively, with the canonical distance and the (d2, j) lexicographic minimum -- so the result
-// is bit-identical to the full brute-force scan.  Two-level culling: 64x64-pixel coarse boxes, then
-// their 8x8 child tiles; survivors are found with ballots, candidates are wave-uniform (scalar loads).
+// Both organized clouds are cut into 8x8-pixel tiles: one wavefront = one tile = 64 slots.
+// Source slot id = tile*64 + (v%8)*8 + (u%8) is ALSO the summation order of S4 (chunks of 256
+// slots = 4 consecutive tiles).  Correspondences refer to targets by ORIGINAL pixel index j.
 constexpr int TILE_PX = 8;                 // tile edge in pixels
 constexpr int TILE_SLOTS = 64;             // = one wavefront
 constexpr int COARSE_TILES = 8;            // coarse box edge in tiles (64 px)
+constexpr int TILES_PER_CHUNK = CHUNK / TILE_SLOTS;
 
-struct TileGrid { int ntx, nty, ntiles, ncx, ncy, ncoarse; };
+struct TileGrid { int ntx, nty, ntiles, ncx, ncy, ncoarse, nchunks, nslots; };
 
 __device__ __forceinline__ float wave_min(float v)
 {
@@ -362,13 +211,15 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
-// grid (ntiles, 2, B), block 64.  Slot w = raster-compact index (int bits), -1 = empty.
-// Target tiles are compacted inside the tile (valid slots first) and get an AABB:
-// box[2*t] = (minx, miny, minz, count), box[2*t+1] = (maxx, maxy, maxz, 0).
+// grid (ntiles, 2, B), block 64.  srcT slot w = pixel index (int bits) or -1; rows outside
+// [row0,row1) hold no source (dense multi-GPU mode).  Target tiles are compacted inside the tile
+// (valid slots first, w = pixel index) and get an AABB taken from the data:
+// box[2t] = (minx, miny, minz, count), box[2t+1] = (maxx, maxy, maxz, 0).
 __global__ __launch_bounds__(64) void k_build_tiles(const SlotPtrs *__restrict__ slots,
-                                                    const int *__restrict__ pos_src, const int *__restrict__ pos_tgt,
+                                                    const float4 *__restrict__ nrm_all,
                                                     float4 *__restrict__ srcT, float4 *__restrict__ tgtT,
-                                                    float4 *__restrict__ tbox, Geometry g, TileGrid tg)
+                                                    float4 *__restrict__ tbox, int *__restrict__ counts,
+                                                    Geometry g, TileGrid tg, int use_normals, int row0, int row1)
 {
     const int t = blockIdx.x, which = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
     const int tx = t % tg.ntx, ty = t / tg.ntx;
@@ -378,17 +229,17 @@ __global__ __launch_bounds__(64) void k_build_tiles(const SlotPtrs *__restrict__
     bool ok = false;
     if (u < g.W && v < g.H) {
         const int pix = v * g.W + u;
-        const int pos = (which == 0 ? pos_src : pos_tgt)[(size_t)b * g.N + pix];
-        if (pos >= 0) {
-            const float4 c = (which == 0 ? slots[b].src : slots[b].tgt)[pix];
-            q = make_float4(c.x, c.y, c.z, __int_as_float(pos));
-            ok = true;
-        }
+        const float4 c = (which == 0 ? slots[b].src : slots[b].tgt)[pix];
+        ok = pt_valid(c.x, c.y, c.z, g.zmax);
+        if (which == 0) ok = ok && v >= row0 && v < row1;
+        else if (ok && use_normals) ok = nrm_all[(size_t)b * g.N + pix].w > 0.5f;
+        if (ok) q = make_float4(c.x, c.y, c.z, __int_as_float(pix));
     }
-    const size_t base = ((size_t)b * tg.ntiles + t) * TILE_SLOTS;
-    if (which == 0) { srcT[base + lane] = q; return; }
     const unsigned long long m = __ballot(ok);
     const int cnt = __popcll(m);
+    if (lane == 0 && cnt) atomicAdd(counts + b * 4 + which, cnt);
+    const size_t base = ((size_t)b * tg.ntiles + t) * TILE_SLOTS;
+    if (which == 0) { srcT[base + lane] = q; return; }
     const int slot = ok ? __popcll(m & ((1ull << lane) - 1ull)) : cnt + __popcll(~m & ((1ull << lane) - 1ull));
     tgtT[base + slot] = q;
     const float mnx = wave_min(ok ? q.x : inf), mny = wave_min(ok ? q.y : inf), mnz = wave_min(ok ? q.z : inf);
@@ -418,127 +269,149 @@ __global__ __launch_bounds__(64) void k_coarse_boxes(const float4 *__restrict__ 
     }
 }
 
-__device__ __forceinline__ float box_gap2(const float4 lo, const float4 hi, float qminx, float qminy, float qminz,
-                                          float qmaxx, float qmaxy, float qmaxz)
+// stable raster-order stream compaction, one 1024-thread block per (pair, src|tgt).  Only the full
+// brute-force modes use these lists.  src w = SLOT id of the pixel, tgt w = pixel index.
+__global__ __launch_bounds__(1024) void k_compact(const SlotPtrs *__restrict__ slots,
+                                                  const float4 *__restrict__ nrm_all,
+                                                  float4 *__restrict__ src_c, float4 *__restrict__ tgt_c,
+                                                  int *__restrict__ ccounts, Geometry g, TileGrid tg,
+                                                  int use_normals, int row0, int row1)
 {
-    const float gx = fmaxf(0.0f, fmaxf(lo.x - qmaxx, qminx - hi.x));
-    const float gy = fmaxf(0.0f, fmaxf(lo.y - qmaxy, qminy - hi.y));
-    const float gz = fmaxf(0.0f, fmaxf(lo.z - qmaxz, qminz - hi.z));
-    return gx * gx + gy * gy + gz * gz;      // empty boxes (lo=+inf, hi=-inf) give +inf
-}
-
-constexpr int NNT_WAVES = 4;
-
-// grid (ceil(ntiles/4), B), block 256 = 4 independent waves, one source tile each.
-__global__ __launch_bounds__(64 * NNT_WAVES) void k_nn_tiles(const float4 *__restrict__ srcT,
-                                                             const float4 *__restrict__ tgtT,
-                                                             const float4 *__restrict__ tbox,
-                                                             const float4 *__restrict__ cbox,
-                                                             const float4 *__restrict__ tgt_c,
-                                                             const int *__restrict__ pos_tgt,
-                                                             const int *__restrict__ corr,
-                                                             const double *__restrict__ Tcur,
-                                                             unsigned long long *__restrict__ best,
-                                                             Geometry g, TileGrid tg)
-{
-    const int lane = threadIdx.x & 63;
-    const int t = __builtin_amdgcn_readfirstlane(blockIdx.x * NNT_WAVES + (threadIdx.x >> 6));
-    const int b = blockIdx.y;
-    if (t >= tg.ntiles) return;
-    const int N = g.N;
-    const float inf = __int_as_float(0x7f800000);
-    const float4 s = srcT[((size_t)b * tg.ntiles + t) * TILE_SLOTS + lane];
-    const int i = __float_as_int(s.w);
-    const bool valid = i >= 0;
-    if (__ballot(valid) == 0ull) return;
-    const Rt m = load_rt(Tcur + b * 16);
-    float px, py, pz;
-    xform(m, s.x, s.y, s.z, px, py, pz);
-    // ---- upper bound: previous match, else the target at the same pixel, else the gate
-    int jg = -1;
-    if (valid) {
-        jg = corr[(size_t)b * N + i];
-        if (jg < 0) {
-            const int u = (t % tg.ntx) * TILE_PX + (lane & 7), v = (t / tg.ntx) * TILE_PX + (lane >> 3);
-            jg = pos_tgt[(size_t)b * N + v * g.W + u];
+    __shared__ int wave_tot[16];
+    const int which = blockIdx.x, b = blockIdx.y;
+    const float4 *__restrict__ cloud = which == 0 ? slots[b].src : slots[b].tgt;
+    const float4 *__restrict__ nrm = nrm_all + (size_t)b * g.N;
+    float4 *__restrict__ outp = (which == 0 ? src_c : tgt_c) + (size_t)b * g.N;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i_begin = which == 0 ? row0 * g.W : 0;
+    const int i_end = which == 0 ? row1 * g.W : g.N;
+    int base = 0;
+    for (int t0 = i_begin; t0 < i_end; t0 += 1024) {
+        const int i = t0 + tid;
+        float4 q = make_float4(0, 0, 0, 0);
+        bool ok = false;
+        if (i < i_end) {
+            q = cloud[i];
+            ok = pt_valid(q.x, q.y, q.z, g.zmax);
+            if (ok && which == 1 && use_normals) ok = nrm[i].w > 0.5f;
         }
-    }
-    float bd = g.gate2;
-    unsigned int bj = 0xffffffffu;
-    if (jg >= 0) {
-        const float4 q = tgt_c[(size_t)b * N + jg];
-        const float d2g = canon_d2(px, py, pz, q.x, q.y, q.z);
-        if (d2g <= g.gate2) { bd = d2g; bj = (unsigned int)jg; }
-    }
-    unsigned long long bkey = ((unsigned long long)(unsigned int)__float_as_int(bd) << 32) | bj;
-    const float4 *__restrict__ TB = tbox + (size_t)b * tg.ntiles * 2;
-    const float4 *__restrict__ CB = cbox + (size_t)b * tg.ncoarse * 2;
-    const float4 *__restrict__ TT = tgtT + (size_t)b * tg.ntiles * TILE_SLOTS;
-    // scan one target tile (wave-uniform tt) if some lane can still improve/tie inside its box
-    auto scan_tile = [&](int tt) {
-        const float4 lo = TB[2 * tt], hi = TB[2 * tt + 1];              // uniform -> scalar loads
-        const float cur = __int_as_float((int)(unsigned int)(bkey >> 32));
-        const float gx = fmaxf(0.0f, fmaxf(lo.x - px, px - hi.x));
-        const float gy = fmaxf(0.0f, fmaxf(lo.y - py, py - hi.y));
-        const float gz = fmaxf(0.0f, fmaxf(lo.z - pz, pz - hi.z));
-        const bool need = valid && (gx * gx + gy * gy + gz * gz) <= cur * 1.00001f + 1e-30f;
-        if (__ballot(need) == 0ull) return;
-        const int cnt = __builtin_amdgcn_readfirstlane(__float_as_int(lo.w));
-        const float4 *__restrict__ cand = TT + (size_t)tt * TILE_SLOTS;
-#pragma unroll 4
-        for (int k = 0; k < cnt; ++k) {
-            const float4 q = cand[k];                                   // wave-uniform address
-            const float d2 = canon_d2(px, py, pz, q.x, q.y, q.z);
-            const unsigned long long key =
-                ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(q.w);
-            bkey = key < bkey ? key : bkey;
-        }
-    };
-    // ---- phase A: the 3x3 tiles around the same image location first (centre, then ring): this is
-    // where the neighbours are for frame-to-frame motion, so the bounds shrink before the wide search
-    const int tx0 = t % tg.ntx, ty0 = t / tg.ntx;
-    {
-        const int ox[9] = { 0, -1, 1, 0, 0, -1, 1, -1, 1 }, oy[9] = { 0, 0, 0, -1, 1, -1, -1, 1, 1 };
+        const unsigned long long m = __ballot(ok);
+        const int prefix = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[w] = __popcll(m);
+        __syncthreads();
+        int woff = 0, total = 0;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const int tx = tx0 + ox[k], ty = ty0 + oy[k];
-            if (tx >= 0 && tx < tg.ntx && ty >= 0 && ty < tg.nty) scan_tile(ty * tg.ntx + tx);
-        }
-    }
-    // ---- phase B: every other tile whose box is within reach of the (shrunken) bounds
-    const float qminx = wave_min(valid ? px : inf), qminy = wave_min(valid ? py : inf), qminz = wave_min(valid ? pz : inf);
-    const float qmaxx = wave_max(valid ? px : -inf), qmaxy = wave_max(valid ? py : -inf), qmaxz = wave_max(valid ? pz : -inf);
-    for (int c0 = 0; c0 < tg.ncoarse; c0 += 64) {
-        float umax = wave_max(valid ? __int_as_float((int)(unsigned int)(bkey >> 32)) : 0.0f);
-        float thr = umax * 1.00001f + 1e-30f;        // covers the rounding of box_gap2 and of canon_d2
-        const int c = c0 + lane;
-        bool hit = false;
-        if (c < tg.ncoarse) hit = box_gap2(CB[2 * c], CB[2 * c + 1], qminx, qminy, qminz, qmaxx, qmaxy, qmaxz) <= thr;
-        unsigned long long cm = __ballot(hit);
-        while (cm) {
-            const int cc = c0 + __builtin_ctzll(cm);
-            cm &= cm - 1;
-            const int ctx = (cc % tg.ncx) * COARSE_TILES, cty = (cc / tg.ncx) * COARSE_TILES;
-            const int tx = ctx + (lane & 7), ty = cty + (lane >> 3);
-            umax = wave_max(valid ? __int_as_float((int)(unsigned int)(bkey >> 32)) : 0.0f);
-            thr = umax * 1.00001f + 1e-30f;
-            bool hit2 = false;
-            if (tx < tg.ntx && ty < tg.nty && !(abs(tx - tx0) <= 1 && abs(ty - ty0) <= 1)) {
-                const int tt = ty * tg.ntx + tx;
-                hit2 = box_gap2(TB[2 * tt], TB[2 * tt + 1], qminx, qminy, qminz, qmaxx, qmaxy, qmaxz) <= thr;
+        for (int k = 0; k < 16; ++k) { const int c = wave_tot[k]; if (k < w) woff += c; total += c; }
+        if (ok) {
+            int tag = i;
+            if (which == 0) {
+                const int v = i / g.W, u = i - v * g.W;
+                tag = ((v / TILE_PX) * tg.ntx + u / TILE_PX) * TILE_SLOTS + (v % TILE_PX) * TILE_PX + (u % TILE_PX);
             }
-            unsigned long long tm = __ballot(hit2);
-            while (tm) {
-                const int k2 = __builtin_ctzll(tm);
-                tm &= tm - 1;
-                scan_tile((cty + (k2 >> 3)) * tg.ntx + ctx + (k2 & 7));
-            }
+            outp[base + woff + prefix] = make_float4(q.x, q.y, q.z, __int_as_float(tag));
         }
+        base += total;
+        __syncthreads();
     }
-    if (valid) best[(size_t)b * N + i] = bkey;
+    if (tid == 0) ccounts[b * 4 + which] = base;
 }
 
-// rows of the normal equations for compact source i matched to compact target j (spec S4)
+// ------------------------------------------------------------------------------------ S4
+struct Rt { float r00, r01, r02, r10, r11, r12, r20, r21, r22, t0, t1, t2; };
+
+__device__ __forceinline__ Rt load_rt(const double *__restrict__ T)
+{
+    Rt m;
+    m.r00 = (float)T[0]; m.r01 = (float)T[1]; m.r02 = (float)T[2];  m.t0 = (float)T[3];
+    m.r10 = (float)T[4]; m.r11 = (float)T[5]; m.r12 = (float)T[6];  m.t1 = (float)T[7];
+    m.r20 = (float)T[8]; m.r21 = (float)T[9]; m.r22 = (float)T[10]; m.t2 = (float)T[11];
+    return m;
+}
+
+__device__ __forceinline__ void xform(const Rt &m, float x, float y, float z, float &ox, float &oy, float &oz)
+{
+    ox = __fmaf_rn(m.r02, z, __fmaf_rn(m.r01, y, m.r00 * x)) + m.t0;
+    oy = __fmaf_rn(m.r12, z, __fmaf_rn(m.r11, y, m.r10 * x)) + m.t1;
+    oz = __fmaf_rn(m.r22, z, __fmaf_rn(m.r21, y, m.r20 * x)) + m.t2;
+}
+
+__device__ __forceinline__ float canon_d2(float px, float py, float pz, float qx, float qy, float qz)
+{
+    const float dx = qx - px, dy = qy - py, dz = qz - pz;
+    return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, dx * dx));
+}
+
+// exact brute force on the VALU.  grid = (query blocks, target splits, pairs).  Each thread owns
+// NN_QPT queries (registers) taken from the raster-compacted source list; target tiles of NN_TILE
+// points are staged in LDS and read with broadcast ds_read_b128.  Splits merge through a 64-bit
+// atomicMin on (d2 bits << 32 | j): the float bits of a non-negative d2 order like unsigned ints,
+// so the minimum is the smallest d2 and, among equal d2, the smallest target pixel index j -- the
+// spec's tie-break, independent of scheduling.  best[] is indexed by source SLOT.
+__global__ __launch_bounds__(NN_BLOCK) void k_nn_valu(const float4 *__restrict__ src_c,
+                                                      const float4 *__restrict__ tgt_c,
+                                                      const int *__restrict__ ccounts,
+                                                      const double *__restrict__ Tcur,
+                                                      unsigned long long *__restrict__ best, int N, int nslots,
+                                                      int nsplit)
+{
+    __shared__ float4 tile[NN_TILE];
+    const int b = blockIdx.z;
+    const int ns = ccounts[b * 4 + 0], nt = ccounts[b * 4 + 1];
+    const int q0 = blockIdx.x * (NN_BLOCK * NN_QPT);
+    if (q0 >= ns) return;
+    const int ntiles = (nt + NN_TILE - 1) / NN_TILE;
+    const int tile_begin = (int)(((long long)blockIdx.y * ntiles) / nsplit);
+    const int tile_end = (int)(((long long)(blockIdx.y + 1) * ntiles) / nsplit);
+    if (tile_begin >= tile_end) return;
+    const float4 *__restrict__ S = src_c + (size_t)b * N;
+    const float4 *__restrict__ Q = tgt_c + (size_t)b * N;
+    const Rt m = load_rt(Tcur + b * 16);
+    float px[NN_QPT], py[NN_QPT], pz[NN_QPT], bd[NN_QPT];
+    int bj[NN_QPT], slot[NN_QPT];
+    const float inf = __int_as_float(0x7f800000);
+#pragma unroll
+    for (int k = 0; k < NN_QPT; ++k) {
+        const int i = q0 + k * NN_BLOCK + threadIdx.x;
+        float4 s = make_float4(0, 0, 0, __int_as_float(-1));
+        if (i < ns) s = S[i];
+        slot[k] = __float_as_int(s.w);
+        xform(m, s.x, s.y, s.z, px[k], py[k], pz[k]);
+        bd[k] = inf; bj[k] = -1;
+    }
+    for (int t = tile_begin; t < tile_end; ++t) {
+        const int j0 = t * NN_TILE;
+        __syncthreads();
+        for (int k = threadIdx.x; k < NN_TILE; k += NN_BLOCK) {
+            const int j = j0 + k;
+            float4 q = make_float4(inf, inf, inf, 0.0f);
+            if (j < nt) q = Q[j];
+            tile[k] = q;
+        }
+        __syncthreads();
+        const int cnt = min(NN_TILE, nt - j0);
+#pragma unroll 4
+        for (int jj = 0; jj < cnt; ++jj) {
+            const float4 c = tile[jj];
+#pragma unroll
+            for (int k = 0; k < NN_QPT; ++k) {
+                const float d2 = canon_d2(px[k], py[k], pz[k], c.x, c.y, c.z);
+                const bool lt = d2 < bd[k];     // ascending raster order: ties keep the smallest pixel index
+                bd[k] = lt ? d2 : bd[k];
+                bj[k] = lt ? j0 + jj : bj[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NN_QPT; ++k) {
+        if (slot[k] >= 0 && bj[k] >= 0) {
+            const unsigned int pix = (unsigned int)__float_as_int(Q[bj[k]].w);
+            const unsigned long long key = ((unsigned long long)(unsigned int)__float_as_int(bd[k]) << 32) | pix;
+            atomicMin(best + (size_t)b * nslots + slot[k], key);
+        }
+    }
+}
+
+// rows of the normal equations for a source point p' matched to target point q with normal n (spec S4)
 __device__ __forceinline__ void row_sums(int estimator, float pxf, float pyf, float pzf, const float4 q4,
                                          const float4 n4, double *__restrict__ s)
 {
@@ -568,92 +441,227 @@ __device__ __forceinline__ void row_sums(int estimator, float pxf, float pyf, fl
     }
 }
 
-// block tree: sh[k*256 + i] += sh[k*256 + i + s] for s = 128..1 -- the spec's association order.
-// The s*29 independent adds of a level are spread over all 256 threads.
-__device__ __forceinline__ void tree256(double *__restrict__ sh, int tid)
+// wave part of the spec's 256-element tree: levels 32,16,..,1 (a[i] += a[i+s], i < s) as shuffles
+__device__ __forceinline__ double wave_tree64(double x)
 {
-    for (int s = CHUNK / 2; s >= 1; s >>= 1) {
-        __syncthreads();
-        for (int w = tid; w < s * NSUMS; w += CHUNK) {
-            const int k = w / s, i = w - k * s;
-            sh[k * CHUNK + i] += sh[k * CHUNK + i + s];
-        }
-    }
-    __syncthreads();
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x = x + __shfl_down(x, o);
+    return x;      // valid in lane 0
 }
 
-// grid = (chunks, pairs); decodes + resets the packed NN keys, writes corr/d2 (compact order),
-// forms the 29 row products per correspondence and tree-reduces the chunk.
-__global__ __launch_bounds__(CHUNK) void k_accumulate(const float4 *__restrict__ src_c,
-                                                      const float4 *__restrict__ tgt_c,
-                                                      const float4 *__restrict__ tgt_cn,
-                                                      const int *__restrict__ counts,
+constexpr int ACC_LDS_DOUBLES = NSUMS * 128;
+
+// Chunk reduction of 256 slots held one-per-thread (4 waves): levels 128 and 64 of the tree are
+// wave-to-wave adds through LDS (wave0 += wave2, wave1 += wave3; wave0 += wave1), the rest are
+// in-wave shuffles.  Same association order as tree256 in the oracle.  All 256 threads must call.
+__device__ __forceinline__ void chunk_reduce_store(double *__restrict__ s, double *__restrict__ sh /*ACC_LDS_DOUBLES*/,
+                                                   double *__restrict__ out29)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (w >= 2) {
+#pragma unroll
+        for (int k = 0; k < NSUMS; ++k) sh[k * 128 + (w - 2) * 64 + lane] = s[k];
+    }
+    __syncthreads();
+    if (w < 2) {
+#pragma unroll
+        for (int k = 0; k < NSUMS; ++k) s[k] = s[k] + sh[k * 128 + w * 64 + lane];
+    }
+    __syncthreads();
+    if (w == 1) {
+#pragma unroll
+        for (int k = 0; k < NSUMS; ++k) sh[k * 128 + lane] = s[k];
+    }
+    __syncthreads();
+    if (w == 0) {
+#pragma unroll
+        for (int k = 0; k < NSUMS; ++k) {
+            const double x = wave_tree64(s[k] + sh[k * 128 + lane]);
+            if (lane == 0) out29[k] = x;
+        }
+    }
+}
+
+// decode a packed NN key, apply the gate, record the correspondence and form the row products
+__device__ __forceinline__ void finish_slot(bool valid, unsigned long long key, float px, float py, float pz,
+                                            const float4 *__restrict__ tcloud, const float4 *__restrict__ tnrm,
+                                            float gate2, int estimator, int *__restrict__ corr_out,
+                                            float *__restrict__ cd2_out, double *__restrict__ s)
+{
+#pragma unroll
+    for (int k = 0; k < NSUMS; ++k) s[k] = 0.0;
+    const int j = (int)(unsigned int)(key & 0xffffffffull);
+    const float d2 = __int_as_float((int)(unsigned int)(key >> 32));
+    const bool ok = valid && (j >= 0) && (d2 <= gate2);
+    *corr_out = ok ? j : -1;
+    *cd2_out = ok ? d2 : __int_as_float(0x7f800000);
+    if (ok) {
+        const float4 q4 = tcloud[j];
+        float4 n4 = make_float4(0, 0, 0, 0);
+        if (estimator == 0) n4 = tnrm[j];
+        row_sums(estimator, px, py, pz, q4, n4, s);
+    }
+}
+
+// accumulation for the brute-force modes: grid (nchunks, B), one thread per source slot
+__global__ __launch_bounds__(CHUNK) void k_accumulate(const SlotPtrs *__restrict__ slots,
+                                                      const float4 *__restrict__ nrm_all,
+                                                      const float4 *__restrict__ srcT,
                                                       const double *__restrict__ Tcur,
                                                       unsigned long long *__restrict__ best,
                                                       int *__restrict__ corr, float *__restrict__ cd2,
-                                                      double *__restrict__ partials, int N, int max_chunks,
-                                                      float gate2, int estimator)
+                                                      double *__restrict__ partials, Geometry g, TileGrid tg)
 {
-    __shared__ double sh[NSUMS * CHUNK];
-    const int b = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
-    const int ns = counts[b * 4 + 0];
-    if (c * CHUNK >= ns) return;
-    const int i = c * CHUNK + tid;
+    __shared__ double sh[ACC_LDS_DOUBLES];
+    const int b = blockIdx.y, c = blockIdx.x;
+    const int slot = c * CHUNK + threadIdx.x;
+    const size_t gs = (size_t)b * tg.nslots + slot;
+    float4 sp = make_float4(0, 0, 0, __int_as_float(-1));
+    if (slot < tg.ntiles * TILE_SLOTS) sp = srcT[(size_t)b * tg.ntiles * TILE_SLOTS + slot];
+    const bool valid = __float_as_int(sp.w) >= 0;
+    const Rt m = load_rt(Tcur + b * 16);
+    float px, py, pz;
+    xform(m, sp.x, sp.y, sp.z, px, py, pz);
+    const unsigned long long key = best[gs];
+    best[gs] = ~0ull;
     double s[NSUMS];
+    finish_slot(valid, key, px, py, pz, slots[b].tgt, nrm_all + (size_t)b * g.N, g.gate2, g.estimator, corr + gs, cd2 + gs, s);
+    chunk_reduce_store(s, sh, partials + ((size_t)b * tg.nchunks + c) * NSUMS);
+}
+
+// ------------------------------------------------------------------ S4, tile-pruned exact NN
+// A tile of an organized depth image is a small 3-D patch, so its axis-aligned bounding box (taken
+// from the DATA, no camera model assumed) is tight.  Every query of a source tile knows an upper
+// bound U_i >= d2(i, NN(i)) (distance to the previous iteration's match, else to the target at the
+// same pixel, else the max_corr_dist gate), hence every candidate that can win or tie lies in a
+// target tile whose box is within sqrt(U_i) of query i.  Only those tiles are scanned -- exhaustively,
+// with the canonical distance and the (d2, j) lexicographic minimum -- so the result is bit-identical
+// to the full brute-force scan.  Order: the 3x3 tiles at the same image location first (bounds
+// shrink), then a two-level sweep (64x64-px coarse boxes -> child tiles) by ballots against the wave's
+// AABB; before a surviving tile is scanned each lane re-tests its own point against the tile box.
+// Candidates are wave-uniform: the compiler turns their loads into scalar s_load_dwordx16.
+__device__ __forceinline__ float box_gap2(const float4 lo, const float4 hi, float qminx, float qminy, float qminz,
+                                          float qmaxx, float qmaxy, float qmaxz)
+{
+    const float gx = fmaxf(0.0f, fmaxf(lo.x - qmaxx, qminx - hi.x));
+    const float gy = fmaxf(0.0f, fmaxf(lo.y - qmaxy, qminy - hi.y));
+    const float gz = fmaxf(0.0f, fmaxf(lo.z - qmaxz, qminz - hi.z));
+    return gx * gx + gy * gy + gz * gz;      // empty boxes (lo=+inf, hi=-inf) give +inf
+}
+
+// grid (nchunks, B), block 256 = 4 waves = 4 consecutive source tiles = one summation chunk
+__global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restrict__ slots,
+                                                        const float4 *__restrict__ nrm_all,
+                                                        const float4 *__restrict__ srcT,
+                                                        const float4 *__restrict__ tgtT,
+                                                        const float4 *__restrict__ tbox,
+                                                        const float4 *__restrict__ cbox,
+                                                        const double *__restrict__ Tcur,
+                                                        int *__restrict__ corr, float *__restrict__ cd2,
+                                                        double *__restrict__ partials, Geometry g, TileGrid tg)
+{
+    __shared__ double sh[ACC_LDS_DOUBLES];
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.y, c = blockIdx.x;
+    const int t = __builtin_amdgcn_readfirstlane(c * TILES_PER_CHUNK + (threadIdx.x >> 6));
+    const int slot = c * CHUNK + threadIdx.x;
+    const size_t gs = (size_t)b * tg.nslots + slot;
+    const float inf = __int_as_float(0x7f800000);
+    const float4 *__restrict__ tcloud = slots[b].tgt;
+    const float4 *__restrict__ tnrm = nrm_all + (size_t)b * g.N;
+    float4 s4 = make_float4(0, 0, 0, __int_as_float(-1));
+    if (t < tg.ntiles) s4 = srcT[((size_t)b * tg.ntiles + t) * TILE_SLOTS + lane];
+    const int pix = __float_as_int(s4.w);
+    const bool valid = pix >= 0;
+    const Rt m = load_rt(Tcur + b * 16);
+    float px, py, pz;
+    xform(m, s4.x, s4.y, s4.z, px, py, pz);
+    unsigned long long bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
+    if (__ballot(valid) != 0ull) {
+        // ---- upper bound: previous match, else the target at the same pixel, else the gate
+        int jg = -1;
+        if (valid) {
+            jg = corr[gs];
+            if (jg < 0) jg = pix;
+        }
+        if (jg >= 0) {
+            const float4 q = tcloud[jg];
+            bool tv = pt_valid(q.x, q.y, q.z, g.zmax);
+            if (tv && g.estimator == 0) tv = tnrm[jg].w > 0.5f;
+            const float d2g = canon_d2(px, py, pz, q.x, q.y, q.z);
+            if (tv && d2g <= g.gate2) bkey = ((unsigned long long)(unsigned int)__float_as_int(d2g) << 32) | (unsigned int)jg;
+        }
+        const float4 *__restrict__ TB = tbox + (size_t)b * tg.ntiles * 2;
+        const float4 *__restrict__ CB = cbox + (size_t)b * tg.ncoarse * 2;
+        const float4 *__restrict__ TT = tgtT + (size_t)b * tg.ntiles * TILE_SLOTS;
+        // scan one target tile (wave-uniform tt) if some lane can still improve/tie inside its box
+        auto scan_tile = [&](int tt) {
+            const float4 lo = TB[2 * tt], hi = TB[2 * tt + 1];              // uniform -> scalar loads
+            const float cur = __int_as_float((int)(unsigned int)(bkey >> 32));
+            const float gx = fmaxf(0.0f, fmaxf(lo.x - px, px - hi.x));
+            const float gy = fmaxf(0.0f, fmaxf(lo.y - py, py - hi.y));
+            const float gz = fmaxf(0.0f, fmaxf(lo.z - pz, pz - hi.z));
+            const bool need = valid && (gx * gx + gy * gy + gz * gz) <= cur * 1.00001f + 1e-30f;
+            if (__ballot(need) == 0ull) return;
+            const int cnt = __builtin_amdgcn_readfirstlane(__float_as_int(lo.w));
+            const float4 *__restrict__ cand = TT + (size_t)tt * TILE_SLOTS;
+#pragma unroll 4
+            for (int k = 0; k < cnt; ++k) {
+                const float4 q = cand[k];                                   // wave-uniform address
+                const float d2 = canon_d2(px, py, pz, q.x, q.y, q.z);
+                const unsigned long long key =
+                    ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(q.w);
+                bkey = key < bkey ? key : bkey;
+            }
+        };
+        // ---- phase A: the 3x3 tiles around the same image location (centre, then ring)
+        const int tx0 = t % tg.ntx, ty0 = t / tg.ntx;
+        {
+            const int ox[9] = { 0, -1, 1, 0, 0, -1, 1, -1, 1 }, oy[9] = { 0, 0, 0, -1, 1, -1, -1, 1, 1 };
 #pragma unroll
-    for (int k = 0; k < NSUMS; ++k) s[k] = 0.0;
-    if (i < ns) {
-        const size_t gi = (size_t)b * N + i;
-        const unsigned long long key = best[gi];
-        best[gi] = ~0ull;
-        const int j = (int)(unsigned int)(key & 0xffffffffull);
-        const float d2 = __int_as_float((int)(unsigned int)(key >> 32));
-        const bool ok = (j >= 0) && (d2 <= gate2);
-        corr[gi] = ok ? j : -1;
-        cd2[gi] = ok ? d2 : __int_as_float(0x7f800000);
-        if (ok) {
-            const Rt m = load_rt(Tcur + b * 16);
-            const float4 sp = src_c[gi];
-            float px, py, pz;
-            xform(m, sp.x, sp.y, sp.z, px, py, pz);
-            const float4 q4 = tgt_c[(size_t)b * N + j];
-            float4 n4 = make_float4(0, 0, 0, 0);
-            if (estimator == 0) n4 = tgt_cn[(size_t)b * N + j];
-            row_sums(estimator, px, py, pz, q4, n4, s);
+            for (int k = 0; k < 9; ++k) {
+                const int tx = tx0 + ox[k], ty = ty0 + oy[k];
+                if (tx >= 0 && tx < tg.ntx && ty >= 0 && ty < tg.nty) scan_tile(ty * tg.ntx + tx);
+            }
+        }
+        // ---- phase B: every other tile whose box is within reach of the (shrunken) bounds
+        const float qminx = wave_min(valid ? px : inf), qminy = wave_min(valid ? py : inf), qminz = wave_min(valid ? pz : inf);
+        const float qmaxx = wave_max(valid ? px : -inf), qmaxy = wave_max(valid ? py : -inf), qmaxz = wave_max(valid ? pz : -inf);
+        for (int c0 = 0; c0 < tg.ncoarse; c0 += 64) {
+            float umax = wave_max(valid ? __int_as_float((int)(unsigned int)(bkey >> 32)) : 0.0f);
+            float thr = umax * 1.00001f + 1e-30f;        // covers the rounding of box_gap2 and of canon_d2
+            const int cidx = c0 + lane;
+            bool hit = false;
+            if (cidx < tg.ncoarse) hit = box_gap2(CB[2 * cidx], CB[2 * cidx + 1], qminx, qminy, qminz, qmaxx, qmaxy, qmaxz) <= thr;
+            unsigned long long cm = __ballot(hit);
+            while (cm) {
+                const int cc = c0 + __builtin_ctzll(cm);
+                cm &= cm - 1;
+                const int ctx = (cc % tg.ncx) * COARSE_TILES, cty = (cc / tg.ncx) * COARSE_TILES;
+                const int tx = ctx + (lane & 7), ty = cty + (lane >> 3);
+                umax = wave_max(valid ? __int_as_float((int)(unsigned int)(bkey >> 32)) : 0.0f);
+                thr = umax * 1.00001f + 1e-30f;
+                bool hit2 = false;
+                if (tx < tg.ntx && ty < tg.nty && !(abs(tx - tx0) <= 1 && abs(ty - ty0) <= 1)) {
+                    const int tt = ty * tg.ntx + tx;
+                    hit2 = box_gap2(TB[2 * tt], TB[2 * tt + 1], qminx, qminy, qminz, qmaxx, qmaxy, qmaxz) <= thr;
+                }
+                unsigned long long tm = __ballot(hit2);
+                while (tm) {
+                    const int k2 = __builtin_ctzll(tm);
+                    tm &= tm - 1;
+                    scan_tile((cty + (k2 >> 3)) * tg.ntx + ctx + (k2 & 7));
+                }
+            }
         }
     }
-#pragma unroll
-    for (int k = 0; k < NSUMS; ++k) sh[k * CHUNK + tid] = s[k];
-    tree256(sh, tid);
-    if (tid < NSUMS) partials[((size_t)b * max_chunks + c) * NSUMS + tid] = sh[tid * CHUNK];
+    // ---- fused S4 accumulation of this chunk (4 tiles = 256 slots)
+    double s[NSUMS];
+    finish_slot(valid, bkey, px, py, pz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, s);
+    chunk_reduce_store(s, sh, partials + ((size_t)b * tg.nchunks + c) * NSUMS);
 }
 
 // ------------------------------------------------------------------------------------ S5
-// level 2/3 of the reduction: groups of 256 chunk partials -> tree, groups summed in order.
-__global__ __launch_bounds__(CHUNK) void k_reduce(const double *__restrict__ partials,
-                                                  const int *__restrict__ counts, double *__restrict__ sums,
-                                                  int max_chunks)
-{
-    __shared__ double sh[NSUMS * CHUNK];
-    __shared__ double tot[NSUMS];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int ns = counts[b * 4 + 0];
-    const int nchunks = (ns + CHUNK - 1) / CHUNK;
-    const int ngroups = (nchunks + CHUNK - 1) / CHUNK;
-    if (tid < NSUMS) tot[tid] = 0.0;
-    for (int g = 0; g < ngroups; ++g) {
-        const int c = g * CHUNK + tid;
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < NSUMS; ++k)
-            sh[k * CHUNK + tid] = c < nchunks ? partials[((size_t)b * max_chunks + c) * NSUMS + k] : 0.0;
-        tree256(sh, tid);
-        if (tid < NSUMS) tot[tid] = g == 0 ? sh[tid * CHUNK] : tot[tid] + sh[tid * CHUNK];
-    }
-    __syncthreads();
-    if (tid < NSUMS) sums[b * NSUMS + tid] = tot[tid];
-}
-
 // deterministic sin/cos (spec): Cody-Waite reduction by pi/2 + Taylor/Horner, basic ops only
 __device__ inline void spec_sincos(double x, double &s, double &c)
 {
@@ -791,18 +799,14 @@ __device__ inline void compose(const double *dR, const double *dt, double *T)
     for (int k = 0; k < 16; ++k) T[k] = Tn[k];
 }
 
-// one thread per pair: solve + SE(3) update, trace bookkeeping.  (The data-parallel work is in
-// k_accumulate/k_reduce; this is ~1e3 dependent fp64 ops.)
-__global__ void k_solve(const double *__restrict__ sums_all, double *__restrict__ Tcur,
-                        double *__restrict__ trace_T, double *__restrict__ trace_S,
-                        int *__restrict__ flags, int B, int it, int iters, int estimator)
+// solve + SE(3) update from the 29 sums (one thread), trace bookkeeping
+__device__ inline void solve_update_one(const double *__restrict__ sums, double *__restrict__ Tcur_b,
+                                        double *__restrict__ trace_T_b, double *__restrict__ trace_S_b,
+                                        int *__restrict__ flag, int it, int estimator)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    double sums[NSUMS], T[16];
-    for (int k = 0; k < NSUMS; ++k) sums[k] = sums_all[b * NSUMS + k];
-    for (int k = 0; k < 16; ++k) T[k] = Tcur[b * 16 + k];
-    for (int k = 0; k < NSUMS; ++k) trace_S[((size_t)b * iters + it) * NSUMS + k] = sums[k];
+    double T[16];
+    for (int k = 0; k < 16; ++k) T[k] = Tcur_b[k];
+    for (int k = 0; k < NSUMS; ++k) trace_S_b[(size_t)it * NSUMS + k] = sums[k];
     int rc = 0;
     double dR[9], dt[3];
     if (estimator == 0) {
@@ -834,10 +838,65 @@ __global__ void k_solve(const double *__restrict__ sums_all, double *__restrict_
     }
     if (rc) {
         compose(dR, dt, T);
-        for (int k = 0; k < 16; ++k) Tcur[b * 16 + k] = T[k];
-        if (rc == 2) flags[b] = 1;
+        for (int k = 0; k < 16; ++k) Tcur_b[k] = T[k];
+        if (rc == 2) *flag = 1;
     }
-    for (int k = 0; k < 16; ++k) trace_T[((size_t)b * (iters + 1) + it + 1) * 16 + k] = T[k];
+    for (int k = 0; k < 16; ++k) trace_T_b[(size_t)(it + 1) * 16 + k] = T[k];
+}
+
+constexpr int RS_THREADS = 1024;
+constexpr int RS_MAXGROUPS = 64;
+
+// grid (B), block 1024 (16 waves).  Levels 2 and 3 of the reduction: each (group g of 256 chunk
+// partials, component k) is one wave-sized tree -- lane l adds chunks (l, l+128) and (l+64, l+192),
+// then those two, then shuffles -- exactly tree256's association; group results are summed in order.
+// do_solve = 0 leaves only the sums (dense multi-GPU mode reduces them across ranks first).
+__global__ __launch_bounds__(RS_THREADS) void k_reduce_solve(const double *__restrict__ partials,
+                                                             double *__restrict__ sums_all,
+                                                             double *__restrict__ Tcur, double *__restrict__ trace_T,
+                                                             double *__restrict__ trace_S, int *__restrict__ flags,
+                                                             TileGrid tg, int it, int iters, int estimator, int do_solve)
+{
+    __shared__ double P2[RS_MAXGROUPS * NSUMS];
+    __shared__ double tot[NSUMS];
+    const int b = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nchunks = tg.nchunks;
+    const int ngroups = (nchunks + CHUNK - 1) / CHUNK;
+    const double *__restrict__ P = partials + (size_t)b * nchunks * NSUMS;
+    for (int tree = w; tree < ngroups * NSUMS; tree += RS_THREADS / 64) {
+        const int gq = tree / NSUMS, k = tree - gq * NSUMS;
+        const int c0 = gq * CHUNK + lane;
+        const double v0 = c0 < nchunks ? P[(size_t)c0 * NSUMS + k] : 0.0;
+        const double v1 = c0 + 64 < nchunks ? P[(size_t)(c0 + 64) * NSUMS + k] : 0.0;
+        const double v2 = c0 + 128 < nchunks ? P[(size_t)(c0 + 128) * NSUMS + k] : 0.0;
+        const double v3 = c0 + 192 < nchunks ? P[(size_t)(c0 + 192) * NSUMS + k] : 0.0;
+        const double x = wave_tree64((v0 + v2) + (v1 + v3));
+        if (lane == 0) P2[gq * NSUMS + k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < NSUMS) {
+        double a = P2[threadIdx.x];
+        for (int gq = 1; gq < ngroups; ++gq) a = a + P2[gq * NSUMS + threadIdx.x];
+        tot[threadIdx.x] = a;
+        sums_all[b * NSUMS + threadIdx.x] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && do_solve)
+        solve_update_one(tot, Tcur + b * 16, trace_T + (size_t)b * (iters + 1) * 16, trace_S + (size_t)b * iters * NSUMS,
+                         flags + b, it, estimator);
+}
+
+// dense mode: solve from externally reduced sums (one thread per pair)
+__global__ void k_solve(const double *__restrict__ sums_all, double *__restrict__ Tcur,
+                        double *__restrict__ trace_T, double *__restrict__ trace_S,
+                        int *__restrict__ flags, int B, int it, int iters, int estimator)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double sums[NSUMS];
+    for (int k = 0; k < NSUMS; ++k) sums[k] = sums_all[b * NSUMS + k];
+    solve_update_one(sums, Tcur + b * 16, trace_T + (size_t)b * (iters + 1) * 16, trace_S + (size_t)b * iters * NSUMS,
+                     flags + b, it, estimator);
 }
 
 __global__ void k_init_T(const double *__restrict__ T_init, double *__restrict__ Tcur,
@@ -853,37 +912,33 @@ __global__ void k_init_T(const double *__restrict__ T_init, double *__restrict__
     flags[b] = 0;
 }
 
-// compact-order correspondences -> original linear indices (for get_correspondences)
+// slot-order correspondences -> original pixel order (for get_correspondences)
 __global__ __launch_bounds__(256) void k_fill_corr(int *__restrict__ idx, float *__restrict__ d2, int N)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < N) { idx[i] = -1; d2[i] = __int_as_float(0x7f800000); }
 }
 
-__global__ __launch_bounds__(256) void k_scatter_corr(const float4 *__restrict__ src_c,
-                                                      const float4 *__restrict__ tgt_c,
-                                                      const int *__restrict__ corr, const float *__restrict__ cd2,
-                                                      const int *__restrict__ counts, int b, int N,
+__global__ __launch_bounds__(256) void k_scatter_corr(const float4 *__restrict__ srcT, const int *__restrict__ corr,
+                                                      const float *__restrict__ cd2, int b, TileGrid tg,
                                                       int *__restrict__ idx, float *__restrict__ d2)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= counts[b * 4 + 0]) return;
-    const size_t gi = (size_t)b * N + i;
-    const int oi = __float_as_int(src_c[gi].w);
-    const int j = corr[gi];
-    idx[oi] = j >= 0 ? __float_as_int(tgt_c[(size_t)b * N + j].w) : -1;
-    d2[oi] = cd2[gi];
+    const int slot = blockIdx.x * 256 + threadIdx.x;
+    if (slot >= tg.ntiles * TILE_SLOTS) return;
+    const int pix = __float_as_int(srcT[(size_t)b * tg.ntiles * TILE_SLOTS + slot].w);
+    if (pix < 0) return;
+    idx[pix] = corr[(size_t)b * tg.nslots + slot];
+    d2[pix] = cd2[(size_t)b * tg.nslots + slot];
 }
 
 // ------------------------------------------------------------------------------------ a6
-// per-plane moments relative to an origin point, sequential-in-index semantics are not needed
-// here: sums are accumulated per plane with the same 256-chunk tree over the raster order.
+// per-plane moments relative to an origin point, 256-pixel chunk tree; chunks are summed on the host
 __global__ __launch_bounds__(CHUNK) void k_plane_sums(const float4 *__restrict__ cloud,
                                                       const int *__restrict__ labels, int N, int nplanes,
                                                       const double *__restrict__ origin /* nplanes*3 */,
                                                       double *__restrict__ partials /* chunks*nplanes*10 */)
 {
-    __shared__ double sh[NSUMS * CHUNK];
+    __shared__ double sh[10 * CHUNK];
     const int c = blockIdx.x, tid = threadIdx.x, i = c * CHUNK + tid;
     const int lab = i < N ? labels[i] : -1;
     float4 q = make_float4(0, 0, 0, 0);
