@@ -522,11 +522,20 @@ static void tree256(double (*v)[ORC_NSUMS])   /* v[256][29] -> v[0] */
 }
 
 /* Summation order (spec S4): sources are enumerated by SLOT, tile-major over 8x8-pixel tiles
- * (tile t = ty*ntx + tx, slot = t*64 + (v%8)*8 + (u%8); the image is padded to whole tiles and
- * the tile count to whole chunks).  A slot without a valid source point or without a gated
- * correspondence contributes zeros.  Chunks of 256 slots (= 4 consecutive tiles) are reduced by
- * tree256, groups of 256 chunk results again by tree256, group results summed in order. */
+ * (tile t = ty*ntx + tx, slot = t*64 + (v%8)*8 + (u%8); the image is padded to whole tiles).
+ * A slot without a valid source point or without a gated correspondence contributes zeros.
+ *   level 1: the 64 slots of a tile by tree64  (a[i] += a[i+s], i < s, s = 32,16,..,1)
+ *   level 2: groups of 256 consecutive tile results by tree256 (s = 128,..,1; missing tiles = 0)
+ *   level 3: group results summed in ascending order.
+ * (one wavefront owns one tile on the GPU: level 1 is its shuffle tree) */
 #define ORC_TILE 8
+static void tree64(double (*v)[ORC_NSUMS])
+{
+    for (int s = 32; s >= 1; s >>= 1)
+        for (int i = 0; i < s; ++i)
+            for (int k = 0; k < ORC_NSUMS; ++k) v[i][k] += v[i + s][k];
+}
+
 static void accumulate(const clist *src, const clist *tgt, const double *T, int estimator,
                        const int *corr, int W, int H, int nt, double *total /*29*/)
 {
@@ -534,8 +543,7 @@ static void accumulate(const clist *src, const clist *tgt, const double *T, int 
     transform_f(T, Rf, tf);
     const int ntx = (W + ORC_TILE - 1) / ORC_TILE, nty = (H + ORC_TILE - 1) / ORC_TILE;
     const int ntiles = ntx * nty;
-    const int nchunks = (ntiles * 64 + ORC_CHUNK - 1) / ORC_CHUNK;
-    const int ngroups = (nchunks + ORC_CHUNK - 1) / ORC_CHUNK;
+    const int ngroups = (ntiles + ORC_CHUNK - 1) / ORC_CHUNK;
     /* pixel -> compact source index */
     int *cidx = malloc(sizeof(int) * (size_t)(W * H));
     for (int i = 0; i < W * H; ++i) cidx[i] = -1;
@@ -544,22 +552,18 @@ static void accumulate(const clist *src, const clist *tgt, const double *T, int 
     (void)nt;
 #pragma omp parallel num_threads(nt)
     {
-        double (*v)[ORC_NSUMS] = malloc(sizeof(*v) * ORC_CHUNK);
+        double (*v)[ORC_NSUMS] = malloc(sizeof(*v) * 64);
 #pragma omp for schedule(static)
-        for (int c = 0; c < nchunks; ++c) {
-            for (int l = 0; l < ORC_CHUNK; ++l) {
-                const int slot = c * ORC_CHUNK + l;
-                const int t = slot / 64, ln = slot % 64;
+        for (int t = 0; t < ntiles; ++t) {
+            for (int ln = 0; ln < 64; ++ln) {
+                const int u = (t % ntx) * ORC_TILE + (ln & 7), vv = (t / ntx) * ORC_TILE + (ln >> 3);
                 int i = -1;
-                if (t < ntiles) {
-                    const int u = (t % ntx) * ORC_TILE + (ln & 7), vv = (t / ntx) * ORC_TILE + (ln >> 3);
-                    if (u < W && vv < H) i = cidx[vv * W + u];
-                }
-                if (i >= 0) row_sums(src, tgt, Rf, tf, estimator, i, corr[i], v[l]);
-                else for (int k = 0; k < ORC_NSUMS; ++k) v[l][k] = 0.0;
+                if (u < W && vv < H) i = cidx[vv * W + u];
+                if (i >= 0) row_sums(src, tgt, Rf, tf, estimator, i, corr[i], v[ln]);
+                else for (int k = 0; k < ORC_NSUMS; ++k) v[ln][k] = 0.0;
             }
-            tree256(v);
-            memcpy(P1[c], v[0], sizeof(double) * ORC_NSUMS);
+            tree64(v);
+            memcpy(P1[t], v[0], sizeof(double) * ORC_NSUMS);
         }
         free(v);
     }

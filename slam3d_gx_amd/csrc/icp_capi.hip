@@ -24,9 +24,10 @@ struct slam3d_icp_handle {
     // device buffers
     float4 *own_src = nullptr, *own_tgt = nullptr, *nrm = nullptr, *src_c = nullptr, *tgt_c = nullptr;
     int *counts = nullptr, *ccounts = nullptr, *corr = nullptr, *flags = nullptr;
+    unsigned int *ticket = nullptr;
     unsigned long long *best = nullptr;
     float *cd2 = nullptr;
-    double *partials = nullptr, *sums = nullptr, *Tcur = nullptr, *trace_T = nullptr, *trace_S = nullptr, *d_Tinit = nullptr;
+    double *partials = nullptr, *GP = nullptr, *sums = nullptr, *Tcur = nullptr, *trace_T = nullptr, *trace_S = nullptr, *d_Tinit = nullptr;
     SlotPtrs *d_slots = nullptr;
     unsigned char *d_raw = nullptr; size_t raw_bytes = 0;
     uint16_t *d_depth = nullptr;
@@ -106,7 +107,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->own_src); F(h->own_tgt); F(h->nrm); F(h->src_c); F(h->tgt_c); F(h->counts); F(h->ccounts); F(h->corr);
     F(h->flags); F(h->best); F(h->cd2); F(h->partials); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
     F(h->d_Tinit); F(h->d_slots); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4);
-    F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox);
+    F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox); F(h->GP); F(h->ticket);
     if (h->pin_slots) (void)hipHostFree(h->pin_slots);
     if (h->pin_T) (void)hipHostFree(h->pin_T);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -157,7 +158,9 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     tg.ncoarse = tg.ncx * tg.ncy;
     tg.nchunks = (tg.ntiles + TILES_PER_CHUNK - 1) / TILES_PER_CHUNK;
     tg.nslots = tg.nchunks * CHUNK;
-    if ((tg.nchunks + CHUNK - 1) / CHUNK > RS_MAXGROUPS) { delete h; return SLAM3D_E_INVALID; }
+    tg.ngroups = (tg.ntiles + CHUNK - 1) / CHUNK;
+    tg.tpad = tg.ngroups * CHUNK;
+    if (tg.ngroups > RS_MAXGROUPS) { delete h; return SLAM3D_E_INVALID; }
     const size_t BN = (size_t)h->maxB * h->N;
     const size_t BS = (size_t)h->maxB * tg.nslots;
     const bool brute = nn_mode_of(h) != SLAM3D_NN_TILES;
@@ -169,7 +172,8 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     if (brute) { A(dalloc(h->src_c, BN)); A(dalloc(h->tgt_c, BN)); A(dalloc(h->best, BS)); }
     A(dalloc(h->counts, (size_t)h->maxB * 4)); A(dalloc(h->ccounts, (size_t)h->maxB * 4));
     A(dalloc(h->corr, BS)); A(dalloc(h->flags, (size_t)h->maxB)); A(dalloc(h->cd2, BS));
-    A(dalloc(h->partials, (size_t)h->maxB * tg.nchunks * NSUMS));
+    A(dalloc(h->partials, (size_t)h->maxB * NSUMS * tg.tpad));
+    A(dalloc(h->GP, (size_t)h->maxB * RS_MAXGROUPS * NSUMS)); A(dalloc(h->ticket, (size_t)h->maxB));
     A(dalloc(h->sums, (size_t)h->maxB * NSUMS)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
     A(dalloc(h->trace_T, (size_t)h->maxB * (iters + 1) * 16)); A(dalloc(h->trace_S, (size_t)h->maxB * iters * NSUMS));
     A(dalloc(h->d_Tinit, (size_t)h->maxB * 16)); A(dalloc(h->d_slots, (size_t)h->maxB));
@@ -191,6 +195,8 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     }
     h->h_slots.assign(h->maxB, SlotPtrs{ nullptr, nullptr });
     (void)hipMemsetAsync(h->counts, 0, sizeof(int) * 4 * h->maxB, h->stream);
+    (void)hipMemsetAsync(h->ticket, 0, sizeof(unsigned int) * h->maxB, h->stream);
+    (void)hipMemsetAsync(h->partials, 0, sizeof(double) * (size_t)h->maxB * NSUMS * tg.tpad, h->stream);   // padding tiles stay 0
     *out = h;
     return SLAM3D_OK;
 }
@@ -346,8 +352,8 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         hipLaunchKernelGGL(k_accumulate, dim3(tg.nchunks, B), dim3(CHUNK), 0, s, h->d_slots, h->nrm, h->srcT, h->Tcur, h->best,
                            h->corr, h->cd2, h->partials, h->g, tg);
     }
-    hipLaunchKernelGGL(k_reduce_solve, dim3(B), dim3(RS_THREADS), 0, s, h->partials, h->sums, h->Tcur, h->trace_T, h->trace_S,
-                       h->flags, tg, it, iters, h->p.estimator, do_solve);
+    hipLaunchKernelGGL(k_reduce_solve, dim3(tg.ngroups, B), dim3(CHUNK), 0, s, h->partials, h->GP, h->ticket, h->sums, h->Tcur,
+                       h->trace_T, h->trace_S, h->flags, tg, it, iters, h->p.estimator, do_solve);
     HIPCHK(h, hipGetLastError());
     return SLAM3D_OK;
 }

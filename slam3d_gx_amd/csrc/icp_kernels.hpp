@@ -189,14 +189,17 @@ __global__ __launch_bounds__(NRM_BX * NRM_BY) void k_normals(const SlotPtrs *__r
 
 // ------------------------------------------------------------------------------------ S3
 // Both organized clouds are cut into 8x8-pixel tiles: one wavefront = one tile = 64 slots.
-// Source slot id = tile*64 + (v%8)*8 + (u%8) is ALSO the summation order of S4 (chunks of 256
-// slots = 4 consecutive tiles).  Correspondences refer to targets by ORIGINAL pixel index j.
+// Source slot id = tile*64 + (v%8)*8 + (u%8) is ALSO the summation order of S4 (level 1: the 64
+// slots of a tile, level 2: groups of 256 tiles).  Correspondences refer to targets by ORIGINAL
+// pixel index j.
 constexpr int TILE_PX = 8;                 // tile edge in pixels
 constexpr int TILE_SLOTS = 64;             // = one wavefront
 constexpr int COARSE_TILES = 8;            // coarse box edge in tiles (64 px)
 constexpr int TILES_PER_CHUNK = CHUNK / TILE_SLOTS;
 
-struct TileGrid { int ntx, nty, ntiles, ncx, ncy, ncoarse, nchunks, nslots; };
+// nchunks = launch blocks of 4 tiles, nslots = padded slot count, ngroups = level-2 groups,
+// tpad = ngroups*256 (padded tile count: row length of the component-major tile partials)
+struct TileGrid { int ntx, nty, ntiles, ncx, ncy, ncoarse, nchunks, nslots, ngroups, tpad; };
 
 __device__ __forceinline__ float wave_min(float v)
 {
@@ -449,36 +452,16 @@ __device__ __forceinline__ double wave_tree64(double x)
     return x;      // valid in lane 0
 }
 
-constexpr int ACC_LDS_DOUBLES = NSUMS * 128;
-
-// Chunk reduction of 256 slots held one-per-thread (4 waves): levels 128 and 64 of the tree are
-// wave-to-wave adds through LDS (wave0 += wave2, wave1 += wave3; wave0 += wave1), the rest are
-// in-wave shuffles.  Same association order as tree256 in the oracle.  All 256 threads must call.
-__device__ __forceinline__ void chunk_reduce_store(double *__restrict__ s, double *__restrict__ sh /*ACC_LDS_DOUBLES*/,
-                                                   double *__restrict__ out29)
+// Level 1 of the spec's reduction: the wave's 64 slots by shuffles; lane 0 stores the tile's 29
+// partial sums component-major (TP[k][tile]) so that level 2 reads them coalesced.
+__device__ __forceinline__ void tile_reduce_store(const double *__restrict__ s, double *__restrict__ TPb /*[29][tpad]*/,
+                                                  int tile, int tpad)
 {
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (w >= 2) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-        for (int k = 0; k < NSUMS; ++k) sh[k * 128 + (w - 2) * 64 + lane] = s[k];
-    }
-    __syncthreads();
-    if (w < 2) {
-#pragma unroll
-        for (int k = 0; k < NSUMS; ++k) s[k] = s[k] + sh[k * 128 + w * 64 + lane];
-    }
-    __syncthreads();
-    if (w == 1) {
-#pragma unroll
-        for (int k = 0; k < NSUMS; ++k) sh[k * 128 + lane] = s[k];
-    }
-    __syncthreads();
-    if (w == 0) {
-#pragma unroll
-        for (int k = 0; k < NSUMS; ++k) {
-            const double x = wave_tree64(s[k] + sh[k * 128 + lane]);
-            if (lane == 0) out29[k] = x;
-        }
+    for (int k = 0; k < NSUMS; ++k) {
+        const double x = wave_tree64(s[k]);
+        if (lane == 0) TPb[(size_t)k * tpad + tile] = x;
     }
 }
 
@@ -503,21 +486,21 @@ __device__ __forceinline__ void finish_slot(bool valid, unsigned long long key, 
     }
 }
 
-// accumulation for the brute-force modes: grid (nchunks, B), one thread per source slot
+// accumulation for the brute-force modes: grid (nchunks, B), one thread per source slot, one wave per tile
 __global__ __launch_bounds__(CHUNK) void k_accumulate(const SlotPtrs *__restrict__ slots,
                                                       const float4 *__restrict__ nrm_all,
                                                       const float4 *__restrict__ srcT,
                                                       const double *__restrict__ Tcur,
                                                       unsigned long long *__restrict__ best,
                                                       int *__restrict__ corr, float *__restrict__ cd2,
-                                                      double *__restrict__ partials, Geometry g, TileGrid tg)
+                                                      double *__restrict__ TP, Geometry g, TileGrid tg)
 {
-    __shared__ double sh[ACC_LDS_DOUBLES];
     const int b = blockIdx.y, c = blockIdx.x;
+    const int t = c * TILES_PER_CHUNK + (threadIdx.x >> 6);
+    if (t >= tg.ntiles) return;
     const int slot = c * CHUNK + threadIdx.x;
     const size_t gs = (size_t)b * tg.nslots + slot;
-    float4 sp = make_float4(0, 0, 0, __int_as_float(-1));
-    if (slot < tg.ntiles * TILE_SLOTS) sp = srcT[(size_t)b * tg.ntiles * TILE_SLOTS + slot];
+    const float4 sp = srcT[(size_t)b * tg.ntiles * TILE_SLOTS + slot];
     const bool valid = __float_as_int(sp.w) >= 0;
     const Rt m = load_rt(Tcur + b * 16);
     float px, py, pz;
@@ -526,7 +509,7 @@ __global__ __launch_bounds__(CHUNK) void k_accumulate(const SlotPtrs *__restrict
     best[gs] = ~0ull;
     double s[NSUMS];
     finish_slot(valid, key, px, py, pz, slots[b].tgt, nrm_all + (size_t)b * g.N, g.gate2, g.estimator, corr + gs, cd2 + gs, s);
-    chunk_reduce_store(s, sh, partials + ((size_t)b * tg.nchunks + c) * NSUMS);
+    tile_reduce_store(s, TP + (size_t)b * NSUMS * tg.tpad, t, tg.tpad);
 }
 
 // ------------------------------------------------------------------ S4, tile-pruned exact NN
@@ -549,7 +532,7 @@ __device__ __forceinline__ float box_gap2(const float4 lo, const float4 hi, floa
     return gx * gx + gy * gy + gz * gz;      // empty boxes (lo=+inf, hi=-inf) give +inf
 }
 
-// grid (nchunks, B), block 256 = 4 waves = 4 consecutive source tiles = one summation chunk
+// grid (nchunks, B), block 256 = 4 independent waves = 4 consecutive source tiles (no barriers, no LDS)
 __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restrict__ slots,
                                                         const float4 *__restrict__ nrm_all,
                                                         const float4 *__restrict__ srcT,
@@ -558,19 +541,18 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
                                                         const float4 *__restrict__ cbox,
                                                         const double *__restrict__ Tcur,
                                                         int *__restrict__ corr, float *__restrict__ cd2,
-                                                        double *__restrict__ partials, Geometry g, TileGrid tg)
+                                                        double *__restrict__ TP, Geometry g, TileGrid tg)
 {
-    __shared__ double sh[ACC_LDS_DOUBLES];
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.y, c = blockIdx.x;
     const int t = __builtin_amdgcn_readfirstlane(c * TILES_PER_CHUNK + (threadIdx.x >> 6));
+    if (t >= tg.ntiles) return;
     const int slot = c * CHUNK + threadIdx.x;
     const size_t gs = (size_t)b * tg.nslots + slot;
     const float inf = __int_as_float(0x7f800000);
     const float4 *__restrict__ tcloud = slots[b].tgt;
     const float4 *__restrict__ tnrm = nrm_all + (size_t)b * g.N;
-    float4 s4 = make_float4(0, 0, 0, __int_as_float(-1));
-    if (t < tg.ntiles) s4 = srcT[((size_t)b * tg.ntiles + t) * TILE_SLOTS + lane];
+    const float4 s4 = srcT[((size_t)b * tg.ntiles + t) * TILE_SLOTS + lane];
     const int pix = __float_as_int(s4.w);
     const bool valid = pix >= 0;
     const Rt m = load_rt(Tcur + b * 16);
@@ -655,10 +637,10 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
             }
         }
     }
-    // ---- fused S4 accumulation of this chunk (4 tiles = 256 slots)
+    // ---- fused S4 accumulation, level 1: this tile's 64 slots
     double s[NSUMS];
     finish_slot(valid, bkey, px, py, pz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, s);
-    chunk_reduce_store(s, sh, partials + ((size_t)b * tg.nchunks + c) * NSUMS);
+    tile_reduce_store(s, TP + (size_t)b * NSUMS * tg.tpad, t, tg.tpad);
 }
 
 // ------------------------------------------------------------------------------------ S5
@@ -844,39 +826,62 @@ __device__ inline void solve_update_one(const double *__restrict__ sums, double 
     for (int k = 0; k < 16; ++k) trace_T_b[(size_t)(it + 1) * 16 + k] = T[k];
 }
 
-constexpr int RS_THREADS = 1024;
 constexpr int RS_MAXGROUPS = 64;
 
-// grid (B), block 1024 (16 waves).  Levels 2 and 3 of the reduction: each (group g of 256 chunk
-// partials, component k) is one wave-sized tree -- lane l adds chunks (l, l+128) and (l+64, l+192),
-// then those two, then shuffles -- exactly tree256's association; group results are summed in order.
-// do_solve = 0 leaves only the sums (dense multi-GPU mode reduces them across ranks first).
-__global__ __launch_bounds__(RS_THREADS) void k_reduce_solve(const double *__restrict__ partials,
-                                                             double *__restrict__ sums_all,
-                                                             double *__restrict__ Tcur, double *__restrict__ trace_T,
-                                                             double *__restrict__ trace_S, int *__restrict__ flags,
-                                                             TileGrid tg, int it, int iters, int estimator, int do_solve)
+// Levels 2 and 3 of the reduction + solve.  grid (ngroups, B), block 256 (4 waves).  Block g reduces
+// group g (256 tile partials) of every component: one wave per tree -- lane l adds tiles (l, l+128)
+// and (l+64, l+192), then those two, then shuffles: exactly tree256's association.  The block that
+// finishes last (device-scope ticket) sums the group results in ascending order (level 3) and, when
+// do_solve, runs the 6x6 / 3x3 solve and the SE(3) update.  TP rows are zero beyond ntiles.
+__global__ __launch_bounds__(CHUNK) void k_reduce_solve(const double *__restrict__ TP, double *__restrict__ GP,
+                                                        unsigned int *__restrict__ ticket,
+                                                        double *__restrict__ sums_all,
+                                                        double *__restrict__ Tcur, double *__restrict__ trace_T,
+                                                        double *__restrict__ trace_S, int *__restrict__ flags,
+                                                        TileGrid tg, int it, int iters, int estimator, int do_solve)
 {
-    __shared__ double P2[RS_MAXGROUPS * NSUMS];
     __shared__ double tot[NSUMS];
-    const int b = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int nchunks = tg.nchunks;
-    const int ngroups = (nchunks + CHUNK - 1) / CHUNK;
-    const double *__restrict__ P = partials + (size_t)b * nchunks * NSUMS;
-    for (int tree = w; tree < ngroups * NSUMS; tree += RS_THREADS / 64) {
-        const int gq = tree / NSUMS, k = tree - gq * NSUMS;
-        const int c0 = gq * CHUNK + lane;
-        const double v0 = c0 < nchunks ? P[(size_t)c0 * NSUMS + k] : 0.0;
-        const double v1 = c0 + 64 < nchunks ? P[(size_t)(c0 + 64) * NSUMS + k] : 0.0;
-        const double v2 = c0 + 128 < nchunks ? P[(size_t)(c0 + 128) * NSUMS + k] : 0.0;
-        const double v3 = c0 + 192 < nchunks ? P[(size_t)(c0 + 192) * NSUMS + k] : 0.0;
-        const double x = wave_tree64((v0 + v2) + (v1 + v3));
-        if (lane == 0) P2[gq * NSUMS + k] = x;
+    __shared__ int is_last;
+    const int gq = blockIdx.x, b = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double *__restrict__ P = TP + (size_t)b * NSUMS * tg.tpad + (size_t)gq * CHUNK + lane;
+    double *__restrict__ G = GP + (size_t)b * RS_MAXGROUPS * NSUMS;
+    double x[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int k = w + 4 * r;
+        x[r] = 0.0;
+        if (k < NSUMS) {
+            const double *__restrict__ Pk = P + (size_t)k * tg.tpad;
+            x[r] = (Pk[0] + Pk[128]) + (Pk[64] + Pk[192]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int k = w + 4 * r;
+        const double y = wave_tree64(x[r]);
+        if (k < NSUMS && lane == 0) G[gq * NSUMS + k] = y;
+    }
+    // publish this group's 29 sums and take a ticket.  Inter-workgroup hand-off on gfx950 (per-CU L1 and
+    // per-XCD L2 are not coherent): every wave drains its stores, one lane does the agent-scope release
+    // before the ticket and, in the last block, the agent-scope acquire before the plain re-reads.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int prev = __hip_atomic_fetch_add(ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (prev == (unsigned int)(tg.ngroups - 1));
+        if (is_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(ticket + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
     }
     __syncthreads();
+    if (!is_last) return;
     if (threadIdx.x < NSUMS) {
-        double a = P2[threadIdx.x];
-        for (int gq = 1; gq < ngroups; ++gq) a = a + P2[gq * NSUMS + threadIdx.x];
+        const double *Gv = G;
+        double a = Gv[threadIdx.x];
+        for (int q = 1; q < tg.ngroups; ++q) a = a + Gv[q * NSUMS + threadIdx.x];
         tot[threadIdx.x] = a;
         sums_all[b * NSUMS + threadIdx.x] = a;
     }
