@@ -153,6 +153,10 @@ int slam3d_icp_get_clouds(slam3d_icp_handle *h, int32_t slot, float *src_xyz4, f
 int slam3d_icp_get_timings(slam3d_icp_handle *h, float ms[4]);
 /* duration of each iteration's NN launch of the last run (ms), nn_ms[iterations] */
 int slam3d_icp_get_iteration_timings(slam3d_icp_handle *h, float *nn_ms);
+/* developer statistics of the LAST NN launch (slot 0), 8 int64 per source tile: clock at start / after
+ * prologue / after the 3x3 scan / after the wide scan / at the end, tiles scanned, candidates, batches.
+ * Only available when the handle was created with SLAM3D_NN_DEBUG=1 in the environment. */
+int slam3d_icp_get_nn_debug(slam3d_icp_handle *h, int64_t *out, int32_t n);
 
 /* ---- building blocks (rows a5, a6 of the scope table) ------------------------------------ */
 /* u16 depth (host) -> organized float4 cloud (host); src/convert2PCD.cpp:54-72 */

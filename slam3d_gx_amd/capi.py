@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "slam3d_icp_align_depth_batch", "slam3d_icp_set_clouds_host", "slam3d_icp_set_depth_host",
     "slam3d_icp_set_clouds_device", "slam3d_icp_set_depth_device", "slam3d_icp_run",
     "slam3d_icp_fetch_results", "slam3d_icp_get_correspondences", "slam3d_icp_get_trace",
-    "slam3d_icp_get_clouds", "slam3d_icp_get_timings", "slam3d_icp_get_iteration_timings", "slam3d_backproject_u16", "slam3d_fit_planes",
+    "slam3d_icp_get_clouds", "slam3d_icp_get_timings", "slam3d_icp_get_iteration_timings", "slam3d_icp_get_nn_debug", "slam3d_backproject_u16", "slam3d_fit_planes",
     "slam3d_icp_dense_set_rows", "slam3d_icp_dense_begin", "slam3d_icp_dense_partial",
     "slam3d_icp_dense_update", "slam3d_icp_dense_finish",
 ]
@@ -237,6 +237,12 @@ class IcpHandle:
         ms = np.zeros(max(self.params.iterations, 1), dtype=np.float32)
         self._check(self.lib.slam3d_icp_get_iteration_timings(self._h, _vp(ms)), False)
         return ms[: self.params.iterations]
+
+    def get_nn_debug(self) -> np.ndarray:
+        nt = ((self.params.width + 7) // 8) * ((self.params.height + 7) // 8)
+        out = np.zeros(nt * 10, dtype=np.int64)
+        self._check(self.lib.slam3d_icp_get_nn_debug(self._h, _vp(out), C.c_int32(out.size)), False)
+        return np.concatenate([out[: nt * 8].reshape(nt, 8), out[nt * 8:].reshape(nt, 2)], axis=1)
 
     # ---- building blocks ---------------------------------------------------------------
     def backproject_u16(self, depth: np.ndarray) -> np.ndarray:

@@ -35,7 +35,9 @@ struct slam3d_icp_handle {
     float4 *d_scratch4 = nullptr;
     // 8x8-pixel tiles (slot order of the sums; target tiles + boxes for the pruned NN)
     TileGrid tg;
-    float4 *srcT = nullptr, *tgtT = nullptr, *tbox = nullptr, *cbox = nullptr;
+    float4 *srcT = nullptr, *tgtT = nullptr, *tbox = nullptr, *cbox = nullptr, *prevq = nullptr;
+    long long *dbg = nullptr;     // per-tile NN statistics, only with SLAM3D_NN_DEBUG=1
+    int *hint = nullptr;          // per source tile: target tile where the previous matches were
     // host
     std::vector<SlotPtrs> h_slots;
     SlotPtrs *pin_slots = nullptr;
@@ -107,7 +109,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->own_src); F(h->own_tgt); F(h->nrm); F(h->src_c); F(h->tgt_c); F(h->counts); F(h->ccounts); F(h->corr);
     F(h->flags); F(h->best); F(h->cd2); F(h->partials); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
     F(h->d_Tinit); F(h->d_slots); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4);
-    F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox); F(h->GP); F(h->ticket);
+    F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox); F(h->GP); F(h->ticket); F(h->dbg); F(h->prevq); F(h->hint);
     if (h->pin_slots) (void)hipHostFree(h->pin_slots);
     if (h->pin_T) (void)hipHostFree(h->pin_T);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -171,9 +173,11 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     A(dalloc(h->own_src, BN)); A(dalloc(h->own_tgt, BN)); A(dalloc(h->nrm, BN));
     if (brute) { A(dalloc(h->src_c, BN)); A(dalloc(h->tgt_c, BN)); A(dalloc(h->best, BS)); }
     A(dalloc(h->counts, (size_t)h->maxB * 4)); A(dalloc(h->ccounts, (size_t)h->maxB * 4));
-    A(dalloc(h->corr, BS)); A(dalloc(h->flags, (size_t)h->maxB)); A(dalloc(h->cd2, BS));
+    A(dalloc(h->corr, BS)); A(dalloc(h->flags, (size_t)h->maxB)); A(dalloc(h->cd2, BS)); A(dalloc(h->prevq, BS));
     A(dalloc(h->partials, (size_t)h->maxB * NSUMS * tg.tpad));
     A(dalloc(h->GP, (size_t)h->maxB * RS_MAXGROUPS * NSUMS)); A(dalloc(h->ticket, (size_t)h->maxB));
+    A(dalloc(h->hint, (size_t)h->maxB * tg.ntiles));
+    if (getenv("SLAM3D_NN_DEBUG")) A(dalloc(h->dbg, (size_t)tg.ntiles * 10));
     A(dalloc(h->sums, (size_t)h->maxB * NSUMS)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
     A(dalloc(h->trace_T, (size_t)h->maxB * (iters + 1) * 16)); A(dalloc(h->trace_S, (size_t)h->maxB * iters * NSUMS));
     A(dalloc(h->d_Tinit, (size_t)h->maxB * 16)); A(dalloc(h->d_slots, (size_t)h->maxB));
@@ -311,7 +315,9 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
     const bool brute = nn_mode_of(h) != SLAM3D_NN_TILES;
     const TileGrid &tg = h->tg;
     HIPCHK(h, hipMemsetAsync(h->counts, 0, sizeof(int) * 4 * (size_t)B, s));
-    HIPCHK(h, hipMemsetAsync(h->corr, 0xFF, sizeof(int) * (size_t)B * tg.nslots, s));   // no previous match yet
+    HIPCHK(h, hipMemsetAsync(h->corr, 0xFF, sizeof(int) * (size_t)B * tg.nslots, s));      // no previous match yet
+    HIPCHK(h, hipMemsetAsync(h->prevq, 0xFF, sizeof(float4) * (size_t)B * tg.nslots, s));  // (w = -1)
+    HIPCHK(h, hipMemsetAsync(h->hint, 0xFF, sizeof(int) * (size_t)B * tg.ntiles, s));
     const int use_normals = h->p.estimator == SLAM3D_EST_POINT2PLANE ? 1 : 0;
     if (use_normals) {
         dim3 grid((g.W + NRM_BX - 1) / NRM_BX, (g.H + NRM_BY - 1) / NRM_BY, B);
@@ -341,7 +347,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
     if (e0) HIPCHK(h, hipEventRecord(e0, s));
     if (nn_mode_of(h) == SLAM3D_NN_TILES) {
         hipLaunchKernelGGL(k_nn_tiles_acc, dim3(tg.nchunks, B), dim3(CHUNK), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
-                           h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->partials, h->g, tg);
+                           h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, h->partials, h->g, tg, h->dbg);
         if (e1) HIPCHK(h, hipEventRecord(e1, s));
     } else {
         const int nsplit = pick_nsplit(h, B);
@@ -350,7 +356,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
                            h->best, h->N, tg.nslots, nsplit);
         if (e1) HIPCHK(h, hipEventRecord(e1, s));
         hipLaunchKernelGGL(k_accumulate, dim3(tg.nchunks, B), dim3(CHUNK), 0, s, h->d_slots, h->nrm, h->srcT, h->Tcur, h->best,
-                           h->corr, h->cd2, h->partials, h->g, tg);
+                           h->corr, h->cd2, h->prevq, h->partials, h->g, tg);
     }
     hipLaunchKernelGGL(k_reduce_solve, dim3(tg.ngroups, B), dim3(CHUNK), 0, s, h->partials, h->GP, h->ticket, h->sums, h->Tcur,
                        h->trace_T, h->trace_S, h->flags, tg, it, iters, h->p.estimator, do_solve);
@@ -542,6 +548,16 @@ extern "C" int slam3d_icp_get_timings(slam3d_icp_handle *h, float ms[4])
         nn += t;
     }
     ms[0] = pre; ms[1] = nn; ms[2] = tot - pre - nn; ms[3] = tot;
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_get_nn_debug(slam3d_icp_handle *h, int64_t *out /* ntiles*8 */, int32_t n)
+{
+    if (!h || !out) return SLAM3D_E_INVALID;
+    if (!h->dbg || !h->ran || n < h->tg.ntiles * 10) return SLAM3D_E_STATE;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    HIPCHK(h, hipStreamSynchronize(h->run_stream));
+    HIPCHK(h, hipMemcpy(out, h->dbg, sizeof(long long) * (size_t)h->tg.ntiles * 10, hipMemcpyDeviceToHost));
     return SLAM3D_OK;
 }
 

@@ -201,17 +201,38 @@ constexpr int TILES_PER_CHUNK = CHUNK / TILE_SLOTS;
 // tpad = ngroups*256 (padded tile count: row length of the component-major tile partials)
 struct TileGrid { int ntx, nty, ntiles, ncx, ncy, ncoarse, nchunks, nslots, ngroups, tpad; };
 
+// ---- wave64 cross-lane helpers on the VALU (DPP within a 16-lane row, v_permlane16/32_swap across
+// rows -- gfx950); no LDS round trips.  Inputs are never NaN here (+-inf marks "no value").
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float rdlane(float v, int lane_uniform)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
+}
+__device__ __forceinline__ float fmin_nn(float a, float b) { return b < a ? b : a; }
+__device__ __forceinline__ float fmax_nn(float a, float b) { return b > a ? b : a; }
+
+// all-lanes min / max: xor-1, xor-2 (quad_perm), row_half_mirror, row_mirror, then rows 0<->1 / 2<->3
+// (v_permlane16_swap) and halves (v_permlane32_swap)
 __device__ __forceinline__ float wave_min(float v)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
+    v = fmin_nn(v, dpp_f<0xB1>(v)); v = fmin_nn(v, dpp_f<0x4E>(v));
+    v = fmin_nn(v, dpp_f<0x141>(v)); v = fmin_nn(v, dpp_f<0x140>(v));
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+    v = fmin_nn(__int_as_float(r[0]), __int_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+    return fmin_nn(__int_as_float(r[0]), __int_as_float(r[1]));
 }
 __device__ __forceinline__ float wave_max(float v)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
+    v = fmax_nn(v, dpp_f<0xB1>(v)); v = fmax_nn(v, dpp_f<0x4E>(v));
+    v = fmax_nn(v, dpp_f<0x141>(v)); v = fmax_nn(v, dpp_f<0x140>(v));
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
+    v = fmax_nn(__int_as_float(r[0]), __int_as_float(r[1]));
+    r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
+    return fmax_nn(__int_as_float(r[0]), __int_as_float(r[1]));
 }
 
 // grid (ntiles, 2, B), block 64.  srcT slot w = pixel index (int bits) or -1; rows outside
@@ -444,32 +465,86 @@ __device__ __forceinline__ void row_sums(int estimator, float pxf, float pyf, fl
     }
 }
 
-// wave part of the spec's 256-element tree: levels 32,16,..,1 (a[i] += a[i+s], i < s) as shuffles
+// the spec's tree64: levels s = 32,16,..,1 of a[i] += a[i+s] (i < s).  Lane i obtains a[i+s] with
+// v_permlane32_swap (s=32: lower half <- upper half), v_permlane16_swap (s=16: row 0 <- row 1) and
+// DPP row_shl:s (s = 8,4,2,1, inside a 16-lane row); two 32-bit moves per double, no LDS.
+template <int CTRL> __device__ __forceinline__ double dpp_d(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_tree64(double x)
 {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) x = x + __shfl_down(x, o);
+    {
+        const int lo = __double2loint(x), hi = __double2hiint(x);
+        const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        x = x + __hiloint2double(rh[1], rl[1]);
+    }
+    {
+        const int lo = __double2loint(x), hi = __double2hiint(x);
+        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        x = x + __hiloint2double(rh[1], rl[1]);
+    }
+    x = x + dpp_d<0x108>(x);
+    x = x + dpp_d<0x104>(x);
+    x = x + dpp_d<0x102>(x);
+    x = x + dpp_d<0x101>(x);
     return x;      // valid in lane 0
 }
 
-// Level 1 of the spec's reduction: the wave's 64 slots by shuffles; lane 0 stores the tile's 29
-// partial sums component-major (TP[k][tile]) so that level 2 reads them coalesced.
+// tree64 of FOUR components at once (same association as wave_tree64 for each of them):
+//   level 32: v_permlane32_swap(a, b) puts a's lower/upper halves side by side with b's, so ONE add yields
+//             a[i]+a[i+32] in lanes 0..31 and b[i]+b[i+32] in lanes 32..63;
+//   level 16: v_permlane16_swap on two such registers -> rows 0..3 hold components (a, c, b, d);
+//   levels 8..1: DPP row_shl inside each 16-lane row.  Result: lanes 0,16,32,48 hold the sums of a,c,b,d.
+__device__ __forceinline__ double swap32_add(double a, double b)
+{
+    const auto rl = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);   // (a_lo | b_lo) + (a_hi | b_hi)
+}
+__device__ __forceinline__ double swap16_add(double x, double y)
+{
+    const auto rl = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
+    return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);   // rows (x0|y0|x2|y2) + (x1|y1|x3|y3)
+}
+__device__ __forceinline__ double wave_tree64_x4(double a, double b, double c, double d)
+{
+    double x = swap16_add(swap32_add(a, b), swap32_add(c, d));
+    x = x + dpp_d<0x108>(x);
+    x = x + dpp_d<0x104>(x);
+    x = x + dpp_d<0x102>(x);
+    x = x + dpp_d<0x101>(x);
+    return x;      // lane 0: a, lane 16: c, lane 32: b, lane 48: d
+}
+
+// Level 1 of the spec's reduction: the wave's 64 slots; the tile's 29 partial sums are stored
+// component-major (TP[k][tile]) so that level 2 reads them coalesced.
 __device__ __forceinline__ void tile_reduce_store(const double *__restrict__ s, double *__restrict__ TPb /*[29][tpad]*/,
                                                   int tile, int tpad)
 {
     const int lane = threadIdx.x & 63;
+    const int sel = lane >> 4;                       // row -> which of (a, c, b, d)
+    const int koff = sel == 0 ? 0 : (sel == 1 ? 2 : (sel == 2 ? 1 : 3));
 #pragma unroll
-    for (int k = 0; k < NSUMS; ++k) {
-        const double x = wave_tree64(s[k]);
-        if (lane == 0) TPb[(size_t)k * tpad + tile] = x;
+    for (int k = 0; k < 28; k += 4) {
+        const double x = wave_tree64_x4(s[k], s[k + 1], s[k + 2], s[k + 3]);
+        if ((lane & 15) == 0) TPb[(size_t)(k + koff) * tpad + tile] = x;
     }
+    const double x = wave_tree64(s[28]);
+    if (lane == 0) TPb[(size_t)28 * tpad + tile] = x;
 }
 
 // decode a packed NN key, apply the gate, record the correspondence and form the row products
 __device__ __forceinline__ void finish_slot(bool valid, unsigned long long key, float px, float py, float pz,
                                             const float4 *__restrict__ tcloud, const float4 *__restrict__ tnrm,
                                             float gate2, int estimator, int *__restrict__ corr_out,
-                                            float *__restrict__ cd2_out, double *__restrict__ s)
+                                            float *__restrict__ cd2_out, float4 *__restrict__ prevq_out,
+                                            double *__restrict__ s)
 {
 #pragma unroll
     for (int k = 0; k < NSUMS; ++k) s[k] = 0.0;
@@ -478,12 +553,15 @@ __device__ __forceinline__ void finish_slot(bool valid, unsigned long long key, 
     const bool ok = valid && (j >= 0) && (d2 <= gate2);
     *corr_out = ok ? j : -1;
     *cd2_out = ok ? d2 : __int_as_float(0x7f800000);
+    float4 pq = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
     if (ok) {
         const float4 q4 = tcloud[j];
         float4 n4 = make_float4(0, 0, 0, 0);
         if (estimator == 0) n4 = tnrm[j];
         row_sums(estimator, px, py, pz, q4, n4, s);
+        pq = make_float4(q4.x, q4.y, q4.z, __int_as_float(j));
     }
+    *prevq_out = pq;        // next iteration's upper bound comes from this point (no dependent gather)
 }
 
 // accumulation for the brute-force modes: grid (nchunks, B), one thread per source slot, one wave per tile
@@ -493,6 +571,7 @@ __global__ __launch_bounds__(CHUNK) void k_accumulate(const SlotPtrs *__restrict
                                                       const double *__restrict__ Tcur,
                                                       unsigned long long *__restrict__ best,
                                                       int *__restrict__ corr, float *__restrict__ cd2,
+                                                      float4 *__restrict__ prevq,
                                                       double *__restrict__ TP, Geometry g, TileGrid tg)
 {
     const int b = blockIdx.y, c = blockIdx.x;
@@ -508,7 +587,8 @@ __global__ __launch_bounds__(CHUNK) void k_accumulate(const SlotPtrs *__restrict
     const unsigned long long key = best[gs];
     best[gs] = ~0ull;
     double s[NSUMS];
-    finish_slot(valid, key, px, py, pz, slots[b].tgt, nrm_all + (size_t)b * g.N, g.gate2, g.estimator, corr + gs, cd2 + gs, s);
+    finish_slot(valid, key, px, py, pz, slots[b].tgt, nrm_all + (size_t)b * g.N, g.gate2, g.estimator, corr + gs, cd2 + gs,
+                prevq + gs, s);
     tile_reduce_store(s, TP + (size_t)b * NSUMS * tg.tpad, t, tg.tpad);
 }
 
@@ -532,7 +612,14 @@ __device__ __forceinline__ float box_gap2(const float4 lo, const float4 hi, floa
     return gx * gx + gy * gy + gz * gz;      // empty boxes (lo=+inf, hi=-inf) give +inf
 }
 
-// grid (nchunks, B), block 256 = 4 independent waves = 4 consecutive source tiles (no barriers, no LDS)
+constexpr int NN_STAGE = 8;          // target tiles staged in LDS per batch (8 KB per wave, 32 KB per block)
+
+// grid (nchunks, B), block 256 = 4 independent waves = 4 consecutive source tiles (no block barriers).
+// Latency structure: everything the wave will certainly need is requested in ONE round of loads at
+// the top (source slot, previous match point, same-pixel target, the first 8 tiles of the 3x3
+// neighbourhood, the coarse boxes and the child boxes of the own coarse cell).  Candidate tiles are
+// parked in this wave's private LDS slab and scanned with broadcast ds_read_b128 (every lane reads
+// the same candidate); all cross-lane reductions are DPP / permlane (VALU rate).
 __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restrict__ slots,
                                                         const float4 *__restrict__ nrm_all,
                                                         const float4 *__restrict__ srcT,
@@ -541,44 +628,88 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
                                                         const float4 *__restrict__ cbox,
                                                         const double *__restrict__ Tcur,
                                                         int *__restrict__ corr, float *__restrict__ cd2,
-                                                        double *__restrict__ TP, Geometry g, TileGrid tg)
+                                                        float4 *__restrict__ prevq, int *__restrict__ hint,
+                                                        double *__restrict__ TP, Geometry g, TileGrid tg,
+                                                        long long *__restrict__ dbg /* nullable: 8 x int64 per tile */)
 {
+    __shared__ float4 stage_all[TILES_PER_CHUNK][NN_STAGE * TILE_SLOTS];
+    const long long clk0 = dbg ? clock64() : 0;
+    long long clk1 = 0, clk2 = 0, clk3 = 0, clk2a = 0, clk2b = 0;
+    int n_scanned = 0, n_cand = 0, n_batches = 0, n_chit = 0, n_fhit = 0, n_refined = 0;
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.y, c = blockIdx.x;
-    const int t = __builtin_amdgcn_readfirstlane(c * TILES_PER_CHUNK + (threadIdx.x >> 6));
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = c * TILES_PER_CHUNK + w;
     if (t >= tg.ntiles) return;
+    float4 *__restrict__ st = stage_all[w];
     const int slot = c * CHUNK + threadIdx.x;
     const size_t gs = (size_t)b * tg.nslots + slot;
     const float inf = __int_as_float(0x7f800000);
     const float4 *__restrict__ tcloud = slots[b].tgt;
     const float4 *__restrict__ tnrm = nrm_all + (size_t)b * g.N;
+    const float4 *__restrict__ TB = tbox + (size_t)b * tg.ntiles * 2;
+    const float4 *__restrict__ CB = cbox + (size_t)b * tg.ncoarse * 2;
+    const float4 *__restrict__ TT = tgtT + (size_t)b * tg.ntiles * TILE_SLOTS;
     const float4 s4 = srcT[((size_t)b * tg.ntiles + t) * TILE_SLOTS + lane];
     const int pix = __float_as_int(s4.w);
     const bool valid = pix >= 0;
-    const Rt m = load_rt(Tcur + b * 16);
-    float px, py, pz;
-    xform(m, s4.x, s4.y, s4.z, px, py, pz);
     unsigned long long bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
+    float px = 0.0f, py = 0.0f, pz = 0.0f;
     if (__ballot(valid) != 0ull) {
-        // ---- upper bound: previous match, else the target at the same pixel, else the gate
-        int jg = -1;
-        if (valid) {
-            jg = corr[gs];
-            if (jg < 0) jg = pix;
+        // centre of the first (3x3) scan: where this tile's matches were in the previous iteration (a hint
+        // only -- exactness never depends on it); initially the same image location
+        const int th = __builtin_amdgcn_readfirstlane(hint[(size_t)b * tg.ntiles + t]);
+        const int tc = (th >= 0 && th < tg.ntiles) ? th : t;
+        const int tx0 = tc % tg.ntx, ty0 = tc / tg.ntx;
+        const int cown = (ty0 / COARSE_TILES) * tg.ncx + tx0 / COARSE_TILES;     // coarse cell of that centre
+        int tt[NN_STAGE];
+        float4 r[NN_STAGE];
+        // ---- phase A tile list: centre, edge neighbours, three corners of the 3x3 block at the same location
+        {
+            const int ox[NN_STAGE] = { 0, -1, 1, 0, 0, -1, 1, -1 }, oy[NN_STAGE] = { 0, 0, 0, -1, 1, -1, -1, 1 };
+#pragma unroll
+            for (int k = 0; k < NN_STAGE; ++k) {
+                const int tx = tx0 + ox[k], ty = ty0 + oy[k];
+                tt[k] = (tx >= 0 && tx < tg.ntx && ty >= 0 && ty < tg.nty) ? ty * tg.ntx + tx : -1;
+            }
         }
-        if (jg >= 0) {
-            const float4 q = tcloud[jg];
-            bool tv = pt_valid(q.x, q.y, q.z, g.zmax);
-            if (tv && g.estimator == 0) tv = tnrm[jg].w > 0.5f;
-            const float d2g = canon_d2(px, py, pz, q.x, q.y, q.z);
+        // ---- one round of independent loads
+#pragma unroll
+        for (int k = 0; k < NN_STAGE; ++k)
+            r[k] = tt[k] >= 0 ? TT[(size_t)tt[k] * TILE_SLOTS + lane] : make_float4(inf, inf, inf, __int_as_float(-1));
+        const float4 pq = prevq[gs];
+        float4 qs = make_float4(0, 0, 0, 0);
+        float ws = 1.0f;
+        {   // same-pixel target: the address follows from (tile, lane), no need to wait for the source slot
+            const int ug = (t % tg.ntx) * TILE_PX + (lane & 7), vg = (t / tg.ntx) * TILE_PX + (lane >> 3);
+            if (ug < g.W && vg < g.H) { qs = tcloud[vg * g.W + ug]; if (g.estimator == 0) ws = tnrm[vg * g.W + ug].w; }
+        }
+        float4 clo0 = make_float4(inf, inf, inf, 0), chi0 = make_float4(-inf, -inf, -inf, 0), clo1 = clo0, chi1 = chi0;
+        if (lane < tg.ncoarse) { clo0 = CB[2 * lane]; chi0 = CB[2 * lane + 1]; }
+        if (lane + 64 < tg.ncoarse) { clo1 = CB[2 * (lane + 64)]; chi1 = CB[2 * (lane + 64) + 1]; }
+        float4 olo = make_float4(inf, inf, inf, 0), ohi = make_float4(-inf, -inf, -inf, 0);     // own cell's child boxes
+        {
+            const int tx = (cown % tg.ncx) * COARSE_TILES + (lane & 7), ty = (cown / tg.ncx) * COARSE_TILES + (lane >> 3);
+            if (tx < tg.ntx && ty < tg.nty) { olo = TB[2 * (ty * tg.ntx + tx)]; ohi = TB[2 * (ty * tg.ntx + tx) + 1]; }
+        }
+        const Rt m = load_rt(Tcur + b * 16);
+        xform(m, s4.x, s4.y, s4.z, px, py, pz);
+        // ---- upper bound: previous match, else the target at the same pixel, else the gate
+        {
+            const int jprev = __float_as_int(pq.w);
+            const bool have_prev = valid && jprev >= 0;
+            const bool tv = have_prev || (valid && pt_valid(qs.x, qs.y, qs.z, g.zmax) && ws > 0.5f);
+            const int jg = have_prev ? jprev : pix;
+            const float4 qg = have_prev ? pq : qs;
+            const float d2g = canon_d2(px, py, pz, qg.x, qg.y, qg.z);
             if (tv && d2g <= g.gate2) bkey = ((unsigned long long)(unsigned int)__float_as_int(d2g) << 32) | (unsigned int)jg;
         }
-        const float4 *__restrict__ TB = tbox + (size_t)b * tg.ntiles * 2;
-        const float4 *__restrict__ CB = cbox + (size_t)b * tg.ncoarse * 2;
-        const float4 *__restrict__ TT = tgtT + (size_t)b * tg.ntiles * TILE_SLOTS;
-        // scan one target tile (wave-uniform tt) if some lane can still improve/tie inside its box
-        auto scan_tile = [&](int tt) {
-            const float4 lo = TB[2 * tt], hi = TB[2 * tt + 1];              // uniform -> scalar loads
+        // waves that still carry a gate-sized bound have the long wide search ahead of them: let them run
+        // ahead of their SIMD neighbours so that they do not become the tail of the launch
+        if (__ballot(valid && (unsigned int)(bkey & 0xffffffffull) == 0xffffffffu) != 0ull) __builtin_amdgcn_s_setprio(2);
+        // scan staged tile k (tile id tile, both wave-uniform) if some lane can still improve/tie inside its box
+        auto scan_staged = [&](int k, int tile) __attribute__((always_inline)) {
+            const float4 lo = TB[2 * tile], hi = TB[2 * tile + 1];           // uniform -> scalar loads
             const float cur = __int_as_float((int)(unsigned int)(bkey >> 32));
             const float gx = fmaxf(0.0f, fmaxf(lo.x - px, px - hi.x));
             const float gy = fmaxf(0.0f, fmaxf(lo.y - py, py - hi.y));
@@ -586,61 +717,130 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
             const bool need = valid && (gx * gx + gy * gy + gz * gz) <= cur * 1.00001f + 1e-30f;
             if (__ballot(need) == 0ull) return;
             const int cnt = __builtin_amdgcn_readfirstlane(__float_as_int(lo.w));
-            const float4 *__restrict__ cand = TT + (size_t)tt * TILE_SLOTS;
-#pragma unroll 4
-            for (int k = 0; k < cnt; ++k) {
-                const float4 q = cand[k];                                   // wave-uniform address
+            n_scanned += 1; n_cand += cnt;
+            const float4 *__restrict__ cand = st + k * TILE_SLOTS;
+#pragma unroll 8
+            for (int i = 0; i < cnt; ++i) {
+                const float4 q = cand[i];                                    // same address in every lane: LDS broadcast
                 const float d2 = canon_d2(px, py, pz, q.x, q.y, q.z);
                 const unsigned long long key =
                     ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(q.w);
                 bkey = key < bkey ? key : bkey;
             }
         };
-        // ---- phase A: the 3x3 tiles around the same image location (centre, then ring)
-        const int tx0 = t % tg.ntx, ty0 = t / tg.ntx;
-        {
-            const int ox[9] = { 0, -1, 1, 0, 0, -1, 1, -1, 1 }, oy[9] = { 0, 0, 0, -1, 1, -1, -1, 1, 1 };
+        auto park_and_scan = [&]() __attribute__((always_inline)) {
+            n_batches += 1;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const int tx = tx0 + ox[k], ty = ty0 + oy[k];
-                if (tx >= 0 && tx < tg.ntx && ty >= 0 && ty < tg.nty) scan_tile(ty * tg.ntx + tx);
-            }
-        }
+            for (int k = 0; k < NN_STAGE; ++k) st[k * TILE_SLOTS + lane] = r[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int k = 0; k < NN_STAGE; ++k)
+                if (tt[k] >= 0) scan_staged(k, tt[k]);
+            __builtin_amdgcn_wave_barrier();
+        };
+        if (dbg) clk1 = clock64();
+        park_and_scan();
+        if (dbg) clk2 = clock64();
         // ---- phase B: every other tile whose box is within reach of the (shrunken) bounds
         const float qminx = wave_min(valid ? px : inf), qminy = wave_min(valid ? py : inf), qminz = wave_min(valid ? pz : inf);
         const float qmaxx = wave_max(valid ? px : -inf), qmaxy = wave_max(valid ? py : -inf), qmaxz = wave_max(valid ? pz : -inf);
+        // fine level: ballot the children of coarse cell cc against the wave box, stage + scan survivors
+        auto sweep_cell = [&](int cc, const float4 lo, const float4 hi) __attribute__((always_inline)) {
+            const int ctx = (cc % tg.ncx) * COARSE_TILES, cty = (cc / tg.ncx) * COARSE_TILES;
+            const int tx = ctx + (lane & 7), ty = cty + (lane >> 3);
+            const float umax = wave_max(valid ? __int_as_float((int)(unsigned int)(bkey >> 32)) : 0.0f);
+            const float thr = umax * 1.00001f + 1e-30f;      // covers the rounding of box_gap2 and of canon_d2
+            bool hit2 = false;
+            if (tx < tg.ntx && ty < tg.nty) {
+                const int dx = tx - tx0, dy = ty - ty0;
+                const bool in_a = abs(dx) <= 1 && abs(dy) <= 1 && !(dx == 1 && dy == 1);   // the 8 tiles of phase A
+                hit2 = !in_a && box_gap2(lo, hi, qminx, qminy, qminz, qmaxx, qmaxy, qmaxz) <= thr;
+            }
+            unsigned long long tm0 = __ballot(hit2), tm = 0ull;
+            n_chit += 1; n_fhit += __popcll(tm0);
+            // refine BEFORE fetching anything: a tile is staged only if some lane's own ball reaches its box
+            // (lane k2 holds the box of child k2 -> broadcast it with v_readlane)
+            while (tm0) {
+                const int k2 = __builtin_ctzll(tm0);
+                tm0 &= tm0 - 1;
+                const float lx = rdlane(lo.x, k2), ly = rdlane(lo.y, k2), lz = rdlane(lo.z, k2);
+                const float hx = rdlane(hi.x, k2), hy = rdlane(hi.y, k2), hz = rdlane(hi.z, k2);
+                const float cur = __int_as_float((int)(unsigned int)(bkey >> 32));
+                const float gx = fmaxf(0.0f, fmaxf(lx - px, px - hx));
+                const float gy = fmaxf(0.0f, fmaxf(ly - py, py - hy));
+                const float gz = fmaxf(0.0f, fmaxf(lz - pz, pz - hz));
+                const bool need = valid && (gx * gx + gy * gy + gz * gz) <= cur * 1.00001f + 1e-30f;
+                if (__ballot(need) != 0ull) tm |= 1ull << k2;
+            }
+            n_refined += __popcll(tm);
+            while (tm) {
+#pragma unroll
+                for (int k = 0; k < NN_STAGE; ++k) {
+                    tt[k] = -1;
+                    if (tm) {
+                        const int k2 = __builtin_ctzll(tm);
+                        tm &= tm - 1;
+                        tt[k] = (cty + (k2 >> 3)) * tg.ntx + ctx + (k2 & 7);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NN_STAGE; ++k)
+                    r[k] = tt[k] >= 0 ? TT[(size_t)tt[k] * TILE_SLOTS + lane] : make_float4(inf, inf, inf, __int_as_float(-1));
+                park_and_scan();
+            }
+        };
+        if (dbg) clk2a = clock64();
+        sweep_cell(cown, olo, ohi);                       // own cell first: its child boxes are already here
+        if (dbg) clk2b = clock64();
         for (int c0 = 0; c0 < tg.ncoarse; c0 += 64) {
-            float umax = wave_max(valid ? __int_as_float((int)(unsigned int)(bkey >> 32)) : 0.0f);
-            float thr = umax * 1.00001f + 1e-30f;        // covers the rounding of box_gap2 and of canon_d2
+            const float umax = wave_max(valid ? __int_as_float((int)(unsigned int)(bkey >> 32)) : 0.0f);
+            const float thr = umax * 1.00001f + 1e-30f;
             const int cidx = c0 + lane;
-            bool hit = false;
-            if (cidx < tg.ncoarse) hit = box_gap2(CB[2 * cidx], CB[2 * cidx + 1], qminx, qminy, qminz, qmaxx, qmaxy, qmaxz) <= thr;
+            float4 lo, hi;
+            if (c0 == 0) { lo = clo0; hi = chi0; }
+            else if (c0 == 64) { lo = clo1; hi = chi1; }
+            else {
+                lo = make_float4(inf, inf, inf, 0); hi = make_float4(-inf, -inf, -inf, 0);
+                if (cidx < tg.ncoarse) { lo = CB[2 * cidx]; hi = CB[2 * cidx + 1]; }
+            }
+            const bool hit = cidx != cown && box_gap2(lo, hi, qminx, qminy, qminz, qmaxx, qmaxy, qmaxz) <= thr;
             unsigned long long cm = __ballot(hit);
             while (cm) {
                 const int cc = c0 + __builtin_ctzll(cm);
                 cm &= cm - 1;
-                const int ctx = (cc % tg.ncx) * COARSE_TILES, cty = (cc / tg.ncx) * COARSE_TILES;
-                const int tx = ctx + (lane & 7), ty = cty + (lane >> 3);
-                umax = wave_max(valid ? __int_as_float((int)(unsigned int)(bkey >> 32)) : 0.0f);
-                thr = umax * 1.00001f + 1e-30f;
-                bool hit2 = false;
-                if (tx < tg.ntx && ty < tg.nty && !(abs(tx - tx0) <= 1 && abs(ty - ty0) <= 1)) {
-                    const int tt = ty * tg.ntx + tx;
-                    hit2 = box_gap2(TB[2 * tt], TB[2 * tt + 1], qminx, qminy, qminz, qmaxx, qmaxy, qmaxz) <= thr;
-                }
-                unsigned long long tm = __ballot(hit2);
-                while (tm) {
-                    const int k2 = __builtin_ctzll(tm);
-                    tm &= tm - 1;
-                    scan_tile((cty + (k2 >> 3)) * tg.ntx + ctx + (k2 & 7));
-                }
+                const int tx = (cc % tg.ncx) * COARSE_TILES + (lane & 7), ty = (cc / tg.ncx) * COARSE_TILES + (lane >> 3);
+                float4 flo = make_float4(inf, inf, inf, 0), fhi = make_float4(-inf, -inf, -inf, 0);
+                if (tx < tg.ntx && ty < tg.nty) { flo = TB[2 * (ty * tg.ntx + tx)]; fhi = TB[2 * (ty * tg.ntx + tx) + 1]; }
+                sweep_cell(cc, flo, fhi);
             }
         }
     }
+    if (dbg) clk3 = clock64();
     // ---- fused S4 accumulation, level 1: this tile's 64 slots
     double s[NSUMS];
-    finish_slot(valid, bkey, px, py, pz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, s);
+    finish_slot(valid, bkey, px, py, pz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, prevq + gs, s);
     tile_reduce_store(s, TP + (size_t)b * NSUMS * tg.tpad, t, tg.tpad);
+    {   // hint for the next iteration: the tile holding the match of a lane near the tile centre
+        const bool ok = s[27] != 0.0;
+        const unsigned long long mm = __ballot(ok);
+        if (mm) {
+            const unsigned long long ctr = mm & 0x0000001818000000ull;      // lanes 27,28,35,36
+            const int src_lane = __builtin_ctzll(ctr ? ctr : mm);
+            const int jm = __builtin_amdgcn_readlane((int)(unsigned int)(bkey & 0xffffffffull), src_lane);
+            if (lane == 0) hint[(size_t)b * tg.ntiles + t] = ((jm / g.W) / TILE_PX) * tg.ntx + (jm % g.W) / TILE_PX;
+        }
+    }
+    if (dbg && b == 0 && lane == 0) {
+        long long *d = dbg + (size_t)t * 8;
+        d[0] = clk0; d[1] = clk1; d[2] = clk2; d[3] = clk3; d[4] = clock64();
+        d[5] = n_scanned | ((long long)n_chit << 32); d[6] = n_cand | ((long long)n_fhit << 32);
+        d[7] = n_batches | ((long long)n_refined << 32);
+        d[1] = clk1 | 0; d[2] = clk2;
+        // pack two extra deltas into the high bits of slot 1/2 is not possible (64-bit clocks): reuse cd2-free slots
+        dbg[(size_t)tg.ntiles * 8 + (size_t)t * 2] = clk2a; dbg[(size_t)tg.ntiles * 8 + (size_t)t * 2 + 1] = clk2b;
+    }
 }
 
 // ------------------------------------------------------------------------------------ S5
