@@ -38,6 +38,7 @@ struct slam3d_icp_handle {
     float4 *srcT = nullptr, *tgtT = nullptr, *tbox = nullptr, *cbox = nullptr, *prevq = nullptr;
     long long *dbg = nullptr;     // per-tile NN statistics, only with SLAM3D_NN_DEBUG=1
     int *hint = nullptr;          // per source tile: target tile where the previous matches were
+    int *scount = nullptr;        // per source tile: valid source points
     // host
     std::vector<SlotPtrs> h_slots;
     SlotPtrs *pin_slots = nullptr;
@@ -109,7 +110,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->own_src); F(h->own_tgt); F(h->nrm); F(h->src_c); F(h->tgt_c); F(h->counts); F(h->ccounts); F(h->corr);
     F(h->flags); F(h->best); F(h->cd2); F(h->partials); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
     F(h->d_Tinit); F(h->d_slots); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4);
-    F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox); F(h->GP); F(h->ticket); F(h->dbg); F(h->prevq); F(h->hint);
+    F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox); F(h->GP); F(h->ticket); F(h->dbg); F(h->prevq); F(h->hint); F(h->scount);
     if (h->pin_slots) (void)hipHostFree(h->pin_slots);
     if (h->pin_T) (void)hipHostFree(h->pin_T);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -176,7 +177,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     A(dalloc(h->corr, BS)); A(dalloc(h->flags, (size_t)h->maxB)); A(dalloc(h->cd2, BS)); A(dalloc(h->prevq, BS));
     A(dalloc(h->partials, (size_t)h->maxB * NSUMS * tg.tpad));
     A(dalloc(h->GP, (size_t)h->maxB * RS_MAXGROUPS * NSUMS)); A(dalloc(h->ticket, (size_t)h->maxB));
-    A(dalloc(h->hint, (size_t)h->maxB * tg.ntiles));
+    A(dalloc(h->hint, (size_t)h->maxB * tg.ntiles)); A(dalloc(h->scount, (size_t)h->maxB * tg.ntiles));
     if (getenv("SLAM3D_NN_DEBUG")) A(dalloc(h->dbg, (size_t)tg.ntiles * 10));
     A(dalloc(h->sums, (size_t)h->maxB * NSUMS)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
     A(dalloc(h->trace_T, (size_t)h->maxB * (iters + 1) * 16)); A(dalloc(h->trace_S, (size_t)h->maxB * iters * NSUMS));
@@ -324,13 +325,12 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         hipLaunchKernelGGL(k_normals, grid, dim3(NRM_BX, NRM_BY), 0, s, h->d_slots, h->nrm, g);
     }
     hipLaunchKernelGGL(k_build_tiles, dim3(tg.ntiles, 2, B), dim3(64), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT, h->tbox,
-                       h->counts, g, tg, use_normals, h->row0, h->row1);
+                       h->scount, g, tg, use_normals, h->row0, h->row1);
+    hipLaunchKernelGGL(k_coarse_boxes, dim3(tg.ncoarse, B), dim3(64), 0, s, h->tbox, h->scount, h->cbox, h->counts, tg);
     if (brute) {
         HIPCHK(h, hipMemsetAsync(h->best, 0xFF, sizeof(unsigned long long) * (size_t)B * tg.nslots, s));
         hipLaunchKernelGGL(k_compact, dim3(2, B), dim3(1024), 0, s, h->d_slots, h->nrm, h->src_c, h->tgt_c, h->ccounts, g, tg,
                            use_normals, h->row0, h->row1);
-    } else {
-        hipLaunchKernelGGL(k_coarse_boxes, dim3(tg.ncoarse, B), dim3(64), 0, s, h->tbox, h->cbox, tg);
     }
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
     hipLaunchKernelGGL(k_init_T, dim3((B + 63) / 64), dim3(64), 0, s, dT, h->Tcur, h->trace_T, h->flags, B, iters);

@@ -242,7 +242,7 @@ __device__ __forceinline__ float wave_max(float v)
 __global__ __launch_bounds__(64) void k_build_tiles(const SlotPtrs *__restrict__ slots,
                                                     const float4 *__restrict__ nrm_all,
                                                     float4 *__restrict__ srcT, float4 *__restrict__ tgtT,
-                                                    float4 *__restrict__ tbox, int *__restrict__ counts,
+                                                    float4 *__restrict__ tbox, int *__restrict__ scount,
                                                     Geometry g, TileGrid tg, int use_normals, int row0, int row1)
 {
     const int t = blockIdx.x, which = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
@@ -261,9 +261,12 @@ __global__ __launch_bounds__(64) void k_build_tiles(const SlotPtrs *__restrict__
     }
     const unsigned long long m = __ballot(ok);
     const int cnt = __popcll(m);
-    if (lane == 0 && cnt) atomicAdd(counts + b * 4 + which, cnt);
     const size_t base = ((size_t)b * tg.ntiles + t) * TILE_SLOTS;
-    if (which == 0) { srcT[base + lane] = q; return; }
+    if (which == 0) {
+        srcT[base + lane] = q;
+        if (lane == 0) scount[(size_t)b * tg.ntiles + t] = cnt;     // summed per coarse cell (no hot atomic)
+        return;
+    }
     const int slot = ok ? __popcll(m & ((1ull << lane) - 1ull)) : cnt + __popcll(~m & ((1ull << lane) - 1ull));
     tgtT[base + slot] = q;
     const float mnx = wave_min(ok ? q.x : inf), mny = wave_min(ok ? q.y : inf), mnz = wave_min(ok ? q.z : inf);
@@ -274,17 +277,23 @@ __global__ __launch_bounds__(64) void k_build_tiles(const SlotPtrs *__restrict__
     }
 }
 
-// grid (ncoarse, B), block 64: AABB of the 8x8 child tiles
-__global__ __launch_bounds__(64) void k_coarse_boxes(const float4 *__restrict__ tbox, float4 *__restrict__ cbox, TileGrid tg)
+// grid (ncoarse, B), block 64: AABB of the 8x8 child tiles; also totals the valid source / target counts
+__global__ __launch_bounds__(64) void k_coarse_boxes(const float4 *__restrict__ tbox, const int *__restrict__ scount,
+                                                     float4 *__restrict__ cbox, int *__restrict__ counts, TileGrid tg)
 {
     const int c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int tx = (c % tg.ncx) * COARSE_TILES + (lane & 7), ty = (c / tg.ncx) * COARSE_TILES + (lane >> 3);
     const float inf = __int_as_float(0x7f800000);
     float4 lo = make_float4(inf, inf, inf, 0.0f), hi = make_float4(-inf, -inf, -inf, 0.0f);
+    int ns = 0, nt = 0;
     if (tx < tg.ntx && ty < tg.nty) {
         const size_t t = (size_t)b * tg.ntiles + (size_t)ty * tg.ntx + tx;
         lo = tbox[t * 2]; hi = tbox[t * 2 + 1];
+        ns = scount[t]; nt = __float_as_int(lo.w);
     }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { ns += __shfl_xor(ns, o); nt += __shfl_xor(nt, o); }
+    if (lane == 0) { if (ns) atomicAdd(counts + b * 4, ns); if (nt) atomicAdd(counts + b * 4 + 1, nt); }
     const float mnx = wave_min(lo.x), mny = wave_min(lo.y), mnz = wave_min(lo.z);
     const float mxx = wave_max(hi.x), mxy = wave_max(hi.y), mxz = wave_max(hi.z);
     if (lane == 0) {
@@ -744,19 +753,41 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
         park_and_scan();
         if (dbg) clk2 = clock64();
         // ---- phase B: every other tile whose box is within reach of the (shrunken) bounds
-        const float qminx = wave_min(valid ? px : inf), qminy = wave_min(valid ? py : inf), qminz = wave_min(valid ? pz : inf);
-        const float qmaxx = wave_max(valid ? px : -inf), qmaxy = wave_max(valid ? py : -inf), qmaxz = wave_max(valid ? pz : -inf);
-        // fine level: ballot the children of coarse cell cc against the wave box, stage + scan survivors
+        // The wave-level test uses TWO query boxes: lanes whose bound is already small ("tight", radius below a
+        // quarter of the gate) and the rest ("loose": no match yet / far match).  A few loose lanes then no
+        // longer inflate the search region of the whole wave.
+        const float bnd0 = __int_as_float((int)(unsigned int)(bkey >> 32));
+        const bool tight = valid && bnd0 <= 0.0625f * g.gate2, loose = valid && !tight;
+        const float qminx = wave_min(tight ? px : inf), qminy = wave_min(tight ? py : inf), qminz = wave_min(tight ? pz : inf);
+        const float qmaxx = wave_max(tight ? px : -inf), qmaxy = wave_max(tight ? py : -inf), qmaxz = wave_max(tight ? pz : -inf);
+        const bool any_loose = __ballot(loose) != 0ull;
+        float lminx = inf, lminy = inf, lminz = inf, lmaxx = -inf, lmaxy = -inf, lmaxz = -inf;
+        if (any_loose) {
+            lminx = wave_min(loose ? px : inf); lminy = wave_min(loose ? py : inf); lminz = wave_min(loose ? pz : inf);
+            lmaxx = wave_max(loose ? px : -inf); lmaxy = wave_max(loose ? py : -inf); lmaxz = wave_max(loose ? pz : -inf);
+        }
+        // gap test of a box against both query boxes with the CURRENT class bounds (empty class -> never hits)
+        auto reach = [&](const float4 lo, const float4 hi, float thr_t, float thr_l) __attribute__((always_inline)) {
+            bool h = box_gap2(lo, hi, qminx, qminy, qminz, qmaxx, qmaxy, qmaxz) <= thr_t;
+            if (any_loose) h = h || box_gap2(lo, hi, lminx, lminy, lminz, lmaxx, lmaxy, lmaxz) <= thr_l;
+            return h;
+        };
+        auto class_thr = [&](float &thr_t, float &thr_l) __attribute__((always_inline)) {
+            const float cur = __int_as_float((int)(unsigned int)(bkey >> 32));
+            thr_t = wave_max(tight ? cur : 0.0f) * 1.00001f + 1e-30f;    // covers the rounding of box_gap2 and of canon_d2
+            thr_l = any_loose ? wave_max(loose ? cur : 0.0f) * 1.00001f + 1e-30f : 0.0f;
+        };
+        // fine level: ballot the children of coarse cell cc against the wave boxes, stage + scan survivors
         auto sweep_cell = [&](int cc, const float4 lo, const float4 hi) __attribute__((always_inline)) {
             const int ctx = (cc % tg.ncx) * COARSE_TILES, cty = (cc / tg.ncx) * COARSE_TILES;
             const int tx = ctx + (lane & 7), ty = cty + (lane >> 3);
-            const float umax = wave_max(valid ? __int_as_float((int)(unsigned int)(bkey >> 32)) : 0.0f);
-            const float thr = umax * 1.00001f + 1e-30f;      // covers the rounding of box_gap2 and of canon_d2
+            float thr_t, thr_l;
+            class_thr(thr_t, thr_l);
             bool hit2 = false;
             if (tx < tg.ntx && ty < tg.nty) {
                 const int dx = tx - tx0, dy = ty - ty0;
                 const bool in_a = abs(dx) <= 1 && abs(dy) <= 1 && !(dx == 1 && dy == 1);   // the 8 tiles of phase A
-                hit2 = !in_a && box_gap2(lo, hi, qminx, qminy, qminz, qmaxx, qmaxy, qmaxz) <= thr;
+                hit2 = !in_a && reach(lo, hi, thr_t, thr_l);
             }
             unsigned long long tm0 = __ballot(hit2), tm = 0ull;
             n_chit += 1; n_fhit += __popcll(tm0);
@@ -795,8 +826,8 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
         sweep_cell(cown, olo, ohi);                       // own cell first: its child boxes are already here
         if (dbg) clk2b = clock64();
         for (int c0 = 0; c0 < tg.ncoarse; c0 += 64) {
-            const float umax = wave_max(valid ? __int_as_float((int)(unsigned int)(bkey >> 32)) : 0.0f);
-            const float thr = umax * 1.00001f + 1e-30f;
+            float thr_t, thr_l;
+            class_thr(thr_t, thr_l);
             const int cidx = c0 + lane;
             float4 lo, hi;
             if (c0 == 0) { lo = clo0; hi = chi0; }
@@ -805,7 +836,7 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
                 lo = make_float4(inf, inf, inf, 0); hi = make_float4(-inf, -inf, -inf, 0);
                 if (cidx < tg.ncoarse) { lo = CB[2 * cidx]; hi = CB[2 * cidx + 1]; }
             }
-            const bool hit = cidx != cown && box_gap2(lo, hi, qminx, qminy, qminz, qmaxx, qmaxy, qmaxz) <= thr;
+            const bool hit = cidx != cown && reach(lo, hi, thr_t, thr_l);
             unsigned long long cm = __ballot(hit);
             while (cm) {
                 const int cc = c0 + __builtin_ctzll(cm);
