@@ -1,0 +1,75 @@
+// GraphicEndICP.h -- host-side mirror of the reference's front end for the plane-ICP path.
+//
+// The reference's plug-in seam is virtual-method override of GraphicEnd (src/GraphicEnd.h:74-216); its
+// second front end GraphicEnd2 (src/GraphicEnd.h:262-275, src/GraphicEnd2.cpp) overrides
+// init/run/readimage/multiPnP and main() picks the subclass (src/run_SLAM.cpp:21 vs
+// src/run_SLAM_imageonly.cpp:21).  GraphicEndICP has the same method names, defaults and result type, but
+// its frames are organized depth images (kept on the GPU as organized clouds) and multiPnP forwards to the
+// C-ABI slam3d_icp_* (include/slam3d_icp.h).  It is self-contained (no PCL / OpenCV / g2o / Eigen): those
+// are not available here, and PLANE/KEYFRAME carry OpenCV members (src/GraphicEnd.h:41-57).  INTEGRATION.md
+// shows the ~40-line subclass that plugs the same calls into the real GraphicEnd.
+#pragma once
+#include <cstdint>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../include/slam3d_icp.h"
+#include "ParameterReader.h"
+
+// RESULT_OF_MULTIPNP {T, norm, inliers} (src/GraphicEnd.h:59-69); T row-major instead of Eigen::Isometry3d
+struct RESULT_OF_MULTIPNP {
+    RESULT_OF_MULTIPNP();
+    double T[16];
+    double norm;
+    int inliers;
+    bool isIdentity() const;          // the reference's failure test (src/GraphicEnd.cpp:173)
+};
+
+struct FRAME {                        // stands in for KEYFRAME / vector<PLANE> (src/GraphicEnd.h:51-57)
+    int id = 0;
+    int frame_index = 0;
+    std::vector<uint16_t> depth;      // organized 16-bit depth, width*height
+};
+
+void mat4_identity(double *T);
+void mat4_mul(const double *A, const double *B, double *C);
+void mat4_inverse_rigid(const double *T, double *Ti);
+
+class GraphicEndICP {
+ public:
+    GraphicEndICP();
+    virtual ~GraphicEndICP();
+
+    virtual void init(const std::string &param_file = "./parameters.yaml");   // src/GraphicEnd.cpp:77-148
+    virtual int run();                                                         // src/GraphicEnd.cpp:150-264
+    virtual int readimage();                                                   // src/GraphicEnd.cpp:266-302
+    virtual void generateKeyFrame(const double *T);                            // src/GraphicEnd.cpp:304-351
+    virtual void saveFinalResult(const std::string &fileaddr);                 // src/GraphicEnd.cpp:661-682
+    // same call shape and defaults as GraphicEnd::multiPnP (src/GraphicEnd.h:134)
+    virtual RESULT_OF_MULTIPNP multiPnP(FRAME &frame1, FRAME &frame2, bool loopclosure = false, int frame_index = 0,
+                                        int minimum_inliers = 12);
+    // loop-closure candidates are independent pairs: one batched call (src/GraphicEnd.cpp:685-762)
+    std::vector<RESULT_OF_MULTIPNP> multiPnPBatch(const std::vector<const FRAME *> &f1, const std::vector<const FRAME *> &f2,
+                                                  int minimum_inliers = 12);
+
+    int index() const { return _index; }
+    const double *robot() const { return _robot; }
+    const std::vector<FRAME> &keyframes() const { return _keyframes; }
+    int lostCount() const { return _lost; }
+
+ protected:
+    ParameterReader *_reader = nullptr;
+    slam3d_icp_handle *_icp = nullptr;
+    slam3d_icp_params _params;
+    std::string _depPath;
+    std::ofstream _errorfile, _trajfile;
+    int _index = 0, _start_index = 1, _end_index = 1, _lost = 0, _lost_frames = 10, _max_batch = 1;
+    double _max_pos_change = 0.25, _error_threshold = 1.0, _loop_closure_error = 1.5;
+    int _loop_closure_inliers = 30;
+    FRAME _present, _currKF, _last;
+    std::vector<FRAME> _keyframes;
+    std::vector<std::vector<double> > _kf_poses;     // keyframe poses (row-major 4x4), what the reference keeps in g2o
+    double _robot[16], _kf_pos[16];
+    void writeTrajectoryLine(int frame_index, const double *T);
+};
