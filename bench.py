@@ -2,16 +2,23 @@
 """bench.py -- ICP iterations/s of the MI355X plane-ICP path (BASELINE.json metric).
 
 A *step* is one pass of the hot path over one batch of synthetic frame pairs that are already
-resident in HBM: preprocessing (normals, compaction) + `iterations` ICP iterations + the pose
-records back on the host.  Workload at N=1: BASELINE config 2 (single 640x480 pair, seed 1000,
-20 iterations, point-to-plane); `--pairs P` batches P pairs per GPU (config 3 = 64).
-For N>1 every rank processes its own pairs (seed 1000 + rank*P + i) -- the path has no data-path
-collective -- and the SE(3) pose records are all-gathered over RCCL once per step (weak scaling).
+resident in HBM: preprocessing (normals, tiles) + `iterations` ICP iterations + the pose records
+back on the host.  Workload at N=1: BASELINE config 2 (single 640x480 pair, seed 1000, 20
+iterations, point-to-plane); `--pairs P` batches P pairs per GPU (config 3 = 64).  For N>1 every
+rank processes its own pairs (seed 1000 + rank*P + i) -- the path has no data-path collective --
+and the SE(3) pose records are all-gathered over RCCL once per step (weak scaling).
+`--mode dense` is BASELINE config 5: ONE pair whose source rows are sharded over the ranks, with a
+29-double all-reduce per iteration (strong scaling).
 
-Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (the NN search):
-achieved = algorithmic flops per launch (8 * n_src * n_tgt summed over the launch's pairs,
-SURVEY.md 8(d)) / mean launch duration measured with HIP events on the launch stream.
-`cpu_baseline` times the CPU oracle (exact kd-tree NN, OpenMP) on the same pair on the host.
+Prints ONE JSON line on rank 0.
+  roofline            the dominant kernel of the measured (default, tile-pruned) path: k_nn_tiles_acc.
+                      It streams each array once per iteration, so it is accounted against HBM:
+                      achieved = algorithmic bytes per launch (12 B src xyz + 4 B idx per
+                      valid source point, 12 B xyz + 12 B normal per valid target point) / mean launch
+                      duration measured with HIP events on the launch stream.
+  roofline_bruteforce the north-star algorithm (full brute-force scan, SLAM3D_NN_BRUTE_VALU) measured in
+                      the same process on the same pair: 8*n_src*n_tgt flop per launch vs the fp32 peak.
+  cpu_baseline        the CPU oracle (exact kd-tree NN, OpenMP) timed on the host on the same pair.
 """
 from __future__ import annotations
 
@@ -27,21 +34,24 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md:40-41 (vector == f32-MFMA peak)
+FP32_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md:40-41 (vector == f32-MFMA dense peak)
+HBM_PEAK_GBPS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec; 6.29 TB/s measured copy)
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=1, help="frame pairs per GPU per step (config 3: 64)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--iterations", type=int, default=20)
     ap.add_argument("--estimator", choices=["point2plane", "svd"], default="point2plane")
-    ap.add_argument("--nn-mode", type=int, default=0)
+    ap.add_argument("--nn-mode", type=int, default=0, help="0 auto(tiles) 1 brute-force VALU 3 tiles")
+    ap.add_argument("--mode", choices=["batch", "dense"], default="batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bruteforce", action="store_true")
     ap.add_argument("--seed0", type=int, default=1000)
     return ap.parse_args()
 
@@ -70,10 +80,10 @@ def cpu_baseline_leg(pair, s4, t4, args, gpu_result, gpu_idx):
     rot, tr = O.pose_error(ro["T_trace"][-1], gpu_result["T_raw"])
     out = {
         "value": args.iterations / t_all, "unit": "ICP iterations/s", "cores": cores, "kind": "port",
-        "sample": f"oracle/ (exact kd-tree NN + same estimator, OpenMP all cores), 1 pair seed {pair.seed} x "
-                  f"{args.iterations} iterations incl. normals+kd-tree build, median of 3",
+        "sample": f"oracle/ (exact kd-tree NN + same estimator, OpenMP on all {cores} hardware threads), 1 pair seed "
+                  f"{pair.seed} x {args.iterations} iterations incl. normals + kd-tree build, median of 3",
         "single_thread_value": it1 / t_one,
-        "single_thread_sample": f"same, 1 thread, {it1} iterations (PCL's ICP is single-threaded)",
+        "single_thread_sample": f"same, 1 thread, {it1} iterations (PCL's own ICP is single-threaded)",
     }
     parity = {
         "rot_err_rad": rot, "trans_err_m": tr,
@@ -83,11 +93,41 @@ def cpu_baseline_leg(pair, s4, t4, args, gpu_result, gpu_idx):
     return out, parity
 
 
+def bruteforce_leg(capi, intr, est, d_src_ptr, d_tgt_ptr, local_rank, iterations=3):
+    """The north-star algorithm on the same resident pair: every source x every target (fp32 VALU)."""
+    params = capi.default_params(intr, estimator=est, iterations=iterations, max_batch=1, device=local_rank,
+                                 nn_mode=capi.NN_BRUTE_VALU)
+    with capi.IcpHandle(params) as h:
+        h.set_clouds_device(0, d_src_ptr, d_tgt_ptr)
+        h.run(1)
+        h.fetch_results(1)                       # warm-up
+        h.run(1)
+        r = h.fetch_results(1)[0]
+        ms = float(np.mean(h.get_iteration_timings()))
+    flops = 8.0 * r["n_src"] * r["n_tgt"]
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "k_nn_valu (full brute-force scan, LDS-tiled, fp32 VALU)", "bound": "mfma", "achieved": ach,
+            "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": None,
+            "launch_ms": ms, "flops_per_launch": flops, "iterations_per_s_if_used": 1e3 / ms,
+            "note": "fp32 distance contraction; peak = fp32 vector == f32-MFMA dense peak (no MFMA issued by this kernel)"}
+
+
+def committed_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile (not a live measurement)."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d["k_nn_tiles_acc"]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
+
+
 def main():
     args = parse_args()
     import torch
     import torch.distributed as dist
-    from slam3d_gx_amd import capi, shard, synth
+    from slam3d_gx_amd import capi, dense, shard, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -102,10 +142,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    P = args.pairs
+    is_dense = args.mode == "dense"
+    P = 1 if is_dense else args.pairs
     est = capi.EST_POINT2PLANE if args.estimator == "point2plane" else capi.EST_SVD
     # ---- synthetic inputs, uploaded once: the timed region starts with clouds resident in HBM
-    pairs = [synth.make_pair(args.seed0 + rank * P + i, args.width, args.height) for i in range(P)]
+    seeds = [args.seed0] if is_dense else [args.seed0 + rank * P + i for i in range(P)]
+    pairs = [synth.make_pair(s, args.width, args.height) for s in seeds]
     intr = pairs[0].intr
     src_host = [synth.backproject_numpy(p.depth_src, intr) for p in pairs]
     tgt_host = [synth.backproject_numpy(p.depth_tgt, intr) for p in pairs]
@@ -118,13 +160,15 @@ def main():
     for i in range(P):
         h.set_clouds_device(i, d_src.data_ptr() + i * rec_bytes, d_tgt.data_ptr() + i * rec_bytes)
     stream = torch.cuda.current_stream().cuda_stream
-
     table = {}
+    allreduce = dense.allreduce_sum_torch(dev) if world > 1 else None
 
     def step():
+        if is_dense:      # one exchange per iteration: 29-double all-reduce (RCCL)
+            return [dense.dense_align(h, world, rank, None, allreduce, stream)]
         h.run(P, None, stream)
         res = h.fetch_results(P)
-        if world > 1:   # RCCL all-gather of the 160-byte pose records (T, norm, inliers, status, rmse)
+        if world > 1:     # RCCL all-gather of the 160-byte pose records (T, norm, inliers, status, rmse)
             table["poses"] = shard.gather_records(shard.pack_records(res), world * P, device=dev)
         return res
 
@@ -142,8 +186,9 @@ def main():
     res = None
     for _ in range(args.steps):
         res = step()
-        tm = h.get_timings()
-        nn_ms.append(tm["nn_ms"]); tot_ms.append(tm["total_ms"]); pre_ms.append(tm["preprocess_ms"])
+        if not is_dense:
+            tm = h.get_timings()
+            nn_ms.append(tm["nn_ms"]); tot_ms.append(tm["total_ms"]); pre_ms.append(tm["preprocess_ms"])
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -151,42 +196,60 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    total_iters = world * P * args.iterations * args.steps
+    total_iters = (1 if is_dense else world * P) * args.iterations * args.steps
     value = total_iters / elapsed
-    # ---- roofline of the dominant kernel (NN search): one launch = one iteration over P pairs
-    flops_per_launch = sum(8.0 * r["n_src"] * r["n_tgt"] for r in res)
-    launch_ms = statistics.mean(nn_ms) / max(args.iterations, 1)
-    achieved = flops_per_launch / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
-    alg_bytes = sum((12 + 4) * r["n_src"] + (12 + (12 if est == 0 else 0)) * r["n_tgt"] for r in res)
+    size_tag = f"{args.width}x{args.height}"
     out = {
-        "metric": "ICP iterations/sec on 640x480 clouds" if (args.width, args.height) == (640, 480)
-                  else f"ICP iterations/sec on {args.width}x{args.height} clouds",
+        "metric": f"ICP iterations/sec on {size_tag} clouds",
         "value": value, "unit": "ICP iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "strong" if is_dense else "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": (f"BASELINE config {'2' if P == 1 else '3-style'}: {P} frame pair(s)/GPU of "
-                         f"{args.width}x{args.height}, {args.iterations} ICP iterations, {args.estimator}, "
-                         f"exact brute-force NN, seeds {args.seed0}+"),
+            "workload": (f"BASELINE config 5: one {size_tag} pair, source rows sharded over {world} GPU(s), "
+                         f"{args.iterations} iterations, {args.estimator}, 232-byte all-reduce per iteration" if is_dense else
+                         f"BASELINE config {'2' if P == 1 else '3'}: {P} frame pair(s) per GPU of {size_tag}, "
+                         f"{args.iterations} ICP iterations, {args.estimator}, exact NN (tile-pruned brute force), "
+                         f"seeds {seeds[0]}..{seeds[-1]}"),
             "pairs_per_gpu": P, "iterations": args.iterations, "estimator": args.estimator,
+            "nn_mode": {0: "auto(tiles)", 1: "brute_valu", 3: "tiles"}.get(args.nn_mode, str(args.nn_mode)),
             "n_src": [r["n_src"] for r in res][:4], "n_tgt": [r["n_tgt"] for r in res][:4],
-            "parallelism": f"pairs sharded 1 process/GPU x{world}, RCCL all-gather of pose records",
+            "parallelism": (f"source rows over {world} rank(s), RCCL all-reduce of 29 doubles per iteration" if is_dense else
+                            f"pairs sharded one process per GPU x{world}, one RCCL all-gather of pose records per step"),
         },
-        "roofline": {
-            "kernel": "k_nn (exact brute-force 1-NN)", "bound": "mfma", "achieved": achieved,
-            "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_PEAK_TFLOPS, "traffic": None,
-            "launch_ms": launch_ms, "flops_per_launch": flops_per_launch,
-            "note": "fp32 distance contraction; peak = fp32 vector == f32-MFMA dense peak",
-            "hbm_algorithmic_bytes_per_launch": alg_bytes,
-            "hbm_achieved_GBps": alg_bytes / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0,
-        },
-        "kernel_ms_per_step": {"preprocess": statistics.mean(pre_ms), "nn": statistics.mean(nn_ms),
-                               "total": statistics.mean(tot_ms)},
         "status": [r["status"] for r in res][:8],
-        "nn_ms_per_iteration": [round(float(x), 4) for x in h.get_iteration_timings()],
     }
+    if not is_dense:
+        # ---- roofline of the dominant kernel: one launch = one ICP iteration over the P resident pairs
+        launch_ms = statistics.mean(nn_ms) / max(args.iterations, 1)
+        alg_bytes = sum((12 + 4) * r["n_src"] + (12 + (12 if est == 0 else 0)) * r["n_tgt"] for r in res)
+        flops = sum(8.0 * r["n_src"] * r["n_tgt"] for r in res)
+        if args.nn_mode == capi.NN_BRUTE_VALU:
+            ach = flops / (launch_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "k_nn_valu (full brute-force scan)", "bound": "mfma", "achieved": ach,
+                               "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": None,
+                               "launch_ms": launch_ms, "flops_per_launch": flops}
+        else:
+            ach = alg_bytes / (launch_ms * 1e-3) / 1e9
+            traffic, src = committed_traffic() if (P == 1 and size_tag == "640x480" and est == 0) else (None, None)
+            out["roofline"] = {
+                "kernel": "k_nn_tiles_acc (exact tile-pruned NN + fused normal-equation accumulation)",
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+                "traffic": traffic, "traffic_source": src, "launch_ms": launch_ms,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "equivalent_bruteforce_tflops": flops / (launch_ms * 1e-3) / 1e12,
+                "note": ("streaming accounting (each array once per iteration); the kernel is VALU-issue/latency bound, "
+                         "not HBM bound -- see DESIGN.md section 6; equivalent_bruteforce_tflops = flops a full scan "
+                         "would need / this launch time (exceeds the 157.3 TF peak because >99 % of the pairs are proven "
+                         "irrelevant by bounding boxes, not evaluated)"),
+            }
+        out["kernel_ms_per_step"] = {"preprocess": statistics.mean(pre_ms), "nn": statistics.mean(nn_ms),
+                                     "total": statistics.mean(tot_ms)}
+        out["nn_ms_per_iteration"] = [round(float(x), 4) for x in h.get_iteration_timings()]
     if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
+        if world == 1 and not is_dense and not args.no_bruteforce and args.nn_mode != capi.NN_BRUTE_VALU:
+            out["roofline_bruteforce"] = bruteforce_leg(capi, intr, est, d_src.data_ptr(), d_tgt.data_ptr(), local_rank)
+        if not args.no_cpu_baseline and world == 1 and not is_dense:
             idx, _ = h.get_correspondences(0)
             cb, parity = cpu_baseline_leg(pairs[0], src_host[0], tgt_host[0], args, res[0], idx)
             out["cpu_baseline"] = cb

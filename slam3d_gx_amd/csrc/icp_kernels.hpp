@@ -689,7 +689,7 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
         const float4 pq = prevq[gs];
         float4 qs = make_float4(0, 0, 0, 0);
         float ws = 1.0f;
-        {   // same-pixel target: the address follows from (tile, lane), no need to wait for the source slot
+        if (__float_as_int(pq.w) < 0) {   // no previous match (first iteration): fall back to the target at the same pixel
             const int ug = (t % tg.ntx) * TILE_PX + (lane & 7), vg = (t / tg.ntx) * TILE_PX + (lane >> 3);
             if (ug < g.W && vg < g.H) { qs = tcloud[vg * g.W + ug]; if (g.estimator == 0) ws = tnrm[vg * g.W + ug].w; }
         }

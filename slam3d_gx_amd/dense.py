@@ -1,0 +1,49 @@
+"""Dense mode (BASELINE config 5): ONE frame pair sharded over ranks by source rows.
+
+Every rank holds the full target (tiles, boxes, normals) and the source rows
+shard.dense_row_range(height, world, rank).  Per iteration each rank runs the NN search and the
+normal-equation accumulation on its rows (slam3d_icp_dense_partial), the 29 partial sums are
+all-reduced (the path's single exchange step: 232 bytes), and every rank solves the same 6x6 /
+3x3 system and updates T identically (slam3d_icp_dense_update).  Correspondences are unaffected by
+the sharding (each query still sees the whole target); the pose differs from the 1-rank run only by
+the fp64 summation order across ranks.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+
+from . import shard
+
+
+def allreduce_sum_torch(device=None) -> Callable[[np.ndarray], np.ndarray]:
+    """29-double all-reduce over torch.distributed (RCCL on the GPU box, gloo in CPU tests)."""
+    import torch
+    import torch.distributed as dist
+
+    def f(x: np.ndarray) -> np.ndarray:
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return x
+        t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64))
+        if device is not None:
+            t = t.to(device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.cpu().numpy()
+
+    return f
+
+
+def dense_align(handle, world: int, rank: int, T_init=None, allreduce: Optional[Callable] = None, stream: int = 0) -> dict:
+    """Runs params.iterations dense iterations on `handle` (slot 0 must hold the pair)."""
+    r0, r1 = shard.dense_row_range(handle.params.height, world, rank)
+    handle.dense_set_rows(r0, r1)
+    handle.dense_begin(T_init, stream)
+    total = np.zeros(29)
+    for _ in range(handle.params.iterations):
+        part = handle.dense_partial(stream)
+        total = allreduce(part) if allreduce is not None else part
+        handle.dense_update(total, stream)
+    res = handle.dense_finish(total)
+    handle.dense_set_rows(0, handle.params.height)
+    return res

@@ -174,3 +174,43 @@ def test_odd_image_size_not_multiple_of_tile(gpu_lib):
         idx, d2 = h.get_correspondences(0)
         Tt, _ = h.get_trace(0)
     assert np.array_equal(idx, ro["idx"]) and np.array_equal(Tt, ro["T_trace"])
+
+
+def test_dense_mode_two_emulated_ranks(gpu_lib):
+    """Dense mode (config 5 shape, reduced): one pair, source rows sharded over 2 'ranks' (two handles on one
+    GPU, host-side sum standing in for the RCCL all-reduce).  Indices are unaffected by the sharding; the pose
+    differs from the oracle only by the fp64 summation order across ranks (<< 1e-4)."""
+    from slam3d_gx_amd import dense, shard
+    pr, s4, t4 = _pair(1002, 320, 240)
+    iters = 6
+    ro = O.icp(s4, t4, O.params(pr.intr, iterations=iters, nn_method=1))
+    hs = [capi.IcpHandle(capi.default_params(pr.intr, iterations=iters)) for _ in range(2)]
+    try:
+        for r, h in enumerate(hs):
+            h.set_clouds_host(0, s4, t4)
+            h.dense_set_rows(*shard.dense_row_range(pr.intr.height, 2, r))
+            h.dense_begin(None)
+        total = None
+        for _ in range(iters):
+            parts = [h.dense_partial() for h in hs]
+            total = parts[0] + parts[1]
+            for h in hs:
+                h.dense_update(total)
+        res = [h.dense_finish(total) for h in hs]
+        idx = [h.get_correspondences(0)[0] for h in hs]
+    finally:
+        for h in hs:
+            h.close()
+    assert np.array_equal(res[0]["T_raw"], res[1]["T_raw"])            # every rank holds the same pose
+    rot, tr = O.pose_error(ro["T_trace"][-1], res[0]["T_raw"])
+    assert rot <= ROT_TOL and tr <= TRANS_TOL
+    assert res[0]["inliers"] == ro["inliers"]
+    r0, r1 = shard.dense_row_range(pr.intr.height, 2, 0)
+    W = pr.intr.width
+    merged = np.where(np.arange(idx[0].size) < r1 * W, idx[0], idx[1])
+    assert np.array_equal(merged, ro["idx"])
+    # single-rank dense run == batch run, bit for bit
+    with capi.IcpHandle(capi.default_params(pr.intr, iterations=iters)) as h:
+        h.set_clouds_host(0, s4, t4)
+        r1rank = dense.dense_align(h, 1, 0)
+    assert np.array_equal(r1rank["T_raw"], ro["T_trace"][-1])

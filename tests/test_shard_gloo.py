@@ -71,3 +71,52 @@ def test_two_rank_gather_equals_single_process():
     ref = shard.pack_records([_solve_pair(s) for s in SEEDS])
     assert table.shape == (len(SEEDS), shard.RECORD_DOUBLES)
     assert np.array_equal(table, ref)
+
+
+def _dense_worker(rank, world, port, q):
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from slam3d_gx_amd import dense
+
+    class FakeHandle:
+        """stands in for capi.IcpHandle: partial sums are a deterministic function of (rows, iteration)"""
+        class P:
+            height = 48; iterations = 3
+        params = P()
+
+        def __init__(self):
+            self.rows = None; self.it = 0; self.updates = []
+        def dense_set_rows(self, a, b): self.rows = (a, b)
+        def dense_begin(self, T, stream): self.it = 0
+        def dense_partial(self, stream):
+            a, b = self.rows
+            return np.arange(29, dtype=np.float64) * (b - a) + 1000.0 * self.it + a
+        def dense_update(self, total, stream): self.updates.append(total.copy()); self.it += 1
+        def dense_finish(self, total): return dict(total=total.copy(), updates=self.updates)
+
+    h = FakeHandle()
+    out = dense.dense_align(h, world, rank, allreduce=dense.allreduce_sum_torch())
+    q.put((rank, out["total"], h.rows))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dense_allreduce_loop_two_ranks():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dense_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # rows 0..24 and 24..48; last iteration it=2: sum over ranks of (k*24 + 2000 + a)
+    want = np.arange(29.0) * 48 + 4000.0 + 24.0
+    assert np.array_equal(got[0][1], want) and np.array_equal(got[1][1], want)
+    assert got[0][2] == (0, 48) and got[1][2] == (0, 48)      # rows restored after the run
