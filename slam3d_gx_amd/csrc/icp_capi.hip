@@ -716,13 +716,13 @@ extern "C" int slam3d_icp_dense_update(slam3d_icp_handle *h, const double sums[S
     if (!h->ran || h->dense_it >= (h->p.iterations > 0 ? h->p.iterations : 1)) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
-    memcpy(h->pin_T, sums, sizeof(double) * NSUMS);
-    HIPCHK(h, hipMemcpyAsync(h->sums, h->pin_T, sizeof(double) * NSUMS, hipMemcpyHostToDevice, s));
+    memcpy(h->pin_out, sums, sizeof(double) * NSUMS);           // pin_out holds (16+29)*maxB doubles
+    HIPCHK(h, hipMemcpyAsync(h->sums, h->pin_out, sizeof(double) * NSUMS, hipMemcpyHostToDevice, s));
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, s, h->sums, h->Tcur, h->trace_T, h->trace_S, h->flags, 1, h->dense_it,
                        iters, h->p.estimator);
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipStreamSynchronize(s));   // pin_T is reused by the next call
+    HIPCHK(h, hipStreamSynchronize(s));   // pin_out is reused by the next call
     h->dense_it++;
     return SLAM3D_OK;
 }

@@ -1057,7 +1057,7 @@ __device__ inline void solve_update_one(const double *__restrict__ sums, double 
     for (int k = 0; k < 16; ++k) trace_T_b[(size_t)(it + 1) * 16 + k] = T[k];
 }
 
-constexpr int RS_MAXGROUPS = 64;
+constexpr int RS_MAXGROUPS = 256;     // up to 65536 tiles = 4.2 Mpixel
 
 // Levels 2 and 3 of the reduction + solve.  grid (ngroups, B), block 256 (4 waves).  Block g reduces
 // group g (256 tile partials) of every component: one wave per tree -- lane l adds tiles (l, l+128)
