@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--iterations", type=int, default=20)
     ap.add_argument("--estimator", choices=["point2plane", "svd"], default="point2plane")
-    ap.add_argument("--nn-mode", type=int, default=0, help="0 auto(tiles) 1 brute-force VALU 3 tiles")
+    ap.add_argument("--nn-mode", type=int, default=0, help="0 auto(tiles) 1 brute-force VALU 2 brute-force MFMA 3 tiles")
     ap.add_argument("--mode", choices=["batch", "dense"], default="batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bruteforce", action="store_true")
@@ -93,23 +93,29 @@ def cpu_baseline_leg(pair, s4, t4, args, gpu_result, gpu_idx):
     return out, parity
 
 
-def bruteforce_leg(capi, intr, est, d_src_ptr, d_tgt_ptr, local_rank, iterations=3):
-    """The north-star algorithm on the same resident pair: every source x every target (fp32 VALU)."""
-    params = capi.default_params(intr, estimator=est, iterations=iterations, max_batch=1, device=local_rank,
-                                 nn_mode=capi.NN_BRUTE_VALU)
-    with capi.IcpHandle(params) as h:
-        h.set_clouds_device(0, d_src_ptr, d_tgt_ptr)
-        h.run(1)
-        h.fetch_results(1)                       # warm-up
-        h.run(1)
-        r = h.fetch_results(1)[0]
-        ms = float(np.mean(h.get_iteration_timings()))
-    flops = 8.0 * r["n_src"] * r["n_tgt"]
+def bruteforce_leg(capi, intr, est, d_src_ptr, d_tgt_ptr, local_rank, iterations=4):
+    """The north-star algorithm on the same resident pair: every source x every target, distance step as a
+    dense contraction on the f32 MFMA pipe (k_nn_mfma); the fp32-VALU scan (k_nn_valu) is timed beside it."""
+    out = {}
+    for mode, name in ((capi.NN_BRUTE_MFMA, "mfma"), (capi.NN_BRUTE_VALU, "valu")):
+        params = capi.default_params(intr, estimator=est, iterations=iterations, max_batch=1, device=local_rank, nn_mode=mode)
+        with capi.IcpHandle(params) as h:
+            h.set_clouds_device(0, d_src_ptr, d_tgt_ptr)
+            h.run(1)
+            h.fetch_results(1)                       # warm-up
+            h.run(1)
+            r = h.fetch_results(1)[0]
+            ms = float(np.mean(h.get_iteration_timings()[1:]))    # iteration 0 has no previous match to bound the filter
+        out[name] = (ms, 8.0 * r["n_src"] * r["n_tgt"])
+    ms, flops = out["mfma"]
     ach = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "k_nn_valu (full brute-force scan, LDS-tiled, fp32 VALU)", "bound": "mfma", "achieved": ach,
-            "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": None,
-            "launch_ms": ms, "flops_per_launch": flops, "iterations_per_s_if_used": 1e3 / ms,
-            "note": "fp32 distance contraction; peak = fp32 vector == f32-MFMA dense peak (no MFMA issued by this kernel)"}
+    vms, _ = out["valu"]
+    return {"kernel": "k_nn_mfma (full brute-force scan: v_mfma_f32_16x16x4_f32 distance contraction as a conservative "
+                      "filter + exact fp32 re-evaluation of flagged pairs; bit-identical results)",
+            "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
+            "traffic": None, "launch_ms": ms, "flops_per_launch": flops, "iterations_per_s_if_used": 1e3 / ms,
+            "valu_kernel": {"kernel": "k_nn_valu (same scan on the fp32 VALU)", "launch_ms": vms,
+                            "achieved": flops / (vms * 1e-3) / 1e12, "frac": flops / (vms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}}
 
 
 def committed_traffic():
@@ -212,7 +218,7 @@ def main():
                          f"{args.iterations} ICP iterations, {args.estimator}, exact NN (tile-pruned brute force), "
                          f"seeds {seeds[0]}..{seeds[-1]}"),
             "pairs_per_gpu": P, "iterations": args.iterations, "estimator": args.estimator,
-            "nn_mode": {0: "auto(tiles)", 1: "brute_valu", 3: "tiles"}.get(args.nn_mode, str(args.nn_mode)),
+            "nn_mode": {0: "auto(tiles)", 1: "brute_valu", 2: "brute_mfma", 3: "tiles"}.get(args.nn_mode, str(args.nn_mode)),
             "n_src": [r["n_src"] for r in res][:4], "n_tgt": [r["n_tgt"] for r in res][:4],
             "parallelism": (f"source rows over {world} rank(s), RCCL all-reduce of 29 doubles per iteration" if is_dense else
                             f"pairs sharded one process per GPU x{world}, one RCCL all-gather of pose records per step"),
@@ -224,9 +230,10 @@ def main():
         launch_ms = statistics.mean(nn_ms) / max(args.iterations, 1)
         alg_bytes = sum((12 + 4) * r["n_src"] + (12 + (12 if est == 0 else 0)) * r["n_tgt"] for r in res)
         flops = sum(8.0 * r["n_src"] * r["n_tgt"] for r in res)
-        if args.nn_mode == capi.NN_BRUTE_VALU:
+        if args.nn_mode in (capi.NN_BRUTE_VALU, capi.NN_BRUTE_MFMA):
             ach = flops / (launch_ms * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "k_nn_valu (full brute-force scan)", "bound": "mfma", "achieved": ach,
+            out["roofline"] = {"kernel": "k_nn_mfma" if args.nn_mode == capi.NN_BRUTE_MFMA else "k_nn_valu (full brute-force scan)",
+                               "bound": "mfma", "achieved": ach,
                                "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": None,
                                "launch_ms": launch_ms, "flops_per_launch": flops}
         else:
@@ -247,7 +254,7 @@ def main():
                                      "total": statistics.mean(tot_ms)}
         out["nn_ms_per_iteration"] = [round(float(x), 4) for x in h.get_iteration_timings()]
     if rank == 0:
-        if world == 1 and not is_dense and not args.no_bruteforce and args.nn_mode != capi.NN_BRUTE_VALU:
+        if world == 1 and not is_dense and not args.no_bruteforce and args.nn_mode in (capi.NN_AUTO, capi.NN_TILES):
             out["roofline_bruteforce"] = bruteforce_leg(capi, intr, est, d_src.data_ptr(), d_tgt.data_ptr(), local_rank)
         if not args.no_cpu_baseline and world == 1 and not is_dense:
             idx, _ = h.get_correspondences(0)

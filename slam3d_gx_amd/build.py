@@ -15,6 +15,7 @@ LIB = os.path.join(HERE, "libslam3d_icp.so")
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+    "-mllvm", "-amdgpu-mfma-vgpr-form",      # MFMA results straight into VGPRs (the VALU folds them)
 ]
 
 

@@ -39,6 +39,8 @@ struct slam3d_icp_handle {
     long long *dbg = nullptr;     // per-tile NN statistics, only with SLAM3D_NN_DEBUG=1
     int *hint = nullptr;          // per source tile: target tile where the previous matches were
     int *scount = nullptr;        // per source tile: valid source points
+    float *tgtB = nullptr;        // BRUTE_MFMA: B-layout targets [B][4][npad]
+    unsigned int *qmax2 = nullptr; int npad = 0;
     // host
     std::vector<SlotPtrs> h_slots;
     SlotPtrs *pin_slots = nullptr;
@@ -110,7 +112,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->own_src); F(h->own_tgt); F(h->nrm); F(h->src_c); F(h->tgt_c); F(h->counts); F(h->ccounts); F(h->corr);
     F(h->flags); F(h->best); F(h->cd2); F(h->partials); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
     F(h->d_Tinit); F(h->d_slots); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4);
-    F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox); F(h->GP); F(h->ticket); F(h->dbg); F(h->prevq); F(h->hint); F(h->scount);
+    F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox); F(h->GP); F(h->ticket); F(h->dbg); F(h->prevq); F(h->hint); F(h->scount); F(h->tgtB); F(h->qmax2);
     if (h->pin_slots) (void)hipHostFree(h->pin_slots);
     if (h->pin_T) (void)hipHostFree(h->pin_T);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -137,7 +139,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     if (p->width <= 0 || p->height <= 0 || p->max_batch <= 0 || p->iterations < 0) return SLAM3D_E_INVALID;
     if (p->normal_window < 1 || (p->normal_window & 1) == 0 || p->normal_window / 2 > NRM_RMAX) return SLAM3D_E_INVALID;
     if (p->estimator != SLAM3D_EST_POINT2PLANE && p->estimator != SLAM3D_EST_SVD) return SLAM3D_E_INVALID;
-    if (p->nn_mode < SLAM3D_NN_AUTO || p->nn_mode > SLAM3D_NN_TILES || p->nn_mode == SLAM3D_NN_BRUTE_MFMA) return SLAM3D_E_INVALID;
+    if (p->nn_mode < SLAM3D_NN_AUTO || p->nn_mode > SLAM3D_NN_TILES) return SLAM3D_E_INVALID;
     if (!(p->max_corr_dist > 0.0) || !(p->z_filter > 0.0)) return SLAM3D_E_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device < 0 || p->device >= ndev) return SLAM3D_E_NODEVICE;
@@ -173,6 +175,10 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     A(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     A(dalloc(h->own_src, BN)); A(dalloc(h->own_tgt, BN)); A(dalloc(h->nrm, BN));
     if (brute) { A(dalloc(h->src_c, BN)); A(dalloc(h->tgt_c, BN)); A(dalloc(h->best, BS)); }
+    h->npad = ((h->N + MF_TCH - 1) / MF_TCH + 1) * MF_TCH;
+    if (nn_mode_of(h) == SLAM3D_NN_BRUTE_MFMA) {
+        A(dalloc(h->tgtB, (size_t)h->maxB * 4 * h->npad)); A(dalloc(h->qmax2, (size_t)h->maxB));
+    }
     A(dalloc(h->counts, (size_t)h->maxB * 4)); A(dalloc(h->ccounts, (size_t)h->maxB * 4));
     A(dalloc(h->corr, BS)); A(dalloc(h->flags, (size_t)h->maxB)); A(dalloc(h->cd2, BS)); A(dalloc(h->prevq, BS));
     A(dalloc(h->partials, (size_t)h->maxB * NSUMS * tg.tpad));
@@ -331,6 +337,11 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         HIPCHK(h, hipMemsetAsync(h->best, 0xFF, sizeof(unsigned long long) * (size_t)B * tg.nslots, s));
         hipLaunchKernelGGL(k_compact, dim3(2, B), dim3(1024), 0, s, h->d_slots, h->nrm, h->src_c, h->tgt_c, h->ccounts, g, tg,
                            use_normals, h->row0, h->row1);
+        if (nn_mode_of(h) == SLAM3D_NN_BRUTE_MFMA) {
+            HIPCHK(h, hipMemsetAsync(h->qmax2, 0, sizeof(unsigned int) * (size_t)B, s));
+            hipLaunchKernelGGL(k_make_bfrag, dim3(h->npad / 256, B), dim3(256), 0, s, h->tgt_c, h->ccounts, h->tgtB, h->qmax2,
+                               h->N, h->npad, 0.5f * g.zmax);
+        }
     }
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
     hipLaunchKernelGGL(k_init_T, dim3((B + 63) / 64), dim3(64), 0, s, dT, h->Tcur, h->trace_T, h->flags, B, iters);
@@ -350,10 +361,20 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
                            h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, h->partials, h->g, tg, h->dbg);
         if (e1) HIPCHK(h, hipEventRecord(e1, s));
     } else {
-        const int nsplit = pick_nsplit(h, B);
-        const int qblocks = (h->N + NN_BLOCK * NN_QPT - 1) / (NN_BLOCK * NN_QPT);
-        hipLaunchKernelGGL(k_nn_valu, dim3(qblocks, nsplit, B), dim3(NN_BLOCK), 0, s, h->src_c, h->tgt_c, h->ccounts, h->Tcur,
-                           h->best, h->N, tg.nslots, nsplit);
+        if (nn_mode_of(h) == SLAM3D_NN_BRUTE_MFMA) {
+            // one wave per block; target slices so that a pair alone still gives every SIMD several waves
+            int msplit = (8 * 1024 + (h->N / MF_Q) * B - 1) / ((h->N / MF_Q) * B);
+            if (msplit < 1) msplit = 1;
+            if (msplit > 16) msplit = 16;
+            hipLaunchKernelGGL(k_nn_mfma, dim3((h->N + MF_Q - 1) / MF_Q, msplit, B), dim3(64), 0, s, h->d_slots, h->nrm, h->src_c, h->tgt_c,
+                               h->tgtB, h->qmax2, h->ccounts, h->prevq, h->Tcur, h->best, h->g, tg, h->npad, 0.5f * h->g.zmax,
+                               msplit);
+        } else {
+            const int nsplit = pick_nsplit(h, B);
+            const int qblocks = (h->N + NN_BLOCK * NN_QPT - 1) / (NN_BLOCK * NN_QPT);
+            hipLaunchKernelGGL(k_nn_valu, dim3(qblocks, nsplit, B), dim3(NN_BLOCK), 0, s, h->src_c, h->tgt_c, h->ccounts, h->Tcur,
+                               h->best, h->N, tg.nslots, nsplit);
+        }
         if (e1) HIPCHK(h, hipEventRecord(e1, s));
         hipLaunchKernelGGL(k_accumulate, dim3(tg.nchunks, B), dim3(CHUNK), 0, s, h->d_slots, h->nrm, h->srcT, h->Tcur, h->best,
                            h->corr, h->cd2, h->prevq, h->partials, h->g, tg);

@@ -444,6 +444,186 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_valu(const float4 *__restrict__
     }
 }
 
+// ------------------------------------------------------------- full brute force on the matrix cores
+// SLAM3D_NN_BRUTE_MFMA: the distance step as a dense contraction on v_mfma_f32_16x16x4_f32.  With
+// coordinates taken relative to a fixed centre c, for query i (row) and candidate j (column)
+//     D[i][j] = sum_k A[i][k] B[k][j] + C[i],   A[i] = (-2px,-2py,-2pz, 1),  B[.][j] = (qx,qy,qz,|q|^2),
+//     C[i] = -(U_i - |p|^2 + eps_i)                     =>   D[i][j] = |p-q|^2 - U_i - eps_i  (+ rounding)
+// so D <= 0 flags every pair whose distance can be <= the query's upper bound U_i (previous match /
+// same-pixel target / gate).  The MFMA result is only a FILTER: flagged pairs (a few per query) are
+// re-evaluated with the canonical fp32 distance and merged with ds_min_u64 on (d2 bits << 32 | pixel),
+// so the output is bit-identical to the VALU scan.  eps_i bounds every rounding in the chain
+// (DESIGN.md section 5): the k-ordered fma chain of the MFMA, |q|^2, |p|^2, the centring.
+// 64 queries per wave (4 row blocks) share each B fragment: 4 MFMAs per ds_read_b32; the VALU only
+// folds the 16 results with v_min3 and tests the sign.  Targets stream through LDS in chunks of 256,
+// global loads of chunk n+1 are issued before chunk n is computed.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int MF_TCH = 256;
+
+// B-layout target arrays for the MFMA scan: rel coords + squared norm, SoA rows of length npad
+__global__ __launch_bounds__(256) void k_make_bfrag(const float4 *__restrict__ tgt_c, const int *__restrict__ ccounts,
+                                                    float *__restrict__ tgtB, unsigned int *__restrict__ qmax2_bits,
+                                                    int N, int npad, float cz)
+{
+    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= npad) return;
+    const int nt = ccounts[b * 4 + 1];
+    float rx = 1e4f, ry = 1e4f, rz = 1e4f, n2 = 3e8f;                 // padding: far away, never flagged
+    if (j < nt) {
+        const float4 q = tgt_c[(size_t)b * N + j];
+        rx = q.x; ry = q.y; rz = q.z - cz;
+        n2 = __fmaf_rn(rz, rz, __fmaf_rn(ry, ry, rx * rx));
+        atomicMax(qmax2_bits + b, (unsigned int)__float_as_int(n2));   // non-negative floats order like uints
+    }
+    float *__restrict__ Bb = tgtB + (size_t)b * 4 * npad;
+    Bb[j] = rx; Bb[(size_t)npad + j] = ry; Bb[2 * (size_t)npad + j] = rz; Bb[3 * (size_t)npad + j] = n2;
+}
+
+// grid (ceil(N/MF_Q), splits, B), block 64 = ONE independent wave: MF_Q = 128 consecutive compacted sources (8 row
+// blocks of 16: eight MFMAs share each B fragment, halving the L2->register stream per flop) against one
+// contiguous slice of the targets.  No LDS staging and no barriers: the B fragments (4 bytes per lane and
+// group) stream straight from L2 into registers, eight groups ahead; exact candidates are fetched only
+// for flagged pairs.  Slices merge with a 64-bit atomicMin on best[] (same key as the VALU kernel).
+constexpr int MF_AHEAD = 8;
+constexpr int MF_RB = 8;                 // row blocks (of 16 queries) per wave
+constexpr int MF_Q = 16 * MF_RB;         // queries per wave
+
+__global__ __launch_bounds__(64) void k_nn_mfma(const SlotPtrs *__restrict__ slots, const float4 *__restrict__ nrm_all,
+                                                const float4 *__restrict__ src_c, const float4 *__restrict__ tgt_c,
+                                                const float *__restrict__ tgtB, const unsigned int *__restrict__ qmax2_bits,
+                                                const int *__restrict__ ccounts, const float4 *__restrict__ prevq,
+                                                const double *__restrict__ Tcur, unsigned long long *__restrict__ best,
+                                                Geometry g, TileGrid tg, int npad, float cz, int nsplit)
+{
+    __shared__ float4 qpos[MF_Q];
+    __shared__ float4 qrel[MF_Q];
+    __shared__ float qthr[MF_Q];
+    __shared__ unsigned long long qkey[MF_Q];
+    const int b = blockIdx.z, lane = threadIdx.x;
+    const int N = g.N;
+    const int ns = ccounts[b * 4 + 0], nt = ccounts[b * 4 + 1];
+    const int i0 = blockIdx.x * MF_Q;
+    if (i0 >= ns) return;
+    const float4 *__restrict__ Q = tgt_c + (size_t)b * N;
+    const float *__restrict__ Bb = tgtB + (size_t)b * 4 * npad;
+    const float4 *__restrict__ tcloud = slots[b].tgt;
+    const float4 *__restrict__ tnrm = nrm_all + (size_t)b * N;
+    // ---- each lane prepares MF_Q/64 queries: transformed point, upper bound, filter threshold
+    const Rt m = load_rt(Tcur + b * 16);
+    const float qmax2 = __int_as_float((int)qmax2_bits[b]);
+    int my_slot[MF_Q / 64];
+#pragma unroll
+    for (int h = 0; h < MF_Q / 64; ++h) {
+        const int ql = h * 64 + lane, i = i0 + ql;
+        float4 s4 = make_float4(0, 0, 0, __int_as_float(-1));
+        if (i < ns) s4 = src_c[(size_t)b * N + i];
+        const int slot = __float_as_int(s4.w);
+        const bool valid = slot >= 0;
+        my_slot[h] = slot;
+        float px, py, pz;
+        xform(m, s4.x, s4.y, s4.z, px, py, pz);
+        unsigned long long bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
+        if (valid) {
+            const float4 pq = prevq[(size_t)b * tg.nslots + slot];
+            const int jprev = __float_as_int(pq.w);
+            float4 qg = pq;
+            int jg = jprev;
+            bool tv = jprev >= 0;
+            if (!tv) {                                             // same-pixel target as the first guess
+                const int tile = slot >> 6, ln = slot & 63;
+                const int u = (tile % tg.ntx) * TILE_PX + (ln & 7), v = (tile / tg.ntx) * TILE_PX + (ln >> 3);
+                jg = v * g.W + u;
+                qg = tcloud[jg];
+                tv = pt_valid(qg.x, qg.y, qg.z, g.zmax) && (g.estimator != 0 || tnrm[jg].w > 0.5f);
+            }
+            const float d2g = canon_d2(px, py, pz, qg.x, qg.y, qg.z);
+            if (tv && d2g <= g.gate2) bkey = ((unsigned long long)(unsigned int)__float_as_int(d2g) << 32) | (unsigned int)jg;
+        }
+        const float U = __int_as_float((int)(unsigned int)(bkey >> 32));
+        const float rx = px, ry = py, rz = pz - cz;
+        const float n2p = __fmaf_rn(rz, rz, __fmaf_rn(ry, ry, rx * rx));
+        const float eps = 1.0e-6f * (n2p + qmax2) + 4.0e-6f * sqrtf(U) + 1.0e-6f;
+        qpos[ql] = make_float4(px, py, pz, 0.0f);
+        qrel[ql] = make_float4(-2.0f * rx, -2.0f * ry, -2.0f * rz, 1.0f);
+        qthr[ql] = valid ? (U - n2p) + eps : -1e30f;           // invalid rows can never be flagged
+        qkey[ql] = bkey;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- MFMA operands: A[rb] = component (lane>>4) of query rb*16 + (lane&15); C[rb][r] = -thr of row 4*(lane>>4)+r
+    const int kq = lane >> 4, jq = lane & 15;
+    float A[MF_RB];
+    f32x4 Cc[MF_RB];
+#pragma unroll
+    for (int rb = 0; rb < MF_RB; ++rb) {
+        const float4 a4 = qrel[rb * 16 + jq];
+        A[rb] = kq == 0 ? a4.x : (kq == 1 ? a4.y : (kq == 2 ? a4.z : a4.w));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cc[rb][r] = -qthr[rb * 16 + 4 * kq + r];
+    }
+    // ---- this block's slice of the target groups (16 targets per group; the padded tail is never flagged)
+    const int ngroups = (nt + 15) / 16;
+    const int g_begin = (int)(((long long)blockIdx.y * ngroups) / nsplit);
+    const int g_end = (int)(((long long)(blockIdx.y + 1) * ngroups) / nsplit);
+    const float *__restrict__ Bl = Bb + (size_t)kq * npad + jq;             // this lane's stream: Bl[16 * group]
+    auto fold = [&](const f32x4 *D, int grp) __attribute__((always_inline)) {
+        int mn = 0x7fffffff;                                               // "some value <= 0" <=> "min of the bits as int <= 0"
+#pragma unroll
+        for (int rb = 0; rb < MF_RB; ++rb)
+            mn = min(mn, min(min(__float_as_int(D[rb][0]), __float_as_int(D[rb][1])),
+                             min(__float_as_int(D[rb][2]), __float_as_int(D[rb][3]))));
+        if (__ballot(mn <= 0) != 0ull) {
+            // exact re-evaluation of the flagged pairs (rare): canonical distance, 64-bit key, LDS atomic min
+            const int j = grp * 16 + jq;
+            float4 c4 = make_float4(0, 0, 0, __int_as_float(-1));
+            if (j < nt) c4 = Q[j];
+#pragma unroll
+            for (int rb = 0; rb < MF_RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool f = D[rb][r] <= 0.0f && j < nt;
+                    if (__ballot(f) != 0ull && f) {
+                        const int qi = rb * 16 + 4 * kq + r;
+                        const float4 p4 = qpos[qi];
+                        const float d2 = canon_d2(p4.x, p4.y, p4.z, c4.x, c4.y, c4.z);
+                        const unsigned long long key =
+                            ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(c4.w);
+                        atomicMin(&qkey[qi], key);
+                    }
+                }
+        }
+    };
+    float bf[MF_AHEAD], bn[MF_AHEAD];
+#pragma unroll
+    for (int u = 0; u < MF_AHEAD; ++u) bf[u] = Bl[(size_t)16 * min(g_begin + u, ngroups)];     // npad leaves room past the end
+    for (int g0 = g_begin; g0 < g_end; g0 += MF_AHEAD) {
+#pragma unroll
+        for (int u = 0; u < MF_AHEAD; ++u) bn[u] = Bl[(size_t)16 * min(g0 + MF_AHEAD + u, ngroups)];   // next 8 groups in flight
+        f32x4 D[2][MF_RB];
+#pragma unroll
+        for (int rb = 0; rb < MF_RB; ++rb) D[0][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rb], bf[0], Cc[rb], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < MF_AHEAD; ++u) {
+            if (u + 1 < MF_AHEAD) {
+#pragma unroll
+                for (int rb = 0; rb < MF_RB; ++rb)
+                    D[(u + 1) & 1][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rb], bf[u + 1], Cc[rb], 0, 0, 0);
+            }
+            if (g0 + u < g_end) fold(D[u & 1], g0 + u);
+        }
+#pragma unroll
+        for (int u = 0; u < MF_AHEAD; ++u) bf[u] = bn[u];
+    }
+#pragma unroll
+    for (int h = 0; h < MF_Q / 64; ++h) {
+        if (my_slot[h] >= 0) {
+            const unsigned long long key = qkey[h * 64 + lane];
+            if ((unsigned int)(key & 0xffffffffull) != 0xffffffffu) atomicMin(best + (size_t)b * tg.nslots + my_slot[h], key);
+        }
+    }
+}
+
 // rows of the normal equations for a source point p' matched to target point q with normal n (spec S4)
 __device__ __forceinline__ void row_sums(int estimator, float pxf, float pyf, float pzf, const float4 q4,
                                          const float4 n4, double *__restrict__ s)

@@ -146,7 +146,7 @@ def test_T_init_and_roundtrip_property(gpu_lib):
     assert rot < 1e-4 and tr < 1e-4
 
 
-@pytest.mark.parametrize("nn_mode", [capi.NN_BRUTE_VALU, capi.NN_TILES])
+@pytest.mark.parametrize("nn_mode", [capi.NN_BRUTE_VALU, capi.NN_BRUTE_MFMA, capi.NN_TILES])
 @pytest.mark.parametrize("estimator", [0, 1])
 def test_every_nn_mode_is_bit_identical(gpu_lib, nn_mode, estimator):
     """All NN variants (full brute force, tile-pruned) must return the same indices / d2 / poses as the
