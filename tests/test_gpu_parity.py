@@ -214,3 +214,38 @@ def test_dense_mode_two_emulated_ranks(gpu_lib):
         h.set_clouds_host(0, s4, t4)
         r1rank = dense.dense_align(h, 1, 0)
     assert np.array_equal(r1rank["T_raw"], ro["T_trace"][-1])
+
+
+def test_config3_batch_of_full_size_pairs(gpu_lib):
+    """BASELINE config 3 shape (16 of the 64 pairs to keep the oracle leg short): one batched call on 640x480 pairs.
+    Every pair converges to its analytic pose within the noise floor; sampled pairs equal the oracle bit for bit."""
+    B = 16
+    prs = [_pair(1000 + i, 640, 480) for i in range(B)]
+    intr = prs[0][0].intr
+    with capi.IcpHandle(capi.default_params(intr, iterations=20, max_batch=B)) as h:
+        res = h.align_batch([p[1] for p in prs], [p[2] for p in prs])
+        idx_first, idx_last = h.get_correspondences(0)[0], h.get_correspondences(B - 1)[0]
+    assert all(r["status"] == 0 for r in res)
+    for (pr, _, _), r in zip(prs, res):
+        rot, tr = O.pose_error(pr.T_gt, r["T"])
+        assert rot < 3e-3 and tr < 1e-2, (pr.seed, rot, tr)
+    for b, idx in ((0, idx_first), (B - 1, idx_last)):
+        pr, s4, t4 = prs[b]
+        ro = O.icp(s4, t4, O.params(intr, iterations=20, nn_method=1))
+        assert np.array_equal(idx, ro["idx"])
+        assert np.array_equal(res[b]["T_raw"], ro["T_trace"][-1])
+
+
+def test_config5_dense_1280x960(gpu_lib):
+    """BASELINE config 5 shape: one 1280x960 pair (1.2 M points), point-to-plane, vs the kd-tree oracle."""
+    pr, s4, t4 = _pair(2000, 1280, 960)
+    iters = 8
+    ro = O.icp(s4, t4, O.params(pr.intr, iterations=iters, nn_method=1))
+    with capi.IcpHandle(capi.default_params(pr.intr, iterations=iters)) as h:
+        r = h.align(s4, t4)
+        idx, d2 = h.get_correspondences(0)
+    assert r["n_src"] == ro["n_src"] and r["n_tgt"] == ro["n_tgt"]
+    assert np.array_equal(idx, ro["idx"]) and np.array_equal(d2, ro["d2"])
+    rot, tr = O.pose_error(ro["T_trace"][-1], r["T_raw"])
+    assert rot <= ROT_TOL and tr <= TRANS_TOL
+    assert np.array_equal(r["T_raw"], ro["T_trace"][-1])
