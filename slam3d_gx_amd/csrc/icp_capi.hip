@@ -190,7 +190,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     A(dalloc(h->d_Tinit, (size_t)h->maxB * 16)); A(dalloc(h->d_slots, (size_t)h->maxB));
     A(dalloc(h->d_depth, (size_t)2 * h->N)); A(dalloc(h->d_idx, (size_t)h->N)); A(dalloc(h->d_d2, (size_t)h->N));
     A(dalloc(h->d_scratch4, (size_t)h->N));
-    A(dalloc(h->srcT, (size_t)h->maxB * tg.ntiles * TILE_SLOTS)); A(dalloc(h->tgtT, (size_t)h->maxB * tg.ntiles * TILE_SLOTS));
+    A(dalloc(h->srcT, (size_t)h->maxB * tg.ntiles * TILE_SLOTS)); A(dalloc(h->tgtT, (size_t)h->maxB * tg.ntiles * TILE_REC));
     A(dalloc(h->tbox, (size_t)h->maxB * tg.ntiles * 2)); A(dalloc(h->cbox, (size_t)h->maxB * tg.ncoarse * 2));
     A(hipHostMalloc((void **)&h->pin_slots, sizeof(SlotPtrs) * h->maxB, hipHostMallocDefault));
     A(hipHostMalloc((void **)&h->pin_T, sizeof(double) * 16 * h->maxB, hipHostMallocDefault));

@@ -194,6 +194,7 @@ __global__ __launch_bounds__(NRM_BX * NRM_BY) void k_normals(const SlotPtrs *__r
 // pixel index j.
 constexpr int TILE_PX = 8;                 // tile edge in pixels
 constexpr int TILE_SLOTS = 64;             // = one wavefront
+constexpr int TILE_REC = 72;               // target tile record: 64 slots (4 quadrants x 16) + 4 x (lo, hi) quadrant boxes
 constexpr int COARSE_TILES = 8;            // coarse box edge in tiles (64 px)
 constexpr int TILES_PER_CHUNK = CHUNK / TILE_SLOTS;
 
@@ -236,9 +237,10 @@ __device__ __forceinline__ float wave_max(float v)
 }
 
 // grid (ntiles, 2, B), block 64.  srcT slot w = pixel index (int bits) or -1; rows outside
-// [row0,row1) hold no source (dense multi-GPU mode).  Target tiles are compacted inside the tile
-// (valid slots first, w = pixel index) and get an AABB taken from the data:
-// box[2t] = (minx, miny, minz, count), box[2t+1] = (maxx, maxy, maxz, 0).
+// [row0,row1) hold no source (dense multi-GPU mode).  A target tile record (TILE_REC float4) holds its four
+// 4x4-pixel quadrants, each compacted (valid slots first, w = pixel index) into 16 slots, followed by the
+// quadrants' AABBs (lo.xyz, count | hi.xyz); the tile AABB goes to box[2t] = (min, count), box[2t+1] = (max, 0).
+// All boxes are taken from the data (no camera model).
 __global__ __launch_bounds__(64) void k_build_tiles(const SlotPtrs *__restrict__ slots,
                                                     const float4 *__restrict__ nrm_all,
                                                     float4 *__restrict__ srcT, float4 *__restrict__ tgtT,
@@ -261,16 +263,35 @@ __global__ __launch_bounds__(64) void k_build_tiles(const SlotPtrs *__restrict__
     }
     const unsigned long long m = __ballot(ok);
     const int cnt = __popcll(m);
-    const size_t base = ((size_t)b * tg.ntiles + t) * TILE_SLOTS;
     if (which == 0) {
-        srcT[base + lane] = q;
+        srcT[((size_t)b * tg.ntiles + t) * TILE_SLOTS + lane] = q;
         if (lane == 0) scount[(size_t)b * tg.ntiles + t] = cnt;     // summed per coarse cell (no hot atomic)
         return;
     }
-    const int slot = ok ? __popcll(m & ((1ull << lane) - 1ull)) : cnt + __popcll(~m & ((1ull << lane) - 1ull));
-    tgtT[base + slot] = q;
-    const float mnx = wave_min(ok ? q.x : inf), mny = wave_min(ok ? q.y : inf), mnz = wave_min(ok ? q.z : inf);
-    const float mxx = wave_max(ok ? q.x : -inf), mxy = wave_max(ok ? q.y : -inf), mxz = wave_max(ok ? q.z : -inf);
+    // quadrant of this lane's pixel: (row >= 4) * 2 + (col >= 4); lanes of one quadrant differ in bits 0,1,3,4
+    const int qd = ((lane >> 5) << 1) | ((lane >> 2) & 1);
+    const unsigned long long qmask = (qd & 1 ? 0xF0F0F0F0ull : 0x0F0F0F0Full) << (qd & 2 ? 32 : 0);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int cntq = __popcll(m & qmask);
+    const int rank = ok ? __popcll(m & qmask & below) : cntq + __popcll(~m & qmask & below);
+    const size_t base = ((size_t)b * tg.ntiles + t) * TILE_REC;
+    tgtT[base + qd * 16 + rank] = q;
+    float mnx = ok ? q.x : inf, mny = ok ? q.y : inf, mnz = ok ? q.z : inf;
+    float mxx = ok ? q.x : -inf, mxy = ok ? q.y : -inf, mxz = ok ? q.z : -inf;
+#pragma unroll
+    for (int o = 1; o <= 16; o = (o == 2 ? 8 : o * 2)) {          // xor 1, 2, 8, 16: inside the quadrant
+        mnx = fminf(mnx, __shfl_xor(mnx, o)); mny = fminf(mny, __shfl_xor(mny, o)); mnz = fminf(mnz, __shfl_xor(mnz, o));
+        mxx = fmaxf(mxx, __shfl_xor(mxx, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o));
+    }
+    if ((lane & 0x1B) == 0) {                                     // lanes 0, 4, 32, 36: first lane of each quadrant
+        tgtT[base + TILE_SLOTS + 2 * qd] = make_float4(mnx, mny, mnz, __int_as_float(cntq));
+        tgtT[base + TILE_SLOTS + 2 * qd + 1] = make_float4(mxx, mxy, mxz, 0.0f);
+    }
+#pragma unroll
+    for (int o = 4; o <= 32; o *= 8) {                            // xor 4, 32: across the quadrants
+        mnx = fminf(mnx, __shfl_xor(mnx, o)); mny = fminf(mny, __shfl_xor(mny, o)); mnz = fminf(mnz, __shfl_xor(mnz, o));
+        mxx = fmaxf(mxx, __shfl_xor(mxx, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o));
+    }
     if (lane == 0) {
         tbox[((size_t)b * tg.ntiles + t) * 2] = make_float4(mnx, mny, mnz, __int_as_float(cnt));
         tbox[((size_t)b * tg.ntiles + t) * 2 + 1] = make_float4(mxx, mxy, mxz, 0.0f);
@@ -801,7 +822,7 @@ __device__ __forceinline__ float box_gap2(const float4 lo, const float4 hi, floa
     return gx * gx + gy * gy + gz * gz;      // empty boxes (lo=+inf, hi=-inf) give +inf
 }
 
-constexpr int NN_STAGE = 8;          // target tiles staged in LDS per batch (8 KB per wave, 32 KB per block)
+constexpr int NN_STAGE = 7;          // target tile records staged in LDS per batch (7 x 1152 B per wave, 31.5 KB per block)
 
 // grid (nchunks, B), block 256 = 4 independent waves = 4 consecutive source tiles (no block barriers).
 // Latency structure: everything the wave will certainly need is requested in ONE round of loads at
@@ -821,7 +842,7 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
                                                         double *__restrict__ TP, Geometry g, TileGrid tg,
                                                         long long *__restrict__ dbg /* nullable: 8 x int64 per tile */)
 {
-    __shared__ float4 stage_all[TILES_PER_CHUNK][NN_STAGE * TILE_SLOTS];
+    __shared__ float4 stage_all[TILES_PER_CHUNK][NN_STAGE * TILE_REC];
     const long long clk0 = dbg ? clock64() : 0;
     long long clk1 = 0, clk2 = 0, clk3 = 0, clk2a = 0, clk2b = 0;
     int n_scanned = 0, n_cand = 0, n_batches = 0, n_chit = 0, n_fhit = 0, n_refined = 0;
@@ -838,7 +859,7 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
     const float4 *__restrict__ tnrm = nrm_all + (size_t)b * g.N;
     const float4 *__restrict__ TB = tbox + (size_t)b * tg.ntiles * 2;
     const float4 *__restrict__ CB = cbox + (size_t)b * tg.ncoarse * 2;
-    const float4 *__restrict__ TT = tgtT + (size_t)b * tg.ntiles * TILE_SLOTS;
+    const float4 *__restrict__ TT = tgtT + (size_t)b * tg.ntiles * TILE_REC;
     const float4 s4 = srcT[((size_t)b * tg.ntiles + t) * TILE_SLOTS + lane];
     const int pix = __float_as_int(s4.w);
     const bool valid = pix >= 0;
@@ -853,9 +874,9 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
         const int cown = (ty0 / COARSE_TILES) * tg.ncx + tx0 / COARSE_TILES;     // coarse cell of that centre
         int tt[NN_STAGE];
         float4 r[NN_STAGE];
-        // ---- phase A tile list: centre, edge neighbours, three corners of the 3x3 block at the same location
+        // ---- phase A tile list: centre, edge neighbours, two corners of the 3x3 block around the hint
         {
-            const int ox[NN_STAGE] = { 0, -1, 1, 0, 0, -1, 1, -1 }, oy[NN_STAGE] = { 0, 0, 0, -1, 1, -1, -1, 1 };
+            const int ox[NN_STAGE] = { 0, -1, 1, 0, 0, -1, 1 }, oy[NN_STAGE] = { 0, 0, 0, -1, 1, -1, -1 };
 #pragma unroll
             for (int k = 0; k < NN_STAGE; ++k) {
                 const int tx = tx0 + ox[k], ty = ty0 + oy[k];
@@ -865,7 +886,7 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
         // ---- one round of independent loads
 #pragma unroll
         for (int k = 0; k < NN_STAGE; ++k)
-            r[k] = tt[k] >= 0 ? TT[(size_t)tt[k] * TILE_SLOTS + lane] : make_float4(inf, inf, inf, __int_as_float(-1));
+            r[k] = tt[k] >= 0 ? TT[(size_t)tt[k] * TILE_REC + lane] : make_float4(inf, inf, inf, __int_as_float(-1));
         const float4 pq = prevq[gs];
         float4 qs = make_float4(0, 0, 0, 0);
         float ws = 1.0f;
@@ -896,31 +917,46 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
         // waves that still carry a gate-sized bound have the long wide search ahead of them: let them run
         // ahead of their SIMD neighbours so that they do not become the tail of the launch
         if (__ballot(valid && (unsigned int)(bkey & 0xffffffffull) == 0xffffffffu) != 0ull) __builtin_amdgcn_s_setprio(2);
-        // scan staged tile k (tile id tile, both wave-uniform) if some lane can still improve/tie inside its box
-        auto scan_staged = [&](int k, int tile) __attribute__((always_inline)) {
-            const float4 lo = TB[2 * tile], hi = TB[2 * tile + 1];           // uniform -> scalar loads
+        // scan staged tile k (tile id tile, both wave-uniform): tile box first, then its four 4x4-pixel quadrants,
+        // each only if some lane can still improve/tie inside that box
+        auto lane_gap_ok = [&](const float4 lo, const float4 hi) __attribute__((always_inline)) {
             const float cur = __int_as_float((int)(unsigned int)(bkey >> 32));
             const float gx = fmaxf(0.0f, fmaxf(lo.x - px, px - hi.x));
             const float gy = fmaxf(0.0f, fmaxf(lo.y - py, py - hi.y));
             const float gz = fmaxf(0.0f, fmaxf(lo.z - pz, pz - hi.z));
-            const bool need = valid && (gx * gx + gy * gy + gz * gz) <= cur * 1.00001f + 1e-30f;
-            if (__ballot(need) == 0ull) return;
-            const int cnt = __builtin_amdgcn_readfirstlane(__float_as_int(lo.w));
-            n_scanned += 1; n_cand += cnt;
-            const float4 *__restrict__ cand = st + k * TILE_SLOTS;
-#pragma unroll 8
-            for (int i = 0; i < cnt; ++i) {
-                const float4 q = cand[i];                                    // same address in every lane: LDS broadcast
-                const float d2 = canon_d2(px, py, pz, q.x, q.y, q.z);
-                const unsigned long long key =
-                    ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(q.w);
-                bkey = key < bkey ? key : bkey;
+            return valid && (gx * gx + gy * gy + gz * gz) <= cur * 1.00001f + 1e-30f;
+        };
+        auto scan_staged = [&](int k, int tile) __attribute__((always_inline)) {
+            if (__ballot(lane_gap_ok(TB[2 * tile], TB[2 * tile + 1])) == 0ull) return;     // uniform -> scalar loads
+            n_scanned += 1;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const float4 lo = st[k * TILE_REC + TILE_SLOTS + 2 * qd], hi = st[k * TILE_REC + TILE_SLOTS + 2 * qd + 1];
+                const int cnt = __builtin_amdgcn_readfirstlane(__float_as_int(lo.w));
+                if (cnt == 0 || __ballot(lane_gap_ok(lo, hi)) == 0ull) continue;
+                n_cand += cnt;
+                const float4 *__restrict__ cand = st + k * TILE_REC + qd * 16;
+#pragma unroll 4
+                for (int i = 0; i < cnt; ++i) {
+                    const float4 q = cand[i];                                // same address in every lane: LDS broadcast
+                    const float d2 = canon_d2(px, py, pz, q.x, q.y, q.z);
+                    const unsigned long long key =
+                        ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(q.w);
+                    bkey = key < bkey ? key : bkey;
+                }
             }
         };
         auto park_and_scan = [&]() __attribute__((always_inline)) {
             n_batches += 1;
+            // lanes 0..55 fetch the quadrant boxes of the staged tiles (8 float4 per tile) with one load
+            int my_tile = -1;
 #pragma unroll
-            for (int k = 0; k < NN_STAGE; ++k) st[k * TILE_SLOTS + lane] = r[k];
+            for (int k = 0; k < NN_STAGE; ++k) if ((lane >> 3) == k) my_tile = tt[k];
+            float4 qb = make_float4(inf, inf, inf, 0.0f);                    // empty box, count 0
+            if (my_tile >= 0) qb = TT[(size_t)my_tile * TILE_REC + TILE_SLOTS + (lane & 7)];
+#pragma unroll
+            for (int k = 0; k < NN_STAGE; ++k) st[k * TILE_REC + lane] = r[k];
+            if (lane < NN_STAGE * 8) st[(lane >> 3) * TILE_REC + TILE_SLOTS + (lane & 7)] = qb;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -966,7 +1002,8 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
             bool hit2 = false;
             if (tx < tg.ntx && ty < tg.nty) {
                 const int dx = tx - tx0, dy = ty - ty0;
-                const bool in_a = abs(dx) <= 1 && abs(dy) <= 1 && !(dx == 1 && dy == 1);   // the 8 tiles of phase A
+                // the 7 tiles of phase A: the 3x3 block without its two lower corners (-1,+1), (+1,+1)
+                const bool in_a = abs(dx) <= 1 && abs(dy) <= 1 && !(dy == 1 && dx != 0);
                 hit2 = !in_a && reach(lo, hi, thr_t, thr_l);
             }
             unsigned long long tm0 = __ballot(hit2), tm = 0ull;
@@ -998,7 +1035,7 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
                 }
 #pragma unroll
                 for (int k = 0; k < NN_STAGE; ++k)
-                    r[k] = tt[k] >= 0 ? TT[(size_t)tt[k] * TILE_SLOTS + lane] : make_float4(inf, inf, inf, __int_as_float(-1));
+                    r[k] = tt[k] >= 0 ? TT[(size_t)tt[k] * TILE_REC + lane] : make_float4(inf, inf, inf, __int_as_float(-1));
                 park_and_scan();
             }
         };
