@@ -822,14 +822,20 @@ __device__ __forceinline__ float box_gap2(const float4 lo, const float4 hi, floa
     return gx * gx + gy * gy + gz * gz;      // empty boxes (lo=+inf, hi=-inf) give +inf
 }
 
-constexpr int NN_STAGE = 7;          // target tile records staged in LDS per batch (7 x 1152 B per wave, 31.5 KB per block)
+constexpr int NN_STAGE = 5;          // target tile records staged in LDS per batch (5 x 1152 B per wave)
+constexpr int NN_MAX_ITEMS = 256;    // (owner wave, coarse cell) work items shared by the 4 waves of a block
 
-// grid (nchunks, B), block 256 = 4 independent waves = 4 consecutive source tiles (no block barriers).
-// Latency structure: everything the wave will certainly need is requested in ONE round of loads at
-// the top (source slot, previous match point, same-pixel target, the first 8 tiles of the 3x3
-// neighbourhood, the coarse boxes and the child boxes of the own coarse cell).  Candidate tiles are
-// parked in this wave's private LDS slab and scanned with broadcast ds_read_b128 (every lane reads
-// the same candidate); all cross-lane reductions are DPP / permlane (VALU rate).
+// grid (nchunks, B), block 256 = 4 waves.  Wave w of block c OWNS source tile c + w*nchunks (four tiles from
+// four different image bands, so that an expensive tile -- e.g. one lying over a hole of the target, which
+// must prove "nothing within max_corr_dist" -- rarely shares a block with another one).
+//   1. every wave: one round of loads, upper bounds, exhaustive scan of the 5 tiles around its hint tile;
+//   2. every wave publishes its queries (point, running key, tight/loose class) in LDS and appends one work
+//      item per coarse cell its two query boxes can reach;                                   -- barrier --
+//   3. all four waves drain the item list together: an item = sweep one coarse cell for one owner (child
+//      boxes -> ballot -> per-lane re-test -> stage tiles in this wave's LDS slab -> scan the needed
+//      quadrants), merged into the owner's keys with ds_min_u64;                             -- barrier --
+//   4. every wave finishes its own tile: gate, row products, level-1 reduction, hint for the next iteration.
+// The result is independent of which wave processes which item (keys are merged by an exact minimum).
 __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restrict__ slots,
                                                         const float4 *__restrict__ nrm_all,
                                                         const float4 *__restrict__ srcT,
@@ -843,50 +849,179 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
                                                         long long *__restrict__ dbg /* nullable: 8 x int64 per tile */)
 {
     __shared__ float4 stage_all[TILES_PER_CHUNK][NN_STAGE * TILE_REC];
+    __shared__ float4 qpos[TILES_PER_CHUNK][TILE_SLOTS];              // p'.xyz, w = 0 invalid / 1 tight / 2 loose
+    __shared__ unsigned long long qkey[TILES_PER_CHUNK][TILE_SLOTS];
+    __shared__ int wcentre[TILES_PER_CHUNK][2];                        // hint centre (tx0, ty0) of each owner
+    __shared__ int items[NN_MAX_ITEMS];
+    __shared__ int n_items, next_item;
     const long long clk0 = dbg ? clock64() : 0;
-    long long clk1 = 0, clk2 = 0, clk3 = 0, clk2a = 0, clk2b = 0;
+    long long clk1 = 0, clk2 = 0, clk3 = 0;
     int n_scanned = 0, n_cand = 0, n_batches = 0, n_chit = 0, n_fhit = 0, n_refined = 0;
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.y, c = blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int t = c * TILES_PER_CHUNK + w;
-    if (t >= tg.ntiles) return;
+    const int t = c + w * tg.nchunks;                                   // interleaved ownership
+    const bool has_tile = t < tg.ntiles;
     float4 *__restrict__ st = stage_all[w];
-    const int slot = c * CHUNK + threadIdx.x;
-    const size_t gs = (size_t)b * tg.nslots + slot;
+    const size_t gs = (size_t)b * tg.nslots + (size_t)(has_tile ? t : 0) * TILE_SLOTS + lane;
     const float inf = __int_as_float(0x7f800000);
     const float4 *__restrict__ tcloud = slots[b].tgt;
     const float4 *__restrict__ tnrm = nrm_all + (size_t)b * g.N;
     const float4 *__restrict__ TB = tbox + (size_t)b * tg.ntiles * 2;
     const float4 *__restrict__ CB = cbox + (size_t)b * tg.ncoarse * 2;
     const float4 *__restrict__ TT = tgtT + (size_t)b * tg.ntiles * TILE_REC;
-    const float4 s4 = srcT[((size_t)b * tg.ntiles + t) * TILE_SLOTS + lane];
-    const int pix = __float_as_int(s4.w);
-    const bool valid = pix >= 0;
-    unsigned long long bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
+    if (threadIdx.x == 0) { n_items = 0; next_item = 0; }
+    __syncthreads();
+
+    // ---- "current query" context: the wave's own tile in step 1, an item's owner in step 3
     float px = 0.0f, py = 0.0f, pz = 0.0f;
-    if (__ballot(valid) != 0ull) {
-        // centre of the first (3x3) scan: where this tile's matches were in the previous iteration (a hint
-        // only -- exactness never depends on it); initially the same image location
+    bool valid = false, tight = false, loose = false;
+    unsigned long long bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
+    int tx0 = 0, ty0 = 0;
+    int tt[NN_STAGE];
+    float4 r[NN_STAGE];
+
+    auto lane_gap_ok = [&](const float4 lo, const float4 hi) __attribute__((always_inline)) {
+        const float cur = __int_as_float((int)(unsigned int)(bkey >> 32));
+        const float gx = fmaxf(0.0f, fmaxf(lo.x - px, px - hi.x));
+        const float gy = fmaxf(0.0f, fmaxf(lo.y - py, py - hi.y));
+        const float gz = fmaxf(0.0f, fmaxf(lo.z - pz, pz - hi.z));
+        return valid && (gx * gx + gy * gy + gz * gz) <= cur * 1.00001f + 1e-30f;
+    };
+    // scan staged tile k (tile id tile, both wave-uniform): tile box first, then its four 4x4-pixel quadrants,
+    // each only if some lane can still improve/tie inside that box
+    auto scan_staged = [&](int k, int tile) __attribute__((always_inline)) {
+        if (__ballot(lane_gap_ok(TB[2 * tile], TB[2 * tile + 1])) == 0ull) return;     // uniform -> scalar loads
+        n_scanned += 1;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const float4 lo = st[k * TILE_REC + TILE_SLOTS + 2 * qd], hi = st[k * TILE_REC + TILE_SLOTS + 2 * qd + 1];
+            const int cnt = __builtin_amdgcn_readfirstlane(__float_as_int(lo.w));
+            if (cnt == 0 || __ballot(lane_gap_ok(lo, hi)) == 0ull) continue;
+            n_cand += cnt;
+            const float4 *__restrict__ cand = st + k * TILE_REC + qd * 16;
+#pragma unroll 4
+            for (int i = 0; i < cnt; ++i) {
+                const float4 q = cand[i];                                // same address in every lane: LDS broadcast
+                const float d2 = canon_d2(px, py, pz, q.x, q.y, q.z);
+                const unsigned long long key =
+                    ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(q.w);
+                bkey = key < bkey ? key : bkey;
+            }
+        }
+    };
+    auto fetch_batch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NN_STAGE; ++k)
+            r[k] = tt[k] >= 0 ? TT[(size_t)tt[k] * TILE_REC + lane] : make_float4(inf, inf, inf, __int_as_float(-1));
+    };
+    auto park_and_scan = [&]() __attribute__((always_inline)) {
+        n_batches += 1;
+        // lanes 0..39 fetch the quadrant boxes of the staged tiles (8 float4 per tile) with one load
+        int my_tile = -1;
+#pragma unroll
+        for (int k = 0; k < NN_STAGE; ++k) if ((lane >> 3) == k) my_tile = tt[k];
+        float4 qb = make_float4(inf, inf, inf, 0.0f);                    // empty box, count 0
+        if (my_tile >= 0) qb = TT[(size_t)my_tile * TILE_REC + TILE_SLOTS + (lane & 7)];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < NN_STAGE; ++k) st[k * TILE_REC + lane] = r[k];
+        if (lane < NN_STAGE * 8) st[(lane >> 3) * TILE_REC + TILE_SLOTS + (lane & 7)] = qb;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < NN_STAGE; ++k)
+            if (tt[k] >= 0) scan_staged(k, tt[k]);
+        __builtin_amdgcn_wave_barrier();
+    };
+    // The wave-level tests use TWO query boxes: lanes whose bound is already small ("tight", radius below a
+    // quarter of the gate) and the rest ("loose": no match yet / far match), so that a few loose lanes do not
+    // inflate the search region of the whole wave.
+    float qminx, qminy, qminz, qmaxx, qmaxy, qmaxz, lminx, lminy, lminz, lmaxx, lmaxy, lmaxz;
+    bool any_loose = false;
+    auto class_boxes = [&]() __attribute__((always_inline)) {
+        qminx = wave_min(tight ? px : inf); qminy = wave_min(tight ? py : inf); qminz = wave_min(tight ? pz : inf);
+        qmaxx = wave_max(tight ? px : -inf); qmaxy = wave_max(tight ? py : -inf); qmaxz = wave_max(tight ? pz : -inf);
+        any_loose = __ballot(loose) != 0ull;
+        lminx = lminy = lminz = inf; lmaxx = lmaxy = lmaxz = -inf;
+        if (any_loose) {
+            lminx = wave_min(loose ? px : inf); lminy = wave_min(loose ? py : inf); lminz = wave_min(loose ? pz : inf);
+            lmaxx = wave_max(loose ? px : -inf); lmaxy = wave_max(loose ? py : -inf); lmaxz = wave_max(loose ? pz : -inf);
+        }
+    };
+    // gap test of a box against both query boxes with the CURRENT class bounds (empty class -> never hits)
+    auto reach = [&](const float4 lo, const float4 hi, float thr_t, float thr_l) __attribute__((always_inline)) {
+        bool h = box_gap2(lo, hi, qminx, qminy, qminz, qmaxx, qmaxy, qmaxz) <= thr_t;
+        if (any_loose) h = h || box_gap2(lo, hi, lminx, lminy, lminz, lmaxx, lmaxy, lmaxz) <= thr_l;
+        return h;
+    };
+    auto class_thr = [&](float &thr_t, float &thr_l) __attribute__((always_inline)) {
+        const float cur = __int_as_float((int)(unsigned int)(bkey >> 32));
+        thr_t = wave_max(tight ? cur : 0.0f) * 1.00001f + 1e-30f;    // covers the rounding of box_gap2 and of canon_d2
+        thr_l = any_loose ? wave_max(loose ? cur : 0.0f) * 1.00001f + 1e-30f : 0.0f;
+    };
+    // fine level: ballot the children of coarse cell cc against the wave boxes, re-test per lane, stage + scan
+    auto sweep_cell = [&](int cc) __attribute__((always_inline)) {
+        const int ctx = (cc % tg.ncx) * COARSE_TILES, cty = (cc / tg.ncx) * COARSE_TILES;
+        const int tx = ctx + (lane & 7), ty = cty + (lane >> 3);
+        float4 lo = make_float4(inf, inf, inf, 0), hi = make_float4(-inf, -inf, -inf, 0);
+        if (tx < tg.ntx && ty < tg.nty) { lo = TB[2 * (ty * tg.ntx + tx)]; hi = TB[2 * (ty * tg.ntx + tx) + 1]; }
+        float thr_t, thr_l;
+        class_thr(thr_t, thr_l);
+        bool hit2 = false;
+        if (tx < tg.ntx && ty < tg.nty) {
+            const int dx = tx - tx0, dy = ty - ty0;
+            const bool in_a = abs(dx) + abs(dy) <= 1;            // the 5 tiles of step 1: centre + edge neighbours
+            hit2 = !in_a && reach(lo, hi, thr_t, thr_l);
+        }
+        unsigned long long tm0 = __ballot(hit2), tm = 0ull;
+        n_chit += 1; n_fhit += __popcll(tm0);
+        // refine BEFORE fetching anything: a tile is staged only if some lane's own ball reaches its box
+        // (lane k2 holds the box of child k2 -> broadcast it with v_readlane)
+        while (tm0) {
+            const int k2 = __builtin_ctzll(tm0);
+            tm0 &= tm0 - 1;
+            const float4 blo = make_float4(rdlane(lo.x, k2), rdlane(lo.y, k2), rdlane(lo.z, k2), 0.0f);
+            const float4 bhi = make_float4(rdlane(hi.x, k2), rdlane(hi.y, k2), rdlane(hi.z, k2), 0.0f);
+            if (__ballot(lane_gap_ok(blo, bhi)) != 0ull) tm |= 1ull << k2;
+        }
+        n_refined += __popcll(tm);
+        while (tm) {
+#pragma unroll
+            for (int k = 0; k < NN_STAGE; ++k) {
+                tt[k] = -1;
+                if (tm) {
+                    const int k2 = __builtin_ctzll(tm);
+                    tm &= tm - 1;
+                    tt[k] = (cty + (k2 >> 3)) * tg.ntx + ctx + (k2 & 7);
+                }
+            }
+            fetch_batch();
+            park_and_scan();
+        }
+    };
+
+    // ================= step 1: own tile =================
+    const float4 s4 = has_tile ? srcT[((size_t)b * tg.ntiles + t) * TILE_SLOTS + lane] : make_float4(0, 0, 0, __int_as_float(-1));
+    const int pix = __float_as_int(s4.w);
+    const bool own_valid = pix >= 0;
+    float opx = 0.0f, opy = 0.0f, opz = 0.0f;
+    if (__ballot(own_valid) != 0ull) {
+        // centre of the first scan: where this tile's matches were in the previous iteration (a hint only --
+        // exactness never depends on it); initially the same image location
         const int th = __builtin_amdgcn_readfirstlane(hint[(size_t)b * tg.ntiles + t]);
         const int tc = (th >= 0 && th < tg.ntiles) ? th : t;
-        const int tx0 = tc % tg.ntx, ty0 = tc / tg.ntx;
-        const int cown = (ty0 / COARSE_TILES) * tg.ncx + tx0 / COARSE_TILES;     // coarse cell of that centre
-        int tt[NN_STAGE];
-        float4 r[NN_STAGE];
-        // ---- phase A tile list: centre, edge neighbours, two corners of the 3x3 block around the hint
+        tx0 = tc % tg.ntx; ty0 = tc / tg.ntx;
         {
-            const int ox[NN_STAGE] = { 0, -1, 1, 0, 0, -1, 1 }, oy[NN_STAGE] = { 0, 0, 0, -1, 1, -1, -1 };
+            const int ox[NN_STAGE] = { 0, -1, 1, 0, 0 }, oy[NN_STAGE] = { 0, 0, 0, -1, 1 };
 #pragma unroll
             for (int k = 0; k < NN_STAGE; ++k) {
                 const int tx = tx0 + ox[k], ty = ty0 + oy[k];
                 tt[k] = (tx >= 0 && tx < tg.ntx && ty >= 0 && ty < tg.nty) ? ty * tg.ntx + tx : -1;
             }
         }
-        // ---- one round of independent loads
-#pragma unroll
-        for (int k = 0; k < NN_STAGE; ++k)
-            r[k] = tt[k] >= 0 ? TT[(size_t)tt[k] * TILE_REC + lane] : make_float4(inf, inf, inf, __int_as_float(-1));
+        fetch_batch();                                             // one round of independent loads ...
         const float4 pq = prevq[gs];
         float4 qs = make_float4(0, 0, 0, 0);
         float ws = 1.0f;
@@ -894,16 +1029,9 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
             const int ug = (t % tg.ntx) * TILE_PX + (lane & 7), vg = (t / tg.ntx) * TILE_PX + (lane >> 3);
             if (ug < g.W && vg < g.H) { qs = tcloud[vg * g.W + ug]; if (g.estimator == 0) ws = tnrm[vg * g.W + ug].w; }
         }
-        float4 clo0 = make_float4(inf, inf, inf, 0), chi0 = make_float4(-inf, -inf, -inf, 0), clo1 = clo0, chi1 = chi0;
-        if (lane < tg.ncoarse) { clo0 = CB[2 * lane]; chi0 = CB[2 * lane + 1]; }
-        if (lane + 64 < tg.ncoarse) { clo1 = CB[2 * (lane + 64)]; chi1 = CB[2 * (lane + 64) + 1]; }
-        float4 olo = make_float4(inf, inf, inf, 0), ohi = make_float4(-inf, -inf, -inf, 0);     // own cell's child boxes
-        {
-            const int tx = (cown % tg.ncx) * COARSE_TILES + (lane & 7), ty = (cown / tg.ncx) * COARSE_TILES + (lane >> 3);
-            if (tx < tg.ntx && ty < tg.nty) { olo = TB[2 * (ty * tg.ntx + tx)]; ohi = TB[2 * (ty * tg.ntx + tx) + 1]; }
-        }
         const Rt m = load_rt(Tcur + b * 16);
         xform(m, s4.x, s4.y, s4.z, px, py, pz);
+        valid = own_valid;
         // ---- upper bound: previous match, else the target at the same pixel, else the gate
         {
             const int jprev = __float_as_int(pq.w);
@@ -914,161 +1042,75 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
             const float d2g = canon_d2(px, py, pz, qg.x, qg.y, qg.z);
             if (tv && d2g <= g.gate2) bkey = ((unsigned long long)(unsigned int)__float_as_int(d2g) << 32) | (unsigned int)jg;
         }
-        // waves that still carry a gate-sized bound have the long wide search ahead of them: let them run
-        // ahead of their SIMD neighbours so that they do not become the tail of the launch
-        if (__ballot(valid && (unsigned int)(bkey & 0xffffffffull) == 0xffffffffu) != 0ull) __builtin_amdgcn_s_setprio(2);
-        // scan staged tile k (tile id tile, both wave-uniform): tile box first, then its four 4x4-pixel quadrants,
-        // each only if some lane can still improve/tie inside that box
-        auto lane_gap_ok = [&](const float4 lo, const float4 hi) __attribute__((always_inline)) {
-            const float cur = __int_as_float((int)(unsigned int)(bkey >> 32));
-            const float gx = fmaxf(0.0f, fmaxf(lo.x - px, px - hi.x));
-            const float gy = fmaxf(0.0f, fmaxf(lo.y - py, py - hi.y));
-            const float gz = fmaxf(0.0f, fmaxf(lo.z - pz, pz - hi.z));
-            return valid && (gx * gx + gy * gy + gz * gz) <= cur * 1.00001f + 1e-30f;
-        };
-        auto scan_staged = [&](int k, int tile) __attribute__((always_inline)) {
-            if (__ballot(lane_gap_ok(TB[2 * tile], TB[2 * tile + 1])) == 0ull) return;     // uniform -> scalar loads
-            n_scanned += 1;
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const float4 lo = st[k * TILE_REC + TILE_SLOTS + 2 * qd], hi = st[k * TILE_REC + TILE_SLOTS + 2 * qd + 1];
-                const int cnt = __builtin_amdgcn_readfirstlane(__float_as_int(lo.w));
-                if (cnt == 0 || __ballot(lane_gap_ok(lo, hi)) == 0ull) continue;
-                n_cand += cnt;
-                const float4 *__restrict__ cand = st + k * TILE_REC + qd * 16;
-#pragma unroll 4
-                for (int i = 0; i < cnt; ++i) {
-                    const float4 q = cand[i];                                // same address in every lane: LDS broadcast
-                    const float d2 = canon_d2(px, py, pz, q.x, q.y, q.z);
-                    const unsigned long long key =
-                        ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(q.w);
-                    bkey = key < bkey ? key : bkey;
-                }
-            }
-        };
-        auto park_and_scan = [&]() __attribute__((always_inline)) {
-            n_batches += 1;
-            // lanes 0..55 fetch the quadrant boxes of the staged tiles (8 float4 per tile) with one load
-            int my_tile = -1;
-#pragma unroll
-            for (int k = 0; k < NN_STAGE; ++k) if ((lane >> 3) == k) my_tile = tt[k];
-            float4 qb = make_float4(inf, inf, inf, 0.0f);                    // empty box, count 0
-            if (my_tile >= 0) qb = TT[(size_t)my_tile * TILE_REC + TILE_SLOTS + (lane & 7)];
-#pragma unroll
-            for (int k = 0; k < NN_STAGE; ++k) st[k * TILE_REC + lane] = r[k];
-            if (lane < NN_STAGE * 8) st[(lane >> 3) * TILE_REC + TILE_SLOTS + (lane & 7)] = qb;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int k = 0; k < NN_STAGE; ++k)
-                if (tt[k] >= 0) scan_staged(k, tt[k]);
-            __builtin_amdgcn_wave_barrier();
-        };
         if (dbg) clk1 = clock64();
         park_and_scan();
         if (dbg) clk2 = clock64();
-        // ---- phase B: every other tile whose box is within reach of the (shrunken) bounds
-        // The wave-level test uses TWO query boxes: lanes whose bound is already small ("tight", radius below a
-        // quarter of the gate) and the rest ("loose": no match yet / far match).  A few loose lanes then no
-        // longer inflate the search region of the whole wave.
+        opx = px; opy = py; opz = pz;
+        // ---- step 2: publish the queries and one work item per reachable coarse cell
         const float bnd0 = __int_as_float((int)(unsigned int)(bkey >> 32));
-        const bool tight = valid && bnd0 <= 0.0625f * g.gate2, loose = valid && !tight;
-        const float qminx = wave_min(tight ? px : inf), qminy = wave_min(tight ? py : inf), qminz = wave_min(tight ? pz : inf);
-        const float qmaxx = wave_max(tight ? px : -inf), qmaxy = wave_max(tight ? py : -inf), qmaxz = wave_max(tight ? pz : -inf);
-        const bool any_loose = __ballot(loose) != 0ull;
-        float lminx = inf, lminy = inf, lminz = inf, lmaxx = -inf, lmaxy = -inf, lmaxz = -inf;
-        if (any_loose) {
-            lminx = wave_min(loose ? px : inf); lminy = wave_min(loose ? py : inf); lminz = wave_min(loose ? pz : inf);
-            lmaxx = wave_max(loose ? px : -inf); lmaxy = wave_max(loose ? py : -inf); lmaxz = wave_max(loose ? pz : -inf);
-        }
-        // gap test of a box against both query boxes with the CURRENT class bounds (empty class -> never hits)
-        auto reach = [&](const float4 lo, const float4 hi, float thr_t, float thr_l) __attribute__((always_inline)) {
-            bool h = box_gap2(lo, hi, qminx, qminy, qminz, qmaxx, qmaxy, qmaxz) <= thr_t;
-            if (any_loose) h = h || box_gap2(lo, hi, lminx, lminy, lminz, lmaxx, lmaxy, lmaxz) <= thr_l;
-            return h;
-        };
-        auto class_thr = [&](float &thr_t, float &thr_l) __attribute__((always_inline)) {
-            const float cur = __int_as_float((int)(unsigned int)(bkey >> 32));
-            thr_t = wave_max(tight ? cur : 0.0f) * 1.00001f + 1e-30f;    // covers the rounding of box_gap2 and of canon_d2
-            thr_l = any_loose ? wave_max(loose ? cur : 0.0f) * 1.00001f + 1e-30f : 0.0f;
-        };
-        // fine level: ballot the children of coarse cell cc against the wave boxes, stage + scan survivors
-        auto sweep_cell = [&](int cc, const float4 lo, const float4 hi) __attribute__((always_inline)) {
-            const int ctx = (cc % tg.ncx) * COARSE_TILES, cty = (cc / tg.ncx) * COARSE_TILES;
-            const int tx = ctx + (lane & 7), ty = cty + (lane >> 3);
-            float thr_t, thr_l;
-            class_thr(thr_t, thr_l);
-            bool hit2 = false;
-            if (tx < tg.ntx && ty < tg.nty) {
-                const int dx = tx - tx0, dy = ty - ty0;
-                // the 7 tiles of phase A: the 3x3 block without its two lower corners (-1,+1), (+1,+1)
-                const bool in_a = abs(dx) <= 1 && abs(dy) <= 1 && !(dy == 1 && dx != 0);
-                hit2 = !in_a && reach(lo, hi, thr_t, thr_l);
-            }
-            unsigned long long tm0 = __ballot(hit2), tm = 0ull;
-            n_chit += 1; n_fhit += __popcll(tm0);
-            // refine BEFORE fetching anything: a tile is staged only if some lane's own ball reaches its box
-            // (lane k2 holds the box of child k2 -> broadcast it with v_readlane)
-            while (tm0) {
-                const int k2 = __builtin_ctzll(tm0);
-                tm0 &= tm0 - 1;
-                const float lx = rdlane(lo.x, k2), ly = rdlane(lo.y, k2), lz = rdlane(lo.z, k2);
-                const float hx = rdlane(hi.x, k2), hy = rdlane(hi.y, k2), hz = rdlane(hi.z, k2);
-                const float cur = __int_as_float((int)(unsigned int)(bkey >> 32));
-                const float gx = fmaxf(0.0f, fmaxf(lx - px, px - hx));
-                const float gy = fmaxf(0.0f, fmaxf(ly - py, py - hy));
-                const float gz = fmaxf(0.0f, fmaxf(lz - pz, pz - hz));
-                const bool need = valid && (gx * gx + gy * gy + gz * gz) <= cur * 1.00001f + 1e-30f;
-                if (__ballot(need) != 0ull) tm |= 1ull << k2;
-            }
-            n_refined += __popcll(tm);
-            while (tm) {
-#pragma unroll
-                for (int k = 0; k < NN_STAGE; ++k) {
-                    tt[k] = -1;
-                    if (tm) {
-                        const int k2 = __builtin_ctzll(tm);
-                        tm &= tm - 1;
-                        tt[k] = (cty + (k2 >> 3)) * tg.ntx + ctx + (k2 & 7);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < NN_STAGE; ++k)
-                    r[k] = tt[k] >= 0 ? TT[(size_t)tt[k] * TILE_REC + lane] : make_float4(inf, inf, inf, __int_as_float(-1));
-                park_and_scan();
-            }
-        };
-        if (dbg) clk2a = clock64();
-        sweep_cell(cown, olo, ohi);                       // own cell first: its child boxes are already here
-        if (dbg) clk2b = clock64();
+        tight = valid && bnd0 <= 0.0625f * g.gate2; loose = valid && !tight;
+        qpos[w][lane] = make_float4(px, py, pz, valid ? (tight ? 1.0f : 2.0f) : 0.0f);
+        qkey[w][lane] = bkey;
+        if (lane == 0) { wcentre[w][0] = tx0; wcentre[w][1] = ty0; }
+        class_boxes();
+        float thr_t, thr_l;
+        class_thr(thr_t, thr_l);
         for (int c0 = 0; c0 < tg.ncoarse; c0 += 64) {
-            float thr_t, thr_l;
-            class_thr(thr_t, thr_l);
             const int cidx = c0 + lane;
-            float4 lo, hi;
-            if (c0 == 0) { lo = clo0; hi = chi0; }
-            else if (c0 == 64) { lo = clo1; hi = chi1; }
-            else {
-                lo = make_float4(inf, inf, inf, 0); hi = make_float4(-inf, -inf, -inf, 0);
-                if (cidx < tg.ncoarse) { lo = CB[2 * cidx]; hi = CB[2 * cidx + 1]; }
+            bool hit = false;
+            if (cidx < tg.ncoarse) hit = reach(CB[2 * cidx], CB[2 * cidx + 1], thr_t, thr_l);
+            const unsigned long long cm = __ballot(hit);
+            const int cnt = __popcll(cm);
+            int base = 0;
+            if (lane == 0 && cnt) base = atomicAdd(&n_items, cnt);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (hit) {
+                const int pos = base + __popcll(cm & ((1ull << lane) - 1ull));
+                if (pos < NN_MAX_ITEMS) items[pos] = (w << 16) | cidx;
             }
-            const bool hit = cidx != cown && reach(lo, hi, thr_t, thr_l);
-            unsigned long long cm = __ballot(hit);
-            while (cm) {
-                const int cc = c0 + __builtin_ctzll(cm);
-                cm &= cm - 1;
-                const int tx = (cc % tg.ncx) * COARSE_TILES + (lane & 7), ty = (cc / tg.ncx) * COARSE_TILES + (lane >> 3);
-                float4 flo = make_float4(inf, inf, inf, 0), fhi = make_float4(-inf, -inf, -inf, 0);
-                if (tx < tg.ntx && ty < tg.nty) { flo = TB[2 * (ty * tg.ntx + tx)]; fhi = TB[2 * (ty * tg.ntx + tx) + 1]; }
-                sweep_cell(cc, flo, fhi);
+            // cells that do not fit in the shared list are swept right here by their owner
+            if (base + cnt > NN_MAX_ITEMS) {
+                unsigned long long rest = cm;
+                int skip = NN_MAX_ITEMS - base; if (skip < 0) skip = 0;
+                while (rest) {
+                    const int k = __builtin_ctzll(rest);
+                    rest &= rest - 1;
+                    if (skip > 0) { --skip; continue; }
+                    sweep_cell(c0 + k);
+                }
+                qkey[w][lane] = bkey;
             }
         }
     }
+    __syncthreads();
+    // ================= step 3: drain the shared item list =================
+    {
+        const int total = min(n_items, NN_MAX_ITEMS);
+        while (true) {
+            int it = 0;
+            if (lane == 0) it = atomicAdd(&next_item, 1);
+            it = __builtin_amdgcn_readfirstlane(it);
+            if (it >= total) break;
+            const int item = items[it];
+            const int owner = item >> 16, cc = item & 0xffff;
+            const float4 q = qpos[owner][lane];
+            px = q.x; py = q.y; pz = q.z;
+            valid = q.w > 0.5f; tight = q.w == 1.0f; loose = q.w == 2.0f;
+            bkey = qkey[owner][lane];
+            tx0 = wcentre[owner][0]; ty0 = wcentre[owner][1];
+            class_boxes();
+            sweep_cell(cc);
+            if (valid) atomicMin(&qkey[owner][lane], bkey);
+        }
+    }
+    __syncthreads();
     if (dbg) clk3 = clock64();
-    // ---- fused S4 accumulation, level 1: this tile's 64 slots
+    if (!has_tile) return;
+    // ================= step 4: this wave's own tile: fused S4 accumulation, level 1 =================
+    bkey = qkey[w][lane];
+    if (__ballot(own_valid) == 0ull) bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
     double s[NSUMS];
-    finish_slot(valid, bkey, px, py, pz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, prevq + gs, s);
+    finish_slot(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, prevq + gs, s);
     tile_reduce_store(s, TP + (size_t)b * NSUMS * tg.tpad, t, tg.tpad);
     {   // hint for the next iteration: the tile holding the match of a lane near the tile centre
         const bool ok = s[27] != 0.0;
@@ -1085,9 +1127,7 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
         d[0] = clk0; d[1] = clk1; d[2] = clk2; d[3] = clk3; d[4] = clock64();
         d[5] = n_scanned | ((long long)n_chit << 32); d[6] = n_cand | ((long long)n_fhit << 32);
         d[7] = n_batches | ((long long)n_refined << 32);
-        d[1] = clk1 | 0; d[2] = clk2;
-        // pack two extra deltas into the high bits of slot 1/2 is not possible (64-bit clocks): reuse cd2-free slots
-        dbg[(size_t)tg.ntiles * 8 + (size_t)t * 2] = clk2a; dbg[(size_t)tg.ntiles * 8 + (size_t)t * 2 + 1] = clk2b;
+        dbg[(size_t)tg.ntiles * 8 + (size_t)t * 2] = clk2; dbg[(size_t)tg.ntiles * 8 + (size_t)t * 2 + 1] = clk2;
     }
 }
 
