@@ -357,7 +357,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
     if (e0) HIPCHK(h, hipEventRecord(e0, s));
     if (nn_mode_of(h) == SLAM3D_NN_TILES) {
-        hipLaunchKernelGGL(k_nn_tiles_acc, dim3(tg.nchunks, B), dim3(CHUNK), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
+        hipLaunchKernelGGL(k_nn_tiles_acc, dim3((tg.ntiles + NN_WAVES - 1) / NN_WAVES, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
                            h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, h->partials, h->g, tg, h->dbg);
         if (e1) HIPCHK(h, hipEventRecord(e1, s));
     } else {

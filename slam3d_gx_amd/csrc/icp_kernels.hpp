@@ -823,10 +823,11 @@ __device__ __forceinline__ float box_gap2(const float4 lo, const float4 hi, floa
 }
 
 constexpr int NN_STAGE = 5;          // target tile records staged in LDS per batch (5 x 1152 B per wave)
-constexpr int NN_MAX_ITEMS = 256;    // (owner wave, coarse cell) work items shared by the 4 waves of a block
+constexpr int NN_MAX_ITEMS = 256;    // (owner wave, coarse cell) work items shared by the waves of a block
+constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (8 measured slower: 2 blocks per CU)
 
-// grid (nchunks, B), block 256 = 4 waves.  Wave w of block c OWNS source tile c + w*nchunks (four tiles from
-// four different image bands, so that an expensive tile -- e.g. one lying over a hole of the target, which
+// grid (ceil(ntiles/4), B), block 256 = 4 waves.  Wave w of block c OWNS source tile c + w*gridDim.x (four tiles
+// from four different image bands, so that an expensive tile -- e.g. one lying over a hole of the target, which
 // must prove "nothing within max_corr_dist" -- rarely shares a block with another one).
 //   1. every wave: one round of loads, upper bounds, exhaustive scan of the 5 tiles around its hint tile;
 //   2. every wave publishes its queries (point, running key, tight/loose class) in LDS and appends one work
@@ -836,7 +837,7 @@ constexpr int NN_MAX_ITEMS = 256;    // (owner wave, coarse cell) work items sha
 //      quadrants), merged into the owner's keys with ds_min_u64;                             -- barrier --
 //   4. every wave finishes its own tile: gate, row products, level-1 reduction, hint for the next iteration.
 // The result is independent of which wave processes which item (keys are merged by an exact minimum).
-__global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restrict__ slots,
+__global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *__restrict__ slots,
                                                         const float4 *__restrict__ nrm_all,
                                                         const float4 *__restrict__ srcT,
                                                         const float4 *__restrict__ tgtT,
@@ -848,10 +849,10 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
                                                         double *__restrict__ TP, Geometry g, TileGrid tg,
                                                         long long *__restrict__ dbg /* nullable: 8 x int64 per tile */)
 {
-    __shared__ float4 stage_all[TILES_PER_CHUNK][NN_STAGE * TILE_REC];
-    __shared__ float4 qpos[TILES_PER_CHUNK][TILE_SLOTS];              // p'.xyz, w = 0 invalid / 1 tight / 2 loose
-    __shared__ unsigned long long qkey[TILES_PER_CHUNK][TILE_SLOTS];
-    __shared__ int wcentre[TILES_PER_CHUNK][2];                        // hint centre (tx0, ty0) of each owner
+    __shared__ float4 stage_all[NN_WAVES][NN_STAGE * TILE_REC];
+    __shared__ float4 qpos[NN_WAVES][TILE_SLOTS];                     // p'.xyz, w = 0 invalid / 1 tight / 2 loose
+    __shared__ unsigned long long qkey[NN_WAVES][TILE_SLOTS];
+    __shared__ int wcentre[NN_WAVES][2];                               // hint centre (tx0, ty0) of each owner
     __shared__ int items[NN_MAX_ITEMS];
     __shared__ int n_items, next_item;
     const long long clk0 = dbg ? clock64() : 0;
@@ -860,7 +861,7 @@ __global__ __launch_bounds__(CHUNK) void k_nn_tiles_acc(const SlotPtrs *__restri
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.y, c = blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int t = c + w * tg.nchunks;                                   // interleaved ownership
+    const int t = c + w * (int)gridDim.x;                               // interleaved ownership
     const bool has_tile = t < tg.ntiles;
     float4 *__restrict__ st = stage_all[w];
     const size_t gs = (size_t)b * tg.nslots + (size_t)(has_tile ? t : 0) * TILE_SLOTS + lane;

@@ -20,8 +20,7 @@ for it in (1, iters):
     d = d[d[:, 1] > 0]
     lo32 = lambda x: x & 0xffffffff
     hi32 = lambda x: x >> 32
-    for name, v in (("lifetime", d[:, 4] - d[:, 0]), ("prologue", d[:, 1] - d[:, 0]), ("phaseA", d[:, 2] - d[:, 1]), ("B:aabb", d[:, 8] - d[:, 2]),
-                    ("B:own cell", d[:, 9] - d[:, 8]), ("B:coarse loop", d[:, 3] - d[:, 9]),
+    for name, v in (("lifetime", d[:, 4] - d[:, 0]), ("prologue", d[:, 1] - d[:, 0]), ("own 5 tiles", d[:, 2] - d[:, 1]), ("publish+items (to barrier 2)", d[:, 3] - d[:, 2]),
                     ("epilogue", d[:, 4] - d[:, 3]), ("tiles scanned", lo32(d[:, 5])), ("candidates", lo32(d[:, 6])), ("batches", lo32(d[:, 7])),
                     ("cells swept", hi32(d[:, 5])), ("fine hits", hi32(d[:, 6])), ("refined hits", hi32(d[:, 7]))):
         print(f"{name:14s} mean {v.mean():10.1f}  p50 {np.percentile(v,50):9.0f}  p90 {np.percentile(v,90):9.0f}  p99 {np.percentile(v,99):9.0f}  max {v.max():9.0f}")
