@@ -249,3 +249,25 @@ def test_config5_dense_1280x960(gpu_lib):
     rot, tr = O.pose_error(ro["T_trace"][-1], r["T_raw"])
     assert rot <= ROT_TOL and tr <= TRANS_TOL
     assert np.array_equal(r["T_raw"], ro["T_trace"][-1])
+
+
+def test_fit_planes_vs_oracle(gpu_lib):
+    """Row a6: per-plane {sum p, sum pp^T, n} -> eigen -> (n, d) with d >= 0 (src/GraphicEnd.cpp:360-387).
+    The GPU reduces the moments with a 256-pixel chunk tree, the oracle sequentially: float outputs agree to 1e-6."""
+    pr = synth.make_pair(1001, 640, 480)
+    d, lab = synth.render_depth(np.eye(4), pr.intr, 1001, 1, hole_block=32, want_labels=True)
+    assert np.array_equal(d, pr.depth_src)
+    cloud = synth.backproject_numpy(d, pr.intr)
+    ref_planes, ref_counts = O.fit_planes(cloud, lab, 3)
+    with capi.IcpHandle(capi.default_params(pr.intr)) as h:
+        got = h.fit_planes(cloud, lab, 3)
+        # also through 32-byte PointXYZRGBA-like records
+        c8 = np.zeros(cloud.shape[:2] + (8,), dtype=np.float32); c8[..., :3] = cloud[..., :3]
+        got8 = h.fit_planes(c8, lab, 3)
+    for k in range(3):
+        assert got[k]["count"] == ref_counts[k] == int((lab == k).sum())
+        assert np.abs(got[k]["coeff"] - ref_planes[k]).max() < 1e-6
+        assert got[k]["coeff"][3] >= 0 and abs(np.linalg.norm(got[k]["coeff"][:3]) - 1) < 1e-6
+        assert np.array_equal(got[k]["coeff"], got8[k]["coeff"])
+    expect = np.array([[0, -1, 0, 1.2], [1, 0, 0, 2.0], [0, 0, -1, 4.5]])
+    assert np.allclose(np.stack([g["coeff"] for g in got]), expect, atol=5e-3)
