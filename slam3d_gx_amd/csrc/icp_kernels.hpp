@@ -1348,29 +1348,25 @@ __global__ __launch_bounds__(CHUNK) void k_reduce_solve(const double *__restrict
     for (int r = 0; r < 8; ++r) {
         const int k = w + 4 * r;
         const double y = wave_tree64(x[r]);
-        if (k < NSUMS && lane == 0) G[gq * NSUMS + k] = y;
+        // 8-byte agent-scope (write-through) store: visible to the block that finishes last without an L2 release
+        if (k < NSUMS && lane == 0) __hip_atomic_store(G + gq * NSUMS + k, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // publish this group's 29 sums and take a ticket.  Inter-workgroup hand-off on gfx950 (per-CU L1 and
-    // per-XCD L2 are not coherent): every wave drains its stores, one lane does the agent-scope release
-    // before the ticket and, in the last block, the agent-scope acquire before the plain re-reads.
+    // Inter-workgroup hand-off on gfx950 (per-CU L1 and per-XCD L2 are not coherent): both sides use 8-byte
+    // agent-scope accesses for the payload (stores write through, loads bypass L1/stale L2 lines), every wave
+    // drains its stores before the block takes its ticket, and the ticket is an agent-scope atomic.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned int prev = __hip_atomic_fetch_add(ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         is_last = (prev == (unsigned int)(tg.ngroups - 1));
-        if (is_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(ticket + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        }
+        if (is_last) __hip_atomic_store(ticket + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
     __syncthreads();
     if (!is_last) return;
     if (threadIdx.x < NSUMS) {
-        const double *Gv = G;
-        double a = Gv[threadIdx.x];
-        for (int q = 1; q < tg.ngroups; ++q) a = a + Gv[q * NSUMS + threadIdx.x];
+        double a = __hip_atomic_load(G + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 1; q < tg.ngroups; ++q)
+            a = a + __hip_atomic_load(G + q * NSUMS + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         tot[threadIdx.x] = a;
         sums_all[b * NSUMS + threadIdx.x] = a;
     }
