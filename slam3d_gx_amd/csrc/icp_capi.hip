@@ -39,6 +39,7 @@ struct slam3d_icp_handle {
     long long *dbg = nullptr;     // per-tile NN statistics, only with SLAM3D_NN_DEBUG=1
     int *hint = nullptr;          // per source tile: target tile where the previous matches were
     int *scount = nullptr;        // per source tile: valid source points
+    int *perm = nullptr, *cost = nullptr;   // balanced tile->(block,wave) assignment and its input (cycles per tile)
     float *tgtB = nullptr;        // BRUTE_MFMA: B-layout targets [B][4][npad]
     unsigned int *qmax2 = nullptr; int npad = 0;
     // host
@@ -112,7 +113,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->own_src); F(h->own_tgt); F(h->nrm); F(h->src_c); F(h->tgt_c); F(h->counts); F(h->ccounts); F(h->corr);
     F(h->flags); F(h->best); F(h->cd2); F(h->partials); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
     F(h->d_Tinit); F(h->d_slots); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4);
-    F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox); F(h->GP); F(h->ticket); F(h->dbg); F(h->prevq); F(h->hint); F(h->scount); F(h->tgtB); F(h->qmax2);
+    F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox); F(h->GP); F(h->ticket); F(h->dbg); F(h->prevq); F(h->hint); F(h->scount); F(h->perm); F(h->cost); F(h->tgtB); F(h->qmax2);
     if (h->pin_slots) (void)hipHostFree(h->pin_slots);
     if (h->pin_T) (void)hipHostFree(h->pin_T);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
@@ -184,6 +185,8 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     A(dalloc(h->partials, (size_t)h->maxB * NSUMS * tg.tpad));
     A(dalloc(h->GP, (size_t)h->maxB * RS_MAXGROUPS * NSUMS)); A(dalloc(h->ticket, (size_t)h->maxB));
     A(dalloc(h->hint, (size_t)h->maxB * tg.ntiles)); A(dalloc(h->scount, (size_t)h->maxB * tg.ntiles));
+    A(dalloc(h->cost, (size_t)h->maxB * tg.ntiles));
+    A(dalloc(h->perm, (size_t)h->maxB * ((tg.ntiles + NN_WAVES - 1) / NN_WAVES) * NN_WAVES));
     if (getenv("SLAM3D_NN_DEBUG")) A(dalloc(h->dbg, (size_t)tg.ntiles * 10));
     A(dalloc(h->sums, (size_t)h->maxB * NSUMS)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
     A(dalloc(h->trace_T, (size_t)h->maxB * (iters + 1) * 16)); A(dalloc(h->trace_S, (size_t)h->maxB * iters * NSUMS));
@@ -325,6 +328,7 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
     HIPCHK(h, hipMemsetAsync(h->corr, 0xFF, sizeof(int) * (size_t)B * tg.nslots, s));      // no previous match yet
     HIPCHK(h, hipMemsetAsync(h->prevq, 0xFF, sizeof(float4) * (size_t)B * tg.nslots, s));  // (w = -1)
     HIPCHK(h, hipMemsetAsync(h->hint, 0xFF, sizeof(int) * (size_t)B * tg.ntiles, s));
+    HIPCHK(h, hipMemsetAsync(h->perm, 0xFF, sizeof(int) * (size_t)B * ((tg.ntiles + NN_WAVES - 1) / NN_WAVES) * NN_WAVES, s));
     const int use_normals = h->p.estimator == SLAM3D_EST_POINT2PLANE ? 1 : 0;
     if (use_normals) {
         dim3 grid((g.W + NRM_BX - 1) / NRM_BX, (g.H + NRM_BY - 1) / NRM_BY, B);
@@ -358,7 +362,9 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
     if (e0) HIPCHK(h, hipEventRecord(e0, s));
     if (nn_mode_of(h) == SLAM3D_NN_TILES) {
         hipLaunchKernelGGL(k_nn_tiles_acc, dim3((tg.ntiles + NN_WAVES - 1) / NN_WAVES, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
-                           h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, h->partials, h->g, tg, h->dbg);
+                           h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, h->perm, h->cost, h->partials, h->g, tg, h->dbg);
+        if (it == 1 && do_solve)      // costs are stable from the second iteration on: balance the blocks once
+            hipLaunchKernelGGL(k_balance, dim3(B), dim3(1024), 0, s, h->cost, h->perm, tg, (tg.ntiles + NN_WAVES - 1) / NN_WAVES);
         if (e1) HIPCHK(h, hipEventRecord(e1, s));
     } else {
         if (nn_mode_of(h) == SLAM3D_NN_BRUTE_MFMA) {

@@ -846,10 +846,12 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
                                                         const double *__restrict__ Tcur,
                                                         int *__restrict__ corr, float *__restrict__ cd2,
                                                         float4 *__restrict__ prevq, int *__restrict__ hint,
+                                                        const int *__restrict__ perm, int *__restrict__ cost,
                                                         double *__restrict__ TP, Geometry g, TileGrid tg,
                                                         long long *__restrict__ dbg /* nullable: 8 x int64 per tile */)
 {
     __shared__ float4 stage_all[NN_WAVES][NN_STAGE * TILE_REC];
+    __shared__ int wcost[NN_WAVES];                                    // cycles spent for each owner (all helpers)
     __shared__ float4 qpos[NN_WAVES][TILE_SLOTS];                     // p'.xyz, w = 0 invalid / 1 tight / 2 loose
     __shared__ unsigned long long qkey[NN_WAVES][TILE_SLOTS];
     __shared__ int wcentre[NN_WAVES][2];                               // hint centre (tx0, ty0) of each owner
@@ -861,8 +863,12 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.y, c = blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int t = c + w * (int)gridDim.x;                               // interleaved ownership
+    // ownership: the measured-cost balanced assignment once k_balance has run (perm >= 0 tile, -2 none),
+    // before that (-1) tiles interleaved over the image bands
+    const int pt = __builtin_amdgcn_readfirstlane(perm[((size_t)b * gridDim.x + c) * NN_WAVES + w]);
+    const int t = pt == -1 ? c + w * (int)gridDim.x : (pt < 0 ? tg.ntiles : pt);
     const bool has_tile = t < tg.ntiles;
+    const long long cw0 = clock64();
     float4 *__restrict__ st = stage_all[w];
     const size_t gs = (size_t)b * tg.nslots + (size_t)(has_tile ? t : 0) * TILE_SLOTS + lane;
     const float inf = __int_as_float(0x7f800000);
@@ -872,6 +878,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
     const float4 *__restrict__ CB = cbox + (size_t)b * tg.ncoarse * 2;
     const float4 *__restrict__ TT = tgtT + (size_t)b * tg.ntiles * TILE_REC;
     if (threadIdx.x == 0) { n_items = 0; next_item = 0; }
+    if (threadIdx.x < NN_WAVES) wcost[threadIdx.x] = 0;
     __syncthreads();
 
     // ---- "current query" context: the wave's own tile in step 1, an item's owner in step 3
@@ -1083,6 +1090,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
             }
         }
     }
+    if (lane == 0) atomicAdd(&wcost[w], (int)(clock64() - cw0));
     __syncthreads();
     // ================= step 3: drain the shared item list =================
     {
@@ -1094,6 +1102,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
             if (it >= total) break;
             const int item = items[it];
             const int owner = item >> 16, cc = item & 0xffff;
+            const long long ci0 = clock64();
             const float4 q = qpos[owner][lane];
             px = q.x; py = q.y; pz = q.z;
             valid = q.w > 0.5f; tight = q.w == 1.0f; loose = q.w == 2.0f;
@@ -1102,11 +1111,13 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
             class_boxes();
             sweep_cell(cc);
             if (valid) atomicMin(&qkey[owner][lane], bkey);
+            if (lane == 0) atomicAdd(&wcost[owner], (int)(clock64() - ci0));
         }
     }
     __syncthreads();
     if (dbg) clk3 = clock64();
     if (!has_tile) return;
+    if (lane == 0) cost[(size_t)b * tg.ntiles + t] = wcost[w];           // input of k_balance
     // ================= step 4: this wave's own tile: fused S4 accumulation, level 1 =================
     bkey = qkey[w][lane];
     if (__ballot(own_valid) == 0ull) bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
@@ -1129,6 +1140,38 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
         d[5] = n_scanned | ((long long)n_chit << 32); d[6] = n_cand | ((long long)n_fhit << 32);
         d[7] = n_batches | ((long long)n_refined << 32);
         dbg[(size_t)tg.ntiles * 8 + (size_t)t * 2] = clk2; dbg[(size_t)tg.ntiles * 8 + (size_t)t * 2 + 1] = clk2;
+    }
+}
+
+// Cost-balanced tile -> (block, wave) assignment for the following iterations.  grid (B), block 1024.
+// Tiles are ranked by the cycles the previous launch spent on them (256 buckets, counting sort, heaviest
+// first) and dealt to the blocks in serpentine order, so every block receives one tile of each quartile and
+// the block sums even out.  Any assignment gives identical results (partials are stored per tile); this only
+// removes the slow-block tail of k_nn_tiles_acc.
+__global__ __launch_bounds__(1024) void k_balance(const int *__restrict__ cost, int *__restrict__ perm, TileGrid tg, int nblk)
+{
+    __shared__ int hist[256], start[256], cmax;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int *__restrict__ C = cost + (size_t)b * tg.ntiles;
+    int *__restrict__ P = perm + (size_t)b * nblk * NN_WAVES;
+    if (tid < 256) hist[tid] = 0;
+    if (tid == 0) cmax = 1;
+    __syncthreads();
+    int m = 1;
+    for (int t = tid; t < tg.ntiles; t += 1024) m = max(m, C[t]);
+    atomicMax(&cmax, m);
+    for (int s = tid; s < nblk * NN_WAVES; s += 1024) P[s] = -2;
+    __syncthreads();
+    const long long mx = cmax;
+    for (int t = tid; t < tg.ntiles; t += 1024) atomicAdd(&hist[255 - (int)(((long long)C[t] * 255) / mx)], 1);   // bucket 0 = heaviest
+    __syncthreads();
+    if (tid == 0) { int a = 0; for (int k = 0; k < 256; ++k) { start[k] = a; a += hist[k]; } }
+    __syncthreads();
+    for (int t = tid; t < tg.ntiles; t += 1024) {
+        const int r = atomicAdd(&start[255 - (int)(((long long)C[t] * 255) / mx)], 1);      // rank, heaviest first
+        const int q = r / nblk, i = r - q * nblk;
+        const int blk = (q & 1) ? nblk - 1 - i : i;
+        P[blk * NN_WAVES + q] = t;
     }
 }
 
