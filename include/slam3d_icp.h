@@ -149,9 +149,14 @@ int slam3d_icp_get_trace(slam3d_icp_handle *h, int32_t slot, double *T_trace, do
 /* organized float4 clouds / target normals as the device holds them (each N*4 floats, nullable) */
 int slam3d_icp_get_clouds(slam3d_icp_handle *h, int32_t slot, float *src_xyz4, float *tgt_xyz4,
                           float *tgt_nrm4);
-/* kernel time of the last run, by bucket (ms): [0] preprocess [1] nn [2] accumulate+solve [3] total */
+/* Per-launch HIP events around every iteration's NN kernel (off by default: every event record serialises the
+ * stream for ~6 us, ~15 % of a single-pair run).  Takes effect from the next slam3d_icp_run. */
+int slam3d_icp_set_profiling(slam3d_icp_handle *h, int32_t on);
+/* kernel time of the last run, by bucket (ms): [0] preprocess [1] nn [2] accumulate+solve [3] total;
+ * without profiling [1] is 0 and [2] holds everything after preprocessing */
 int slam3d_icp_get_timings(slam3d_icp_handle *h, float ms[4]);
-/* duration of each iteration's NN launch of the last run (ms), nn_ms[iterations] */
+/* duration of each iteration's NN launch of the last run (ms), nn_ms[iterations]; SLAM3D_E_STATE unless the
+ * run was profiled */
 int slam3d_icp_get_iteration_timings(slam3d_icp_handle *h, float *nn_ms);
 /* developer statistics of the LAST NN launch (slot 0), 8 int64 per source tile: clock at start / after
  * prologue / after the 3x3 scan / after the wide scan / at the end, tiles scanned, candidates, batches.

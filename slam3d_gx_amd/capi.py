@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "slam3d_icp_align_depth_batch", "slam3d_icp_set_clouds_host", "slam3d_icp_set_depth_host",
     "slam3d_icp_set_clouds_device", "slam3d_icp_set_depth_device", "slam3d_icp_run",
     "slam3d_icp_fetch_results", "slam3d_icp_get_correspondences", "slam3d_icp_get_trace",
-    "slam3d_icp_get_clouds", "slam3d_icp_get_timings", "slam3d_icp_get_iteration_timings", "slam3d_icp_get_nn_debug", "slam3d_backproject_u16", "slam3d_fit_planes",
+    "slam3d_icp_get_clouds", "slam3d_icp_set_profiling", "slam3d_icp_get_timings", "slam3d_icp_get_iteration_timings", "slam3d_icp_get_nn_debug", "slam3d_backproject_u16", "slam3d_fit_planes",
     "slam3d_icp_dense_set_rows", "slam3d_icp_dense_begin", "slam3d_icp_dense_partial",
     "slam3d_icp_dense_update", "slam3d_icp_dense_finish",
 ]
@@ -227,6 +227,9 @@ class IcpHandle:
         n = np.empty((H, W, 4), dtype=np.float32) if normals else None
         self._check(self.lib.slam3d_icp_get_clouds(self._h, C.c_int32(slot), _vp(s), _vp(t), _vp(n)), False)
         return s, t, n
+
+    def set_profiling(self, on: bool = True):
+        self._check(self.lib.slam3d_icp_set_profiling(self._h, int(bool(on))), False)
 
     def get_timings(self):
         ms = (C.c_float * 4)()

@@ -49,6 +49,9 @@ struct slam3d_icp_handle {
     double *pin_out = nullptr;    // maxB*(16+29)
     int *pin_int = nullptr;       // maxB*5
     std::vector<hipEvent_t> ev;   // 0 start, 1 after preprocess, 2 end, then (nn0,nn1) per iteration
+    int slots_uploaded = 0;       // entries of d_slots that match pin_slots
+    bool profiling = false;       // record the per-iteration events (each costs ~6 us of stream serialisation)
+    bool ran_profiled = false;
     bool ran = false; int last_B = 0;
     int row0 = 0, row1 = 0; int dense_it = 0;
     std::string err;
@@ -311,11 +314,21 @@ static int pick_nsplit(const slam3d_icp_handle *h, int B)
 static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init, hipStream_t s)
 {
     const Geometry &g = h->g;
+    bool same = B <= h->slots_uploaded;                 // the device copy of the slot table is still current
     for (int b = 0; b < B; ++b) {
         if (!h->h_slots[b].src || !h->h_slots[b].tgt) return SLAM3D_E_STATE;
-        h->pin_slots[b] = h->h_slots[b];
+        same = same && memcmp(&h->pin_slots[b], &h->h_slots[b], sizeof(SlotPtrs)) == 0;
     }
-    HIPCHK(h, hipMemcpyAsync(h->d_slots, h->pin_slots, sizeof(SlotPtrs) * B, hipMemcpyHostToDevice, s));
+    if (!same) {                                        // by kernel argument: nothing in flight reads host memory
+        for (int b0 = 0; b0 < B; b0 += SLOT_ARGS) {
+            SlotArgs a;
+            const int n = B - b0 < SLOT_ARGS ? B - b0 : SLOT_ARGS;
+            for (int k = 0; k < n; ++k) a.p[k] = h->pin_slots[b0 + k] = h->h_slots[b0 + k];
+            hipLaunchKernelGGL(k_set_slots, dim3(1), dim3(64), 0, s, h->d_slots + b0, a, n);
+        }
+        h->slots_uploaded = B;
+    }
+    const int nperm = ((h->tg.ntiles + NN_WAVES - 1) / NN_WAVES) * NN_WAVES;
     const double *dT = nullptr;
     if (T_init) {
         memcpy(h->pin_T, T_init, sizeof(double) * 16 * B);
@@ -324,18 +337,13 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
     }
     const bool brute = nn_mode_of(h) != SLAM3D_NN_TILES;
     const TileGrid &tg = h->tg;
-    HIPCHK(h, hipMemsetAsync(h->counts, 0, sizeof(int) * 4 * (size_t)B, s));
-    HIPCHK(h, hipMemsetAsync(h->corr, 0xFF, sizeof(int) * (size_t)B * tg.nslots, s));      // no previous match yet
-    HIPCHK(h, hipMemsetAsync(h->prevq, 0xFF, sizeof(float4) * (size_t)B * tg.nslots, s));  // (w = -1)
-    HIPCHK(h, hipMemsetAsync(h->hint, 0xFF, sizeof(int) * (size_t)B * tg.ntiles, s));
-    HIPCHK(h, hipMemsetAsync(h->perm, 0xFF, sizeof(int) * (size_t)B * ((tg.ntiles + NN_WAVES - 1) / NN_WAVES) * NN_WAVES, s));
     const int use_normals = h->p.estimator == SLAM3D_EST_POINT2PLANE ? 1 : 0;
     if (use_normals) {
         dim3 grid((g.W + NRM_BX - 1) / NRM_BX, (g.H + NRM_BY - 1) / NRM_BY, B);
         hipLaunchKernelGGL(k_normals, grid, dim3(NRM_BX, NRM_BY), 0, s, h->d_slots, h->nrm, g);
     }
     hipLaunchKernelGGL(k_build_tiles, dim3(tg.ntiles, 2, B), dim3(64), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT, h->tbox,
-                       h->scount, g, tg, use_normals, h->row0, h->row1);
+                       h->scount, h->corr, h->prevq, h->hint, h->perm, nperm, h->counts, g, tg, use_normals, h->row0, h->row1);
     hipLaunchKernelGGL(k_coarse_boxes, dim3(tg.ncoarse, B), dim3(64), 0, s, h->tbox, h->scount, h->cbox, h->counts, tg);
     if (brute) {
         HIPCHK(h, hipMemsetAsync(h->best, 0xFF, sizeof(unsigned long long) * (size_t)B * tg.nslots, s));
@@ -406,14 +414,22 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
     HIPCHK(h, hipEventRecord(h->ev[1], s));
     const int iters = h->p.iterations;
     for (int it = 0; it < iters; ++it) {
-        rc = enqueue_iteration(h, B, s, h->ev[3 + 2 * it], h->ev[4 + 2 * it], it, 1);
+        rc = enqueue_iteration(h, B, s, h->profiling ? h->ev[3 + 2 * it] : nullptr, h->profiling ? h->ev[4 + 2 * it] : nullptr, it, 1);
         if (rc) return rc;
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev[2], s));
     h->run_stream = s;
     h->ran = true;
+    h->ran_profiled = h->profiling;
     h->last_B = B;
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_set_profiling(slam3d_icp_handle *h, int32_t on)
+{
+    if (!h) return SLAM3D_E_INVALID;
+    h->profiling = on != 0;
     return SLAM3D_OK;
 }
 
@@ -569,7 +585,7 @@ extern "C" int slam3d_icp_get_timings(slam3d_icp_handle *h, float ms[4])
     float pre = 0, tot = 0, nn = 0;
     HIPCHK(h, hipEventElapsedTime(&pre, h->ev[0], h->ev[1]));
     HIPCHK(h, hipEventElapsedTime(&tot, h->ev[0], h->ev[2]));
-    for (int it = 0; it < h->p.iterations; ++it) {
+    for (int it = 0; h->ran_profiled && it < h->p.iterations; ++it) {
         float t = 0;
         HIPCHK(h, hipEventElapsedTime(&t, h->ev[3 + 2 * it], h->ev[4 + 2 * it]));
         nn += t;
@@ -591,7 +607,7 @@ extern "C" int slam3d_icp_get_nn_debug(slam3d_icp_handle *h, int64_t *out /* nti
 extern "C" int slam3d_icp_get_iteration_timings(slam3d_icp_handle *h, float *nn_ms)
 {
     if (!h || !nn_ms) return SLAM3D_E_INVALID;
-    if (!h->ran) return SLAM3D_E_STATE;
+    if (!h->ran || !h->ran_profiled) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     HIPCHK(h, hipEventSynchronize(h->ev[2]));
     for (int it = 0; it < h->p.iterations; ++it)

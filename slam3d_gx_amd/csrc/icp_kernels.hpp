@@ -31,6 +31,13 @@ struct SlotPtrs {                  // per frame-pair device pointers (organized 
     const float4 *src;
     const float4 *tgt;
 };
+constexpr int SLOT_ARGS = 32;
+struct SlotArgs { SlotPtrs p[SLOT_ARGS]; };
+// the slot table travels as a kernel argument (copied at launch), not through pinned host memory
+__global__ void k_set_slots(SlotPtrs *__restrict__ dst, SlotArgs a, int n)
+{
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = a.p[threadIdx.x];
+}
 
 struct Geometry {
     int W, H, N;
@@ -245,9 +252,28 @@ __global__ __launch_bounds__(64) void k_build_tiles(const SlotPtrs *__restrict__
                                                     const float4 *__restrict__ nrm_all,
                                                     float4 *__restrict__ srcT, float4 *__restrict__ tgtT,
                                                     float4 *__restrict__ tbox, int *__restrict__ scount,
+                                                    int *__restrict__ corr, float4 *__restrict__ prevq,
+                                                    int *__restrict__ hint, int *__restrict__ perm, int nperm,
+                                                    int *__restrict__ counts,
                                                     Geometry g, TileGrid tg, int use_normals, int row0, int row1)
 {
     const int t = blockIdx.x, which = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    if (which == 0) {
+        // per-run state of the iteration kernels, reset here instead of by five memset launches: no previous
+        // match (corr = -1, prevq.w = -1 bits), no hint tile, default tile ownership, zero totals
+        const size_t slot = (size_t)b * tg.nslots + (size_t)t * TILE_SLOTS + lane;
+        const float ones = __int_as_float(-1);
+        corr[slot] = -1;
+        prevq[slot] = make_float4(ones, ones, ones, ones);
+        if (lane == 0) hint[(size_t)b * tg.ntiles + t] = -1;
+        for (int k = t * 64 + lane; k < nperm; k += tg.ntiles * 64) perm[(size_t)b * nperm + k] = -1;
+        if (t == 0 && lane < 4) counts[b * 4 + lane] = 0;
+        if (t == tg.ntiles - 1)                                       // slot padding up to a whole launch block
+            for (int k = tg.ntiles * TILE_SLOTS + lane; k < tg.nslots; k += 64) {
+                corr[(size_t)b * tg.nslots + k] = -1;
+                prevq[(size_t)b * tg.nslots + k] = make_float4(ones, ones, ones, ones);
+            }
+    }
     const int tx = t % tg.ntx, ty = t / tg.ntx;
     const int u = tx * TILE_PX + (lane & 7), v = ty * TILE_PX + (lane >> 3);
     const float inf = __int_as_float(0x7f800000);

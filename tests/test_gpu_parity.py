@@ -271,3 +271,22 @@ def test_fit_planes_vs_oracle(gpu_lib):
         assert np.array_equal(got[k]["coeff"], got8[k]["coeff"])
     expect = np.array([[0, -1, 0, 1.2], [1, 0, 0, 2.0], [0, 0, -1, 4.5]])
     assert np.allclose(np.stack([g["coeff"] for g in got]), expect, atol=5e-3)
+
+
+def test_profiling_is_opt_in_and_does_not_change_results(gpu_lib):
+    """Per-launch events (slam3d_icp_set_profiling) only add timing: same T, and the iteration timings are
+    refused for a run that was not profiled."""
+    pr, s4, t4 = _pair(31, 320, 240)
+    with capi.IcpHandle(capi.default_params(pr.intr, iterations=6, max_batch=1)) as h:
+        r0 = h.align(s4, t4)
+        with pytest.raises(capi.Slam3dError) as e:
+            h.get_iteration_timings()
+        assert e.value.code == -5
+        tm = h.get_timings()
+        assert tm["nn_ms"] == 0.0 and tm["total_ms"] > 0.0
+        h.set_profiling(True)
+        r1 = h.align(s4, t4)
+        ms = h.get_iteration_timings()
+        assert ms.shape == (6,) and (ms > 0).all()
+        assert h.get_timings()["nn_ms"] > 0.0
+    assert np.array_equal(r0["T"], r1["T"]) and r0["inliers"] == r1["inliers"]
