@@ -45,6 +45,8 @@ struct slam3d_icp_handle {
     // host
     std::vector<SlotPtrs> h_slots;
     SlotPtrs *pin_slots = nullptr;
+    double *pin_res = nullptr, *d_res = nullptr;   // host-mapped result records (RES_REC doubles per pair) and their device address
+    bool res_mapped = false;                      // the last run wrote pin_res
     double *pin_T = nullptr;      // maxB*16
     double *pin_out = nullptr;    // maxB*(16+29)
     int *pin_int = nullptr;       // maxB*5
@@ -118,6 +120,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->d_Tinit); F(h->d_slots); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4);
     F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox); F(h->GP); F(h->ticket); F(h->dbg); F(h->prevq); F(h->hint); F(h->scount); F(h->perm); F(h->cost); F(h->tgtB); F(h->qmax2);
     if (h->pin_slots) (void)hipHostFree(h->pin_slots);
+    if (h->pin_res) (void)hipHostFree(h->pin_res);
     if (h->pin_T) (void)hipHostFree(h->pin_T);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->pin_int) (void)hipHostFree(h->pin_int);
@@ -199,6 +202,8 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     A(dalloc(h->srcT, (size_t)h->maxB * tg.ntiles * TILE_SLOTS)); A(dalloc(h->tgtT, (size_t)h->maxB * tg.ntiles * TILE_REC));
     A(dalloc(h->tbox, (size_t)h->maxB * tg.ntiles * 2)); A(dalloc(h->cbox, (size_t)h->maxB * tg.ncoarse * 2));
     A(hipHostMalloc((void **)&h->pin_slots, sizeof(SlotPtrs) * h->maxB, hipHostMallocDefault));
+    A(hipHostMalloc((void **)&h->pin_res, sizeof(double) * RES_REC * h->maxB, hipHostMallocMapped));
+    A(hipHostGetDevicePointer((void **)&h->d_res, h->pin_res, 0));
     A(hipHostMalloc((void **)&h->pin_T, sizeof(double) * 16 * h->maxB, hipHostMallocDefault));
     A(hipHostMalloc((void **)&h->pin_out, sizeof(double) * (16 + NSUMS) * h->maxB, hipHostMallocDefault));
     A(hipHostMalloc((void **)&h->pin_int, sizeof(int) * 5 * h->maxB, hipHostMallocDefault));
@@ -394,7 +399,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
                            h->corr, h->cd2, h->prevq, h->partials, h->g, tg);
     }
     hipLaunchKernelGGL(k_reduce_solve, dim3(tg.ngroups, B), dim3(CHUNK), 0, s, h->partials, h->GP, h->ticket, h->sums, h->Tcur,
-                       h->trace_T, h->trace_S, h->flags, tg, it, iters, h->p.estimator, do_solve);
+                       h->trace_T, h->trace_S, h->flags, h->counts, do_solve ? h->d_res : nullptr, tg, it, iters, h->p.estimator, do_solve);
     HIPCHK(h, hipGetLastError());
     return SLAM3D_OK;
 }
@@ -422,6 +427,7 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
     h->run_stream = s;
     h->ran = true;
     h->ran_profiled = h->profiling;
+    h->res_mapped = iters > 0;
     h->last_B = B;
     return SLAM3D_OK;
 }
@@ -464,6 +470,14 @@ extern "C" int slam3d_icp_fetch_results(slam3d_icp_handle *h, int32_t B, slam3d_
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = h->run_stream;
     const int iters = h->p.iterations;
+    if (h->res_mapped) {        // the final k_reduce_solve wrote the records into host-mapped memory
+        HIPCHK(h, hipStreamSynchronize(s));
+        for (int b = 0; b < B; ++b) {
+            const double *r = h->pin_res + (size_t)b * RES_REC;
+            finish_result(h->p, r, r + 16, (int)r[45], (int)r[46], (int)r[47], out + b);
+        }
+        return SLAM3D_OK;
+    }
     HIPCHK(h, hipMemcpyAsync(h->pin_out, h->Tcur, sizeof(double) * 16 * B, hipMemcpyDeviceToHost, s));
     double *ps = h->pin_out + 16 * (size_t)h->maxB;
     if (iters > 0)
@@ -735,7 +749,7 @@ extern "C" int slam3d_icp_dense_begin(slam3d_icp_handle *h, const double *T_init
     const int rc = enqueue_preprocess(h, 1, T_init, s);
     if (rc) return rc;
     h->dense_it = 0;
-    h->run_stream = s; h->ran = true; h->last_B = 1;
+    h->run_stream = s; h->ran = true; h->last_B = 1; h->res_mapped = false; h->ran_profiled = false;
     return SLAM3D_OK;
 }
 

@@ -31,6 +31,7 @@ struct SlotPtrs {                  // per frame-pair device pointers (organized 
     const float4 *src;
     const float4 *tgt;
 };
+constexpr int RES_REC = 48;        // doubles per pair in the host-mapped result record
 constexpr int SLOT_ARGS = 32;
 struct SlotArgs { SlotPtrs p[SLOT_ARGS]; };
 // the slot table travels as a kernel argument (copied at launch), not through pinned host memory
@@ -1396,6 +1397,7 @@ __global__ __launch_bounds__(CHUNK) void k_reduce_solve(const double *__restrict
                                                         double *__restrict__ sums_all,
                                                         double *__restrict__ Tcur, double *__restrict__ trace_T,
                                                         double *__restrict__ trace_S, int *__restrict__ flags,
+                                                        const int *__restrict__ counts, double *__restrict__ res_host,
                                                         TileGrid tg, int it, int iters, int estimator, int do_solve)
 {
     __shared__ double tot[NSUMS];
@@ -1440,9 +1442,18 @@ __global__ __launch_bounds__(CHUNK) void k_reduce_solve(const double *__restrict
         sums_all[b * NSUMS + threadIdx.x] = a;
     }
     __syncthreads();
-    if (threadIdx.x == 0 && do_solve)
+    if (threadIdx.x == 0 && do_solve) {
         solve_update_one(tot, Tcur + b * 16, trace_T + (size_t)b * (iters + 1) * 16, trace_S + (size_t)b * iters * NSUMS,
                          flags + b, it, estimator);
+        if (res_host && it == iters - 1) {
+            // final iteration: the pose record goes straight to host-mapped memory (T, last sums, degenerate flag,
+            // n_src, n_tgt), so fetch_results is a stream synchronisation with no copy launches behind it
+            double *__restrict__ r = res_host + (size_t)b * RES_REC;
+            for (int k = 0; k < 16; ++k) r[k] = Tcur[b * 16 + k];
+            for (int k = 0; k < NSUMS; ++k) r[16 + k] = tot[k];
+            r[45] = (double)flags[b]; r[46] = (double)counts[b * 4]; r[47] = (double)counts[b * 4 + 1];
+        }
+    }
 }
 
 // dense mode: solve from externally reduced sums (one thread per pair)
