@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bruteforce", action="store_true")
     ap.add_argument("--seed0", type=int, default=1000)
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo + --one-device: exercise the N>1 code path with several ranks on ONE GPU (tests only)")
+    ap.add_argument("--one-device", action="store_true")
     return ap.parse_args()
 
 
@@ -143,11 +146,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the ICP path)")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    host_comm = args.dist_backend == "gloo"       # exchange buffers on the host (RCCL needs one GPU per rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if host_comm:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     is_dense = args.mode == "dense"
     P = 1 if is_dense else args.pairs
@@ -168,16 +177,26 @@ def main():
         h.set_clouds_device(i, d_src.data_ptr() + i * rec_bytes, d_tgt.data_ptr() + i * rec_bytes)
     stream = torch.cuda.current_stream().cuda_stream
     table = {}
-    allreduce = dense.allreduce_sum_torch(dev) if world > 1 else None
+    d_sums = torch.zeros(29, dtype=torch.float64, device=dev)       # dense mode: the per-iteration exchange buffer
+    gatherer = shard.PoseGatherer(world * P, device=None if host_comm else dev) if (world > 1 and not is_dense) else None
+    host_allreduce = dense.allreduce_sum_torch(None) if (host_comm and world > 1) else None
 
     def step():
-        if is_dense:      # one exchange per iteration: 29-double all-reduce (RCCL)
-            return [dense.dense_align(h, world, rank, None, allreduce, stream)]
+        if is_dense:      # one exchange per iteration: 29-double all-reduce (RCCL), device resident
+            if host_allreduce:
+                return [dense.dense_align(h, world, rank, None, host_allreduce, stream)]
+            return [dense.dense_align_device(h, world, rank, d_sums, None, stream)]
         h.run(P, None, stream)
         res = h.fetch_results(P)
-        if world > 1:     # RCCL all-gather of the 160-byte pose records (T, norm, inliers, status, rmse)
-            table["poses"] = shard.gather_records(shard.pack_records(res), world * P, device=dev)
+        if gatherer:      # RCCL all-gather of the 160-byte pose records (T, norm, inliers, status, rmse), one per
+            gatherer.submit(shard.pack_records(res))     # step, overlapping the next step's kernels
+            if len(gatherer.pending) > 1:
+                table["poses"] = gatherer.collect()
         return res
+
+    def drain():
+        while gatherer and gatherer.pending:
+            table["poses"] = gatherer.collect()
 
     def fence():
         torch.cuda.synchronize()
@@ -187,12 +206,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     nn_ms, tot_ms, pre_ms = [], [], []
     fence()
     t0 = time.perf_counter()
     res = None
     for _ in range(args.steps):
         res = step()
+    drain()                 # the last step's pose table is on every rank before the clock stops
     fence()
     elapsed = time.perf_counter() - t0
     if not is_dense:
@@ -203,9 +224,10 @@ def main():
             step()
             tm = h.get_timings()
             nn_ms.append(tm["nn_ms"]); tot_ms.append(tm["total_ms"]); pre_ms.append(tm["preprocess_ms"])
+        drain()
         fence()
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_comm else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -182,6 +182,12 @@ int slam3d_icp_dense_partial(slam3d_icp_handle *h, double sums[SLAM3D_ICP_NSUMS]
 int slam3d_icp_dense_update(slam3d_icp_handle *h, const double sums[SLAM3D_ICP_NSUMS], void *stream);
 int slam3d_icp_dense_finish(slam3d_icp_handle *h, const double last_sums[SLAM3D_ICP_NSUMS],
                             slam3d_icp_result *out);
+/* the same three with the 29 sums in a caller-owned DEVICE buffer: partial writes it, the caller all-reduces it
+ * in place on the same stream (RCCL), update reads it.  No host synchronisation until finish. */
+int slam3d_icp_dense_partial_device(slam3d_icp_handle *h, double *d_sums, void *stream);
+int slam3d_icp_dense_update_device(slam3d_icp_handle *h, const double *d_sums, void *stream);
+int slam3d_icp_dense_finish_device(slam3d_icp_handle *h, const double *d_last_sums, void *stream,
+                                   slam3d_icp_result *out);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = [
     "slam3d_icp_get_clouds", "slam3d_icp_set_profiling", "slam3d_icp_get_timings", "slam3d_icp_get_iteration_timings", "slam3d_icp_get_nn_debug", "slam3d_backproject_u16", "slam3d_fit_planes",
     "slam3d_icp_dense_set_rows", "slam3d_icp_dense_begin", "slam3d_icp_dense_partial",
     "slam3d_icp_dense_update", "slam3d_icp_dense_finish",
+    "slam3d_icp_dense_partial_device", "slam3d_icp_dense_update_device", "slam3d_icp_dense_finish_device",
 ]
 
 
@@ -278,6 +279,17 @@ class IcpHandle:
     def dense_update(self, sums: np.ndarray, stream: int = 0):
         s = np.ascontiguousarray(sums, dtype=np.float64).reshape(NSUMS)
         self._check(self.lib.slam3d_icp_dense_update(self._h, _vp(s), C.c_void_p(stream)), False)
+
+    def dense_partial_device(self, d_sums: int, stream: int = 0):
+        self._check(self.lib.slam3d_icp_dense_partial_device(self._h, C.c_void_p(d_sums), C.c_void_p(stream)), False)
+
+    def dense_update_device(self, d_sums: int, stream: int = 0):
+        self._check(self.lib.slam3d_icp_dense_update_device(self._h, C.c_void_p(d_sums), C.c_void_p(stream)), False)
+
+    def dense_finish_device(self, d_sums: int, stream: int = 0) -> dict:
+        out = Result()
+        self._check(self.lib.slam3d_icp_dense_finish_device(self._h, C.c_void_p(d_sums), C.c_void_p(stream), C.byref(out)), False)
+        return out.as_dict()
 
     def dense_finish(self, last_sums: np.ndarray) -> dict:
         s = np.ascontiguousarray(last_sums, dtype=np.float64).reshape(NSUMS)

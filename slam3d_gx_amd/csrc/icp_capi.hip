@@ -368,8 +368,10 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
 
 // one iteration's data-parallel part: NN search + normal-equation chunks, then the 29-sum reduction
 // (+ solve and SE(3) update when do_solve)
-static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int it, int do_solve)
+static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int it, int do_solve,
+                             double *sums_out = nullptr)
 {
+    if (!sums_out) sums_out = h->sums;
     const TileGrid &tg = h->tg;
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
     if (e0) HIPCHK(h, hipEventRecord(e0, s));
@@ -398,7 +400,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         hipLaunchKernelGGL(k_accumulate, dim3(tg.nchunks, B), dim3(CHUNK), 0, s, h->d_slots, h->nrm, h->srcT, h->Tcur, h->best,
                            h->corr, h->cd2, h->prevq, h->partials, h->g, tg);
     }
-    hipLaunchKernelGGL(k_reduce_solve, dim3(tg.ngroups, B), dim3(CHUNK), 0, s, h->partials, h->GP, h->ticket, h->sums, h->Tcur,
+    hipLaunchKernelGGL(k_reduce_solve, dim3(tg.ngroups, B), dim3(CHUNK), 0, s, h->partials, h->GP, h->ticket, sums_out, h->Tcur,
                        h->trace_T, h->trace_S, h->flags, h->counts, do_solve ? h->d_res : nullptr, tg, it, iters, h->p.estimator, do_solve);
     HIPCHK(h, hipGetLastError());
     return SLAM3D_OK;
@@ -781,6 +783,49 @@ extern "C" int slam3d_icp_dense_update(slam3d_icp_handle *h, const double sums[S
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(s));   // pin_out is reused by the next call
     h->dense_it++;
+    return SLAM3D_OK;
+}
+
+// Device-resident forms of the three calls above: the 29 sums stay in a caller-owned device buffer, so the
+// exchange (an RCCL all-reduce on the same stream) needs no host round trip; nothing here synchronises.
+extern "C" int slam3d_icp_dense_partial_device(slam3d_icp_handle *h, double *d_sums, void *stream)
+{
+    if (!h || !d_sums) return SLAM3D_E_INVALID;
+    if (!h->ran) return SLAM3D_E_STATE;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
+    return enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0, d_sums);
+}
+
+extern "C" int slam3d_icp_dense_update_device(slam3d_icp_handle *h, const double *d_sums, void *stream)
+{
+    if (!h || !d_sums) return SLAM3D_E_INVALID;
+    const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
+    if (!h->ran || h->dense_it >= iters) return SLAM3D_E_STATE;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, s, d_sums, h->Tcur, h->trace_T, h->trace_S, h->flags, 1, h->dense_it,
+                       iters, h->p.estimator);
+    HIPCHK(h, hipGetLastError());
+    h->dense_it++;
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_dense_finish_device(slam3d_icp_handle *h, const double *d_last_sums, void *stream,
+                                              slam3d_icp_result *out)
+{
+    if (!h || !out || !d_last_sums) return SLAM3D_E_INVALID;
+    if (!h->ran) return SLAM3D_E_STATE;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
+    double *ps = h->pin_out + 16;
+    HIPCHK(h, hipMemcpyAsync(h->pin_out, h->Tcur, sizeof(double) * 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(ps, d_last_sums, sizeof(double) * NSUMS, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->pin_int, h->counts, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->pin_int + 4, h->flags, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    finish_result(h->p, h->pin_out, ps, h->pin_int[4], h->pin_int[0], h->pin_int[1], out);
+    out->iterations = h->dense_it;
     return SLAM3D_OK;
 }
 

@@ -47,3 +47,23 @@ def dense_align(handle, world: int, rank: int, T_init=None, allreduce: Optional[
     res = handle.dense_finish(total)
     handle.dense_set_rows(0, handle.params.height)
     return res
+
+
+def dense_align_device(handle, world: int, rank: int, d_sums, T_init=None, stream: int = 0) -> dict:
+    """dense_align with the exchange kept on the device: `d_sums` is a torch float64 tensor of 29 elements on the
+    handle's GPU; per iteration partial -> in-place all-reduce (RCCL, same stream) -> update, with no host
+    synchronisation until the final fetch."""
+    import torch.distributed as dist
+    r0, r1 = shard.dense_row_range(handle.params.height, world, rank)
+    handle.dense_set_rows(r0, r1)
+    handle.dense_begin(T_init, stream)
+    on = dist.is_initialized() and dist.get_world_size() > 1
+    ptr = d_sums.data_ptr()
+    for _ in range(handle.params.iterations):
+        handle.dense_partial_device(ptr, stream)
+        if on:
+            dist.all_reduce(d_sums, op=dist.ReduceOp.SUM)
+        handle.dense_update_device(ptr, stream)
+    res = handle.dense_finish_device(ptr, stream)
+    handle.dense_set_rows(0, handle.params.height)
+    return res

@@ -214,6 +214,14 @@ def test_dense_mode_two_emulated_ranks(gpu_lib):
         h.set_clouds_host(0, s4, t4)
         r1rank = dense.dense_align(h, 1, 0)
     assert np.array_equal(r1rank["T_raw"], ro["T_trace"][-1])
+    # device-resident exchange buffer (what bench.py --mode dense runs over RCCL): same bits again
+    import torch
+    d_sums = torch.zeros(29, dtype=torch.float64, device="cuda:0")
+    with capi.IcpHandle(capi.default_params(pr.intr, iterations=iters)) as h:
+        h.set_clouds_host(0, s4, t4)
+        rdev = dense.dense_align_device(h, 1, 0, d_sums, None, torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(rdev["T_raw"], r1rank["T_raw"]) and rdev["inliers"] == r1rank["inliers"]
+    assert rdev["rmse"] == r1rank["rmse"]
 
 
 def test_config3_batch_of_full_size_pairs(gpu_lib):

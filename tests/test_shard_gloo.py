@@ -49,6 +49,14 @@ def _worker(rank, world, port, q):
     b, e = shard.shard_range(len(SEEDS), world, rank)
     local = [_solve_pair(s) for s in SEEDS[b:e]]
     table = shard.gather_records(shard.pack_records(local), len(SEEDS))
+    # the preallocated, one-step-pipelined gatherer bench.py uses must give the same table
+    pg = shard.PoseGatherer(len(SEEDS))
+    rec = shard.pack_records(local)
+    pg.submit(rec)
+    pg.submit(rec * 2.0)
+    t1, t2 = pg.collect(), pg.collect()
+    assert np.array_equal(t1, table) and np.array_equal(t2, table * 2.0)
+    assert np.array_equal(pg.gather(rec), table)
     if rank == 0:
         q.put(table)
     dist.barrier()
