@@ -49,7 +49,8 @@ def parse_args():
     ap.add_argument("--iterations", type=int, default=20)
     ap.add_argument("--estimator", choices=["point2plane", "svd"], default="point2plane")
     ap.add_argument("--nn-mode", type=int, default=0, help="0 auto(tiles) 1 brute-force VALU 2 brute-force MFMA 3 tiles")
-    ap.add_argument("--mode", choices=["batch", "dense"], default="batch")
+    ap.add_argument("--mode", choices=["batch", "dense", "seg"], default="batch",
+                    help="seg: row f-2, batched RANSAC plane segmentation of --pairs frames per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bruteforce", action="store_true")
     ap.add_argument("--seed0", type=int, default=1000)
@@ -133,6 +134,74 @@ def committed_traffic():
         return None, None
 
 
+def seg_mode(args, torch, dist, capi, synth, world, rank, local_rank, dev):
+    """Row f-2: plane segmentation of F = --pairs resident frames per GPU and step."""
+    F = args.pairs
+    seeds = [args.seed0 + rank * F + i for i in range(F)]
+    frames = [synth.make_pair(s, args.width, args.height) for s in seeds]
+    intr = frames[0].intr
+    host = [synth.backproject_numpy(p.depth_src, intr).reshape(-1, 4) for p in frames]
+    d = torch.from_numpy(np.stack(host)).to(dev)
+    N = args.width * args.height
+    d_lab = torch.zeros((F, N), dtype=torch.int32, device=dev)
+    h = capi.IcpHandle(capi.default_params(intr, max_batch=F, device=local_rank))
+    sp = h.seg_params(seed=args.seed0)
+    ptrs = [d.data_ptr() + i * N * 16 for i in range(F)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out_planes = None
+    for _ in range(args.warmup):
+        h.segment_planes_device(ptrs, sp, d_lab.data_ptr(), stream)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_planes = h.segment_planes_device(ptrs, sp, d_lab.data_ptr(), stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    rounds = [len(p) for p in out_planes]
+    # point passes: init + per round (count, moments, label); each reads 16 B cloud + 4 B label per pixel
+    passes = sum(1 + 3 * min(sp.max_planes, r + 1) for r in rounds)
+    alg_bytes = passes * 20 * N
+    value = world * F * args.steps / elapsed
+    out = {
+        "metric": f"plane segmentations/sec on {args.width}x{args.height} organized clouds", "value": value, "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+int64", "data": "synthetic",
+        "config": {"workload": f"row f-2: {F} frame(s) per GPU, <= {sp.max_planes} planes, {sp.hypotheses} hypotheses per round, "
+                               f"threshold {sp.distance_threshold:.2f} m, plane_percent {sp.plane_percent:.1f}",
+                   "frames_per_gpu": F, "planes_found": rounds[:8]},
+        "roofline": {"kernel": "whole launch sequence (k_seg_init + rounds x {hyp, count, moments, refine, label})",
+                     "bound": "hbm", "achieved": alg_bytes / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_step": alg_bytes,
+                     "note": "17 dependent small launches per call; launch latency, not bandwidth, bounds one frame"},
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            t1 = time.perf_counter()
+            po, lo = O.segment_planes(host[0], seed=args.seed0)
+            dt = time.perf_counter() - t1
+            lab0 = d_lab[0].cpu().numpy()
+            out["cpu_baseline"] = {"value": 1.0 / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                                   "sample": "oracle/seg_oracle.c, frame 0, single thread"}
+            out["parity_vs_oracle"] = {"labels_equal": bool(np.array_equal(lab0, lo)),
+                                       "coeff_equal": bool(all(np.array_equal(a["coeff"], b["coeff"]) for a, b in zip(out_planes[0], po)))}
+        print(json.dumps(out))
+    h.close()
+
+
 def main():
     args = parse_args()
     import torch
@@ -158,6 +227,11 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.mode == "seg":
+        seg_mode(args, torch, dist, capi, synth, world, rank, local_rank, dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     is_dense = args.mode == "dense"
     P = 1 if is_dense else args.pairs
     est = capi.EST_POINT2PLANE if args.estimator == "point2plane" else capi.EST_SVD

@@ -171,6 +171,27 @@ int slam3d_backproject_u16(slam3d_icp_handle *h, const uint16_t *depth, float *x
 int slam3d_fit_planes(slam3d_icp_handle *h, const slam3d_cloud_view *cloud, const int32_t *labels,
                       int32_t nplanes, slam3d_plane *planes);
 
+/* ---- plane segmentation (replaces the pcl::SACSegmentation loop of extractPlanesAndGenerateImage,
+ * src/GraphicEnd.cpp:353-430): up to max_planes rounds of seeded RANSAC + least-squares refinement while more
+ * than plane_percent of the valid points are unassigned (:372); planes in extraction order, unit normal, d >= 0
+ * (:383-387).  labels[N]: -2 invalid pixel, -1 valid but on no plane, r = plane r. */
+typedef struct slam3d_seg_params {
+    float    distance_threshold;   /* parameters.yaml distance_threshold (0.08), :365 */
+    float    plane_percent;        /* parameters.yaml plane_percent (0.2), :372 */
+    int32_t  max_planes;           /* parameters.yaml max_planes (3), :424; <= 8 */
+    int32_t  hypotheses;           /* RANSAC hypotheses per round, 1..64 (PCL's default budget is 50) */
+    uint64_t seed;                 /* counter-based PRNG seed: same seed, same planes */
+} slam3d_seg_params;
+void slam3d_seg_default_params(slam3d_seg_params *sp);
+/* one organized host cloud; planes[max_planes], labels nullable */
+int slam3d_segment_planes(slam3d_icp_handle *h, const slam3d_cloud_view *cloud, const slam3d_seg_params *sp,
+                          slam3d_plane *planes, int32_t *nplanes, int32_t *labels);
+/* B organized float4 clouds resident on the device (d_clouds: host array of B device pointers);
+ * planes[B*max_planes], nplanes[B] on the host, d_labels (device, B*N) nullable */
+int slam3d_segment_planes_device(slam3d_icp_handle *h, int32_t B, const void *const *d_clouds,
+                                 const slam3d_seg_params *sp, slam3d_plane *planes, int32_t *nplanes,
+                                 int32_t *d_labels, void *stream);
+
 /* ---- dense (single pair sharded over ranks) building blocks, one exchange per iteration -- */
 /* restrict the source rows this handle works on to [row_begin,row_end) of slot 0 */
 int slam3d_icp_dense_set_rows(slam3d_icp_handle *h, int32_t row_begin, int32_t row_end);

@@ -92,6 +92,19 @@ int orc_nn_once(const float *src4, const float *tgt4, const orc_params *p,
 void orc_fit_planes(const float *xyz4, const int32_t *labels, int n, int nplanes,
                     float *planes, int32_t *counts);
 
+/* batched plane segmentation (row f-2, seg_oracle.c): labels[n] out: -2 invalid pixel, -1 valid on no plane,
+ * r = plane r; planes[max_planes*8] = a b c d cx cy cz count; returns the number of planes */
+#define ORC_SEG_DRAWS 32
+typedef struct {
+    float distance_threshold;   /* parameters.yaml distance_threshold 0.08 (src/GraphicEnd.cpp:365) */
+    float plane_percent;        /* plane_percent 0.2 (:372) */
+    int32_t max_planes;         /* max_planes 3 (:424) */
+    int32_t hypotheses;         /* per round, <= 64 */
+    uint64_t seed;
+} orc_seg_params;
+int orc_segment_planes(const float *xyz4, int n, float zmax, const orc_seg_params *sp, float *planes,
+                       int32_t *labels);
+
 /* pose error metric a14: E = Tref^-1 * T ; trans = ||E_t||, rot = acos(clamp((tr-1)/2)) */
 void orc_pose_error(const double *Tref, const double *T, double *rot_err, double *trans_err);
 

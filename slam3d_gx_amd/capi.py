@@ -24,6 +24,7 @@ EXPORTED_SYMBOLS = [
     "slam3d_icp_set_clouds_device", "slam3d_icp_set_depth_device", "slam3d_icp_run",
     "slam3d_icp_fetch_results", "slam3d_icp_get_correspondences", "slam3d_icp_get_trace",
     "slam3d_icp_get_clouds", "slam3d_icp_set_profiling", "slam3d_icp_get_timings", "slam3d_icp_get_iteration_timings", "slam3d_icp_get_nn_debug", "slam3d_backproject_u16", "slam3d_fit_planes",
+    "slam3d_seg_default_params", "slam3d_segment_planes", "slam3d_segment_planes_device",
     "slam3d_icp_dense_set_rows", "slam3d_icp_dense_begin", "slam3d_icp_dense_partial",
     "slam3d_icp_dense_update", "slam3d_icp_dense_finish",
     "slam3d_icp_dense_partial_device", "slam3d_icp_dense_update_device", "slam3d_icp_dense_finish_device",
@@ -63,6 +64,11 @@ class Plane(C.Structure):
     _fields_ = [("coeff", C.c_float * 4), ("count", C.c_int32), ("centroid", C.c_float * 3)]
 
 
+class SegParams(C.Structure):
+    _fields_ = [("distance_threshold", C.c_float), ("plane_percent", C.c_float), ("max_planes", C.c_int32),
+                ("hypotheses", C.c_int32), ("seed", C.c_uint64)]
+
+
 class Slam3dError(RuntimeError):
     def __init__(self, code: int, msg: str):
         super().__init__(f"slam3d_icp error {code}: {msg}")
@@ -91,9 +97,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.slam3d_icp_destroy.restype = None
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("slam3d_strerror", "slam3d_last_error", "slam3d_icp_destroy", "slam3d_icp_default_params"):
+        if name not in ("slam3d_strerror", "slam3d_last_error", "slam3d_icp_destroy", "slam3d_icp_default_params",
+                        "slam3d_seg_default_params"):
             fn.restype = C.c_int
     lib.slam3d_icp_default_params.restype = None
+    lib.slam3d_seg_default_params.restype = None
     if path is None:
         _lib = lib
     return lib
@@ -262,6 +270,42 @@ class IcpHandle:
         planes = (Plane * nplanes)()
         self._check(self.lib.slam3d_fit_planes(self._h, C.byref(cv), _vp(lab), C.c_int32(nplanes), planes), False)
         return [dict(coeff=np.array(p.coeff), count=p.count, centroid=np.array(p.centroid)) for p in planes]
+
+    # ---- plane segmentation (f-2) ---------------------------------------------------------
+    @staticmethod
+    def seg_params(**kw) -> SegParams:
+        sp = SegParams()
+        load_library().slam3d_seg_default_params(C.byref(sp))
+        for k, v in kw.items():
+            if not hasattr(sp, k):
+                raise AttributeError(k)
+            setattr(sp, k, v)
+        return sp
+
+    @staticmethod
+    def _planes_out(planes, nplanes, B, maxp):
+        return [[dict(coeff=np.array(planes[b * maxp + r].coeff), count=planes[b * maxp + r].count,
+                      centroid=np.array(planes[b * maxp + r].centroid)) for r in range(nplanes[b])] for b in range(B)]
+
+    def segment_planes(self, xyz4: np.ndarray, sp: Optional[SegParams] = None, want_labels: bool = True):
+        sp = sp or self.seg_params()
+        c = np.ascontiguousarray(xyz4, dtype=np.float32)
+        cv = _cloud_view(c, self.params.width, self.params.height)
+        planes = (Plane * sp.max_planes)()
+        npl = (C.c_int32 * 1)()
+        lab = np.zeros(self.params.width * self.params.height, dtype=np.int32) if want_labels else None
+        self._check(self.lib.slam3d_segment_planes(self._h, C.byref(cv), C.byref(sp), planes, npl, _vp(lab)), False)
+        return self._planes_out(planes, npl, 1, sp.max_planes)[0], lab
+
+    def segment_planes_device(self, d_cloud_ptrs: Sequence[int], sp: Optional[SegParams] = None, d_labels: int = 0, stream: int = 0):
+        sp = sp or self.seg_params()
+        B = len(d_cloud_ptrs)
+        ptrs = (C.c_void_p * B)(*[C.c_void_p(p) for p in d_cloud_ptrs])
+        planes = (Plane * (sp.max_planes * B))()
+        npl = (C.c_int32 * B)()
+        self._check(self.lib.slam3d_segment_planes_device(self._h, C.c_int32(B), ptrs, C.byref(sp), planes, npl,
+                                                          C.c_void_p(d_labels), C.c_void_p(stream)), False)
+        return self._planes_out(planes, npl, B, sp.max_planes)
 
     # ---- dense mode --------------------------------------------------------------------
     def dense_set_rows(self, r0: int, r1: int):

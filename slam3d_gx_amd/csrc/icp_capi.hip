@@ -5,6 +5,7 @@
 // every entry point that computes runs HIP kernels on a gfx950 device or returns an error.
 #include "../../include/slam3d_icp.h"
 #include "icp_kernels.hpp"
+#include "plane_seg.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -33,6 +34,10 @@ struct slam3d_icp_handle {
     uint16_t *d_depth = nullptr;
     int *d_idx = nullptr; float *d_d2 = nullptr;
     float4 *d_scratch4 = nullptr;
+    // plane segmentation (f-2): allocated on first use
+    SegState *seg_state = nullptr, *pin_seg = nullptr;
+    int *seg_labels = nullptr;
+    const float4 **seg_ptrs = nullptr;
     // 8x8-pixel tiles (slot order of the sums; target tiles + boxes for the pruned NN)
     TileGrid tg;
     float4 *srcT = nullptr, *tgtT = nullptr, *tbox = nullptr, *cbox = nullptr, *prevq = nullptr;
@@ -121,6 +126,8 @@ static void free_all(slam3d_icp_handle *h)
     F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox); F(h->GP); F(h->ticket); F(h->dbg); F(h->prevq); F(h->hint); F(h->scount); F(h->perm); F(h->cost); F(h->tgtB); F(h->qmax2);
     if (h->pin_slots) (void)hipHostFree(h->pin_slots);
     if (h->pin_res) (void)hipHostFree(h->pin_res);
+    if (h->pin_seg) (void)hipHostFree(h->pin_seg);
+    F(h->seg_state); F(h->seg_labels); F(h->seg_ptrs);
     if (h->pin_T) (void)hipHostFree(h->pin_T);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->pin_int) (void)hipHostFree(h->pin_int);
@@ -728,6 +735,98 @@ extern "C" int slam3d_fit_planes(slam3d_icp_handle *h, const slam3d_cloud_view *
         P.coeff[0] = (float)nx; P.coeff[1] = (float)ny; P.coeff[2] = (float)nz; P.coeff[3] = (float)d;
         P.centroid[0] = (float)cx; P.centroid[1] = (float)cy; P.centroid[2] = (float)cz;
     }
+    return SLAM3D_OK;
+}
+
+// ------------------------------------------------------------------------------ plane segmentation (f-2)
+extern "C" void slam3d_seg_default_params(slam3d_seg_params *sp)
+{
+    if (!sp) return;
+    sp->distance_threshold = 0.08f;     // parameters.yaml:45 distance_threshold
+    sp->plane_percent = 0.2f;           // parameters.yaml:46 plane_percent
+    sp->max_planes = 3;                 // parameters.yaml:47 max_planes
+    sp->hypotheses = 64;
+    sp->seed = 1;
+}
+
+static int seg_alloc(slam3d_icp_handle *h)
+{
+    if (h->seg_state) return SLAM3D_OK;
+    if (hipMalloc((void **)&h->seg_state, sizeof(SegState) * h->maxB) != hipSuccess ||
+        hipMalloc((void **)&h->seg_labels, sizeof(int) * (size_t)h->maxB * h->N) != hipSuccess ||
+        hipMalloc((void **)&h->seg_ptrs, sizeof(float4 *) * h->maxB) != hipSuccess ||
+        hipHostMalloc((void **)&h->pin_seg, sizeof(SegState) * h->maxB, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return SLAM3D_E_NOMEM;
+    }
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_segment_planes_device(slam3d_icp_handle *h, int32_t B, const void *const *d_clouds,
+                                            const slam3d_seg_params *sp, slam3d_plane *planes, int32_t *nplanes,
+                                            int32_t *d_labels, void *stream)
+{
+    if (!h || !d_clouds || !sp || !planes || !nplanes || B <= 0 || B > h->maxB) return SLAM3D_E_INVALID;
+    if (sp->max_planes < 1 || sp->max_planes > SEG_MAXP || sp->hypotheses < 1 || sp->hypotheses > SEG_H ||
+        !(sp->distance_threshold > 0.0f) || !(sp->plane_percent >= 0.0f))
+        return SLAM3D_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    int rc = seg_alloc(h);
+    if (rc) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    const int N = h->N;
+    for (int b0 = 0; b0 < B; b0 += PTR_ARGS) {
+        PtrArgs a;
+        const int n = B - b0 < PTR_ARGS ? B - b0 : PTR_ARGS;
+        for (int k = 0; k < n; ++k) {
+            if (!d_clouds[b0 + k]) return SLAM3D_E_INVALID;
+            a.p[k] = static_cast<const float4 *>(d_clouds[b0 + k]);
+        }
+        hipLaunchKernelGGL(k_set_ptrs, dim3(1), dim3(64), 0, s, h->seg_ptrs + b0, a, n);
+    }
+    int *lab = d_labels ? d_labels : h->seg_labels;
+    const SegParams P = { sp->distance_threshold, sp->plane_percent, sp->max_planes, sp->hypotheses, sp->seed };
+    const dim3 pg((N + SEG_BLOCK * SEG_PTS - 1) / (SEG_BLOCK * SEG_PTS), B);
+    HIPCHK(h, hipMemsetAsync(h->seg_state, 0, sizeof(SegState) * B, s));
+    hipLaunchKernelGGL(k_seg_init, pg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, h->g.zmax);
+    for (int r = 0; r < P.max_planes; ++r) {
+        hipLaunchKernelGGL(k_seg_hyp, dim3(B), dim3(64), 0, s, h->seg_ptrs, lab, h->seg_state, N, P, r);
+        hipLaunchKernelGGL(k_seg_count, dim3(pg.x, pg.y, (P.hypotheses + SEG_HGROUP - 1) / SEG_HGROUP), dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, P.hypotheses);
+        hipLaunchKernelGGL(k_seg_moments, pg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, P.hypotheses);
+        hipLaunchKernelGGL(k_seg_refine, dim3(B), dim3(64), 0, s, h->seg_state, P.hypotheses, r);
+        hipLaunchKernelGGL(k_seg_label, pg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, P.thr, r);
+    }
+    hipLaunchKernelGGL(k_seg_final, dim3(B), dim3(1), 0, s, h->seg_state, P.max_planes);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->pin_seg, h->seg_state, sizeof(SegState) * B, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    for (int b = 0; b < B; ++b) {
+        const SegState &st = h->pin_seg[b];
+        nplanes[b] = st.nplanes;
+        for (int r = 0; r < sp->max_planes; ++r) {
+            slam3d_plane &o = planes[(size_t)b * sp->max_planes + r];
+            memset(&o, 0, sizeof o);
+            if (r >= st.nplanes) continue;
+            const SegPlane &q = st.planes[r];
+            o.coeff[0] = q.a; o.coeff[1] = q.b; o.coeff[2] = q.c; o.coeff[3] = q.d;
+            o.count = q.count;
+            o.centroid[0] = q.cx; o.centroid[1] = q.cy; o.centroid[2] = q.cz;
+        }
+    }
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_segment_planes(slam3d_icp_handle *h, const slam3d_cloud_view *cloud, const slam3d_seg_params *sp,
+                                     slam3d_plane *planes, int32_t *nplanes, int32_t *labels)
+{
+    if (!h || !cloud || !sp || !planes || !nplanes) return SLAM3D_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    int rc = upload_cloud(h, cloud, h->d_scratch4);
+    if (rc) return rc;
+    const void *ptr = h->d_scratch4;
+    rc = slam3d_segment_planes_device(h, 1, &ptr, sp, planes, nplanes, nullptr, h->stream);
+    if (rc) return rc;
+    if (labels) HIPCHK(h, hipMemcpy(labels, h->seg_labels, sizeof(int) * (size_t)h->N, hipMemcpyDeviceToHost));
     return SLAM3D_OK;
 }
 

@@ -1,0 +1,315 @@
+// plane_seg.hpp -- batched RANSAC plane segmentation on gfx950.
+//
+// Replaces the pcl::SACSegmentation loop of GraphicEnd::extractPlanesAndGenerateImage
+// (src/GraphicEnd.cpp:353-430): up to max_planes rounds of {H seeded hypotheses, consensus count over the
+// unassigned points, least-squares refinement of the consensus set, re-selection, sign rule d >= 0 (:383-387),
+// removal of the inliers (:419-420)} while more than plane_percent of the cloud is unassigned (:372).
+// Spec P1-P5; oracle/seg_oracle.c is the CPU twin and gives the same bits:
+// the consensus counts are integers, the moments are integer fixed point (order-free, so wave reductions and
+// atomics are exact) and the 3x3 eigen solve is the spec's cyclic Jacobi run by one thread.
+//
+// One launch sequence serves B frames (blockIdx.y / blockIdx.x = frame).  Nothing returns to the host between
+// the rounds: the loop condition lives in SegState.done on the device.
+#pragma once
+
+#include "icp_kernels.hpp"
+
+namespace s3d {
+
+constexpr int SEG_H = 64;          // hypotheses per round (lane h of a wave owns hypothesis h)
+constexpr int SEG_DRAWS = 32;      // PRNG draws a hypothesis may spend on its three points
+constexpr int SEG_MAXP = 8;        // planes per frame
+constexpr int SEG_PTS = 4;         // points per thread in the consensus / moment kernels
+constexpr int SEG_BLOCK = 256;
+constexpr int SEG_HGROUP = 16;     // hypotheses per k_seg_count block (grid.z = SEG_H / SEG_HGROUP)
+
+struct SegParams { float thr, percent; int max_planes, hypotheses; unsigned long long seed; };
+
+struct SegHyp { float nx, ny, nz, dd, thr2nn; int ok; float p0x, p0y, p0z; };
+
+struct SegPlane { float a, b, c, d, cx, cy, cz; int count; };
+
+struct SegState {                  // one per frame, zeroed before k_seg_init
+    int n_valid, remaining, nplanes, done;
+    int best, lab_count, pad0, pad1;
+    int counts[SEG_H];
+    long long mom[10];
+    SegHyp hyp[SEG_H];
+    SegPlane planes[SEG_MAXP];
+};
+
+__device__ __forceinline__ unsigned long long seg_mix64(unsigned long long z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ bool seg_inlier(float nx, float ny, float nz, float dd, float thr2nn, float4 q)
+{
+    const float e = __fmaf_rn(nx, q.x, __fmaf_rn(ny, q.y, nz * q.z)) + dd;
+    return e * e <= thr2nn;
+}
+
+// sum over the 256 threads of a block (valid in thread 0): wave shuffles, then LDS across the four waves
+__device__ __forceinline__ int block_sum_int(int v)
+{
+    __shared__ int part[SEG_BLOCK / 64];
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return part[0] + part[1] + part[2] + part[3];
+}
+
+// P1: labels = -1 (valid, unassigned) / -2 (invalid); n_valid.  grid (ceil(N/1024), B)
+__global__ __launch_bounds__(SEG_BLOCK) void k_seg_init(const float4 *const *__restrict__ clouds, int *__restrict__ labels,
+                                                        SegState *__restrict__ st, int N, float zmax)
+{
+    const int b = blockIdx.y;
+    const float4 *__restrict__ cloud = clouds[b];
+    int *__restrict__ lab = labels + (size_t)b * N;
+    int nv = 0;
+#pragma unroll
+    for (int k = 0; k < SEG_PTS; ++k) {
+        const int i = (blockIdx.x * SEG_PTS + k) * SEG_BLOCK + threadIdx.x;
+        if (i < N) {
+            const float4 q = cloud[i];
+            const bool ok = pt_valid(q.x, q.y, q.z, zmax);
+            lab[i] = ok ? -1 : -2;
+            nv += ok ? 1 : 0;
+        }
+    }
+    nv = block_sum_int(nv);
+    if (threadIdx.x == 0 && nv) atomicAdd(&st[b].n_valid, nv);     // one same-address atomic per block, not per wave
+}
+
+// bookkeeping of the round that just ended (P4 tail): accept plane r-1 if it kept any point
+__device__ __forceinline__ void seg_close_round(SegState &s, int r)
+{
+    if (r == 0) { s.remaining = s.n_valid; return; }
+    if (s.done) return;
+    const int got = s.lab_count;
+    if (got == 0) { s.done = 1; return; }
+    s.planes[r - 1].count = got;
+    s.nplanes = r;
+    s.remaining -= got;
+}
+
+// P2: loop condition + the H hypotheses of round r.  grid (B), block 64
+__global__ __launch_bounds__(64) void k_seg_hyp(const float4 *const *__restrict__ clouds, const int *__restrict__ labels,
+                                                SegState *__restrict__ st, int N, SegParams sp, int r)
+{
+    const int b = blockIdx.x, h = threadIdx.x;
+    SegState &s = st[b];
+    __shared__ int done;
+    if (h == 0) {
+        seg_close_round(s, r);
+        if (!s.done && (s.n_valid < 3 || !((double)s.remaining > (double)sp.percent * (double)s.n_valid))) s.done = 1;
+        done = s.done;
+        s.lab_count = 0;
+    }
+    __syncthreads();
+    if (done) return;
+    if (h < 10) s.mom[h] = 0;
+    s.counts[h] = 0;
+    SegHyp hy;
+    hy.nx = hy.ny = hy.nz = hy.dd = hy.thr2nn = 0.0f; hy.ok = 0; hy.p0x = hy.p0y = hy.p0z = 0.0f;
+    if (h < sp.hypotheses) {
+        const float4 *__restrict__ cloud = clouds[b];
+        const int *__restrict__ lab = labels + (size_t)b * N;
+        unsigned long long x = sp.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(1 + r * 4096 + h);
+        int pick0 = -1, pick1 = -1, pick2 = -1, np = 0;
+        for (int t = 0; t < SEG_DRAWS && np < 3; ++t) {
+            x += 0x9E3779B97F4A7C15ull;
+            const unsigned long long o = seg_mix64(x);
+            const int pix = (int)(((o >> 32) * (unsigned long long)N) >> 32);
+            if (lab[pix] != -1) continue;
+            if ((np > 0 && pick0 == pix) || (np > 1 && pick1 == pix)) continue;
+            if (np == 0) pick0 = pix; else if (np == 1) pick1 = pix; else pick2 = pix;
+            ++np;
+        }
+        if (np == 3) {
+            const float4 p0 = cloud[pick0], p1 = cloud[pick1], p2 = cloud[pick2];
+            const float ax = p1.x - p0.x, ay = p1.y - p0.y, az = p1.z - p0.z;
+            const float bx = p2.x - p0.x, by = p2.y - p0.y, bz = p2.z - p0.z;
+            const float nx = __fmaf_rn(ay, bz, -(az * by));
+            const float ny = __fmaf_rn(az, bx, -(ax * bz));
+            const float nz = __fmaf_rn(ax, by, -(ay * bx));
+            const float nn = __fmaf_rn(nz, nz, __fmaf_rn(ny, ny, nx * nx));
+            if (nn > 1e-16f) {
+                hy.nx = nx; hy.ny = ny; hy.nz = nz;
+                hy.dd = -__fmaf_rn(nx, p0.x, __fmaf_rn(ny, p0.y, nz * p0.z));
+                hy.thr2nn = (sp.thr * sp.thr) * nn;
+                hy.ok = 1;
+                hy.p0x = p0.x; hy.p0y = p0.y; hy.p0z = p0.z;
+            }
+        }
+    }
+    s.hyp[h] = hy;
+}
+
+// P2: consensus counts.  grid (ceil(N/1024), B), block 256.  Each thread keeps SEG_PTS points in registers;
+// lane h holds hypothesis h and the wave-uniform loop broadcasts it with v_readlane; a ballot + popcount gives
+// the wave's count for hypothesis h, which lane h keeps; the four waves meet in LDS and the block ends with
+// one 64-lane atomic (same-address global atomics serialise, so there is one per block, not per wave).
+__global__ __launch_bounds__(SEG_BLOCK) void k_seg_count(const float4 *const *__restrict__ clouds, const int *__restrict__ labels,
+                                                         SegState *__restrict__ st, int N, int H)
+{
+    const int b = blockIdx.y;
+    SegState &s = st[b];
+    if (s.done) return;
+    const float4 *__restrict__ cloud = clouds[b];
+    const int *__restrict__ lab = labels + (size_t)b * N;
+    float4 q[SEG_PTS];
+    bool live[SEG_PTS];
+#pragma unroll
+    for (int k = 0; k < SEG_PTS; ++k) {
+        const int i = (blockIdx.x * SEG_PTS + k) * SEG_BLOCK + threadIdx.x;
+        live[k] = i < N && lab[i] == -1;
+        q[k] = live[k] ? cloud[i] : make_float4(0, 0, 0, 0);
+    }
+    const int lane = threadIdx.x & 63;
+    __shared__ int bc[SEG_H];
+    if (threadIdx.x < SEG_H) bc[threadIdx.x] = 0;
+    __syncthreads();
+    // lane h holds hypothesis h; the loop broadcasts it with v_readlane (no dependent scalar loads)
+    const SegHyp mh = s.hyp[lane];
+    const unsigned long long okm = __ballot(mh.ok != 0);
+    int mine = 0;
+    // blockIdx.z picks a quarter of the hypotheses: four times the waves for the same number of atomics
+    const int h0 = blockIdx.z * SEG_HGROUP, h1 = min(H, h0 + SEG_HGROUP);
+    for (int h = h0; h < h1; ++h) {
+        if (!((okm >> h) & 1ull)) continue;
+        const float nx = rdlane(mh.nx, h), ny = rdlane(mh.ny, h), nz = rdlane(mh.nz, h), dd = rdlane(mh.dd, h),
+                    t2 = rdlane(mh.thr2nn, h);
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < SEG_PTS; ++k) c += __popcll(__ballot(live[k] && seg_inlier(nx, ny, nz, dd, t2, q[k])));
+        if (lane == h) mine = c;
+    }
+    if (mine) atomicAdd(&bc[lane], mine);
+    __syncthreads();
+    if (threadIdx.x < SEG_H && bc[threadIdx.x]) atomicAdd(&s.counts[threadIdx.x], bc[threadIdx.x]);
+}
+
+// P2 tail + P3: every block finds the best hypothesis (max count, smallest h on ties), block 0 records it, then
+// the block adds its points' fixed-point moments about the hypothesis' first sample.  grid (ceil(N/1024), B)
+__global__ __launch_bounds__(SEG_BLOCK) void k_seg_moments(const float4 *const *__restrict__ clouds, const int *__restrict__ labels,
+                                                           SegState *__restrict__ st, int N, int H)
+{
+    const int b = blockIdx.y;
+    SegState &s = st[b];
+    if (s.done) return;
+    const int lane = threadIdx.x & 63;
+    // argmax over (count desc, h asc): key = count * 64 + (63 - h)
+    int key = lane < H ? s.counts[lane] * 64 + (63 - lane) : -1;
+    for (int o = 32; o >= 1; o >>= 1) key = max(key, __shfl_xor(key, o));
+    const int best = 63 - (key & 63), bc = key >> 6;
+    if (bc < 3) return;                       // k_seg_refine raises done
+    if (blockIdx.x == 0 && threadIdx.x == 0) s.best = best;
+    const SegHyp &hy = s.hyp[best];
+    const float nx = hy.nx, ny = hy.ny, nz = hy.nz, dd = hy.dd, t2 = hy.thr2nn;
+    const double ox = hy.p0x, oy = hy.p0y, oz = hy.p0z;
+    const float4 *__restrict__ cloud = clouds[b];
+    const int *__restrict__ lab = labels + (size_t)b * N;
+    long long m[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) m[k] = 0;
+#pragma unroll
+    for (int k = 0; k < SEG_PTS; ++k) {
+        const int i = (blockIdx.x * SEG_PTS + k) * SEG_BLOCK + threadIdx.x;
+        if (i < N && lab[i] == -1) {
+            const float4 q = cloud[i];
+            if (seg_inlier(nx, ny, nz, dd, t2, q)) {
+                const long long qx = __double2ll_rn(((double)q.x - ox) * 65536.0), qy = __double2ll_rn(((double)q.y - oy) * 65536.0),
+                                qz = __double2ll_rn(((double)q.z - oz) * 65536.0);
+                m[0] += 1; m[1] += qx; m[2] += qy; m[3] += qz;
+                m[4] += qx * qx; m[5] += qx * qy; m[6] += qx * qz; m[7] += qy * qy; m[8] += qy * qz; m[9] += qz * qz;
+            }
+        }
+    }
+    __shared__ unsigned long long bm[10];
+    if (threadIdx.x < 10) bm[threadIdx.x] = 0;
+    __syncthreads();
+    if (__any(m[0] != 0)) {
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            long long v = m[k];
+            for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+            m[k] = v;
+        }
+        long long mine = 0;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) if (lane == k) mine = m[k];
+        if (lane < 10) atomicAdd(&bm[lane], (unsigned long long)mine);
+    }
+    __syncthreads();
+    if (threadIdx.x < 10 && bm[threadIdx.x]) atomicAdd(reinterpret_cast<unsigned long long *>(&s.mom[threadIdx.x]), bm[threadIdx.x]);
+}
+
+// P3 tail: covariance -> eigenvector of the smallest eigenvalue -> (n, d), sign rule.  grid (B), block 64
+__global__ __launch_bounds__(64) void k_seg_refine(SegState *__restrict__ st, int H, int r)
+{
+    SegState &s = st[blockIdx.x];
+    if (s.done) return;
+    const int lane = threadIdx.x;
+    int key = lane < H ? s.counts[lane] * 64 + (63 - lane) : -1;
+    for (int o = 32; o >= 1; o >>= 1) key = max(key, __shfl_xor(key, o));
+    if (lane != 0) return;
+    if ((key >> 6) < 3) { s.done = 1; return; }
+    const SegHyp &hy = s.hyp[s.best];
+    const double ox = hy.p0x, oy = hy.p0y, oz = hy.p0z;
+    const double inv = 1.0 / (double)s.mom[0];
+    const double mx = (double)s.mom[1] * inv, my = (double)s.mom[2] * inv, mz = (double)s.mom[3] * inv;
+    Sym3 C;
+    C.a00 = (double)s.mom[4] * inv - mx * mx; C.a01 = (double)s.mom[5] * inv - mx * my; C.a02 = (double)s.mom[6] * inv - mx * mz;
+    C.a11 = (double)s.mom[7] * inv - my * my; C.a12 = (double)s.mom[8] * inv - my * mz; C.a22 = (double)s.mom[9] * inv - mz * mz;
+    double nx, ny, nz;
+    eig3_smallest(C, nx, ny, nz);
+    const double cx = ox + mx / 65536.0, cy = oy + my / 65536.0, cz = oz + mz / 65536.0;
+    double d = -((nx * cx + ny * cy) + nz * cz);
+    if (d < 0.0) { nx = -nx; ny = -ny; nz = -nz; d = -d; }      // src/GraphicEnd.cpp:383-387
+    SegPlane &P = s.planes[r];
+    P.a = (float)nx; P.b = (float)ny; P.c = (float)nz; P.d = (float)d;
+    P.cx = (float)cx; P.cy = (float)cy; P.cz = (float)cz; P.count = 0;
+}
+
+// P4: the plane's points = unassigned points within thr of the refined plane.  grid (ceil(N/1024), B)
+__global__ __launch_bounds__(SEG_BLOCK) void k_seg_label(const float4 *const *__restrict__ clouds, int *__restrict__ labels,
+                                                         SegState *__restrict__ st, int N, float thr, int r)
+{
+    const int b = blockIdx.y;
+    SegState &s = st[b];
+    if (s.done) return;
+    const SegPlane &P = s.planes[r];
+    const float a = P.a, bb = P.b, c = P.c, d = P.d;
+    const float4 *__restrict__ cloud = clouds[b];
+    int *__restrict__ lab = labels + (size_t)b * N;
+    int got = 0;
+#pragma unroll
+    for (int k = 0; k < SEG_PTS; ++k) {
+        const int i = (blockIdx.x * SEG_PTS + k) * SEG_BLOCK + threadIdx.x;
+        if (i < N && lab[i] == -1) {
+            const float4 q = cloud[i];
+            const float e = __fmaf_rn(a, q.x, __fmaf_rn(bb, q.y, c * q.z)) + d;
+            if (fabsf(e) <= thr) { lab[i] = r; ++got; }
+        }
+    }
+    got = block_sum_int(got);
+    if (threadIdx.x == 0 && got) atomicAdd(&s.lab_count, got);
+}
+
+// bookkeeping of the last round.  grid (B), block 1
+__global__ void k_seg_final(SegState *__restrict__ st, int rounds)
+{
+    seg_close_round(st[blockIdx.x], rounds);
+}
+
+constexpr int PTR_ARGS = 32;
+struct PtrArgs { const float4 *p[PTR_ARGS]; };
+__global__ void k_set_ptrs(const float4 **__restrict__ dst, PtrArgs a, int n)
+{
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = a.p[threadIdx.x];
+}
+
+}  // namespace s3d

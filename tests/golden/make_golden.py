@@ -6,6 +6,8 @@
   reference_golden.json   DERIVED outputs only (hashes, poses, counts) of the oracle run on the
                           reference's real fixtures data/exp1/dep/{1,2}.png and bin/dep_1.png, read from
                           /root/reference.  No reference data or source is copied (GPLv3).
+  segmentation_golden.json  f-2 plane segmentation (oracle/seg_oracle.c) on synthetic frames + derived outputs on
+                          the reference's data/exp1/dep/1.png
 Floats are stored as C99 hex strings (bit-exact round trip).
 """
 import hashlib
@@ -101,6 +103,35 @@ def reference():
     json.dump(out, open(os.path.join(HERE, "reference_golden.json"), "w"), indent=1)
 
 
+def seg_summary(planes, labels):
+    return dict(nplanes=len(planes), labels_sha256=sha(labels), unassigned=int((labels == -1).sum()),
+                invalid=int((labels == -2).sum()),
+                planes=[dict(coeff=[float(x).hex() for x in p["coeff"]], centroid=[float(x).hex() for x in p["centroid"]],
+                             count=p["count"]) for p in planes])
+
+
+def segmentation():
+    """f-2 plane segmentation: oracle/seg_oracle.c on synthetic frames and (derived outputs only) on the
+    reference's data/exp1/dep/1.png."""
+    out = dict(generator="tests/golden/make_golden.py segmentation", cases=[])
+    for (w, h, seed) in ((160, 120, 1000), (320, 240, 1001), (640, 480, 1000), (640, 480, 1002)):
+        pr = synth.make_pair(seed, w, h)
+        s4 = synth.backproject_numpy(pr.depth_src, pr.intr)
+        planes, labels = O.segment_planes(s4, seed=seed)
+        c = dict(seed=seed, width=w, height=h, depth_sha256=pr.sha256())
+        c.update(seg_summary(planes, labels))
+        out["cases"].append(c)
+        print("seg", w, h, seed, [p["count"] for p in planes])
+    if os.path.isdir(REF):
+        d1 = read_png16(os.path.join(REF, "data/exp1/dep/1.png"))
+        c1 = O.backproject(d1, O.params(synth.Intrinsics()))
+        planes, labels = O.segment_planes(c1, seed=1)
+        out["reference_dep1"] = seg_summary(planes, labels)
+        print("seg reference dep1", [(p["count"], p["coeff"]) for p in planes])
+    json.dump(out, open(os.path.join(HERE, "segmentation_golden.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    synthetic()
-    reference()
+    which = sys.argv[1:] or ["synthetic", "reference", "segmentation"]
+    for w in which:
+        {"synthetic": synthetic, "reference": reference, "segmentation": segmentation}[w]()

@@ -127,6 +127,24 @@ def fit_planes(xyz4, labels, nplanes: int):
     return planes, counts
 
 
+class SegParams(C.Structure):
+    _fields_ = [("distance_threshold", C.c_float), ("plane_percent", C.c_float), ("max_planes", C.c_int32),
+                ("hypotheses", C.c_int32), ("seed", C.c_uint64)]
+
+
+def segment_planes(xyz4, zmax=7.0, distance_threshold=0.08, plane_percent=0.2, max_planes=3, hypotheses=64, seed=1):
+    """-> (planes[nplanes] dicts(coeff, centroid, count), labels[N])"""
+    xyz4 = np.ascontiguousarray(xyz4, dtype=np.float32).reshape(-1, 4)
+    n = xyz4.shape[0]
+    sp = SegParams(distance_threshold, plane_percent, max_planes, hypotheses, seed)
+    planes = np.zeros((max_planes, 8), dtype=np.float32)
+    labels = np.zeros(n, dtype=np.int32)
+    f = lib().orc_segment_planes
+    f.restype = C.c_int
+    k = f(_fp(xyz4, C.c_float), C.c_int(n), C.c_float(zmax), C.byref(sp), _fp(planes, C.c_float), _fp(labels, C.c_int32))
+    return [dict(coeff=planes[i, :4].copy(), centroid=planes[i, 4:7].copy(), count=int(planes[i, 7])) for i in range(k)], labels
+
+
 def pose_error(Tref, T):
     Tref = np.ascontiguousarray(Tref, dtype=np.float64).reshape(16)
     T = np.ascontiguousarray(T, dtype=np.float64).reshape(16)

@@ -298,3 +298,43 @@ def test_profiling_is_opt_in_and_does_not_change_results(gpu_lib):
         assert ms.shape == (6,) and (ms > 0).all()
         assert h.get_timings()["nn_ms"] > 0.0
     assert np.array_equal(r0["T"], r1["T"]) and r0["inliers"] == r1["inliers"]
+
+
+@pytest.mark.parametrize("size,seed", [((160, 120), 3), ((320, 240), 1), ((640, 480), 7)])
+def test_plane_segmentation_matches_oracle_bit_for_bit(gpu_lib, size, seed):
+    """f-2: batched RANSAC plane segmentation.  Integer consensus counts, integer fixed-point moments and the
+    spec's Jacobi solve leave no room for rounding differences: labels, coefficients, centroids and counts
+    are identical to oracle/seg_oracle.c."""
+    pr, s4, _ = _pair(1000 + seed, *size)
+    po, lo = O.segment_planes(s4, seed=seed)
+    with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1)) as h:
+        pg, lg = h.segment_planes(s4, h.seg_params(seed=seed))
+    assert len(pg) == len(po) and len(po) >= 2
+    assert np.array_equal(lg, lo)
+    for a, b in zip(pg, po):
+        assert a["count"] == b["count"]
+        assert np.array_equal(a["coeff"], b["coeff"]) and np.array_equal(a["centroid"], b["centroid"])
+        assert a["coeff"][3] >= 0 and abs(np.linalg.norm(a["coeff"][:3]) - 1) < 1e-6     # src/GraphicEnd.cpp:383-387
+
+
+def test_plane_segmentation_batch_on_device_and_edge_cases(gpu_lib):
+    import torch
+    pr, s4, t4 = _pair(1003, 320, 240)
+    N = 320 * 240
+    empty = np.full((N, 4), np.nan, dtype=np.float32)                      # no valid point: zero planes
+    few = empty.copy(); few[:2] = [[0, 0, 1, 1], [0.1, 0, 1, 1]]          # two points: no plane possible
+    clouds = [np.ascontiguousarray(c, dtype=np.float32).reshape(N, 4) for c in (s4, t4, empty, few)]
+    d = torch.from_numpy(np.stack(clouds)).to("cuda:0")
+    d_lab = torch.zeros((4, N), dtype=torch.int32, device="cuda:0")
+    with capi.IcpHandle(capi.default_params(pr.intr, max_batch=4)) as h:
+        sp = h.seg_params(seed=11, max_planes=4, hypotheses=48)
+        out = h.segment_planes_device([d.data_ptr() + i * N * 16 for i in range(4)], sp, d_lab.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream)
+    lab = d_lab.cpu().numpy()
+    for i, c in enumerate(clouds):
+        po, lo = O.segment_planes(c, seed=11, max_planes=4, hypotheses=48)
+        assert len(out[i]) == len(po)
+        assert np.array_equal(lab[i], lo)
+        for a, b in zip(out[i], po):
+            assert a["count"] == b["count"] and np.array_equal(a["coeff"], b["coeff"])
+    assert len(out[2]) == 0 and len(out[3]) == 0 and (lab[2] == -2).all() and (lab[3][:2] == -1).all()
