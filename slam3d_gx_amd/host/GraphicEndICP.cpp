@@ -50,6 +50,7 @@ GraphicEndICP::GraphicEndICP()
 {
     mat4_identity(_robot);
     mat4_identity(_kf_pos);
+    mat4_identity(_graph_pose);
     slam3d_icp_default_params(&_params);
 }
 
@@ -75,6 +76,15 @@ void GraphicEndICP::init(const string &param_file)
     _lost_frames = _reader->GetInt("lost_frames", 10);
     _loop_closure_error = _reader->GetDouble("loop_closure_error", 1.5);
     _loop_closure_inliers = _reader->GetInt("loop_closure_inliers", 30);
+    _loop_closure_detection = _reader->Has("loop_closure_detection") && _reader->GetPara("loop_closure_detection") == "yes";
+    _loopclosure_frames = _reader->GetInt("loopclosure_frames", 30);
+    _lc_state = (unsigned long long)_reader->GetInt("loopclosure_seed", 1);
+    _extract_planes = _reader->Has("icp_extract_planes") && _reader->GetPara("icp_extract_planes") == "yes";
+    slam3d_seg_default_params(&_seg);
+    _seg.distance_threshold = (float)_reader->GetDouble("distance_threshold", 0.08);   // src/GraphicEnd.cpp:89
+    _seg.plane_percent = (float)_reader->GetDouble("plane_percent", 0.2);              // :93
+    _seg.max_planes = _reader->GetInt("max_planes", 3);                                // :95
+    _seg.hypotheses = _reader->GetInt("ransac_hypotheses", 64);
     if (_reader->Has("detector_name") && _reader->GetPara("detector_name") != "ICP")
         cout << "note: detector_name/descriptor_name are ignored by the ICP front end" << endl;
 
@@ -92,7 +102,8 @@ void GraphicEndICP::init(const string &param_file)
     _params.normal_window = _reader->GetInt("icp_normal_window", 7);
     _params.min_inliers = _reader->GetInt("icp_min_inliers", 12);
     _params.error_threshold = _error_threshold;
-    _max_batch = _reader->GetInt("loopclosure_frames", 30);
+    _max_batch = _loopclosure_frames + 2;              // random candidates + the two adjacent keyframes, one launch
+    if (_max_batch < 1) _max_batch = 1;
     _params.max_batch = _max_batch;
     _params.device = _reader->GetInt("hip_device", 0);
     const int rc = slam3d_icp_create(&_params, &_icp);
@@ -102,6 +113,8 @@ void GraphicEndICP::init(const string &param_file)
     }
     _errorfile.open("./data/error_of_transform.log");              // src/GraphicEnd.cpp:153
     _trajfile.open("./data/trajectory_icp.txt");
+    _lcfile.open("./data/lc.txt");                                 // displayLC, src/GraphicEnd.cpp:843
+    if (_extract_planes) _planefile.open("./data/planes.txt");
 
     // first frame = keyframe 0 at the origin (src/GraphicEnd.cpp:106-145)
     readimage();
@@ -110,9 +123,25 @@ void GraphicEndICP::init(const string &param_file)
     _currKF.frame_index = _index;
     _keyframes.push_back(_currKF);
     _kf_poses.push_back(vector<double>(_kf_pos, _kf_pos + 16));
+    _graph.addVertex(0, _kf_pos, true);                            // the first vertex is fixed (src/SLAMEnd: setFixed(true))
     _last = _present;
     writeTrajectoryLine(_index, _robot);
     _index++;
+}
+
+vector<slam3d_plane> GraphicEndICP::extractPlanes(const FRAME &frame)
+{
+    // depth -> organized cloud on the GPU -> batched RANSAC segmentation (both behind the C-ABI)
+    vector<float> xyz((size_t)_params.width * _params.height * 4);
+    vector<slam3d_plane> planes(_seg.max_planes), out;
+    if (slam3d_backproject_u16(_icp, frame.depth.data(), xyz.data()) != SLAM3D_OK) return out;
+    slam3d_cloud_view v = { xyz.data(), 16, _params.width, _params.height };
+    int n = 0;
+    _seg.seed = (uint64_t)frame.frame_index + 1;
+    if (slam3d_segment_planes(_icp, &v, &_seg, planes.data(), &n, nullptr) != SLAM3D_OK) return out;
+    out.assign(planes.begin(), planes.begin() + n);
+    cout << "Total planes: " << n << endl;                         // src/GraphicEnd.cpp:428
+    return out;
 }
 
 int GraphicEndICP::readimage()
@@ -130,6 +159,17 @@ int GraphicEndICP::readimage()
         return -1;
     }
     _present.frame_index = _index;
+    _present.connect.clear();
+    _present.planes.clear();
+    if (_extract_planes) {
+        _present.planes = extractPlanes(_present);
+        _planefile << _index << " " << _present.planes.size();
+        for (size_t k = 0; k < _present.planes.size(); ++k) {
+            const slam3d_plane &p = _present.planes[k];
+            _planefile << " " << p.coeff[0] << " " << p.coeff[1] << " " << p.coeff[2] << " " << p.coeff[3] << " " << p.count;
+        }
+        _planefile << endl;
+    }
     cout << "load ok." << endl;
     return 0;
 }
@@ -181,6 +221,131 @@ void GraphicEndICP::generateKeyFrame(const double *T)
     memcpy(_kf_pos, P, sizeof P);
     _keyframes.push_back(_currKF);
     _kf_poses.push_back(vector<double>(_kf_pos, _kf_pos + 16));
+    // VertexSE3 + EdgeSE3(previous keyframe -> this one, measurement T, information 100) (:319-338).  The
+    // reference starts every vertex at Identity (:325); here the initial estimate is the chain of the edge
+    // measurements (V_new = V_prev * T, the EdgeSE3 convention), so the file is consistent before optimisation.
+    mat4_mul(_graph_pose, T, _graph_pose);
+    _graph.addVertex(_currKF.id, _graph_pose);
+    _graph.addEdge(_currKF.id - 1, _currKF.id, T, 100.0);
+}
+
+bool GraphicEndICP::acceptLoop(const RESULT_OF_MULTIPNP &r) const
+{
+    return !r.isIdentity() && r.norm <= _loop_closure_error && r.inliers >= _loop_closure_inliers;
+}
+
+void GraphicEndICP::loopClosure()
+{
+    if (_keyframes.size() <= 3) return;                            // :687
+    cout << "Checking loop closure." << endl;
+    // candidates: the two adjacent keyframes (:694-722) and up to loopclosure_frames distinct random earlier
+    // ones (:725-761).  They are independent pairs against the current keyframe: ONE batched launch.
+    vector<int> cand;
+    for (int i = -3; i > -5; i--) {
+        const int n = (int)_keyframes.size() + i;
+        if (n >= 0) cand.push_back(n);
+    }
+    const size_t n_adjacent = cand.size();
+    vector<int> checked;
+    for (int i = 0; i < _loopclosure_frames; i++) {
+        _lc_state += 0x9E3779B97F4A7C15ull;
+        unsigned long long z = _lc_state;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+        const int frame = (int)(z % (unsigned long long)(_keyframes.size() - 3));
+        bool seen = false;
+        for (size_t k = 0; k < checked.size(); ++k) seen = seen || checked[k] == frame;
+        if (seen) continue;                                        // :728
+        checked.push_back(frame);
+        cand.push_back(frame);
+    }
+    vector<const FRAME *> f1(cand.size()), f2(cand.size(), &_currKF);
+    for (size_t k = 0; k < cand.size(); ++k) f1[k] = &_keyframes[cand[k]];
+    vector<RESULT_OF_MULTIPNP> res = multiPnPBatch(f1, f2, _loop_closure_inliers);
+    for (size_t k = 0; k < cand.size(); ++k) {
+        if (!acceptLoop(res[k])) continue;
+        double Ti[16];
+        mat4_inverse_rigid(res[k].T, Ti);                          // :707
+        _graph.addEdge(_keyframes[cand[k]].id, _currKF.id, Ti, 100.0, true);
+        if (k >= n_adjacent) {
+            _lcfile << _keyframes[cand[k]].frame_index << " " << _currKF.frame_index << " " << res[k].norm << " "
+                    << res[k].inliers << endl;                     // displayLC :865
+            _keyframes.back().connect.push_back(cand[k]);          // :760
+        }
+    }
+}
+
+void GraphicEndICP::lostRecovery()
+{
+    // the present frame becomes a keyframe with no edge to its predecessor (:764-838)
+    cout << "Lost Recovery..." << endl;
+    _currKF = _present;
+    _currKF.id = (int)_keyframes.size();
+    _currKF.frame_index = _index;
+    memcpy(_kf_pos, _robot, sizeof _kf_pos);                       // :772
+    ofstream fout("./data/lost.txt", ofstream::app);
+    fout << _currKF.id << " " << _currKF.frame_index << endl;      // :774-776
+    fout.close();
+    _keyframes.push_back(_currKF);
+    _kf_poses.push_back(vector<double>(_kf_pos, _kf_pos + 16));
+    _graph.addVertex(_currKF.id, _graph_pose);                     // no edge to the predecessor: position unknown (:793)
+    // against every earlier keyframe (:808-836): independent pairs, batched
+    const int n = (int)_keyframes.size() - 1;
+    vector<const FRAME *> f1(n), f2(n, &_currKF);
+    for (int i = 0; i < n; ++i) f1[i] = &_keyframes[i];
+    vector<RESULT_OF_MULTIPNP> res = multiPnPBatch(f1, f2);
+    for (int i = 0; i < n; ++i) {
+        if (!acceptLoop(res[i])) continue;
+        double Ti[16];
+        mat4_inverse_rigid(res[i].T, Ti);
+        _graph.addEdge(_keyframes[i].id, _currKF.id, Ti, 100.0, true);
+        _keyframes.back().connect.push_back(i);
+    }
+    _lost = 0;
+}
+
+bool GraphicEndICP::check(int frame1, int frame2)
+{
+    cout << "checking " << frame1 << ", " << frame2 << endl;
+    RESULT_OF_MULTIPNP result = multiPnP(_keyframes[frame1], _keyframes[frame2], true, _keyframes[frame1].frame_index,
+                                         _loop_closure_inliers);
+    if (!acceptLoop(result)) return false;
+    double Ti[16];
+    mat4_inverse_rigid(result.T, Ti);
+    _graph.addEdge(_keyframes[frame1].id, _keyframes[frame2].id, Ti, 100.0, true);
+    _moreLoops++;
+    return true;
+}
+
+vector<int> GraphicEndICP::checknearby(int source, int target)
+{
+    vector<int> checked;
+    int index = target;
+    while (index > 0) {                                            // walk down until a pair fails (:925-934)
+        index--;
+        if (index == source) continue;
+        if (check(source, index)) checked.push_back(index); else break;
+    }
+    index = target;
+    while (index < (int)_keyframes.size() - 1) {                   // walk up (:936-945)
+        index++;
+        if (index == source) continue;
+        if (check(source, index)) checked.push_back(index); else break;
+    }
+    return checked;
+}
+
+void GraphicEndICP::findMoreLoops()
+{
+    cout << "Find more loops" << endl;
+    _moreLoops = 0;
+    for (size_t i = 0; i < _keyframes.size(); i++) {
+        if (_keyframes[i].connect.empty()) continue;
+        for (size_t j = 0; j < _keyframes[i].connect.size(); j++) {
+            vector<int> checked = checknearby((int)i, _keyframes[i].connect[j]);
+            for (size_t k = 0; k < checked.size(); k++) checknearby(checked[k], (int)i);
+        }
+    }
+    cout << "Total " << _moreLoops << " loops found. " << endl;
 }
 
 int GraphicEndICP::run()
@@ -217,6 +382,7 @@ int GraphicEndICP::run()
         _errorfile << result.norm << endl;                          // :232
         mat4_mul(T, _kf_pos, _robot);
         generateKeyFrame(T);
+        if (_loop_closure_detection) loopClosure();                // :236-237
         _lost = 0;
         _last = _present;
     } else {
@@ -225,7 +391,11 @@ int GraphicEndICP::run()
         _lost = 0;
         _last = _present;
     }
-    if (_lost > _lost_frames) cerr << "the robot lost. (lost recovery is out of scope of the ICP path)" << endl;
+    if (_lost > _lost_frames) {                                     // :250-255
+        cerr << "the robot lost. Perform lost recovery." << endl;
+        lostRecovery();
+        _last = _present;
+    }
     writeTrajectoryLine(_index, _robot);
     _index++;
     _present.frame_index = _index;
@@ -235,17 +405,8 @@ int GraphicEndICP::run()
 void GraphicEndICP::writeTrajectoryLine(int frame_index, const double *T)
 {
     // TUM trajectory line "timestamp tx ty tz qx qy qz qw" (src/generateTrajectory.cpp:62-72)
-    const double tr = T[0] + T[5] + T[10];
     double qw, qx, qy, qz;
-    if (tr > 0) {
-        const double s = sqrt(tr + 1.0) * 2; qw = 0.25 * s; qx = (T[9] - T[6]) / s; qy = (T[2] - T[8]) / s; qz = (T[4] - T[1]) / s;
-    } else if (T[0] > T[5] && T[0] > T[10]) {
-        const double s = sqrt(1.0 + T[0] - T[5] - T[10]) * 2; qw = (T[9] - T[6]) / s; qx = 0.25 * s; qy = (T[1] + T[4]) / s; qz = (T[2] + T[8]) / s;
-    } else if (T[5] > T[10]) {
-        const double s = sqrt(1.0 + T[5] - T[0] - T[10]) * 2; qw = (T[2] - T[8]) / s; qx = (T[1] + T[4]) / s; qy = 0.25 * s; qz = (T[6] + T[9]) / s;
-    } else {
-        const double s = sqrt(1.0 + T[10] - T[0] - T[5]) * 2; qw = (T[4] - T[1]) / s; qx = (T[2] + T[8]) / s; qy = (T[6] + T[9]) / s; qz = 0.25 * s;
-    }
+    rot_to_quat(T, qx, qy, qz, qw);
     char buf[256];
     snprintf(buf, sizeof buf, "%d %.9f %.9f %.9f %.9f %.9f %.9f %.9f", frame_index, T[3], T[7], T[11], qx, qy, qz, qw);
     _trajfile << buf << endl;
@@ -253,6 +414,10 @@ void GraphicEndICP::writeTrajectoryLine(int frame_index, const double *T)
 
 void GraphicEndICP::saveFinalResult(const string &fileaddr)
 {
+    // closing loops around the accepted ones, then the graph hand-off (the reference optimises here and saves
+    // final_after.g2o, :664-680; the optimiser is g2o's, out of scope, so the un-optimised graph is written)
+    if (_loop_closure_detection) findMoreLoops();
+    _graph.save("./data/final.g2o");
     // keyframe.txt: "id frame_index" (src/GraphicEnd.cpp:673-681)
     ofstream fout(fileaddr.c_str());
     for (size_t i = 0; i < _keyframes.size(); ++i) fout << _keyframes[i].id << " " << _keyframes[i].frame_index << endl;

@@ -16,6 +16,7 @@
 
 #include "../../include/slam3d_icp.h"
 #include "ParameterReader.h"
+#include "PoseGraph.h"
 
 // RESULT_OF_MULTIPNP {T, norm, inliers} (src/GraphicEnd.h:59-69); T row-major instead of Eigen::Isometry3d
 struct RESULT_OF_MULTIPNP {
@@ -30,6 +31,8 @@ struct FRAME {                        // stands in for KEYFRAME / vector<PLANE> 
     int id = 0;
     int frame_index = 0;
     std::vector<uint16_t> depth;      // organized 16-bit depth, width*height
+    std::vector<slam3d_plane> planes; // PLANE::coff of src/GraphicEnd.h:43 (filled when icp_extract_planes: yes)
+    std::vector<int> connect;         // loop-closure partners, KEYFRAME::connect (src/GraphicEnd.cpp:760)
 };
 
 void mat4_identity(double *T);
@@ -46,6 +49,13 @@ class GraphicEndICP {
     virtual int readimage();                                                   // src/GraphicEnd.cpp:266-302
     virtual void generateKeyFrame(const double *T);                            // src/GraphicEnd.cpp:304-351
     virtual void saveFinalResult(const std::string &fileaddr);                 // src/GraphicEnd.cpp:661-682
+    virtual void loopClosure();                                                // src/GraphicEnd.cpp:685-762
+    virtual void lostRecovery();                                               // src/GraphicEnd.cpp:764-838
+    virtual void findMoreLoops();                                              // src/GraphicEnd.cpp:868-890
+    virtual bool check(int frame1, int frame2);                                // src/GraphicEnd.cpp:892-917
+    virtual std::vector<int> checknearby(int source, int target);              // src/GraphicEnd.cpp:919-947
+    // plane list of a frame: the SACSegmentation loop of extractPlanesAndGenerateImage (src/GraphicEnd.cpp:353-430)
+    virtual std::vector<slam3d_plane> extractPlanes(const FRAME &frame);
     // same call shape and defaults as GraphicEnd::multiPnP (src/GraphicEnd.h:134)
     virtual RESULT_OF_MULTIPNP multiPnP(FRAME &frame1, FRAME &frame2, bool loopclosure = false, int frame_index = 0,
                                         int minimum_inliers = 12);
@@ -57,6 +67,8 @@ class GraphicEndICP {
     const double *robot() const { return _robot; }
     const std::vector<FRAME> &keyframes() const { return _keyframes; }
     int lostCount() const { return _lost; }
+    const PoseGraph &graph() const { return _graph; }
+    int moreLoops() const { return _moreLoops; }
 
  protected:
     ParameterReader *_reader = nullptr;
@@ -70,6 +82,14 @@ class GraphicEndICP {
     FRAME _present, _currKF, _last;
     std::vector<FRAME> _keyframes;
     std::vector<std::vector<double> > _kf_poses;     // keyframe poses (row-major 4x4), what the reference keeps in g2o
-    double _robot[16], _kf_pos[16];
+    double _robot[16], _kf_pos[16], _graph_pose[16];
     void writeTrajectoryLine(int frame_index, const double *T);
+    // accept test shared by loopClosure / lostRecovery / check (:701-706): not Identity, norm, inliers
+    bool acceptLoop(const RESULT_OF_MULTIPNP &r) const;
+    PoseGraph _graph;
+    bool _loop_closure_detection = false, _extract_planes = false;
+    int _loopclosure_frames = 30, _moreLoops = 0;
+    unsigned long long _lc_state = 1;                 // counter-based PRNG replacing rand() (src/GraphicEnd.cpp:69,725)
+    slam3d_seg_params _seg;
+    std::ofstream _lcfile, _planefile;
 };

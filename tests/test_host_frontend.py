@@ -25,7 +25,7 @@ error_threshold: 1.0
 distance_threshold: 0.08
 plane_percent: 0.2
 max_planes: 3
-loop_closure_detection: no
+loop_closure_detection: {lc}
 loopclosure_frames: 4
 loop_closure_error: 1.5
 loop_closure_inliers: 30
@@ -39,6 +39,7 @@ camera_factor: 1000.0
 image_width: {w}
 image_height: {h}
 icp_iterations: 15
+icp_extract_planes: {planes}
 """
 
 
@@ -59,7 +60,7 @@ def test_png_and_parameter_readers(tmp_path):
     png = tmp_path / "d.png"
     _write_png16(str(png), pr.depth_src)
     yml = tmp_path / "parameters.yaml"
-    yml.write_text(PARAMS.format(src="/data/x", mpc=0.25, fx=517.0, fy=517.0, cx=318.6, cy=255.3, w=320, h=240))
+    yml.write_text(PARAMS.format(src="/data/x", mpc=0.25, fx=517.0, fy=517.0, cx=318.6, cy=255.3, w=320, h=240, lc="no", planes="no"))
     out = subprocess.run([os.path.join(HOST, "host_selftest"), str(png), str(yml)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().splitlines()
@@ -90,7 +91,7 @@ def test_run_slam_driver_tracks_synthetic_sequence(gpu_lib, tmp_path):
         d = synth.render_depth(P, intr, 4242, 10 + k, hole_block=hb)
         _write_png16(str(data / "dep_index" / f"{k + 1}.png"), d)
     (tmp_path / "parameters.yaml").write_text(
-        PARAMS.format(src=str(data), mpc=10.0, fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=W, h=H))
+        PARAMS.format(src=str(data), mpc=10.0, fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=W, h=H, lc="no", planes="no"))
     out = subprocess.run([os.path.join(HOST, "run_SLAM"), "4"], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     norms = [float(x) for x in (tmp_path / "data" / "error_of_transform.log").read_text().split()]
@@ -101,3 +102,75 @@ def test_run_slam_driver_tracks_synthetic_sequence(gpu_lib, tmp_path):
         cam_to_world = np.linalg.inv(poses[k])          # robot = T^-1 * kf_pos with kf_pos = I (src/GraphicEnd.cpp:169-170,245)
         assert np.abs(traj[k, 1:4] - cam_to_world[:3, 3]).max() < 3e-2   # quarter-resolution ICP accuracy, not a parity bar
     assert (tmp_path / "data" / "keyframe.txt").read_text().split() == ["0", "1"]
+
+
+def _quat_to_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _se3(v):
+    T = np.eye(4)
+    T[:3, 3] = v[:3]
+    T[:3, :3] = _quat_to_R(v[3:7])
+    return T
+
+
+@pytest.mark.gpu
+def test_run_slam_keyframes_loop_closure_and_g2o_handoff(gpu_lib, tmp_path):
+    """Rows f-3 / f-4: a there-and-back synthetic sequence with a small max_pos_change makes every frame a keyframe
+    (src/GraphicEnd.cpp:230-240); loopClosure (:685-762) aligns the new keyframe against the adjacent and the
+    random earlier keyframes in ONE batched launch and adds EdgeSE3s; saveFinalResult writes the graph in g2o
+    text format (:661-682) and keyframe.txt; planes.txt holds the per-frame plane list (:353-430)."""
+    _build_host()
+    W, H = 320, 240
+    intr = synth.Intrinsics.scaled(W, H)
+    step = synth.pose_from_seed(4242, max_angle_deg=1.0, max_trans=0.02)
+    data = tmp_path / "ds"
+    (data / "dep_index").mkdir(parents=True)
+    (tmp_path / "data").mkdir()
+    out_poses = [np.eye(4)]
+    for k in range(4):
+        out_poses.append(step @ out_poses[-1])
+    poses = out_poses + out_poses[-2::-1]                      # 0 1 2 3 4 3 2 1 0
+    hb = max(2, int(round(32 * W / 640.0)))
+    for k, P in enumerate(poses):
+        _write_png16(str(data / "dep_index" / f"{k + 1}.png"), synth.render_depth(P, intr, 4242, 10 + k, hole_block=hb))
+    (tmp_path / "parameters.yaml").write_text(
+        PARAMS.format(src=str(data), mpc=0.005, fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=W, h=H, lc="yes", planes="yes"))
+    out = subprocess.run([os.path.join(HOST, "run_SLAM"), str(len(poses) - 1)], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    kf = np.loadtxt(str(tmp_path / "data" / "keyframe.txt"), dtype=int)
+    assert kf.shape == (len(poses), 2) and list(kf[:, 0]) == list(range(len(poses)))       # every frame a keyframe
+    V, E, fixed = {}, [], []
+    for line in (tmp_path / "data" / "final.g2o").read_text().splitlines():
+        t = line.split()
+        if t[0] == "VERTEX_SE3:QUAT":
+            V[int(t[1])] = _se3([float(x) for x in t[2:9]])
+        elif t[0] == "EDGE_SE3:QUAT":
+            assert len(t) == 3 + 7 + 21
+            info = [float(x) for x in t[10:]]
+            assert info == [100, 0, 0, 0, 0, 0, 100, 0, 0, 0, 0, 100, 0, 0, 0, 100, 0, 0, 100, 0, 100]   # :330-334
+            E.append((int(t[1]), int(t[2]), _se3([float(x) for x in t[3:10]])))
+        elif t[0] == "FIX":
+            fixed.append(int(t[1]))
+    assert sorted(V) == list(range(len(poses))) and fixed == [0]
+    odo = [(a, b) for a, b, _ in E if b == a + 1]
+    loops = [(a, b) for a, b, _ in E if b != a + 1]
+    assert len(set(odo)) == len(poses) - 1 and len(loops) >= 4                               # chain + closures
+    for a, b, M in E:                                        # every edge agrees with the vertex estimates
+        err = np.linalg.inv(M) @ np.linalg.inv(V[a]) @ V[b]
+        ang = np.arccos(np.clip((np.trace(err[:3, :3]) - 1) / 2, -1, 1))
+        assert ang < 0.03 and np.linalg.norm(err[:3, 3]) < 0.06, (a, b, ang, err[:3, 3])
+    # the camera came back: last vertex close to the first
+    assert np.linalg.norm(V[len(poses) - 1][:3, 3]) < 0.06
+    lc = (tmp_path / "data" / "lc.txt").read_text().split()
+    assert len(lc) % 4 == 0
+    planes = (tmp_path / "data" / "planes.txt").read_text().strip().splitlines()
+    assert len(planes) == len(poses)
+    for ln in planes:
+        t = ln.split()
+        n = int(t[1])
+        assert 2 <= n <= 3 and len(t) == 2 + 5 * n and all(float(t[2 + 5 * k + 3]) >= 0 for k in range(n))   # d >= 0 (:383-387)
