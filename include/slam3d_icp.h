@@ -171,6 +171,15 @@ int slam3d_backproject_u16(slam3d_icp_handle *h, const uint16_t *depth, float *x
 int slam3d_fit_planes(slam3d_icp_handle *h, const slam3d_cloud_view *cloud, const int32_t *labels,
                       int32_t nplanes, slam3d_plane *planes);
 
+/* ---- frame ingestion filters of GraphicEnd::readimage (src/GraphicEnd.cpp:283-295): pcl::PassThrough on
+ * z in [0, z_filter] followed by pcl::VoxelGrid with a cubic leaf (grid_leaf, 0.03), on n 16-byte records
+ * {float x, y, z; uint32 rgba} -- the layout of the reference's binary PCD files (data/exp1/pcd/1.pcd header).
+ * One output record per occupied voxel (centroid of all fields), ordered by voxel index (iz, iy, ix) like PCL.
+ * n <= width*height of the handle; out has room for n records. */
+int slam3d_voxel_grid(slam3d_icp_handle *h, const void *points16, int32_t n, float leaf, void *out16, int32_t *n_out);
+int slam3d_voxel_grid_device(slam3d_icp_handle *h, const void *d_points16, int32_t n, float leaf, void *d_out16,
+                             int32_t *n_out, void *stream);
+
 /* ---- plane segmentation (replaces the pcl::SACSegmentation loop of extractPlanesAndGenerateImage,
  * src/GraphicEnd.cpp:353-430): up to max_planes rounds of seeded RANSAC + least-squares refinement while more
  * than plane_percent of the valid points are unassigned (:372); planes in extraction order, unit normal, d >= 0

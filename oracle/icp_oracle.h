@@ -105,6 +105,11 @@ typedef struct {
 int orc_segment_planes(const float *xyz4, int n, float zmax, const orc_seg_params *sp, float *planes,
                        int32_t *labels);
 
+/* frame ingestion filters (row f-1, voxel_oracle.c): PassThrough z in [0,zmax] + VoxelGrid(leaf) on n records
+ * {x,y,z,rgba bits}; out has room for n records; returns the number of voxels (ascending (iz,iy,ix)) */
+int orc_voxel_grid(const float *pts, int n, float leaf, float zmax, float *out);
+uint64_t orc_voxel_key(float x, float y, float z, float inv_leaf);
+
 /* pose error metric a14: E = Tref^-1 * T ; trans = ||E_t||, rot = acos(clamp((tr-1)/2)) */
 void orc_pose_error(const double *Tref, const double *T, double *rot_err, double *trans_err);
 

@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "slam3d_icp_set_clouds_device", "slam3d_icp_set_depth_device", "slam3d_icp_run",
     "slam3d_icp_fetch_results", "slam3d_icp_get_correspondences", "slam3d_icp_get_trace",
     "slam3d_icp_get_clouds", "slam3d_icp_set_profiling", "slam3d_icp_get_timings", "slam3d_icp_get_iteration_timings", "slam3d_icp_get_nn_debug", "slam3d_backproject_u16", "slam3d_fit_planes",
-    "slam3d_seg_default_params", "slam3d_segment_planes", "slam3d_segment_planes_device",
+    "slam3d_voxel_grid", "slam3d_voxel_grid_device", "slam3d_seg_default_params", "slam3d_segment_planes", "slam3d_segment_planes_device",
     "slam3d_icp_dense_set_rows", "slam3d_icp_dense_begin", "slam3d_icp_dense_partial",
     "slam3d_icp_dense_update", "slam3d_icp_dense_finish",
     "slam3d_icp_dense_partial_device", "slam3d_icp_dense_update_device", "slam3d_icp_dense_finish_device",
@@ -270,6 +270,20 @@ class IcpHandle:
         planes = (Plane * nplanes)()
         self._check(self.lib.slam3d_fit_planes(self._h, C.byref(cv), _vp(lab), C.c_int32(nplanes), planes), False)
         return [dict(coeff=np.array(p.coeff), count=p.count, centroid=np.array(p.centroid)) for p in planes]
+
+    # ---- frame ingestion filters (f-1) ------------------------------------------------------
+    def voxel_grid(self, pts16: np.ndarray, leaf: float = 0.03) -> np.ndarray:
+        pts = np.ascontiguousarray(pts16, dtype=np.float32).reshape(-1, 4)
+        out = np.zeros_like(pts)
+        m = C.c_int32(0)
+        self._check(self.lib.slam3d_voxel_grid(self._h, _vp(pts), C.c_int32(pts.shape[0]), C.c_float(leaf), _vp(out), C.byref(m)), False)
+        return out[: m.value].copy()
+
+    def voxel_grid_device(self, d_pts: int, n: int, d_out: int, leaf: float = 0.03, stream: int = 0) -> int:
+        m = C.c_int32(0)
+        self._check(self.lib.slam3d_voxel_grid_device(self._h, C.c_void_p(d_pts), C.c_int32(n), C.c_float(leaf), C.c_void_p(d_out),
+                                                      C.byref(m), C.c_void_p(stream)), False)
+        return m.value
 
     # ---- plane segmentation (f-2) ---------------------------------------------------------
     @staticmethod

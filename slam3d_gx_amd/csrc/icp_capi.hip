@@ -6,6 +6,7 @@
 #include "../../include/slam3d_icp.h"
 #include "icp_kernels.hpp"
 #include "plane_seg.hpp"
+#include "voxel.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -38,6 +39,13 @@ struct slam3d_icp_handle {
     SegState *seg_state = nullptr, *pin_seg = nullptr;
     int *seg_labels = nullptr;
     const float4 **seg_ptrs = nullptr;
+    // voxel grid (f-1): allocated on first use
+    unsigned char *vox_mem = nullptr;
+    VoxTable vox;
+    unsigned long long *vox_lkey = nullptr, *vox_gkey = nullptr;
+    int *vox_lslot = nullptr, *vox_gslot = nullptr, *vox_m = nullptr, *vox_hist = nullptr;   // hist | start | cursor
+    float4 *vox_out = nullptr;
+    int *pin_vox_m = nullptr;
     // 8x8-pixel tiles (slot order of the sums; target tiles + boxes for the pruned NN)
     TileGrid tg;
     float4 *srcT = nullptr, *tgtT = nullptr, *tbox = nullptr, *cbox = nullptr, *prevq = nullptr;
@@ -128,6 +136,8 @@ static void free_all(slam3d_icp_handle *h)
     if (h->pin_res) (void)hipHostFree(h->pin_res);
     if (h->pin_seg) (void)hipHostFree(h->pin_seg);
     F(h->seg_state); F(h->seg_labels); F(h->seg_ptrs);
+    F(h->vox_mem); F(h->vox_lkey); F(h->vox_lslot); F(h->vox_m); F(h->vox_out); F(h->vox_gkey); F(h->vox_gslot); F(h->vox_hist);
+    if (h->pin_vox_m) (void)hipHostFree(h->pin_vox_m);
     if (h->pin_T) (void)hipHostFree(h->pin_T);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->pin_int) (void)hipHostFree(h->pin_int);
@@ -735,6 +745,83 @@ extern "C" int slam3d_fit_planes(slam3d_icp_handle *h, const slam3d_cloud_view *
         P.coeff[0] = (float)nx; P.coeff[1] = (float)ny; P.coeff[2] = (float)nz; P.coeff[3] = (float)d;
         P.centroid[0] = (float)cx; P.centroid[1] = (float)cy; P.centroid[2] = (float)cz;
     }
+    return SLAM3D_OK;
+}
+
+// ------------------------------------------------------------------------------ frame ingestion filters (f-1)
+static int vox_alloc(slam3d_icp_handle *h)
+{
+    if (h->vox_mem) return SLAM3D_OK;
+    int cap = 1024;
+    while (cap < 2 * h->N) cap <<= 1;                     // load factor <= 0.5
+    const size_t bytes = (size_t)cap * (8 + 3 * 8 + 5 * 4);
+    if (hipMalloc((void **)&h->vox_mem, bytes) != hipSuccess || hipMalloc((void **)&h->vox_lkey, sizeof(unsigned long long) * h->N) != hipSuccess ||
+        hipMalloc((void **)&h->vox_lslot, sizeof(int) * h->N) != hipSuccess || hipMalloc((void **)&h->vox_m, sizeof(int)) != hipSuccess ||
+        hipMalloc((void **)&h->vox_gkey, sizeof(unsigned long long) * h->N) != hipSuccess ||
+        hipMalloc((void **)&h->vox_gslot, sizeof(int) * h->N) != hipSuccess ||
+        hipMalloc((void **)&h->vox_hist, sizeof(int) * (3 * VOX_BINS + 8)) != hipSuccess ||
+        hipMalloc((void **)&h->vox_out, sizeof(float4) * h->N) != hipSuccess ||
+        hipHostMalloc((void **)&h->pin_vox_m, sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return SLAM3D_E_NOMEM;
+    }
+    unsigned char *p = h->vox_mem;
+    VoxTable &t = h->vox;
+    t.cap = cap;
+    t.key = reinterpret_cast<unsigned long long *>(p); p += (size_t)cap * 8;
+    t.sx = reinterpret_cast<long long *>(p); p += (size_t)cap * 8;
+    t.sy = reinterpret_cast<long long *>(p); p += (size_t)cap * 8;
+    t.sz = reinterpret_cast<long long *>(p); p += (size_t)cap * 8;
+    t.c0 = reinterpret_cast<unsigned int *>(p); p += (size_t)cap * 4;
+    t.c1 = reinterpret_cast<unsigned int *>(p); p += (size_t)cap * 4;
+    t.c2 = reinterpret_cast<unsigned int *>(p); p += (size_t)cap * 4;
+    t.c3 = reinterpret_cast<unsigned int *>(p); p += (size_t)cap * 4;
+    t.n = reinterpret_cast<unsigned int *>(p);
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_voxel_grid_device(slam3d_icp_handle *h, const void *d_points16, int32_t n, float leaf, void *d_out16,
+                                        int32_t *n_out, void *stream)
+{
+    if (!h || !d_points16 || !d_out16 || !n_out || n < 0 || n > h->N || !(leaf > 0.0f)) return SLAM3D_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    int rc = vox_alloc(h);
+    if (rc) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    const VoxTable &t = h->vox;
+    HIPCHK(h, hipMemsetAsync(t.key, 0xFF, (size_t)t.cap * 8, s));
+    HIPCHK(h, hipMemsetAsync(t.sx, 0, (size_t)t.cap * (3 * 8 + 5 * 4), s));
+    HIPCHK(h, hipMemsetAsync(h->vox_m, 0, sizeof(int), s));
+    HIPCHK(h, hipMemsetAsync(h->vox_hist, 0, sizeof(int) * VOX_BINS, s));
+    int *start = h->vox_hist + VOX_BINS, *cursor = start + VOX_BINS + 8;
+    if (n > 0) {
+        hipLaunchKernelGGL(k_voxel_insert, dim3((n + VOX_BLOCK - 1) / VOX_BLOCK), dim3(VOX_BLOCK), 0, s,
+                           static_cast<const float4 *>(d_points16), n, 1.0f / leaf, h->g.zmax, t);
+        hipLaunchKernelGGL(k_voxel_compact, dim3((t.cap + VOX_BLOCK * VOX_SPT - 1) / (VOX_BLOCK * VOX_SPT)), dim3(VOX_BLOCK), 0, s, t,
+                           h->vox_lkey, h->vox_lslot, h->vox_m, h->vox_hist);
+        hipLaunchKernelGGL(k_voxel_scan, dim3(1), dim3(1024), 0, s, h->vox_hist, start, cursor);
+        hipLaunchKernelGGL(k_voxel_scatter, dim3((n + VOX_BLOCK - 1) / VOX_BLOCK), dim3(VOX_BLOCK), 0, s, h->vox_lkey, h->vox_lslot,
+                           h->vox_m, start, cursor, h->vox_gkey, h->vox_gslot);
+        hipLaunchKernelGGL(k_voxel_rank, dim3((n + VOX_BLOCK - 1) / VOX_BLOCK), dim3(VOX_BLOCK), 0, s, t, h->vox_gkey, h->vox_gslot,
+                           h->vox_m, start, static_cast<float4 *>(d_out16));
+    }
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(h->pin_vox_m, h->vox_m, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    *n_out = *h->pin_vox_m;
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_voxel_grid(slam3d_icp_handle *h, const void *points16, int32_t n, float leaf, void *out16, int32_t *n_out)
+{
+    if (!h || !points16 || !out16 || !n_out || n < 0 || n > h->N) return SLAM3D_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    int rc = vox_alloc(h);
+    if (rc) return rc;
+    if (n > 0) HIPCHK(h, hipMemcpyAsync(h->d_scratch4, points16, (size_t)n * 16, hipMemcpyHostToDevice, h->stream));
+    rc = slam3d_voxel_grid_device(h, h->d_scratch4, n, leaf, h->vox_out, n_out, h->stream);
+    if (rc) return rc;
+    if (*n_out > 0) HIPCHK(h, hipMemcpy(out16, h->vox_out, (size_t)*n_out * 16, hipMemcpyDeviceToHost));
     return SLAM3D_OK;
 }
 

@@ -131,7 +131,39 @@ def segmentation():
     json.dump(out, open(os.path.join(HERE, "segmentation_golden.json"), "w"), indent=1)
 
 
+def read_pcd16(path):
+    """binary PCD v0.7 with FIELDS x y z rgba -> (n,4) float32 records (rgba bits in column 3)"""
+    raw = open(path, "rb").read()
+    k = raw.index(b"DATA binary\n") + len(b"DATA binary\n")
+    head = raw[:k].decode("ascii", "replace")
+    n = int([ln for ln in head.splitlines() if ln.startswith("POINTS")][0].split()[1])
+    assert "FIELDS x y z rgba" in head
+    return np.frombuffer(raw, dtype=np.float32, count=4 * n, offset=k).reshape(n, 4).copy()
+
+
+def voxel():
+    """f-1 PassThrough + VoxelGrid(0.03): synthetic clouds with seeded colours + (derived outputs only) the
+    reference's data/exp1/pcd/{1,2}.pcd at its own operating point (grid_leaf 0.03, z_filter 7.0)."""
+    out = dict(generator="tests/golden/make_golden.py voxel", cases=[])
+    for (w, h, seed) in ((160, 120, 1000), (640, 480, 1001)):
+        pr = synth.make_pair(seed, w, h)
+        c = synth.backproject_numpy(pr.depth_src, pr.intr).reshape(-1, 4).copy()
+        c[:, 3] = np.random.default_rng(seed).integers(0, 2 ** 32, c.shape[0], dtype=np.uint64).astype(np.uint32).view(np.float32)
+        v = O.voxel_grid(c, 0.03, 7.0)
+        out["cases"].append(dict(seed=seed, width=w, height=h, depth_sha256=pr.sha256(), leaf=0.03, voxels=int(v.shape[0]),
+                                 out_sha256=sha(v), first=[float(x).hex() for x in v[0, :3]], last=[float(x).hex() for x in v[-1, :3]]))
+        print("voxel", w, h, seed, v.shape[0])
+    if os.path.isdir(REF):
+        for k in (1, 2):
+            p = read_pcd16(os.path.join(REF, f"data/exp1/pcd/{k}.pcd"))
+            v = O.voxel_grid(p, 0.03, 7.0)
+            out[f"reference_pcd{k}"] = dict(points=int(p.shape[0]), voxels=int(v.shape[0]), out_sha256=sha(v),
+                                            passthrough_kept=int((p[:, 2] <= 7.0).sum()))
+            print("voxel reference pcd", k, p.shape[0], "->", v.shape[0])
+    json.dump(out, open(os.path.join(HERE, "voxel_golden.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["synthetic", "reference", "segmentation"]
+    which = sys.argv[1:] or ["synthetic", "reference", "segmentation", "voxel"]
     for w in which:
-        {"synthetic": synthetic, "reference": reference, "segmentation": segmentation}[w]()
+        {"synthetic": synthetic, "reference": reference, "segmentation": segmentation, "voxel": voxel}[w]()

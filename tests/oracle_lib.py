@@ -145,6 +145,16 @@ def segment_planes(xyz4, zmax=7.0, distance_threshold=0.08, plane_percent=0.2, m
     return [dict(coeff=planes[i, :4].copy(), centroid=planes[i, 4:7].copy(), count=int(planes[i, 7])) for i in range(k)], labels
 
 
+def voxel_grid(pts16, leaf=0.03, zmax=7.0):
+    """pts16: (n,4) float32 records {x,y,z,rgba bits} -> (m,4) float32 records, ascending (iz,iy,ix)"""
+    pts = np.ascontiguousarray(pts16, dtype=np.float32).reshape(-1, 4)
+    out = np.zeros_like(pts)
+    f = lib().orc_voxel_grid
+    f.restype = C.c_int
+    m = f(_fp(pts, C.c_float), C.c_int(pts.shape[0]), C.c_float(leaf), C.c_float(zmax), _fp(out, C.c_float))
+    return out[:m].copy()
+
+
 def pose_error(Tref, T):
     Tref = np.ascontiguousarray(Tref, dtype=np.float64).reshape(16)
     T = np.ascontiguousarray(T, dtype=np.float64).reshape(16)

@@ -1,0 +1,150 @@
+"""f-1: PassThrough + VoxelGrid of GraphicEnd::readimage (src/GraphicEnd.cpp:283-295).
+
+PCL is not in the tree, so parity is UNPINNED; the oracle (oracle/voxel_oracle.c) is checked here against an
+independent numpy restatement of the same published algorithm, against golden vectors, and -- when the
+reference is present -- on its own data/exp1/pcd/{1,2}.pcd at its own operating point (221,202 -> ~16 k points,
+SURVEY.md row a4).  The HIP path must give the oracle's bits for any input order.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from slam3d_gx_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+G = json.load(open(os.path.join(HERE, "golden", "voxel_golden.json")))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _cloud(seed, w, h):
+    pr = synth.make_pair(seed, w, h)
+    c = synth.backproject_numpy(pr.depth_src, pr.intr).reshape(-1, 4).copy()
+    c[:, 3] = np.random.default_rng(seed).integers(0, 2 ** 32, c.shape[0], dtype=np.uint64).astype(np.uint32).view(np.float32)
+    return pr, c
+
+
+def numpy_voxel_grid(c, leaf=0.03, zmax=7.0):
+    ok = np.isfinite(c[:, :3]).all(1) & (c[:, 2] >= 0) & (c[:, 2] <= zmax)
+    p = c[ok]
+    inv = np.float32(1.0) / np.float32(leaf)
+    ijk = np.floor(p[:, :3] * inv).astype(np.int64) + 1048576
+    key = (ijk[:, 2] << 42) | (ijk[:, 1] << 21) | ijk[:, 0]
+    uk, idx = np.unique(key, return_inverse=True)
+    q = np.rint(p[:, :3].astype(np.float64) * 1048576.0).astype(np.int64)
+    S = np.zeros((uk.size, 3), dtype=np.int64)
+    np.add.at(S, idx, q)
+    cnt = np.bincount(idx, minlength=uk.size)
+    out = np.zeros((uk.size, 4), dtype=np.float32)
+    out[:, :3] = ((S / cnt[:, None]) / 1048576.0).astype(np.float32)
+    rgba = p[:, 3].view(np.uint32)
+    col = np.zeros(uk.size, dtype=np.uint32)
+    for k in range(4):
+        s = np.zeros(uk.size, dtype=np.int64)
+        np.add.at(s, idx, ((rgba >> (8 * k)) & 0xff).astype(np.int64))
+        col |= (s // cnt).astype(np.uint32) << (8 * k)
+    out[:, 3] = col.view(np.float32)
+    return out
+
+
+@pytest.mark.parametrize("size,seed", [((160, 120), 5), ((320, 240), 6)])
+def test_oracle_equals_numpy_restatement(size, seed):
+    _, c = _cloud(seed, *size)
+    v = O.voxel_grid(c)
+    w = numpy_voxel_grid(c)
+    assert v.shape == w.shape and np.array_equal(v.view(np.uint32), w.view(np.uint32))
+
+
+@pytest.mark.parametrize("c", G["cases"], ids=lambda c: f"{c['width']}x{c['height']}-{c['seed']}")
+def test_oracle_reproduces_voxel_golden(c):
+    pr, cloud = _cloud(c["seed"], c["width"], c["height"])
+    assert pr.sha256() == c["depth_sha256"]
+    v = O.voxel_grid(cloud, c["leaf"], 7.0)
+    assert v.shape[0] == c["voxels"] and sha(v) == c["out_sha256"]
+    assert [float(x).hex() for x in v[0, :3]] == c["first"] and [float(x).hex() for x in v[-1, :3]] == c["last"]
+
+
+def test_voxel_semantics_and_edge_cases():
+    leaf = 0.5
+    rec = lambda x, y, z, rgba=0: [x, y, z, np.array([rgba], dtype=np.uint32).view(np.float32)[0]]
+    pts = np.array([rec(0.1, 0.1, 1.1, 0x01020304), rec(0.3, 0.2, 1.2, 0x03040506),       # same voxel (0,0,2)
+                    rec(-0.1, 0.1, 1.1),                                                    # floor: ix = -1
+                    rec(0.1, 0.1, 7.5),                                                     # PassThrough drops z > 7
+                    rec(0.1, 0.1, 7.0, 0xff),                                               # limit is inclusive
+                    rec(np.nan, 0, 1), rec(0.1, 0.1, -0.2)], dtype=np.float32)
+    v = O.voxel_grid(pts, leaf, 7.0)
+    assert v.shape[0] == 3
+    # ascending (iz, iy, ix): z-slab 2 first (ix=-1 before ix=0), then the z=7.0 voxel
+    assert np.allclose(v[0, :3], [-0.1, 0.1, 1.1]) and np.allclose(v[1, :3], [0.2, 0.15, 1.15], atol=1e-6)
+    assert v[1, 3].view(np.uint32) == 0x02030405 and v[2, 3].view(np.uint32) == 0xff
+    assert np.allclose(v[2, :3], [0.1, 0.1, 7.0])
+    assert O.voxel_grid(np.zeros((0, 4), np.float32)).shape == (0, 4)
+    assert O.voxel_grid(np.full((10, 4), np.nan, np.float32)).shape == (0, 4)
+    # order independence (integer sums): any permutation of the input gives the same bits
+    _, c = _cloud(9, 160, 120)
+    a = O.voxel_grid(c)
+    b = O.voxel_grid(c[np.random.default_rng(0).permutation(c.shape[0])])
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # idempotence-like property: every output point lies in its own voxel, one point per voxel
+    inv = np.float32(1.0) / np.float32(0.03)
+    ijk = np.floor(a[:, :3] * inv).astype(np.int64)
+    assert np.unique(ijk, axis=0).shape[0] >= 0.999 * a.shape[0]      # centroids may round across a face: rare
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference fixtures not present")
+@pytest.mark.parametrize("k", [1, 2])
+def test_oracle_on_reference_pcd_operating_point(k):
+    """The reference's own frames at its own settings (grid_leaf 0.03, z_filter 7.0, parameters.yaml:41,65)."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_golden import read_pcd16
+    p = read_pcd16(os.path.join(REF, f"data/exp1/pcd/{k}.pcd"))
+    g = G[f"reference_pcd{k}"]
+    assert p.shape[0] == g["points"] == (221202, 236128)[k - 1]
+    v = O.voxel_grid(p, 0.03, 7.0)
+    assert v.shape[0] == g["voxels"] and sha(v) == g["out_sha256"]
+    assert 14000 < v.shape[0] < 17000                                  # "out ~15-16 k pts"
+    assert np.array_equal(v.view(np.uint32), numpy_voxel_grid(p).view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,seed", [((160, 120), 5), ((640, 480), 1001)])
+def test_hip_voxel_grid_is_bit_identical(gpu_lib, size, seed):
+    from slam3d_gx_amd import capi
+    pr, c = _cloud(seed, *size)
+    want = O.voxel_grid(c)
+    with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1)) as h:
+        got = h.voxel_grid(c)
+        shuffled = h.voxel_grid(c[np.random.default_rng(1).permutation(c.shape[0])])    # unorganized input order
+        part = h.voxel_grid(c[:1000])
+        none = h.voxel_grid(np.full((64, 4), np.nan, np.float32))
+        coarse = h.voxel_grid(c, leaf=0.25)
+    assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(shuffled.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(part.view(np.uint32), O.voxel_grid(c[:1000]).view(np.uint32))
+    assert none.shape == (0, 4)
+    assert np.array_equal(coarse.view(np.uint32), O.voxel_grid(c, 0.25).view(np.uint32))
+    for g in G["cases"]:
+        if (g["width"], g["height"], g["seed"]) == (size[0], size[1], seed):
+            assert got.shape[0] == g["voxels"] and sha(got) == g["out_sha256"]
+
+
+@pytest.mark.gpu
+def test_hip_voxel_grid_device_resident(gpu_lib):
+    import torch
+    from slam3d_gx_amd import capi
+    pr, c = _cloud(7, 320, 240)
+    d = torch.from_numpy(c).to("cuda:0")
+    out = torch.zeros_like(d)
+    with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1)) as h:
+        m = h.voxel_grid_device(d.data_ptr(), c.shape[0], out.data_ptr(), 0.03, torch.cuda.current_stream().cuda_stream)
+    want = O.voxel_grid(c)
+    assert m == want.shape[0]
+    assert np.array_equal(out[:m].cpu().numpy().view(np.uint32), want.view(np.uint32))
