@@ -79,6 +79,9 @@ void GraphicEndICP::init(const string &param_file)
     _loop_closure_detection = _reader->Has("loop_closure_detection") && _reader->GetPara("loop_closure_detection") == "yes";
     _loopclosure_frames = _reader->GetInt("loopclosure_frames", 30);
     _lc_state = (unsigned long long)_reader->GetInt("loopclosure_seed", 1);
+    _read_pcd = _reader->Has("icp_read_pcd") && _reader->GetPara("icp_read_pcd") == "yes";
+    _pclPath = source + "/pcd/";                                                       // src/GraphicEnd.cpp:85
+    _grid_leaf = (float)_reader->GetDouble("grid_leaf", 0.03);                         // :288
     _extract_planes = _reader->Has("icp_extract_planes") && _reader->GetPara("icp_extract_planes") == "yes";
     slam3d_seg_default_params(&_seg);
     _seg.distance_threshold = (float)_reader->GetDouble("distance_threshold", 0.08);   // src/GraphicEnd.cpp:89
@@ -161,6 +164,28 @@ int GraphicEndICP::readimage()
     _present.frame_index = _index;
     _present.connect.clear();
     _present.planes.clear();
+    _present.cloud.clear();
+    if (_read_pcd) {
+        // the reference's cloud path: loadPCDFile -> PassThrough z in [0, z_filter] -> VoxelGrid(grid_leaf) (:279-295),
+        // the two filters on the GPU behind slam3d_voxel_grid
+        stringstream ps;
+        ps << _pclPath << _index << ".pcd";
+        vector<PointXYZRGBA16> raw;
+        int pw = 0, ph = 0;
+        string perr;
+        if (!read_pcd(ps.str(), raw, pw, ph, perr)) cerr << "readimage: " << perr << endl;
+        else if ((long long)raw.size() > (long long)_params.width * _params.height) cerr << "readimage: cloud larger than the image" << endl;
+        else {
+            _present.cloud.resize(raw.size());
+            int m = 0;
+            if (slam3d_voxel_grid(_icp, raw.data(), (int)raw.size(), _grid_leaf, _present.cloud.data(), &m) == SLAM3D_OK) {
+                _present.cloud.resize((size_t)m);
+                cout << "cloud " << raw.size() << " -> " << m << " points after PassThrough + VoxelGrid" << endl;
+            } else {
+                _present.cloud.clear();
+            }
+        }
+    }
     if (_extract_planes) {
         _present.planes = extractPlanes(_present);
         _planefile << _index << " " << _present.planes.size();

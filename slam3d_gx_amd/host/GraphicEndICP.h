@@ -17,6 +17,7 @@
 #include "../../include/slam3d_icp.h"
 #include "ParameterReader.h"
 #include "PoseGraph.h"
+#include "pcd_io.h"
 
 // RESULT_OF_MULTIPNP {T, norm, inliers} (src/GraphicEnd.h:59-69); T row-major instead of Eigen::Isometry3d
 struct RESULT_OF_MULTIPNP {
@@ -33,6 +34,7 @@ struct FRAME {                        // stands in for KEYFRAME / vector<PLANE> 
     std::vector<uint16_t> depth;      // organized 16-bit depth, width*height
     std::vector<slam3d_plane> planes; // PLANE::coff of src/GraphicEnd.h:43 (filled when icp_extract_planes: yes)
     std::vector<int> connect;         // loop-closure partners, KEYFRAME::connect (src/GraphicEnd.cpp:760)
+    std::vector<PointXYZRGBA16> cloud; // _currCloud after PassThrough + VoxelGrid (src/GraphicEnd.cpp:283-295), icp_read_pcd: yes
 };
 
 void mat4_identity(double *T);
@@ -92,4 +94,7 @@ class GraphicEndICP {
     unsigned long long _lc_state = 1;                 // counter-based PRNG replacing rand() (src/GraphicEnd.cpp:69,725)
     slam3d_seg_params _seg;
     std::ofstream _lcfile, _planefile;
+    bool _read_pcd = false;
+    std::string _pclPath;
+    float _grid_leaf = 0.03f;
 };

@@ -4,9 +4,32 @@
 
 #include "ParameterReader.h"
 #include "png16.h"
+#include "pcd_io.h"
+#include <cstring>
+#include <string>
+#include <vector>
+
+// host_selftest pcd <in.pcd> <out.pcd>: reads, prints "pcd n width height checksum", writes the records back
+static int pcd_leg(const char *in, const char *out)
+{
+    std::vector<PointXYZRGBA16> pts;
+    int w = 0, h = 0;
+    std::string err;
+    if (!read_pcd(in, pts, w, h, err)) { std::cerr << err << std::endl; return 1; }
+    unsigned long long sum = 0;
+    for (size_t i = 0; i < pts.size(); ++i) {
+        uint32_t b[4];
+        memcpy(b, &pts[i], 16);
+        sum += (unsigned long long)(b[0] ^ (b[1] * 3u) ^ (b[2] * 5u) ^ (b[3] * 7u)) * (i % 9973 + 1);
+    }
+    printf("pcd %zu %d %d %llu\n", pts.size(), w, h, sum);
+    if (!write_pcd_binary(out, pts.data(), pts.size(), w, h, err)) { std::cerr << err << std::endl; return 1; }
+    return 0;
+}
 
 int main(int argc, char **argv)
 {
+    if (argc >= 4 && std::string(argv[1]) == "pcd") return pcd_leg(argv[2], argv[3]);
     if (argc < 3) return 2;
     int w = 0, h = 0;
     std::vector<uint16_t> px;

@@ -40,6 +40,7 @@ image_width: {w}
 image_height: {h}
 icp_iterations: 15
 icp_extract_planes: {planes}
+icp_read_pcd: {pcd}
 """
 
 
@@ -60,7 +61,7 @@ def test_png_and_parameter_readers(tmp_path):
     png = tmp_path / "d.png"
     _write_png16(str(png), pr.depth_src)
     yml = tmp_path / "parameters.yaml"
-    yml.write_text(PARAMS.format(src="/data/x", mpc=0.25, fx=517.0, fy=517.0, cx=318.6, cy=255.3, w=320, h=240, lc="no", planes="no"))
+    yml.write_text(PARAMS.format(src="/data/x", mpc=0.25, fx=517.0, fy=517.0, cx=318.6, cy=255.3, w=320, h=240, lc="no", planes="no", pcd="no"))
     out = subprocess.run([os.path.join(HOST, "host_selftest"), str(png), str(yml)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().splitlines()
@@ -70,6 +71,52 @@ def test_png_and_parameter_readers(tmp_path):
     # GetPara returns strings; unknown key -> "unknown_para_name" + stderr (src/ParameterReader.cpp:121-122)
     assert "data_source=/data/x z_filter=7.0 max_planes=3 missing=unknown_para_name fx=517.000 factor=1000.0 iters=15" in lines[-1]
     assert "Unknown parameter: no_such_key" in out.stderr
+
+
+def _pcd_checksum(rec):
+    b = np.ascontiguousarray(rec, dtype=np.float32).view(np.uint32).reshape(-1, 4).astype(np.uint64)
+    mixed = (b[:, 0] ^ ((b[:, 1] * 3) & 0xffffffff) ^ ((b[:, 2] * 5) & 0xffffffff) ^ ((b[:, 3] * 7) & 0xffffffff))
+    w = (np.arange(b.shape[0], dtype=np.uint64) % np.uint64(9973)) + np.uint64(1)
+    return int((mixed * w).sum(dtype=np.uint64))
+
+
+def test_pcd_reader_writer(tmp_path):
+    """Row f-1: PCD v0.7 binary (the reference's format, src/convert2PCD.cpp:75-79) and ascii, incl. the reference's
+    own data/exp1/pcd/1.pcd when it is present (221,202 records, 3,911 trailing bytes ignored)."""
+    _build_host()
+    exe = os.path.join(HOST, "host_selftest")
+    rng = np.random.default_rng(4)
+    rec = rng.normal(size=(1000, 4)).astype(np.float32)
+    rec[:, 3] = rng.integers(0, 2 ** 32, 1000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    head = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgba\nSIZE 4 4 4 4\nTYPE F F F U\nCOUNT 1 1 1 1\n"
+            "WIDTH 1000\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS 1000\nDATA binary\n")
+    src = tmp_path / "a.pcd"
+    src.write_bytes(head.encode() + rec.tobytes() + b"trailing-garbage")
+    out = subprocess.run([exe, "pcd", str(src), str(tmp_path / "b.pcd")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["pcd", "1000", "1000", "1", str(_pcd_checksum(rec))]
+    assert (tmp_path / "b.pcd").read_bytes() == head.encode() + rec.tobytes()          # byte-identical re-write
+    # ascii with an extra field in front and rgb as the last column
+    asc = "VERSION .7\nFIELDS intensity x y z rgb\nSIZE 4 4 4 4 4\nTYPE F F F F U\nCOUNT 1 1 1 1 1\nWIDTH 2\nHEIGHT 1\nPOINTS 2\nDATA ascii\n" \
+          "9 1.5 -2 3.25 255\n8 0.5 0.25 4 16711680\n"
+    (tmp_path / "c.pcd").write_text(asc)
+    out = subprocess.run([exe, "pcd", str(tmp_path / "c.pcd"), str(tmp_path / "d.pcd")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    want = np.array([[1.5, -2, 3.25, 0], [0.5, 0.25, 4, 0]], dtype=np.float32)
+    want[:, 3] = np.array([255, 16711680], dtype=np.uint32).view(np.float32)
+    assert out.stdout.split() == ["pcd", "2", "2", "1", str(_pcd_checksum(want))]
+    # failure modes: missing file, not a PCD
+    assert subprocess.run([exe, "pcd", str(tmp_path / "nope.pcd"), str(tmp_path / "x.pcd")], capture_output=True).returncode == 1
+    (tmp_path / "e.pcd").write_text("hello\n")
+    assert subprocess.run([exe, "pcd", str(tmp_path / "e.pcd"), str(tmp_path / "x.pcd")], capture_output=True).returncode == 1
+    ref = "/root/reference/data/exp1/pcd/1.pcd"
+    if os.path.exists(ref):
+        raw = open(ref, "rb").read()
+        k = raw.index(b"DATA binary\n") + 12
+        body = np.frombuffer(raw, dtype=np.float32, count=4 * 221202, offset=k).reshape(-1, 4)
+        out = subprocess.run([exe, "pcd", ref, str(tmp_path / "r.pcd")], capture_output=True, text=True)
+        assert out.stdout.split() == ["pcd", "221202", "221202", "1", str(_pcd_checksum(body))]
+        assert (tmp_path / "r.pcd").read_bytes() == raw[: k + 16 * 221202]                # same header, same records
 
 
 @pytest.mark.gpu
@@ -91,7 +138,7 @@ def test_run_slam_driver_tracks_synthetic_sequence(gpu_lib, tmp_path):
         d = synth.render_depth(P, intr, 4242, 10 + k, hole_block=hb)
         _write_png16(str(data / "dep_index" / f"{k + 1}.png"), d)
     (tmp_path / "parameters.yaml").write_text(
-        PARAMS.format(src=str(data), mpc=10.0, fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=W, h=H, lc="no", planes="no"))
+        PARAMS.format(src=str(data), mpc=10.0, fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=W, h=H, lc="no", planes="no", pcd="no"))
     out = subprocess.run([os.path.join(HOST, "run_SLAM"), "4"], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     norms = [float(x) for x in (tmp_path / "data" / "error_of_transform.log").read_text().split()]
@@ -136,10 +183,20 @@ def test_run_slam_keyframes_loop_closure_and_g2o_handoff(gpu_lib, tmp_path):
         out_poses.append(step @ out_poses[-1])
     poses = out_poses + out_poses[-2::-1]                      # 0 1 2 3 4 3 2 1 0
     hb = max(2, int(round(32 * W / 640.0)))
+    (data / "pcd").mkdir()
+    head = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgba\nSIZE 4 4 4 4\nTYPE F F F U\nCOUNT 1 1 1 1\n"
+            "WIDTH {n}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {n}\nDATA binary\n")
+    voxels = []
     for k, P in enumerate(poses):
-        _write_png16(str(data / "dep_index" / f"{k + 1}.png"), synth.render_depth(P, intr, 4242, 10 + k, hole_block=hb))
+        d = synth.render_depth(P, intr, 4242, 10 + k, hole_block=hb)
+        _write_png16(str(data / "dep_index" / f"{k + 1}.png"), d)
+        c = synth.backproject_numpy(d, intr, z_filter=1e9).reshape(-1, 4)
+        c = c[np.isfinite(c[:, 2])].copy()                      # convert2PCD drops d == 0 (src/convert2PCD.cpp:60-61)
+        c[:, 3] = np.float32(0)
+        (data / "pcd" / f"{k + 1}.pcd").write_bytes(head.format(n=c.shape[0]).encode() + c.tobytes())
+        voxels.append((c.shape[0], O.voxel_grid(c, 0.03, 7.0).shape[0]))
     (tmp_path / "parameters.yaml").write_text(
-        PARAMS.format(src=str(data), mpc=0.005, fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=W, h=H, lc="yes", planes="yes"))
+        PARAMS.format(src=str(data), mpc=0.005, fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=W, h=H, lc="yes", planes="yes", pcd="yes"))
     out = subprocess.run([os.path.join(HOST, "run_SLAM"), str(len(poses) - 1)], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     kf = np.loadtxt(str(tmp_path / "data" / "keyframe.txt"), dtype=int)
@@ -166,6 +223,9 @@ def test_run_slam_keyframes_loop_closure_and_g2o_handoff(gpu_lib, tmp_path):
         assert ang < 0.03 and np.linalg.norm(err[:3, 3]) < 0.06, (a, b, ang, err[:3, 3])
     # the camera came back: last vertex close to the first
     assert np.linalg.norm(V[len(poses) - 1][:3, 3]) < 0.06
+    # row f-1: every frame's PCD went through PassThrough + VoxelGrid(grid_leaf) on the GPU
+    clouds = [ln.split() for ln in out.stdout.splitlines() if ln.startswith("cloud ")]
+    assert [(int(t[1]), int(t[3])) for t in clouds] == voxels
     lc = (tmp_path / "data" / "lc.txt").read_text().split()
     assert len(lc) % 4 == 0
     planes = (tmp_path / "data" / "planes.txt").read_text().strip().splitlines()
