@@ -40,14 +40,16 @@ def test_struct_layouts_match_header_sizes(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "slam3d_icp.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(slam3d_icp_params), sizeof(slam3d_icp_result),'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(slam3d_icp_params), sizeof(slam3d_icp_result),'
         ' sizeof(slam3d_cloud_view), sizeof(slam3d_plane), offsetof(slam3d_icp_params, nn_mode),'
-        ' offsetof(slam3d_icp_result, rmse), offsetof(slam3d_icp_result, T_raw));return 0;}\n')
+        ' offsetof(slam3d_icp_result, rmse), offsetof(slam3d_icp_result, T_raw), sizeof(slam3d_seg_params),'
+        ' offsetof(slam3d_seg_params, seed));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert got == [ctypes.sizeof(capi.Params), ctypes.sizeof(capi.Result), ctypes.sizeof(capi.CloudView),
-                   ctypes.sizeof(capi.Plane), capi.Params.nn_mode.offset, capi.Result.rmse.offset, capi.Result.T_raw.offset]
+                   ctypes.sizeof(capi.Plane), capi.Params.nn_mode.offset, capi.Result.rmse.offset, capi.Result.T_raw.offset,
+                   ctypes.sizeof(capi.SegParams), capi.SegParams.seed.offset]
 
 
 def test_create_fails_loudly_without_device_or_with_bad_params():

@@ -338,3 +338,31 @@ def test_plane_segmentation_batch_on_device_and_edge_cases(gpu_lib):
         for a, b in zip(out[i], po):
             assert a["count"] == b["count"] and np.array_equal(a["coeff"], b["coeff"])
     assert len(out[2]) == 0 and len(out[3]) == 0 and (lab[2] == -2).all() and (lab[3][:2] == -1).all()
+
+
+def test_new_entry_points_reject_bad_arguments(gpu_lib):
+    """f-1 / f-2 / dense-device entry points: usage errors are SLAM3D_E_INVALID / _STATE, never a crash."""
+    import ctypes as C
+    pr, s4, _ = _pair(1000, 160, 120)
+    N = 160 * 120
+    with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1)) as h:
+        lib, hp = h.lib, h._h
+        sp = h.seg_params()
+        planes = (capi.Plane * 8)()
+        npl = (C.c_int32 * 1)()
+        m = C.c_int32(0)
+        buf = np.zeros((N, 4), np.float32)
+        assert lib.slam3d_voxel_grid(hp, None, 10, C.c_float(0.03), capi._vp(buf), C.byref(m)) == -1
+        assert lib.slam3d_voxel_grid(hp, capi._vp(buf), N + 1, C.c_float(0.03), capi._vp(buf), C.byref(m)) == -1     # larger than the handle
+        assert lib.slam3d_voxel_grid(hp, capi._vp(buf), 10, C.c_float(0.0), capi._vp(buf), C.byref(m)) == -1         # leaf must be > 0
+        assert lib.slam3d_voxel_grid(hp, capi._vp(buf), 0, C.c_float(0.03), capi._vp(buf), C.byref(m)) == 0 and m.value == 0
+        for bad in (dict(max_planes=0), dict(max_planes=9), dict(hypotheses=0), dict(hypotheses=65), dict(distance_threshold=0.0)):
+            with pytest.raises(capi.Slam3dError) as e:
+                h.segment_planes(s4, h.seg_params(**bad))
+            assert e.value.code == -1
+        assert lib.slam3d_segment_planes(hp, None, C.byref(sp), planes, npl, None) == -1
+        assert lib.slam3d_segment_planes_device(hp, 2, None, C.byref(sp), planes, npl, None, None) == -1             # B > max_batch / no clouds
+        # dense device calls before dense_begin
+        assert lib.slam3d_icp_dense_partial_device(hp, C.c_void_p(8), None) == -5
+        assert lib.slam3d_icp_dense_update_device(hp, None, None) == -1
+        assert lib.slam3d_icp_set_profiling(None, 1) == -1
