@@ -310,7 +310,7 @@ def main():
         h.set_clouds_device(i, d_src.data_ptr() + i * rec_bytes, d_tgt.data_ptr() + i * rec_bytes)
     stream = torch.cuda.current_stream().cuda_stream
     table = {}
-    d_sums = torch.zeros(29, dtype=torch.float64, device=dev)       # dense mode: the per-iteration exchange buffer
+    d_sums = torch.zeros(29, dtype=torch.int64, device=dev)       # dense mode: the per-iteration exchange buffer
     gatherer = shard.PoseGatherer(world * P, device=None if host_comm else dev) if (world > 1 and not is_dense) else None
     host_allreduce = dense.allreduce_sum_torch(None) if (host_comm and world > 1) else None
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SLAM3D_ICP_ABI_VERSION 1
+#define SLAM3D_ICP_ABI_VERSION 2
 #define SLAM3D_ICP_NSUMS 29   /* 21 upper-tri AtA + 6 Atb + count + sum r^2 */
 
 /* return codes: 0 ok; >0 algorithmic (result.T == Identity); <0 usage / runtime errors */
@@ -206,17 +206,19 @@ int slam3d_segment_planes_device(slam3d_icp_handle *h, int32_t B, const void *co
 int slam3d_icp_dense_set_rows(slam3d_icp_handle *h, int32_t row_begin, int32_t row_end);
 /* preprocess slot 0 (normals, compaction) and reset T to T_init */
 int slam3d_icp_dense_begin(slam3d_icp_handle *h, const double *T_init, void *stream);
-/* one NN + accumulate pass over the local rows: 29 partial sums on the host */
-int slam3d_icp_dense_partial(slam3d_icp_handle *h, double sums[SLAM3D_ICP_NSUMS], void *stream);
-/* solve with the (all-reduced) sums and update T on every rank identically */
-int slam3d_icp_dense_update(slam3d_icp_handle *h, const double sums[SLAM3D_ICP_NSUMS], void *stream);
-int slam3d_icp_dense_finish(slam3d_icp_handle *h, const double last_sums[SLAM3D_ICP_NSUMS],
+/* one NN + accumulate pass over the local rows: 29 partial sums on the host.  The sums are int64 fixed point
+ * (unit 2^-32): integer addition is associative, so the all-reduced totals -- and with them the pose -- do not
+ * depend on how the rows were sharded. */
+int slam3d_icp_dense_partial(slam3d_icp_handle *h, int64_t sums[SLAM3D_ICP_NSUMS], void *stream);
+/* solve with the (all-reduced, integer SUM) sums and update T on every rank identically */
+int slam3d_icp_dense_update(slam3d_icp_handle *h, const int64_t sums[SLAM3D_ICP_NSUMS], void *stream);
+int slam3d_icp_dense_finish(slam3d_icp_handle *h, const int64_t last_sums[SLAM3D_ICP_NSUMS],
                             slam3d_icp_result *out);
 /* the same three with the 29 sums in a caller-owned DEVICE buffer: partial writes it, the caller all-reduces it
  * in place on the same stream (RCCL), update reads it.  No host synchronisation until finish. */
-int slam3d_icp_dense_partial_device(slam3d_icp_handle *h, double *d_sums, void *stream);
-int slam3d_icp_dense_update_device(slam3d_icp_handle *h, const double *d_sums, void *stream);
-int slam3d_icp_dense_finish_device(slam3d_icp_handle *h, const double *d_last_sums, void *stream,
+int slam3d_icp_dense_partial_device(slam3d_icp_handle *h, int64_t *d_sums, void *stream);
+int slam3d_icp_dense_update_device(slam3d_icp_handle *h, const int64_t *d_sums, void *stream);
+int slam3d_icp_dense_finish_device(slam3d_icp_handle *h, const int64_t *d_last_sums, void *stream,
                                    slam3d_icp_result *out);
 
 #ifdef __cplusplus

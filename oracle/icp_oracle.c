@@ -514,26 +514,15 @@ static void row_sums(const clist *src, const clist *tgt, const float Rf[9], cons
     }
 }
 
-static void tree256(double (*v)[ORC_NSUMS])   /* v[256][29] -> v[0] */
+/* Summation (spec S4): every slot's 29 products are formed in double (row_sums), scaled by 2^32 and rounded to
+ * the nearest integer (ties to even); the totals are the exact int64 sums of those integers, converted back by
+ * (double)Q / 2^32.  Integer addition is associative, so the totals do not depend on the order or grouping of the
+ * summands: one GPU wave per tile, one atomic per block, any number of GPUs (dense mode) -- the same bits.
+ * Range: |term| <= ~100 (|p x n|^2 at 10 m), 1.2e6 slots at 1280x960 -> |Q| < 2^59. */
+#define ORC_FIX 4294967296.0
+void orc_accumulate_fixed(const double s[ORC_NSUMS], int64_t Q[ORC_NSUMS])
 {
-    for (int s = ORC_CHUNK / 2; s >= 1; s >>= 1)
-        for (int i = 0; i < s; ++i)
-            for (int k = 0; k < ORC_NSUMS; ++k) v[i][k] += v[i + s][k];
-}
-
-/* Summation order (spec S4): sources are enumerated by SLOT, tile-major over 8x8-pixel tiles
- * (tile t = ty*ntx + tx, slot = t*64 + (v%8)*8 + (u%8); the image is padded to whole tiles).
- * A slot without a valid source point or without a gated correspondence contributes zeros.
- *   level 1: the 64 slots of a tile by tree64  (a[i] += a[i+s], i < s, s = 32,16,..,1)
- *   level 2: groups of 256 consecutive tile results by tree256 (s = 128,..,1; missing tiles = 0)
- *   level 3: group results summed in ascending order.
- * (one wavefront owns one tile on the GPU: level 1 is its shuffle tree) */
-#define ORC_TILE 8
-static void tree64(double (*v)[ORC_NSUMS])
-{
-    for (int s = 32; s >= 1; s >>= 1)
-        for (int i = 0; i < s; ++i)
-            for (int k = 0; k < ORC_NSUMS; ++k) v[i][k] += v[i + s][k];
+    for (int k = 0; k < ORC_NSUMS; ++k) Q[k] += llrint(s[k] * ORC_FIX);
 }
 
 static void accumulate(const clist *src, const clist *tgt, const double *T, int estimator,
@@ -541,39 +530,24 @@ static void accumulate(const clist *src, const clist *tgt, const double *T, int 
 {
     float Rf[9], tf[3];
     transform_f(T, Rf, tf);
-    const int ntx = (W + ORC_TILE - 1) / ORC_TILE, nty = (H + ORC_TILE - 1) / ORC_TILE;
-    const int ntiles = ntx * nty;
-    const int ngroups = (ntiles + ORC_CHUNK - 1) / ORC_CHUNK;
-    /* pixel -> compact source index */
-    int *cidx = malloc(sizeof(int) * (size_t)(W * H));
-    for (int i = 0; i < W * H; ++i) cidx[i] = -1;
-    for (int i = 0; i < src->n; ++i) cidx[src->orig[i]] = i;
-    double (*P1)[ORC_NSUMS] = calloc((size_t)(ngroups * ORC_CHUNK + 1), sizeof(*P1));
-    (void)nt;
+    (void)W; (void)H; (void)nt;
+    int64_t Q[ORC_NSUMS];
+    for (int k = 0; k < ORC_NSUMS; ++k) Q[k] = 0;
 #pragma omp parallel num_threads(nt)
     {
-        double (*v)[ORC_NSUMS] = malloc(sizeof(*v) * 64);
+        int64_t q[ORC_NSUMS];
+        double s[ORC_NSUMS];
+        for (int k = 0; k < ORC_NSUMS; ++k) q[k] = 0;
 #pragma omp for schedule(static)
-        for (int t = 0; t < ntiles; ++t) {
-            for (int ln = 0; ln < 64; ++ln) {
-                const int u = (t % ntx) * ORC_TILE + (ln & 7), vv = (t / ntx) * ORC_TILE + (ln >> 3);
-                int i = -1;
-                if (u < W && vv < H) i = cidx[vv * W + u];
-                if (i >= 0) row_sums(src, tgt, Rf, tf, estimator, i, corr[i], v[ln]);
-                else for (int k = 0; k < ORC_NSUMS; ++k) v[ln][k] = 0.0;
-            }
-            tree64(v);
-            memcpy(P1[t], v[0], sizeof(double) * ORC_NSUMS);
+        for (int i = 0; i < src->n; ++i) {
+            if (corr[i] < 0) continue;
+            row_sums(src, tgt, Rf, tf, estimator, i, corr[i], s);
+            orc_accumulate_fixed(s, q);
         }
-        free(v);
+#pragma omp critical
+        for (int k = 0; k < ORC_NSUMS; ++k) Q[k] += q[k];
     }
-    for (int k = 0; k < ORC_NSUMS; ++k) total[k] = 0.0;
-    for (int g = 0; g < ngroups; ++g) {
-        tree256(P1 + (size_t)g * ORC_CHUNK);
-        if (g == 0) memcpy(total, P1[0], sizeof(double) * ORC_NSUMS);
-        else for (int k = 0; k < ORC_NSUMS; ++k) total[k] += P1[(size_t)g * ORC_CHUNK][k];
-    }
-    free(P1); free(cidx);
+    for (int k = 0; k < ORC_NSUMS; ++k) total[k] = (double)Q[k] / ORC_FIX;
 }
 
 /* ------------------------------------------------------------- S5 update */

@@ -330,12 +330,12 @@ class IcpHandle:
         self._check(self.lib.slam3d_icp_dense_begin(self._h, _vp(Ti), C.c_void_p(stream)), False)
 
     def dense_partial(self, stream: int = 0) -> np.ndarray:
-        s = np.zeros(NSUMS, dtype=np.float64)
+        s = np.zeros(NSUMS, dtype=np.int64)          # fixed point, unit 2^-32: integer sums are order-free
         self._check(self.lib.slam3d_icp_dense_partial(self._h, _vp(s), C.c_void_p(stream)), False)
         return s
 
     def dense_update(self, sums: np.ndarray, stream: int = 0):
-        s = np.ascontiguousarray(sums, dtype=np.float64).reshape(NSUMS)
+        s = np.ascontiguousarray(sums, dtype=np.int64).reshape(NSUMS)
         self._check(self.lib.slam3d_icp_dense_update(self._h, _vp(s), C.c_void_p(stream)), False)
 
     def dense_partial_device(self, d_sums: int, stream: int = 0):
@@ -350,7 +350,7 @@ class IcpHandle:
         return out.as_dict()
 
     def dense_finish(self, last_sums: np.ndarray) -> dict:
-        s = np.ascontiguousarray(last_sums, dtype=np.float64).reshape(NSUMS)
+        s = np.ascontiguousarray(last_sums, dtype=np.int64).reshape(NSUMS)
         out = Result()
         self._check(self.lib.slam3d_icp_dense_finish(self._h, _vp(s), C.byref(out)), False)
         return out.as_dict()

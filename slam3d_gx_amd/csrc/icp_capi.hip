@@ -29,7 +29,8 @@ struct slam3d_icp_handle {
     unsigned int *ticket = nullptr;
     unsigned long long *best = nullptr;
     float *cd2 = nullptr;
-    double *partials = nullptr, *GP = nullptr, *sums = nullptr, *Tcur = nullptr, *trace_T = nullptr, *trace_S = nullptr, *d_Tinit = nullptr;
+    long long *acc = nullptr, *sums = nullptr;     // integer accumulators (ACC_R replicas per pair) / raw sums of dense mode
+    double *Tcur = nullptr, *trace_T = nullptr, *trace_S = nullptr, *d_Tinit = nullptr;
     SlotPtrs *d_slots = nullptr;
     unsigned char *d_raw = nullptr; size_t raw_bytes = 0;
     uint16_t *d_depth = nullptr;
@@ -129,9 +130,9 @@ static void free_all(slam3d_icp_handle *h)
 {
     auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(h->own_src); F(h->own_tgt); F(h->nrm); F(h->src_c); F(h->tgt_c); F(h->counts); F(h->ccounts); F(h->corr);
-    F(h->flags); F(h->best); F(h->cd2); F(h->partials); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
+    F(h->flags); F(h->best); F(h->cd2); F(h->acc); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
     F(h->d_Tinit); F(h->d_slots); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4);
-    F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox); F(h->GP); F(h->ticket); F(h->dbg); F(h->prevq); F(h->hint); F(h->scount); F(h->perm); F(h->cost); F(h->tgtB); F(h->qmax2);
+    F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox); F(h->dbg); F(h->prevq); F(h->hint); F(h->scount); F(h->perm); F(h->cost); F(h->tgtB); F(h->qmax2);
     if (h->pin_slots) (void)hipHostFree(h->pin_slots);
     if (h->pin_res) (void)hipHostFree(h->pin_res);
     if (h->pin_seg) (void)hipHostFree(h->pin_seg);
@@ -189,7 +190,6 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     tg.nslots = tg.nchunks * CHUNK;
     tg.ngroups = (tg.ntiles + CHUNK - 1) / CHUNK;
     tg.tpad = tg.ngroups * CHUNK;
-    if (tg.ngroups > RS_MAXGROUPS) { delete h; return SLAM3D_E_INVALID; }
     const size_t BN = (size_t)h->maxB * h->N;
     const size_t BS = (size_t)h->maxB * tg.nslots;
     const bool brute = nn_mode_of(h) != SLAM3D_NN_TILES;
@@ -205,8 +205,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     }
     A(dalloc(h->counts, (size_t)h->maxB * 4)); A(dalloc(h->ccounts, (size_t)h->maxB * 4));
     A(dalloc(h->corr, BS)); A(dalloc(h->flags, (size_t)h->maxB)); A(dalloc(h->cd2, BS)); A(dalloc(h->prevq, BS));
-    A(dalloc(h->partials, (size_t)h->maxB * NSUMS * tg.tpad));
-    A(dalloc(h->GP, (size_t)h->maxB * RS_MAXGROUPS * NSUMS)); A(dalloc(h->ticket, (size_t)h->maxB));
+    A(dalloc(h->acc, (size_t)h->maxB * ACC_R * ACC_STRIDE));
     A(dalloc(h->hint, (size_t)h->maxB * tg.ntiles)); A(dalloc(h->scount, (size_t)h->maxB * tg.ntiles));
     A(dalloc(h->cost, (size_t)h->maxB * tg.ntiles));
     A(dalloc(h->perm, (size_t)h->maxB * ((tg.ntiles + NN_WAVES - 1) / NN_WAVES) * NN_WAVES));
@@ -234,8 +233,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     }
     h->h_slots.assign(h->maxB, SlotPtrs{ nullptr, nullptr });
     (void)hipMemsetAsync(h->counts, 0, sizeof(int) * 4 * h->maxB, h->stream);
-    (void)hipMemsetAsync(h->ticket, 0, sizeof(unsigned int) * h->maxB, h->stream);
-    (void)hipMemsetAsync(h->partials, 0, sizeof(double) * (size_t)h->maxB * NSUMS * tg.tpad, h->stream);   // padding tiles stay 0
+    (void)hipMemsetAsync(h->acc, 0, sizeof(long long) * (size_t)h->maxB * ACC_R * ACC_STRIDE, h->stream);   // k_solve_acc re-zeroes after every launch
     *out = h;
     return SLAM3D_OK;
 }
@@ -386,15 +384,14 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
 // one iteration's data-parallel part: NN search + normal-equation chunks, then the 29-sum reduction
 // (+ solve and SE(3) update when do_solve)
 static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int it, int do_solve,
-                             double *sums_out = nullptr)
+                             long long *raw_out = nullptr)
 {
-    if (!sums_out) sums_out = h->sums;
     const TileGrid &tg = h->tg;
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
     if (e0) HIPCHK(h, hipEventRecord(e0, s));
     if (nn_mode_of(h) == SLAM3D_NN_TILES) {
         hipLaunchKernelGGL(k_nn_tiles_acc, dim3((tg.ntiles + NN_WAVES - 1) / NN_WAVES, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
-                           h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, h->perm, h->cost, h->partials, h->g, tg, h->dbg);
+                           h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, h->perm, h->cost, h->acc, h->g, tg, h->dbg);
         if (it == 1 && do_solve)      // costs are stable from the second iteration on: balance the blocks once
             hipLaunchKernelGGL(k_balance, dim3(B), dim3(1024), 0, s, h->cost, h->perm, tg, (tg.ntiles + NN_WAVES - 1) / NN_WAVES);
         if (e1) HIPCHK(h, hipEventRecord(e1, s));
@@ -415,10 +412,10 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         }
         if (e1) HIPCHK(h, hipEventRecord(e1, s));
         hipLaunchKernelGGL(k_accumulate, dim3(tg.nchunks, B), dim3(CHUNK), 0, s, h->d_slots, h->nrm, h->srcT, h->Tcur, h->best,
-                           h->corr, h->cd2, h->prevq, h->partials, h->g, tg);
+                           h->corr, h->cd2, h->prevq, h->acc, h->g, tg);
     }
-    hipLaunchKernelGGL(k_reduce_solve, dim3(tg.ngroups, B), dim3(CHUNK), 0, s, h->partials, h->GP, h->ticket, sums_out, h->Tcur,
-                       h->trace_T, h->trace_S, h->flags, h->counts, do_solve ? h->d_res : nullptr, tg, it, iters, h->p.estimator, do_solve);
+    hipLaunchKernelGGL(k_solve_acc, dim3(B), dim3(64), 0, s, h->acc, raw_out, h->Tcur, h->trace_T, h->trace_S, h->flags, h->counts,
+                       do_solve ? h->d_res : nullptr, it, iters, h->p.estimator, do_solve);
     HIPCHK(h, hipGetLastError());
     return SLAM3D_OK;
 }
@@ -941,28 +938,28 @@ extern "C" int slam3d_icp_dense_begin(slam3d_icp_handle *h, const double *T_init
     return SLAM3D_OK;
 }
 
-extern "C" int slam3d_icp_dense_partial(slam3d_icp_handle *h, double sums[SLAM3D_ICP_NSUMS], void *stream)
+extern "C" int slam3d_icp_dense_partial(slam3d_icp_handle *h, int64_t sums[SLAM3D_ICP_NSUMS], void *stream)
 {
     if (!h || !sums) return SLAM3D_E_INVALID;
     if (!h->ran) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
-    const int rc = enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0);
+    const int rc = enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0, h->sums);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->pin_out, h->sums, sizeof(double) * NSUMS, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->pin_out, h->sums, sizeof(int64_t) * NSUMS, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
-    memcpy(sums, h->pin_out, sizeof(double) * NSUMS);
+    memcpy(sums, h->pin_out, sizeof(int64_t) * NSUMS);
     return SLAM3D_OK;
 }
 
-extern "C" int slam3d_icp_dense_update(slam3d_icp_handle *h, const double sums[SLAM3D_ICP_NSUMS], void *stream)
+extern "C" int slam3d_icp_dense_update(slam3d_icp_handle *h, const int64_t sums[SLAM3D_ICP_NSUMS], void *stream)
 {
     if (!h || !sums) return SLAM3D_E_INVALID;
     if (!h->ran || h->dense_it >= (h->p.iterations > 0 ? h->p.iterations : 1)) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
-    memcpy(h->pin_out, sums, sizeof(double) * NSUMS);           // pin_out holds (16+29)*maxB doubles
-    HIPCHK(h, hipMemcpyAsync(h->sums, h->pin_out, sizeof(double) * NSUMS, hipMemcpyHostToDevice, s));
+    memcpy(h->pin_out, sums, sizeof(int64_t) * NSUMS);          // pin_out holds (16+29)*maxB 8-byte words
+    HIPCHK(h, hipMemcpyAsync(h->sums, h->pin_out, sizeof(int64_t) * NSUMS, hipMemcpyHostToDevice, s));
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, s, h->sums, h->Tcur, h->trace_T, h->trace_S, h->flags, 1, h->dense_it,
                        iters, h->p.estimator);
@@ -974,30 +971,30 @@ extern "C" int slam3d_icp_dense_update(slam3d_icp_handle *h, const double sums[S
 
 // Device-resident forms of the three calls above: the 29 sums stay in a caller-owned device buffer, so the
 // exchange (an RCCL all-reduce on the same stream) needs no host round trip; nothing here synchronises.
-extern "C" int slam3d_icp_dense_partial_device(slam3d_icp_handle *h, double *d_sums, void *stream)
+extern "C" int slam3d_icp_dense_partial_device(slam3d_icp_handle *h, int64_t *d_sums, void *stream)
 {
     if (!h || !d_sums) return SLAM3D_E_INVALID;
     if (!h->ran) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
-    return enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0, d_sums);
+    return enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0, reinterpret_cast<long long *>(d_sums));
 }
 
-extern "C" int slam3d_icp_dense_update_device(slam3d_icp_handle *h, const double *d_sums, void *stream)
+extern "C" int slam3d_icp_dense_update_device(slam3d_icp_handle *h, const int64_t *d_sums, void *stream)
 {
     if (!h || !d_sums) return SLAM3D_E_INVALID;
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
     if (!h->ran || h->dense_it >= iters) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
-    hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, s, d_sums, h->Tcur, h->trace_T, h->trace_S, h->flags, 1, h->dense_it,
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, s, reinterpret_cast<const long long *>(d_sums), h->Tcur, h->trace_T, h->trace_S, h->flags, 1, h->dense_it,
                        iters, h->p.estimator);
     HIPCHK(h, hipGetLastError());
     h->dense_it++;
     return SLAM3D_OK;
 }
 
-extern "C" int slam3d_icp_dense_finish_device(slam3d_icp_handle *h, const double *d_last_sums, void *stream,
+extern "C" int slam3d_icp_dense_finish_device(slam3d_icp_handle *h, const int64_t *d_last_sums, void *stream,
                                               slam3d_icp_result *out)
 {
     if (!h || !out || !d_last_sums) return SLAM3D_E_INVALID;
@@ -1006,16 +1003,18 @@ extern "C" int slam3d_icp_dense_finish_device(slam3d_icp_handle *h, const double
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
     double *ps = h->pin_out + 16;
     HIPCHK(h, hipMemcpyAsync(h->pin_out, h->Tcur, sizeof(double) * 16, hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipMemcpyAsync(ps, d_last_sums, sizeof(double) * NSUMS, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(ps, d_last_sums, sizeof(int64_t) * NSUMS, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(h->pin_int, h->counts, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(h->pin_int + 4, h->flags, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
-    finish_result(h->p, h->pin_out, ps, h->pin_int[4], h->pin_int[0], h->pin_int[1], out);
+    double ls[NSUMS];
+    for (int k = 0; k < NSUMS; ++k) ls[k] = (double)reinterpret_cast<const int64_t *>(ps)[k] / FIX_SCALE;
+    finish_result(h->p, h->pin_out, ls, h->pin_int[4], h->pin_int[0], h->pin_int[1], out);
     out->iterations = h->dense_it;
     return SLAM3D_OK;
 }
 
-extern "C" int slam3d_icp_dense_finish(slam3d_icp_handle *h, const double last_sums[SLAM3D_ICP_NSUMS], slam3d_icp_result *out)
+extern "C" int slam3d_icp_dense_finish(slam3d_icp_handle *h, const int64_t last_sums[SLAM3D_ICP_NSUMS], slam3d_icp_result *out)
 {
     if (!h || !out) return SLAM3D_E_INVALID;
     if (!h->ran) return SLAM3D_E_STATE;
@@ -1025,7 +1024,9 @@ extern "C" int slam3d_icp_dense_finish(slam3d_icp_handle *h, const double last_s
     HIPCHK(h, hipMemcpyAsync(h->pin_int, h->counts, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(h->pin_int + 4, h->flags, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
-    finish_result(h->p, h->pin_out, last_sums, h->pin_int[4], h->pin_int[0], h->pin_int[1], out);
+    double ls[NSUMS];
+    for (int k = 0; k < NSUMS; ++k) ls[k] = last_sums ? (double)last_sums[k] / FIX_SCALE : 0.0;
+    finish_result(h->p, h->pin_out, ls, h->pin_int[4], h->pin_int[0], h->pin_int[1], out);
     out->iterations = h->dense_it;
     return SLAM3D_OK;
 }

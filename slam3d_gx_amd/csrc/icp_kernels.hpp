@@ -197,17 +197,15 @@ __global__ __launch_bounds__(NRM_BX * NRM_BY) void k_normals(const SlotPtrs *__r
 
 // ------------------------------------------------------------------------------------ S3
 // Both organized clouds are cut into 8x8-pixel tiles: one wavefront = one tile = 64 slots.
-// Source slot id = tile*64 + (v%8)*8 + (u%8) is ALSO the summation order of S4 (level 1: the 64
-// slots of a tile, level 2: groups of 256 tiles).  Correspondences refer to targets by ORIGINAL
-// pixel index j.
+// Source slot id = tile*64 + (v%8)*8 + (u%8).  Correspondences refer to targets by ORIGINAL pixel index j.
 constexpr int TILE_PX = 8;                 // tile edge in pixels
 constexpr int TILE_SLOTS = 64;             // = one wavefront
 constexpr int TILE_REC = 72;               // target tile record: 64 slots (4 quadrants x 16) + 4 x (lo, hi) quadrant boxes
 constexpr int COARSE_TILES = 8;            // coarse box edge in tiles (64 px)
 constexpr int TILES_PER_CHUNK = CHUNK / TILE_SLOTS;
 
-// nchunks = launch blocks of 4 tiles, nslots = padded slot count, ngroups = level-2 groups,
-// tpad = ngroups*256 (padded tile count: row length of the component-major tile partials)
+// nchunks = launch blocks of 4 tiles, nslots = padded slot count (ngroups / tpad: unused since the sums became
+// integer accumulators)
 struct TileGrid { int ntx, nty, ntiles, ncx, ncy, ncoarse, nchunks, nslots, ngroups, tpad; };
 
 // ---- wave64 cross-lane helpers on the VALU (DPP within a 16-lane row, v_permlane16/32_swap across
@@ -702,78 +700,62 @@ __device__ __forceinline__ void row_sums(int estimator, float pxf, float pyf, fl
     }
 }
 
-// the spec's tree64: levels s = 32,16,..,1 of a[i] += a[i+s] (i < s).  Lane i obtains a[i+s] with
-// v_permlane32_swap (s=32: lower half <- upper half), v_permlane16_swap (s=16: row 0 <- row 1) and
-// DPP row_shl:s (s = 8,4,2,1, inside a 16-lane row); two 32-bit moves per double, no LDS.
-template <int CTRL> __device__ __forceinline__ double dpp_d(double x)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double wave_tree64(double x)
-{
-    {
-        const int lo = __double2loint(x), hi = __double2hiint(x);
-        const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-        const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-        x = x + __hiloint2double(rh[1], rl[1]);
-    }
-    {
-        const int lo = __double2loint(x), hi = __double2hiint(x);
-        const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-        const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        x = x + __hiloint2double(rh[1], rl[1]);
-    }
-    x = x + dpp_d<0x108>(x);
-    x = x + dpp_d<0x104>(x);
-    x = x + dpp_d<0x102>(x);
-    x = x + dpp_d<0x101>(x);
-    return x;      // valid in lane 0
-}
-
-// tree64 of FOUR components at once (same association as wave_tree64 for each of them):
+// Spec S4 summation: every slot's products are scaled by 2^32 and rounded to int64; the totals are exact integer
+// sums, so neither the order inside the wave, nor which block owns which tile, nor the number of GPUs changes a
+// bit.  The wave sums its 64 lanes with v_permlane32_swap / v_permlane16_swap / DPP row_shl (two 32-bit moves per
+// value, no LDS); FOUR components share one pass:
 //   level 32: v_permlane32_swap(a, b) puts a's lower/upper halves side by side with b's, so ONE add yields
 //             a[i]+a[i+32] in lanes 0..31 and b[i]+b[i+32] in lanes 32..63;
 //   level 16: v_permlane16_swap on two such registers -> rows 0..3 hold components (a, c, b, d);
 //   levels 8..1: DPP row_shl inside each 16-lane row.  Result: lanes 0,16,32,48 hold the sums of a,c,b,d.
-__device__ __forceinline__ double swap32_add(double a, double b)
+constexpr double FIX_SCALE = 4294967296.0;     // 2^32
+constexpr int ACC_R = 16;                      // accumulator replicas per pair: same-address atomics serialise
+constexpr int ACC_STRIDE = 32;                 // int64 per replica (29 used)
+
+__device__ __forceinline__ long long mk_ll(int hi, int lo) { return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo); }
+template <int CTRL> __device__ __forceinline__ long long dpp_ll(long long x)
 {
-    const auto rl = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
-    const auto rh = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
-    return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);   // (a_lo | b_lo) + (a_hi | b_hi)
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(x >> 32), CTRL, 0xf, 0xf, true);
+    return mk_ll(hi, lo);
 }
-__device__ __forceinline__ double swap16_add(double x, double y)
+__device__ __forceinline__ long long swap32_add(long long a, long long b)
 {
-    const auto rl = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
-    const auto rh = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
-    return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);   // rows (x0|y0|x2|y2) + (x1|y1|x3|y3)
+    const auto rl = __builtin_amdgcn_permlane32_swap((int)a, (int)b, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap((int)(a >> 32), (int)(b >> 32), false, false);
+    return mk_ll(rh[0], rl[0]) + mk_ll(rh[1], rl[1]);          // (a_lo | b_lo) + (a_hi | b_hi)
 }
-__device__ __forceinline__ double wave_tree64_x4(double a, double b, double c, double d)
+__device__ __forceinline__ long long swap16_add(long long x, long long y)
 {
-    double x = swap16_add(swap32_add(a, b), swap32_add(c, d));
-    x = x + dpp_d<0x108>(x);
-    x = x + dpp_d<0x104>(x);
-    x = x + dpp_d<0x102>(x);
-    x = x + dpp_d<0x101>(x);
+    const auto rl = __builtin_amdgcn_permlane16_swap((int)x, (int)y, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap((int)(x >> 32), (int)(y >> 32), false, false);
+    return mk_ll(rh[0], rl[0]) + mk_ll(rh[1], rl[1]);          // rows (x0|y0|x2|y2) + (x1|y1|x3|y3)
+}
+__device__ __forceinline__ long long wave_sum_x4(long long a, long long b, long long c, long long d)
+{
+    long long x = swap16_add(swap32_add(a, b), swap32_add(c, d));
+    x = x + dpp_ll<0x108>(x);
+    x = x + dpp_ll<0x104>(x);
+    x = x + dpp_ll<0x102>(x);
+    x = x + dpp_ll<0x101>(x);
     return x;      // lane 0: a, lane 16: c, lane 32: b, lane 48: d
 }
+__device__ __forceinline__ long long fix_ll(double v) { return __double2ll_rn(v * FIX_SCALE); }
 
-// Level 1 of the spec's reduction: the wave's 64 slots; the tile's 29 partial sums are stored
-// component-major (TP[k][tile]) so that level 2 reads them coalesced.
-__device__ __forceinline__ void tile_reduce_store(const double *__restrict__ s, double *__restrict__ TPb /*[29][tpad]*/,
-                                                  int tile, int tpad)
+// the wave's 64 slots -> the pair's accumulators (replica chosen by the block): 8 atomic instructions per wave,
+// four addresses each; tiles without a match issue none
+__device__ __forceinline__ void tile_accumulate(const double *__restrict__ s, long long *__restrict__ acc /* [ACC_STRIDE] */)
 {
     const int lane = threadIdx.x & 63;
     const int sel = lane >> 4;                       // row -> which of (a, c, b, d)
     const int koff = sel == 0 ? 0 : (sel == 1 ? 2 : (sel == 2 ? 1 : 3));
+    if (__ballot(s[27] != 0.0) == 0ull) return;
 #pragma unroll
-    for (int k = 0; k < 28; k += 4) {
-        const double x = wave_tree64_x4(s[k], s[k + 1], s[k + 2], s[k + 3]);
-        if ((lane & 15) == 0) TPb[(size_t)(k + koff) * tpad + tile] = x;
+    for (int k = 0; k < 32; k += 4) {
+        const long long x = wave_sum_x4(fix_ll(s[k]), k + 1 < NSUMS ? fix_ll(s[k + 1]) : 0ll, k + 2 < NSUMS ? fix_ll(s[k + 2]) : 0ll,
+                                        k + 3 < NSUMS ? fix_ll(s[k + 3]) : 0ll);
+        if ((lane & 15) == 0 && x != 0) atomicAdd(reinterpret_cast<unsigned long long *>(acc + k + koff), (unsigned long long)x);
     }
-    const double x = wave_tree64(s[28]);
-    if (lane == 0) TPb[(size_t)28 * tpad + tile] = x;
 }
 
 // decode a packed NN key, apply the gate, record the correspondence and form the row products
@@ -809,7 +791,7 @@ __global__ __launch_bounds__(CHUNK) void k_accumulate(const SlotPtrs *__restrict
                                                       unsigned long long *__restrict__ best,
                                                       int *__restrict__ corr, float *__restrict__ cd2,
                                                       float4 *__restrict__ prevq,
-                                                      double *__restrict__ TP, Geometry g, TileGrid tg)
+                                                      long long *__restrict__ acc, Geometry g, TileGrid tg)
 {
     const int b = blockIdx.y, c = blockIdx.x;
     const int t = c * TILES_PER_CHUNK + (threadIdx.x >> 6);
@@ -826,7 +808,7 @@ __global__ __launch_bounds__(CHUNK) void k_accumulate(const SlotPtrs *__restrict
     double s[NSUMS];
     finish_slot(valid, key, px, py, pz, slots[b].tgt, nrm_all + (size_t)b * g.N, g.gate2, g.estimator, corr + gs, cd2 + gs,
                 prevq + gs, s);
-    tile_reduce_store(s, TP + (size_t)b * NSUMS * tg.tpad, t, tg.tpad);
+    tile_accumulate(s, acc + ((size_t)b * ACC_R + (c % ACC_R)) * ACC_STRIDE);
 }
 
 // ------------------------------------------------------------------ S4, tile-pruned exact NN
@@ -874,7 +856,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
                                                         int *__restrict__ corr, float *__restrict__ cd2,
                                                         float4 *__restrict__ prevq, int *__restrict__ hint,
                                                         const int *__restrict__ perm, int *__restrict__ cost,
-                                                        double *__restrict__ TP, Geometry g, TileGrid tg,
+                                                        long long *__restrict__ acc, Geometry g, TileGrid tg,
                                                         long long *__restrict__ dbg /* nullable: 8 x int64 per tile */)
 {
     __shared__ float4 stage_all[NN_WAVES][NN_STAGE * TILE_REC];
@@ -1150,7 +1132,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
     if (__ballot(own_valid) == 0ull) bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
     double s[NSUMS];
     finish_slot(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, prevq + gs, s);
-    tile_reduce_store(s, TP + (size_t)b * NSUMS * tg.tpad, t, tg.tpad);
+    tile_accumulate(s, acc + ((size_t)b * ACC_R + (c % ACC_R)) * ACC_STRIDE);
     {   // hint for the next iteration: the tile holding the match of a lane near the tile centre
         const bool ok = s[27] != 0.0;
         const unsigned long long mm = __ballot(ok);
@@ -1385,86 +1367,50 @@ __device__ inline void solve_update_one(const double *__restrict__ sums, double 
     for (int k = 0; k < 16; ++k) trace_T_b[(size_t)(it + 1) * 16 + k] = T[k];
 }
 
-constexpr int RS_MAXGROUPS = 256;     // up to 65536 tiles = 4.2 Mpixel
-
-// Levels 2 and 3 of the reduction + solve.  grid (ngroups, B), block 256 (4 waves).  Block g reduces
-// group g (256 tile partials) of every component: one wave per tree -- lane l adds tiles (l, l+128)
-// and (l+64, l+192), then those two, then shuffles: exactly tree256's association.  The block that
-// finishes last (device-scope ticket) sums the group results in ascending order (level 3) and, when
-// do_solve, runs the 6x6 / 3x3 solve and the SE(3) update.  TP rows are zero beyond ntiles.
-__global__ __launch_bounds__(CHUNK) void k_reduce_solve(const double *__restrict__ TP, double *__restrict__ GP,
-                                                        unsigned int *__restrict__ ticket,
-                                                        double *__restrict__ sums_all,
-                                                        double *__restrict__ Tcur, double *__restrict__ trace_T,
-                                                        double *__restrict__ trace_S, int *__restrict__ flags,
-                                                        const int *__restrict__ counts, double *__restrict__ res_host,
-                                                        TileGrid tg, int it, int iters, int estimator, int do_solve)
+// The iteration's tail: grid (B), block 64.  Lane k adds the replicas of component k (integers: any order),
+// converts to double, clears the accumulators for the next launch; lane 0 solves and updates T (do_solve) or the
+// raw integer sums go to `raw_out` for the caller's all-reduce (dense mode).  In the final iteration the pose
+// record goes straight to host-mapped memory, so fetch_results is a stream synchronisation with no copies.
+__global__ __launch_bounds__(64) void k_solve_acc(long long *__restrict__ acc, long long *__restrict__ raw_out,
+                                                  double *__restrict__ Tcur, double *__restrict__ trace_T,
+                                                  double *__restrict__ trace_S, int *__restrict__ flags,
+                                                  const int *__restrict__ counts, double *__restrict__ res_host,
+                                                  int it, int iters, int estimator, int do_solve)
 {
     __shared__ double tot[NSUMS];
-    __shared__ int is_last;
-    const int gq = blockIdx.x, b = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const double *__restrict__ P = TP + (size_t)b * NSUMS * tg.tpad + (size_t)gq * CHUNK + lane;
-    double *__restrict__ G = GP + (size_t)b * RS_MAXGROUPS * NSUMS;
-    double x[8];
+    const int b = blockIdx.x, k = threadIdx.x;
+    long long *__restrict__ A = acc + (size_t)b * ACC_R * ACC_STRIDE;
+    if (k < NSUMS) {
+        long long q = 0;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int k = w + 4 * r;
-        x[r] = 0.0;
-        if (k < NSUMS) {
-            const double *__restrict__ Pk = P + (size_t)k * tg.tpad;
-            x[r] = (Pk[0] + Pk[128]) + (Pk[64] + Pk[192]);
-        }
-    }
+        for (int r = 0; r < ACC_R; ++r) q += __hip_atomic_load(A + r * ACC_STRIDE + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int k = w + 4 * r;
-        const double y = wave_tree64(x[r]);
-        // 8-byte agent-scope (write-through) store: visible to the block that finishes last without an L2 release
-        if (k < NSUMS && lane == 0) __hip_atomic_store(G + gq * NSUMS + k, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // Inter-workgroup hand-off on gfx950 (per-CU L1 and per-XCD L2 are not coherent): both sides use 8-byte
-    // agent-scope accesses for the payload (stores write through, loads bypass L1/stale L2 lines), every wave
-    // drains its stores before the block takes its ticket, and the ticket is an agent-scope atomic.
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned int prev = __hip_atomic_fetch_add(ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = (prev == (unsigned int)(tg.ngroups - 1));
-        if (is_last) __hip_atomic_store(ticket + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        for (int r = 0; r < ACC_R; ++r) A[r * ACC_STRIDE + k] = 0;
+        if (raw_out) raw_out[b * NSUMS + k] = q;
+        tot[k] = (double)q / FIX_SCALE;
     }
     __syncthreads();
-    if (!is_last) return;
-    if (threadIdx.x < NSUMS) {
-        double a = __hip_atomic_load(G + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int q = 1; q < tg.ngroups; ++q)
-            a = a + __hip_atomic_load(G + q * NSUMS + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        tot[threadIdx.x] = a;
-        sums_all[b * NSUMS + threadIdx.x] = a;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && do_solve) {
+    if (k == 0 && do_solve) {
         solve_update_one(tot, Tcur + b * 16, trace_T + (size_t)b * (iters + 1) * 16, trace_S + (size_t)b * iters * NSUMS,
                          flags + b, it, estimator);
         if (res_host && it == iters - 1) {
-            // final iteration: the pose record goes straight to host-mapped memory (T, last sums, degenerate flag,
-            // n_src, n_tgt), so fetch_results is a stream synchronisation with no copy launches behind it
             double *__restrict__ r = res_host + (size_t)b * RES_REC;
-            for (int k = 0; k < 16; ++k) r[k] = Tcur[b * 16 + k];
-            for (int k = 0; k < NSUMS; ++k) r[16 + k] = tot[k];
+            for (int j = 0; j < 16; ++j) r[j] = Tcur[b * 16 + j];
+            for (int j = 0; j < NSUMS; ++j) r[16 + j] = tot[j];
             r[45] = (double)flags[b]; r[46] = (double)counts[b * 4]; r[47] = (double)counts[b * 4 + 1];
         }
     }
 }
 
 // dense mode: solve from externally reduced sums (one thread per pair)
-__global__ void k_solve(const double *__restrict__ sums_all, double *__restrict__ Tcur,
+__global__ void k_solve(const long long *__restrict__ sums_all, double *__restrict__ Tcur,
                         double *__restrict__ trace_T, double *__restrict__ trace_S,
                         int *__restrict__ flags, int B, int it, int iters, int estimator)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     double sums[NSUMS];
-    for (int k = 0; k < NSUMS; ++k) sums[k] = sums_all[b * NSUMS + k];
+    for (int k = 0; k < NSUMS; ++k) sums[k] = (double)sums_all[b * NSUMS + k] / FIX_SCALE;     // all-reduced integer sums
     solve_update_one(sums, Tcur + b * 16, trace_T + (size_t)b * (iters + 1) * 16, trace_S + (size_t)b * iters * NSUMS,
                      flags + b, it, estimator);
 }

@@ -178,8 +178,8 @@ def test_odd_image_size_not_multiple_of_tile(gpu_lib):
 
 def test_dense_mode_two_emulated_ranks(gpu_lib):
     """Dense mode (config 5 shape, reduced): one pair, source rows sharded over 2 'ranks' (two handles on one
-    GPU, host-side sum standing in for the RCCL all-reduce).  Indices are unaffected by the sharding; the pose
-    differs from the oracle only by the fp64 summation order across ranks (<< 1e-4)."""
+    GPU, host-side integer sum standing in for the RCCL all-reduce).  Indices are unaffected by the sharding, and
+    the int64 fixed-point sums make the pose independent of it too."""
     from slam3d_gx_amd import dense, shard
     pr, s4, t4 = _pair(1002, 320, 240)
     iters = 6
@@ -204,6 +204,8 @@ def test_dense_mode_two_emulated_ranks(gpu_lib):
     assert np.array_equal(res[0]["T_raw"], res[1]["T_raw"])            # every rank holds the same pose
     rot, tr = O.pose_error(ro["T_trace"][-1], res[0]["T_raw"])
     assert rot <= ROT_TOL and tr <= TRANS_TOL
+    # integer fixed-point sums are order-free: the sharded run equals the unsharded oracle bit for bit
+    assert np.array_equal(res[0]["T_raw"], ro["T_trace"][-1])
     assert res[0]["inliers"] == ro["inliers"]
     r0, r1 = shard.dense_row_range(pr.intr.height, 2, 0)
     W = pr.intr.width
@@ -216,7 +218,7 @@ def test_dense_mode_two_emulated_ranks(gpu_lib):
     assert np.array_equal(r1rank["T_raw"], ro["T_trace"][-1])
     # device-resident exchange buffer (what bench.py --mode dense runs over RCCL): same bits again
     import torch
-    d_sums = torch.zeros(29, dtype=torch.float64, device="cuda:0")
+    d_sums = torch.zeros(29, dtype=torch.int64, device="cuda:0")
     with capi.IcpHandle(capi.default_params(pr.intr, iterations=iters)) as h:
         h.set_clouds_host(0, s4, t4)
         rdev = dense.dense_align_device(h, 1, 0, d_sums, None, torch.cuda.current_stream().cuda_stream)

@@ -100,7 +100,7 @@ def _dense_worker(rank, world, port, q):
         def dense_begin(self, T, stream): self.it = 0
         def dense_partial(self, stream):
             a, b = self.rows
-            return np.arange(29, dtype=np.float64) * (b - a) + 1000.0 * self.it + a
+            return np.arange(29, dtype=np.int64) * (b - a) + 1000 * self.it + a
         def dense_update(self, total, stream): self.updates.append(total.copy()); self.it += 1
         def dense_finish(self, total): return dict(total=total.copy(), updates=self.updates)
 
@@ -125,6 +125,6 @@ def test_dense_allreduce_loop_two_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     # rows 0..24 and 24..48; last iteration it=2: sum over ranks of (k*24 + 2000 + a)
-    want = np.arange(29.0) * 48 + 4000.0 + 24.0
+    want = np.arange(29, dtype=np.int64) * 48 + 4000 + 24
     assert np.array_equal(got[0][1], want) and np.array_equal(got[1][1], want)
     assert got[0][2] == (0, 48) and got[1][2] == (0, 48)      # rows restored after the run
