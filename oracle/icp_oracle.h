@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 #define ORC_NSUMS 29          /* 21 upper-tri AtA + 6 Atb + count + sum r^2   */
-#define ORC_CHUNK 256         /* reduction chunk of the deterministic tree    */
+#define ORC_CHUNK 256         /* (historic) launch block of four tiles            */
 
 enum { ORC_EST_POINT2PLANE = 0, ORC_EST_SVD = 1 };
 enum { ORC_NN_BRUTE = 0, ORC_NN_KDTREE = 1 };

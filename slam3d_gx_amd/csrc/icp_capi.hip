@@ -486,7 +486,7 @@ extern "C" int slam3d_icp_fetch_results(slam3d_icp_handle *h, int32_t B, slam3d_
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = h->run_stream;
     const int iters = h->p.iterations;
-    if (h->res_mapped) {        // the final k_reduce_solve wrote the records into host-mapped memory
+    if (h->res_mapped) {        // the final k_solve_acc wrote the records into host-mapped memory
         HIPCHK(h, hipStreamSynchronize(s));
         for (int b = 0; b < B; ++b) {
             const double *r = h->pin_res + (size_t)b * RES_REC;

@@ -8,7 +8,7 @@
 //   S4 k_nn_tiles_acc     exact tile-pruned 1-NN fused with the normal-equation accumulation
 //      k_nn_valu          exact full brute-force 1-NN (replaces FLANN matching, src/GraphicEnd.cpp:486-520)
 //      k_accumulate       point-to-plane / Kabsch normal equations, deterministic 256-slot chunk tree
-//   S5 k_reduce_solve     29-double reduction, 6x6 LDL^T or 3x3 SVD, SE(3) update on device
+//   S5 k_solve_acc        integer accumulators -> 29 sums, 6x6 LDL^T or 3x3 SVD, SE(3) update on device
 //   a6 k_plane_sums       per-plane {sum p, sum pp^T, n} -> (n,d)   src/GraphicEnd.cpp:360-387
 //
 // Numerics contract: compiled with -ffp-contract=off; every float/double operation is an
@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
     if (dbg) clk3 = clock64();
     if (!has_tile) return;
     if (lane == 0) cost[(size_t)b * tg.ntiles + t] = wcost[w];           // input of k_balance
-    // ================= step 4: this wave's own tile: fused S4 accumulation, level 1 =================
+    // ================= step 4: this wave's own tile: fused S4 accumulation =================
     bkey = qkey[w][lane];
     if (__ballot(own_valid) == 0ull) bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
     double s[NSUMS];

@@ -113,3 +113,19 @@ def test_fit_planes_synthetic_room():
     assert (counts > 100).all()
     assert np.allclose(planes, expect, atol=5e-3)
     assert (planes[:, 3] >= 0).all()
+
+
+def test_sums_are_fixed_point_integers_and_order_free():
+    """Spec S4 summation: every total is an exact multiple of 2^-32 (int64 fixed point), the count is an integer,
+    and a permuted / re-threaded evaluation gives the same bits (integer addition is associative)."""
+    pr = synth.make_pair(1003, 160, 120)
+    s4 = synth.backproject_numpy(pr.depth_src, pr.intr)
+    t4 = synth.backproject_numpy(pr.depth_tgt, pr.intr)
+    for est in (0, 1):
+        r1 = O.icp(s4, t4, O.params(pr.intr, estimator=est, iterations=3, threads=1))
+        r5 = O.icp(s4, t4, O.params(pr.intr, estimator=est, iterations=3, threads=5))
+        assert np.array_equal(r1["sums_trace"], r5["sums_trace"]) and np.array_equal(r1["T_trace"], r5["T_trace"])
+        q = r1["sums_trace"] * 4294967296.0
+        assert np.array_equal(q, np.rint(q)) and np.abs(q).max() < 2.0 ** 53          # exactly representable here
+        assert np.array_equal(r1["sums_trace"][:, 27], np.rint(r1["sums_trace"][:, 27]))
+        assert r1["inliers"] == int(r1["sums_trace"][-1, 27])
