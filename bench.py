@@ -130,9 +130,9 @@ def committed_traffic():
     try:
         with open(path) as f:
             d = json.load(f)
-        return d["k_nn_tiles_acc"]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+        return d["k_nn_tiles_acc"]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT), d["k_nn_tiles_acc"]
     except Exception:
-        return None, None
+        return None, None, {}
 
 
 def seg_mode(args, torch, dist, capi, synth, world, rank, local_rank, dev):
@@ -400,13 +400,15 @@ def main():
                                "launch_ms": launch_ms, "flops_per_launch": flops}
         else:
             ach = alg_bytes / (launch_ms * 1e-3) / 1e9
-            traffic, src = committed_traffic() if (P == 1 and size_tag == "640x480" and est == 0) else (None, None)
+            traffic, src, prof = committed_traffic() if (P == 1 and size_tag == "640x480" and est == 0) else (None, None, {})
             out["roofline"] = {
                 "kernel": "k_nn_tiles_acc (exact tile-pruned NN + fused normal-equation accumulation)",
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                 "traffic": traffic, "traffic_source": src, "launch_ms": launch_ms,
                 "launch_ms_source": "HIP events around every k_nn_tiles_acc launch, second pass over the same K steps",
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "valu_issue_floor_us": prof.get("valu_issue_floor_us"),      # from the committed PMC profile: the bound that applies
+                "valu_instructions_per_wave": prof.get("valu_instructions_per_wave"),
                 "equivalent_bruteforce_tflops": flops / (launch_ms * 1e-3) / 1e12,
                 "note": ("streaming accounting (each array once per iteration); the kernel is VALU-issue/latency bound, "
                          "not HBM bound -- see DESIGN.md section 6; equivalent_bruteforce_tflops = flops a full scan "

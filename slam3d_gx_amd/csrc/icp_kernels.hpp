@@ -712,38 +712,41 @@ constexpr double FIX_SCALE = 4294967296.0;     // 2^32
 constexpr int ACC_R = 16;                      // accumulator replicas per pair: same-address atomics serialise
 constexpr int ACC_STRIDE = 32;                 // int64 per replica (29 used)
 
-__device__ __forceinline__ long long mk_ll(int hi, int lo) { return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo); }
-template <int CTRL> __device__ __forceinline__ long long dpp_ll(long long x)
+template <int CTRL> __device__ __forceinline__ double dpp_d(double x)
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(x >> 32), CTRL, 0xf, 0xf, true);
-    return mk_ll(hi, lo);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ long long swap32_add(long long a, long long b)
+__device__ __forceinline__ double swap32_add(double a, double b)
 {
-    const auto rl = __builtin_amdgcn_permlane32_swap((int)a, (int)b, false, false);
-    const auto rh = __builtin_amdgcn_permlane32_swap((int)(a >> 32), (int)(b >> 32), false, false);
-    return mk_ll(rh[0], rl[0]) + mk_ll(rh[1], rl[1]);          // (a_lo | b_lo) + (a_hi | b_hi)
+    const auto rl = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+    return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);   // (a_lo | b_lo) + (a_hi | b_hi)
 }
-__device__ __forceinline__ long long swap16_add(long long x, long long y)
+__device__ __forceinline__ double swap16_add(double x, double y)
 {
-    const auto rl = __builtin_amdgcn_permlane16_swap((int)x, (int)y, false, false);
-    const auto rh = __builtin_amdgcn_permlane16_swap((int)(x >> 32), (int)(y >> 32), false, false);
-    return mk_ll(rh[0], rl[0]) + mk_ll(rh[1], rl[1]);          // rows (x0|y0|x2|y2) + (x1|y1|x3|y3)
+    const auto rl = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
+    return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);   // rows (x0|y0|x2|y2) + (x1|y1|x3|y3)
 }
-__device__ __forceinline__ long long wave_sum_x4(long long a, long long b, long long c, long long d)
+__device__ __forceinline__ double wave_sum_x4(double a, double b, double c, double d)
 {
-    long long x = swap16_add(swap32_add(a, b), swap32_add(c, d));
-    x = x + dpp_ll<0x108>(x);
-    x = x + dpp_ll<0x104>(x);
-    x = x + dpp_ll<0x102>(x);
-    x = x + dpp_ll<0x101>(x);
+    double x = swap16_add(swap32_add(a, b), swap32_add(c, d));
+    x = x + dpp_d<0x108>(x);
+    x = x + dpp_d<0x104>(x);
+    x = x + dpp_d<0x102>(x);
+    x = x + dpp_d<0x101>(x);
     return x;      // lane 0: a, lane 16: c, lane 32: b, lane 48: d
 }
-__device__ __forceinline__ long long fix_ll(double v) { return __double2ll_rn(v * FIX_SCALE); }
+// a slot's term in fixed-point units, as an integer-valued double: v * 2^32 is exact, rint rounds to nearest-even
+// like the oracle's llrint.  |term| < 2^39, so the 64-lane sums below stay under 2^53 and every fp64 add of these
+// integers is EXACT -- the wave may add them in any order, in the fp64 pipe, one instruction per add.
+__device__ __forceinline__ double fix_d(double v) { return rint(v * FIX_SCALE); }
 
-// the wave's 64 slots -> the pair's accumulators (replica chosen by the block): 8 atomic instructions per wave,
-// four addresses each; tiles without a match issue none
+// the wave's 64 slots -> the pair's accumulators (replica chosen by the block): the wave total of each component
+// is converted to int64 once (four components per pass sit in lanes 0/16/32/48) and leaves as 8 atomic
+// instructions of four addresses each; tiles without a match issue none
 __device__ __forceinline__ void tile_accumulate(const double *__restrict__ s, long long *__restrict__ acc /* [ACC_STRIDE] */)
 {
     const int lane = threadIdx.x & 63;
@@ -752,9 +755,9 @@ __device__ __forceinline__ void tile_accumulate(const double *__restrict__ s, lo
     if (__ballot(s[27] != 0.0) == 0ull) return;
 #pragma unroll
     for (int k = 0; k < 32; k += 4) {
-        const long long x = wave_sum_x4(fix_ll(s[k]), k + 1 < NSUMS ? fix_ll(s[k + 1]) : 0ll, k + 2 < NSUMS ? fix_ll(s[k + 2]) : 0ll,
-                                        k + 3 < NSUMS ? fix_ll(s[k + 3]) : 0ll);
-        if ((lane & 15) == 0 && x != 0) atomicAdd(reinterpret_cast<unsigned long long *>(acc + k + koff), (unsigned long long)x);
+        const double x = wave_sum_x4(fix_d(s[k]), k + 1 < NSUMS ? fix_d(s[k + 1]) : 0.0, k + 2 < NSUMS ? fix_d(s[k + 2]) : 0.0,
+                                     k + 3 < NSUMS ? fix_d(s[k + 3]) : 0.0);
+        if ((lane & 15) == 0 && x != 0.0) atomicAdd(reinterpret_cast<unsigned long long *>(acc + k + koff), (unsigned long long)__double2ll_rn(x));
     }
 }
 

@@ -46,5 +46,21 @@ if (k, "FETCH_SIZE") in rows and (k, "WRITE_SIZE") in rows:
            "k_nn_tiles_acc": {"fetch_size_kib": round(f, 1), "write_size_kib": round(w, 1), "hbm_bytes_per_launch": int((2 * f + w) * 1024),
                               "hbm_bytes_per_launch_uncorrected": int((f + w) * 1024),
                               "algorithmic_bytes_per_launch": bench.get("roofline", {}).get("algorithmic_bytes_per_launch")}}
+    sq = {c: rows[(k, c)][0] for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
+                                        "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY") if (k, c) in rows}
+    if "SQ_ACTIVE_INST_VALU" in sq and (k, "SQ_BUSY_CYCLES") in rows:
+        # quad-cycle counters: VALU-active quad-cycles summed over the 1024 SIMDs / (launch duration in quad-cycles x 1024)
+        dur_ns = None
+        try:
+            c = sqlite3.connect(glob.glob(os.path.join(src, "pmc_SQ_WAVE_CYCLES", "*.db"))[0])
+            dur_ns = c.execute("select avg(duration) from kernels where name like '%k_nn_tiles_acc%'").fetchone()[0]
+        except Exception:
+            pass
+        out["k_nn_tiles_acc"]["sq_counters_per_launch"] = {kk: round(v, 1) for kk, v in sq.items()}
+        if dur_ns:
+            out["k_nn_tiles_acc"]["launch_ns_in_pmc_run"] = round(dur_ns, 1)
+            out["k_nn_tiles_acc"]["valu_instructions_per_wave"] = round(sq.get("SQ_INSTS_VALU", 0) / max(sq.get("SQ_WAVES", 1), 1), 1)
+            # 4 cycles per wave64 VALU instruction on a 16-lane SIMD, 1024 SIMDs, ~2.3 GHz
+            out["k_nn_tiles_acc"]["valu_issue_floor_us"] = round(sq.get("SQ_INSTS_VALU", 0) * 4 / 1024 / 2.3e3, 2)
     json.dump(out, open(os.path.join(dst, "r01_traffic.json"), "w"), indent=1)
 print(json.dumps({k2: bench[k2] for k2 in ("value", "ms_per_step")}), "written", tag)
