@@ -7,11 +7,11 @@
 //
 //   k_voxel_insert   one thread per point: 64-bit voxel key (iz,iy,ix) -> open-addressing hash table in HBM
 //                    (capacity >= 2n, linear probing, atomicCAS on the key), atomic adds into the entry
-//   k_voxel_compact  occupied slots -> dense list (one global ticket per block) + histogram of the z slabs
-//   k_voxel_scan / k_voxel_scatter   counting sort of the list by slab (iz is the most significant key field)
+//   k_voxel_compact  occupied slots -> dense list (one global ticket per block) + histogram of the (iz, iy) rows
+//   k_voxel_scan / k_voxel_scatter   counting sort of the list by row (iz, iy are the most significant key fields)
 //   k_voxel_rank     output order = ascending key, like PCL's sorted linear voxel index: rank = start of the
-//                    slab + number of smaller keys inside the slab (LDS-tiled compares), centroid written at
-//                    that rank.  No host round trip anywhere: the entry count stays on the device.
+//                    rows a block touches + number of smaller keys among them (LDS-tiled compares), centroid
+//                    written at that rank.  No host round trip anywhere: the entry count stays on the device.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -47,70 +47,85 @@ __device__ __forceinline__ unsigned int vox_hash(unsigned long long k)
     return (unsigned int)(k ^ (k >> 31));
 }
 
+// inclusive sum over the lanes of the same run (runs = maximal stretches of consecutive lanes with equal keys,
+// numbered by `seg`): Hillis-Steele with a segment test; integer adds, so exact
+template <typename T> __device__ __forceinline__ T run_scan(T v, int seg)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const T u = __shfl_up(v, o);
+        const int su = __shfl_up(seg, o);
+        if (lane >= o && su == seg) v += u;
+    }
+    return v;
+}
+
+// One thread per point.  Neighbouring pixels of an organized cloud fall into the same voxel 3-10 times in a row,
+// and atomics of one wave to one address serialise, so each run of equal keys inside the wave is summed first
+// (integers: same bits) and only the last lane of the run touches the table.
 __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(const float4 *__restrict__ pts, int n, float inv_leaf, float zmax,
                                                             VoxTable t)
 {
     const int i = blockIdx.x * VOX_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = pts[i];
-    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && p.z >= 0.0f && p.z <= zmax)) return;     // PassThrough
-    const unsigned long long key = vox_key(p.x, p.y, p.z, inv_leaf);
+    const int lane = threadIdx.x & 63;
+    float4 p = make_float4(0.0f, 0.0f, -1.0f, 0.0f);
+    if (i < n) p = pts[i];
+    const bool ok = isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && p.z >= 0.0f && p.z <= zmax;     // PassThrough
+    const unsigned long long key = ok ? vox_key(p.x, p.y, p.z, inv_leaf) : VOX_EMPTY;
+    const unsigned long long prev = __shfl_up(key, 1);
+    const bool head = lane == 0 || prev != key;
+    const unsigned long long heads = __ballot(head);
+    const int seg = __popcll(heads & ((2ull << lane) - 1ull));                  // run number of this lane
+    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+    const unsigned int rgba = (unsigned int)__float_as_int(p.w);
+    const long long qx = run_scan(ok ? __double2ll_rn((double)p.x * 1048576.0) : 0ll, seg);
+    const long long qy = run_scan(ok ? __double2ll_rn((double)p.y * 1048576.0) : 0ll, seg);
+    const long long qz = run_scan(ok ? __double2ll_rn((double)p.z * 1048576.0) : 0ll, seg);
+    // colour channels and the count travel packed: (c0 | c1 << 32), (c2 | c3 << 32) and the count stay below 2^32 each
+    // inside a wave (64 x 255)
+    const unsigned long long c01 = run_scan((unsigned long long)(rgba & 0xffu) | ((unsigned long long)((rgba >> 8) & 0xffu) << 32), seg);
+    const unsigned long long c23 = run_scan((unsigned long long)((rgba >> 16) & 0xffu) | ((unsigned long long)(rgba >> 24) << 32), seg);
+    const int cnt = run_scan(1, seg);
+    if (!ok || !tail) return;
     unsigned int s = vox_hash(key) & (unsigned int)(t.cap - 1);
     for (;;) {
-        const unsigned long long prev = atomicCAS(t.key + s, VOX_EMPTY, key);
-        if (prev == VOX_EMPTY || prev == key) break;
+        const unsigned long long was = atomicCAS(t.key + s, VOX_EMPTY, key);
+        if (was == VOX_EMPTY || was == key) break;
         s = (s + 1) & (unsigned int)(t.cap - 1);
     }
-    const unsigned int rgba = (unsigned int)__float_as_int(p.w);
-    atomicAdd(reinterpret_cast<unsigned long long *>(t.sx + s), (unsigned long long)__double2ll_rn((double)p.x * 1048576.0));
-    atomicAdd(reinterpret_cast<unsigned long long *>(t.sy + s), (unsigned long long)__double2ll_rn((double)p.y * 1048576.0));
-    atomicAdd(reinterpret_cast<unsigned long long *>(t.sz + s), (unsigned long long)__double2ll_rn((double)p.z * 1048576.0));
-    atomicAdd(t.c0 + s, rgba & 0xffu);
-    atomicAdd(t.c1 + s, (rgba >> 8) & 0xffu);
-    atomicAdd(t.c2 + s, (rgba >> 16) & 0xffu);
-    atomicAdd(t.c3 + s, rgba >> 24);
-    atomicAdd(t.n + s, 1u);
+    atomicAdd(reinterpret_cast<unsigned long long *>(t.sx + s), (unsigned long long)qx);
+    atomicAdd(reinterpret_cast<unsigned long long *>(t.sy + s), (unsigned long long)qy);
+    atomicAdd(reinterpret_cast<unsigned long long *>(t.sz + s), (unsigned long long)qz);
+    atomicAdd(t.c0 + s, (unsigned int)c01);
+    atomicAdd(t.c1 + s, (unsigned int)(c01 >> 32));
+    atomicAdd(t.c2 + s, (unsigned int)c23);
+    atomicAdd(t.c3 + s, (unsigned int)(c23 >> 32));
+    atomicAdd(t.n + s, (unsigned int)cnt);
 }
 
-constexpr int VOX_BINS = 8192;        // z slabs of the ordering pass (iz clamped: the order stays monotone)
+constexpr int VOX_BZ = 256, VOX_BY = 256;   // ordering bins: (iz, iy) rows, both clamped (the order stays monotone)
+constexpr int VOX_BINS = VOX_BZ * VOX_BY;
 constexpr int VOX_SPT = 16;           // table slots per thread in k_voxel_compact
 
+// bin = the (iz, iy) row of the voxel: a monotone function of the key (clamping only merges rows at the ends), so
+// bins are ordered like keys and a row holds at most one voxel per ix -- a few hundred entries even for a wall
+// that fills a whole z slab
 __device__ __forceinline__ int vox_bin(unsigned long long key)
 {
-    const long long iz = (long long)(key >> 42) - 1048576;       // >= 0 after PassThrough
-    return (int)(iz < 0 ? 0 : (iz > VOX_BINS - 1 ? VOX_BINS - 1 : iz));
+    const int iz = (int)(key >> 42) - 1048576;                   // >= 0 after PassThrough
+    const int iy = (int)((key >> 21) & 0x1FFFFF) - 1048576 + VOX_BY / 2;
+    const int bz = iz < 0 ? 0 : (iz > VOX_BZ - 1 ? VOX_BZ - 1 : iz);
+    const int by = iy < 0 ? 0 : (iy > VOX_BY - 1 ? VOX_BY - 1 : iy);
+    return bz * VOX_BY + by;
 }
 
-// counter[bin] += 1 for every active lane, returning the lane's ticket; lanes of the wave that hit the same bin
-// share ONE atomic (a wall at constant depth puts 40 % of the voxels into one slab: per-lane atomics on that
-// address serialise)
-__device__ __forceinline__ int wave_ticket(int *__restrict__ counter, int bin, bool active)
-{
-    const int lane = threadIdx.x & 63;
-    int ticket = 0;
-    unsigned long long todo = __ballot(active);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int b0 = __shfl(bin, leader);
-        const unsigned long long grp = __ballot(active && bin == b0) & todo;
-        int base = 0;
-        if (lane == leader) base = atomicAdd(counter + b0, __popcll(grp));
-        base = __shfl(base, leader);
-        if ((grp >> lane) & 1ull) ticket = base + __popcll(grp & ((1ull << lane) - 1ull));
-        todo &= ~grp;
-    }
-    return ticket;
-}
-
-// occupied slots -> dense (key, slot) list + histogram of the z slabs.  Each block scans 4096 slots, takes ONE
-// ticket from the global counter and flushes ONE block-local histogram (same-address global atomics serialise:
-// one per wave cost 166 us here).
+// occupied slots -> dense (key, slot) list + histogram of the (iz, iy) rows.  Each block scans 4096 slots and
+// takes ONE ticket from the global counter (same-address global atomics serialise: one per wave cost 166 us).
 __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_compact(VoxTable t, unsigned long long *__restrict__ lkey, int *__restrict__ lslot,
                                                              int *__restrict__ m, int *__restrict__ hist)
 {
     __shared__ int wsum[VOX_BLOCK / 64], base_sh;
-    __shared__ int lh[VOX_BINS];                                 // block-local slab histogram (32 KB of LDS)
-    for (int k = threadIdx.x; k < VOX_BINS; k += VOX_BLOCK) lh[k] = 0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int s0 = blockIdx.x * VOX_BLOCK * VOX_SPT;
     unsigned long long k[VOX_SPT];
@@ -137,23 +152,25 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_compact(VoxTable t, unsigne
         if (k[j] != VOX_EMPTY) {
             lkey[pos] = k[j];
             lslot[pos] = s0 + j * VOX_BLOCK + threadIdx.x;
-            atomicAdd(&lh[vox_bin(k[j])], 1);                    // LDS atomic; flushed once per block below
+            atomicAdd(hist + vox_bin(k[j]), 1);                  // 65536 rows, hashed order: no address is hot
             ++pos;
         }
     }
-    __syncthreads();
-    for (int k = threadIdx.x; k < VOX_BINS; k += VOX_BLOCK)
-        if (lh[k]) atomicAdd(hist + k, lh[k]);
 }
 
-// exclusive prefix of the slab histogram -> start[]; cursor[] reset.  one block of 1024
+// exclusive prefix of the row histogram -> start[]; cursor[] reset.  one block of 1024
 __global__ __launch_bounds__(1024) void k_voxel_scan(const int *__restrict__ hist, int *__restrict__ start, int *__restrict__ cursor)
 {
     __shared__ int part[1024];
     constexpr int PER = VOX_BINS / 1024;
     int loc[PER], sum = 0;
+    const int4 *__restrict__ h4 = reinterpret_cast<const int4 *>(hist + threadIdx.x * PER);
 #pragma unroll
-    for (int j = 0; j < PER; ++j) { loc[j] = hist[threadIdx.x * PER + j]; sum += loc[j]; }
+    for (int j = 0; j < PER / 4; ++j) {
+        const int4 v = h4[j];
+        loc[4 * j] = v.x; loc[4 * j + 1] = v.y; loc[4 * j + 2] = v.z; loc[4 * j + 3] = v.w;
+        sum += (v.x + v.y) + (v.z + v.w);
+    }
     part[threadIdx.x] = sum;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
@@ -172,7 +189,7 @@ __global__ __launch_bounds__(1024) void k_voxel_scan(const int *__restrict__ his
     if (threadIdx.x == 1023) start[VOX_BINS] = run;
 }
 
-// group the list by slab (order inside a slab is arbitrary; k_voxel_rank fixes it)
+// group the list by row (order inside a row is arbitrary; k_voxel_rank fixes it)
 __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_scatter(const unsigned long long *__restrict__ lkey, const int *__restrict__ lslot,
                                                              const int *__restrict__ m, const int *__restrict__ start,
                                                              int *__restrict__ cursor, unsigned long long *__restrict__ gkey,
@@ -182,17 +199,16 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_scatter(const unsigned long
     const bool live = e < *m;
     const unsigned long long k = live ? lkey[e] : 0ull;
     const int b = live ? vox_bin(k) : 0;
-    const int tk = wave_ticket(cursor, b, live);
     if (!live) return;
-    const int pos = start[b] + tk;
+    const int pos = start[b] + atomicAdd(cursor + b, 1);
     gkey[pos] = k;
     gslot[pos] = lslot[e];
 }
 
-// Output order = ascending key, like PCL's sorted linear voxel index.  Keys are grouped by slab and slabs are
-// ordered, so an entry's rank = start of its slab + the keys of that slab below its own: the block stages the
-// union of its entries' slabs through LDS and every thread compares inside its own slab only.  grid covers the
-// worst case (n entries); blocks beyond *m leave at once.
+// Output order = ascending key, like PCL's sorted linear voxel index.  Keys are grouped by (iz, iy) row and rows
+// are ordered, so an entry's rank = start of the first row its block touches + the keys of the block's rows below
+// its own: the block stages the union of its entries' rows through LDS.  grid covers the worst case (n entries);
+// blocks beyond *m leave at once.
 __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_rank(VoxTable t, const unsigned long long *__restrict__ gkey,
                                                           const int *__restrict__ gslot, const int *__restrict__ m,
                                                           const int *__restrict__ start, float4 *__restrict__ out)
