@@ -711,27 +711,24 @@ void orc_fit_planes(const float *xyz4, const int32_t *labels, int n, int nplanes
                     float *planes, int32_t *counts)
 {
     for (int pl = 0; pl < nplanes; ++pl) {
-        /* sums relative to the first labelled point, in index order, 256-chunk tree like S4 */
-        int first = -1;
-        for (int i = 0; i < n; ++i) if (labels[i] == pl) { first = i; break; }
+        /* integer fixed-point (2^-16 m) moments about the sensor origin: exact, order-free sums (same arithmetic
+         * as P3 of the segmentation spec) */
         planes[4 * pl] = planes[4 * pl + 1] = planes[4 * pl + 2] = planes[4 * pl + 3] = 0.0f;
         counts[pl] = 0;
-        if (first < 0) continue;
-        const double ox = xyz4[4 * (size_t)first], oy = xyz4[4 * (size_t)first + 1], oz = xyz4[4 * (size_t)first + 2];
-        double s[10] = { 0 };
+        int64_t m[10] = { 0 };
         for (int i = 0; i < n; ++i) {
             if (labels[i] != pl) continue;
-            const double dx = (double)xyz4[4 * (size_t)i] - ox, dy = (double)xyz4[4 * (size_t)i + 1] - oy,
-                         dz = (double)xyz4[4 * (size_t)i + 2] - oz;
-            s[0] += 1.0; s[1] += dx; s[2] += dy; s[3] += dz;
-            s[4] += dx * dx; s[5] += dx * dy; s[6] += dx * dz; s[7] += dy * dy; s[8] += dy * dz; s[9] += dz * dz;
+            const int64_t x = llrint((double)xyz4[4 * (size_t)i] * 65536.0), y = llrint((double)xyz4[4 * (size_t)i + 1] * 65536.0),
+                          z = llrint((double)xyz4[4 * (size_t)i + 2] * 65536.0);
+            m[0] += 1; m[1] += x; m[2] += y; m[3] += z;
+            m[4] += x * x; m[5] += x * y; m[6] += x * z; m[7] += y * y; m[8] += y * z; m[9] += z * z;
         }
-        counts[pl] = (int32_t)s[0];
-        if (s[0] < 3.0) continue;
-        const double inv = 1.0 / s[0];
-        const double mx = s[1] * inv, my = s[2] * inv, mz = s[3] * inv;
-        double C[6] = { s[4] * inv - mx * mx, s[5] * inv - mx * my, s[6] * inv - mx * mz,
-                        s[7] * inv - my * my, s[8] * inv - my * mz, s[9] * inv - mz * mz };
+        counts[pl] = (int32_t)m[0];
+        if (m[0] < 3) continue;
+        const double inv = 1.0 / (double)m[0];
+        const double mx = (double)m[1] * inv, my = (double)m[2] * inv, mz = (double)m[3] * inv;
+        double C[6] = { (double)m[4] * inv - mx * mx, (double)m[5] * inv - mx * my, (double)m[6] * inv - mx * mz,
+                        (double)m[7] * inv - my * my, (double)m[8] * inv - my * mz, (double)m[9] * inv - mz * mz };
         double ev[3], V[9];
         orc_eig3(C, ev, V);
         int k = 0;
@@ -739,9 +736,10 @@ void orc_fit_planes(const float *xyz4, const int32_t *labels, int n, int nplanes
         if (ev[2] < ev[k]) k = 2;
         double nx = V[0 + k], ny = V[3 + k], nz = V[6 + k];
         const double len = sqrt(nx * nx + ny * ny + nz * nz);
-        nx /= len; ny /= len; nz /= len;
-        double d = -(nx * (ox + mx) + ny * (oy + my) + nz * (oz + mz));
-        if (d < 0.0) { nx = -nx; ny = -ny; nz = -nz; d = -d; }
+        nx = nx / len; ny = ny / len; nz = nz / len;
+        const double cx = mx / 65536.0, cy = my / 65536.0, cz = mz / 65536.0;
+        double d = -((nx * cx + ny * cy) + nz * cz);
+        if (d < 0.0) { nx = -nx; ny = -ny; nz = -nz; d = -d; }            /* src/GraphicEnd.cpp:383-387 */
         planes[4 * pl] = (float)nx; planes[4 * pl + 1] = (float)ny; planes[4 * pl + 2] = (float)nz; planes[4 * pl + 3] = (float)d;
     }
 }

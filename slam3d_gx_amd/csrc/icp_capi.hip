@@ -40,6 +40,7 @@ struct slam3d_icp_handle {
     SegState *seg_state = nullptr, *pin_seg = nullptr;
     int *seg_labels = nullptr;
     const float4 **seg_ptrs = nullptr;
+    FitState *fit_state = nullptr, *pin_fit = nullptr;   // slam3d_fit_planes
     // voxel grid (f-1): allocated on first use
     unsigned char *vox_mem = nullptr;
     VoxTable vox;
@@ -136,6 +137,8 @@ static void free_all(slam3d_icp_handle *h)
     if (h->pin_slots) (void)hipHostFree(h->pin_slots);
     if (h->pin_res) (void)hipHostFree(h->pin_res);
     if (h->pin_seg) (void)hipHostFree(h->pin_seg);
+    if (h->pin_fit) (void)hipHostFree(h->pin_fit);
+    F(h->fit_state);
     F(h->seg_state); F(h->seg_labels); F(h->seg_ptrs);
     F(h->vox_mem); F(h->vox_lkey); F(h->vox_lslot); F(h->vox_m); F(h->vox_out); F(h->vox_gkey); F(h->vox_gslot); F(h->vox_hist);
     if (h->pin_vox_m) (void)hipHostFree(h->pin_vox_m);
@@ -658,89 +661,37 @@ extern "C" int slam3d_backproject_u16(slam3d_icp_handle *h, const uint16_t *dept
     return SLAM3D_OK;
 }
 
-// host twin of the device Jacobi (same operation order) for the handful of per-plane solves
-static void host_eig3_smallest(double a00, double a01, double a02, double a11, double a12, double a22,
-                               double &nx, double &ny, double &nz)
-{
-    double a[3][3] = { { a00, a01, a02 }, { a01, a11, a12 }, { a02, a12, a22 } };
-    double v[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } };
-    const int PP[3] = { 0, 0, 1 }, QQ[3] = { 1, 2, 2 }, RR[3] = { 2, 1, 0 };
-    for (int sweep = 0; sweep < 8; ++sweep)
-        for (int k = 0; k < 3; ++k) {
-            const int p = PP[k], q = QQ[k], r = RR[k];
-            const double apq = a[p][q];
-            if (apq == 0.0) continue;
-            const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
-            double t = 1.0 / (fabs(theta) + sqrt(theta * theta + 1.0));
-            if (theta < 0.0) t = -t;
-            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-            a[p][p] -= t * apq; a[q][q] += t * apq; a[p][q] = a[q][p] = 0.0;
-            const double arp = a[r][p], arq = a[r][q];
-            a[r][p] = a[p][r] = c * arp - s * arq;
-            a[r][q] = a[q][r] = s * arp + c * arq;
-            for (int m = 0; m < 3; ++m) {
-                const double vp = v[m][p], vq = v[m][q];
-                v[m][p] = c * vp - s * vq; v[m][q] = s * vp + c * vq;
-            }
-        }
-    int k = 0;
-    if (a[1][1] < a[k][k]) k = 1;
-    if (a[2][2] < a[k][k]) k = 2;
-    nx = v[0][k]; ny = v[1][k]; nz = v[2][k];
-    const double len = sqrt(nx * nx + ny * ny + nz * nz);
-    nx /= len; ny /= len; nz /= len;
-}
-
 extern "C" int slam3d_fit_planes(slam3d_icp_handle *h, const slam3d_cloud_view *cloud, const int32_t *labels,
                                  int32_t nplanes, slam3d_plane *planes)
 {
-    if (!h || !cloud || !labels || !planes || nplanes <= 0 || nplanes > 16) return SLAM3D_E_INVALID;
+    if (!h || !cloud || !labels || !planes || nplanes <= 0 || nplanes > FIT_MAXP) return SLAM3D_E_INVALID;
     HIPCHK(h, hipSetDevice(h->p.device));
     const int N = h->N;
     int rc = upload_cloud(h, cloud, h->d_scratch4);
     if (rc) return rc;
-    // origin of each plane's moments = its first labelled point (keeps the sums well conditioned)
-    std::vector<double> origin(3 * (size_t)nplanes, 0.0);
-    std::vector<int> first(nplanes, -1);
-    int found = 0;
-    for (int i = 0; i < N && found < nplanes; ++i) {
-        const int l = labels[i];
-        if (l >= 0 && l < nplanes && first[l] < 0) {
-            first[l] = i; ++found;
-            const float *q = reinterpret_cast<const float *>((const unsigned char *)cloud->data + (size_t)i * cloud->stride_bytes);
-            origin[3 * l] = q[0]; origin[3 * l + 1] = q[1]; origin[3 * l + 2] = q[2];
+    if (!h->fit_state) {
+        if (hipMalloc((void **)&h->fit_state, sizeof(FitState)) != hipSuccess ||
+            hipHostMalloc((void **)&h->pin_fit, sizeof(FitState), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return SLAM3D_E_NOMEM;
         }
     }
-    const int chunks = (N + CHUNK - 1) / CHUNK;
-    double *d_origin = nullptr, *d_part = nullptr;
-    HIPCHK(h, hipMalloc((void **)&d_origin, sizeof(double) * 3 * nplanes));
-    HIPCHK(h, hipMalloc((void **)&d_part, sizeof(double) * 10 * (size_t)nplanes * chunks));
-    HIPCHK(h, hipMemcpyAsync(d_origin, origin.data(), sizeof(double) * 3 * nplanes, hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipMemcpyAsync(h->d_idx, labels, sizeof(int) * N, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_plane_sums, dim3(chunks), dim3(CHUNK), 0, h->stream, h->d_scratch4, h->d_idx, N, nplanes, d_origin, d_part);
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipMemcpyAsync(h->d_idx, labels, sizeof(int) * N, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemsetAsync(h->fit_state, 0, sizeof(FitState), s));
+    hipLaunchKernelGGL(k_fit_moments, dim3((N + SEG_BLOCK * SEG_PTS - 1) / (SEG_BLOCK * SEG_PTS)), dim3(SEG_BLOCK), 0, s, h->d_scratch4,
+                       h->d_idx, N, nplanes, h->fit_state);
+    hipLaunchKernelGGL(k_fit_refine, dim3(1), dim3(64), 0, s, h->fit_state, nplanes);
     HIPCHK(h, hipGetLastError());
-    std::vector<double> part(10 * (size_t)nplanes * chunks);
-    HIPCHK(h, hipMemcpyAsync(part.data(), d_part, sizeof(double) * part.size(), hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    (void)hipFree(d_origin); (void)hipFree(d_part);
+    HIPCHK(h, hipMemcpyAsync(h->pin_fit, h->fit_state, sizeof(FitState), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
     for (int pl = 0; pl < nplanes; ++pl) {
-        double s[10] = { 0 };
-        for (int c = 0; c < chunks; ++c)
-            for (int k = 0; k < 10; ++k) s[k] += part[((size_t)c * nplanes + pl) * 10 + k];
+        const SegPlane &q = h->pin_fit->out[pl];
         slam3d_plane &P = planes[pl];
         memset(&P, 0, sizeof P);
-        P.count = (int)s[0];
-        if (s[0] < 3.0) continue;
-        const double inv = 1.0 / s[0];
-        const double mx = s[1] * inv, my = s[2] * inv, mz = s[3] * inv;
-        double nx, ny, nz;
-        host_eig3_smallest(s[4] * inv - mx * mx, s[5] * inv - mx * my, s[6] * inv - mx * mz,
-                           s[7] * inv - my * my, s[8] * inv - my * mz, s[9] * inv - mz * mz, nx, ny, nz);
-        const double cx = origin[3 * pl] + mx, cy = origin[3 * pl + 1] + my, cz = origin[3 * pl + 2] + mz;
-        double d = -(nx * cx + ny * cy + nz * cz);
-        if (d < 0.0) { nx = -nx; ny = -ny; nz = -nz; d = -d; }     // src/GraphicEnd.cpp:383-387
-        P.coeff[0] = (float)nx; P.coeff[1] = (float)ny; P.coeff[2] = (float)nz; P.coeff[3] = (float)d;
-        P.centroid[0] = (float)cx; P.centroid[1] = (float)cy; P.centroid[2] = (float)cz;
+        P.coeff[0] = q.a; P.coeff[1] = q.b; P.coeff[2] = q.c; P.coeff[3] = q.d;
+        P.count = q.count;
+        P.centroid[0] = q.cx; P.centroid[1] = q.cy; P.centroid[2] = q.cz;
     }
     return SLAM3D_OK;
 }

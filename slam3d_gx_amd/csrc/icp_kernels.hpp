@@ -9,7 +9,7 @@
 //      k_nn_valu          exact full brute-force 1-NN (replaces FLANN matching, src/GraphicEnd.cpp:486-520)
 //      k_accumulate       point-to-plane / Kabsch normal equations, deterministic 256-slot chunk tree
 //   S5 k_solve_acc        integer accumulators -> 29 sums, 6x6 LDL^T or 3x3 SVD, SE(3) update on device
-//   a6 k_plane_sums       per-plane {sum p, sum pp^T, n} -> (n,d)   src/GraphicEnd.cpp:360-387
+//   a6 k_fit_moments / k_fit_refine (plane_seg.hpp)  per-plane {sum p, sum pp^T, n} -> (n,d)   src/GraphicEnd.cpp:360-387
 //
 // Numerics contract: compiled with -ffp-contract=off; every float/double operation is an
 // individually rounded IEEE op in the order written (explicit __fmaf_rn where the spec has an
@@ -1448,43 +1448,6 @@ __global__ __launch_bounds__(256) void k_scatter_corr(const float4 *__restrict__
     if (pix < 0) return;
     idx[pix] = corr[(size_t)b * tg.nslots + slot];
     d2[pix] = cd2[(size_t)b * tg.nslots + slot];
-}
-
-// ------------------------------------------------------------------------------------ a6
-// per-plane moments relative to an origin point, 256-pixel chunk tree; chunks are summed on the host
-__global__ __launch_bounds__(CHUNK) void k_plane_sums(const float4 *__restrict__ cloud,
-                                                      const int *__restrict__ labels, int N, int nplanes,
-                                                      const double *__restrict__ origin /* nplanes*3 */,
-                                                      double *__restrict__ partials /* chunks*nplanes*10 */)
-{
-    __shared__ double sh[10 * CHUNK];
-    const int c = blockIdx.x, tid = threadIdx.x, i = c * CHUNK + tid;
-    const int lab = i < N ? labels[i] : -1;
-    float4 q = make_float4(0, 0, 0, 0);
-    if (i < N) q = cloud[i];
-    for (int pl = 0; pl < nplanes; ++pl) {
-        double s[10];
-#pragma unroll
-        for (int k = 0; k < 10; ++k) s[k] = 0.0;
-        if (lab == pl) {
-            const double dx = (double)q.x - origin[pl * 3], dy = (double)q.y - origin[pl * 3 + 1],
-                         dz = (double)q.z - origin[pl * 3 + 2];
-            s[0] = 1.0; s[1] = dx; s[2] = dy; s[3] = dz;
-            s[4] = dx * dx; s[5] = dx * dy; s[6] = dx * dz; s[7] = dy * dy; s[8] = dy * dz; s[9] = dz * dz;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 10; ++k) sh[k * CHUNK + tid] = s[k];
-        for (int st = CHUNK / 2; st >= 1; st >>= 1) {
-            __syncthreads();
-            for (int w = tid; w < st * 10; w += CHUNK) {
-                const int k = w / st, ii = w - k * st;
-                sh[k * CHUNK + ii] += sh[k * CHUNK + ii + st];
-            }
-        }
-        __syncthreads();
-        if (tid < 10) partials[((size_t)c * nplanes + pl) * 10 + tid] = sh[tid * CHUNK];
-    }
 }
 
 } // namespace s3d

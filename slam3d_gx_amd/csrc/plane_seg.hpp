@@ -305,6 +305,94 @@ __global__ void k_seg_final(SegState *__restrict__ st, int rounds)
     seg_close_round(st[blockIdx.x], rounds);
 }
 
+// ------------------------------------------------------------------------------------ a6: planes from labels
+// slam3d_fit_planes: per-plane least-squares fit for GIVEN labels (the refinement PCL runs inside
+// SACSegmentation::segment, src/GraphicEnd.cpp:360-375).  Same arithmetic as P3 with the sensor origin as the
+// moment origin: integer fixed-point (2^-16 m) moments -> covariance -> smallest eigenvector -> (n, d), d >= 0.
+constexpr int FIT_MAXP = 16;
+struct FitState { long long mom[FIT_MAXP][10]; SegPlane out[FIT_MAXP]; };
+
+// grid (ceil(N/1024)), block 256: every plane present in the block is summed (wave shuffles -> LDS -> one set of
+// atomics per block and plane)
+__global__ __launch_bounds__(SEG_BLOCK) void k_fit_moments(const float4 *__restrict__ cloud, const int *__restrict__ labels, int N,
+                                                           int nplanes, FitState *__restrict__ st)
+{
+    __shared__ unsigned long long bm[10];
+    __shared__ int present;
+    const int lane = threadIdx.x & 63;
+    long long q[SEG_PTS][3];
+    int lab[SEG_PTS];
+#pragma unroll
+    for (int k = 0; k < SEG_PTS; ++k) {
+        const int i = (blockIdx.x * SEG_PTS + k) * SEG_BLOCK + threadIdx.x;
+        lab[k] = -1;
+        q[k][0] = q[k][1] = q[k][2] = 0;
+        if (i < N) {
+            lab[k] = labels[i];
+            if (lab[k] >= 0 && lab[k] < nplanes) {
+                const float4 p = cloud[i];
+                q[k][0] = __double2ll_rn((double)p.x * 65536.0); q[k][1] = __double2ll_rn((double)p.y * 65536.0);
+                q[k][2] = __double2ll_rn((double)p.z * 65536.0);
+            }
+        }
+    }
+    for (int pl = 0; pl < nplanes; ++pl) {
+        __syncthreads();
+        if (threadIdx.x < 10) bm[threadIdx.x] = 0;
+        if (threadIdx.x == 0) present = 0;
+        __syncthreads();
+        long long m[10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) m[k] = 0;
+#pragma unroll
+        for (int k = 0; k < SEG_PTS; ++k)
+            if (lab[k] == pl) {
+                const long long x = q[k][0], y = q[k][1], z = q[k][2];
+                m[0] += 1; m[1] += x; m[2] += y; m[3] += z;
+                m[4] += x * x; m[5] += x * y; m[6] += x * z; m[7] += y * y; m[8] += y * z; m[9] += z * z;
+            }
+        if (__any(m[0] != 0)) {
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                long long v = m[k];
+                for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+                m[k] = v;
+            }
+            long long mine = 0;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) if (lane == k) mine = m[k];
+            if (lane < 10) atomicAdd(&bm[lane], (unsigned long long)mine);
+            if (lane == 0) present = 1;
+        }
+        __syncthreads();
+        if (present && threadIdx.x < 10) atomicAdd(reinterpret_cast<unsigned long long *>(&st->mom[pl][threadIdx.x]), bm[threadIdx.x]);
+    }
+}
+
+// one lane per plane
+__global__ __launch_bounds__(64) void k_fit_refine(FitState *__restrict__ st, int nplanes)
+{
+    const int pl = threadIdx.x;
+    if (pl >= nplanes) return;
+    const long long *m = st->mom[pl];
+    SegPlane &P = st->out[pl];
+    P.a = P.b = P.c = P.d = P.cx = P.cy = P.cz = 0.0f;
+    P.count = (int)m[0];
+    if (m[0] < 3) return;
+    const double inv = 1.0 / (double)m[0];
+    const double mx = (double)m[1] * inv, my = (double)m[2] * inv, mz = (double)m[3] * inv;
+    Sym3 C;
+    C.a00 = (double)m[4] * inv - mx * mx; C.a01 = (double)m[5] * inv - mx * my; C.a02 = (double)m[6] * inv - mx * mz;
+    C.a11 = (double)m[7] * inv - my * my; C.a12 = (double)m[8] * inv - my * mz; C.a22 = (double)m[9] * inv - mz * mz;
+    double nx, ny, nz;
+    eig3_smallest(C, nx, ny, nz);
+    const double cx = mx / 65536.0, cy = my / 65536.0, cz = mz / 65536.0;
+    double d = -((nx * cx + ny * cy) + nz * cz);
+    if (d < 0.0) { nx = -nx; ny = -ny; nz = -nz; d = -d; }      // src/GraphicEnd.cpp:383-387
+    P.a = (float)nx; P.b = (float)ny; P.c = (float)nz; P.d = (float)d;
+    P.cx = (float)cx; P.cy = (float)cy; P.cz = (float)cz;
+}
+
 constexpr int PTR_ARGS = 32;
 struct PtrArgs { const float4 *p[PTR_ARGS]; };
 __global__ void k_set_ptrs(const float4 **__restrict__ dst, PtrArgs a, int n)

@@ -263,7 +263,7 @@ def test_config5_dense_1280x960(gpu_lib):
 
 def test_fit_planes_vs_oracle(gpu_lib):
     """Row a6: per-plane {sum p, sum pp^T, n} -> eigen -> (n, d) with d >= 0 (src/GraphicEnd.cpp:360-387).
-    The GPU reduces the moments with a 256-pixel chunk tree, the oracle sequentially: float outputs agree to 1e-6."""
+    Integer fixed-point moments (exact, order-free) + the spec's Jacobi on the device: bit-identical to the oracle."""
     pr = synth.make_pair(1001, 640, 480)
     d, lab = synth.render_depth(np.eye(4), pr.intr, 1001, 1, hole_block=32, want_labels=True)
     assert np.array_equal(d, pr.depth_src)
@@ -276,7 +276,7 @@ def test_fit_planes_vs_oracle(gpu_lib):
         got8 = h.fit_planes(c8, lab, 3)
     for k in range(3):
         assert got[k]["count"] == ref_counts[k] == int((lab == k).sum())
-        assert np.abs(got[k]["coeff"] - ref_planes[k]).max() < 1e-6
+        assert np.array_equal(got[k]["coeff"], ref_planes[k])
         assert got[k]["coeff"][3] >= 0 and abs(np.linalg.norm(got[k]["coeff"][:3]) - 1) < 1e-6
         assert np.array_equal(got[k]["coeff"], got8[k]["coeff"])
     expect = np.array([[0, -1, 0, 1.2], [1, 0, 0, 2.0], [0, 0, -1, 4.5]])
