@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo + --one-device: exercise the N>1 code path with several ranks on ONE GPU (tests only)")
     ap.add_argument("--one-device", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="one handle, every step fetched before the next is queued")
     return ap.parse_args()
 
 
@@ -313,10 +314,16 @@ def main():
     d_tgt = torch.from_numpy(np.stack(tgt_host)).to(dev)
     params = capi.default_params(intr, estimator=est, iterations=args.iterations, max_batch=P,
                                  device=local_rank, nn_mode=args.nn_mode)
-    h = capi.IcpHandle(params)
+    # two handles (each with its own HIP stream) on the same resident inputs alternate from step to step (batch mode):
+    # step k+1 is queued before step k's poses are fetched (fetch waits for its own run's end event only), so two
+    # consecutive steps overlap on the GPU and the host round trip is hidden.  `single_step_latency_ms` reports the
+    # un-overlapped time of one step next to it.
+    handles = [capi.IcpHandle(params) for _ in range(1 if (is_dense or args.no_pipeline) else 2)]
+    h = handles[0]
     rec_bytes = 4 * args.width * args.height * 4
-    for i in range(P):
-        h.set_clouds_device(i, d_src.data_ptr() + i * rec_bytes, d_tgt.data_ptr() + i * rec_bytes)
+    for hh in handles:
+        for i in range(P):
+            hh.set_clouds_device(i, d_src.data_ptr() + i * rec_bytes, d_tgt.data_ptr() + i * rec_bytes)
     stream = torch.cuda.current_stream().cuda_stream
     table = {}
     d_sums = torch.zeros(29, dtype=torch.int64, device=dev)       # dense mode: the per-iteration exchange buffer
@@ -329,12 +336,31 @@ def main():
                 return [dense.dense_align(h, world, rank, None, host_allreduce, stream)]
             return [dense.dense_align_device(h, world, rank, d_sums, None, stream)]
         h.run(P, None, stream)
-        res = h.fetch_results(P)
+        return finish(h)
+
+    def finish(hh):
+        res = hh.fetch_results(P)
         if gatherer:      # RCCL all-gather of the 160-byte pose records (T, norm, inliers, status, rmse), one per
             gatherer.submit(shard.pack_records(res))     # step, overlapping the next step's kernels
             if len(gatherer.pending) > 1:
                 table["poses"] = gatherer.collect()
         return res
+
+    def run_steps(n):
+        """n steps, software-pipelined over the handles; every step's poses are fetched (and gathered) inside"""
+        if len(handles) == 1:
+            out = None
+            for _ in range(n):
+                out = step()
+            return out
+        out = None
+        for k in range(n):
+            handles[k % 2].run(P, None, stream)
+            if k > 0:
+                out = finish(handles[(k - 1) % 2])
+        if n > 0:
+            out = finish(handles[(n - 1) % 2])
+        return out
 
     def drain():
         while gatherer and gatherer.pending:
@@ -346,19 +372,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     drain()
     nn_ms, tot_ms, pre_ms = [], [], []
     fence()
     t0 = time.perf_counter()
-    res = None
-    for _ in range(args.steps):
-        res = step()
+    res = run_steps(args.steps)
+    h_last = handles[(args.steps - 1) % len(handles)]
     drain()                 # the last step's pose table is on every rank before the clock stops
     fence()
     elapsed = time.perf_counter() - t0
+    latency_ms = None
     if not is_dense:
+        nl = min(args.steps, 10)
+        fence()
+        tl = time.perf_counter()
+        for _ in range(nl):
+            step()
+        drain()
+        fence()
+        latency_ms = 1e3 * (time.perf_counter() - tl) / nl
         # kernel durations for the roofline: the same K steps again with per-launch HIP events on the launch
         # stream (kept out of the timed region because every event record serialises the stream for ~6 us)
         h.set_profiling(True)
@@ -389,6 +422,9 @@ def main():
                          f"{args.iterations} ICP iterations, {args.estimator}, exact NN (tile-pruned brute force), "
                          f"seeds {seeds[0]}..{seeds[-1]}"),
             "pairs_per_gpu": P, "iterations": args.iterations, "estimator": args.estimator,
+            "step_pipelining": (f"{len(handles)} handles, each on its own HIP stream, alternate: step k+1 is queued before step k's poses "
+                                "are fetched, so two consecutive steps overlap on the GPU; every step's poses reach the host inside "
+                                "the timed region") if len(handles) > 1 else "none",
             "nn_mode": {0: "auto(tiles)", 1: "brute_valu", 2: "brute_mfma", 3: "tiles"}.get(args.nn_mode, str(args.nn_mode)),
             "n_src": [r["n_src"] for r in res][:4], "n_tgt": [r["n_tgt"] for r in res][:4],
             "parallelism": (f"source rows over {world} rank(s), RCCL all-reduce of 29 doubles per iteration" if is_dense else
@@ -396,6 +432,8 @@ def main():
         },
         "status": [r["status"] for r in res][:8],
     }
+    if latency_ms is not None:
+        out["single_step_latency_ms"] = latency_ms      # one step at a time (no overlap between steps), same inputs
     if not is_dense:
         # ---- roofline of the dominant kernel: one launch = one ICP iteration over the P resident pairs
         launch_ms = statistics.mean(nn_ms) / max(args.iterations, 1)
@@ -436,7 +474,8 @@ def main():
             out["cpu_baseline"] = cb
             out["parity_vs_oracle"] = parity
         print(json.dumps(out))
-    h.close()
+    for hh in handles:
+        hh.close()
     if world > 1:
         dist.destroy_process_group()
 

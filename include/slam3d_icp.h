@@ -153,7 +153,7 @@ int slam3d_icp_get_clouds(slam3d_icp_handle *h, int32_t slot, float *src_xyz4, f
  * stream for ~6 us, ~15 % of a single-pair run).  Takes effect from the next slam3d_icp_run. */
 int slam3d_icp_set_profiling(slam3d_icp_handle *h, int32_t on);
 /* kernel time of the last run, by bucket (ms): [0] preprocess [1] nn [2] accumulate+solve [3] total;
- * without profiling [1] is 0 and [2] holds everything after preprocessing */
+ * without profiling [0] and [1] are 0 and [2] holds everything */
 int slam3d_icp_get_timings(slam3d_icp_handle *h, float ms[4]);
 /* duration of each iteration's NN launch of the last run (ms), nn_ms[iterations]; SLAM3D_E_STATE unless the
  * run was profiled */

@@ -435,7 +435,7 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
     HIPCHK(h, hipEventRecord(h->ev[0], s));
     int rc = enqueue_preprocess(h, B, T_init, s);
     if (rc) return rc;
-    HIPCHK(h, hipEventRecord(h->ev[1], s));
+    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[1], s));
     const int iters = h->p.iterations;
     for (int it = 0; it < iters; ++it) {
         rc = enqueue_iteration(h, B, s, h->profiling ? h->ev[3 + 2 * it] : nullptr, h->profiling ? h->ev[4 + 2 * it] : nullptr, it, 1);
@@ -490,7 +490,9 @@ extern "C" int slam3d_icp_fetch_results(slam3d_icp_handle *h, int32_t B, slam3d_
     hipStream_t s = h->run_stream;
     const int iters = h->p.iterations;
     if (h->res_mapped) {        // the final k_solve_acc wrote the records into host-mapped memory
-        HIPCHK(h, hipStreamSynchronize(s));
+        // wait for THIS run only (its end event), not for whatever else the caller queued on the stream since:
+        // two handles can then alternate on one stream and the host never leaves the GPU idle between runs
+        HIPCHK(h, hipEventSynchronize(h->ev[2]));
         for (int b = 0; b < B; ++b) {
             const double *r = h->pin_res + (size_t)b * RES_REC;
             finish_result(h->p, r, r + 16, (int)r[45], (int)r[46], (int)r[47], out + b);
@@ -616,7 +618,7 @@ extern "C" int slam3d_icp_get_timings(slam3d_icp_handle *h, float ms[4])
     HIPCHK(h, hipSetDevice(h->p.device));
     HIPCHK(h, hipEventSynchronize(h->ev[2]));
     float pre = 0, tot = 0, nn = 0;
-    HIPCHK(h, hipEventElapsedTime(&pre, h->ev[0], h->ev[1]));
+    if (h->ran_profiled) HIPCHK(h, hipEventElapsedTime(&pre, h->ev[0], h->ev[1]));
     HIPCHK(h, hipEventElapsedTime(&tot, h->ev[0], h->ev[2]));
     for (int it = 0; h->ran_profiled && it < h->p.iterations; ++it) {
         float t = 0;

@@ -244,7 +244,7 @@ __device__ __forceinline__ float wave_max(float v)
 
 // grid (ntiles, 2, B), block 64.  srcT slot w = pixel index (int bits) or -1; rows outside
 // [row0,row1) hold no source (dense multi-GPU mode).  A target tile record (TILE_REC float4) holds its four
-// 4x4-pixel quadrants, each compacted (valid slots first, w = pixel index) into 16 slots, followed by the
+// 4x4-pixel quadrants, each compacted (valid slots first; a slot is (pixel index, x, y, z)) into 16 slots, followed by the
 // quadrants' AABBs (lo.xyz, count | hi.xyz); the tile AABB goes to box[2t] = (min, count), box[2t+1] = (max, 0).
 // All boxes are taken from the data (no camera model).
 __global__ __launch_bounds__(64) void k_build_tiles(const SlotPtrs *__restrict__ slots,
@@ -300,7 +300,9 @@ __global__ __launch_bounds__(64) void k_build_tiles(const SlotPtrs *__restrict__
     const int cntq = __popcll(m & qmask);
     const int rank = ok ? __popcll(m & qmask & below) : cntq + __popcll(~m & qmask & below);
     const size_t base = ((size_t)b * tg.ntiles + t) * TILE_REC;
-    tgtT[base + qd * 16 + rank] = q;
+    // stored as (pixel, x, y, z): the scan's 64-bit key (d2 bits << 32 | pixel) then forms in place -- the
+    // distance lands in the register next to the pixel index, no move per candidate
+    tgtT[base + qd * 16 + rank] = make_float4(q.w, q.x, q.y, q.z);
     float mnx = ok ? q.x : inf, mny = ok ? q.y : inf, mnz = ok ? q.z : inf;
     float mxx = ok ? q.x : -inf, mxy = ok ? q.y : -inf, mxz = ok ? q.z : -inf;
 #pragma unroll
@@ -923,9 +925,9 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
 #pragma unroll 4
             for (int i = 0; i < cnt; ++i) {
                 const float4 q = cand[i];                                // same address in every lane: LDS broadcast
-                const float d2 = canon_d2(px, py, pz, q.x, q.y, q.z);
+                const float d2 = canon_d2(px, py, pz, q.y, q.z, q.w);     // record = (pixel, x, y, z)
                 const unsigned long long key =
-                    ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(q.w);
+                    ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(q.x);
                 bkey = key < bkey ? key : bkey;
             }
         }
@@ -933,7 +935,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
     auto fetch_batch = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NN_STAGE; ++k)
-            r[k] = tt[k] >= 0 ? TT[(size_t)tt[k] * TILE_REC + lane] : make_float4(inf, inf, inf, __int_as_float(-1));
+            r[k] = tt[k] >= 0 ? TT[(size_t)tt[k] * TILE_REC + lane] : make_float4(__int_as_float(-1), inf, inf, inf);
     };
     auto park_and_scan = [&]() __attribute__((always_inline)) {
         n_batches += 1;
