@@ -868,7 +868,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
     __shared__ int wcost[NN_WAVES];                                    // cycles spent for each owner (all helpers)
     __shared__ float4 qpos[NN_WAVES][TILE_SLOTS];                     // p'.xyz, w = 0 invalid / 1 tight / 2 loose
     __shared__ unsigned long long qkey[NN_WAVES][TILE_SLOTS];
-    __shared__ int wcentre[NN_WAVES][2];                               // hint centre (tx0, ty0) of each owner
+    __shared__ int wcentre[NN_WAVES][8];                               // the step-1 tiles of each owner (NN_STAGE used)
+    __shared__ float wbox[NN_WAVES][16];                               // each owner's tight / loose query boxes + flag
     __shared__ int items[NN_MAX_ITEMS];
     __shared__ int n_items, next_item;
     const long long clk0 = dbg ? clock64() : 0;
@@ -899,7 +900,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
     float px = 0.0f, py = 0.0f, pz = 0.0f;
     bool valid = false, tight = false, loose = false;
     unsigned long long bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
-    int tx0 = 0, ty0 = 0;
+    int ta[NN_STAGE] = { -1, -1, -1, -1, -1 };        // the tiles of the current owner's step 1
     int tt[NN_STAGE];
     float4 r[NN_STAGE];
 
@@ -993,8 +994,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
         class_thr(thr_t, thr_l);
         bool hit2 = false;
         if (tx < tg.ntx && ty < tg.nty) {
-            const int dx = tx - tx0, dy = ty - ty0;
-            const bool in_a = abs(dx) + abs(dy) <= 1;            // the 5 tiles of step 1: centre + edge neighbours
+            const int tid = ty * tg.ntx + tx;                    // already scanned in step 1?
+            const bool in_a = tid == ta[0] || tid == ta[1] || tid == ta[2] || tid == ta[3] || tid == ta[4];
             hit2 = !in_a && reach(lo, hi, thr_t, thr_l);
         }
         unsigned long long tm0 = __ballot(hit2), tm = 0ull;
@@ -1032,10 +1033,19 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
     if (__ballot(own_valid) != 0ull) {
         // centre of the first scan: where this tile's matches were in the previous iteration (a hint only --
         // exactness never depends on it); initially the same image location
+        // hint = the (up to 2x2) block of target tiles that the 8x8 source patch covered in the previous iteration
+        // (top-left tile | extends in x << 24 | extends in y << 25); without one: the same image location and its
+        // four edge neighbours
         const int th = __builtin_amdgcn_readfirstlane(hint[(size_t)b * tg.ntiles + t]);
-        const int tc = (th >= 0 && th < tg.ntiles) ? th : t;
-        tx0 = tc % tg.ntx; ty0 = tc / tg.ntx;
-        {
+        if (th >= 0 && (th & 0xffffff) < tg.ntiles) {
+            const int base = th & 0xffffff, fx = (th >> 24) & 1, fy = (th >> 25) & 1;
+            tt[0] = base;
+            tt[1] = fx ? base + 1 : -1;
+            tt[2] = fy ? base + tg.ntx : -1;
+            tt[3] = (fx && fy) ? base + tg.ntx + 1 : -1;
+            tt[4] = -1;
+        } else {
+            const int tx0 = t % tg.ntx, ty0 = t / tg.ntx;
             const int ox[NN_STAGE] = { 0, -1, 1, 0, 0 }, oy[NN_STAGE] = { 0, 0, 0, -1, 1 };
 #pragma unroll
             for (int k = 0; k < NN_STAGE; ++k) {
@@ -1043,6 +1053,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
                 tt[k] = (tx >= 0 && tx < tg.ntx && ty >= 0 && ty < tg.nty) ? ty * tg.ntx + tx : -1;
             }
         }
+#pragma unroll
+        for (int k = 0; k < NN_STAGE; ++k) ta[k] = tt[k];
         fetch_batch();                                             // one round of independent loads ...
         const float4 pq = prevq[gs];
         float4 qs = make_float4(0, 0, 0, 0);
@@ -1073,8 +1085,20 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
         tight = valid && bnd0 <= 0.0625f * g.gate2; loose = valid && !tight;
         qpos[w][lane] = make_float4(px, py, pz, valid ? (tight ? 1.0f : 2.0f) : 0.0f);
         qkey[w][lane] = bkey;
-        if (lane == 0) { wcentre[w][0] = tx0; wcentre[w][1] = ty0; }
+        if (lane < NN_STAGE) {
+            int v = ta[0];
+#pragma unroll
+            for (int k = 1; k < NN_STAGE; ++k) if (lane == k) v = ta[k];
+            wcentre[w][lane] = v;
+        }
         class_boxes();
+        if (lane < 13) {   // the boxes do not change while the items are drained: helpers read them instead of redoing 12 wave reductions
+            const float bx[13] = { qminx, qminy, qminz, qmaxx, qmaxy, qmaxz, lminx, lminy, lminz, lmaxx, lmaxy, lmaxz, any_loose ? 1.0f : 0.0f };
+            float v = bx[0];
+#pragma unroll
+            for (int k = 1; k < 13; ++k) if (lane == k) v = bx[k];
+            wbox[w][lane] = v;
+        }
         float thr_t, thr_l;
         class_thr(thr_t, thr_l);
         for (int c0 = 0; c0 < tg.ncoarse; c0 += 64) {
@@ -1121,8 +1145,13 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
             px = q.x; py = q.y; pz = q.z;
             valid = q.w > 0.5f; tight = q.w == 1.0f; loose = q.w == 2.0f;
             bkey = qkey[owner][lane];
-            tx0 = wcentre[owner][0]; ty0 = wcentre[owner][1];
-            class_boxes();
+#pragma unroll
+            for (int k = 0; k < NN_STAGE; ++k) ta[k] = wcentre[owner][k];
+            qminx = wbox[owner][0]; qminy = wbox[owner][1]; qminz = wbox[owner][2];
+            qmaxx = wbox[owner][3]; qmaxy = wbox[owner][4]; qmaxz = wbox[owner][5];
+            lminx = wbox[owner][6]; lminy = wbox[owner][7]; lminz = wbox[owner][8];
+            lmaxx = wbox[owner][9]; lmaxy = wbox[owner][10]; lmaxz = wbox[owner][11];
+            any_loose = wbox[owner][12] != 0.0f;
             sweep_cell(cc);
             if (valid) atomicMin(&qkey[owner][lane], bkey);
             if (lane == 0) atomicAdd(&wcost[owner], (int)(clock64() - ci0));
@@ -1145,7 +1174,14 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_tiles_acc(const SlotPtrs *
             const unsigned long long ctr = mm & 0x0000001818000000ull;      // lanes 27,28,35,36
             const int src_lane = __builtin_ctzll(ctr ? ctr : mm);
             const int jm = __builtin_amdgcn_readlane((int)(unsigned int)(bkey & 0xffffffffull), src_lane);
-            if (lane == 0) hint[(size_t)b * tg.ntiles + t] = ((jm / g.W) / TILE_PX) * tg.ntx + (jm % g.W) / TILE_PX;
+            if (lane == 0) {
+                // the 8x8 patch seen from that lane's match: pixels [um - lx, um - lx + 7] x [vm - ly, vm - ly + 7]
+                const int vm = jm / g.W, um = jm - vm * g.W;
+                const int u0 = max(0, um - (src_lane & 7)), u1 = min(g.W - 1, um - (src_lane & 7) + 7);
+                const int v0 = max(0, vm - (src_lane >> 3)), v1 = min(g.H - 1, vm - (src_lane >> 3) + 7);
+                const int ax0 = u0 / TILE_PX, ay0 = v0 / TILE_PX;
+                hint[(size_t)b * tg.ntiles + t] = (ay0 * tg.ntx + ax0) | ((u1 / TILE_PX > ax0) << 24) | ((v1 / TILE_PX > ay0) << 25);
+            }
         }
     }
     if (dbg && b == 0 && lane == 0) {
