@@ -473,6 +473,16 @@ def main():
             cb, parity = cpu_baseline_leg(pairs[0], src_host[0], tgt_host[0], args, res[0], idx)
             out["cpu_baseline"] = cb
             out["parity_vs_oracle"] = parity
+        # the flat report SURVEY.md 8(d) lists, assembled from the objects above
+        rb, rf, cb_, pv = out.get("roofline_bruteforce", {}), out.get("roofline", {}), out.get("cpu_baseline", {}), out.get("parity_vs_oracle", {})
+        out["survey_8d"] = {
+            "gpus": world, "pairs": (1 if is_dense else world * P), "iters": args.iterations, "wall_s": elapsed,
+            "icp_iters_per_s": value, "nn_tflops": rb.get("achieved"), "nn_frac_fp32_peak": rb.get("frac"),
+            "hbm_GBps": rf.get("achieved") if rf.get("unit") == "GB/s" else None,
+            "hbm_frac_peak": rf.get("frac") if rf.get("unit") == "GB/s" else None,
+            "cpu_B_iters_per_s": cb_.get("value"), "cpu_B_1thread_iters_per_s": cb_.get("single_thread_value"), "cores": cb_.get("cores"),
+            "max_rot_err": pv.get("rot_err_rad"), "max_trans_err": pv.get("trans_err_m"), "idx_mismatches": pv.get("idx_mismatches"),
+        }
         print(json.dumps(out))
     for hh in handles:
         hh.close()
