@@ -379,7 +379,7 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         }
     }
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
-    hipLaunchKernelGGL(k_init_T, dim3((B + 63) / 64), dim3(64), 0, s, dT, h->Tcur, h->trace_T, h->flags, B, iters);
+    hipLaunchKernelGGL(k_init_T, dim3(B), dim3(64), 0, s, dT, h->Tcur, h->trace_T, h->flags, h->acc, iters);
     HIPCHK(h, hipGetLastError());
     return SLAM3D_OK;
 }

@@ -1456,17 +1456,18 @@ __global__ void k_solve(const long long *__restrict__ sums_all, double *__restri
                      flags + b, it, estimator);
 }
 
-__global__ void k_init_T(const double *__restrict__ T_init, double *__restrict__ Tcur,
-                         double *__restrict__ trace_T, int *__restrict__ flags, int B, int iters)
+// grid (B), block 64: T = T_init (or Identity), trace row 0, flags, and clean accumulators for the run
+__global__ __launch_bounds__(64) void k_init_T(const double *__restrict__ T_init, double *__restrict__ Tcur,
+                                               double *__restrict__ trace_T, int *__restrict__ flags, long long *__restrict__ acc, int iters)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    for (int k = 0; k < 16; ++k) {
+    const int b = blockIdx.x, k = threadIdx.x;
+    for (int j = k; j < ACC_R * ACC_STRIDE; j += 64) acc[(size_t)b * ACC_R * ACC_STRIDE + j] = 0;
+    if (k < 16) {
         const double v = T_init ? T_init[b * 16 + k] : ((k % 5 == 0) ? 1.0 : 0.0);
         Tcur[b * 16 + k] = v;
         trace_T[((size_t)b * (iters + 1)) * 16 + k] = v;
     }
-    flags[b] = 0;
+    if (k == 0) flags[b] = 0;
 }
 
 // slot-order correspondences -> original pixel order (for get_correspondences)
