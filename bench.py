@@ -59,6 +59,7 @@ def parse_args():
                     help="gloo + --one-device: exercise the N>1 code path with several ranks on ONE GPU (tests only)")
     ap.add_argument("--one-device", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one handle, every step fetched before the next is queued")
+    ap.add_argument("--in-flight", type=int, default=2, help="steps in flight (handles alternating, one HIP stream each); default 2 = double buffering")
     return ap.parse_args()
 
 
@@ -318,7 +319,7 @@ def main():
     # step k+1 is queued before step k's poses are fetched (fetch waits for its own run's end event only), so two
     # consecutive steps overlap on the GPU and the host round trip is hidden.  `single_step_latency_ms` reports the
     # un-overlapped time of one step next to it.
-    handles = [capi.IcpHandle(params) for _ in range(1 if (is_dense or args.no_pipeline) else 2)]
+    handles = [capi.IcpHandle(params) for _ in range(1 if (is_dense or args.no_pipeline) else max(1, min(8, args.in_flight)))]
     h = handles[0]
     rec_bytes = 4 * args.width * args.height * 4
     for hh in handles:
@@ -353,13 +354,13 @@ def main():
             for _ in range(n):
                 out = step()
             return out
-        out = None
+        out, nh = None, len(handles)
         for k in range(n):
-            handles[k % 2].run(P, None, stream)
-            if k > 0:
-                out = finish(handles[(k - 1) % 2])
-        if n > 0:
-            out = finish(handles[(n - 1) % 2])
+            handles[k % nh].run(P, None, stream)
+            if k >= nh - 1:
+                out = finish(handles[(k - (nh - 1)) % nh])
+        for k in range(max(0, n - (nh - 1)), n):
+            out = finish(handles[k % nh])
         return out
 
     def drain():
