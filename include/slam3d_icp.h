@@ -179,6 +179,13 @@ int slam3d_fit_planes(slam3d_icp_handle *h, const slam3d_cloud_view *cloud, cons
 int slam3d_voxel_grid(slam3d_icp_handle *h, const void *points16, int32_t n, float leaf, void *out16, int32_t *n_out);
 int slam3d_voxel_grid_device(slam3d_icp_handle *h, const void *d_points16, int32_t n, float leaf, void *d_out16,
                              int32_t *n_out, void *stream);
+/* ---- keyframe cloud merge of saveOutput (src/saveOutput.cpp:47-103): per keyframe VoxelGrid alone (:80-83), then
+ * PassThrough z in [0, pass_z] and pcl::transformPointCloud by the keyframe's pose (:84-92); the merged cloud goes
+ * through VoxelGrid alone once more (:97-100).  Same 16-byte records.  pass_transform writes NaN for dropped
+ * records (VoxelGrid ignores them), so no compaction is needed between the steps. */
+int slam3d_voxel_grid_only(slam3d_icp_handle *h, const void *points16, int32_t n, float leaf, void *out16, int32_t *n_out);
+int slam3d_pass_transform(slam3d_icp_handle *h, const void *points16, int32_t n, float z_max, const double *T /* 16, row-major */,
+                          void *out16, int32_t *n_kept);
 
 /* ---- plane segmentation (replaces the pcl::SACSegmentation loop of extractPlanesAndGenerateImage,
  * src/GraphicEnd.cpp:353-430): up to max_planes rounds of seeded RANSAC + least-squares refinement while more

@@ -108,6 +108,9 @@ int orc_segment_planes(const float *xyz4, int n, float zmax, const orc_seg_param
 /* frame ingestion filters (row f-1, voxel_oracle.c): PassThrough z in [0,zmax] + VoxelGrid(leaf) on n records
  * {x,y,z,rgba bits}; out has room for n records; returns the number of voxels (ascending (iz,iy,ix)) */
 int orc_voxel_grid(const float *pts, int n, float leaf, float zmax, float *out);
+int orc_voxel_grid_range(const float *pts, int n, float leaf, float zmin, float zmax, float *out);
+/* keyframe cloud merge of src/saveOutput.cpp:84-92: PassThrough + rigid transform, dropped records -> NaN; returns kept */
+int orc_pass_transform(const float *pts, int n, float zmax, const double *T, float *out);
 uint64_t orc_voxel_key(float x, float y, float z, float inv_leaf);
 
 /* pose error metric a14: E = Tref^-1 * T ; trans = ||E_t||, rot = acos(clamp((tr-1)/2)) */

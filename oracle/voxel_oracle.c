@@ -38,12 +38,40 @@ uint64_t orc_voxel_key(float x, float y, float z, float inv_leaf)
 
 int orc_voxel_grid(const float *pts /* n x {x,y,z,rgba bits} */, int n, float leaf, float zmax, float *out)
 {
+    return orc_voxel_grid_range(pts, n, leaf, 0.0f, zmax, out);
+}
+
+/* src/saveOutput.cpp:84-92 (spec T1): PassThrough z in [0, zmax], then pcl::transformPointCloud by T (row-major 4x4):
+ * each coordinate = fma(R_r2, z, fma(R_r1, y, R_r0 * x)) + t_r in double, rounded once to float; dropped -> NaN */
+int orc_pass_transform(const float *pts, int n, float zmax, const double *T, float *out)
+{
+    int kept = 0;
+    for (int i = 0; i < n; ++i) {
+        const float *p = pts + 4 * (size_t)i;
+        float *o = out + 4 * (size_t)i;
+        if (isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]) && p[2] >= 0.0f && p[2] <= zmax) {
+            const double x = p[0], y = p[1], z = p[2];
+            o[0] = (float)(fma(T[2], z, fma(T[1], y, T[0] * x)) + T[3]);
+            o[1] = (float)(fma(T[6], z, fma(T[5], y, T[4] * x)) + T[7]);
+            o[2] = (float)(fma(T[10], z, fma(T[9], y, T[8] * x)) + T[11]);
+            o[3] = p[3];
+            ++kept;
+        } else {
+            o[0] = o[1] = o[2] = NAN; o[3] = 0.0f;
+        }
+    }
+    return kept;
+}
+
+/* zmin = -inf, zmax = +inf: pcl::VoxelGrid alone */
+int orc_voxel_grid_range(const float *pts, int n, float leaf, float zmin, float zmax, float *out)
+{
     const float inv_leaf = 1.0f / leaf;
     uint64_t *ki = (uint64_t *)malloc(sizeof(uint64_t) * 2 * (size_t)(n > 0 ? n : 1));
     int m = 0;
     for (int i = 0; i < n; ++i) {
         const float *p = pts + 4 * (size_t)i;
-        if (!(isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]) && p[2] >= 0.0f && p[2] <= zmax)) continue;   /* PassThrough */
+        if (!(isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]) && p[2] >= zmin && p[2] <= zmax)) continue;   /* PassThrough */
         ki[2 * m] = orc_voxel_key(p[0], p[1], p[2], inv_leaf);
         ki[2 * m + 1] = (uint64_t)i;
         ++m;

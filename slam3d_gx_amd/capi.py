@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "slam3d_icp_set_clouds_device", "slam3d_icp_set_depth_device", "slam3d_icp_run",
     "slam3d_icp_fetch_results", "slam3d_icp_get_correspondences", "slam3d_icp_get_trace",
     "slam3d_icp_get_clouds", "slam3d_icp_set_profiling", "slam3d_icp_get_timings", "slam3d_icp_get_iteration_timings", "slam3d_icp_get_nn_debug", "slam3d_backproject_u16", "slam3d_fit_planes",
-    "slam3d_voxel_grid", "slam3d_voxel_grid_device", "slam3d_seg_default_params", "slam3d_segment_planes", "slam3d_segment_planes_device",
+    "slam3d_voxel_grid", "slam3d_voxel_grid_device", "slam3d_voxel_grid_only", "slam3d_pass_transform", "slam3d_seg_default_params", "slam3d_segment_planes", "slam3d_segment_planes_device",
     "slam3d_icp_dense_set_rows", "slam3d_icp_dense_begin", "slam3d_icp_dense_partial",
     "slam3d_icp_dense_update", "slam3d_icp_dense_finish",
     "slam3d_icp_dense_partial_device", "slam3d_icp_dense_update_device", "slam3d_icp_dense_finish_device",
@@ -278,6 +278,21 @@ class IcpHandle:
         m = C.c_int32(0)
         self._check(self.lib.slam3d_voxel_grid(self._h, _vp(pts), C.c_int32(pts.shape[0]), C.c_float(leaf), _vp(out), C.byref(m)), False)
         return out[: m.value].copy()
+
+    def voxel_grid_only(self, pts16: np.ndarray, leaf: float = 0.03) -> np.ndarray:
+        pts = np.ascontiguousarray(pts16, dtype=np.float32).reshape(-1, 4)
+        out = np.zeros_like(pts)
+        m = C.c_int32(0)
+        self._check(self.lib.slam3d_voxel_grid_only(self._h, _vp(pts), C.c_int32(pts.shape[0]), C.c_float(leaf), _vp(out), C.byref(m)), False)
+        return out[: m.value].copy()
+
+    def pass_transform(self, pts16: np.ndarray, T: np.ndarray, z_max: float = 5.0):
+        pts = np.ascontiguousarray(pts16, dtype=np.float32).reshape(-1, 4)
+        Tm = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+        out = np.zeros_like(pts)
+        m = C.c_int32(0)
+        self._check(self.lib.slam3d_pass_transform(self._h, _vp(pts), C.c_int32(pts.shape[0]), C.c_float(z_max), _vp(Tm), _vp(out), C.byref(m)), False)
+        return out, m.value
 
     def voxel_grid_device(self, d_pts: int, n: int, d_out: int, leaf: float = 0.03, stream: int = 0) -> int:
         m = C.c_int32(0)

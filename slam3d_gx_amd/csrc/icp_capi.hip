@@ -730,8 +730,8 @@ static int vox_alloc(slam3d_icp_handle *h)
     return SLAM3D_OK;
 }
 
-extern "C" int slam3d_voxel_grid_device(slam3d_icp_handle *h, const void *d_points16, int32_t n, float leaf, void *d_out16,
-                                        int32_t *n_out, void *stream)
+static int voxel_grid_impl(slam3d_icp_handle *h, const void *d_points16, int32_t n, float leaf, float zmin, float zmax, void *d_out16,
+                           int32_t *n_out, void *stream)
 {
     if (!h || !d_points16 || !d_out16 || !n_out || n < 0 || n > h->N || !(leaf > 0.0f)) return SLAM3D_E_INVALID;
     HIPCHK(h, hipSetDevice(h->p.device));
@@ -746,7 +746,7 @@ extern "C" int slam3d_voxel_grid_device(slam3d_icp_handle *h, const void *d_poin
     int *start = h->vox_hist + VOX_BINS, *cursor = start + VOX_BINS + 8;
     if (n > 0) {
         hipLaunchKernelGGL(k_voxel_insert, dim3((n + VOX_BLOCK - 1) / VOX_BLOCK), dim3(VOX_BLOCK), 0, s,
-                           static_cast<const float4 *>(d_points16), n, 1.0f / leaf, h->g.zmax, t);
+                           static_cast<const float4 *>(d_points16), n, 1.0f / leaf, zmin, zmax, t);
         hipLaunchKernelGGL(k_voxel_compact, dim3((t.cap + VOX_BLOCK * VOX_SPT - 1) / (VOX_BLOCK * VOX_SPT)), dim3(VOX_BLOCK), 0, s, t,
                            h->vox_lkey, h->vox_lslot, h->vox_m, h->vox_hist);
         hipLaunchKernelGGL(k_voxel_scan, dim3(1), dim3(1024), 0, s, h->vox_hist, start, cursor);
@@ -762,17 +762,63 @@ extern "C" int slam3d_voxel_grid_device(slam3d_icp_handle *h, const void *d_poin
     return SLAM3D_OK;
 }
 
-extern "C" int slam3d_voxel_grid(slam3d_icp_handle *h, const void *points16, int32_t n, float leaf, void *out16, int32_t *n_out)
+extern "C" int slam3d_voxel_grid_device(slam3d_icp_handle *h, const void *d_points16, int32_t n, float leaf, void *d_out16,
+                                        int32_t *n_out, void *stream)
+{
+    if (!h) return SLAM3D_E_INVALID;
+    return voxel_grid_impl(h, d_points16, n, leaf, 0.0f, h->g.zmax, d_out16, n_out, stream);      // PassThrough z in [0, z_filter]
+}
+
+static int voxel_host(slam3d_icp_handle *h, const void *points16, int32_t n, float leaf, float zmin, float zmax, void *out16, int32_t *n_out)
 {
     if (!h || !points16 || !out16 || !n_out || n < 0 || n > h->N) return SLAM3D_E_INVALID;
     HIPCHK(h, hipSetDevice(h->p.device));
     int rc = vox_alloc(h);
     if (rc) return rc;
     if (n > 0) HIPCHK(h, hipMemcpyAsync(h->d_scratch4, points16, (size_t)n * 16, hipMemcpyHostToDevice, h->stream));
-    rc = slam3d_voxel_grid_device(h, h->d_scratch4, n, leaf, h->vox_out, n_out, h->stream);
+    rc = voxel_grid_impl(h, h->d_scratch4, n, leaf, zmin, zmax, h->vox_out, n_out, h->stream);
     if (rc) return rc;
     if (*n_out > 0) HIPCHK(h, hipMemcpy(out16, h->vox_out, (size_t)*n_out * 16, hipMemcpyDeviceToHost));
     return SLAM3D_OK;
+}
+
+// pcl::VoxelGrid alone: every finite point, no PassThrough (src/saveOutput.cpp:80-83 and :97-100)
+extern "C" int slam3d_voxel_grid_only(slam3d_icp_handle *h, const void *points16, int32_t n, float leaf, void *out16, int32_t *n_out)
+{
+    const float inf = __builtin_inff();
+    return voxel_host(h, points16, n, leaf, -inf, inf, out16, n_out);
+}
+
+// src/saveOutput.cpp:84-92: PassThrough z in [0, z_max] + pcl::transformPointCloud by T (row-major 4x4); out16[i] is the
+// transformed record or NaN when record i was dropped; *n_kept = records kept
+extern "C" int slam3d_pass_transform(slam3d_icp_handle *h, const void *points16, int32_t n, float z_max, const double *T,
+                                     void *out16, int32_t *n_kept)
+{
+    if (!h || !points16 || !out16 || !n_kept || !T || n < 0 || n > h->N) return SLAM3D_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    int rc = vox_alloc(h);
+    if (rc) return rc;
+    hipStream_t s = h->stream;
+    Pose34 P;
+    for (int k = 0; k < 12; ++k) P.m[k] = T[k];
+    HIPCHK(h, hipMemsetAsync(h->vox_m, 0, sizeof(int), s));
+    if (n > 0) {
+        HIPCHK(h, hipMemcpyAsync(h->d_scratch4, points16, (size_t)n * 16, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_pass_transform, dim3((n + VOX_BLOCK - 1) / VOX_BLOCK), dim3(VOX_BLOCK), 0, s, h->d_scratch4, n, z_max, P,
+                           h->vox_out, h->vox_m);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(out16, h->vox_out, (size_t)n * 16, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(h, hipMemcpyAsync(h->pin_vox_m, h->vox_m, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    *n_kept = *h->pin_vox_m;
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_voxel_grid(slam3d_icp_handle *h, const void *points16, int32_t n, float leaf, void *out16, int32_t *n_out)
+{
+    if (!h) return SLAM3D_E_INVALID;
+    return voxel_host(h, points16, n, leaf, 0.0f, h->g.zmax, out16, n_out);
 }
 
 // ------------------------------------------------------------------------------ plane segmentation (f-2)

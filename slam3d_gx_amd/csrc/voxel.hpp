@@ -64,14 +64,14 @@ template <typename T> __device__ __forceinline__ T run_scan(T v, int seg)
 // One thread per point.  Neighbouring pixels of an organized cloud fall into the same voxel 3-10 times in a row,
 // and atomics of one wave to one address serialise, so each run of equal keys inside the wave is summed first
 // (integers: same bits) and only the last lane of the run touches the table.
-__global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(const float4 *__restrict__ pts, int n, float inv_leaf, float zmax,
+__global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(const float4 *__restrict__ pts, int n, float inv_leaf, float zmin, float zmax,
                                                             VoxTable t)
 {
     const int i = blockIdx.x * VOX_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
     float4 p = make_float4(0.0f, 0.0f, -1.0f, 0.0f);
     if (i < n) p = pts[i];
-    const bool ok = isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && p.z >= 0.0f && p.z <= zmax;     // PassThrough
+    const bool ok = i < n && isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && p.z >= zmin && p.z <= zmax;     // PassThrough
     const unsigned long long key = ok ? vox_key(p.x, p.y, p.z, inv_leaf) : VOX_EMPTY;
     const unsigned long long prev = __shfl_up(key, 1);
     const bool head = lane == 0 || prev != key;
@@ -104,7 +104,8 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(const float4 *__rest
     atomicAdd(t.n + s, (unsigned int)cnt);
 }
 
-constexpr int VOX_BZ = 256, VOX_BY = 256;   // ordering bins: (iz, iy) rows, both clamped (the order stays monotone)
+constexpr int VOX_BZ = 512, VOX_BY = 256;   // ordering bins: (iz, iy) rows, both clamped (the order stays monotone)
+constexpr int zbias = 128;                   // iz in [-128, 383] has its own slab (-3.8 m .. 11.5 m at a 3 cm leaf)
 constexpr int VOX_BINS = VOX_BZ * VOX_BY;
 constexpr int VOX_SPT = 16;           // table slots per thread in k_voxel_compact
 
@@ -113,11 +114,13 @@ constexpr int VOX_SPT = 16;           // table slots per thread in k_voxel_compa
 // that fills a whole z slab
 __device__ __forceinline__ int vox_bin(unsigned long long key)
 {
-    const int iz = (int)(key >> 42) - 1048576;                   // >= 0 after PassThrough
+    const int iz = (int)(key >> 42) - 1048576 + (int)zbias;      // clouds in a world frame may have negative z
     const int iy = (int)((key >> 21) & 0x1FFFFF) - 1048576 + VOX_BY / 2;
-    const int bz = iz < 0 ? 0 : (iz > VOX_BZ - 1 ? VOX_BZ - 1 : iz);
+    // slabs outside the table collapse into the first / last BIN (not row: rows of different slabs must not interleave)
+    if (iz < 0) return 0;
+    if (iz > VOX_BZ - 1) return VOX_BINS - 1;
     const int by = iy < 0 ? 0 : (iy > VOX_BY - 1 ? VOX_BY - 1 : iy);
-    return bz * VOX_BY + by;
+    return iz * VOX_BY + by;
 }
 
 // occupied slots -> dense (key, slot) list + histogram of the (iz, iy) rows.  Each block scans 4096 slots and
@@ -253,6 +256,33 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_rank(VoxTable t, const unsi
     const unsigned int rgba = (t.c0[s] / ni) | ((t.c1[s] / ni) << 8) | ((t.c2[s] / ni) << 16) | ((t.c3[s] / ni) << 24);
     o.w = __int_as_float((int)rgba);
     out[rank] = o;
+}
+
+// src/saveOutput.cpp:84-92: PassThrough z in [0, z_max] on a (down-sampled) keyframe cloud, then
+// pcl::transformPointCloud by the keyframe's pose.  Spec T1: a kept record becomes (float)(R p + t), each
+// coordinate = fma(R_r2, z, fma(R_r1, y, R_r0 * x)) + t_r in double; a dropped record becomes NaN (the voxel
+// grid that follows ignores it), so the output keeps the input order and no compaction is needed.
+struct Pose34 { double m[12]; };
+__global__ __launch_bounds__(VOX_BLOCK) void k_pass_transform(const float4 *__restrict__ pts, int n, float zmax, Pose34 P,
+                                                              float4 *__restrict__ out, int *__restrict__ kept)
+{
+    const int i = blockIdx.x * VOX_BLOCK + threadIdx.x;
+    bool ok = false;
+    float4 o = make_float4(__int_as_float(0x7fc00000), __int_as_float(0x7fc00000), __int_as_float(0x7fc00000), 0.0f);
+    if (i < n) {
+        const float4 p = pts[i];
+        ok = isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && p.z >= 0.0f && p.z <= zmax;
+        if (ok) {
+            const double x = p.x, y = p.y, z = p.z;
+            o.x = (float)(fma(P.m[2], z, fma(P.m[1], y, P.m[0] * x)) + P.m[3]);
+            o.y = (float)(fma(P.m[6], z, fma(P.m[5], y, P.m[4] * x)) + P.m[7]);
+            o.z = (float)(fma(P.m[10], z, fma(P.m[9], y, P.m[8] * x)) + P.m[11]);
+            o.w = p.w;
+        }
+        out[i] = o;
+    }
+    const unsigned long long m = __ballot(ok);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(kept, __popcll(m));
 }
 
 }  // namespace s3d

@@ -155,6 +155,25 @@ def voxel_grid(pts16, leaf=0.03, zmax=7.0):
     return out[:m].copy()
 
 
+def voxel_grid_only(pts16, leaf=0.03):
+    pts = np.ascontiguousarray(pts16, dtype=np.float32).reshape(-1, 4)
+    out = np.zeros_like(pts)
+    f = lib().orc_voxel_grid_range
+    f.restype = C.c_int
+    m = f(_fp(pts, C.c_float), C.c_int(pts.shape[0]), C.c_float(leaf), C.c_float(-np.inf), C.c_float(np.inf), _fp(out, C.c_float))
+    return out[:m].copy()
+
+
+def pass_transform(pts16, T, z_max=5.0):
+    pts = np.ascontiguousarray(pts16, dtype=np.float32).reshape(-1, 4)
+    Tm = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+    out = np.zeros_like(pts)
+    f = lib().orc_pass_transform
+    f.restype = C.c_int
+    k = f(_fp(pts, C.c_float), C.c_int(pts.shape[0]), C.c_float(z_max), _fp(Tm, C.c_double), _fp(out, C.c_float))
+    return out, k
+
+
 def pose_error(Tref, T):
     Tref = np.ascontiguousarray(Tref, dtype=np.float64).reshape(16)
     T = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
