@@ -11,6 +11,7 @@ struct PoseVertex { int id; double T[16]; bool fixed; };
 struct PoseEdge { int from, to; double T[16]; double info_diag[6]; bool robust; };
 
 void rot_to_quat(const double *T, double &qx, double &qy, double &qz, double &qw);
+void quat_to_mat4(const double *t3, double qx, double qy, double qz, double qw, double *T);
 
 class PoseGraph {
  public:
@@ -18,6 +19,8 @@ class PoseGraph {
     // measurement T: pose of vertex `to` expressed in the frame of vertex `from` (EdgeSE3 convention)
     void addEdge(int from, int to, const double *T, double info = 100.0, bool robust = false);
     bool save(const std::string &path) const;              // VERTEX_SE3:QUAT / EDGE_SE3:QUAT / FIX
+    bool load(const std::string &path);                    // the same text format (what saveOutput reads, src/saveOutput.cpp:29)
+    const PoseVertex *vertex(int id) const;
     const std::vector<PoseVertex> &vertices() const { return _v; }
     const std::vector<PoseEdge> &edges() const { return _e; }
 

@@ -100,6 +100,17 @@ bool read_pcd(const string &path, vector<PointXYZRGBA16> &pts, int &width, int &
     return false;
 }
 
+bool write_pcd_ascii(const string &path, const PointXYZRGBA16 *pts, size_t n, int width, int height, string &err)
+{
+    FILE *f = fopen(path.c_str(), "w");
+    if (!f) { err = "cannot create " + path; return false; }
+    fprintf(f, "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgba\nSIZE 4 4 4 4\nTYPE F F F U\nCOUNT 1 1 1 1\n"
+               "WIDTH %d\nHEIGHT %d\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS %zu\nDATA ascii\n", width, height, n);
+    for (size_t i = 0; i < n; ++i) fprintf(f, "%.9g %.9g %.9g %u\n", pts[i].x, pts[i].y, pts[i].z, pts[i].rgba);   // %.9g round-trips a float
+    fclose(f);
+    return true;
+}
+
 bool write_pcd_binary(const string &path, const PointXYZRGBA16 *pts, size_t n, int width, int height, string &err)
 {
     FILE *f = fopen(path.c_str(), "wb");

@@ -13,3 +13,5 @@ struct PointXYZRGBA16 { float x, y, z; uint32_t rgba; };   // the binary record 
 bool read_pcd(const std::string &path, std::vector<PointXYZRGBA16> &pts, int &width, int &height, std::string &err);
 // header as PCL writes it for PointXYZRGBA (same lines as the reference's fixtures), DATA binary
 bool write_pcd_binary(const std::string &path, const PointXYZRGBA16 *pts, size_t n, int width, int height, std::string &err);
+// DATA ascii, what pcl::io::savePCDFile(name, cloud) writes by default (src/saveOutput.cpp:101)
+bool write_pcd_ascii(const std::string &path, const PointXYZRGBA16 *pts, size_t n, int width, int height, std::string &err);

@@ -186,7 +186,7 @@ def test_run_slam_keyframes_loop_closure_and_g2o_handoff(gpu_lib, tmp_path):
     (data / "pcd").mkdir()
     head = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgba\nSIZE 4 4 4 4\nTYPE F F F U\nCOUNT 1 1 1 1\n"
             "WIDTH {n}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {n}\nDATA binary\n")
-    voxels = []
+    voxels, pcd_clouds = [], []
     for k, P in enumerate(poses):
         d = synth.render_depth(P, intr, 4242, 10 + k, hole_block=hb)
         _write_png16(str(data / "dep_index" / f"{k + 1}.png"), d)
@@ -195,6 +195,7 @@ def test_run_slam_keyframes_loop_closure_and_g2o_handoff(gpu_lib, tmp_path):
         c[:, 3] = np.float32(0)
         (data / "pcd" / f"{k + 1}.pcd").write_bytes(head.format(n=c.shape[0]).encode() + c.tobytes())
         voxels.append((c.shape[0], O.voxel_grid(c, 0.03, 7.0).shape[0]))
+        pcd_clouds.append(c)
     (tmp_path / "parameters.yaml").write_text(
         PARAMS.format(src=str(data), mpc=0.005, fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=W, h=H, lc="yes", planes="yes", pcd="yes"))
     out = subprocess.run([os.path.join(HOST, "run_SLAM"), str(len(poses) - 1)], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
@@ -234,3 +235,25 @@ def test_run_slam_keyframes_loop_closure_and_g2o_handoff(gpu_lib, tmp_path):
         t = ln.split()
         n = int(t[1])
         assert 2 <= n <= 3 and len(t) == 2 + 5 * n and all(float(t[2 + 5 * k + 3]) >= 0 for k in range(n))   # d >= 0 (:383-387)
+
+    # row f-3: the reference's map builder (src/saveOutput.cpp) on the files just written: VoxelGrid, PassThrough z <= 5,
+    # transform by the g2o vertex pose, merge, VoxelGrid -> result.pcd; checked against the oracle pipeline
+    out = subprocess.run([os.path.join(HOST, "saveOutput"), "data/keyframe.txt", "data/final.g2o"], cwd=str(tmp_path),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    parts = []
+    for kid, frame in kf:
+        v = O.voxel_grid_only(pcd_clouds[frame - 1], 0.03)
+        t, _ = O.pass_transform(v, V[kid], 5.0)
+        parts.append(t)
+    want = O.voxel_grid_only(np.concatenate(parts), 0.03)
+    txt = (tmp_path / "result.pcd").read_text().splitlines()
+    assert txt[2] == "FIELDS x y z rgba" and txt[10] == "DATA ascii"
+    got = np.array([[float(x) for x in ln.split()[:3]] for ln in txt[11:]], dtype=np.float32)
+    assert f"POINTS {got.shape[0]}" == txt[9]
+    # the poses went through text (9 significant digits) in both pipelines but are rebuilt by different code: a
+    # voxel on a face can flip, nothing more
+    assert abs(got.shape[0] - want.shape[0]) <= max(3, want.shape[0] // 2000)
+    if got.shape[0] == want.shape[0]:
+        assert np.abs(got - want[:, :3]).max() < 0.035
+    assert "final result saved" in out.stdout
