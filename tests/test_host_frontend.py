@@ -119,6 +119,27 @@ def test_pcd_reader_writer(tmp_path):
         assert (tmp_path / "r.pcd").read_bytes() == raw[: k + 16 * 221202]                # same header, same records
 
 
+def test_generate_trajectory_tool(tmp_path):
+    """Row f-3: generateTrajectory keyframe.txt final.g2o (src/generateTrajectory.cpp): g2o text + associate.txt time
+    stamps -> TUM lines.  Pure host I/O, runs without a GPU."""
+    _build_host()
+    (tmp_path / "ds").mkdir()
+    (tmp_path / "ds" / "associate.txt").write_text("".join(f"{1305031102.1 + 0.03 * k:.6f} rgb/{k}.png {1305031102.2 + 0.03 * k:.6f} depth/{k}.png\n" for k in range(6)))
+    (tmp_path / "parameters.yaml").write_text(PARAMS.format(src=str(tmp_path / "ds"), mpc=0.25, fx=525.0, fy=525.0, cx=319.5, cy=239.5,
+                                                            w=640, h=480, lc="no", planes="no", pcd="no"))
+    h = np.sqrt(0.5)
+    (tmp_path / "final.g2o").write_text(
+        "VERTEX_SE3:QUAT 0 0 0 0 0 0 0 1\nVERTEX_SE3:QUAT 1 0.5 -0.25 1.5 0 0 %.17g %.17g\nFIX 0\n"
+        "EDGE_SE3:QUAT 0 1 0.5 -0.25 1.5 0 0 %.17g %.17g 100 0 0 0 0 0 100 0 0 0 0 100 0 0 0 100 0 0 100 0 100\n" % (h, h, h, h))
+    (tmp_path / "keyframe.txt").write_text("0 1\n1 4\n7 5\n")                 # vertex 7 does not exist: skipped (:64-65)
+    out = subprocess.run([os.path.join(HOST, "generateTrajectory"), "keyframe.txt", "final.g2o"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert out.returncode == 0 and "trajectory saved." in out.stdout
+    rows = [ln.split() for ln in (tmp_path / "trajectory.txt").read_text().splitlines()]
+    assert len(rows) == 2 and rows[0][0] == "1305031102.100000" and rows[1][0] == "1305031102.190000"    # frames 1 and 4
+    assert np.allclose([float(x) for x in rows[0][1:]], [0, 0, 0, 0, 0, 0, 1])
+    assert np.allclose([float(x) for x in rows[1][1:]], [0.5, -0.25, 1.5, 0, 0, h, h], atol=1e-6)   # 90 degrees about z survives the round trip
+
+
 @pytest.mark.gpu
 def test_run_slam_driver_tracks_synthetic_sequence(gpu_lib, tmp_path):
     """run_SLAM N on a synthetic dep_index/ sequence: every frame is aligned against the keyframe, the robot
