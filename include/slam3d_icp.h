@@ -171,6 +171,13 @@ int slam3d_backproject_u16(slam3d_icp_handle *h, const uint16_t *depth, float *x
 int slam3d_fit_planes(slam3d_icp_handle *h, const slam3d_cloud_view *cloud, const int32_t *labels,
                       int32_t nplanes, slam3d_plane *planes);
 
+/* Plane association of GraphicEnd::match(vector<PLANE>&, vector<PLANE>&) (src/GraphicEnd.cpp:459-484): for every plane of
+ * p1 the nearest plane of p2 by L2 distance on (a, b, c, d) -- what FlannBasedMatcher::match returns as
+ * DMatch{queryIdx = i, trainIdx, distance}, computed exactly (<= 8 x 8 planes; ties -> lowest index).  Host code,
+ * needs no device.  train_idx[i] = -1 when n2 == 0. */
+int slam3d_match_planes(const slam3d_plane *p1, int32_t n1, const slam3d_plane *p2, int32_t n2, int32_t *train_idx,
+                        float *distance);
+
 /* ---- frame ingestion filters of GraphicEnd::readimage (src/GraphicEnd.cpp:283-295): pcl::PassThrough on
  * z in [0, z_filter] followed by pcl::VoxelGrid with a cubic leaf (grid_leaf, 0.03), on n 16-byte records
  * {float x, y, z; uint32 rgba} -- the layout of the reference's binary PCD files (data/exp1/pcd/1.pcd header).

@@ -24,7 +24,7 @@ EXPORTED_SYMBOLS = [
     "slam3d_icp_set_clouds_device", "slam3d_icp_set_depth_device", "slam3d_icp_run",
     "slam3d_icp_fetch_results", "slam3d_icp_get_correspondences", "slam3d_icp_get_trace",
     "slam3d_icp_get_clouds", "slam3d_icp_set_profiling", "slam3d_icp_get_timings", "slam3d_icp_get_iteration_timings", "slam3d_icp_get_nn_debug", "slam3d_backproject_u16", "slam3d_fit_planes",
-    "slam3d_voxel_grid", "slam3d_voxel_grid_device", "slam3d_voxel_grid_only", "slam3d_pass_transform", "slam3d_seg_default_params", "slam3d_segment_planes", "slam3d_segment_planes_device",
+    "slam3d_match_planes", "slam3d_voxel_grid", "slam3d_voxel_grid_device", "slam3d_voxel_grid_only", "slam3d_pass_transform", "slam3d_seg_default_params", "slam3d_segment_planes", "slam3d_segment_planes_device",
     "slam3d_icp_dense_set_rows", "slam3d_icp_dense_begin", "slam3d_icp_dense_partial",
     "slam3d_icp_dense_update", "slam3d_icp_dense_finish",
     "slam3d_icp_dense_partial_device", "slam3d_icp_dense_update_device", "slam3d_icp_dense_finish_device",
@@ -105,6 +105,23 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     if path is None:
         _lib = lib
     return lib
+
+
+def match_planes(coeffs1, coeffs2):
+    """(n1,4), (n2,4) plane coefficients -> (train_idx[n1], distance[n1]); host code, no device needed"""
+    a = np.ascontiguousarray(coeffs1, dtype=np.float32).reshape(-1, 4)
+    b = np.ascontiguousarray(coeffs2, dtype=np.float32).reshape(-1, 4)
+    pa, pb = (Plane * max(1, a.shape[0]))(), (Plane * max(1, b.shape[0]))()
+    for i in range(a.shape[0]):
+        pa[i].coeff[:] = a[i].tolist()
+    for j in range(b.shape[0]):
+        pb[j].coeff[:] = b[j].tolist()
+    idx = np.zeros(max(1, a.shape[0]), dtype=np.int32)
+    dist = np.zeros(max(1, a.shape[0]), dtype=np.float32)
+    rc = load_library().slam3d_match_planes(pa, C.c_int32(a.shape[0]), pb, C.c_int32(b.shape[0]), _vp(idx), _vp(dist))
+    if rc:
+        raise Slam3dError(rc, "slam3d_match_planes")
+    return idx[: a.shape[0]], dist[: a.shape[0]]
 
 
 def default_params(intr=None, **kw) -> Params:

@@ -698,6 +698,25 @@ extern "C" int slam3d_fit_planes(slam3d_icp_handle *h, const slam3d_cloud_view *
     return SLAM3D_OK;
 }
 
+// ------------------------------------------------------------------------------ a9: plane association
+extern "C" int slam3d_match_planes(const slam3d_plane *p1, int32_t n1, const slam3d_plane *p2, int32_t n2, int32_t *train_idx,
+                                   float *distance)
+{
+    if (n1 < 0 || n2 < 0 || (n1 > 0 && (!p1 || !train_idx)) || (n2 > 0 && !p2)) return SLAM3D_E_INVALID;
+    for (int i = 0; i < n1; ++i) {
+        int best = -1;
+        float bd = __builtin_inff();
+        for (int j = 0; j < n2; ++j) {
+            float d2 = 0.0f;
+            for (int k = 0; k < 4; ++k) { const float e = p1[i].coeff[k] - p2[j].coeff[k]; d2 = fmaf(e, e, d2); }
+            if (d2 < bd) { bd = d2; best = j; }
+        }
+        train_idx[i] = best;
+        if (distance) distance[i] = best >= 0 ? sqrtf(bd) : __builtin_inff();
+    }
+    return SLAM3D_OK;
+}
+
 // ------------------------------------------------------------------------------ frame ingestion filters (f-1)
 static int vox_alloc(slam3d_icp_handle *h)
 {

@@ -254,6 +254,14 @@ void GraphicEndICP::generateKeyFrame(const double *T)
     _graph.addEdge(_currKF.id - 1, _currKF.id, T, 100.0);
 }
 
+vector<int> GraphicEndICP::match(const vector<slam3d_plane> &p1, const vector<slam3d_plane> &p2)
+{
+    cout << "GraphicEnd::match two planes" << endl;                // src/GraphicEnd.cpp:461
+    vector<int> idx(p1.size(), -1);
+    if (!p1.empty()) slam3d_match_planes(p1.data(), (int)p1.size(), p2.data(), (int)p2.size(), idx.data(), nullptr);
+    return idx;
+}
+
 bool GraphicEndICP::acceptLoop(const RESULT_OF_MULTIPNP &r) const
 {
     return !r.isIdentity() && r.norm <= _loop_closure_error && r.inliers >= _loop_closure_inliers;

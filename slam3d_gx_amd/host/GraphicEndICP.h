@@ -58,6 +58,8 @@ class GraphicEndICP {
     virtual std::vector<int> checknearby(int source, int target);              // src/GraphicEnd.cpp:919-947
     // plane list of a frame: the SACSegmentation loop of extractPlanesAndGenerateImage (src/GraphicEnd.cpp:353-430)
     virtual std::vector<slam3d_plane> extractPlanes(const FRAME &frame);
+    // DMatch list of GraphicEnd::match(vector<PLANE>&, vector<PLANE>&) (src/GraphicEnd.cpp:459-484): trainIdx per plane of p1
+    virtual std::vector<int> match(const std::vector<slam3d_plane> &p1, const std::vector<slam3d_plane> &p2);
     // same call shape and defaults as GraphicEnd::multiPnP (src/GraphicEnd.h:134)
     virtual RESULT_OF_MULTIPNP multiPnP(FRAME &frame1, FRAME &frame2, bool loopclosure = false, int frame_index = 0,
                                         int minimum_inliers = 12);

@@ -63,3 +63,19 @@ def test_create_fails_loudly_without_device_or_with_bad_params():
     with pytest.raises(capi.Slam3dError) as e:
         capi.IcpHandle(p)
     assert e.value.code == -1
+
+
+def test_match_planes_is_exact_nearest_neighbour_without_gpu():
+    """Row a9 (src/GraphicEnd.cpp:459-484): FLANN's approximate 4-d match on <= 3 planes, done exactly on the host."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    a = rng.normal(size=(3, 4)).astype(np.float32)
+    b = np.concatenate([a[[2, 0]] + np.float32(0.01), rng.normal(size=(2, 4)).astype(np.float32) + 5])
+    idx, dist = capi.match_planes(a, b)
+    d = np.linalg.norm(a[:, None, :].astype(np.float64) - b[None, :, :], axis=2)
+    assert list(idx) == list(d.argmin(1)) and idx[0] == 1 and idx[2] == 0
+    assert np.allclose(dist, d.min(1), rtol=1e-6)
+    tie_idx, _ = capi.match_planes(a[:1], np.stack([a[0], a[0]]))
+    assert list(tie_idx) == [0]                                    # ties -> lowest index
+    none_idx, none_d = capi.match_planes(a, np.zeros((0, 4), np.float32))
+    assert list(none_idx) == [-1, -1, -1] and np.isinf(none_d).all()
