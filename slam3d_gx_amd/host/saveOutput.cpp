@@ -53,6 +53,7 @@ int main(int argc, char **argv)
     const size_t cap = max(biggest, total);                        // the merged cloud is at most the sum of the inputs
     p.width = 2048; p.height = (int)((cap + 2047) / 2048); if (p.height < 8) p.height = 8;
     p.iterations = 1; p.max_batch = 1;
+    p.fx = p.fy = 1e9; p.cx = p.cy = 0.0; p.z_filter = 1.0;        // no camera behind this handle: it only hosts the cloud kernels
     p.device = reader.GetInt("hip_device", 0);
     slam3d_icp_handle *hdl = nullptr;
     int rc = slam3d_icp_create(&p, &hdl);

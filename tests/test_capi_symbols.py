@@ -63,6 +63,11 @@ def test_create_fails_loudly_without_device_or_with_bad_params():
     with pytest.raises(capi.Slam3dError) as e:
         capi.IcpHandle(p)
     assert e.value.code == -1
+    p = capi.default_params()
+    p.z_filter = 500.0                      # 640x480 points at up to ~600 m: the int64 fixed-point sums could overflow
+    with pytest.raises(capi.Slam3dError) as e:
+        capi.IcpHandle(p)
+    assert e.value.code == -1
 
 
 def test_match_planes_is_exact_nearest_neighbour_without_gpu():
