@@ -170,12 +170,13 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     if (p->nn_mode < SLAM3D_NN_AUTO || p->nn_mode > SLAM3D_NN_TILES) return SLAM3D_E_INVALID;
     if (!(p->max_corr_dist > 0.0) || !(p->z_filter > 0.0)) return SLAM3D_E_INVALID;
     {   // range of the int64 fixed-point sums (unit 2^-32): a term is at most |p|^2, all N slots may carry one.  With the
-        // declared camera the farthest valid point is z_filter * sqrt(1 + tx^2 + ty^2); N * |p|^2 must stay below 2^30
-        // (2^62 in fixed point).  640x480 @ 7 m uses 2^-6 of that; a configuration beyond it is refused, not wrapped.
+        // declared camera the farthest valid point is z_filter * sqrt(1 + tx^2 + ty^2); N * |p|^2 must stay below 2^28
+        // (2^60 in fixed point; the plane moments about a sample point need the factor 4 of (2|p|)^2).  640x480 @ 7 m
+        // is 11 times below, 1280x960 @ 7 m 2.8 times; a configuration beyond it is refused, not wrapped.
         const double tx = (p->fx > 0.0) ? fmax(p->cx, p->width - 1 - p->cx) / p->fx : 1.0;
         const double ty = (p->fy > 0.0) ? fmax(p->cy, p->height - 1 - p->cy) / p->fy : 1.0;
         const double r2 = p->z_filter * p->z_filter * (1.0 + tx * tx + ty * ty);
-        if (!((double)p->width * p->height * r2 < 1073741824.0)) return SLAM3D_E_INVALID;
+        if (!((double)p->width * p->height * r2 < 268435456.0)) return SLAM3D_E_INVALID;
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device < 0 || p->device >= ndev) return SLAM3D_E_NODEVICE;
