@@ -368,3 +368,26 @@ def test_new_entry_points_reject_bad_arguments(gpu_lib):
         assert lib.slam3d_icp_dense_partial_device(hp, C.c_void_p(8), None) == -5
         assert lib.slam3d_icp_dense_update_device(hp, None, None) == -1
         assert lib.slam3d_icp_set_profiling(None, 1) == -1
+
+
+def test_batches_larger_than_one_argument_block(gpu_lib):
+    """The slot / pointer tables travel as kernel arguments in blocks of 32: a batch of 40 small pairs (and 40 frames
+    for the segmentation) must give, pair by pair, what single calls give."""
+    import torch
+    B, W, H = 40, 96, 72
+    prs = [synth.make_pair(3000 + i, W, H) for i in range(B)]
+    src = [synth.backproject_numpy(p.depth_src, p.intr) for p in prs]
+    tgt = [synth.backproject_numpy(p.depth_tgt, p.intr) for p in prs]
+    Ti = [np.eye(4) for _ in range(B)]
+    Ti[37] = synth.pose_from_seed(9, max_angle_deg=0.5, max_trans=0.01)
+    with capi.IcpHandle(capi.default_params(prs[0].intr, iterations=4, max_batch=B)) as h:
+        res = h.align_batch(src, tgt, Ti)
+        idx37, _ = h.get_correspondences(37)
+        d = torch.from_numpy(np.stack([s.reshape(-1, 4) for s in src])).to("cuda:0")
+        planes = h.segment_planes_device([d.data_ptr() + i * W * H * 16 for i in range(B)], h.seg_params(seed=5))
+    for i in (0, 31, 32, 37, 39):
+        ro = O.icp(src[i], tgt[i], O.params(prs[i].intr, iterations=4, nn_method=0), T_init=Ti[i])
+        assert np.array_equal(res[i]["T_raw"], ro["T_trace"][-1]) and res[i]["inliers"] == ro["inliers"]
+        po, _ = O.segment_planes(src[i], seed=5)
+        assert len(planes[i]) == len(po) and all(np.array_equal(a["coeff"], b["coeff"]) for a, b in zip(planes[i], po))
+    assert np.array_equal(idx37, O.icp(src[37], tgt[37], O.params(prs[37].intr, iterations=4, nn_method=0), T_init=Ti[37])["idx"])
