@@ -67,6 +67,9 @@ struct slam3d_icp_handle {
     int *pin_int = nullptr;       // maxB*5
     std::vector<hipEvent_t> ev;   // 0 start, 1 after preprocess, 2 end, then (nn0,nn1) per iteration
     int slots_uploaded = 0;       // entries of d_slots that match pin_slots
+    hipGraphExec_t graph_exec = nullptr;   // the captured run (slam3d_icp_run without profiling)
+    int graph_B = 0, graph_rows[2] = { 0, 0 };
+    bool graph_T = false, use_graph = true;
     bool profiling = false;       // record the per-iteration events (each costs ~6 us of stream serialisation)
     bool ran_profiled = false;
     bool ran = false; int last_B = 0;
@@ -135,6 +138,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->d_Tinit); F(h->d_slots); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4);
     F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox); F(h->dbg); F(h->prevq); F(h->hint); F(h->scount); F(h->perm); F(h->cost); F(h->tgtB); F(h->qmax2);
     if (h->pin_slots) (void)hipHostFree(h->pin_slots);
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->pin_res) (void)hipHostFree(h->pin_res);
     if (h->pin_seg) (void)hipHostFree(h->pin_seg);
     if (h->pin_fit) (void)hipHostFree(h->pin_fit);
@@ -222,6 +226,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     A(dalloc(h->cost, (size_t)h->maxB * tg.ntiles));
     A(dalloc(h->perm, (size_t)h->maxB * ((tg.ntiles + NN_WAVES - 1) / NN_WAVES) * NN_WAVES));
     if (getenv("SLAM3D_NN_DEBUG")) A(dalloc(h->dbg, (size_t)tg.ntiles * 10));
+    if (getenv("SLAM3D_NO_GRAPH") || getenv("SLAM3D_NN_DEBUG")) h->use_graph = false;
     A(dalloc(h->sums, (size_t)h->maxB * NSUMS)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
     A(dalloc(h->trace_T, (size_t)h->maxB * (iters + 1) * 16)); A(dalloc(h->trace_S, (size_t)h->maxB * iters * NSUMS));
     A(dalloc(h->d_Tinit, (size_t)h->maxB * 16)); A(dalloc(h->d_slots, (size_t)h->maxB));
@@ -343,9 +348,9 @@ static int pick_nsplit(const slam3d_icp_handle *h, int B)
     return ns;
 }
 
-static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init, hipStream_t s)
+// host-side staging of a run: the slot table (kernel arguments, only when it changed) and T_init into pinned memory
+static int stage_inputs(slam3d_icp_handle *h, int B, const double *T_init, hipStream_t s)
 {
-    const Geometry &g = h->g;
     bool same = B <= h->slots_uploaded;                 // the device copy of the slot table is still current
     for (int b = 0; b < B; ++b) {
         if (!h->h_slots[b].src || !h->h_slots[b].tgt) return SLAM3D_E_STATE;
@@ -360,10 +365,18 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         }
         h->slots_uploaded = B;
     }
+    if (T_init) memcpy(h->pin_T, T_init, sizeof(double) * 16 * B);
+    HIPCHK(h, hipGetLastError());
+    return SLAM3D_OK;
+}
+
+// device-side part of the preprocessing (everything here has launch-invariant arguments: it can live in a graph)
+static int enqueue_preprocess_dev(slam3d_icp_handle *h, int B, bool has_T, hipStream_t s)
+{
+    const Geometry &g = h->g;
     const int nperm = ((h->tg.ntiles + NN_WAVES - 1) / NN_WAVES) * NN_WAVES;
     const double *dT = nullptr;
-    if (T_init) {
-        memcpy(h->pin_T, T_init, sizeof(double) * 16 * B);
+    if (has_T) {
         HIPCHK(h, hipMemcpyAsync(h->d_Tinit, h->pin_T, sizeof(double) * 16 * B, hipMemcpyHostToDevice, s));
         dT = h->d_Tinit;
     }
@@ -391,6 +404,12 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
     hipLaunchKernelGGL(k_init_T, dim3(B), dim3(64), 0, s, dT, h->Tcur, h->trace_T, h->flags, h->acc, iters);
     HIPCHK(h, hipGetLastError());
     return SLAM3D_OK;
+}
+
+static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init, hipStream_t s)
+{
+    const int rc = stage_inputs(h, B, T_init, s);
+    return rc ? rc : enqueue_preprocess_dev(h, B, T_init != nullptr, s);
 }
 
 // one iteration's data-parallel part: NN search + normal-equation chunks, then the 29-sum reduction
@@ -442,13 +461,37 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
         HIPCHK(h, hipStreamWaitEvent(s, h->ev[0], 0));
     }
     HIPCHK(h, hipEventRecord(h->ev[0], s));
-    int rc = enqueue_preprocess(h, B, T_init, s);
-    if (rc) return rc;
-    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[1], s));
     const int iters = h->p.iterations;
-    for (int it = 0; it < iters; ++it) {
-        rc = enqueue_iteration(h, B, s, h->profiling ? h->ev[3 + 2 * it] : nullptr, h->profiling ? h->ev[4 + 2 * it] : nullptr, it, 1);
+    int rc;
+    if (!h->profiling && h->use_graph) {
+        // The whole run (preprocessing + iterations x {NN, solve}) has launch-invariant arguments: it is captured once
+        // per (B, T_init given) into a HIP graph and replayed with one hipGraphLaunch; only the slot table (kernel
+        // arguments) and T_init (pinned staging) change from run to run and stay outside.
+        rc = stage_inputs(h, B, T_init, s);
         if (rc) return rc;
+        const bool has_T = T_init != nullptr;
+        if (!h->graph_exec || h->graph_B != B || h->graph_T != has_T || h->graph_rows[0] != h->row0 || h->graph_rows[1] != h->row1) {
+            if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_preprocess_dev(h, B, has_T, s);
+            for (int it = 0; it < iters && !rc; ++it) rc = enqueue_iteration(h, B, s, nullptr, nullptr, it, 1);
+            const hipError_t ce = hipStreamEndCapture(s, &graph);
+            if (rc || ce != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); (void)hipGetLastError(); return rc ? rc : SLAM3D_E_HIP; }
+            const hipError_t ie = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ie != hipSuccess) { h->graph_exec = nullptr; (void)hipGetLastError(); return SLAM3D_E_HIP; }
+            h->graph_B = B; h->graph_T = has_T; h->graph_rows[0] = h->row0; h->graph_rows[1] = h->row1;
+        }
+        HIPCHK(h, hipGraphLaunch(h->graph_exec, s));
+    } else {
+        rc = enqueue_preprocess(h, B, T_init, s);
+        if (rc) return rc;
+        if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[1], s));
+        for (int it = 0; it < iters; ++it) {
+            rc = enqueue_iteration(h, B, s, h->profiling ? h->ev[3 + 2 * it] : nullptr, h->profiling ? h->ev[4 + 2 * it] : nullptr, it, 1);
+            if (rc) return rc;
+        }
     }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev[2], s));
