@@ -391,3 +391,34 @@ def test_batches_larger_than_one_argument_block(gpu_lib):
         po, _ = O.segment_planes(src[i], seed=5)
         assert len(planes[i]) == len(po) and all(np.array_equal(a["coeff"], b["coeff"]) for a, b in zip(planes[i], po))
     assert np.array_equal(idx37, O.icp(src[37], tgt[37], O.params(prs[37].intr, iterations=4, nn_method=0), T_init=Ti[37])["idx"])
+
+
+@pytest.mark.parametrize("case_seed", [11, 12, 13])
+def test_randomised_configurations_stay_bit_identical(gpu_lib, case_seed):
+    """A slice of tools/soak_parity.py (300 random cases run clean on the MI355X): random size, gate, estimator,
+    iteration count, initial guess and sparsity; indices, d2 bits, every iterate and the sums equal the oracle's."""
+    rng = np.random.default_rng(case_seed)
+    for _ in range(4):
+        W = int(rng.choice([64, 104, 160, 200])); H = int(rng.choice([48, 72, 120, 150]))
+        seed = int(rng.integers(0, 1 << 30)); est = int(rng.integers(0, 2)); iters = int(rng.integers(1, 6))
+        gate = float(rng.choice([0.01, 0.03, 0.1, 0.3, 1.0]))
+        pr = synth.make_pair(seed, W, H, noise=bool(rng.integers(0, 2)), holes=bool(rng.integers(0, 2)))
+        s4 = synth.backproject_numpy(pr.depth_src, pr.intr); t4 = synth.backproject_numpy(pr.depth_tgt, pr.intr)
+        mode, Ti = int(rng.integers(0, 4)), None
+        if mode == 1:
+            Ti = synth.pose_from_seed(seed + 1, max_angle_deg=8.0, max_trans=0.3)
+        elif mode == 2:
+            s4 = s4.copy(); s4[rng.random(s4.shape[:2]) < 0.7] = np.nan
+        elif mode == 3:
+            t4 = t4.copy(); t4[rng.random(t4.shape[:2]) < 0.9] = np.nan
+        kw = dict(estimator=est, iterations=iters, max_corr_dist=gate)
+        ro = O.icp(s4, t4, O.params(pr.intr, nn_method=0, **kw), T_init=Ti)
+        with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1, **kw)) as h:
+            rg = h.align(s4, t4, Ti)
+            idx, d2 = h.get_correspondences(0)
+            Tt, St = h.get_trace(0)
+        ctx = dict(W=W, H=H, seed=seed, est=est, iters=iters, gate=gate, mode=mode)
+        assert np.array_equal(idx, ro["idx"]), ctx
+        assert np.array_equal(d2.view(np.uint32), ro["d2"].view(np.uint32)), ctx
+        assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:iters], ro["sums_trace"]), ctx
+        assert rg["status"] == ro["status"] and rg["inliers"] == ro["inliers"], ctx

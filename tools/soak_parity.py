@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Randomised parity soak (developer tool, needs an MI355X): random sizes / seeds / gates / estimators / initial guesses,
+HIP (default tile-pruned mode) vs the brute-force oracle: indices, d2, every iterate T and the sums must be identical.
+usage: tools/soak_parity.py [n_cases] [seed]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O
+from slam3d_gx_amd import capi, synth
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = 0
+t0 = time.time()
+for case in range(n_cases):
+    W = int(rng.choice([64, 96, 104, 128, 160, 200, 256, 320]))
+    H = int(rng.choice([48, 56, 72, 96, 120, 150, 200, 240]))
+    seed = int(rng.integers(0, 1 << 30))
+    est = int(rng.integers(0, 2))
+    iters = int(rng.integers(1, 7))
+    gate = float(rng.choice([0.01, 0.03, 0.1, 0.3, 1.0]))
+    pr = synth.make_pair(seed, W, H, noise=bool(rng.integers(0, 2)), holes=bool(rng.integers(0, 2)))
+    s4 = synth.backproject_numpy(pr.depth_src, pr.intr); t4 = synth.backproject_numpy(pr.depth_tgt, pr.intr)
+    mode = rng.integers(0, 4)
+    Ti = None
+    if mode == 1:      # bad initial guess
+        Ti = synth.pose_from_seed(seed + 1, max_angle_deg=8.0, max_trans=0.3)
+    elif mode == 2:    # sparse target / source
+        k = rng.random(s4.shape[:2]) < 0.7; s4 = s4.copy(); s4[k] = np.nan
+    elif mode == 3:
+        k = rng.random(t4.shape[:2]) < 0.9; t4 = t4.copy(); t4[k] = np.nan
+    kw = dict(estimator=est, iterations=iters, max_corr_dist=gate)
+    ro = O.icp(s4, t4, O.params(pr.intr, nn_method=0, **kw), T_init=Ti)
+    with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1, **kw)) as h:
+        rg = h.align(s4, t4, Ti)
+        idx, d2 = h.get_correspondences(0)
+        Tt, St = h.get_trace(0)
+    ok = (np.array_equal(idx, ro["idx"]) and np.array_equal(d2.view(np.uint32), ro["d2"].view(np.uint32))
+          and np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:iters], ro["sums_trace"])
+          and rg["status"] == ro["status"] and rg["inliers"] == ro["inliers"])
+    if not ok:
+        bad += 1
+        print("MISMATCH", dict(case=case, W=W, H=H, seed=seed, est=est, iters=iters, gate=gate, mode=int(mode)),
+              "idx", int((idx != ro["idx"]).sum()), flush=True)
+print(f"{n_cases} cases, {bad} mismatches, {time.time() - t0:.1f} s")
+sys.exit(1 if bad else 0)
