@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity soak (developer tool, needs an MI355X): random sizes / seeds / gates / estimators / initial guesses,
 HIP (default tile-pruned mode) vs the brute-force oracle: indices, d2, every iterate T and the sums must be identical.
-usage: tools/soak_parity.py [n_cases] [seed]"""
+usage: tools/soak_parity.py [n_cases] [seed] [nn_mode: 0 auto(tiles) 1 brute VALU 2 brute MFMA]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,6 +11,7 @@ from slam3d_gx_amd import capi, synth
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+nn_mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 bad = 0
 t0 = time.time()
 for case in range(n_cases):
@@ -32,7 +33,7 @@ for case in range(n_cases):
         k = rng.random(t4.shape[:2]) < 0.9; t4 = t4.copy(); t4[k] = np.nan
     kw = dict(estimator=est, iterations=iters, max_corr_dist=gate)
     ro = O.icp(s4, t4, O.params(pr.intr, nn_method=0, **kw), T_init=Ti)
-    with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1, **kw)) as h:
+    with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1, nn_mode=nn_mode, **kw)) as h:
         rg = h.align(s4, t4, Ti)
         idx, d2 = h.get_correspondences(0)
         Tt, St = h.get_trace(0)
