@@ -422,3 +422,30 @@ def test_randomised_configurations_stay_bit_identical(gpu_lib, case_seed):
         assert np.array_equal(d2.view(np.uint32), ro["d2"].view(np.uint32)), ctx
         assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:iters], ro["sums_trace"]), ctx
         assert rg["status"] == ro["status"] and rg["inliers"] == ro["inliers"], ctx
+
+
+def test_two_handles_in_flight_give_the_sequential_results(gpu_lib):
+    """What bench.py's double buffering relies on: two handles (one HIP stream each) with runs queued back to back;
+    fetch_results waits for its own run only and returns exactly what a lone run returns."""
+    import torch
+    prs = [synth.make_pair(5000 + i, 320, 240) for i in range(2)]
+    src = [torch.from_numpy(synth.backproject_numpy(p.depth_src, p.intr)).to("cuda:0") for p in prs]
+    tgt = [torch.from_numpy(synth.backproject_numpy(p.depth_tgt, p.intr)).to("cuda:0") for p in prs]
+    hs = [capi.IcpHandle(capi.default_params(prs[0].intr, iterations=8, max_batch=1)) for _ in range(2)]
+    try:
+        lone = []
+        for k in range(2):
+            hs[k].set_clouds_device(0, src[k].data_ptr(), tgt[k].data_ptr())
+            hs[k].run(1)
+            lone.append(hs[k].fetch_results(1)[0])
+        for rep in range(5):                       # queue A, queue B, then fetch A, fetch B (graph replays on two streams)
+            hs[0].run(1); hs[1].run(1)
+            both = [hs[0].fetch_results(1)[0], hs[1].fetch_results(1)[0]]
+            for k in range(2):
+                assert np.array_equal(both[k]["T_raw"], lone[k]["T_raw"]) and both[k]["inliers"] == lone[k]["inliers"]
+    finally:
+        for h in hs:
+            h.close()
+    for k in range(2):
+        ro = O.icp(src[k].cpu().numpy(), tgt[k].cpu().numpy(), O.params(prs[k].intr, iterations=8, nn_method=1))
+        assert np.array_equal(lone[k]["T_raw"], ro["T_trace"][-1])
