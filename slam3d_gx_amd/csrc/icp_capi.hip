@@ -67,6 +67,7 @@ struct slam3d_icp_handle {
     int *pin_int = nullptr;       // maxB*5
     std::vector<hipEvent_t> ev;   // 0 start, 1 after preprocess, 2 end, then (nn0,nn1) per iteration
     int slots_uploaded = 0;       // entries of d_slots that match pin_slots
+    int dense_batch = 4;          // pairs per launch from which the 7-waves-per-SIMD build of the NN kernel is used
     hipGraphExec_t graph_exec = nullptr;   // the captured run (slam3d_icp_run without profiling)
     int graph_B = 0, graph_rows[2] = { 0, 0 };
     bool graph_T = false, use_graph = true;
@@ -227,6 +228,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     A(dalloc(h->perm, (size_t)h->maxB * ((tg.ntiles + NN_WAVES - 1) / NN_WAVES) * NN_WAVES));
     if (getenv("SLAM3D_NN_DEBUG")) A(dalloc(h->dbg, (size_t)tg.ntiles * 10));
     if (getenv("SLAM3D_NO_GRAPH") || getenv("SLAM3D_NN_DEBUG")) h->use_graph = false;
+    if (getenv("SLAM3D_DENSE_BATCH")) h->dense_batch = atoi(getenv("SLAM3D_DENSE_BATCH"));
     A(dalloc(h->sums, (size_t)h->maxB * NSUMS)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
     A(dalloc(h->trace_T, (size_t)h->maxB * (iters + 1) * 16)); A(dalloc(h->trace_S, (size_t)h->maxB * iters * NSUMS));
     A(dalloc(h->d_Tinit, (size_t)h->maxB * 16)); A(dalloc(h->d_slots, (size_t)h->maxB));
@@ -421,8 +423,13 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
     if (e0) HIPCHK(h, hipEventRecord(e0, s));
     if (nn_mode_of(h) == SLAM3D_NN_TILES) {
-        hipLaunchKernelGGL(k_nn_tiles_acc, dim3((tg.ntiles + NN_WAVES - 1) / NN_WAVES, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
-                           h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, h->perm, h->cost, h->acc, h->g, tg, h->dbg);
+        // few pairs: 4 staged records / 6 waves per SIMD (latency); many pairs: 3 records / 7 waves per SIMD (throughput)
+        if (B >= h->dense_batch)
+            hipLaunchKernelGGL((k_nn_tiles_acc<3, 7>), dim3((tg.ntiles + NN_WAVES - 1) / NN_WAVES, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
+                               h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, h->perm, h->cost, h->acc, h->g, tg, h->dbg);
+        else
+            hipLaunchKernelGGL((k_nn_tiles_acc<4, 6>), dim3((tg.ntiles + NN_WAVES - 1) / NN_WAVES, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
+                               h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, h->perm, h->cost, h->acc, h->g, tg, h->dbg);
         if (it == 1 && do_solve)      // costs are stable from the second iteration on: balance the blocks once
             hipLaunchKernelGGL(k_balance, dim3(B), dim3(1024), 0, s, h->cost, h->perm, tg, (tg.ntiles + NN_WAVES - 1) / NN_WAVES);
         if (e1) HIPCHK(h, hipEventRecord(e1, s));

@@ -836,7 +836,9 @@ __device__ __forceinline__ float box_gap2(const float4 lo, const float4 hi, floa
     return gx * gx + gy * gy + gz * gz;      // empty boxes (lo=+inf, hi=-inf) give +inf
 }
 
-constexpr int NN_STAGE = 4;          // target tile records staged in LDS per batch (4 x 1152 B per wave: 6 blocks per CU)
+// Two builds of the kernel: <4 staged tile records per wave, 6 waves per SIMD> covers the whole 2x2 hint block in
+// step 1 and is the faster one when a launch holds few pairs (latency bound); <3, 7> trades the fourth record for a
+// seventh wave per SIMD and wins when many pairs fill the chip (throughput bound: 44 k -> 47.6 k it/s at 64 pairs).
 constexpr int NN_MAX_ITEMS = 256;    // (owner wave, coarse cell) work items shared by the waves of a block
 constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (8 measured slower: 2 blocks per CU)
 
@@ -851,7 +853,8 @@ constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (
 //      quadrants), merged into the owner's keys with ds_min_u64;                             -- barrier --
 //   4. every wave finishes its own tile: gate, row products, level-1 reduction, hint for the next iteration.
 // The result is independent of which wave processes which item (keys are merged by an exact minimum).
-__global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_nn_tiles_acc(const SlotPtrs *__restrict__ slots,
+template <int NN_STAGE, int WPE>
+__global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_nn_tiles_acc(const SlotPtrs *__restrict__ slots,
                                                         const float4 *__restrict__ nrm_all,
                                                         const float4 *__restrict__ srcT,
                                                         const float4 *__restrict__ tgtT,
@@ -900,7 +903,9 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(6
     float px = 0.0f, py = 0.0f, pz = 0.0f;
     bool valid = false, tight = false, loose = false;
     unsigned long long bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
-    int ta[NN_STAGE] = { -1, -1, -1, -1 };            // the tiles of the current owner's step 1
+    int ta[NN_STAGE];                                 // the tiles of the current owner's step 1
+#pragma unroll
+    for (int k = 0; k < NN_STAGE; ++k) ta[k] = -1;
     int tt[NN_STAGE];
     float4 r[NN_STAGE];
 
@@ -995,7 +1000,9 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(6
         bool hit2 = false;
         if (tx < tg.ntx && ty < tg.nty) {
             const int tid = ty * tg.ntx + tx;                    // already scanned in step 1?
-            const bool in_a = tid == ta[0] || tid == ta[1] || tid == ta[2] || tid == ta[3];
+            bool in_a = false;
+#pragma unroll
+            for (int k = 0; k < NN_STAGE; ++k) in_a = in_a || tid == ta[k];
             hit2 = !in_a && reach(lo, hi, thr_t, thr_l);
         }
         unsigned long long tm0 = __ballot(hit2), tm = 0ull;
@@ -1042,10 +1049,10 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(6
             tt[0] = base;
             tt[1] = fx ? base + 1 : -1;
             tt[2] = fy ? base + tg.ntx : -1;
-            tt[3] = (fx && fy) ? base + tg.ntx + 1 : -1;
+            if constexpr (NN_STAGE >= 4) tt[3] = (fx && fy) ? base + tg.ntx + 1 : -1;     // (else: through the items)
         } else {
             const int tx0 = t % tg.ntx, ty0 = t / tg.ntx;
-            const int ox[NN_STAGE] = { 0, -1, 1, 0 }, oy[NN_STAGE] = { 0, 0, 0, -1 };     // (the rest of the ring comes through the items)
+            const int ox[4] = { 0, -1, 1, 0 }, oy[4] = { 0, 0, 0, -1 };                     // (the rest of the ring comes through the items)
 #pragma unroll
             for (int k = 0; k < NN_STAGE; ++k) {
                 const int tx = tx0 + ox[k], ty = ty0 + oy[k];
