@@ -836,9 +836,11 @@ __device__ __forceinline__ float box_gap2(const float4 lo, const float4 hi, floa
     return gx * gx + gy * gy + gz * gz;      // empty boxes (lo=+inf, hi=-inf) give +inf
 }
 
-// Two builds of the kernel: <4 staged tile records per wave, 6 waves per SIMD> covers the whole 2x2 hint block in
-// step 1 and is the faster one when a launch holds few pairs (latency bound); <3, 7> trades the fourth record for a
-// seventh wave per SIMD and wins when many pairs fill the chip (throughput bound: 44 k -> 47.6 k it/s at 64 pairs).
+// Two builds of the kernel.  <4 staged tile records per wave, 6 waves per SIMD, cooperative>: the four waves of a
+// block share their work items; it scans the whole 2x2 hint block in step 1 and is the faster one while a launch
+// holds few pairs (latency bound: the slowest block ends the launch).  <3, 7, not cooperative>: every wave sweeps its
+// own cells -- no shared lists, no block barriers, 14 KB of LDS -- and a seventh wave per SIMD; it wins when many
+// pairs fill the chip (throughput bound: 64 pairs 44 k -> 52 k it/s).
 constexpr int NN_MAX_ITEMS = 256;    // (owner wave, coarse cell) work items shared by the waves of a block
 constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (8 measured slower: 2 blocks per CU)
 
@@ -853,7 +855,7 @@ constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (
 //      quadrants), merged into the owner's keys with ds_min_u64;                             -- barrier --
 //   4. every wave finishes its own tile: gate, row products, level-1 reduction, hint for the next iteration.
 // The result is independent of which wave processes which item (keys are merged by an exact minimum).
-template <int NN_STAGE, int WPE>
+template <int NN_STAGE, int WPE, bool COOP>
 __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_nn_tiles_acc(const SlotPtrs *__restrict__ slots,
                                                         const float4 *__restrict__ nrm_all,
                                                         const float4 *__restrict__ srcT,
@@ -1089,16 +1091,18 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         // ---- step 2: publish the queries and one work item per reachable coarse cell
         const float bnd0 = __int_as_float((int)(unsigned int)(bkey >> 32));
         tight = valid && bnd0 <= 0.0625f * g.gate2; loose = valid && !tight;
-        qpos[w][lane] = make_float4(px, py, pz, valid ? (tight ? 1.0f : 2.0f) : 0.0f);
-        qkey[w][lane] = bkey;
-        if (lane < NN_STAGE) {
-            int v = ta[0];
+        if constexpr (COOP) {
+            qpos[w][lane] = make_float4(px, py, pz, valid ? (tight ? 1.0f : 2.0f) : 0.0f);
+            qkey[w][lane] = bkey;
+            if (lane < NN_STAGE) {
+                int v = ta[0];
 #pragma unroll
-            for (int k = 1; k < NN_STAGE; ++k) if (lane == k) v = ta[k];
-            wcentre[w][lane] = v;
+                for (int k = 1; k < NN_STAGE; ++k) if (lane == k) v = ta[k];
+                wcentre[w][lane] = v;
+            }
         }
         class_boxes();
-        if (lane < 13) {   // the boxes do not change while the items are drained: helpers read them instead of redoing 12 wave reductions
+        if (COOP && lane < 13) {   // the boxes do not change while the items are drained: helpers read them instead of redoing 12 wave reductions
             const float bx[13] = { qminx, qminy, qminz, qmaxx, qmaxy, qmaxz, lminx, lminy, lminz, lmaxx, lmaxy, lmaxz, any_loose ? 1.0f : 0.0f };
             float v = bx[0];
 #pragma unroll
@@ -1112,6 +1116,15 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             bool hit = false;
             if (cidx < tg.ncoarse) hit = reach(CB[2 * cidx], CB[2 * cidx + 1], thr_t, thr_l);
             const unsigned long long cm = __ballot(hit);
+            if constexpr (!COOP) {          // throughput build: every wave sweeps its own cells, nothing is shared
+                unsigned long long rest = cm;
+                while (rest) {
+                    const int k = __builtin_ctzll(rest);
+                    rest &= rest - 1;
+                    sweep_cell(c0 + k);
+                }
+                continue;
+            }
             const int cnt = __popcll(cm);
             int base = 0;
             if (lane == 0 && cnt) base = atomicAdd(&n_items, cnt);
@@ -1135,9 +1148,9 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         }
     }
     if (lane == 0) atomicAdd(&wcost[w], (int)(clock64() - cw0));
-    __syncthreads();
+    if constexpr (COOP) __syncthreads();
     // ================= step 3: drain the shared item list =================
-    {
+    if constexpr (COOP) {
         const int total = min(n_items, NN_MAX_ITEMS);
         while (true) {
             int it = 0;
@@ -1163,12 +1176,12 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             if (lane == 0) atomicAdd(&wcost[owner], (int)(clock64() - ci0));
         }
     }
-    __syncthreads();
+    if constexpr (COOP) __syncthreads();
     if (dbg) clk3 = clock64();
     if (!has_tile) return;
     if (lane == 0) cost[(size_t)b * tg.ntiles + t] = wcost[w];           // input of k_balance
     // ================= step 4: this wave's own tile: fused S4 accumulation =================
-    bkey = qkey[w][lane];
+    if constexpr (COOP) bkey = qkey[w][lane];
     if (__ballot(own_valid) == 0ull) bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
     double s[NSUMS];
     finish_slot(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, prevq + gs, s);
