@@ -673,32 +673,47 @@ __global__ __launch_bounds__(64) void k_nn_mfma(const SlotPtrs *__restrict__ slo
 }
 
 // rows of the normal equations for a source point p' matched to target point q with normal n (spec S4)
-__device__ __forceinline__ void row_sums(int estimator, float pxf, float pyf, float pzf, const float4 q4,
-                                         const float4 n4, double *__restrict__ s)
+// A slot's 29 terms are products of a handful of values; only those eight ("basis") stay live between the gather
+// and the reduction, the products are formed group by group while they are summed (58 VGPRs of row sums made the
+// epilogue the register peak of the kernel).  point-to-plane: v = a[0..5], b, 1;  svd: v = p', q, |q - p'|^2, 1.
+// A slot without a correspondence has an all-zero basis, hence all-zero terms.
+struct RowBasis { double v[8]; };
+
+__device__ __forceinline__ void row_basis(int estimator, float pxf, float pyf, float pzf, const float4 q4, const float4 n4, RowBasis &B)
 {
     const double px = pxf, py = pyf, pz = pzf;
     const double qx = q4.x, qy = q4.y, qz = q4.z;
     const double dx = qx - px, dy = qy - py, dz = qz - pz;
     if (estimator == 0) {
         const double nx = n4.x, ny = n4.y, nz = n4.z;
-        double a[6];
-        a[0] = py * nz - pz * ny; a[1] = pz * nx - px * nz; a[2] = px * ny - py * nx;
-        a[3] = nx; a[4] = ny; a[5] = nz;
-        const double bb = (nx * dx + ny * dy) + nz * dz;
-        int k = 0;
-#pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = r; c < 6; ++c) s[k++] = a[r] * a[c];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) s[21 + r] = a[r] * bb;
-        s[27] = 1.0; s[28] = bb * bb;
+        B.v[0] = py * nz - pz * ny; B.v[1] = pz * nx - px * nz; B.v[2] = px * ny - py * nx;
+        B.v[3] = nx; B.v[4] = ny; B.v[5] = nz;
+        B.v[6] = (nx * dx + ny * dy) + nz * dz;
     } else {
-        s[0] = px; s[1] = py; s[2] = pz; s[3] = qx; s[4] = qy; s[5] = qz;
-        s[6] = px * qx; s[7] = px * qy; s[8] = px * qz;
-        s[9] = py * qx; s[10] = py * qy; s[11] = py * qz;
-        s[12] = pz * qx; s[13] = pz * qy; s[14] = pz * qz;
-        s[27] = 1.0; s[28] = (dx * dx + dy * dy) + dz * dz;
+        B.v[0] = px; B.v[1] = py; B.v[2] = pz; B.v[3] = qx; B.v[4] = qy; B.v[5] = qz;
+        B.v[6] = (dx * dx + dy * dy) + dz * dz;
+    }
+    B.v[7] = 1.0;
+}
+
+// term K of the 29-slot record (spec S4), K a compile-time constant
+template <int EST, int K> __device__ __forceinline__ double row_term(const RowBasis &B)
+{
+    if constexpr (K >= NSUMS) return 0.0;
+    else if constexpr (K == 27) return B.v[7];
+    else if constexpr (EST == 0) {
+        if constexpr (K < 21) {
+            constexpr int r = K < 6 ? 0 : (K < 11 ? 1 : (K < 15 ? 2 : (K < 18 ? 3 : (K < 20 ? 4 : 5))));
+            constexpr int first = r == 0 ? 0 : (r == 1 ? 6 : (r == 2 ? 11 : (r == 3 ? 15 : (r == 4 ? 18 : 20))));
+            constexpr int c = r + (K - first);
+            return B.v[r] * B.v[c];
+        } else if constexpr (K < 27) return B.v[K - 21] * B.v[6];
+        else return B.v[6] * B.v[6];
+    } else {
+        if constexpr (K < 6) return B.v[7] != 0.0 ? B.v[K] : 0.0;
+        else if constexpr (K < 15) return B.v[(K - 6) / 3] * B.v[3 + (K - 6) % 3];
+        else if constexpr (K < 27) return 0.0;
+        else return B.v[6];
     }
 }
 
@@ -749,18 +764,29 @@ __device__ __forceinline__ double fix_d(double v) { return rint(v * FIX_SCALE); 
 // the wave's 64 slots -> the pair's accumulators (replica chosen by the block): the wave total of each component
 // is converted to int64 once (four components per pass sit in lanes 0/16/32/48) and leaves as 8 atomic
 // instructions of four addresses each; tiles without a match issue none
-__device__ __forceinline__ void tile_accumulate(const double *__restrict__ s, long long *__restrict__ acc /* [ACC_STRIDE] */)
+template <int EST, int K0> __device__ __forceinline__ void tile_accumulate_group(const RowBasis &B, long long *__restrict__ acc, int lane, int koff)
+{
+    const double x = wave_sum_x4(fix_d(row_term<EST, K0>(B)), fix_d(row_term<EST, K0 + 1>(B)), fix_d(row_term<EST, K0 + 2>(B)),
+                                 fix_d(row_term<EST, K0 + 3>(B)));
+    if ((lane & 15) == 0 && x != 0.0) atomicAdd(reinterpret_cast<unsigned long long *>(acc + K0 + koff), (unsigned long long)__double2ll_rn(x));
+}
+template <int EST> __device__ __forceinline__ void tile_accumulate_est(const RowBasis &B, long long *__restrict__ acc)
 {
     const int lane = threadIdx.x & 63;
     const int sel = lane >> 4;                       // row -> which of (a, c, b, d)
     const int koff = sel == 0 ? 0 : (sel == 1 ? 2 : (sel == 2 ? 1 : 3));
-    if (__ballot(s[27] != 0.0) == 0ull) return;
-#pragma unroll
-    for (int k = 0; k < 32; k += 4) {
-        const double x = wave_sum_x4(fix_d(s[k]), k + 1 < NSUMS ? fix_d(s[k + 1]) : 0.0, k + 2 < NSUMS ? fix_d(s[k + 2]) : 0.0,
-                                     k + 3 < NSUMS ? fix_d(s[k + 3]) : 0.0);
-        if ((lane & 15) == 0 && x != 0.0) atomicAdd(reinterpret_cast<unsigned long long *>(acc + k + koff), (unsigned long long)__double2ll_rn(x));
+    tile_accumulate_group<EST, 0>(B, acc, lane, koff);  tile_accumulate_group<EST, 4>(B, acc, lane, koff);
+    tile_accumulate_group<EST, 8>(B, acc, lane, koff);  tile_accumulate_group<EST, 12>(B, acc, lane, koff);
+    if constexpr (EST == 0) {                        // svd: terms 15..26 are zero
+        tile_accumulate_group<EST, 16>(B, acc, lane, koff); tile_accumulate_group<EST, 20>(B, acc, lane, koff);
     }
+    tile_accumulate_group<EST, 24>(B, acc, lane, koff); tile_accumulate_group<EST, 28>(B, acc, lane, koff);
+}
+__device__ __forceinline__ void tile_accumulate(int estimator, const RowBasis &B, long long *__restrict__ acc /* [ACC_STRIDE] */)
+{
+    if (__ballot(B.v[7] != 0.0) == 0ull) return;
+    if (estimator == 0) tile_accumulate_est<0>(B, acc);
+    else tile_accumulate_est<1>(B, acc);
 }
 
 // decode a packed NN key, apply the gate, record the correspondence and form the row products
@@ -768,10 +794,10 @@ __device__ __forceinline__ void finish_slot(bool valid, unsigned long long key, 
                                             const float4 *__restrict__ tcloud, const float4 *__restrict__ tnrm,
                                             float gate2, int estimator, int *__restrict__ corr_out,
                                             float *__restrict__ cd2_out, float4 *__restrict__ prevq_out,
-                                            double *__restrict__ s)
+                                            RowBasis &B)
 {
 #pragma unroll
-    for (int k = 0; k < NSUMS; ++k) s[k] = 0.0;
+    for (int k = 0; k < 8; ++k) B.v[k] = 0.0;
     const int j = (int)(unsigned int)(key & 0xffffffffull);
     const float d2 = __int_as_float((int)(unsigned int)(key >> 32));
     const bool ok = valid && (j >= 0) && (d2 <= gate2);
@@ -782,7 +808,7 @@ __device__ __forceinline__ void finish_slot(bool valid, unsigned long long key, 
         const float4 q4 = tcloud[j];
         float4 n4 = make_float4(0, 0, 0, 0);
         if (estimator == 0) n4 = tnrm[j];
-        row_sums(estimator, px, py, pz, q4, n4, s);
+        row_basis(estimator, px, py, pz, q4, n4, B);
         pq = make_float4(q4.x, q4.y, q4.z, __int_as_float(j));
     }
     *prevq_out = pq;        // next iteration's upper bound comes from this point (no dependent gather)
@@ -810,10 +836,10 @@ __global__ __launch_bounds__(CHUNK) void k_accumulate(const SlotPtrs *__restrict
     xform(m, sp.x, sp.y, sp.z, px, py, pz);
     const unsigned long long key = best[gs];
     best[gs] = ~0ull;
-    double s[NSUMS];
+    RowBasis rb;
     finish_slot(valid, key, px, py, pz, slots[b].tgt, nrm_all + (size_t)b * g.N, g.gate2, g.estimator, corr + gs, cd2 + gs,
-                prevq + gs, s);
-    tile_accumulate(s, acc + ((size_t)b * ACC_R + (c % ACC_R)) * ACC_STRIDE);
+                prevq + gs, rb);
+    tile_accumulate(g.estimator, rb, acc + ((size_t)b * ACC_R + (c % ACC_R)) * ACC_STRIDE);
 }
 
 // ------------------------------------------------------------------ S4, tile-pruned exact NN
@@ -1183,11 +1209,11 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     // ================= step 4: this wave's own tile: fused S4 accumulation =================
     if constexpr (COOP) bkey = qkey[w][lane];
     if (__ballot(own_valid) == 0ull) bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
-    double s[NSUMS];
-    finish_slot(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, prevq + gs, s);
-    tile_accumulate(s, acc + ((size_t)b * ACC_R + (c % ACC_R)) * ACC_STRIDE);
+    RowBasis rb;
+    finish_slot(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, prevq + gs, rb);
+    tile_accumulate(g.estimator, rb, acc + ((size_t)b * ACC_R + (c % ACC_R)) * ACC_STRIDE);
     {   // hint for the next iteration: the tile holding the match of a lane near the tile centre
-        const bool ok = s[27] != 0.0;
+        const bool ok = rb.v[7] != 0.0;
         const unsigned long long mm = __ballot(ok);
         if (mm) {
             const unsigned long long ctr = mm & 0x0000001818000000ull;      // lanes 27,28,35,36
