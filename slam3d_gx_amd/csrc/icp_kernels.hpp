@@ -864,9 +864,9 @@ __device__ __forceinline__ float box_gap2(const float4 lo, const float4 hi, floa
 
 // Two builds of the kernel.  <4 staged tile records per wave, 6 waves per SIMD, cooperative>: the four waves of a
 // block share their work items; it scans the whole 2x2 hint block in step 1 and is the faster one while a launch
-// holds few pairs (latency bound: the slowest block ends the launch).  <3, 7, not cooperative>: every wave sweeps its
-// own cells -- no shared lists, no block barriers, 14 KB of LDS -- and a seventh wave per SIMD; it wins when many
-// pairs fill the chip (throughput bound: 64 pairs 44 k -> 52 k it/s).
+// holds few pairs (latency bound: the slowest block ends the launch).  <3, 8, not cooperative>: every wave sweeps its
+// own cells -- no shared lists, no block barriers, 14 KB of LDS, 55 VGPRs -- at the full 8 waves per SIMD; it wins
+// when many pairs fill the chip (throughput bound: 64 pairs 44 k -> 55 k it/s).
 constexpr int NN_MAX_ITEMS = 256;    // (owner wave, coarse cell) work items shared by the waves of a block
 constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (8 measured slower: 2 blocks per CU)
 
