@@ -423,13 +423,13 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
     if (e0) HIPCHK(h, hipEventRecord(e0, s));
     if (nn_mode_of(h) == SLAM3D_NN_TILES) {
-        // few pairs: cooperative blocks, 4 staged records, 6 waves per SIMD (latency bound); from 8 pairs per launch:
-        // every wave on its own, 3 records, 8 waves per SIMD (throughput bound)
+        // few pairs: cooperative blocks, 7 waves per SIMD (latency bound); from 8 pairs per launch: every wave on its
+        // own, 8 waves per SIMD (throughput bound); three staged tile records per wave in both
         if (B >= h->dense_batch)
             hipLaunchKernelGGL((k_nn_tiles_acc<3, 8, false>), dim3((tg.ntiles + NN_WAVES - 1) / NN_WAVES, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
                                h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, h->perm, h->cost, h->acc, h->g, tg, h->dbg);
         else
-            hipLaunchKernelGGL((k_nn_tiles_acc<4, 6, true>), dim3((tg.ntiles + NN_WAVES - 1) / NN_WAVES, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
+            hipLaunchKernelGGL((k_nn_tiles_acc<3, 7, true>), dim3((tg.ntiles + NN_WAVES - 1) / NN_WAVES, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
                                h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, h->perm, h->cost, h->acc, h->g, tg, h->dbg);
         if (it == 1 && do_solve)      // costs are stable from the second iteration on: balance the blocks once
             hipLaunchKernelGGL(k_balance, dim3(B), dim3(1024), 0, s, h->cost, h->perm, tg, (tg.ntiles + NN_WAVES - 1) / NN_WAVES);

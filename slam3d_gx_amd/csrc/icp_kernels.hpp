@@ -862,11 +862,11 @@ __device__ __forceinline__ float box_gap2(const float4 lo, const float4 hi, floa
     return gx * gx + gy * gy + gz * gz;      // empty boxes (lo=+inf, hi=-inf) give +inf
 }
 
-// Two builds of the kernel.  <4 staged tile records per wave, 6 waves per SIMD, cooperative>: the four waves of a
-// block share their work items; it scans the whole 2x2 hint block in step 1 and is the faster one while a launch
-// holds few pairs (latency bound: the slowest block ends the launch).  <3, 8, not cooperative>: every wave sweeps its
-// own cells -- no shared lists, no block barriers, 14 KB of LDS, 55 VGPRs -- at the full 8 waves per SIMD; it wins
-// when many pairs fill the chip (throughput bound: 64 pairs 44 k -> 55 k it/s).
+// Two builds of the kernel, three staged tile records per wave in both.  <3, 7 waves per SIMD, cooperative>: the four
+// waves of a block share their work items (21 KB LDS per block, 65 VGPRs); the faster one while a launch holds few
+// pairs (latency bound: the slowest block ends the launch).  <3, 8, not cooperative>: every wave sweeps its own cells
+// -- no shared lists, no block barriers, 14 KB of LDS, 55 VGPRs -- at the full 8 waves per SIMD; it wins when many
+// pairs fill the chip (throughput bound: 64 pairs 44 k -> 55 k it/s).
 constexpr int NN_MAX_ITEMS = 256;    // (owner wave, coarse cell) work items shared by the waves of a block
 constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (8 measured slower: 2 blocks per CU)
 
