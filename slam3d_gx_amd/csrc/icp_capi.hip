@@ -203,6 +203,8 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     tg.ntiles = tg.ntx * tg.nty;
     tg.ncx = (tg.ntx + COARSE_TILES - 1) / COARSE_TILES; tg.ncy = (tg.nty + COARSE_TILES - 1) / COARSE_TILES;
     tg.ncoarse = tg.ncx * tg.ncy;
+    tg.mag_ncx = (unsigned int)((0x100000000ull + tg.ncx - 1) / tg.ncx);
+    tg.mag_W = (unsigned int)((0x100000000ull + p->width - 1) / p->width);
     tg.nchunks = (tg.ntiles + TILES_PER_CHUNK - 1) / TILES_PER_CHUNK;
     tg.nslots = tg.nchunks * CHUNK;
     tg.ngroups = (tg.ntiles + CHUNK - 1) / CHUNK;

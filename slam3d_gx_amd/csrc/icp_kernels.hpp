@@ -206,7 +206,8 @@ constexpr int TILES_PER_CHUNK = CHUNK / TILE_SLOTS;
 
 // nchunks = launch blocks of 4 tiles, nslots = padded slot count (ngroups / tpad: unused since the sums became
 // integer accumulators)
-struct TileGrid { int ntx, nty, ntiles, ncx, ncy, ncoarse, nchunks, nslots, ngroups, tpad; };
+// mag_x = ceil(2^32 / x): q = umulhi(n, mag_x) is n / x exactly for n * x < 2^32 (scalar multiply, no VALU division)
+struct TileGrid { int ntx, nty, ntiles, ncx, ncy, ncoarse, nchunks, nslots, ngroups, tpad; unsigned int mag_ncx, mag_W; };
 
 // ---- wave64 cross-lane helpers on the VALU (DPP within a 16-lane row, v_permlane16/32_swap across
 // rows -- gfx950); no LDS round trips.  Inputs are never NaN here (+-inf marks "no value").
@@ -1019,7 +1020,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     };
     // fine level: ballot the children of coarse cell cc against the wave boxes, re-test per lane, stage + scan
     auto sweep_cell = [&](int cc) __attribute__((always_inline)) {
-        const int ctx = (cc % tg.ncx) * COARSE_TILES, cty = (cc / tg.ncx) * COARSE_TILES;
+        const int ccy = tg.ncx == 1 ? cc : (int)__umulhi((unsigned int)cc, tg.mag_ncx);     // (2^32 / 1 has no 32-bit magic)
+        const int ctx = (cc - ccy * tg.ncx) * COARSE_TILES, cty = ccy * COARSE_TILES;
         const int tx = ctx + (lane & 7), ty = cty + (lane >> 3);
         float4 lo = make_float4(inf, inf, inf, 0), hi = make_float4(-inf, -inf, -inf, 0);
         if (tx < tg.ntx && ty < tg.nty) { lo = TB[2 * (ty * tg.ntx + tx)]; hi = TB[2 * (ty * tg.ntx + tx) + 1]; }
@@ -1221,7 +1223,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             const int jm = __builtin_amdgcn_readlane((int)(unsigned int)(bkey & 0xffffffffull), src_lane);
             if (lane == 0) {
                 // the 8x8 patch seen from that lane's match: pixels [um - lx, um - lx + 7] x [vm - ly, vm - ly + 7]
-                const int vm = jm / g.W, um = jm - vm * g.W;
+                const int vm = g.W == 1 ? jm : (int)__umulhi((unsigned int)jm, tg.mag_W), um = jm - vm * g.W;
                 const int u0 = max(0, um - (src_lane & 7)), u1 = min(g.W - 1, um - (src_lane & 7) + 7);
                 const int v0 = max(0, vm - (src_lane >> 3)), v1 = min(g.H - 1, vm - (src_lane >> 3) + 7);
                 const int ax0 = u0 / TILE_PX, ay0 = v0 / TILE_PX;
