@@ -947,8 +947,9 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     };
     // scan staged tile k (tile id tile, both wave-uniform): tile box first, then its four 4x4-pixel quadrants,
     // each only if some lane can still improve/tie inside that box
+    bool hinted = false;        // step 1 scans tiles that the hint picked: their tile-level test nearly always passes, skip it
     auto scan_staged = [&](int k, int tile) __attribute__((always_inline)) {
-        if (__ballot(lane_gap_ok(TB[2 * tile], TB[2 * tile + 1])) == 0ull) return;     // uniform -> scalar loads
+        if (!hinted && __ballot(lane_gap_ok(TB[2 * tile], TB[2 * tile + 1])) == 0ull) return;     // uniform -> scalar loads
         n_scanned += 1;
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
@@ -1113,7 +1114,9 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             if (tv && d2g <= g.gate2) bkey = ((unsigned long long)(unsigned int)__float_as_int(d2g) << 32) | (unsigned int)jg;
         }
         if (dbg) clk1 = clock64();
+        hinted = th >= 0;
         park_and_scan();
+        hinted = false;
         if (dbg) clk2 = clock64();
         opx = px; opy = py; opz = pz;
         // ---- step 2: publish the queries and one work item per reachable coarse cell
