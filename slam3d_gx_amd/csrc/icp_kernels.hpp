@@ -938,24 +938,31 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     int tt[NN_STAGE];
     float4 r[NN_STAGE];
 
-    auto lane_gap_ok = [&](const float4 lo, const float4 hi) __attribute__((always_inline)) {
-        const float cur = __int_as_float((int)(unsigned int)(bkey >> 32));
+    // Can this lane's ball still reach into the box?  gap_i <= |q_i - p_i| for every q in the box (rounding is
+    // monotone), the sum has the canonical association, and the threshold is the lane's current best d2 with a 1e-5
+    // margin over the few-ulp differences that remain; a threshold taken earlier is larger, hence still conservative.
+    auto lane_thr = [&]() __attribute__((always_inline)) {
+        return __int_as_float((int)(unsigned int)(bkey >> 32)) * 1.00001f + 1e-30f;
+    };
+    auto lane_gap_le = [&](const float4 lo, const float4 hi, float thr) __attribute__((always_inline)) {
         const float gx = fmaxf(0.0f, fmaxf(lo.x - px, px - hi.x));
         const float gy = fmaxf(0.0f, fmaxf(lo.y - py, py - hi.y));
         const float gz = fmaxf(0.0f, fmaxf(lo.z - pz, pz - hi.z));
-        return valid && (gx * gx + gy * gy + gz * gz) <= cur * 1.00001f + 1e-30f;
+        return valid && __fmaf_rn(gz, gz, __fmaf_rn(gy, gy, gx * gx)) <= thr;
     };
+    auto lane_gap_ok = [&](const float4 lo, const float4 hi) __attribute__((always_inline)) { return lane_gap_le(lo, hi, lane_thr()); };
     // scan staged tile k (tile id tile, both wave-uniform): tile box first, then its four 4x4-pixel quadrants,
     // each only if some lane can still improve/tie inside that box
     bool hinted = false;        // step 1 scans tiles that the hint picked: their tile-level test nearly always passes, skip it
     auto scan_staged = [&](int k, int tile) __attribute__((always_inline)) {
-        if (!hinted && __ballot(lane_gap_ok(TB[2 * tile], TB[2 * tile + 1])) == 0ull) return;     // uniform -> scalar loads
+        const float thr = lane_thr();          // once per tile: the quadrant tests below may use this (larger) value
+        if (!hinted && __ballot(lane_gap_le(TB[2 * tile], TB[2 * tile + 1], thr)) == 0ull) return;     // uniform -> scalar loads
         n_scanned += 1;
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             const float4 lo = st[k * TILE_REC + TILE_SLOTS + 2 * qd], hi = st[k * TILE_REC + TILE_SLOTS + 2 * qd + 1];
             const int cnt = __builtin_amdgcn_readfirstlane(__float_as_int(lo.w));
-            if (cnt == 0 || __ballot(lane_gap_ok(lo, hi)) == 0ull) continue;
+            if (cnt == 0 || __ballot(lane_gap_le(lo, hi, thr)) == 0ull) continue;
             n_cand += cnt;
             const float4 *__restrict__ cand = st + k * TILE_REC + qd * 16;
 #pragma unroll 4
