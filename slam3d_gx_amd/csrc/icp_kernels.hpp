@@ -223,24 +223,32 @@ __device__ __forceinline__ float fmin_nn(float a, float b) { return b < a ? b : 
 __device__ __forceinline__ float fmax_nn(float a, float b) { return b > a ? b : a; }
 
 // all-lanes min / max: xor-1, xor-2 (quad_perm), row_half_mirror, row_mirror, then rows 0<->1 / 2<->3
-// (v_permlane16_swap) and halves (v_permlane32_swap)
+// (v_permlane16_swap) and halves (v_permlane32_swap).  The four in-row steps are single v_min/v_max_f32 with a DPP
+// source (every lane of these permutations is valid, so no `old` operand is needed); the s_nop covers the two wait
+// states a DPP read needs after the VALU write of the same register.  Inputs are never NaN.
+#define S3D_DPP4(OP, v)                                                                                              \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"                             \
+        "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"                             \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"                                 \
+        "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"                                           \
+        : "+v"(v))
 __device__ __forceinline__ float wave_min(float v)
 {
-    v = fmin_nn(v, dpp_f<0xB1>(v)); v = fmin_nn(v, dpp_f<0x4E>(v));
-    v = fmin_nn(v, dpp_f<0x141>(v)); v = fmin_nn(v, dpp_f<0x140>(v));
+    S3D_DPP4("v_min_f32_dpp", v);
     auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
-    v = fmin_nn(__int_as_float(r[0]), __int_as_float(r[1]));
+    asm("v_min_f32 %0, %1, %2" : "=v"(v) : "v"(r[0]), "v"(r[1]));
     r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
-    return fmin_nn(__int_as_float(r[0]), __int_as_float(r[1]));
+    asm("v_min_f32 %0, %1, %2" : "=v"(v) : "v"(r[0]), "v"(r[1]));
+    return v;
 }
 __device__ __forceinline__ float wave_max(float v)
 {
-    v = fmax_nn(v, dpp_f<0xB1>(v)); v = fmax_nn(v, dpp_f<0x4E>(v));
-    v = fmax_nn(v, dpp_f<0x141>(v)); v = fmax_nn(v, dpp_f<0x140>(v));
+    S3D_DPP4("v_max_f32_dpp", v);
     auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(v), __float_as_int(v), false, false);
-    v = fmax_nn(__int_as_float(r[0]), __int_as_float(r[1]));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(r[0]), "v"(r[1]));
     r = __builtin_amdgcn_permlane32_swap(__float_as_int(v), __float_as_int(v), false, false);
-    return fmax_nn(__int_as_float(r[0]), __int_as_float(r[1]));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(r[0]), "v"(r[1]));
+    return v;
 }
 
 // grid (ntiles, 2, B), block 64.  srcT slot w = pixel index (int bits) or -1; rows outside
