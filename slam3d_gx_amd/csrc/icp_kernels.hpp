@@ -682,10 +682,13 @@ __global__ __launch_bounds__(64) void k_nn_mfma(const SlotPtrs *__restrict__ slo
 }
 
 // rows of the normal equations for a source point p' matched to target point q with normal n (spec S4)
+constexpr double FIX_SCALE = 4294967296.0;     // 2^32: unit of the fixed-point sums (spec S4)
 // A slot's 29 terms are products of a handful of values; only those eight ("basis") stay live between the gather
 // and the reduction, the products are formed group by group while they are summed (58 VGPRs of row sums made the
 // epilogue the register peak of the kernel).  point-to-plane: v = a[0..5], b, 1;  svd: v = p', q, |q - p'|^2, 1.
-// A slot without a correspondence has an all-zero basis, hence all-zero terms.
+// A slot without a correspondence has an all-zero basis, hence all-zero terms.  The basis carries the fixed-point
+// scale (2^16 per factor, 2^32 on single values): powers of two commute with the rounding of the products, so
+// row_term returns exactly term * 2^32 of the spec and the only thing left per term is the rint.
 struct RowBasis { double v[8]; };
 
 __device__ __forceinline__ void row_basis(int estimator, float pxf, float pyf, float pzf, const float4 q4, const float4 n4, RowBasis &B)
@@ -695,14 +698,14 @@ __device__ __forceinline__ void row_basis(int estimator, float pxf, float pyf, f
     const double dx = qx - px, dy = qy - py, dz = qz - pz;
     if (estimator == 0) {
         const double nx = n4.x, ny = n4.y, nz = n4.z;
-        B.v[0] = py * nz - pz * ny; B.v[1] = pz * nx - px * nz; B.v[2] = px * ny - py * nx;
-        B.v[3] = nx; B.v[4] = ny; B.v[5] = nz;
-        B.v[6] = (nx * dx + ny * dy) + nz * dz;
+        B.v[0] = (py * nz - pz * ny) * 65536.0; B.v[1] = (pz * nx - px * nz) * 65536.0; B.v[2] = (px * ny - py * nx) * 65536.0;
+        B.v[3] = nx * 65536.0; B.v[4] = ny * 65536.0; B.v[5] = nz * 65536.0;
+        B.v[6] = ((nx * dx + ny * dy) + nz * dz) * 65536.0;
     } else {
-        B.v[0] = px; B.v[1] = py; B.v[2] = pz; B.v[3] = qx; B.v[4] = qy; B.v[5] = qz;
-        B.v[6] = (dx * dx + dy * dy) + dz * dz;
+        B.v[0] = px * FIX_SCALE; B.v[1] = py * FIX_SCALE; B.v[2] = pz * FIX_SCALE; B.v[3] = qx; B.v[4] = qy; B.v[5] = qz;
+        B.v[6] = ((dx * dx + dy * dy) + dz * dz) * FIX_SCALE;
     }
-    B.v[7] = 1.0;
+    B.v[7] = FIX_SCALE;
 }
 
 // term K of the 29-slot record (spec S4), K a compile-time constant
@@ -719,7 +722,8 @@ template <int EST, int K> __device__ __forceinline__ double row_term(const RowBa
         } else if constexpr (K < 27) return B.v[K - 21] * B.v[6];
         else return B.v[6] * B.v[6];
     } else {
-        if constexpr (K < 6) return B.v[7] != 0.0 ? B.v[K] : 0.0;
+        if constexpr (K < 3) return B.v[K];
+        else if constexpr (K < 6) return B.v[K] * FIX_SCALE;
         else if constexpr (K < 15) return B.v[(K - 6) / 3] * B.v[3 + (K - 6) % 3];
         else if constexpr (K < 27) return 0.0;
         else return B.v[6];
@@ -734,7 +738,6 @@ template <int EST, int K> __device__ __forceinline__ double row_term(const RowBa
 //             a[i]+a[i+32] in lanes 0..31 and b[i]+b[i+32] in lanes 32..63;
 //   level 16: v_permlane16_swap on two such registers -> rows 0..3 hold components (a, c, b, d);
 //   levels 8..1: DPP row_shl inside each 16-lane row.  Result: lanes 0,16,32,48 hold the sums of a,c,b,d.
-constexpr double FIX_SCALE = 4294967296.0;     // 2^32
 constexpr int ACC_R = 16;                      // accumulator replicas per pair: same-address atomics serialise
 constexpr int ACC_STRIDE = 32;                 // int64 per replica (29 used)
 
@@ -765,18 +768,17 @@ __device__ __forceinline__ double wave_sum_x4(double a, double b, double c, doub
     x = x + dpp_d<0x101>(x);
     return x;      // lane 0: a, lane 16: c, lane 32: b, lane 48: d
 }
-// a slot's term in fixed-point units, as an integer-valued double: v * 2^32 is exact, rint rounds to nearest-even
-// like the oracle's llrint.  |term| < 2^39, so the 64-lane sums below stay under 2^53 and every fp64 add of these
-// integers is EXACT -- the wave may add them in any order, in the fp64 pipe, one instruction per add.
-__device__ __forceinline__ double fix_d(double v) { return rint(v * FIX_SCALE); }
+// A slot's term in fixed-point units is an integer-valued double: row_term returns term * 2^32 exactly and rint
+// rounds it to nearest-even like the oracle's llrint.  |term| < 2^39, so the 64-lane sums stay under 2^53 and every
+// fp64 add of these integers is EXACT -- the wave may add them in any order, in the fp64 pipe, one instruction per add.
 
 // the wave's 64 slots -> the pair's accumulators (replica chosen by the block): the wave total of each component
 // is converted to int64 once (four components per pass sit in lanes 0/16/32/48) and leaves as 8 atomic
 // instructions of four addresses each; tiles without a match issue none
 template <int EST, int K0> __device__ __forceinline__ void tile_accumulate_group(const RowBasis &B, long long *__restrict__ acc, int lane, int koff)
 {
-    const double x = wave_sum_x4(fix_d(row_term<EST, K0>(B)), fix_d(row_term<EST, K0 + 1>(B)), fix_d(row_term<EST, K0 + 2>(B)),
-                                 fix_d(row_term<EST, K0 + 3>(B)));
+    const double x = wave_sum_x4(rint(row_term<EST, K0>(B)), rint(row_term<EST, K0 + 1>(B)), rint(row_term<EST, K0 + 2>(B)),
+                                 rint(row_term<EST, K0 + 3>(B)));
     if ((lane & 15) == 0 && x != 0.0) atomicAdd(reinterpret_cast<unsigned long long *>(acc + K0 + koff), (unsigned long long)__double2ll_rn(x));
 }
 template <int EST> __device__ __forceinline__ void tile_accumulate_est(const RowBasis &B, long long *__restrict__ acc)
