@@ -36,13 +36,14 @@ for (name, ctr), (v, n) in sorted(rows.items()):
     md += f"| `{name}` | {ctr} | {v:.1f} | {n} |\n"
 open(os.path.join(dst, f"{tag}_kernel_stats.md"), "w").write(md)
 
-k = "s3d::k_nn_tiles_acc"
+cands = sorted({n for (n, _c) in rows if "k_nn_tiles_acc" in n})       # template instance, e.g. "void s3d::k_nn_tiles_acc<3, 7, true>"
+k = cands[0] if cands else "s3d::k_nn_tiles_acc"
 if (k, "FETCH_SIZE") in rows and (k, "WRITE_SIZE") in rows:
     f, w = rows[(k, "FETCH_SIZE")][0], rows[(k, "WRITE_SIZE")][0]
     out = {"_comment": ("HBM traffic of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE in separate runs, KiB per "
                         f"dispatch, averaged over {rows[(k, 'FETCH_SIZE')][1]} dispatches of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline "
                         "--no-bruteforce`). FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for wide coalesced reads on "
-                        f"gfx950. See profiles/{tag}_kernel_stats.md."),
+                        f"gfx950. Kernel instance: {k}. See profiles/{tag}_kernel_stats.md."),
            "k_nn_tiles_acc": {"fetch_size_kib": round(f, 1), "write_size_kib": round(w, 1), "hbm_bytes_per_launch": int((2 * f + w) * 1024),
                               "hbm_bytes_per_launch_uncorrected": int((f + w) * 1024),
                               "algorithmic_bytes_per_launch": bench.get("roofline", {}).get("algorithmic_bytes_per_launch")}}
