@@ -25,7 +25,7 @@ rows = {}
 for db in sorted(glob.glob(os.path.join(src, "pmc_*", "*.db"))):
     c = sqlite3.connect(db)
     q = ("select name, counter_name, avg(v), count(*) from (select name, dispatch_id, counter_name, sum(counter_value) v from pmc_events "
-         "where name like 's3d::%' group by dispatch_id, counter_name) group by name, counter_name")
+         "where name like '%s3d::%' group by dispatch_id, counter_name) group by name, counter_name")
     for name, ctr, v, n in c.execute(q):
         rows[(name.split("(")[0], ctr)] = (v, n)
 md += ("\n## PMC passes (separate runs, `rocprofv3 --kernel-trace --pmc <counters> -- python bench.py --steps 2 --warmup 1 "
