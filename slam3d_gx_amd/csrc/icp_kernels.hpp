@@ -779,7 +779,10 @@ template <int EST, int K0> __device__ __forceinline__ void tile_accumulate_group
 {
     const double x = wave_sum_x4(rint(row_term<EST, K0>(B)), rint(row_term<EST, K0 + 1>(B)), rint(row_term<EST, K0 + 2>(B)),
                                  rint(row_term<EST, K0 + 3>(B)));
-    if ((lane & 15) == 0 && x != 0.0) atomicAdd(reinterpret_cast<unsigned long long *>(acc + K0 + koff), (unsigned long long)__double2ll_rn(x));
+    // x is an integer below 2^46 in magnitude: adding 1.5 * 2^52 leaves it in the low mantissa bits (two's complement),
+    // three instructions instead of the generic double -> int64 conversion
+    const long long q = __double_as_longlong(x + 6755399441055744.0) - 0x4338000000000000ll;
+    if ((lane & 15) == 0 && q != 0) atomicAdd(reinterpret_cast<unsigned long long *>(acc + K0 + koff), (unsigned long long)q);
 }
 template <int EST> __device__ __forceinline__ void tile_accumulate_est(const RowBasis &B, long long *__restrict__ acc)
 {
