@@ -451,3 +451,24 @@ def test_two_handles_in_flight_give_the_sequential_results(gpu_lib):
     for k in range(2):
         ro = O.icp(src[k].cpu().numpy(), tgt[k].cpu().numpy(), O.params(prs[k].intr, iterations=8, nn_method=1))
         assert np.array_equal(lone[k]["T_raw"], ro["T_trace"][-1])
+
+
+@pytest.mark.parametrize("mode", ["batch", "dense"])
+def test_bench_two_ranks_on_one_device(gpu_lib, mode):
+    """bench.py's N>1 code path (pair sharding + pipelined pose all-gather / dense integer all-reduce) with two ranks
+    sharing this GPU over gloo: RCCL needs one GPU per rank, everything else is the code the driver runs."""
+    import json, os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--width", "320", "--height", "240", "--iterations", "6", "--no-cpu-baseline", "--no-bruteforce",
+           "--dist-backend", "gloo", "--one-device"] + (["--mode", "dense"] if mode == "dense" else [])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["status"][0] == 0
+    assert d["scaling"] == ("strong" if mode == "dense" else "weak")
