@@ -41,8 +41,8 @@ HBM_PEAK_GBPS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec; 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=1, help="frame pairs per GPU per step (config 3: 64)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
@@ -73,13 +73,13 @@ def cpu_baseline_leg(pair, s4, t4, args, gpu_result, gpu_idx):
     p_all = O.params(pair.intr, estimator=est, iterations=args.iterations, nn_method=1, threads=0)
     times = []
     ro = None
-    for _ in range(3):
+    for _ in range(9):
         t0 = time.perf_counter()
         ro = O.icp(s4, t4, p_all, trace=True)
         times.append(time.perf_counter() - t0)
     t_all = statistics.median(times)
-    # PCL's ICP is single-threaded: time one thread on a bounded sample (4 iterations)
-    it1 = min(4, args.iterations)
+    # PCL's ICP is single-threaded: time one thread on a bounded sample (10 iterations, ~1.5 s)
+    it1 = min(10, args.iterations)
     p_one = O.params(pair.intr, estimator=est, iterations=it1, nn_method=1, threads=1)
     t0 = time.perf_counter()
     O.icp(s4, t4, p_one, trace=False)
@@ -88,7 +88,7 @@ def cpu_baseline_leg(pair, s4, t4, args, gpu_result, gpu_idx):
     out = {
         "value": args.iterations / t_all, "unit": "ICP iterations/s", "cores": cores, "kind": "port",
         "sample": f"oracle/ (exact kd-tree NN + same estimator, OpenMP on all {cores} hardware threads), 1 pair seed "
-                  f"{pair.seed} x {args.iterations} iterations incl. normals + kd-tree build, median of 3",
+                  f"{pair.seed} x {args.iterations} iterations incl. normals + kd-tree build, median of 9 (~4 s on all cores)",
         "single_thread_value": it1 / t_one,
         "single_thread_sample": f"same, 1 thread, {it1} iterations (PCL's own ICP is single-threaded)",
     }
