@@ -254,6 +254,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     }
     h->h_slots.assign(h->maxB, SlotPtrs{ nullptr, nullptr });
     (void)hipMemsetAsync(h->counts, 0, sizeof(int) * 4 * h->maxB, h->stream);
+    (void)hipMemsetAsync(h->perm, 0xFF, sizeof(int) * (size_t)h->maxB * ((tg.ntiles + NN_WAVES - 1) / NN_WAVES) * NN_WAVES, h->stream);   // -1: interleaved default
     (void)hipMemsetAsync(h->acc, 0, sizeof(long long) * (size_t)h->maxB * ACC_R * ACC_STRIDE, h->stream);   // k_solve_acc re-zeroes after every launch
     *out = h;
     return SLAM3D_OK;

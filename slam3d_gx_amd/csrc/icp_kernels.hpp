@@ -274,7 +274,8 @@ __global__ __launch_bounds__(64) void k_build_tiles(const SlotPtrs *__restrict__
         corr[slot] = -1;
         prevq[slot] = make_float4(ones, ones, ones, ones);
         if (lane == 0) hint[(size_t)b * tg.ntiles + t] = -1;
-        for (int k = t * 64 + lane; k < nperm; k += tg.ntiles * 64) perm[(size_t)b * nperm + k] = -1;
+        // (perm is NOT reset: the cost-balanced ownership of the previous run on this slot is the best guess for the
+        // first two iterations of the next one -- consecutive frame pairs look alike; any map gives the same bits)
         if (t == 0 && lane < 4) counts[b * 4 + lane] = 0;
         if (t == tg.ntiles - 1)                                       // slot padding up to a whole launch block
             for (int k = tg.ntiles * TILE_SLOTS + lane; k < tg.nslots; k += 64) {
