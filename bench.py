@@ -457,6 +457,7 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "valu_issue_floor_us": prof.get("valu_issue_floor_us"),      # from the committed PMC profile: the bound that applies
                 "valu_instructions_per_wave": prof.get("valu_instructions_per_wave"),
+                "valu_issue_frac": (prof.get("valu_issue_floor_us") / (launch_ms * 1e3)) if prof.get("valu_issue_floor_us") else None,
                 "equivalent_bruteforce_tflops": flops / (launch_ms * 1e-3) / 1e12,
                 "note": ("streaming accounting (each array once per iteration); the kernel is VALU-issue/latency bound, "
                          "not HBM bound -- see DESIGN.md section 6; equivalent_bruteforce_tflops = flops a full scan "
