@@ -791,7 +791,7 @@ static int vox_alloc(slam3d_icp_handle *h)
         hipMalloc((void **)&h->vox_lslot, sizeof(int) * h->N) != hipSuccess || hipMalloc((void **)&h->vox_m, sizeof(int)) != hipSuccess ||
         hipMalloc((void **)&h->vox_gkey, sizeof(unsigned long long) * h->N) != hipSuccess ||
         hipMalloc((void **)&h->vox_gslot, sizeof(int) * h->N) != hipSuccess ||
-        hipMalloc((void **)&h->vox_hist, sizeof(int) * (3 * VOX_BINS + 8)) != hipSuccess ||
+        hipMalloc((void **)&h->vox_hist, sizeof(int) * (3 * VOX_BINS + 8 + VOX_SCAN_BLOCKS)) != hipSuccess ||
         hipMalloc((void **)&h->vox_out, sizeof(float4) * h->N) != hipSuccess ||
         hipHostMalloc((void **)&h->pin_vox_m, sizeof(int), hipHostMallocDefault) != hipSuccess) {
         (void)hipGetLastError();
@@ -825,13 +825,14 @@ static int voxel_grid_impl(slam3d_icp_handle *h, const void *d_points16, int32_t
     HIPCHK(h, hipMemsetAsync(t.sx, 0, (size_t)t.cap * (3 * 8 + 5 * 4), s));
     HIPCHK(h, hipMemsetAsync(h->vox_m, 0, sizeof(int), s));
     HIPCHK(h, hipMemsetAsync(h->vox_hist, 0, sizeof(int) * VOX_BINS, s));
-    int *start = h->vox_hist + VOX_BINS, *cursor = start + VOX_BINS + 8;
+    int *start = h->vox_hist + VOX_BINS, *cursor = start + VOX_BINS + 8, *btot = cursor + VOX_BINS;
     if (n > 0) {
         hipLaunchKernelGGL(k_voxel_insert, dim3((n + VOX_BLOCK - 1) / VOX_BLOCK), dim3(VOX_BLOCK), 0, s,
                            static_cast<const float4 *>(d_points16), n, 1.0f / leaf, zmin, zmax, t);
         hipLaunchKernelGGL(k_voxel_compact, dim3((t.cap + VOX_BLOCK * VOX_SPT - 1) / (VOX_BLOCK * VOX_SPT)), dim3(VOX_BLOCK), 0, s, t,
                            h->vox_lkey, h->vox_lslot, h->vox_m, h->vox_hist);
-        hipLaunchKernelGGL(k_voxel_scan, dim3(1), dim3(1024), 0, s, h->vox_hist, start, cursor);
+        hipLaunchKernelGGL(k_voxel_scan1, dim3(VOX_SCAN_BLOCKS), dim3(1024), 0, s, h->vox_hist, start, cursor, btot);
+        hipLaunchKernelGGL(k_voxel_scan2, dim3(VOX_SCAN_BLOCKS), dim3(1024), 0, s, start, btot);
         hipLaunchKernelGGL(k_voxel_scatter, dim3((n + VOX_BLOCK - 1) / VOX_BLOCK), dim3(VOX_BLOCK), 0, s, h->vox_lkey, h->vox_lslot,
                            h->vox_m, start, cursor, h->vox_gkey, h->vox_gslot);
         hipLaunchKernelGGL(k_voxel_rank, dim3((n + VOX_BLOCK - 1) / VOX_BLOCK), dim3(VOX_BLOCK), 0, s, t, h->vox_gkey, h->vox_gslot,

@@ -8,7 +8,7 @@
 //   k_voxel_insert   one thread per point: 64-bit voxel key (iz,iy,ix) -> open-addressing hash table in HBM
 //                    (capacity >= 2n, linear probing, atomicCAS on the key), atomic adds into the entry
 //   k_voxel_compact  occupied slots -> dense list (one global ticket per block) + histogram of the (iz, iy) rows
-//   k_voxel_scan / k_voxel_scatter   counting sort of the list by row (iz, iy are the most significant key fields)
+//   k_voxel_scan1/2 / k_voxel_scatter   counting sort of the list by row (iz, iy are the most significant key fields)
 //   k_voxel_rank     output order = ascending key, like PCL's sorted linear voxel index: rank = start of the
 //                    rows a block touches + number of smaller keys among them (LDS-tiled compares), centroid
 //                    written at that rank.  No host round trip anywhere: the entry count stays on the device.
@@ -161,35 +161,38 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_compact(VoxTable t, unsigne
     }
 }
 
-// exclusive prefix of the row histogram -> start[]; cursor[] reset.  one block of 1024
-__global__ __launch_bounds__(1024) void k_voxel_scan(const int *__restrict__ hist, int *__restrict__ start, int *__restrict__ cursor)
+// exclusive prefix of the row histogram -> start[]; cursor[] reset.  Two launches of VOX_BINS / 1024 blocks:
+// scan1 scans 1024 rows per block (wave shuffles + one LDS step) and leaves the block totals, scan2 adds to every
+// block the sum of the totals before it (128 values, read by every block).
+constexpr int VOX_SCAN_BLOCKS = VOX_BINS / 1024;
+__global__ __launch_bounds__(1024) void k_voxel_scan1(const int *__restrict__ hist, int *__restrict__ start, int *__restrict__ cursor,
+                                                      int *__restrict__ btot)
 {
-    __shared__ int part[1024];
-    constexpr int PER = VOX_BINS / 1024;
-    int loc[PER], sum = 0;
-    const int4 *__restrict__ h4 = reinterpret_cast<const int4 *>(hist + threadIdx.x * PER);
-#pragma unroll
-    for (int j = 0; j < PER / 4; ++j) {
-        const int4 v = h4[j];
-        loc[4 * j] = v.x; loc[4 * j + 1] = v.y; loc[4 * j + 2] = v.z; loc[4 * j + 3] = v.w;
-        sum += (v.x + v.y) + (v.z + v.w);
-    }
-    part[threadIdx.x] = sum;
+    __shared__ int wtot[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int v = hist[i];
+    int incl = v;
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    if (lane == 63) wtot[w] = incl;
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
+    int before = 0;
+    for (int q = 0; q < w; ++q) before += wtot[q];
+    start[i] = before + incl - v;                      // exclusive prefix inside the block
+    cursor[i] = 0;
+    if (threadIdx.x == 1023) btot[blockIdx.x] = before + incl;
+}
+__global__ __launch_bounds__(1024) void k_voxel_scan2(int *__restrict__ start, const int *__restrict__ btot)
+{
+    __shared__ int off_sh;
+    if (threadIdx.x < 64) {
+        int a = 0;
+        for (int q = threadIdx.x; q < (int)blockIdx.x; q += 64) a += btot[q];
+        for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+        if (threadIdx.x == 0) off_sh = a;
     }
-    int run = part[threadIdx.x] - sum;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        start[threadIdx.x * PER + j] = run;
-        cursor[threadIdx.x * PER + j] = 0;
-        run += loc[j];
-    }
-    if (threadIdx.x == 1023) start[VOX_BINS] = run;
+    __syncthreads();
+    start[blockIdx.x * 1024 + threadIdx.x] += off_sh;
+    if (blockIdx.x == VOX_SCAN_BLOCKS - 1 && threadIdx.x == 1023) start[VOX_BINS] = off_sh + btot[blockIdx.x];
 }
 
 // group the list by row (order inside a row is arbitrary; k_voxel_rank fixes it)
