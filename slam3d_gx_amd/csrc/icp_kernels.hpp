@@ -877,6 +877,17 @@ __device__ __forceinline__ float box_gap2(const float4 lo, const float4 hi, floa
     return gx * gx + gy * gy + gz * gz;      // empty boxes (lo=+inf, hi=-inf) give +inf
 }
 
+// min of two packed keys (d2 bits << 32 | pixel).  d2 >= 0 is a float, so the high word is below 0x7f800001 and the
+// 64 bits are a finite non-negative DOUBLE (a denormal when d2 is tiny); non-negative doubles order like their bit
+// patterns, so one v_min_f64 replaces the 64-bit compare and two selects.  (FP64 denormals are always on; inline
+// asm keeps the compiler from wrapping the operands in NaN canonicalisation.)
+__device__ __forceinline__ unsigned long long key_min(unsigned long long a, unsigned long long b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(__longlong_as_double((long long)a)), "v"(__longlong_as_double((long long)b)));
+    return (unsigned long long)__double_as_longlong(r);
+}
+
 // Two builds of the kernel, three staged tile records per wave in both.  <3, 7 waves per SIMD, cooperative>: the four
 // waves of a block share their work items (21 KB LDS per block, 65 VGPRs); the faster one while a launch holds few
 // pairs (latency bound: the slowest block ends the launch).  <3, 8, not cooperative>: every wave sweeps its own cells
@@ -979,13 +990,16 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             if (cnt == 0 || __ballot(lane_gap_le(lo, hi, thr)) == 0ull) continue;
             n_cand += cnt;
             const float4 *__restrict__ cand = st + k * TILE_REC + qd * 16;
-#pragma unroll 4
-            for (int i = 0; i < cnt; ++i) {
-                const float4 q = cand[i];                                // same address in every lane: LDS broadcast
-                const float d2 = canon_d2(px, py, pz, q.y, q.z, q.w);     // record = (pixel, x, y, z)
-                const unsigned long long key =
-                    ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(q.x);
-                bkey = key < bkey ? key : bkey;
+            // four candidates per trip; the padding slots of a quadrant hold (+inf, +inf, +inf): d2 = +inf never wins
+            for (int i = 0; i < cnt; i += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 q = cand[i + u];                            // same address in every lane: LDS broadcast
+                    const float d2 = canon_d2(px, py, pz, q.y, q.z, q.w);     // record = (pixel, x, y, z)
+                    const unsigned long long key =
+                        ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(q.x);
+                    bkey = key_min(bkey, key);
+                }
             }
         }
     };
