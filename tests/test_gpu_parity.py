@@ -472,3 +472,35 @@ def test_bench_two_ranks_on_one_device(gpu_lib, mode):
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["status"][0] == 0
     assert d["scaling"] == ("strong" if mode == "dense" else "weak")
+
+
+@pytest.mark.parametrize("estimator", [0, 1])
+def test_zero_distances_and_duplicate_targets(gpu_lib, estimator):
+    """d2 == 0 makes the packed key a DENORMAL double (high word 0, mantissa = pixel index): the v_min_f64 key minimum
+    must still order by pixel.  Source == target gives d2 = 0 everywhere; duplicated target points give exact ties
+    that must resolve to the smallest pixel index, like the oracle's ascending scan."""
+    pr, s4, _ = _pair(77, 160, 120, noise=False, holes=False)
+    t4 = s4.copy()
+    # duplicate every second column into its left neighbour: exact ties at d2 = 0 between pixel u-1 and u
+    t4[:, 1::2, :] = t4[:, 0::2, :]
+    for src, tgt in ((s4, s4), (s4, t4)):
+        ro = O.icp(src, tgt, O.params(pr.intr, estimator=estimator, iterations=1, nn_method=0))
+        for env in (None, "1"):
+            import os
+            if env:
+                os.environ["SLAM3D_DENSE_BATCH"] = env
+            try:
+                with capi.IcpHandle(capi.default_params(pr.intr, estimator=estimator, iterations=1, max_batch=1)) as h:
+                    h.align(src, tgt)
+                    idx, d2 = h.get_correspondences(0)
+                    Tt, _ = h.get_trace(0)
+            finally:
+                os.environ.pop("SLAM3D_DENSE_BATCH", None)
+            assert np.array_equal(idx, ro["idx"]) and np.array_equal(d2.view(np.uint32), ro["d2"].view(np.uint32))
+            assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"])
+    valid = ro["idx"] >= 0
+    assert (ro["d2"][valid] == 0).mean() > 0.4            # the duplicated columns really produce zero-distance ties
+    u = np.arange(160)[None, :].repeat(120, 0).reshape(-1)
+    even = valid & (u % 2 == 0) & (ro["d2"] == 0)       # target pixels u and u+1 both hold source point u: exact tie
+    if estimator == 1:                                   # (point-to-plane only matches targets that kept a normal)
+        assert even.any() and (ro["idx"][even] == np.nonzero(even)[0]).all()  # ... resolved to the smaller pixel index
