@@ -55,6 +55,8 @@ struct slam3d_icp_handle {
     int *hint = nullptr;          // per source tile: target tile where the previous matches were
     int *scount = nullptr;        // per source tile: valid source points
     int *perm = nullptr, *cost = nullptr;   // balanced tile->(block,wave) assignment and its input (cycles per tile)
+    int *perm_d = nullptr;                  // the same for the throughput build (no bands, no slack)
+    int nn_gx = 0, nn_gx_d = 0, xcd_bands = 1;   // k_nn_tiles_acc grid widths (multiples of 8; nn_gx with slack for the equal-cost XCD bands)
     float *tgtB = nullptr;        // BRUTE_MFMA: B-layout targets [B][4][npad]
     unsigned int *qmax2 = nullptr; int npad = 0;
     // host
@@ -137,7 +139,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->own_src); F(h->own_tgt); F(h->nrm); F(h->src_c); F(h->tgt_c); F(h->counts); F(h->ccounts); F(h->corr);
     F(h->flags); F(h->best); F(h->cd2); F(h->acc); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
     F(h->d_Tinit); F(h->d_slots); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4);
-    F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox); F(h->dbg); F(h->prevq); F(h->hint); F(h->scount); F(h->perm); F(h->cost); F(h->tgtB); F(h->qmax2);
+    F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox); F(h->dbg); F(h->prevq); F(h->hint); F(h->scount); F(h->perm); F(h->perm_d); F(h->cost); F(h->tgtB); F(h->qmax2);
     if (h->pin_slots) (void)hipHostFree(h->pin_slots);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->pin_res) (void)hipHostFree(h->pin_res);
@@ -227,7 +229,14 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     A(dalloc(h->acc, (size_t)h->maxB * ACC_R * ACC_STRIDE));
     A(dalloc(h->hint, (size_t)h->maxB * tg.ntiles)); A(dalloc(h->scount, (size_t)h->maxB * tg.ntiles));
     A(dalloc(h->cost, (size_t)h->maxB * tg.ntiles));
-    A(dalloc(h->perm, (size_t)h->maxB * ((tg.ntiles + NN_WAVES - 1) / NN_WAVES) * NN_WAVES));
+    {   // grid width of the NN kernel: one wave per tile + slack (equal-cost XCD bands differ in tile count), multiple of 8
+        const int slack = getenv("SLAM3D_NN_SLACK") ? atoi(getenv("SLAM3D_NN_SLACK")) : 20;     // 20 %: measured best (10: band spill, 30: more empty waves)
+        if (getenv("SLAM3D_XCD_BANDS")) h->xcd_bands = atoi(getenv("SLAM3D_XCD_BANDS"));
+        const long long waves = ((long long)tg.ntiles * (100 + (slack < 0 ? 0 : slack)) + 99) / 100;
+        h->nn_gx = (int)(((waves + NN_WAVES - 1) / NN_WAVES + 7) / 8 * 8);
+        h->nn_gx_d = ((tg.ntiles + NN_WAVES - 1) / NN_WAVES + 7) / 8 * 8;
+    }
+    A(dalloc(h->perm, (size_t)h->maxB * h->nn_gx * NN_WAVES)); A(dalloc(h->perm_d, (size_t)h->maxB * h->nn_gx_d * NN_WAVES));
     if (getenv("SLAM3D_NN_DEBUG")) A(dalloc(h->dbg, (size_t)tg.ntiles * 10));
     if (getenv("SLAM3D_NO_GRAPH") || getenv("SLAM3D_NN_DEBUG")) h->use_graph = false;
     if (getenv("SLAM3D_DENSE_BATCH")) h->dense_batch = atoi(getenv("SLAM3D_DENSE_BATCH"));
@@ -254,7 +263,8 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     }
     h->h_slots.assign(h->maxB, SlotPtrs{ nullptr, nullptr });
     (void)hipMemsetAsync(h->counts, 0, sizeof(int) * 4 * h->maxB, h->stream);
-    (void)hipMemsetAsync(h->perm, 0xFF, sizeof(int) * (size_t)h->maxB * ((tg.ntiles + NN_WAVES - 1) / NN_WAVES) * NN_WAVES, h->stream);   // -1: interleaved default
+    (void)hipMemsetAsync(h->perm_d, 0xFF, sizeof(int) * (size_t)h->maxB * h->nn_gx_d * NN_WAVES, h->stream);
+    (void)hipMemsetAsync(h->perm, 0xFF, sizeof(int) * (size_t)h->maxB * h->nn_gx * NN_WAVES, h->stream);   // -1: interleaved default
     (void)hipMemsetAsync(h->acc, 0, sizeof(long long) * (size_t)h->maxB * ACC_R * ACC_STRIDE, h->stream);   // k_solve_acc re-zeroes after every launch
     *out = h;
     return SLAM3D_OK;
@@ -379,7 +389,7 @@ static int stage_inputs(slam3d_icp_handle *h, int B, const double *T_init, hipSt
 static int enqueue_preprocess_dev(slam3d_icp_handle *h, int B, bool has_T, hipStream_t s)
 {
     const Geometry &g = h->g;
-    const int nperm = ((h->tg.ntiles + NN_WAVES - 1) / NN_WAVES) * NN_WAVES;
+    const int nperm = h->nn_gx * NN_WAVES;
     const double *dT = nullptr;
     if (has_T) {
         HIPCHK(h, hipMemcpyAsync(h->d_Tinit, h->pin_T, sizeof(double) * 16 * B, hipMemcpyHostToDevice, s));
@@ -428,14 +438,18 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
     if (nn_mode_of(h) == SLAM3D_NN_TILES) {
         // few pairs: cooperative blocks, 7 waves per SIMD (latency bound); from 8 pairs per launch: every wave on its
         // own, 8 waves per SIMD (throughput bound); three staged tile records per wave in both
-        if (B >= h->dense_batch)
-            hipLaunchKernelGGL((k_nn_tiles_acc<3, 8, false>), dim3((tg.ntiles + NN_WAVES - 1) / NN_WAVES, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
-                               h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, h->perm, h->cost, h->acc, h->g, tg, h->dbg);
+        const bool dense = B >= h->dense_batch;
+        const int write_out = (!do_solve || it == iters - 1) ? 1 : 0;      // corr / cd2: only the last iteration's are read
+        int *perm = dense ? h->perm_d : h->perm;
+        const int gx = dense ? h->nn_gx_d : h->nn_gx;
+        if (dense)
+            hipLaunchKernelGGL((k_nn_tiles_acc<3, 8, false>), dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
+                               h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, perm, h->cost, h->acc, h->g, tg, h->dbg, write_out);
         else
-            hipLaunchKernelGGL((k_nn_tiles_acc<3, 7, true>), dim3((tg.ntiles + NN_WAVES - 1) / NN_WAVES, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
-                               h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, h->perm, h->cost, h->acc, h->g, tg, h->dbg);
+            hipLaunchKernelGGL((k_nn_tiles_acc<3, 7, true>), dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
+                               h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, perm, h->cost, h->acc, h->g, tg, h->dbg, write_out);
         if (it == 1 && do_solve)      // costs are stable from the second iteration on: balance the blocks once
-            hipLaunchKernelGGL(k_balance, dim3(B), dim3(1024), 0, s, h->cost, h->perm, tg, (tg.ntiles + NN_WAVES - 1) / NN_WAVES);
+            hipLaunchKernelGGL(k_balance, dim3(B), dim3(1024), 0, s, h->cost, perm, tg, gx, dense ? 0 : h->xcd_bands);
         if (e1) HIPCHK(h, hipEventRecord(e1, s));
     } else {
         if (nn_mode_of(h) == SLAM3D_NN_BRUTE_MFMA) {

@@ -809,15 +809,17 @@ __device__ __forceinline__ void finish_slot(bool valid, unsigned long long key, 
                                             const float4 *__restrict__ tcloud, const float4 *__restrict__ tnrm,
                                             float gate2, int estimator, int *__restrict__ corr_out,
                                             float *__restrict__ cd2_out, float4 *__restrict__ prevq_out,
-                                            RowBasis &B)
+                                            RowBasis &B, bool write_out = true)
 {
 #pragma unroll
     for (int k = 0; k < 8; ++k) B.v[k] = 0.0;
     const int j = (int)(unsigned int)(key & 0xffffffffull);
     const float d2 = __int_as_float((int)(unsigned int)(key >> 32));
     const bool ok = valid && (j >= 0) && (d2 <= gate2);
-    *corr_out = ok ? j : -1;
-    *cd2_out = ok ? d2 : __int_as_float(0x7f800000);
+    if (write_out) {        // the caller-visible correspondence arrays: only the last iteration's are ever read
+        *corr_out = ok ? j : -1;
+        *cd2_out = ok ? d2 : __int_as_float(0x7f800000);
+    }
     float4 pq = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
     if (ok) {
         const float4 q4 = tcloud[j];
@@ -896,9 +898,10 @@ __device__ __forceinline__ unsigned long long key_min(unsigned long long a, unsi
 constexpr int NN_MAX_ITEMS = 256;    // (owner wave, coarse cell) work items shared by the waves of a block
 constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (8 measured slower: 2 blocks per CU)
 
-// grid (ceil(ntiles/4), B), block 256 = 4 waves.  Wave w of block c OWNS source tile c + w*gridDim.x (four tiles
-// from four different image bands, so that an expensive tile -- e.g. one lying over a hole of the target, which
-// must prove "nothing within max_corr_dist" -- rarely shares a block with another one).
+// grid (G, B), block 256 = 4 waves; G = a multiple of 8 >= ntiles/4 (+ slack, see k_balance).  Wave w of block c
+// OWNS one source tile: perm[b][c][w] once k_balance has run (cost-balanced; for few pairs per launch also
+// XCD-local: block c runs on XCD c % 8 and takes its tiles from the c % 8-th band of the frame), before that
+// the c % 8-th eighth of the tiles dealt over that XCD's blocks.
 //   1. every wave: one round of loads, upper bounds, exhaustive scan of the 5 tiles around its hint tile;
 //   2. every wave publishes its queries (point, running key, tight/loose class) in LDS and appends one work
 //      item per coarse cell its two query boxes can reach;                                   -- barrier --
@@ -919,7 +922,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                                                         float4 *__restrict__ prevq, int *__restrict__ hint,
                                                         const int *__restrict__ perm, int *__restrict__ cost,
                                                         long long *__restrict__ acc, Geometry g, TileGrid tg,
-                                                        long long *__restrict__ dbg /* nullable: 8 x int64 per tile */)
+                                                        long long *__restrict__ dbg /* nullable: 8 x int64 per tile */,
+                                                        int write_out /* corr / cd2 wanted (last iteration) */)
 {
     __shared__ float4 stage_all[NN_WAVES][NN_STAGE * TILE_REC];
     __shared__ int wcost[NN_WAVES];                                    // cycles spent for each owner (all helpers)
@@ -938,7 +942,11 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     // ownership: the measured-cost balanced assignment once k_balance has run (perm >= 0 tile, -2 none),
     // before that (-1) tiles interleaved over the image bands
     const int pt = __builtin_amdgcn_readfirstlane(perm[((size_t)b * gridDim.x + c) * NN_WAVES + w]);
-    const int t = pt == -1 ? c + w * (int)gridDim.x : (pt < 0 ? tg.ntiles : pt);
+    int t = pt < 0 ? tg.ntiles : pt;
+    if (pt == -1) {     // default: XCD x (= c % 8, the grid width is a multiple of 8) takes the x-th eighth of the tiles
+        const int nbx = (int)gridDim.x >> 3, j = (c >> 3) + w * nbx, bs = (tg.ntiles + 7) >> 3;
+        t = j < bs ? (c & 7) * bs + j : tg.ntiles;
+    }
     const bool has_tile = t < tg.ntiles;
     const long long cw0 = clock64();
     float4 *__restrict__ st = stage_all[w];
@@ -1250,7 +1258,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     if constexpr (COOP) bkey = qkey[w][lane];
     if (__ballot(own_valid) == 0ull) bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
     RowBasis rb;
-    finish_slot(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, prevq + gs, rb);
+    finish_slot(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, prevq + gs, rb, write_out != 0);
     tile_accumulate(g.estimator, rb, acc + ((size_t)b * ACC_R + (c % ACC_R)) * ACC_STRIDE);
     {   // hint for the next iteration: the tile holding the match of a lane near the tile centre
         const bool ok = rb.v[7] != 0.0;
@@ -1278,35 +1286,85 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     }
 }
 
-// Cost-balanced tile -> (block, wave) assignment for the following iterations.  grid (B), block 1024.
-// Tiles are ranked by the cycles the previous launch spent on them (256 buckets, counting sort, heaviest
-// first) and dealt to the blocks in serpentine order, so every block receives one tile of each quartile and
-// the block sums even out.  Any assignment gives identical results (partials are stored per tile); this only
-// removes the slow-block tail of k_nn_tiles_acc.
-__global__ __launch_bounds__(1024) void k_balance(const int *__restrict__ cost, int *__restrict__ perm, TileGrid tg, int nblk)
+// Cost-balanced, XCD-local tile -> (block, wave) assignment for the following iterations.  grid (B), block 1024.
+// Workgroup c runs on XCD c % 8 (measured; the grid width G is a multiple of 8), and every XCD has its own L2: the
+// tiles are cut, in raster order, into eight bands of equal measured COST (cycles the previous launch spent on
+// them), band x goes to the blocks of XCD x, so an XCD touches one eighth of the target frame (+ halo) instead of
+// all of it.  Inside a band the tiles are ranked by cost (256 buckets, counting sort, heaviest first) and dealt
+// to the XCD's blocks in serpentine order, so every block receives one tile of each quartile and the block sums
+// even out.  G carries slack over ntiles / NN_WAVES because equal-cost bands differ in tile count.  With
+// banded == 0 (the throughput build: many pairs per launch) the whole frame is dealt over all blocks.  Any assignment gives
+// identical results (partials are order-free integer sums); this only shapes time and L2 traffic.
+__global__ __launch_bounds__(1024) void k_balance(const int *__restrict__ cost, int *__restrict__ perm, TileGrid tg, int G, int banded)
 {
-    __shared__ int hist[256], start[256], cmax;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ int hist[8][256], start[8][256], bstart[9], cmax;
+    __shared__ unsigned long long wsum[16], total, carry;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int *__restrict__ C = cost + (size_t)b * tg.ntiles;
-    int *__restrict__ P = perm + (size_t)b * nblk * NN_WAVES;
-    if (tid < 256) hist[tid] = 0;
-    if (tid == 0) cmax = 1;
+    int *__restrict__ P = perm + (size_t)b * G * NN_WAVES;
+    for (int k = tid; k < 8 * 256; k += 1024) (&hist[0][0])[k] = 0;
+    if (tid == 0) { cmax = 1; total = 0; carry = 0; }
+    if (tid < 9) bstart[tid] = tid == 0 ? 0 : tg.ntiles;
     __syncthreads();
     int m = 1;
-    for (int t = tid; t < tg.ntiles; t += 1024) m = max(m, C[t]);
+    unsigned long long part = 0;
+    for (int t = tid; t < tg.ntiles; t += 1024) { m = max(m, C[t]); part += (unsigned long long)max(C[t], 0); }
     atomicMax(&cmax, m);
-    for (int s = tid; s < nblk * NN_WAVES; s += 1024) P[s] = -2;
+    atomicAdd(&total, part);
+    for (int s = tid; s < G * NN_WAVES; s += 1024) P[s] = -2;
     __syncthreads();
     const long long mx = cmax;
-    for (int t = tid; t < tg.ntiles; t += 1024) atomicAdd(&hist[255 - (int)(((long long)C[t] * 255) / mx)], 1);   // bucket 0 = heaviest
+    const unsigned long long tot = total ? total : 1ull;
+    const int nbx = G >> 3, cap = nbx * NN_WAVES;
+    if (banded) {
+        // band boundaries: tile t is in band floor(8 * (cost before t) / total); chunked block scan in raster order
+        for (int base = 0; base < tg.ntiles; base += 1024) {
+            const int t = base + tid;
+            const unsigned long long v = t < tg.ntiles ? (unsigned long long)max(C[t], 0) : 0ull;
+            unsigned long long inc = v;                                   // inclusive scan inside the wave
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const unsigned long long o = __shfl_up(inc, d, 64);
+                if (lane >= d) inc += o;
+            }
+            if (lane == 63) wsum[wv] = inc;
+            __syncthreads();
+            unsigned long long before = carry;
+            for (int k = 0; k < wv; ++k) before += wsum[k];
+            const unsigned long long excl = before + inc - v, incl = before + inc;
+            if (t < tg.ntiles) {
+                const int lo = (int)min(7ull, excl * 8ull / tot), hi = (int)min(7ull, incl * 8ull / tot);
+                for (int x = lo + 1; x <= hi; ++x) bstart[x] = t + 1;
+            }
+            __syncthreads();
+            if (tid == 1023) carry = incl;
+            __syncthreads();
+        }
+        // a band that outgrows its XCD's slots spills into the next one (and the last bands must be able to hold
+        // what is left): as balanced as the slack allows, always a valid assignment since 8 * cap >= ntiles
+        if (tid == 0)
+            for (int x = 0; x < 7; ++x)
+                bstart[x + 1] = max(min(bstart[x + 1], bstart[x] + cap), tg.ntiles - (7 - x) * cap);
+        __syncthreads();
+    }
+    const bool bands = banded != 0;
+    auto band_of = [&](int t) {
+        int x = 0;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) x += t >= bstart[k] ? 1 : 0;
+        return bands ? x : 0;
+    };
+    for (int t = tid; t < tg.ntiles; t += 1024) atomicAdd(&hist[band_of(t)][255 - (int)(((long long)max(C[t], 0) * 255) / mx)], 1);   // bucket 0 = heaviest
     __syncthreads();
-    if (tid == 0) { int a = 0; for (int k = 0; k < 256; ++k) { start[k] = a; a += hist[k]; } }
+    if (tid < 8) { int a = 0; for (int k = 0; k < 256; ++k) { start[tid][k] = a; a += hist[tid][k]; } }
     __syncthreads();
     for (int t = tid; t < tg.ntiles; t += 1024) {
-        const int r = atomicAdd(&start[255 - (int)(((long long)C[t] * 255) / mx)], 1);      // rank, heaviest first
-        const int q = r / nblk, i = r - q * nblk;
-        const int blk = (q & 1) ? nblk - 1 - i : i;
-        P[blk * NN_WAVES + q] = t;
+        const int x = band_of(t);
+        const int r = atomicAdd(&start[x][255 - (int)(((long long)max(C[t], 0) * 255) / mx)], 1);      // rank in the band, heaviest first
+        const int nb = bands ? nbx : G;
+        const int q = r / nb, i = r - q * nb;
+        const int k = (q & 1) ? nb - 1 - i : i;
+        P[(bands ? x + 8 * k : k) * NN_WAVES + q] = t;
     }
 }
 
