@@ -1298,48 +1298,45 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
 __global__ __launch_bounds__(1024) void k_balance(const int *__restrict__ cost, int *__restrict__ perm, TileGrid tg, int G, int banded)
 {
     __shared__ int hist[8][256], start[8][256], bstart[9], cmax;
-    __shared__ unsigned long long wsum[16], total, carry;
+    __shared__ double wsum[16];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int *__restrict__ C = cost + (size_t)b * tg.ntiles;
     int *__restrict__ P = perm + (size_t)b * G * NN_WAVES;
     for (int k = tid; k < 8 * 256; k += 1024) (&hist[0][0])[k] = 0;
-    if (tid == 0) { cmax = 1; total = 0; carry = 0; }
+    if (tid == 0) cmax = 1;
     if (tid < 9) bstart[tid] = tid == 0 ? 0 : tg.ntiles;
     __syncthreads();
+    // thread tid owns the raster segment [t0, t1): cost sum (exact in a double: < 2^53) and maximum
+    const int seg = (tg.ntiles + 1023) / 1024, t0 = min(tid * seg, tg.ntiles), t1 = min(t0 + seg, tg.ntiles);
     int m = 1;
-    unsigned long long part = 0;
-    for (int t = tid; t < tg.ntiles; t += 1024) { m = max(m, C[t]); part += (unsigned long long)max(C[t], 0); }
+    double v = 0.0;
+    for (int t = t0; t < t1; ++t) { const int c = max(C[t], 0); m = max(m, c); v += (double)c; }
     atomicMax(&cmax, m);
-    atomicAdd(&total, part);
     for (int s = tid; s < G * NN_WAVES; s += 1024) P[s] = -2;
+    double inc = v;                                                   // inclusive scan inside the wave
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wv] = inc;
     __syncthreads();
-    const long long mx = cmax;
-    const unsigned long long tot = total ? total : 1ull;
+    const float bscale = 255.0f / (float)cmax;
+    auto bucket_of = [&](int t) { return 255 - min(255, (int)((float)max(C[t], 0) * bscale)); };        // bucket 0 = heaviest
     const int nbx = G >> 3, cap = nbx * NN_WAVES;
     if (banded) {
-        // band boundaries: tile t is in band floor(8 * (cost before t) / total); chunked block scan in raster order
-        for (int base = 0; base < tg.ntiles; base += 1024) {
-            const int t = base + tid;
-            const unsigned long long v = t < tg.ntiles ? (unsigned long long)max(C[t], 0) : 0ull;
-            unsigned long long inc = v;                                   // inclusive scan inside the wave
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const unsigned long long o = __shfl_up(inc, d, 64);
-                if (lane >= d) inc += o;
-            }
-            if (lane == 63) wsum[wv] = inc;
-            __syncthreads();
-            unsigned long long before = carry;
-            for (int k = 0; k < wv; ++k) before += wsum[k];
-            const unsigned long long excl = before + inc - v, incl = before + inc;
-            if (t < tg.ntiles) {
-                const int lo = (int)min(7ull, excl * 8ull / tot), hi = (int)min(7ull, incl * 8ull / tot);
-                for (int x = lo + 1; x <= hi; ++x) bstart[x] = t + 1;
-            }
-            __syncthreads();
-            if (tid == 1023) carry = incl;
-            __syncthreads();
+        // band boundaries: tile t is in band floor(8 * (cost before t) / total) -- any monotone map would do
+        double before = 0.0, total = 0.0;
+        for (int k = 0; k < 16; ++k) { if (k < wv) before += wsum[k]; total += wsum[k]; }
+        const double inv = 8.0 / (total > 0.0 ? total : 1.0);
+        double run = before + inc - v;
+        for (int t = t0; t < t1; ++t) {
+            const int lo = min(7, (int)(run * inv));
+            run += (double)max(C[t], 0);
+            const int hi = min(7, (int)(run * inv));
+            for (int x = lo + 1; x <= hi; ++x) bstart[x] = t + 1;
         }
+        __syncthreads();
         // a band that outgrows its XCD's slots spills into the next one (and the last bands must be able to hold
         // what is left): as balanced as the slack allows, always a valid assignment since 8 * cap >= ntiles
         if (tid == 0)
@@ -1354,13 +1351,26 @@ __global__ __launch_bounds__(1024) void k_balance(const int *__restrict__ cost, 
         for (int k = 1; k < 8; ++k) x += t >= bstart[k] ? 1 : 0;
         return bands ? x : 0;
     };
-    for (int t = tid; t < tg.ntiles; t += 1024) atomicAdd(&hist[band_of(t)][255 - (int)(((long long)max(C[t], 0) * 255) / mx)], 1);   // bucket 0 = heaviest
+    for (int t = tid; t < tg.ntiles; t += 1024) atomicAdd(&hist[band_of(t)][bucket_of(t)], 1);
     __syncthreads();
-    if (tid < 8) { int a = 0; for (int k = 0; k < 256; ++k) { start[tid][k] = a; a += hist[tid][k]; } }
+    if (wv < 8) {      // exclusive scan of band wv's 256 buckets: four per lane
+        int h[4], a = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { h[k] = hist[wv][4 * lane + k]; a += h[k]; }
+        int incl = a;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        int e = incl - a;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { start[wv][4 * lane + k] = e; e += h[k]; }
+    }
     __syncthreads();
     for (int t = tid; t < tg.ntiles; t += 1024) {
         const int x = band_of(t);
-        const int r = atomicAdd(&start[x][255 - (int)(((long long)max(C[t], 0) * 255) / mx)], 1);      // rank in the band, heaviest first
+        const int r = atomicAdd(&start[x][bucket_of(t)], 1);          // rank in the band, heaviest first
         const int nb = bands ? nbx : G;
         const int q = r / nb, i = r - q * nb;
         const int k = (q & 1) ? nb - 1 - i : i;
