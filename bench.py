@@ -59,7 +59,7 @@ def parse_args():
                     help="gloo + --one-device: exercise the N>1 code path with several ranks on ONE GPU (tests only)")
     ap.add_argument("--one-device", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one handle, every step fetched before the next is queued")
-    ap.add_argument("--in-flight", type=int, default=2, help="steps in flight (handles alternating, one HIP stream each); default 2 = double buffering")
+    ap.add_argument("--in-flight", type=int, default=3, help="steps in flight (handles taking turns, one HIP stream each); 1 = one step at a time")
     return ap.parse_args()
 
 
@@ -315,8 +315,8 @@ def main():
     d_tgt = torch.from_numpy(np.stack(tgt_host)).to(dev)
     params = capi.default_params(intr, estimator=est, iterations=args.iterations, max_batch=P,
                                  device=local_rank, nn_mode=args.nn_mode)
-    # two handles (each with its own HIP stream) on the same resident inputs alternate from step to step (batch mode):
-    # step k+1 is queued before step k's poses are fetched (fetch waits for its own run's end event only), so two
+    # --in-flight handles (each with its own HIP stream) on the same resident inputs take turns (batch mode): the next
+    # steps are queued before step k's poses are fetched (fetch waits for its own run's end event only), so
     # consecutive steps overlap on the GPU and the host round trip is hidden.  `single_step_latency_ms` reports the
     # un-overlapped time of one step next to it.
     handles = [capi.IcpHandle(params) for _ in range(1 if (is_dense or args.no_pipeline) else max(1, min(8, args.in_flight)))]
@@ -423,9 +423,9 @@ def main():
                          f"{args.iterations} ICP iterations, {args.estimator}, exact NN (tile-pruned brute force), "
                          f"seeds {seeds[0]}..{seeds[-1]}"),
             "pairs_per_gpu": P, "iterations": args.iterations, "estimator": args.estimator,
-            "step_pipelining": (f"{len(handles)} handles, each on its own HIP stream, alternate: step k+1 is queued before step k's poses "
-                                "are fetched, so two consecutive steps overlap on the GPU; every step's poses reach the host inside "
-                                "the timed region") if len(handles) > 1 else "none",
+            "step_pipelining": (f"{len(handles)} handles, each on its own HIP stream, take turns: the following steps are queued before "
+                                f"step k's poses are fetched, so {len(handles)} consecutive steps overlap on the GPU; every step's poses "
+                                "reach the host inside the timed region") if len(handles) > 1 else "none",
             "nn_mode": {0: "auto(tiles)", 1: "brute_valu", 2: "brute_mfma", 3: "tiles"}.get(args.nn_mode, str(args.nn_mode)),
             "n_src": [r["n_src"] for r in res][:4], "n_tgt": [r["n_tgt"] for r in res][:4],
             "parallelism": (f"source rows over {world} rank(s), RCCL all-reduce of 29 doubles per iteration" if is_dense else

@@ -61,6 +61,9 @@ if (k, "FETCH_SIZE") in rows and (k, "WRITE_SIZE") in rows:
         if dur_ns:
             out["k_nn_tiles_acc"]["launch_ns_in_pmc_run"] = round(dur_ns, 1)
             out["k_nn_tiles_acc"]["valu_instructions_per_wave"] = round(sq.get("SQ_INSTS_VALU", 0) / max(sq.get("SQ_WAVES", 1), 1), 1)
+            out["k_nn_tiles_acc"]["waves_per_launch_note"] = ("SQ_WAVES counts every launched wave; the single-pair grid carries 20 % slack "
+                                                              "(waves without a tile that only help with shared work items), so per "
+                                                              "tile-owning wave the count is SQ_INSTS_VALU / ntiles (4800 tiles at 640x480)")
             # 4 cycles per wave64 VALU instruction on a 16-lane SIMD, 1024 SIMDs, ~2.3 GHz
             out["k_nn_tiles_acc"]["valu_issue_floor_us"] = round(sq.get("SQ_INSTS_VALU", 0) * 4 / 1024 / 2.3e3, 2)
     json.dump(out, open(os.path.join(dst, "r01_traffic.json"), "w"), indent=1)
