@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo + --one-device: exercise the N>1 code path with several ranks on ONE GPU (tests only)")
     ap.add_argument("--one-device", action="store_true")
+    ap.add_argument("--force-collective", action="store_true", help="developer knob: initialise RCCL and run the per-step pose all-gather even with one rank")
     ap.add_argument("--no-pipeline", action="store_true", help="one handle, every step fetched before the next is queued")
     ap.add_argument("--in-flight", type=int, default=3, help="steps in flight (handles taking turns, one HIP stream each); 1 = one step at a time")
     return ap.parse_args()
@@ -290,8 +291,9 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     host_comm = args.dist_backend == "gloo"       # exchange buffers on the host (RCCL needs one GPU per rank)
-    if world > 1:
+    if world > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if host_comm:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -328,7 +330,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     table = {}
     d_sums = torch.zeros(29, dtype=torch.int64, device=dev)       # dense mode: the per-iteration exchange buffer
-    gatherer = shard.PoseGatherer(world * P, device=None if host_comm else dev) if (world > 1 and not is_dense) else None
+    gatherer = (shard.PoseGatherer(world * P, device=None if host_comm else dev, force=args.force_collective)
+                if ((world > 1 or args.force_collective) and not is_dense) else None)
     host_allreduce = dense.allreduce_sum_torch(None) if (host_comm and world > 1) else None
 
     def step():
@@ -488,7 +491,7 @@ def main():
         print(json.dumps(out))
     for hh in handles:
         hh.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

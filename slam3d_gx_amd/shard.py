@@ -63,12 +63,13 @@ class PoseGatherer:
     oldest submitted step (pair order, on every rank).  With gloo/CPU tensors the same calls run
     synchronously.  Exactly one collective per step; no data-path collective."""
 
-    def __init__(self, n_pairs: int, device=None):
+    def __init__(self, n_pairs: int, device=None, force: bool = False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.n_pairs = n_pairs
-        self.on = dist.is_initialized() and dist.get_world_size() > 1
+        # force: run the collective even with one rank (developer knob: RCCL path on a single GPU)
+        self.on = dist.is_initialized() and (dist.get_world_size() > 1 or force)
         self.world = dist.get_world_size() if self.on else 1
         self.rank = dist.get_rank() if self.on else 0
         self.sizes = [shard_range(n_pairs, self.world, r) for r in range(self.world)]
