@@ -504,3 +504,27 @@ def test_zero_distances_and_duplicate_targets(gpu_lib, estimator):
     even = valid & (u % 2 == 0) & (ro["d2"] == 0)       # target pixels u and u+1 both hold source point u: exact tie
     if estimator == 1:                                   # (point-to-plane only matches targets that kept a normal)
         assert even.any() and (ro["idx"][even] == np.nonzero(even)[0]).all()  # ... resolved to the smaller pixel index
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_throughput_build", [False, True])
+def test_tiny_frames_and_ownership_map_reuse(gpu_lib, force_throughput_build, monkeypatch):
+    """Frames of one to a few dozen tiles (fewer tiles than XCD bands, bands of zero tiles, grid slack rounding) and
+    the tile-ownership map carried from one run to the next on the same handle (k_balance: any assignment must own
+    every tile exactly once, so indices, iterates and sums stay the oracle's)."""
+    if force_throughput_build:
+        monkeypatch.setenv("SLAM3D_DENSE_BATCH", "1")
+    for (W, H) in [(8, 8), (16, 8), (24, 16), (40, 24), (72, 40), (136, 8)]:
+        prs = [synth.make_pair(2000 + k, W, H, holes=bool(k & 1)) for k in range(3)]
+        with capi.IcpHandle(capi.default_params(prs[0].intr, iterations=4, max_corr_dist=0.5)) as h:
+            for pr in prs:      # second and third run start from the previous run's ownership map
+                s4 = synth.backproject_numpy(pr.depth_src, pr.intr); t4 = synth.backproject_numpy(pr.depth_tgt, pr.intr)
+                ro = O.icp(s4, t4, O.params(pr.intr, iterations=4, nn_method=0, max_corr_dist=0.5))
+                rg = h.align(s4, t4)
+                idx, d2 = h.get_correspondences(0)
+                Tt, St = h.get_trace(0)
+                ctx = dict(W=W, H=H)
+                assert np.array_equal(idx, ro["idx"]), ctx
+                assert np.array_equal(d2.view(np.uint32), ro["d2"].view(np.uint32)), ctx
+                assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:4], ro["sums_trace"]), ctx
+                assert rg["status"] == ro["status"] and rg["inliers"] == ro["inliers"], ctx
