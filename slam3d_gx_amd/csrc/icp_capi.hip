@@ -430,7 +430,7 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
 // one iteration's data-parallel part: NN search + normal-equation chunks, then the 29-sum reduction
 // (+ solve and SE(3) update when do_solve)
 static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int it, int do_solve,
-                             long long *raw_out = nullptr)
+                             long long *raw_out = nullptr, int balance = 0)
 {
     const TileGrid &tg = h->tg;
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
@@ -448,7 +448,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         else
             hipLaunchKernelGGL((k_nn_tiles_acc<3, 7, true>), dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
                                h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, perm, h->cost, h->acc, h->g, tg, h->dbg, write_out);
-        if (it == 1 && do_solve)      // costs are stable from the second iteration on: balance the blocks once
+        if ((it == 1 && do_solve) || balance)      // costs are stable from the second iteration on: balance the blocks once
             hipLaunchKernelGGL(k_balance, dim3(B), dim3(1024), 0, s, h->cost, perm, tg, gx, dense ? 0 : h->xcd_bands);
         if (e1) HIPCHK(h, hipEventRecord(e1, s));
     } else {
@@ -1040,7 +1040,7 @@ extern "C" int slam3d_icp_dense_partial(slam3d_icp_handle *h, int64_t sums[SLAM3
     if (!h->ran) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
-    const int rc = enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0, h->sums);
+    const int rc = enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0, h->sums, h->dense_it == 1);
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(h->pin_out, h->sums, sizeof(int64_t) * NSUMS, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
@@ -1073,7 +1073,7 @@ extern "C" int slam3d_icp_dense_partial_device(slam3d_icp_handle *h, int64_t *d_
     if (!h->ran) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
-    return enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0, reinterpret_cast<long long *>(d_sums));
+    return enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0, reinterpret_cast<long long *>(d_sums), h->dense_it == 1);
 }
 
 extern "C" int slam3d_icp_dense_update_device(slam3d_icp_handle *h, const int64_t *d_sums, void *stream)

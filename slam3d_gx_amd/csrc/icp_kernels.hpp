@@ -901,7 +901,7 @@ constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (
 // grid (G, B), block 256 = 4 waves; G = a multiple of 8 >= ntiles/4 (+ slack, see k_balance).  Wave w of block c
 // OWNS one source tile: perm[b][c][w] once k_balance has run (cost-balanced; for few pairs per launch also
 // XCD-local: block c runs on XCD c % 8 and takes its tiles from the c % 8-th band of the frame), before that
-// the c % 8-th eighth of the tiles dealt over that XCD's blocks.
+// tile c + w * G.
 //   1. every wave: one round of loads, upper bounds, exhaustive scan of the 5 tiles around its hint tile;
 //   2. every wave publishes its queries (point, running key, tight/loose class) in LDS and appends one work
 //      item per coarse cell its two query boxes can reach;                                   -- barrier --
@@ -942,11 +942,9 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     // ownership: the measured-cost balanced assignment once k_balance has run (perm >= 0 tile, -2 none),
     // before that (-1) tiles interleaved over the image bands
     const int pt = __builtin_amdgcn_readfirstlane(perm[((size_t)b * gridDim.x + c) * NN_WAVES + w]);
-    int t = pt < 0 ? tg.ntiles : pt;
-    if (pt == -1) {     // default: XCD x (= c % 8, the grid width is a multiple of 8) takes the x-th eighth of the tiles
-        const int nbx = (int)gridDim.x >> 3, j = (c >> 3) + w * nbx, bs = (tg.ntiles + 7) >> 3;
-        t = j < bs ? (c & 7) * bs + j : tg.ntiles;
-    }
+    // default (-1, a handle's first two iterations): interleaved, tile c + w * G -- no locality, but even over the XCDs
+    // whatever part of the frame holds the work (row shards of the dense mode)
+    const int t = pt == -1 ? c + w * (int)gridDim.x : (pt < 0 ? tg.ntiles : pt);
     const bool has_tile = t < tg.ntiles;
     const long long cw0 = clock64();
     float4 *__restrict__ st = stage_all[w];
