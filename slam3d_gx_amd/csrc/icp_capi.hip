@@ -209,8 +209,6 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     tg.mag_W = (unsigned int)((0x100000000ull + p->width - 1) / p->width);
     tg.nchunks = (tg.ntiles + TILES_PER_CHUNK - 1) / TILES_PER_CHUNK;
     tg.nslots = tg.nchunks * CHUNK;
-    tg.ngroups = (tg.ntiles + CHUNK - 1) / CHUNK;
-    tg.tpad = tg.ngroups * CHUNK;
     const size_t BN = (size_t)h->maxB * h->N;
     const size_t BS = (size_t)h->maxB * tg.nslots;
     const bool brute = nn_mode_of(h) != SLAM3D_NN_TILES;
@@ -389,7 +387,6 @@ static int stage_inputs(slam3d_icp_handle *h, int B, const double *T_init, hipSt
 static int enqueue_preprocess_dev(slam3d_icp_handle *h, int B, bool has_T, hipStream_t s)
 {
     const Geometry &g = h->g;
-    const int nperm = h->nn_gx * NN_WAVES;
     const double *dT = nullptr;
     if (has_T) {
         HIPCHK(h, hipMemcpyAsync(h->d_Tinit, h->pin_T, sizeof(double) * 16 * B, hipMemcpyHostToDevice, s));
@@ -403,7 +400,7 @@ static int enqueue_preprocess_dev(slam3d_icp_handle *h, int B, bool has_T, hipSt
         hipLaunchKernelGGL(k_normals, grid, dim3(NRM_BX, NRM_BY), 0, s, h->d_slots, h->nrm, g);
     }
     hipLaunchKernelGGL(k_build_tiles, dim3(tg.ntiles, 2, B), dim3(64), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT, h->tbox,
-                       h->scount, h->corr, h->prevq, h->hint, h->perm, nperm, h->counts, g, tg, use_normals, h->row0, h->row1);
+                       h->scount, h->corr, h->prevq, h->hint, h->counts, g, tg, use_normals, h->row0, h->row1);
     hipLaunchKernelGGL(k_coarse_boxes, dim3(tg.ncoarse, B), dim3(64), 0, s, h->tbox, h->scount, h->cbox, h->counts, tg);
     if (brute) {
         HIPCHK(h, hipMemsetAsync(h->best, 0xFF, sizeof(unsigned long long) * (size_t)B * tg.nslots, s));

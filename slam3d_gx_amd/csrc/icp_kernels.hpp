@@ -204,10 +204,9 @@ constexpr int TILE_REC = 72;               // target tile record: 64 slots (4 qu
 constexpr int COARSE_TILES = 8;            // coarse box edge in tiles (64 px)
 constexpr int TILES_PER_CHUNK = CHUNK / TILE_SLOTS;
 
-// nchunks = launch blocks of 4 tiles, nslots = padded slot count (ngroups / tpad: unused since the sums became
-// integer accumulators)
+// nchunks = launch blocks of 4 tiles, nslots = padded slot count
 // mag_x = ceil(2^32 / x): q = umulhi(n, mag_x) is n / x exactly for n * x < 2^32 (scalar multiply, no VALU division)
-struct TileGrid { int ntx, nty, ntiles, ncx, ncy, ncoarse, nchunks, nslots, ngroups, tpad; unsigned int mag_ncx, mag_W; };
+struct TileGrid { int ntx, nty, ntiles, ncx, ncy, ncoarse, nchunks, nslots; unsigned int mag_ncx, mag_W; };
 
 // ---- wave64 cross-lane helpers on the VALU (DPP within a 16-lane row, v_permlane16/32_swap across
 // rows -- gfx950); no LDS round trips.  Inputs are never NaN here (+-inf marks "no value").
@@ -219,8 +218,6 @@ __device__ __forceinline__ float rdlane(float v, int lane_uniform)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_uniform));
 }
-__device__ __forceinline__ float fmin_nn(float a, float b) { return b < a ? b : a; }
-__device__ __forceinline__ float fmax_nn(float a, float b) { return b > a ? b : a; }
 
 // all-lanes min / max: xor-1, xor-2 (quad_perm), row_half_mirror, row_mirror, then rows 0<->1 / 2<->3
 // (v_permlane16_swap) and halves (v_permlane32_swap).  The four in-row steps are single v_min/v_max_f32 with a DPP
@@ -261,7 +258,7 @@ __global__ __launch_bounds__(64) void k_build_tiles(const SlotPtrs *__restrict__
                                                     float4 *__restrict__ srcT, float4 *__restrict__ tgtT,
                                                     float4 *__restrict__ tbox, int *__restrict__ scount,
                                                     int *__restrict__ corr, float4 *__restrict__ prevq,
-                                                    int *__restrict__ hint, int *__restrict__ perm, int nperm,
+                                                    int *__restrict__ hint,
                                                     int *__restrict__ counts,
                                                     Geometry g, TileGrid tg, int use_normals, int row0, int row1)
 {
