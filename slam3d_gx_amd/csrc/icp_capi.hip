@@ -400,7 +400,8 @@ static int enqueue_preprocess_dev(slam3d_icp_handle *h, int B, bool has_T, hipSt
         hipLaunchKernelGGL(k_normals, grid, dim3(NRM_BX, NRM_BY), 0, s, h->d_slots, h->nrm, g);
     }
     hipLaunchKernelGGL(k_build_tiles, dim3(tg.ntiles, 2, B), dim3(64), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT, h->tbox,
-                       h->scount, h->corr, h->prevq, h->hint, h->counts, g, tg, use_normals, h->row0, h->row1);
+                       h->scount, h->corr, h->prevq, h->hint, h->counts, g, tg, use_normals, h->row0, h->row1,
+                       dT, h->Tcur, h->trace_T, h->flags, h->acc, h->p.iterations > 0 ? h->p.iterations : 1);
     hipLaunchKernelGGL(k_coarse_boxes, dim3(tg.ncoarse, B), dim3(64), 0, s, h->tbox, h->scount, h->cbox, h->counts, tg);
     if (brute) {
         HIPCHK(h, hipMemsetAsync(h->best, 0xFF, sizeof(unsigned long long) * (size_t)B * tg.nslots, s));
@@ -412,8 +413,6 @@ static int enqueue_preprocess_dev(slam3d_icp_handle *h, int B, bool has_T, hipSt
                                h->N, h->npad, 0.5f * g.zmax);
         }
     }
-    const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
-    hipLaunchKernelGGL(k_init_T, dim3(B), dim3(64), 0, s, dT, h->Tcur, h->trace_T, h->flags, h->acc, iters);
     HIPCHK(h, hipGetLastError());
     return SLAM3D_OK;
 }

@@ -198,6 +198,8 @@ __global__ __launch_bounds__(NRM_BX * NRM_BY) void k_normals(const SlotPtrs *__r
 // ------------------------------------------------------------------------------------ S3
 // Both organized clouds are cut into 8x8-pixel tiles: one wavefront = one tile = 64 slots.
 // Source slot id = tile*64 + (v%8)*8 + (u%8).  Correspondences refer to targets by ORIGINAL pixel index j.
+constexpr int ACC_R = 16;                      // accumulator replicas per pair: same-address atomics serialise
+constexpr int ACC_STRIDE = 32;                 // int64 per replica (29 used)
 constexpr int TILE_PX = 8;                 // tile edge in pixels
 constexpr int TILE_SLOTS = 64;             // = one wavefront
 constexpr int TILE_REC = 72;               // target tile record: 64 slots (4 quadrants x 16) + 4 x (lo, hi) quadrant boxes
@@ -260,9 +262,22 @@ __global__ __launch_bounds__(64) void k_build_tiles(const SlotPtrs *__restrict__
                                                     int *__restrict__ corr, float4 *__restrict__ prevq,
                                                     int *__restrict__ hint,
                                                     int *__restrict__ counts,
-                                                    Geometry g, TileGrid tg, int use_normals, int row0, int row1)
+                                                    Geometry g, TileGrid tg, int use_normals, int row0, int row1,
+                                                    const double *__restrict__ T_init, double *__restrict__ Tcur,
+                                                    double *__restrict__ trace_T, int *__restrict__ flags,
+                                                    long long *__restrict__ acc, int iters)
 {
     const int t = blockIdx.x, which = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+    if (which == 0 && t == 0) {
+        // start of the run for pair b: T = T_init (or Identity), trace row 0, flags, clean accumulators
+        for (int j = lane; j < ACC_R * ACC_STRIDE; j += 64) acc[(size_t)b * ACC_R * ACC_STRIDE + j] = 0;
+        if (lane < 16) {
+            const double v = T_init ? T_init[b * 16 + lane] : ((lane % 5 == 0) ? 1.0 : 0.0);
+            Tcur[b * 16 + lane] = v;
+            trace_T[((size_t)b * (iters + 1)) * 16 + lane] = v;
+        }
+        if (lane == 0) flags[b] = 0;
+    }
     if (which == 0) {
         // per-run state of the iteration kernels, reset here instead of by five memset launches: no previous
         // match (corr = -1, prevq.w = -1 bits), no hint tile, default tile ownership, zero totals
@@ -736,8 +751,6 @@ template <int EST, int K> __device__ __forceinline__ double row_term(const RowBa
 //             a[i]+a[i+32] in lanes 0..31 and b[i]+b[i+32] in lanes 32..63;
 //   level 16: v_permlane16_swap on two such registers -> rows 0..3 hold components (a, c, b, d);
 //   levels 8..1: DPP row_shl inside each 16-lane row.  Result: lanes 0,16,32,48 hold the sums of a,c,b,d.
-constexpr int ACC_R = 16;                      // accumulator replicas per pair: same-address atomics serialise
-constexpr int ACC_STRIDE = 32;                 // int64 per replica (29 used)
 
 template <int CTRL> __device__ __forceinline__ double dpp_d(double x)
 {
@@ -1602,20 +1615,6 @@ __global__ void k_solve(const long long *__restrict__ sums_all, double *__restri
     for (int k = 0; k < NSUMS; ++k) sums[k] = (double)sums_all[b * NSUMS + k] / FIX_SCALE;     // all-reduced integer sums
     solve_update_one(sums, Tcur + b * 16, trace_T + (size_t)b * (iters + 1) * 16, trace_S + (size_t)b * iters * NSUMS,
                      flags + b, it, estimator);
-}
-
-// grid (B), block 64: T = T_init (or Identity), trace row 0, flags, and clean accumulators for the run
-__global__ __launch_bounds__(64) void k_init_T(const double *__restrict__ T_init, double *__restrict__ Tcur,
-                                               double *__restrict__ trace_T, int *__restrict__ flags, long long *__restrict__ acc, int iters)
-{
-    const int b = blockIdx.x, k = threadIdx.x;
-    for (int j = k; j < ACC_R * ACC_STRIDE; j += 64) acc[(size_t)b * ACC_R * ACC_STRIDE + j] = 0;
-    if (k < 16) {
-        const double v = T_init ? T_init[b * 16 + k] : ((k % 5 == 0) ? 1.0 : 0.0);
-        Tcur[b * 16 + k] = v;
-        trace_T[((size_t)b * (iters + 1)) * 16 + k] = v;
-    }
-    if (k == 0) flags[b] = 0;
 }
 
 // slot-order correspondences -> original pixel order (for get_correspondences)
