@@ -432,7 +432,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
     if (e0) HIPCHK(h, hipEventRecord(e0, s));
     if (nn_mode_of(h) == SLAM3D_NN_TILES) {
-        // few pairs: cooperative blocks, 7 waves per SIMD (latency bound); from 8 pairs per launch: every wave on its
+        // few pairs: cooperative blocks (latency bound); from 8 pairs per launch: every wave on its
         // own, 8 waves per SIMD (throughput bound); three staged tile records per wave in both
         const bool dense = B >= h->dense_batch;
         const int write_out = (!do_solve || it == iters - 1) ? 1 : 0;      // corr / cd2: only the last iteration's are read
@@ -442,7 +442,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
             hipLaunchKernelGGL((k_nn_tiles_acc<3, 8, false>), dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
                                h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, perm, h->cost, h->acc, h->g, tg, h->dbg, write_out);
         else
-            hipLaunchKernelGGL((k_nn_tiles_acc<3, 7, true>), dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
+            hipLaunchKernelGGL((k_nn_tiles_acc<3, 8, true>), dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
                                h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, perm, h->cost, h->acc, h->g, tg, h->dbg, write_out);
         if ((it == 1 && do_solve) || balance)      // costs are stable from the second iteration on: balance the blocks once
             hipLaunchKernelGGL(k_balance, dim3(B), dim3(1024), 0, s, h->cost, perm, tg, gx, dense ? 0 : h->xcd_bands);

@@ -900,8 +900,8 @@ __device__ __forceinline__ unsigned long long key_min(unsigned long long a, unsi
     return (unsigned long long)__double_as_longlong(r);
 }
 
-// Two builds of the kernel, three staged tile records per wave in both.  <3, 7 waves per SIMD, cooperative>: the four
-// waves of a block share their work items (21 KB LDS per block, 65 VGPRs); the faster one while a launch holds few
+// Two builds of the kernel, three staged tile records per wave in both.  <3, 8 waves per SIMD, cooperative>: the four
+// waves of a block share their work items (20,440 B of LDS per block -- eight blocks fit the 160 KB of a CU --, 62 VGPRs); the faster one while a launch holds few
 // pairs (latency bound: the slowest block ends the launch).  <3, 8, not cooperative>: every wave sweeps its own cells
 // -- no shared lists, no block barriers, 14 KB of LDS, 55 VGPRs -- at the full 8 waves per SIMD; it wins when many
 // pairs fill the chip (throughput bound: 64 pairs 44 k -> 55 k it/s).
@@ -937,7 +937,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
 {
     __shared__ float4 stage_all[NN_WAVES][NN_STAGE * TILE_REC];
     __shared__ int wcost[NN_WAVES];                                    // cycles spent for each owner (all helpers)
-    __shared__ float4 qpos[NN_WAVES][TILE_SLOTS];                     // p'.xyz, w = 0 invalid / 1 tight / 2 loose
+    __shared__ float qpos[NN_WAVES][3][TILE_SLOTS];                   // p'.x / .y / .z of each owner's queries (SoA: 3 KB, not 4)
+    __shared__ unsigned long long qcls[NN_WAVES][2];                  // lane masks: valid, tight (loose = valid & ~tight)
     __shared__ unsigned long long qkey[NN_WAVES][TILE_SLOTS];
     __shared__ int wcentre[NN_WAVES][8];                               // the step-1 tiles of each owner (NN_STAGE used)
     __shared__ float wbox[NN_WAVES][16];                               // each owner's tight / loose query boxes + flag
@@ -1174,7 +1175,11 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         const float bnd0 = __int_as_float((int)(unsigned int)(bkey >> 32));
         tight = valid && bnd0 <= 0.0625f * g.gate2; loose = valid && !tight;
         if constexpr (COOP) {
-            qpos[w][lane] = make_float4(px, py, pz, valid ? (tight ? 1.0f : 2.0f) : 0.0f);
+            qpos[w][0][lane] = px; qpos[w][1][lane] = py; qpos[w][2][lane] = pz;
+            {
+                const unsigned long long vm = __ballot(valid), tm = __ballot(tight);
+                if (lane == 0) { qcls[w][0] = vm; qcls[w][1] = tm; }
+            }
             qkey[w][lane] = bkey;
             if (lane < NN_STAGE) {
                 int v = ta[0];
@@ -1242,9 +1247,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             const int item = items[it];
             const int owner = item >> 16, cc = item & 0xffff;
             const long long ci0 = clock64();
-            const float4 q = qpos[owner][lane];
-            px = q.x; py = q.y; pz = q.z;
-            valid = q.w > 0.5f; tight = q.w == 1.0f; loose = q.w == 2.0f;
+            px = qpos[owner][0][lane]; py = qpos[owner][1][lane]; pz = qpos[owner][2][lane];
+            valid = (qcls[owner][0] >> lane) & 1ull; tight = (qcls[owner][1] >> lane) & 1ull; loose = valid && !tight;
             bkey = qkey[owner][lane];
 #pragma unroll
             for (int k = 0; k < NN_STAGE; ++k) ta[k] = wcentre[owner][k];

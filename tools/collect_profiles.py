@@ -36,7 +36,7 @@ for (name, ctr), (v, n) in sorted(rows.items()):
     md += f"| `{name}` | {ctr} | {v:.1f} | {n} |\n"
 open(os.path.join(dst, f"{tag}_kernel_stats.md"), "w").write(md)
 
-cands = sorted({n for (n, _c) in rows if "k_nn_tiles_acc" in n})       # template instance, e.g. "void s3d::k_nn_tiles_acc<3, 7, true>"
+cands = sorted({n for (n, _c) in rows if "k_nn_tiles_acc" in n})       # template instance, e.g. "void s3d::k_nn_tiles_acc<3, 8, true>"
 k = cands[0] if cands else "s3d::k_nn_tiles_acc"
 if (k, "FETCH_SIZE") in rows and (k, "WRITE_SIZE") in rows:
     f, w = rows[(k, "FETCH_SIZE")][0], rows[(k, "WRITE_SIZE")][0]
