@@ -425,6 +425,9 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
 
 // one iteration's data-parallel part: NN search + normal-equation chunks, then the 29-sum reduction
 // (+ solve and SE(3) update when do_solve)
+#ifndef S3D_COOP_WPE
+#define S3D_COOP_WPE 8
+#endif
 static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int it, int do_solve,
                              long long *raw_out = nullptr, int balance = 0)
 {
@@ -438,12 +441,13 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         const int write_out = (!do_solve || it == iters - 1) ? 1 : 0;      // corr / cd2: only the last iteration's are read
         int *perm = dense ? h->perm_d : h->perm;
         const int gx = dense ? h->nn_gx_d : h->nn_gx;
-        if (dense)
-            hipLaunchKernelGGL((k_nn_tiles_acc<3, 8, false>), dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
+        // four instances: {throughput, cooperative} x {production, instrumented (SLAM3D_NN_DEBUG: per-tile clocks and counters)}
+        auto launch = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
                                h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, perm, h->cost, h->acc, h->g, tg, h->dbg, write_out);
-        else
-            hipLaunchKernelGGL((k_nn_tiles_acc<3, 8, true>), dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
-                               h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, perm, h->cost, h->acc, h->g, tg, h->dbg, write_out);
+        };
+        if (dense) { if (h->dbg) launch(k_nn_tiles_acc<3, 8, false, true>); else launch(k_nn_tiles_acc<3, 8, false, false>); }
+        else       { if (h->dbg) launch(k_nn_tiles_acc<3, S3D_COOP_WPE, true, true>);  else launch(k_nn_tiles_acc<3, S3D_COOP_WPE, true, false>); }
         if ((it == 1 && do_solve) || balance)      // costs are stable from the second iteration on: balance the blocks once
             hipLaunchKernelGGL(k_balance, dim3(B), dim3(1024), 0, s, h->cost, perm, tg, gx, dense ? 0 : h->xcd_bands);
         if (e1) HIPCHK(h, hipEventRecord(e1, s));

@@ -920,7 +920,7 @@ constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (
 //      quadrants), merged into the owner's keys with ds_min_u64;                             -- barrier --
 //   4. every wave finishes its own tile: gate, row products, level-1 reduction, hint for the next iteration.
 // The result is independent of which wave processes which item (keys are merged by an exact minimum).
-template <int NN_STAGE, int WPE, bool COOP>
+template <int NN_STAGE, int WPE, bool COOP, bool DBG>
 __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_nn_tiles_acc(const SlotPtrs *__restrict__ slots,
                                                         const float4 *__restrict__ nrm_all,
                                                         const float4 *__restrict__ srcT,
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                                                         float4 *__restrict__ prevq, int *__restrict__ hint,
                                                         const int *__restrict__ perm, int *__restrict__ cost,
                                                         long long *__restrict__ acc, Geometry g, TileGrid tg,
-                                                        long long *__restrict__ dbg /* nullable: 8 x int64 per tile */,
+                                                        long long *__restrict__ dbg /* DBG builds only: 8 x int64 per tile */,
                                                         int write_out /* corr / cd2 wanted (last iteration) */)
 {
     __shared__ float4 stage_all[NN_WAVES][NN_STAGE * TILE_REC];
@@ -944,8 +944,12 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     __shared__ float wbox[NN_WAVES][16];                               // each owner's tight / loose query boxes + flag
     __shared__ int items[NN_MAX_ITEMS];
     __shared__ int n_items, next_item;
-    const long long clk0 = dbg ? clock64() : 0;
+    const long long clk0 = DBG ? clock64() : 0;
     long long clk1 = 0, clk2 = 0, clk3 = 0;
+    // Wave-uniform work counters (scalar adds, no VALU).  They stay in every instance on purpose: with them compiled
+    // out (ROCm 7.2 hipcc) the cooperative instance hangs on the GPU for any frame of more than one tile --
+    // reproducible, independent of the waves-per-SIMD setting, not explained -- while the clock reads (DBG only)
+    // can go: that alone takes 40 of the 117 SGPR spills (v_writelane/v_readlane pairs) out of the production build.
     int n_scanned = 0, n_cand = 0, n_batches = 0, n_chit = 0, n_fhit = 0, n_refined = 0;
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.y, c = blockIdx.x;
@@ -1165,11 +1169,11 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             const float d2g = canon_d2(px, py, pz, qg.x, qg.y, qg.z);
             if (tv && d2g <= g.gate2) bkey = ((unsigned long long)(unsigned int)__float_as_int(d2g) << 32) | (unsigned int)jg;
         }
-        if (dbg) clk1 = clock64();
+        if constexpr (DBG) clk1 = clock64();
         hinted = th >= 0;
         park_and_scan();
         hinted = false;
-        if (dbg) clk2 = clock64();
+        if constexpr (DBG) clk2 = clock64();
         opx = px; opy = py; opz = pz;
         // ---- step 2: publish the queries and one work item per reachable coarse cell
         const float bnd0 = __int_as_float((int)(unsigned int)(bkey >> 32));
@@ -1263,7 +1267,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         }
     }
     if constexpr (COOP) __syncthreads();
-    if (dbg) clk3 = clock64();
+    if constexpr (DBG) clk3 = clock64();
     if (!has_tile) return;
     if (lane == 0) cost[(size_t)b * tg.ntiles + t] = wcost[w];           // input of k_balance
     // ================= step 4: this wave's own tile: fused S4 accumulation =================
@@ -1289,7 +1293,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             }
         }
     }
-    if (dbg && b == 0 && lane == 0) {
+    if (dbg && b == 0 && lane == 0) {       // (clocks are zero unless DBG)
         long long *d = dbg + (size_t)t * 8;
         d[0] = clk0; d[1] = clk1; d[2] = clk2; d[3] = clk3; d[4] = clock64();
         d[5] = n_scanned | ((long long)n_chit << 32); d[6] = n_cand | ((long long)n_fhit << 32);
