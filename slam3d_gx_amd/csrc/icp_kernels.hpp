@@ -900,6 +900,28 @@ __device__ __forceinline__ unsigned long long key_min(unsigned long long a, unsi
     return (unsigned long long)__double_as_longlong(r);
 }
 
+// Wave-uniform fetch-and-add on an LDS word: lane 0 performs the atomic, every lane gets the old value.  One opaque
+// block on purpose.  The source form `if (lane == 0) old = atomicAdd(p, v); old = readfirstlane(old);` inside a loop
+// is fragile: when hipcc (ROCm 7.2) threads the lane-0 branch through the loop, the other lanes spin in an inner
+// loop with lane 0 masked off, readfirstlane then returns THEIR stale value and the wave never leaves -- the
+// cooperative build hung that way as soon as unrelated code (the debug counters) was compiled out.  Must be called
+// with all 64 lanes active and a wave-uniform v.
+__device__ __forceinline__ int lds_fetch_add_uniform(int *p, int v)
+{
+    const unsigned int addr = (unsigned int)(__SIZE_TYPE__)(__attribute__((address_space(3))) int *)p;
+    int old;
+    unsigned long long save;
+    asm volatile("s_mov_b64 %[save], exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "ds_add_rtn_u32 %[old], %[a], %[val]\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "s_mov_b64 exec, %[save]"
+                 : [old] "=&v"(old), [save] "=&s"(save)
+                 : [a] "v"(addr), [val] "v"(v)
+                 : "memory");
+    return __builtin_amdgcn_readfirstlane(old);
+}
+
 // Two builds of the kernel, three staged tile records per wave in both.  <3, 8 waves per SIMD, cooperative>: the four
 // waves of a block share their work items (20,440 B of LDS per block -- eight blocks fit the 160 KB of a CU --, 62 VGPRs); the faster one while a launch holds few
 // pairs (latency bound: the slowest block ends the launch).  <3, 8, not cooperative>: every wave sweeps its own cells
@@ -946,10 +968,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     __shared__ int n_items, next_item;
     const long long clk0 = DBG ? clock64() : 0;
     long long clk1 = 0, clk2 = 0, clk3 = 0;
-    // Wave-uniform work counters (scalar adds, no VALU).  They stay in every instance on purpose: with them compiled
-    // out (ROCm 7.2 hipcc) the cooperative instance hangs on the GPU for any frame of more than one tile --
-    // reproducible, independent of the waves-per-SIMD setting, not explained -- while the clock reads (DBG only)
-    // can go: that alone takes 40 of the 117 SGPR spills (v_writelane/v_readlane pairs) out of the production build.
+    // per-tile work counters and clocks of the instrumented (DBG) instances; compiled out of the production ones
     int n_scanned = 0, n_cand = 0, n_batches = 0, n_chit = 0, n_fhit = 0, n_refined = 0;
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.y, c = blockIdx.x;
@@ -1003,13 +1022,13 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     auto scan_staged = [&](int k, int tile) __attribute__((always_inline)) {
         const float thr = lane_thr();          // once per tile: the quadrant tests below may use this (larger) value
         if (!hinted && __ballot(lane_gap_le(TB[2 * tile], TB[2 * tile + 1], thr)) == 0ull) return;     // uniform -> scalar loads
-        n_scanned += 1;
+        if constexpr (DBG) n_scanned += 1;
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
             const float4 lo = st[k * TILE_REC + TILE_SLOTS + 2 * qd], hi = st[k * TILE_REC + TILE_SLOTS + 2 * qd + 1];
             const int cnt = __builtin_amdgcn_readfirstlane(__float_as_int(lo.w));
             if (cnt == 0 || __ballot(lane_gap_le(lo, hi, thr)) == 0ull) continue;
-            n_cand += cnt;
+            if constexpr (DBG) n_cand += cnt;
             const float4 *__restrict__ cand = st + k * TILE_REC + qd * 16;
             // four candidates per trip; the padding slots of a quadrant hold (+inf, +inf, +inf): d2 = +inf never wins
             for (int i = 0; i < cnt; i += 4) {
@@ -1030,7 +1049,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             r[k] = tt[k] >= 0 ? TT[(size_t)tt[k] * TILE_REC + lane] : make_float4(__int_as_float(-1), inf, inf, inf);
     };
     auto park_and_scan = [&]() __attribute__((always_inline)) {
-        n_batches += 1;
+        if constexpr (DBG) n_batches += 1;
         // lanes 0..39 fetch the quadrant boxes of the staged tiles (8 float4 per tile) with one load
         int my_tile = -1;
 #pragma unroll
@@ -1093,7 +1112,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             hit2 = !in_a && reach(lo, hi, thr_t, thr_l);
         }
         unsigned long long tm0 = __ballot(hit2), tm = 0ull;
-        n_chit += 1; n_fhit += __popcll(tm0);
+        if constexpr (DBG) { n_chit += 1; n_fhit += __popcll(tm0); }
         // refine BEFORE fetching anything: a tile is staged only if some lane's own ball reaches its box
         // (lane k2 holds the box of child k2 -> broadcast it with v_readlane)
         while (tm0) {
@@ -1103,7 +1122,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             const float4 bhi = make_float4(rdlane(hi.x, k2), rdlane(hi.y, k2), rdlane(hi.z, k2), 0.0f);
             if (__ballot(lane_gap_ok(blo, bhi)) != 0ull) tm |= 1ull << k2;
         }
-        n_refined += __popcll(tm);
+        if constexpr (DBG) n_refined += __popcll(tm);
         while (tm) {
 #pragma unroll
             for (int k = 0; k < NN_STAGE; ++k) {
@@ -1217,9 +1236,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                 continue;
             }
             const int cnt = __popcll(cm);
-            int base = 0;
-            if (lane == 0 && cnt) base = atomicAdd(&n_items, cnt);
-            base = __builtin_amdgcn_readfirstlane(base);
+            const int base = cnt ? lds_fetch_add_uniform(&n_items, cnt) : 0;       // cnt is wave-uniform
             if (hit) {
                 const int pos = base + __popcll(cm & ((1ull << lane) - 1ull));
                 if (pos < NN_MAX_ITEMS) items[pos] = (w << 16) | cidx;
@@ -1244,9 +1261,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     if constexpr (COOP) {
         const int total = min(n_items, NN_MAX_ITEMS);
         while (true) {
-            int it = 0;
-            if (lane == 0) it = atomicAdd(&next_item, 1);
-            it = __builtin_amdgcn_readfirstlane(it);
+            const int it = lds_fetch_add_uniform(&next_item, 1);
             if (it >= total) break;
             const int item = items[it];
             const int owner = item >> 16, cc = item & 0xffff;
@@ -1293,7 +1308,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             }
         }
     }
-    if (dbg && b == 0 && lane == 0) {       // (clocks are zero unless DBG)
+    if (DBG && dbg && b == 0 && lane == 0) {
         long long *d = dbg + (size_t)t * 8;
         d[0] = clk0; d[1] = clk1; d[2] = clk2; d[3] = clk3; d[4] = clock64();
         d[5] = n_scanned | ((long long)n_chit << 32); d[6] = n_cand | ((long long)n_fhit << 32);
