@@ -1259,11 +1259,11 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     if constexpr (COOP) __syncthreads();
     // ================= step 3: drain the shared item list =================
     if constexpr (COOP) {
-        const int total = min(n_items, NN_MAX_ITEMS);
+        const int total = __builtin_amdgcn_readfirstlane(min(n_items, NN_MAX_ITEMS));     // same in every lane: keep the loop scalar
         while (true) {
             const int it = lds_fetch_add_uniform(&next_item, 1);
             if (it >= total) break;
-            const int item = items[it];
+            const int item = __builtin_amdgcn_readfirstlane(items[it]);           // one address for the wave: owner and cell are scalars
             const int owner = item >> 16, cc = item & 0xffff;
             const long long ci0 = clock64();
             px = qpos[owner][0][lane]; py = qpos[owner][1][lane]; pz = qpos[owner][2][lane];
