@@ -38,6 +38,22 @@ FP32_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md:40-41 (vec
 HBM_PEAK_GBPS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec; 6.29 TB/s measured copy)
 
 
+_FINAL = []      # rank 0's result line, printed after all teardown so that it is the last line on stdout
+
+
+def _emit_final():
+    """RCCL prints a version banner through C stdio; flush that first, then print the one JSON line and flush."""
+    if not _FINAL:
+        return
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(_FINAL[-1], flush=True)
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,7 +227,7 @@ def seg_mode(args, torch, dist, capi, synth, world, rank, local_rank, dev):
                                    "sample": "oracle/seg_oracle.c, frame 0, single thread"}
             out["parity_vs_oracle"] = {"labels_equal": bool(np.array_equal(lab0, lo)),
                                        "coeff_equal": bool(all(np.array_equal(a["coeff"], b["coeff"]) for a, b in zip(out_planes[0], po)))}
-        print(json.dumps(out))
+        _FINAL.append(json.dumps(out))
     h.close()
 
 
@@ -269,7 +285,7 @@ def voxel_mode(args, torch, dist, capi, synth, world, rank, local_rank, dev):
             out["cpu_baseline"] = {"value": 1.0 / dt, "unit": "frames/s", "cores": 1, "kind": "port",
                                    "sample": "oracle/voxel_oracle.c (qsort by voxel key), same cloud, single thread"}
             out["parity_vs_oracle"] = {"bit_identical": bool(got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)))}
-        print(json.dumps(out))
+        _FINAL.append(json.dumps(out))
     h.close()
 
 
@@ -301,8 +317,9 @@ def main():
 
     if args.mode in ("seg", "voxel"):
         (seg_mode if args.mode == "seg" else voxel_mode)(args, torch, dist, capi, synth, world, rank, local_rank, dev)
-        if world > 1:
+        if dist.is_initialized():
             dist.destroy_process_group()
+        _emit_final()
         return
     is_dense = args.mode == "dense"
     P = 1 if is_dense else args.pairs
@@ -488,11 +505,12 @@ def main():
             "cpu_B_iters_per_s": cb_.get("value"), "cpu_B_1thread_iters_per_s": cb_.get("single_thread_value"), "cores": cb_.get("cores"),
             "max_rot_err": pv.get("rot_err_rad"), "max_trans_err": pv.get("trans_err_m"), "idx_mismatches": pv.get("idx_mismatches"),
         }
-        print(json.dumps(out))
+        _FINAL.append(json.dumps(out))
     for hh in handles:
         hh.close()
     if dist.is_initialized():
         dist.destroy_process_group()
+    _emit_final()
 
 
 if __name__ == "__main__":
