@@ -397,7 +397,8 @@ static int enqueue_preprocess_dev(slam3d_icp_handle *h, int B, bool has_T, hipSt
     const int use_normals = h->p.estimator == SLAM3D_EST_POINT2PLANE ? 1 : 0;
     if (use_normals) {
         dim3 grid((g.W + NRM_BX - 1) / NRM_BX, (g.H + NRM_BY - 1) / NRM_BY, B);
-        hipLaunchKernelGGL(k_normals, grid, dim3(NRM_BX, NRM_BY), 0, s, h->d_slots, h->nrm, g);
+        if (g.win_r == 3) hipLaunchKernelGGL(k_normals<3>, grid, dim3(NRM_BX, NRM_BY), 0, s, h->d_slots, h->nrm, g);
+        else hipLaunchKernelGGL(k_normals<0>, grid, dim3(NRM_BX, NRM_BY), 0, s, h->d_slots, h->nrm, g);
     }
     hipLaunchKernelGGL(k_build_tiles, dim3(tg.ntiles, 2, B), dim3(64), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT, h->tbox,
                        h->scount, h->corr, h->prevq, h->hint, h->counts, g, tg, use_normals, h->row0, h->row1,

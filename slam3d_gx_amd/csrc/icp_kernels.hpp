@@ -132,6 +132,11 @@ __device__ __forceinline__ void eig3_smallest(Sym3 A, double &nx, double &ny, do
 // in LDS once (coalesced float4 rows), then each thread walks its window twice (moments, inliers).
 constexpr int NRM_BX = 32, NRM_BY = 8, NRM_RMAX = 4;
 
+// RT > 0: window radius known at compile time (the default 7x7 window: loops unrolled, LDS offsets immediate);
+// RT == 0: radius from g.win_r.  Invalid neighbours are not branched around: their coordinates are replaced by the
+// centre's, so they add exact zeros to every sum (no accumulator can be -0.0: all start at +0.0), and a lane mask
+// keeps them out of the counts -- the same bits as the skip, one LDS read per neighbour and no divergence.
+template <int RT>
 __global__ __launch_bounds__(NRM_BX * NRM_BY) void k_normals(const SlotPtrs *__restrict__ slots,
                                                              float4 *__restrict__ nrm_all, Geometry g)
 {
@@ -139,7 +144,8 @@ __global__ __launch_bounds__(NRM_BX * NRM_BY) void k_normals(const SlotPtrs *__r
     const int b = blockIdx.z;
     const float4 *__restrict__ cloud = slots[b].tgt;
     float4 *__restrict__ nrm = nrm_all + (size_t)b * g.N;
-    const int r = g.win_r;
+    const int r = RT > 0 ? RT : g.win_r;
+    constexpr int UN = RT > 0 ? 2 * RT + 1 : 1;       // one window row per trip of the outer loop
     const int tw = NRM_BX + 2 * r, th = NRM_BY + 2 * r;
     const int u0 = blockIdx.x * NRM_BX - r, v0 = blockIdx.y * NRM_BY - r;
     const int tid = threadIdx.y * NRM_BX + threadIdx.x;
@@ -156,17 +162,20 @@ __global__ __launch_bounds__(NRM_BX * NRM_BY) void k_normals(const SlotPtrs *__r
     const int u = blockIdx.x * NRM_BX + threadIdx.x, v = blockIdx.y * NRM_BY + threadIdx.y;
     if (u >= g.W || v >= g.H) return;
     float4 out = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const float4 c0 = tile[(threadIdx.y + r) * tw + threadIdx.x + r];
+    const float4 *__restrict__ win = tile + threadIdx.y * tw + threadIdx.x;      // top-left corner of this pixel's window
+    const float4 c0 = win[r * tw + r];
     if (c0.w > 0.5f) {
         const double cx0 = c0.x, cy0 = c0.y, cz0 = c0.z;
         int n = 0;
         double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+#pragma unroll 1
         for (int dv = 0; dv <= 2 * r; ++dv)
+#pragma unroll UN
             for (int du = 0; du <= 2 * r; ++du) {
-                const float4 q = tile[(threadIdx.y + dv) * tw + threadIdx.x + du];
-                if (!(q.w > 0.5f)) continue;
-                const double dx = (double)q.x - cx0, dy = (double)q.y - cy0, dz = (double)q.z - cz0;
-                ++n;
+                const float4 q = win[dv * tw + du];
+                const bool ok = q.w > 0.5f;
+                const double dx = (double)(ok ? q.x : c0.x) - cx0, dy = (double)(ok ? q.y : c0.y) - cy0, dz = (double)(ok ? q.z : c0.z) - cz0;
+                n += ok ? 1 : 0;
                 sx += dx; sy += dy; sz += dz;
                 sxx += dx * dx; sxy += dx * dy; sxz += dx * dz;
                 syy += dy * dy; syz += dy * dz; szz += dz * dz;
@@ -181,13 +190,14 @@ __global__ __launch_bounds__(NRM_BX * NRM_BY) void k_normals(const SlotPtrs *__r
             eig3_smallest(C, nx, ny, nz);
             if (nx * cx0 + ny * cy0 + nz * cz0 > 0.0) { nx = -nx; ny = -ny; nz = -nz; }
             int cnt = 0;
+#pragma unroll 1
             for (int dv = 0; dv <= 2 * r; ++dv)
+#pragma unroll UN
                 for (int du = 0; du <= 2 * r; ++du) {
-                    const float4 q = tile[(threadIdx.y + dv) * tw + threadIdx.x + du];
-                    if (!(q.w > 0.5f)) continue;
+                    const float4 q = win[dv * tw + du];
                     const double dx = (double)q.x - cx0, dy = (double)q.y - cy0, dz = (double)q.z - cz0;
                     const double e = nx * (dx - mx) + ny * (dy - my) + nz * (dz - mz);
-                    if (fabs(e) <= g.in_dist) ++cnt;
+                    cnt += (q.w > 0.5f && fabs(e) <= g.in_dist) ? 1 : 0;       // NaN coordinates of an invalid point: e = NaN, not counted either way
                 }
             if (cnt >= g.min_in) out = make_float4((float)nx, (float)ny, (float)nz, 1.0f);
         }
