@@ -1,28 +1,38 @@
 #!/usr/bin/env python3
 """bench.py -- ICP iterations/s of the MI355X plane-ICP path (BASELINE.json metric).
 
-A *step* is one pass of the hot path over one batch of synthetic frame pairs that are already
-resident in HBM: preprocessing (normals, tiles) + `iterations` ICP iterations + the pose records
-back on the host.  Workload at N=1: BASELINE config 2 (single 640x480 pair, seed 1000, 20
-iterations, point-to-plane); `--pairs P` batches P pairs per GPU (config 3 = 64).  For N>1 every
-rank processes its own pairs (seed 1000 + rank*P + i) -- the path has no data-path collective --
-and the SE(3) pose records are all-gathered over RCCL once per step (weak scaling).
-`--mode dense` is BASELINE config 5: ONE pair whose source rows are sharded over the ranks, with a
-29-double all-reduce per iteration (strong scaling).
+What is timed ("wall = first H2D enqueue -> last pose on host"):
 
-Prints ONE JSON line on rank 0.
-  roofline            the dominant kernel of the measured (default, tile-pruned) path: k_nn_tiles_acc.
-                      It streams each array once per iteration, so it is accounted against HBM:
-                      achieved = algorithmic bytes per launch (12 B src xyz + 4 B idx per
-                      valid source point, 12 B xyz + 12 B normal per valid target point) / mean launch
-                      duration measured with HIP events on the launch stream.
-  roofline_bruteforce the north-star algorithm (full brute-force scan, SLAM3D_NN_BRUTE_VALU) measured in
-                      the same process on the same pair: 8*n_src*n_tgt flop per launch vs the fp32 peak.
-  cpu_baseline        the CPU oracle (exact kd-tree NN, OpenMP) timed on the host on the same pair.
+  A *step* is one pass of the hot path over one batch of synthetic input: `--pairs-per-step` S frame pairs (default
+  256), processed as S / P consecutive alignments of P pairs each (P = `--pairs`, default 1 = BASELINE config 2:
+  a single 640x480 pair, 20 iterations, point-to-plane).  EVERY alignment inside the timed region consists of
+      H2D of BOTH u16 depth images of the pair from pinned host memory (2 x 614 KB)
+      -> back-projection -> target normals -> tile records of both frames -> 20 ICP iterations -> pose record on the host.
+  Nothing is cached from one alignment to the next: the pairs cycle through a pool of `--pool` (default 16) DISTINCT
+  seeded pairs per in-flight handle, so the ownership map, the hints and the caches are never primed by the identical
+  frame.  `--in-flight` handles (one HIP stream each) take turns, i.e. the stream of independent pairs is software
+  pipelined; `single_step_latency_ms` is the same work with one alignment at a time.
+  The former headline (one pair resident in HBM, re-run in place, preprocessing included) is reported as
+  `resident_same_pair_value`; the survey's noise level (sigma = 0.0012 z^2) as `survey_noise`.
+
+  N > 1: every rank processes its own pairs (seeds offset by rank, no data-path collective) and the S pose records of
+  a step are all-gathered over RCCL *inside the library* (slam3d_pose_gather_*), overlapping the next step (weak
+  scaling).  `--mode dense` is BASELINE config 5: ONE pair whose source rows are sharded over the ranks with one
+  29-word all-reduce per iteration (slam3d_icp_dense_run; strong scaling).
+
+Prints ONE JSON line on rank 0.  Beside metric/value/...:
+  roofline            dominant kernel k_nn_tiles_acc accounted against HBM: algorithmic bytes per launch (SURVEY.md
+                      8(d): 12 B xyz + 4 B idx per valid source point, 12 B xyz + 12 B normal per valid target) / mean
+                      launch duration, measured with HIP events on the launch stream over `--profile-aligns` alignments.
+  roofline_bruteforce the north-star algorithm (full brute-force scan) on the f32 MFMA pipe and on the VALU.
+  cpu_baseline        the CPU oracle timed on the host on a bounded sample of the same workload.
+  config3 / config5   BASELINE configs 3 (64 pairs per launch) and 5 (1280x960 dense) measured in the same run, each
+                      with its own roofline and cpu_baseline (N = 1 only; skip with --no-extra-configs).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import statistics
@@ -35,8 +45,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md:40-41 (vector == f32-MFMA dense peak)
-HBM_PEAK_GBPS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec; 6.29 TB/s measured copy)
-
+HBM_PEAK_GBPS = 8000.0       # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec; ~6.3 TB/s achievable)
 
 _FINAL = []      # rank 0's result line, printed after all teardown so that it is the last line on stdout
 
@@ -57,9 +66,11 @@ def _emit_final():
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=1, help="frame pairs per GPU per step (config 3: 64)")
+    ap.add_argument("--pairs", type=int, default=1, help="frame pairs per launch sequence and GPU (config 3: 64)")
+    ap.add_argument("--pairs-per-step", type=int, default=256, help="frame pairs one step processes per GPU (S / --pairs alignments)")
+    ap.add_argument("--pool", type=int, default=16, help="distinct seeded pairs per in-flight handle that the stream cycles through")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--iterations", type=int, default=20)
@@ -68,66 +79,188 @@ def parse_args():
     ap.add_argument("--mode", choices=["batch", "dense", "seg", "voxel"], default="batch",
                     help="seg: row f-2, batched RANSAC plane segmentation of --pairs frames per GPU; "
                          "voxel: row f-1, PassThrough + VoxelGrid(0.03) of one resident cloud per step")
+    ap.add_argument("--noise-sigma", type=float, default=0.0002, help="depth noise sigma/z^2 of the synthetic frames (survey: 0.0012)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bruteforce", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the config-3 / config-5 / survey-noise / resident legs")
+    ap.add_argument("--profile-aligns", type=int, default=48, help="alignments of the event-profiled pass (roofline launch time)")
     ap.add_argument("--seed0", type=int, default=1000)
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo + --one-device: exercise the N>1 code path with several ranks on ONE GPU (tests only)")
     ap.add_argument("--one-device", action="store_true")
-    ap.add_argument("--force-collective", action="store_true", help="developer knob: initialise RCCL and run the per-step pose all-gather even with one rank")
-    ap.add_argument("--no-pipeline", action="store_true", help="one handle, every step fetched before the next is queued")
-    ap.add_argument("--in-flight", type=int, default=3, help="steps in flight (handles taking turns, one HIP stream each); 1 = one step at a time")
+    ap.add_argument("--force-collective", action="store_true", help="developer knob: run the RCCL exchanges even with one rank")
+    ap.add_argument("--no-pipeline", action="store_true", help="one handle, every alignment fetched before the next is queued")
+    ap.add_argument("--in-flight", type=int, default=3, help="alignments in flight (handles taking turns, one HIP stream each)")
     return ap.parse_args()
 
 
-def cpu_baseline_leg(pair, s4, t4, args, gpu_result, gpu_idx):
+def baseline_metric():
+    """BASELINE.json's metric string, verbatim (the driver compares it)."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except Exception:
+        return "ICP iterations/sec on 640×480 clouds; SE(3) pose error vs PCL ref"
+
+
+def kernel_src_sha16():
+    h = hashlib.sha256()
+    with open(os.path.join(ROOT, "slam3d_gx_amd", "csrc", "icp_kernels.hpp"), "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def committed_traffic(tag):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile of THIS kernel source (the profile
+    records the SHA-256 of icp_kernels.hpp it was taken on; a stale profile yields null, never a stale number)."""
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        e = d[tag]
+        if d.get("kernel_src_sha16") != kernel_src_sha16():
+            return None, os.path.relpath(path, ROOT) + " (stale: kernel source changed since the PMC pass)", {}
+        return e["hbm_bytes_per_launch"], os.path.relpath(path, ROOT), e
+    except Exception:
+        return None, None, {}
+
+
+# ------------------------------------------------------------------------------------------------ workload
+class Pool:
+    """`n` distinct seeded frame pairs as u16 depth images in PINNED host memory (so that hipMemcpyAsync is truly
+    asynchronous), plus their float4 clouds for the oracle legs."""
+
+    CACHE = {}          # (seed, width, height, sigma) -> FramePair, filled in parallel by Pool.prefetch
+
+    @classmethod
+    def prefetch(cls, synth, specs):
+        todo = [sp for sp in dict.fromkeys(specs) if sp not in cls.CACHE]
+        if todo:
+            cls.CACHE.update(synth.make_pairs(todo))
+
+    def __init__(self, torch, synth, seeds, width, height, sigma):
+        self.prefetch(synth, [(s, width, height, sigma) for s in seeds])
+        self.pairs = [self.CACHE[(s, width, height, sigma)] for s in seeds]
+        self.intr = self.pairs[0].intr
+        self.depth = torch.empty((len(seeds), 2, height, width), dtype=torch.int16).pin_memory()     # u16 bits
+        arr = self.depth.numpy().view(np.uint16)
+        for i, p in enumerate(self.pairs):
+            arr[i, 0] = p.depth_src
+            arr[i, 1] = p.depth_tgt
+        self.stride = 2 * height * width * 2
+        self.frame_bytes = height * width * 2
+        self.base = self.depth.data_ptr()
+
+    def src_ptr(self, i):
+        return self.base + i * self.stride
+
+    def tgt_ptr(self, i):
+        return self.base + i * self.stride + self.frame_bytes
+
+    def __len__(self):
+        return len(self.pairs)
+
+
+class Streamer:
+    """Software-pipelined stream of alignments over `handles`: alignment k uploads both depth images of its P pairs,
+    runs, and its poses are fetched after the following len(handles)-1 alignments were queued."""
+
+    def __init__(self, handles, pools, P):
+        self.handles, self.pools, self.P = handles, pools, P
+        self.k = 0
+        self.queue = []             # handles with a run in flight, oldest first
+        self.last = None
+
+    def _enqueue(self, hi):
+        h, pool = self.handles[hi], self.pools[hi]
+        n = len(pool)
+        base = (self.k // len(self.handles)) * self.P
+        for i in range(self.P):
+            j = (base + i) % n
+            h.frame_set_depth_host_ptr(2 * i, pool.src_ptr(j))
+            h.frame_set_depth_host_ptr(2 * i + 1, pool.tgt_ptr(j))
+            h.set_pair(i, 2 * i, 2 * i + 1)
+        h.run(self.P)
+        self.queue.append(hi)
+        self.k += 1
+
+    def run(self, n_align, sink=None):
+        """n_align alignments; every one's poses reach the host (and `sink`) before this returns"""
+        nh = len(self.handles)
+        for _ in range(n_align):
+            if len(self.queue) >= nh:
+                self._drain_one(sink)
+            self._enqueue(self.k % nh)
+        while self.queue:
+            self._drain_one(sink)
+        return self.last
+
+    def _drain_one(self, sink):
+        hi = self.queue.pop(0)
+        self.last = self.handles[hi].fetch_results(self.P)
+        if sink is not None:
+            sink.extend(self.last)
+
+
+def cpu_baseline_leg(pair, s4, t4, iterations, est, gpu_result, gpu_idx, brute_sample=True):
     """Times the CPU oracle on the same pair and checks the GPU result against it.
     (oracle use is confined to this leg: checker + CPU baseline, never the measured path)"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    est = 0 if args.estimator == "point2plane" else 1
     cores = os.cpu_count() or 1
-    p_all = O.params(pair.intr, estimator=est, iterations=args.iterations, nn_method=1, threads=0)
+    big = pair.intr.width * pair.intr.height > 640 * 480
+    p_all = O.params(pair.intr, estimator=est, iterations=iterations, nn_method=1, threads=0)
     times = []
     ro = None
-    for _ in range(9):
+    for _ in range(3 if big else 7):
         t0 = time.perf_counter()
         ro = O.icp(s4, t4, p_all, trace=True)
         times.append(time.perf_counter() - t0)
     t_all = statistics.median(times)
-    # PCL's ICP is single-threaded: time one thread on a bounded sample (10 iterations, ~1.5 s)
-    it1 = min(10, args.iterations)
+    # PCL's ICP is single-threaded: time one thread on a bounded sample
+    it1 = min(4 if big else 10, iterations)
     p_one = O.params(pair.intr, estimator=est, iterations=it1, nn_method=1, threads=1)
     t0 = time.perf_counter()
     O.icp(s4, t4, p_one, trace=False)
     t_one = time.perf_counter() - t0
-    rot, tr = O.pose_error(ro["T_trace"][-1], gpu_result["T_raw"])
     out = {
-        "value": args.iterations / t_all, "unit": "ICP iterations/s", "cores": cores, "kind": "port",
-        "sample": f"oracle/ (exact kd-tree NN + same estimator, OpenMP on all {cores} hardware threads), 1 pair seed "
-                  f"{pair.seed} x {args.iterations} iterations incl. normals + kd-tree build, median of 9 (~4 s on all cores)",
+        "value": iterations / t_all, "unit": "ICP iterations/s", "cores": cores, "kind": "port",
+        "sample": f"oracle/ cpu_B (exact kd-tree NN + same estimator, OpenMP on all {cores} hardware threads), 1 pair seed "
+                  f"{pair.seed} x {iterations} iterations incl. normals + kd-tree build, median of {len(times)}",
         "single_thread_value": it1 / t_one,
         "single_thread_sample": f"same, 1 thread, {it1} iterations (PCL's own ICP is single-threaded)",
     }
-    parity = {
-        "rot_err_rad": rot, "trans_err_m": tr,
-        "idx_mismatches": int((gpu_idx != ro["idx"]).sum()),
-        "T_bit_identical": bool(np.array_equal(ro["T_trace"][-1], gpu_result["T_raw"])),
-    }
+    if brute_sample:
+        # cpu_A of SURVEY.md 8(d): the literal brute-force scan with the canonical arithmetic, all cores, ONE NN pass
+        p_br = O.params(pair.intr, estimator=est, iterations=1, nn_method=0, threads=0)
+        t0 = time.perf_counter()
+        O.nn_once(s4, t4, p_br, T=None, use_normals=(est == 0))
+        t_br = time.perf_counter() - t0
+        out["bruteforce_value"] = 1.0 / t_br
+        out["bruteforce_sample"] = f"cpu_A: literal brute-force NN scan (canonical fp32 arithmetic), all {cores} threads, one pass"
+    parity = None
+    if gpu_result is not None:
+        rot, tr = O.pose_error(ro["T_trace"][-1], gpu_result["T_raw"])
+        parity = {
+            "rot_err_rad": rot, "trans_err_m": tr,
+            "idx_mismatches": int((gpu_idx != ro["idx"]).sum()) if gpu_idx is not None else None,
+            "T_bit_identical": bool(np.array_equal(ro["T_trace"][-1], gpu_result["T_raw"])),
+        }
     return out, parity
 
 
-def bruteforce_leg(capi, intr, est, d_src_ptr, d_tgt_ptr, local_rank, iterations=4):
-    """The north-star algorithm on the same resident pair: every source x every target, distance step as a
-    dense contraction on the f32 MFMA pipe (k_nn_mfma); the fp32-VALU scan (k_nn_valu) is timed beside it."""
+def bruteforce_leg(capi, intr, est, s4, t4, local_rank, iterations=4):
+    """The north-star algorithm on one pair of the pool: every source x every target, distance step as a dense
+    contraction on the f32 MFMA pipe (k_nn_mfma); the fp32-VALU scan (k_nn_valu) is timed beside it."""
     out = {}
     for mode, name in ((capi.NN_BRUTE_MFMA, "mfma"), (capi.NN_BRUTE_VALU, "valu")):
         params = capi.default_params(intr, estimator=est, iterations=iterations, max_batch=1, device=local_rank, nn_mode=mode)
         with capi.IcpHandle(params) as h:
-            h.set_clouds_device(0, d_src_ptr, d_tgt_ptr)
+            h.set_clouds_host(0, s4, t4)
             h.set_profiling(True)
             h.run(1)
             h.fetch_results(1)                       # warm-up
+            h.set_clouds_host(0, s4, t4)
             h.run(1)
             r = h.fetch_results(1)[0]
             ms = float(np.mean(h.get_iteration_timings()[1:]))    # iteration 0 has no previous match to bound the filter
@@ -143,26 +276,84 @@ def bruteforce_leg(capi, intr, est, d_src_ptr, d_tgt_ptr, local_rank, iterations
                             "achieved": flops / (vms * 1e-3) / 1e12, "frac": flops / (vms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}}
 
 
-def baseline_metric():
-    """BASELINE.json's metric string, verbatim (the driver compares it)."""
-    try:
-        with open(os.path.join(ROOT, "BASELINE.json")) as f:
-            return json.load(f)["metric"]
-    except Exception:
-        return "ICP iterations/sec on 640\u00d7480 clouds; SE(3) pose error vs PCL ref"
+def profiled_pass(handle, pool, P, n_align, est):
+    """Event-profiled alignments on ONE handle, one at a time (every event record serialises the stream, so this is
+    kept out of the timed region): mean NN launch duration, kernel-only time per alignment, algorithmic bytes."""
+    handle.set_profiling(True)
+    nn, tot, pre, alg, flops, per_it = [], [], [], [], [], None
+    st = Streamer([handle], [pool], P)
+    for _ in range(n_align):
+        res = st.run(1)
+        tm = handle.get_timings()
+        nn.append(tm["nn_ms"]); tot.append(tm["total_ms"]); pre.append(tm["preprocess_ms"])
+        alg.append(sum((12 + 4) * r["n_src"] + (12 + (12 if est == 0 else 0)) * r["n_tgt"] for r in res))
+        flops.append(sum(8.0 * r["n_src"] * r["n_tgt"] for r in res))
+        per_it = handle.get_iteration_timings()
+    handle.set_profiling(False)
+    return dict(nn_ms=statistics.mean(nn), total_ms=statistics.mean(tot), preprocess_ms=statistics.mean(pre),
+                alg_bytes=statistics.mean(alg), flops=statistics.mean(flops), per_it=[round(float(x), 4) for x in per_it])
 
 
-def committed_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC profile (not a live measurement)."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        return d["k_nn_tiles_acc"]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT), d["k_nn_tiles_acc"]
-    except Exception:
-        return None, None, {}
+def tiles_roofline(prof, iterations, tag, note_extra=""):
+    launch_ms = prof["nn_ms"] / max(iterations, 1)
+    ach = prof["alg_bytes"] / (launch_ms * 1e-3) / 1e9
+    traffic, src, pm = committed_traffic(tag)
+    floor = pm.get("valu_issue_floor_us")
+    return {
+        "kernel": "k_nn_tiles_acc (exact tile-pruned NN + fused normal-equation accumulation)",
+        "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
+        "traffic": traffic, "traffic_source": src, "launch_ms": launch_ms,
+        "launch_ms_source": "HIP events around every k_nn_tiles_acc launch on the launch stream, separate pass (alignments one at a time)",
+        "algorithmic_bytes_per_launch": prof["alg_bytes"],
+        "valu_issue_floor_us": floor, "valu_instructions_per_wave": pm.get("valu_instructions_per_wave"),
+        "valu_issue_frac": (floor / (launch_ms * 1e3)) if floor else None,
+        "equivalent_bruteforce_tflops": prof["flops"] / (launch_ms * 1e-3) / 1e12,
+        "note": ("streaming accounting (each array once per iteration); the kernel is VALU-issue/latency bound, not HBM bound "
+                 "(DESIGN.md section 6); equivalent_bruteforce_tflops = flops of a full scan / this launch time" + note_extra),
+    }
 
 
+def timed_stream(torch, dist, world, streamer, steps, warmup, aligns_per_step, comm=None, P=1):
+    """W untimed steps, then EXACTLY K steps between barrier + synchronize; the pose records of every step are
+    gathered over RCCL (pipelined by one step, last table collected before the clock stops)."""
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    pending = 0
+    table = None
+
+    def one_step():
+        nonlocal pending, table
+        sink = [] if comm is not None else None
+        res = streamer.run(aligns_per_step, sink)
+        if comm is not None:
+            if pending >= 2:
+                table = comm.gather_collect(aligns_per_step * P); pending -= 1
+            comm.gather_submit(sink); pending += 1
+        return res
+
+    def drain():
+        nonlocal pending, table
+        while pending:
+            table = comm.gather_collect(aligns_per_step * P); pending -= 1
+
+    res = None
+    for _ in range(warmup):
+        res = one_step()
+    drain()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = one_step()
+    drain()                 # the last step's pose table is on every rank before the clock stops
+    fence()
+    return time.perf_counter() - t0, res, table
+
+
+# ------------------------------------------------------------------------------------------------ rows f-1 / f-2
 def seg_mode(args, torch, dist, capi, synth, world, rank, local_rank, dev):
     """Row f-2: plane segmentation of F = --pairs resident frames per GPU and step."""
     F = args.pairs
@@ -268,11 +459,10 @@ def voxel_mode(args, torch, dist, capi, synth, world, rank, local_rank, dev):
         "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * per,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64 fixed point", "data": "synthetic",
         "config": {"workload": f"row f-1: PassThrough z<=7 + VoxelGrid leaf 0.03 on {n} records of 16 B -> {m} voxels", "points": n, "voxels": m},
-        "roofline": {"kernel": "whole launch sequence (table clear, k_voxel_insert, k_voxel_compact, k_voxel_rank)", "bound": "hbm",
+        "roofline": {"kernel": "whole launch sequence of slam3d_voxel_grid_device", "bound": "hbm",
                      "achieved": alg_bytes / per / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg_bytes / per / 1e9 / HBM_PEAK_GBPS,
                      "traffic": None, "algorithmic_bytes_per_step": alg_bytes,
-                     "note": "algorithmic bytes = records in + records out; the hash table (52 B x 2^20 slots) is cleared and scanned "
-                             "every call, which is the real traffic"},
+                     "note": "algorithmic bytes = records in + records out"},
     }
     if rank == 0:
         if not args.no_cpu_baseline:
@@ -289,11 +479,58 @@ def voxel_mode(args, torch, dist, capi, synth, world, rank, local_rank, dev):
     h.close()
 
 
+# ------------------------------------------------------------------------------------------------ config 5
+def dense_leg(args, torch, dist, capi, synth, world, rank, local_rank, comm, width, height, steps, warmup, want_cpu):
+    """BASELINE config 5: ONE pair (seed 2000 + k), source rows sharded over the ranks, slam3d_icp_dense_run.  A step =
+    one alignment including the H2D of both depth images (every rank uploads the whole pair)."""
+    est = capi.EST_POINT2PLANE if args.estimator == "point2plane" else capi.EST_SVD
+    pool = Pool(torch, synth, [2000 + k for k in range(min(args.pool, 4))], width, height, args.noise_sigma)
+    params = capi.default_params(pool.intr, estimator=est, iterations=args.iterations, max_batch=1, device=local_rank)
+    h = capi.IcpHandle(params)
+    k = [0]
+
+    def step():
+        j = k[0] % len(pool); k[0] += 1
+        h.frame_set_depth_host_ptr(0, pool.src_ptr(j))
+        h.frame_set_depth_host_ptr(1, pool.tgt_ptr(j))
+        h.set_pair(0, 0, 1)
+        return h.dense_run(comm)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(warmup):
+        res = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    out = dict(elapsed=elapsed, res=res, pool=pool, handle=h, last_j=(k[0] - 1) % len(pool))
+    if world == 1:
+        # same kernels through the batch entry (rows = all rows) with per-launch events: the roofline's launch time
+        out["prof"] = profiled_pass(h, pool, 1, min(8, max(2, steps)), est)
+        if want_cpu:
+            j = out["last_j"]
+            pr = pool.pairs[j]
+            s4 = synth.backproject_numpy(pr.depth_src, pr.intr); t4 = synth.backproject_numpy(pr.depth_tgt, pr.intr)
+            h.frame_set_depth_host_ptr(0, pool.src_ptr(j)); h.frame_set_depth_host_ptr(1, pool.tgt_ptr(j)); h.set_pair(0, 0, 1)
+            r = h.dense_run(comm)
+            idx, _ = h.get_correspondences(0)
+            out["cpu"], out["parity"] = cpu_baseline_leg(pr, s4, t4, args.iterations, est, r, idx, brute_sample=False)
+    return out
+
+
 def main():
     args = parse_args()
     import torch
     import torch.distributed as dist
-    from slam3d_gx_amd import capi, dense, shard, synth
+    from slam3d_gx_amd import capi, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -306,7 +543,8 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    host_comm = args.dist_backend == "gloo"       # exchange buffers on the host (RCCL needs one GPU per rank)
+    host_comm = args.dist_backend == "gloo"       # tests only: several ranks on ONE GPU (RCCL needs one GPU per rank)
+    comm = None
     if world > 1 or args.force_collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -314,203 +552,279 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # rendezvous of the library's own RCCL communicator: 128 bytes from rank 0 (torch.distributed is the host
+            # side of the launch contract -- barrier, max-over-ranks -- the data-path exchanges run behind the C-ABI)
+            uid = [capi.comm_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(uid, src=0)
+            comm = capi.Comm(uid[0], rank, world, local_rank)
 
     if args.mode in ("seg", "voxel"):
         (seg_mode if args.mode == "seg" else voxel_mode)(args, torch, dist, capi, synth, world, rank, local_rank, dev)
+        if comm is not None:
+            comm.close()
         if dist.is_initialized():
             dist.destroy_process_group()
         _emit_final()
         return
-    is_dense = args.mode == "dense"
-    P = 1 if is_dense else args.pairs
+
     est = capi.EST_POINT2PLANE if args.estimator == "point2plane" else capi.EST_SVD
-    # ---- synthetic inputs, uploaded once: the timed region starts with clouds resident in HBM
-    seeds = [args.seed0] if is_dense else [args.seed0 + rank * P + i for i in range(P)]
-    pairs = [synth.make_pair(s, args.width, args.height) for s in seeds]
-    intr = pairs[0].intr
-    src_host = [synth.backproject_numpy(p.depth_src, intr) for p in pairs]
-    tgt_host = [synth.backproject_numpy(p.depth_tgt, intr) for p in pairs]
-    d_src = torch.from_numpy(np.stack(src_host)).to(dev)
-    d_tgt = torch.from_numpy(np.stack(tgt_host)).to(dev)
-    params = capi.default_params(intr, estimator=est, iterations=args.iterations, max_batch=P,
-                                 device=local_rank, nn_mode=args.nn_mode)
-    # --in-flight handles (each with its own HIP stream) on the same resident inputs take turns (batch mode): the next
-    # steps are queued before step k's poses are fetched (fetch waits for its own run's end event only), so
-    # consecutive steps overlap on the GPU and the host round trip is hidden.  `single_step_latency_ms` reports the
-    # un-overlapped time of one step next to it.
-    handles = [capi.IcpHandle(params) for _ in range(1 if (is_dense or args.no_pipeline) else max(1, min(8, args.in_flight)))]
-    h = handles[0]
-    rec_bytes = 4 * args.width * args.height * 4
-    for hh in handles:
-        for i in range(P):
-            hh.set_clouds_device(i, d_src.data_ptr() + i * rec_bytes, d_tgt.data_ptr() + i * rec_bytes)
-    stream = torch.cuda.current_stream().cuda_stream
-    table = {}
-    d_sums = torch.zeros(29, dtype=torch.int64, device=dev)       # dense mode: the per-iteration exchange buffer
-    gatherer = (shard.PoseGatherer(world * P, device=None if host_comm else dev, force=args.force_collective)
-                if ((world > 1 or args.force_collective) and not is_dense) else None)
-    host_allreduce = dense.allreduce_sum_torch(None) if (host_comm and world > 1) else None
-
-    def step():
-        if is_dense:      # one exchange per iteration: 29-double all-reduce (RCCL), device resident
-            if host_allreduce:
-                return [dense.dense_align(h, world, rank, None, host_allreduce, stream)]
-            return [dense.dense_align_device(h, world, rank, d_sums, None, stream)]
-        h.run(P, None, stream)
-        return finish(h)
-
-    def finish(hh):
-        res = hh.fetch_results(P)
-        if gatherer:      # RCCL all-gather of the 160-byte pose records (T, norm, inliers, status, rmse), one per
-            gatherer.submit(shard.pack_records(res))     # step, overlapping the next step's kernels
-            if len(gatherer.pending) > 1:
-                table["poses"] = gatherer.collect()
-        return res
-
-    def run_steps(n):
-        """n steps, software-pipelined over the handles; every step's poses are fetched (and gathered) inside"""
-        if len(handles) == 1:
-            out = None
-            for _ in range(n):
-                out = step()
-            return out
-        out, nh = None, len(handles)
-        for k in range(n):
-            handles[k % nh].run(P, None, stream)
-            if k >= nh - 1:
-                out = finish(handles[(k - (nh - 1)) % nh])
-        for k in range(max(0, n - (nh - 1)), n):
-            out = finish(handles[k % nh])
-        return out
-
-    def drain():
-        while gatherer and gatherer.pending:
-            table["poses"] = gatherer.collect()
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    run_steps(args.warmup)
-    drain()
-    nn_ms, tot_ms, pre_ms = [], [], []
-    fence()
-    t0 = time.perf_counter()
-    res = run_steps(args.steps)
-    h_last = handles[(args.steps - 1) % len(handles)]
-    drain()                 # the last step's pose table is on every rank before the clock stops
-    fence()
-    elapsed = time.perf_counter() - t0
-    latency_ms = None
-    if not is_dense:
-        nl = min(args.steps, 10)
-        fence()
-        tl = time.perf_counter()
-        for _ in range(nl):
-            step()
-        drain()
-        fence()
-        latency_ms = 1e3 * (time.perf_counter() - tl) / nl
-        # kernel durations for the roofline: the same K steps again with per-launch HIP events on the launch
-        # stream (kept out of the timed region because every event record serialises the stream for ~6 us)
-        h.set_profiling(True)
-        for _ in range(args.steps):
-            step()
-            tm = h.get_timings()
-            nn_ms.append(tm["nn_ms"]); tot_ms.append(tm["total_ms"]); pre_ms.append(tm["preprocess_ms"])
-        drain()
-        fence()
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_comm else dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    total_iters = (1 if is_dense else world * P) * args.iterations * args.steps
-    value = total_iters / elapsed
     size_tag = f"{args.width}x{args.height}"
+    metric = baseline_metric() if size_tag == "640x480" else f"ICP iterations/sec on {size_tag} clouds; SE(3) pose error vs PCL ref"
+
+    def tmax(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device="cpu" if host_comm else dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    # ================================================================== --mode dense (config 5 as the main line)
+    if args.mode == "dense":
+        if host_comm and world > 1:
+            raise SystemExit("--mode dense needs RCCL (one GPU per rank); the gloo form is covered by tests/test_shard_gloo.py")
+        d = dense_leg(args, torch, dist, capi, synth, world, rank, local_rank, comm, args.width, args.height, args.steps, args.warmup,
+                      want_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+        elapsed = tmax(d["elapsed"])
+        out = {
+            "metric": metric, "value": args.iterations * args.steps / elapsed, "unit": "ICP iterations/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 5: one {size_tag} pair per step (seeds 2000..), source rows sharded over {world} GPU(s), "
+                                   f"{args.iterations} iterations, {args.estimator}; H2D of both u16 depth images inside every step; "
+                                   "one ncclAllReduce of 29 int64 per iteration inside slam3d_icp_dense_run",
+                       "iterations": args.iterations, "estimator": args.estimator,
+                       "parallelism": f"source rows over {world} rank(s), RCCL all-reduce (C-ABI) of 29 int64 per iteration",
+                       "n_src": d["res"]["n_src"], "n_tgt": d["res"]["n_tgt"]},
+            "status": [d["res"]["status"]],
+        }
+        if "prof" in d:
+            out["roofline"] = tiles_roofline(d["prof"], args.iterations, f"k_nn_tiles_acc_{size_tag}")
+        if "cpu" in d:
+            out["cpu_baseline"], out["parity_vs_oracle"] = d["cpu"], d["parity"]
+        if rank == 0:
+            _FINAL.append(json.dumps(out))
+        d["handle"].close()
+        if comm is not None:
+            comm.close()
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        _emit_final()
+        return
+
+    # ================================================================== batch mode: configs 2 / 3
+    P = args.pairs
+    S = max(P, (args.pairs_per_step // P) * P)
+    aligns = S // P
+    n_handles = 1 if args.no_pipeline else max(1, min(8, args.in_flight))
+    pool_n = max(args.pool, P)
+    # every in-flight handle streams its own distinct pairs: seeds seed0 + (rank * n_handles + hi) * pool_n + k
+    want_extra = (rank == 0 and world == 1 and not args.no_extra_configs and args.nn_mode in (capi.NN_AUTO, capi.NN_TILES)
+                  and size_tag == "640x480" and P == 1)
+    specs = [(args.seed0 + (rank * n_handles + hi) * pool_n + k, args.width, args.height, args.noise_sigma)
+             for hi in range(n_handles) for k in range(pool_n)]
+    if want_extra:       # render everything the extra legs need in the same parallel batch
+        specs += [(args.seed0 + k, 640, 480, args.noise_sigma) for k in range(64)]
+        specs += [(args.seed0 + hi * pool_n + k, 640, 480, 0.0012) for hi in range(n_handles) for k in range(min(pool_n, 8))]
+        specs += [(2000 + k, 1280, 960, args.noise_sigma) for k in range(min(args.pool, 4))]
+    Pool.prefetch(synth, specs)
+    pools = [Pool(torch, synth, [args.seed0 + (rank * n_handles + hi) * pool_n + k for k in range(pool_n)], args.width, args.height,
+                  args.noise_sigma) for hi in range(n_handles)]
+    intr = pools[0].intr
+    params = capi.default_params(intr, estimator=est, iterations=args.iterations, max_batch=P, device=local_rank, nn_mode=args.nn_mode)
+    handles = [capi.IcpHandle(params) for _ in range(n_handles)]
+    streamer = Streamer(handles, pools, P)
+    gather = None
+    if comm is not None:
+        gather = comm
+    elif host_comm and world > 1:
+        from slam3d_gx_amd import shard
+
+        class _HostGather:        # tests only (gloo): same submit/collect contract through torch.distributed on the host
+            def __init__(self):
+                self.g = shard.PoseGatherer(world * S, device=None)
+
+            def gather_submit(self, results):
+                self.g.submit(shard.pack_records(results))
+
+            def gather_collect(self, n):
+                return shard.unpack_records(self.g.collect())
+        gather = _HostGather()
+    elapsed, res, table = timed_stream(torch, dist, world, streamer, args.steps, args.warmup, aligns, gather, P)
+    elapsed = tmax(elapsed)
+    total_iters = world * S * args.iterations * args.steps
+    value = total_iters / elapsed
+
     out = {
-        "metric": baseline_metric() if size_tag == "640x480" else f"ICP iterations/sec on {size_tag} clouds; SE(3) pose error vs PCL ref",
-        "value": value, "unit": "ICP iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-        "scaling": "strong" if is_dense else "weak",
+        "metric": metric, "value": value, "unit": "ICP iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": (f"BASELINE config 5: one {size_tag} pair, source rows sharded over {world} GPU(s), "
-                         f"{args.iterations} iterations, {args.estimator}, 232-byte all-reduce per iteration" if is_dense else
-                         f"BASELINE config {'2' if P == 1 else '3'}: {P} frame pair(s) per GPU of {size_tag}, "
-                         f"{args.iterations} ICP iterations, {args.estimator}, exact NN (tile-pruned brute force), "
-                         f"seeds {seeds[0]}..{seeds[-1]}"),
-            "pairs_per_gpu": P, "iterations": args.iterations, "estimator": args.estimator,
-            "step_pipelining": (f"{len(handles)} handles, each on its own HIP stream, take turns: the following steps are queued before "
-                                f"step k's poses are fetched, so {len(handles)} consecutive steps overlap on the GPU; every step's poses "
-                                "reach the host inside the timed region") if len(handles) > 1 else "none",
+            "workload": (f"BASELINE config {'2' if P == 1 else '3'}: a step = {S} frame pairs of {size_tag} per GPU as {aligns} consecutive "
+                         f"alignment(s) of {P} pair(s), {args.iterations} ICP iterations each, {args.estimator}, exact NN (tile-pruned brute "
+                         f"force); EVERY alignment uploads both u16 depth images of its pair(s) from pinned host memory and rebuilds "
+                         f"normals + tiles (nothing cached between alignments); pairs cycle through {pool_n} distinct seeds per in-flight "
+                         f"handle (seeds {pools[0].pairs[0].seed}..{pools[-1].pairs[-1].seed}), noise sigma {args.noise_sigma} z^2"),
+            "pairs_per_step_per_gpu": S, "pairs_per_launch": P, "alignments_per_step": aligns, "iterations": args.iterations,
+            "estimator": args.estimator, "distinct_pairs_per_handle": pool_n, "noise_sigma_over_z2": args.noise_sigma,
+            "h2d_bytes_per_pair": 2 * pools[0].frame_bytes,
+            "step_pipelining": (f"{n_handles} handles, each on its own HIP stream, take turns: alignment k+1.. are queued (H2D + kernels) before "
+                                f"alignment k's poses are fetched; every pose reaches the host inside the timed region") if n_handles > 1 else "none",
             "nn_mode": {0: "auto(tiles)", 1: "brute_valu", 2: "brute_mfma", 3: "tiles"}.get(args.nn_mode, str(args.nn_mode)),
             "n_src": [r["n_src"] for r in res][:4], "n_tgt": [r["n_tgt"] for r in res][:4],
-            "parallelism": (f"source rows over {world} rank(s), RCCL all-reduce of 29 doubles per iteration" if is_dense else
-                            f"pairs sharded one process per GPU x{world}, one RCCL all-gather of pose records per step"),
+            "parallelism": (f"pairs sharded one process per GPU x{world}; one RCCL all-gather (C-ABI slam3d_pose_gather_*) of the step's "
+                            f"{S} pose records per rank, overlapping the next step" if world > 1 else "1 GPU"),
         },
         "status": [r["status"] for r in res][:8],
+        "timed_region_s": elapsed,
     }
-    if latency_ms is not None:
-        out["single_step_latency_ms"] = latency_ms      # one step at a time (no overlap between steps), same inputs
-    if not is_dense:
-        # ---- roofline of the dominant kernel: one launch = one ICP iteration over the P resident pairs
-        launch_ms = statistics.mean(nn_ms) / max(args.iterations, 1)
-        alg_bytes = sum((12 + 4) * r["n_src"] + (12 + (12 if est == 0 else 0)) * r["n_tgt"] for r in res)
-        flops = sum(8.0 * r["n_src"] * r["n_tgt"] for r in res)
-        if args.nn_mode in (capi.NN_BRUTE_VALU, capi.NN_BRUTE_MFMA):
-            ach = flops / (launch_ms * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "k_nn_mfma" if args.nn_mode == capi.NN_BRUTE_MFMA else "k_nn_valu (full brute-force scan)",
-                               "bound": "mfma", "achieved": ach,
-                               "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS, "traffic": None,
-                               "launch_ms": launch_ms, "flops_per_launch": flops}
-        else:
-            ach = alg_bytes / (launch_ms * 1e-3) / 1e9
-            traffic, src, prof = committed_traffic() if (P == 1 and size_tag == "640x480" and est == 0) else (None, None, {})
-            out["roofline"] = {
-                "kernel": "k_nn_tiles_acc (exact tile-pruned NN + fused normal-equation accumulation)",
-                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                "traffic": traffic, "traffic_source": src, "launch_ms": launch_ms,
-                "launch_ms_source": "HIP events around every k_nn_tiles_acc launch, second pass over the same K steps",
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "valu_issue_floor_us": prof.get("valu_issue_floor_us"),      # from the committed PMC profile: the bound that applies
-                "valu_instructions_per_wave": prof.get("valu_instructions_per_wave"),
-                "valu_issue_frac": (prof.get("valu_issue_floor_us") / (launch_ms * 1e3)) if prof.get("valu_issue_floor_us") else None,
-                "equivalent_bruteforce_tflops": flops / (launch_ms * 1e-3) / 1e12,
-                "note": ("streaming accounting (each array once per iteration); the kernel is VALU-issue/latency bound, "
-                         "not HBM bound -- see DESIGN.md section 6; equivalent_bruteforce_tflops = flops a full scan "
-                         "would need / this launch time (exceeds the 157.3 TF peak because >99 % of the pairs are proven "
-                         "irrelevant by bounding boxes, not evaluated)"),
-            }
-        out["kernel_ms_per_step"] = {"preprocess": statistics.mean(pre_ms), "nn": statistics.mean(nn_ms),
-                                     "total": statistics.mean(tot_ms)}
-        out["nn_ms_per_iteration"] = [round(float(x), 4) for x in h.get_iteration_timings()]
-    if rank == 0:
-        if world == 1 and not is_dense and not args.no_bruteforce and args.nn_mode in (capi.NN_AUTO, capi.NN_TILES):
-            out["roofline_bruteforce"] = bruteforce_leg(capi, intr, est, d_src.data_ptr(), d_tgt.data_ptr(), local_rank)
-        if not args.no_cpu_baseline and world == 1 and not is_dense:
-            idx, _ = h.get_correspondences(0)
-            cb, parity = cpu_baseline_leg(pairs[0], src_host[0], tgt_host[0], args, res[0], idx)
-            out["cpu_baseline"] = cb
-            out["parity_vs_oracle"] = parity
+    if table is not None:
+        out["config"]["gathered_pose_records"] = len(table)
+
+    tiles = args.nn_mode in (capi.NN_AUTO, capi.NN_TILES)
+    # ---- un-overlapped latency and the event-profiled pass (rank-local; reported by rank 0)
+    st1 = Streamer([handles[0]], [pools[0]], P)
+    nl = min(32, max(4, aligns))
+    st1.run(2)
+    torch.cuda.synchronize()
+    tl = time.perf_counter()
+    st1.run(nl)
+    torch.cuda.synchronize()
+    out["single_step_latency_ms"] = 1e3 * (time.perf_counter() - tl) / nl
+    out["single_step_latency_note"] = f"one alignment ({P} pair(s)) at a time incl. H2D of both depth images, mean of {nl}"
+    prof = profiled_pass(handles[0], pools[0], P, max(4, min(args.profile_aligns, 4 * aligns)), est)
+    out["kernel_ms_per_alignment"] = {"preprocess": prof["preprocess_ms"], "nn": prof["nn_ms"], "total": prof["total_ms"]}
+    out["kernel_only_value"] = P * args.iterations / (prof["total_ms"] * 1e-3)
+    out["nn_ms_per_iteration"] = prof["per_it"]
+    if tiles:
+        out["roofline"] = tiles_roofline(prof, args.iterations, f"k_nn_tiles_acc_{size_tag}_P{P}")
+    else:
+        launch_ms = prof["nn_ms"] / max(args.iterations, 1)
+        ach = prof["flops"] / (launch_ms * 1e-3) / 1e12
+        out["roofline"] = {"kernel": "k_nn_mfma" if args.nn_mode == capi.NN_BRUTE_MFMA else "k_nn_valu (full brute-force scan)",
+                           "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
+                           "traffic": None, "launch_ms": launch_ms, "flops_per_launch": prof["flops"]}
+
+    if rank == 0 and world == 1:
+        pr0 = pools[0].pairs[0]
+        s4 = synth.backproject_numpy(pr0.depth_src, intr); t4 = synth.backproject_numpy(pr0.depth_tgt, intr)
+        if tiles and not args.no_bruteforce:
+            out["roofline_bruteforce"] = bruteforce_leg(capi, intr, est, s4, t4, local_rank)
+        if not args.no_cpu_baseline:
+            h0 = handles[0]
+            h0.frame_set_depth_host_ptr(0, pools[0].src_ptr(0)); h0.frame_set_depth_host_ptr(1, pools[0].tgt_ptr(0)); h0.set_pair(0, 0, 1)
+            h0.run(1)
+            r0 = h0.fetch_results(1)[0]
+            idx, _ = h0.get_correspondences(0)
+            out["cpu_baseline"], out["parity_vs_oracle"] = cpu_baseline_leg(pr0, s4, t4, args.iterations, est, r0, idx)
+        if want_extra:
+            extra_legs(args, torch, dist, capi, synth, local_rank, est, handles, pools, out)
         # the flat report SURVEY.md 8(d) lists, assembled from the objects above
-        rb, rf, cb_, pv = out.get("roofline_bruteforce", {}), out.get("roofline", {}), out.get("cpu_baseline", {}), out.get("parity_vs_oracle", {})
+        rb, rf, cb_, pv = out.get("roofline_bruteforce", {}), out.get("roofline", {}), out.get("cpu_baseline", {}), out.get("parity_vs_oracle") or {}
         out["survey_8d"] = {
-            "gpus": world, "pairs": (1 if is_dense else world * P), "iters": args.iterations, "wall_s": elapsed,
-            "icp_iters_per_s": value, "nn_tflops": rb.get("achieved"), "nn_frac_fp32_peak": rb.get("frac"),
+            "gpus": world, "pairs": world * S * args.steps, "iters": args.iterations, "wall_s": elapsed,
+            "icp_iters_per_s": value, "kernel_only_icp_iters_per_s": out["kernel_only_value"],
+            "nn_tflops": rb.get("achieved"), "nn_frac_fp32_peak": rb.get("frac"),
             "hbm_GBps": rf.get("achieved") if rf.get("unit") == "GB/s" else None,
             "hbm_frac_peak": rf.get("frac") if rf.get("unit") == "GB/s" else None,
-            "cpu_B_iters_per_s": cb_.get("value"), "cpu_B_1thread_iters_per_s": cb_.get("single_thread_value"), "cores": cb_.get("cores"),
+            "cpu_A_iters_per_s": cb_.get("bruteforce_value"), "cpu_B_iters_per_s": cb_.get("value"),
+            "cpu_B_1thread_iters_per_s": cb_.get("single_thread_value"), "cores": cb_.get("cores"),
             "max_rot_err": pv.get("rot_err_rad"), "max_trans_err": pv.get("trans_err_m"), "idx_mismatches": pv.get("idx_mismatches"),
         }
+    if rank == 0:
         _FINAL.append(json.dumps(out))
     for hh in handles:
         hh.close()
+    if comm is not None:
+        comm.close()
     if dist.is_initialized():
         dist.destroy_process_group()
     _emit_final()
+
+
+def extra_legs(args, torch, dist, capi, synth, local_rank, est, handles, pools, out):
+    """Same process, same box, N = 1: the other regimes next to the headline, each measured (never derived)."""
+    intr = pools[0].intr
+    # ---- (i) the former headline: ONE pair resident in HBM, re-run in place (frames re-declared each time, so the
+    # preprocessing still runs; no H2D, identical frame every time -> primed ownership map and caches)
+    pr0 = pools[0].pairs[0]
+    s4 = synth.backproject_numpy(pr0.depth_src, intr); t4 = synth.backproject_numpy(pr0.depth_tgt, intr)
+    d_s = torch.from_numpy(s4).to(f"cuda:{local_rank}"); d_t = torch.from_numpy(t4).to(f"cuda:{local_rank}")
+    n = 600
+
+    def resident(k):
+        q = []
+        for i in range(k):
+            h = handles[i % len(handles)]
+            if len(q) >= len(handles):
+                q.pop(0).fetch_results(1)
+            h.set_clouds_device(0, d_s.data_ptr(), d_t.data_ptr())
+            h.run(1)
+            q.append(h)
+        while q:
+            q.pop(0).fetch_results(1)
+    resident(30)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    resident(n)
+    torch.cuda.synchronize()
+    out["resident_same_pair_value"] = n * args.iterations / (time.perf_counter() - t0)
+    out["resident_same_pair_note"] = (f"round-1 headline regime: the same pair (seed {pr0.seed}) resident in HBM, {n} runs in place, "
+                                      f"{len(handles)} in flight, no H2D; best case, not the metric")
+    # ---- (ii) survey noise level sigma = 0.0012 z^2 (SURVEY.md 8(d)), same streaming regime
+    if abs(args.noise_sigma - 0.0012) > 1e-9:
+        pools12 = [Pool(torch, synth, [p.seed for p in pool.pairs[:8]], args.width, args.height, 0.0012) for pool in pools]
+        st = Streamer(handles, pools12, 1)
+        st.run(32)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        k = 768
+        st.run(k)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        v = k * args.iterations / dt
+        out["survey_noise"] = {"noise_sigma_over_z2": 0.0012, "value": v, "ratio_to_headline": v / out["value"], "alignments": k,
+                               "n_tgt": st.last[0]["n_tgt"], "inliers": st.last[0]["inliers"],
+                               "note": "same streaming regime (H2D + distinct pairs); with iid noise at this level the reference's 0.01 m / "
+                                       "41-of-49 planarity rule keeps far fewer target normals (DESIGN.md section 3, deviation ii)"}
+    # ---- (iii) BASELINE config 3: 64 pairs per launch sequence
+    P3 = 64
+    pool3 = Pool(torch, synth, [args.seed0 + k for k in range(P3)], args.width, args.height, args.noise_sigma)
+    p3 = capi.default_params(intr, estimator=est, iterations=args.iterations, max_batch=P3, device=local_rank)
+    h3 = [capi.IcpHandle(p3) for _ in range(2)]
+    st3 = Streamer(h3, [pool3, pool3], P3)
+    st3.run(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k3 = 24
+    res3 = st3.run(k3)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof3 = profiled_pass(h3[0], pool3, P3, 3, est)
+    c3 = {"workload": f"BASELINE config 3: {P3} pairs (seeds {args.seed0}..{args.seed0 + P3 - 1}) per launch sequence, {k3} alignments timed, "
+                      "2 in flight, H2D of all 128 depth images inside every alignment",
+          "value": k3 * P3 * args.iterations / dt, "unit": "ICP iterations/s", "ms_per_alignment": 1e3 * dt / k3,
+          "kernel_only_value": P3 * args.iterations / (prof3["total_ms"] * 1e-3),
+          "roofline": tiles_roofline(prof3, args.iterations, "k_nn_tiles_acc_640x480_P64",
+                                     "; with 64 pairs per launch the kernel runs at ~97 % VALU issue (throughput build)"),
+          "status_ok": int(sum(1 for r in res3 if r["status"] == 0))}
+    if "cpu_baseline" in out:
+        c3["cpu_baseline"] = dict(out["cpu_baseline"], sample=out["cpu_baseline"]["sample"] + " -- pairs are independent: the CPU rate per "
+                                  "pair is the same for a batch (one pair of the batch timed)")
+    out["config3"] = c3
+    for h in h3:
+        h.close()
+    # ---- (iv) BASELINE config 5 on one GPU: 1280x960 dense
+    d = dense_leg(args, torch, dist, capi, synth, 1, 0, local_rank, None, 1280, 960, 24, 3, want_cpu=("cpu_baseline" in out))
+    c5 = {"workload": "BASELINE config 5 (1-GPU leg): one 1280x960 pair per step (seeds 2000..2003), slam3d_icp_dense_run, H2D of both depth "
+                      "images inside every step, 24 steps timed",
+          "value": 24 * args.iterations / d["elapsed"], "unit": "ICP iterations/s", "ms_per_step": 1e3 * d["elapsed"] / 24,
+          "roofline": tiles_roofline(d["prof"], args.iterations, "k_nn_tiles_acc_1280x960"),
+          "n_src": d["res"]["n_src"], "n_tgt": d["res"]["n_tgt"]}
+    if "cpu" in d:
+        c5["cpu_baseline"], c5["parity_vs_oracle"] = d["cpu"], d["parity"]
+    out["config5"] = c5
+    d["handle"].close()
 
 
 if __name__ == "__main__":

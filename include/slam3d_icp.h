@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SLAM3D_ICP_ABI_VERSION 2
+#define SLAM3D_ICP_ABI_VERSION 3
 #define SLAM3D_ICP_NSUMS 29   /* 21 upper-tri AtA + 6 Atb + count + sum r^2 */
 
 /* return codes: 0 ok; >0 algorithmic (result.T == Identity); <0 usage / runtime errors */
@@ -41,7 +41,8 @@ enum {
     SLAM3D_E_HIP = -2,              /* HIP runtime error (see slam3d_last_error) */
     SLAM3D_E_NOMEM = -3,
     SLAM3D_E_NODEVICE = -4,         /* no gfx950 device visible */
-    SLAM3D_E_STATE = -5             /* call order violated (e.g. fetch before run) */
+    SLAM3D_E_STATE = -5,            /* call order violated (e.g. fetch before run) */
+    SLAM3D_E_COMM = -6              /* RCCL error / librccl not loadable (see slam3d_comm_last_error) */
 };
 
 enum { SLAM3D_EST_POINT2PLANE = 0, SLAM3D_EST_SVD = 1 };
@@ -68,6 +69,7 @@ typedef struct slam3d_icp_params {
     int32_t max_batch;              /* frame pairs resident per handle                               */
     int32_t device;                 /* HIP device ordinal                                            */
     int32_t nn_mode;                /* SLAM3D_NN_*                                                   */
+    int32_t extra_frames;           /* resident frames beyond the 2*max_batch implicit ones (keyframes) */
 } slam3d_icp_params;
 
 /* a borrowed view of an organized cloud: `data` points at width*height records of
@@ -137,8 +139,25 @@ int slam3d_icp_set_clouds_device(slam3d_icp_handle *h, int32_t slot, const void 
 /* device pointers to u16 depth images; back-projected on the device into the handle's clouds. */
 int slam3d_icp_set_depth_device(slam3d_icp_handle *h, int32_t slot, const void *d_src_depth,
                                 const void *d_tgt_depth);
-/* enqueue preprocessing (normals, compaction) + `iterations` ICP iterations for slots [0,B) on
- * `stream` (hipStream_t, NULL = the handle's own stream).  Asynchronous. */
+/* ---- resident frames ---------------------------------------------------------------------------------------
+ * A frame is the resident unit: its organized cloud plus what the two ICP roles need of it (target: normals, tile
+ * records, boxes; source: tile-major slots).  Those are built ONCE per frame and role, at the first run that uses the
+ * frame that way after it was (re)set, and reused by every later pair: the keyframe of GraphicEnd::run
+ * (src/GraphicEnd.cpp:168) stays the source of many consecutive pairs, and the loop-closure candidates of
+ * src/GraphicEnd.cpp:685-762 all align against the same new keyframe.  Frame ids: slot b's implicit frames are 2b
+ * (source) and 2b+1 (target) -- what set_clouds_* / set_depth_* above fill --, ids 2*max_batch .. 2*max_batch +
+ * extra_frames - 1 are free for the caller (keyframe store).  All frame uploads and runs of one handle are ordered on
+ * the handle's stream (or the stream given to run). */
+int slam3d_icp_frame_count(const slam3d_icp_handle *h);
+int slam3d_icp_frame_set_depth_host(slam3d_icp_handle *h, int32_t frame, const uint16_t *depth);      /* H2D + back-projection */
+int slam3d_icp_frame_set_depth_device(slam3d_icp_handle *h, int32_t frame, const void *d_depth);
+int slam3d_icp_frame_set_cloud_host(slam3d_icp_handle *h, int32_t frame, const slam3d_cloud_view *cloud);
+int slam3d_icp_frame_set_cloud_device(slam3d_icp_handle *h, int32_t frame, const void *d_xyz4);       /* borrowed */
+/* pair `slot` = (source frame, target frame); the frames must have been set before the run */
+int slam3d_icp_set_pair(slam3d_icp_handle *h, int32_t slot, int32_t src_frame, int32_t tgt_frame);
+
+/* enqueue preprocessing of the frames that need it (normals, tiles) + `iterations` ICP iterations for slots
+ * [0,B) on `stream` (hipStream_t, NULL = the handle's own stream).  Asynchronous. */
 int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_init, void *stream);
 /* wait for the run and produce results (norm / thresholds evaluated on the host). */
 int slam3d_icp_fetch_results(slam3d_icp_handle *h, int32_t B, slam3d_icp_result *out);
@@ -148,6 +167,11 @@ int slam3d_icp_fetch_results(slam3d_icp_handle *h, int32_t B, slam3d_icp_result 
 int slam3d_icp_get_correspondences(slam3d_icp_handle *h, int32_t slot, int32_t *idx, float *d2);
 /* T_trace[(iterations+1)*16], sums_trace[iterations*29] (either nullable) */
 int slam3d_icp_get_trace(slam3d_icp_handle *h, int32_t slot, double *T_trace, double *sums_trace);
+/* Correspondences of EVERY iteration ("index parity = memcmp of idx[N] per iteration"): opt-in, costs
+ * one device copy of the slot-order indices per iteration and disables the captured graph.  Takes effect from the
+ * next slam3d_icp_run; get_correspondences_at then returns iteration `it` of the last run (idx[N], pixel order). */
+int slam3d_icp_set_corr_trace(slam3d_icp_handle *h, int32_t on);
+int slam3d_icp_get_correspondences_at(slam3d_icp_handle *h, int32_t slot, int32_t it, int32_t *idx);
 /* organized float4 clouds / target normals as the device holds them (each N*4 floats, nullable) */
 int slam3d_icp_get_clouds(slam3d_icp_handle *h, int32_t slot, float *src_xyz4, float *tgt_xyz4,
                           float *tgt_nrm4);
@@ -231,11 +255,56 @@ int slam3d_icp_dense_update(slam3d_icp_handle *h, const int64_t sums[SLAM3D_ICP_
 int slam3d_icp_dense_finish(slam3d_icp_handle *h, const int64_t last_sums[SLAM3D_ICP_NSUMS],
                             slam3d_icp_result *out);
 /* the same three with the 29 sums in a caller-owned DEVICE buffer: partial writes it, the caller all-reduces it
- * in place on the same stream (RCCL), update reads it.  No host synchronisation until finish. */
+ * in place ON THE SAME STREAM, update reads it.  No host synchronisation until finish.  `stream` must be the stream
+ * the caller's collective is enqueued on: with more than one rank pass it explicitly -- NULL means the handle's own
+ * non-blocking stream, which nothing outside the library is ordered with (slam3d_icp_dense_run does all of this
+ * inside the library and is the form to use). */
 int slam3d_icp_dense_partial_device(slam3d_icp_handle *h, int64_t *d_sums, void *stream);
 int slam3d_icp_dense_update_device(slam3d_icp_handle *h, const int64_t *d_sums, void *stream);
 int slam3d_icp_dense_finish_device(slam3d_icp_handle *h, const int64_t *d_last_sums, void *stream,
                                    slam3d_icp_result *out);
+
+
+/* ---- multi-GPU: one process (or thread) per GPU, RCCL over xGMI behind the C-ABI ------------------------------
+ * SURVEY.md 8(e).  The communicator wraps ncclCommInitRank; librccl is loaded at the first slam3d_comm_* call
+ * (dlopen, reusing a copy the process already holds).  The 128-byte id is created on rank 0 and handed to the
+ * other ranks by the host program (a file, MPI, torch.distributed's store: 128 bytes, once).  Every collective
+ * below is enqueued on a HIP stream the library owns or on the handle's stream, in program order with the
+ * kernels that produce / consume its buffer -- no ordering is left to the caller. */
+typedef struct slam3d_comm slam3d_comm;
+#define SLAM3D_COMM_ID_BYTES 128
+int  slam3d_comm_get_unique_id(void *id /* SLAM3D_COMM_ID_BYTES */);
+int  slam3d_comm_init(const void *id, int32_t rank, int32_t world, int32_t device, slam3d_comm **out);
+void slam3d_comm_destroy(slam3d_comm *c);
+int  slam3d_comm_rank(const slam3d_comm *c);
+int  slam3d_comm_world(const slam3d_comm *c);
+const char *slam3d_comm_last_error(const slam3d_comm *c);
+/* contiguous block [begin, end) of `rank` when n items are dealt over `world` ranks (remainder to the lowest
+ * ranks): pairs of a batch (configs 3/4), source rows of the dense mode (config 5) */
+void slam3d_shard_range(int32_t n, int32_t world, int32_t rank, int32_t *begin, int32_t *end);
+
+/* BASELINE config 5: ONE pair whose source rows are sharded over the ranks of `comm` (NULL = one rank).  Slot 0 of
+ * every rank's handle holds the same pair.  Per iteration: NN + accumulate on the local rows -> ncclAllReduce(SUM)
+ * of the 29 int64 fixed-point sums on the handle's stream -> the same solve on every rank; no host
+ * synchronisation until the result.  Integer sums are order-free: the pose is bit-identical for any world size. */
+int slam3d_icp_dense_run(slam3d_icp_handle *h, slam3d_comm *comm, const double *T_init, slam3d_icp_result *out);
+
+/* BASELINE configs 3/4: pairs are independent, the only exchange is the gather of the SE(3) pose records. */
+typedef struct slam3d_pose_record {      /* 160 bytes */
+    double  T[16];
+    double  norm;
+    int32_t inliers, status;
+    double  rmse;
+    double  _pad;
+} slam3d_pose_record;
+/* ncclAllGather of n_local records per rank (the same n_local on every rank; pad with status = -1 records) into
+ * all[world * n_local], rank order.  submit enqueues H2D + all-gather + D2H on the communicator's own stream and
+ * returns (the exchange overlaps the caller's next kernels); collect waits for the OLDEST submitted gather.  At most
+ * two gathers may be pending. */
+int slam3d_pose_gather_submit(slam3d_comm *c, const slam3d_pose_record *local, int32_t n_local);
+int slam3d_pose_gather_collect(slam3d_comm *c, slam3d_pose_record *all);
+int slam3d_pose_gather(slam3d_comm *c, const slam3d_pose_record *local, int32_t n_local, slam3d_pose_record *all);
+void slam3d_pose_record_from_result(const slam3d_icp_result *r, slam3d_pose_record *rec);
 
 #ifdef __cplusplus
 }

@@ -652,7 +652,7 @@ int orc_icp(const float *src4, const float *tgt4, const orc_params *p, const dou
         have_sums = 1;
         if (sums_trace) memcpy(sums_trace + (size_t)it * ORC_NSUMS, sums, sizeof(sums));
         const int rc = solve_update(sums, p->estimator, T);
-        if (rc == 2) degenerate = 1;
+        if (rc == 2 || rc == 0) degenerate = 1;   /* damped, or no update at all in this iteration: never a silent OK */
         if (T_trace) memcpy(T_trace + (size_t)(it + 1) * 16, T, sizeof(T));
     }
     if (idx_out) {

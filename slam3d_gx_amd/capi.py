@@ -28,7 +28,14 @@ EXPORTED_SYMBOLS = [
     "slam3d_icp_dense_set_rows", "slam3d_icp_dense_begin", "slam3d_icp_dense_partial",
     "slam3d_icp_dense_update", "slam3d_icp_dense_finish",
     "slam3d_icp_dense_partial_device", "slam3d_icp_dense_update_device", "slam3d_icp_dense_finish_device",
+    "slam3d_icp_frame_count", "slam3d_icp_frame_set_depth_host", "slam3d_icp_frame_set_depth_device",
+    "slam3d_icp_frame_set_cloud_host", "slam3d_icp_frame_set_cloud_device", "slam3d_icp_set_pair",
+    "slam3d_icp_set_corr_trace", "slam3d_icp_get_correspondences_at",
+    "slam3d_comm_get_unique_id", "slam3d_comm_init", "slam3d_comm_destroy", "slam3d_comm_rank", "slam3d_comm_world",
+    "slam3d_comm_last_error", "slam3d_shard_range", "slam3d_icp_dense_run", "slam3d_pose_gather_submit",
+    "slam3d_pose_gather_collect", "slam3d_pose_gather", "slam3d_pose_record_from_result",
 ]
+COMM_ID_BYTES = 128
 
 
 class Params(C.Structure):
@@ -39,7 +46,7 @@ class Params(C.Structure):
         ("iterations", C.c_int32), ("max_corr_dist", C.c_double), ("estimator", C.c_int32),
         ("normal_window", C.c_int32), ("normal_min_inliers", C.c_int32), ("normal_inlier_dist", C.c_double),
         ("min_inliers", C.c_int32), ("error_threshold", C.c_double),
-        ("max_batch", C.c_int32), ("device", C.c_int32), ("nn_mode", C.c_int32),
+        ("max_batch", C.c_int32), ("device", C.c_int32), ("nn_mode", C.c_int32), ("extra_frames", C.c_int32),
     ]
 
 
@@ -58,6 +65,11 @@ class Result(C.Structure):
         return dict(T=np.array(self.T).reshape(4, 4), T_raw=np.array(self.T_raw).reshape(4, 4), norm=self.norm,
                     inliers=self.inliers, status=self.status, iterations=self.iterations, n_src=self.n_src,
                     n_tgt=self.n_tgt, rmse=self.rmse)
+
+
+class PoseRecord(C.Structure):      # slam3d_pose_record, 160 bytes
+    _fields_ = [("T", C.c_double * 16), ("norm", C.c_double), ("inliers", C.c_int32), ("status", C.c_int32),
+                ("rmse", C.c_double), ("_pad", C.c_double)]
 
 
 class Plane(C.Structure):
@@ -95,11 +107,21 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.slam3d_icp_create.argtypes = [C.POINTER(Params), C.POINTER(C.c_void_p)]
     lib.slam3d_icp_destroy.argtypes = [C.c_void_p]
     lib.slam3d_icp_destroy.restype = None
+    void_fns = ("slam3d_icp_destroy", "slam3d_icp_default_params", "slam3d_seg_default_params", "slam3d_comm_destroy",
+                "slam3d_shard_range", "slam3d_pose_record_from_result")
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("slam3d_strerror", "slam3d_last_error", "slam3d_icp_destroy", "slam3d_icp_default_params",
-                        "slam3d_seg_default_params"):
+        if name in void_fns:
+            fn.restype = None
+        elif name not in ("slam3d_strerror", "slam3d_last_error", "slam3d_comm_last_error"):
             fn.restype = C.c_int
+    lib.slam3d_comm_last_error.restype = C.c_char_p
+    lib.slam3d_comm_last_error.argtypes = [C.c_void_p]
+    lib.slam3d_comm_destroy.argtypes = [C.c_void_p]
+    lib.slam3d_comm_init.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.slam3d_comm_rank.argtypes = [C.c_void_p]
+    lib.slam3d_comm_world.argtypes = [C.c_void_p]
+    lib.slam3d_icp_frame_count.argtypes = [C.c_void_p]
     lib.slam3d_icp_default_params.restype = None
     lib.slam3d_seg_default_params.restype = None
     if path is None:
@@ -226,6 +248,41 @@ class IcpHandle:
     def set_depth_device(self, slot: int, d_src_ptr: int, d_tgt_ptr: int):
         self._check(self.lib.slam3d_icp_set_depth_device(self._h, C.c_int32(slot), C.c_void_p(d_src_ptr), C.c_void_p(d_tgt_ptr)), False)
 
+    # ---- resident frames -------------------------------------------------------------
+    def frame_count(self) -> int:
+        return int(self.lib.slam3d_icp_frame_count(self._h))
+
+    def first_free_frame(self) -> int:
+        """id of the first caller-owned frame (the 2*max_batch implicit ones come first)"""
+        return 2 * self.params.max_batch
+
+    def frame_set_depth_host(self, frame: int, depth: np.ndarray, keep: bool = True):
+        d = np.ascontiguousarray(depth, dtype=np.uint16)
+        if keep:        # the copy is asynchronous: the array must outlive it
+            self._keep_frames = getattr(self, "_keep_frames", {})
+            self._keep_frames[frame] = d
+        self._check(self.lib.slam3d_icp_frame_set_depth_host(self._h, C.c_int32(frame), _vp(d)), False)
+
+    def frame_set_depth_host_ptr(self, frame: int, ptr: int):
+        """depth image at a raw host address (pinned staging owned by the caller)"""
+        self._check(self.lib.slam3d_icp_frame_set_depth_host(self._h, C.c_int32(frame), C.c_void_p(ptr)), False)
+
+    def frame_set_depth_device(self, frame: int, d_ptr: int):
+        self._check(self.lib.slam3d_icp_frame_set_depth_device(self._h, C.c_int32(frame), C.c_void_p(d_ptr)), False)
+
+    def frame_set_cloud_host(self, frame: int, cloud: np.ndarray):
+        c = np.ascontiguousarray(cloud, dtype=np.float32)
+        self._keep_frames = getattr(self, "_keep_frames", {})
+        self._keep_frames[frame] = c
+        cv = _cloud_view(c, self.params.width, self.params.height)
+        self._check(self.lib.slam3d_icp_frame_set_cloud_host(self._h, C.c_int32(frame), C.byref(cv)), False)
+
+    def frame_set_cloud_device(self, frame: int, d_ptr: int):
+        self._check(self.lib.slam3d_icp_frame_set_cloud_device(self._h, C.c_int32(frame), C.c_void_p(d_ptr)), False)
+
+    def set_pair(self, slot: int, src_frame: int, tgt_frame: int):
+        self._check(self.lib.slam3d_icp_set_pair(self._h, C.c_int32(slot), C.c_int32(src_frame), C.c_int32(tgt_frame)), False)
+
     def run(self, B: int, T_init=None, stream: int = 0):
         Ti = None if T_init is None else np.ascontiguousarray(T_init, dtype=np.float64).reshape(B, 16)
         self._check(self.lib.slam3d_icp_run(self._h, C.c_int32(B), _vp(Ti), C.c_void_p(stream)), False)
@@ -240,6 +297,14 @@ class IcpHandle:
         idx = np.empty(self.N, dtype=np.int32); d2 = np.empty(self.N, dtype=np.float32)
         self._check(self.lib.slam3d_icp_get_correspondences(self._h, C.c_int32(slot), _vp(idx), _vp(d2)), False)
         return idx, d2
+
+    def set_corr_trace(self, on: bool = True):
+        self._check(self.lib.slam3d_icp_set_corr_trace(self._h, int(bool(on))), False)
+
+    def get_correspondences_at(self, it: int, slot: int = 0) -> np.ndarray:
+        idx = np.empty(self.N, dtype=np.int32)
+        self._check(self.lib.slam3d_icp_get_correspondences_at(self._h, C.c_int32(slot), C.c_int32(it), _vp(idx)), False)
+        return idx
 
     def get_trace(self, slot: int = 0):
         it = self.params.iterations
@@ -381,8 +446,82 @@ class IcpHandle:
         self._check(self.lib.slam3d_icp_dense_finish_device(self._h, C.c_void_p(d_sums), C.c_void_p(stream), C.byref(out)), False)
         return out.as_dict()
 
+    def dense_run(self, comm: "Optional[Comm]" = None, T_init=None) -> dict:
+        """BASELINE config 5 inside the library: rows sharded over comm's ranks, ncclAllReduce per iteration"""
+        Ti = None if T_init is None else np.ascontiguousarray(T_init, dtype=np.float64).reshape(16)
+        out = Result()
+        self._check(self.lib.slam3d_icp_dense_run(self._h, comm._c if comm is not None else None, _vp(Ti), C.byref(out)))
+        return out.as_dict()
+
     def dense_finish(self, last_sums: np.ndarray) -> dict:
         s = np.ascontiguousarray(last_sums, dtype=np.int64).reshape(NSUMS)
         out = Result()
         self._check(self.lib.slam3d_icp_dense_finish(self._h, _vp(s), C.byref(out)), False)
         return out.as_dict()
+
+
+def shard_range(n: int, world: int, rank: int):
+    b, e = C.c_int32(0), C.c_int32(0)
+    load_library().slam3d_shard_range(C.c_int32(n), C.c_int32(world), C.c_int32(rank), C.byref(b), C.byref(e))
+    return b.value, e.value
+
+
+def comm_unique_id() -> bytes:
+    """rank 0: the 128-byte id every rank passes to Comm(...)"""
+    buf = (C.c_ubyte * COMM_ID_BYTES)()
+    rc = load_library().slam3d_comm_get_unique_id(buf)
+    if rc:
+        raise Slam3dError(rc, "slam3d_comm_get_unique_id: " + load_library().slam3d_comm_last_error(None).decode())
+    return bytes(buf)
+
+
+class Comm:
+    """RAII wrapper of slam3d_comm (RCCL communicator behind the C-ABI)."""
+
+    def __init__(self, uid: bytes, rank: int, world: int, device: int):
+        self.lib = load_library()
+        assert len(uid) == COMM_ID_BYTES
+        self._c = C.c_void_p()
+        buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(uid)
+        rc = self.lib.slam3d_comm_init(buf, C.c_int32(rank), C.c_int32(world), C.c_int32(device), C.byref(self._c))
+        if rc:
+            raise Slam3dError(rc, "slam3d_comm_init: " + self.lib.slam3d_comm_last_error(None).decode())
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if getattr(self, "_c", None) is not None and self._c.value:
+            self.lib.slam3d_comm_destroy(self._c)
+            self._c = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise Slam3dError(rc, self.lib.slam3d_strerror(rc).decode() + ": " + self.lib.slam3d_comm_last_error(self._c).decode())
+
+    @staticmethod
+    def records(results) -> "C.Array":
+        rec = (PoseRecord * len(results))()
+        for i, r in enumerate(results):
+            rec[i].T[:] = np.asarray(r["T"], dtype=np.float64).reshape(16).tolist()
+            rec[i].norm = r["norm"]; rec[i].inliers = r["inliers"]; rec[i].status = r["status"]; rec[i].rmse = r.get("rmse", 0.0)
+        return rec
+
+    def gather_submit(self, results):
+        rec = self.records(results)
+        self._n = len(results)
+        self._check(self.lib.slam3d_pose_gather_submit(self._c, rec, C.c_int32(len(results))))
+
+    def gather_collect(self, n_local: Optional[int] = None):
+        n = n_local if n_local is not None else self._n
+        out = (PoseRecord * (n * self.world))()
+        self._check(self.lib.slam3d_pose_gather_collect(self._c, out))
+        return [dict(T=np.array(r.T).reshape(4, 4), norm=r.norm, inliers=r.inliers, status=r.status, rmse=r.rmse) for r in out]
+
+    def gather(self, results):
+        self.gather_submit(results)
+        return self.gather_collect(len(results))

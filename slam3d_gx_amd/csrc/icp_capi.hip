@@ -7,7 +7,9 @@
 #include "icp_kernels.hpp"
 #include "plane_seg.hpp"
 #include "voxel.hpp"
+#include "rccl_comm.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -17,25 +19,42 @@
 
 using namespace s3d;
 
+// A resident frame on the host side: which cloud the device holds for it and for which epoch of it the two roles
+// were built (frames are built once, pairs reference them).
+struct FrameHost {
+    const float4 *cloud = nullptr;     // device: the frame's slice of the handle's pool, or a borrowed pointer
+    uint64_t epoch = 0;                // bumped by every set_*; 0 = never set
+    uint64_t src_epoch = 0; int src_row0 = -1, src_row1 = -1;    // source role: built for this epoch and row shard
+    uint64_t tgt_epoch = 0; int tgt_normals = -1;                // target role: built for this epoch with/without normals
+};
+
 struct slam3d_icp_handle {
     slam3d_icp_params p;
     Geometry g;
-    int N = 0, maxB = 0;
+    int N = 0, maxB = 0, maxF = 0;
     hipStream_t stream = nullptr;
     hipStream_t run_stream = nullptr;
-    // device buffers
-    float4 *own_src = nullptr, *own_tgt = nullptr, *nrm = nullptr, *src_c = nullptr, *tgt_c = nullptr;
-    int *counts = nullptr, *ccounts = nullptr, *corr = nullptr, *flags = nullptr;
+    // ---- frames (device pools, maxF entries each)
+    float4 *f_cloud = nullptr, *f_nrm = nullptr, *f_srcT = nullptr, *f_tgtT = nullptr, *f_tbox = nullptr, *f_cbox = nullptr;
+    int *f_scount = nullptr, *f_counts = nullptr;        // [maxF][2][ntiles] per-tile counts of each role; [maxF][4] totals
+    std::vector<FrameHost> frames;
+    // ---- pairs
+    std::vector<int> pair_src, pair_tgt;                 // frame ids, -1 = unset
+    std::vector<PairPtrs> h_pairs, up_pairs;             // wanted / uploaded pair table
+    int pairs_uploaded = 0;
+    PairPtrs *d_pairs = nullptr;
+    float4 *src_c = nullptr, *tgt_c = nullptr;           // brute-force modes: raster-compacted lists per pair
+    int *ccounts = nullptr, *corr = nullptr, *flags = nullptr;
     unsigned int *ticket = nullptr;
     unsigned long long *best = nullptr;
     float *cd2 = nullptr;
     long long *acc = nullptr, *sums = nullptr;     // integer accumulators (ACC_R replicas per pair) / raw sums of dense mode
-    double *Tcur = nullptr, *trace_T = nullptr, *trace_S = nullptr, *d_Tinit = nullptr;
-    SlotPtrs *d_slots = nullptr;
+    double *Tcur = nullptr, *trace_T = nullptr, *trace_S = nullptr;
     unsigned char *d_raw = nullptr; size_t raw_bytes = 0;
     uint16_t *d_depth = nullptr;
     int *d_idx = nullptr; float *d_d2 = nullptr;
     float4 *d_scratch4 = nullptr;
+    int *corr_trace = nullptr; bool want_corr_trace = false, ran_corr_trace = false;   // [iters][maxB][nslots], opt-in
     // plane segmentation (f-2): allocated on first use
     SegState *seg_state = nullptr, *pin_seg = nullptr;
     int *seg_labels = nullptr;
@@ -50,29 +69,24 @@ struct slam3d_icp_handle {
     int *pin_vox_m = nullptr;
     // 8x8-pixel tiles (slot order of the sums; target tiles + boxes for the pruned NN)
     TileGrid tg;
-    float4 *srcT = nullptr, *tgtT = nullptr, *tbox = nullptr, *cbox = nullptr, *prevq = nullptr;
+    float4 *prevq = nullptr;
     long long *dbg = nullptr;     // per-tile NN statistics, only with SLAM3D_NN_DEBUG=1
     int *hint = nullptr;          // per source tile: target tile where the previous matches were
-    int *scount = nullptr;        // per source tile: valid source points
     int *perm = nullptr, *cost = nullptr;   // balanced tile->(block,wave) assignment and its input (cycles per tile)
     int *perm_d = nullptr;                  // the same for the throughput build (no bands, no slack)
     int nn_gx = 0, nn_gx_d = 0, xcd_bands = 1;   // k_nn_tiles_acc grid widths (multiples of 8; nn_gx with slack for the equal-cost XCD bands)
     float *tgtB = nullptr;        // BRUTE_MFMA: B-layout targets [B][4][npad]
     unsigned int *qmax2 = nullptr; int npad = 0;
     // host
-    std::vector<SlotPtrs> h_slots;
-    SlotPtrs *pin_slots = nullptr;
     double *pin_res = nullptr, *d_res = nullptr;   // host-mapped result records (RES_REC doubles per pair) and their device address
     bool res_mapped = false;                      // the last run wrote pin_res
-    double *pin_T = nullptr;      // maxB*16
     double *pin_out = nullptr;    // maxB*(16+29)
     int *pin_int = nullptr;       // maxB*5
     std::vector<hipEvent_t> ev;   // 0 start, 1 after preprocess, 2 end, then (nn0,nn1) per iteration
-    int slots_uploaded = 0;       // entries of d_slots that match pin_slots
     int dense_batch = 8;          // pairs per launch from which the throughput build of the NN kernel is used
-    hipGraphExec_t graph_exec = nullptr;   // the captured run (slam3d_icp_run without profiling)
-    int graph_B = 0, graph_rows[2] = { 0, 0 };
-    bool graph_T = false, use_graph = true;
+    hipGraphExec_t graph_exec = nullptr;   // the captured iteration loop (slam3d_icp_run without profiling)
+    int graph_B = 0;
+    bool use_graph = true;
     bool profiling = false;       // record the per-iteration events (each costs ~6 us of stream serialisation)
     bool ran_profiled = false;
     bool ran = false; int last_B = 0;
@@ -113,6 +127,7 @@ extern "C" void slam3d_icp_default_params(slam3d_icp_params *p)
     p->normal_window = 7; p->normal_min_inliers = 41; p->normal_inlier_dist = 0.01;
     p->min_inliers = 12; p->error_threshold = 1.0;
     p->max_batch = 1; p->device = 0; p->nn_mode = SLAM3D_NN_AUTO;
+    p->extra_frames = 0;
 }
 
 extern "C" const char *slam3d_strerror(int code)
@@ -121,12 +136,13 @@ extern "C" const char *slam3d_strerror(int code)
     case SLAM3D_OK: return "ok";
     case SLAM3D_TOO_FEW_INLIERS: return "too few inliers (T = Identity)";
     case SLAM3D_NORM_EXCEEDED: return "norm of transform above error_threshold (T = Identity)";
-    case SLAM3D_DEGENERATE: return "degenerate geometry: normal equations needed damping (T = Identity)";
+    case SLAM3D_DEGENERATE: return "degenerate geometry: normal equations needed damping or could not be solved (T = Identity)";
     case SLAM3D_E_INVALID: return "invalid argument";
     case SLAM3D_E_HIP: return "HIP runtime error";
     case SLAM3D_E_NOMEM: return "out of memory";
     case SLAM3D_E_NODEVICE: return "no gfx950 (MI355X) device visible; this library has no CPU fallback";
     case SLAM3D_E_STATE: return "call order violated";
+    case SLAM3D_E_COMM: return "RCCL error";
     default: return "unknown status";
     }
 }
@@ -136,11 +152,11 @@ extern "C" const char *slam3d_last_error(const slam3d_icp_handle *h) { return h 
 static void free_all(slam3d_icp_handle *h)
 {
     auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    F(h->own_src); F(h->own_tgt); F(h->nrm); F(h->src_c); F(h->tgt_c); F(h->counts); F(h->ccounts); F(h->corr);
+    F(h->f_cloud); F(h->f_nrm); F(h->f_srcT); F(h->f_tgtT); F(h->f_tbox); F(h->f_cbox); F(h->f_scount); F(h->f_counts);
+    F(h->src_c); F(h->tgt_c); F(h->ccounts); F(h->corr); F(h->ticket);
     F(h->flags); F(h->best); F(h->cd2); F(h->acc); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
-    F(h->d_Tinit); F(h->d_slots); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4);
-    F(h->srcT); F(h->tgtT); F(h->tbox); F(h->cbox); F(h->dbg); F(h->prevq); F(h->hint); F(h->scount); F(h->perm); F(h->perm_d); F(h->cost); F(h->tgtB); F(h->qmax2);
-    if (h->pin_slots) (void)hipHostFree(h->pin_slots);
+    F(h->d_pairs); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4); F(h->corr_trace);
+    F(h->dbg); F(h->prevq); F(h->hint); F(h->perm); F(h->perm_d); F(h->cost); F(h->tgtB); F(h->qmax2);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->pin_res) (void)hipHostFree(h->pin_res);
     if (h->pin_seg) (void)hipHostFree(h->pin_seg);
@@ -149,7 +165,6 @@ static void free_all(slam3d_icp_handle *h)
     F(h->seg_state); F(h->seg_labels); F(h->seg_ptrs);
     F(h->vox_mem); F(h->vox_lkey); F(h->vox_lslot); F(h->vox_m); F(h->vox_out); F(h->vox_gkey); F(h->vox_gslot); F(h->vox_hist);
     if (h->pin_vox_m) (void)hipHostFree(h->pin_vox_m);
-    if (h->pin_T) (void)hipHostFree(h->pin_T);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->pin_int) (void)hipHostFree(h->pin_int);
     for (auto e : h->ev) (void)hipEventDestroy(e);
@@ -171,7 +186,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
 {
     if (!p || !out) return SLAM3D_E_INVALID;
     *out = nullptr;
-    if (p->width <= 0 || p->height <= 0 || p->max_batch <= 0 || p->iterations < 0) return SLAM3D_E_INVALID;
+    if (p->width <= 0 || p->height <= 0 || p->max_batch <= 0 || p->iterations < 0 || p->extra_frames < 0) return SLAM3D_E_INVALID;
     if (p->normal_window < 1 || (p->normal_window & 1) == 0 || p->normal_window / 2 > NRM_RMAX) return SLAM3D_E_INVALID;
     if (p->estimator != SLAM3D_EST_POINT2PLANE && p->estimator != SLAM3D_EST_SVD) return SLAM3D_E_INVALID;
     if (p->nn_mode < SLAM3D_NN_AUTO || p->nn_mode > SLAM3D_NN_TILES) return SLAM3D_E_INVALID;
@@ -192,6 +207,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     if (hipSetDevice(p->device) != hipSuccess) { delete h; return SLAM3D_E_NODEVICE; }
     h->N = p->width * p->height;
     h->maxB = p->max_batch;
+    h->maxF = 2 * p->max_batch + p->extra_frames;
     Geometry &g = h->g;
     g.W = p->width; g.H = p->height; g.N = h->N;
     g.zmax = (float)p->z_filter;
@@ -211,21 +227,26 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     tg.nslots = tg.nchunks * CHUNK;
     const size_t BN = (size_t)h->maxB * h->N;
     const size_t BS = (size_t)h->maxB * tg.nslots;
+    const size_t F = (size_t)h->maxF;
     const bool brute = nn_mode_of(h) != SLAM3D_NN_TILES;
     const int iters = p->iterations > 0 ? p->iterations : 1;
     hipError_t e = hipSuccess;
     auto A = [&](hipError_t r) { if (e == hipSuccess && r != hipSuccess) e = r; };
     A(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    A(dalloc(h->own_src, BN)); A(dalloc(h->own_tgt, BN)); A(dalloc(h->nrm, BN));
+    // frame pools: 16 B cloud + 16 B normals + 16 B source slots + 18 B target records per pixel and frame
+    A(dalloc(h->f_cloud, F * h->N)); A(dalloc(h->f_nrm, F * h->N));
+    A(dalloc(h->f_srcT, F * tg.ntiles * TILE_SLOTS)); A(dalloc(h->f_tgtT, F * tg.ntiles * TILE_REC));
+    A(dalloc(h->f_tbox, F * tg.ntiles * 2)); A(dalloc(h->f_cbox, F * tg.ncoarse * 2));
+    A(dalloc(h->f_scount, F * 2 * tg.ntiles)); A(dalloc(h->f_counts, F * 4));
     if (brute) { A(dalloc(h->src_c, BN)); A(dalloc(h->tgt_c, BN)); A(dalloc(h->best, BS)); }
     h->npad = ((h->N + MF_TCH - 1) / MF_TCH + 1) * MF_TCH;
     if (nn_mode_of(h) == SLAM3D_NN_BRUTE_MFMA) {
         A(dalloc(h->tgtB, (size_t)h->maxB * 4 * h->npad)); A(dalloc(h->qmax2, (size_t)h->maxB));
     }
-    A(dalloc(h->counts, (size_t)h->maxB * 4)); A(dalloc(h->ccounts, (size_t)h->maxB * 4));
+    A(dalloc(h->ccounts, (size_t)h->maxB * 4)); A(dalloc(h->ticket, (size_t)h->maxB));
     A(dalloc(h->corr, BS)); A(dalloc(h->flags, (size_t)h->maxB)); A(dalloc(h->cd2, BS)); A(dalloc(h->prevq, BS));
     A(dalloc(h->acc, (size_t)h->maxB * ACC_R * ACC_STRIDE));
-    A(dalloc(h->hint, (size_t)h->maxB * tg.ntiles)); A(dalloc(h->scount, (size_t)h->maxB * tg.ntiles));
+    A(dalloc(h->hint, (size_t)h->maxB * tg.ntiles));
     A(dalloc(h->cost, (size_t)h->maxB * tg.ntiles));
     {   // grid width of the NN kernel: one wave per tile + slack (equal-cost XCD bands differ in tile count), multiple of 8
         const int slack = getenv("SLAM3D_NN_SLACK") ? atoi(getenv("SLAM3D_NN_SLACK")) : 20;     // 20 %: measured best (10: band spill, 30: more empty waves)
@@ -240,15 +261,11 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     if (getenv("SLAM3D_DENSE_BATCH")) h->dense_batch = atoi(getenv("SLAM3D_DENSE_BATCH"));
     A(dalloc(h->sums, (size_t)h->maxB * NSUMS)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
     A(dalloc(h->trace_T, (size_t)h->maxB * (iters + 1) * 16)); A(dalloc(h->trace_S, (size_t)h->maxB * iters * NSUMS));
-    A(dalloc(h->d_Tinit, (size_t)h->maxB * 16)); A(dalloc(h->d_slots, (size_t)h->maxB));
-    A(dalloc(h->d_depth, (size_t)2 * h->N)); A(dalloc(h->d_idx, (size_t)h->N)); A(dalloc(h->d_d2, (size_t)h->N));
+    A(dalloc(h->d_pairs, (size_t)h->maxB));
+    A(dalloc(h->d_depth, (size_t)h->N)); A(dalloc(h->d_idx, (size_t)h->N)); A(dalloc(h->d_d2, (size_t)h->N));
     A(dalloc(h->d_scratch4, (size_t)h->N));
-    A(dalloc(h->srcT, (size_t)h->maxB * tg.ntiles * TILE_SLOTS)); A(dalloc(h->tgtT, (size_t)h->maxB * tg.ntiles * TILE_REC));
-    A(dalloc(h->tbox, (size_t)h->maxB * tg.ntiles * 2)); A(dalloc(h->cbox, (size_t)h->maxB * tg.ncoarse * 2));
-    A(hipHostMalloc((void **)&h->pin_slots, sizeof(SlotPtrs) * h->maxB, hipHostMallocDefault));
     A(hipHostMalloc((void **)&h->pin_res, sizeof(double) * RES_REC * h->maxB, hipHostMallocMapped));
     A(hipHostGetDevicePointer((void **)&h->d_res, h->pin_res, 0));
-    A(hipHostMalloc((void **)&h->pin_T, sizeof(double) * 16 * h->maxB, hipHostMallocDefault));
     A(hipHostMalloc((void **)&h->pin_out, sizeof(double) * (16 + NSUMS) * h->maxB, hipHostMallocDefault));
     A(hipHostMalloc((void **)&h->pin_int, sizeof(int) * 5 * h->maxB, hipHostMallocDefault));
     h->ev.resize(3 + 2 * (size_t)iters);
@@ -259,16 +276,38 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
         delete h;
         return oom ? SLAM3D_E_NOMEM : SLAM3D_E_HIP;
     }
-    h->h_slots.assign(h->maxB, SlotPtrs{ nullptr, nullptr });
-    (void)hipMemsetAsync(h->counts, 0, sizeof(int) * 4 * h->maxB, h->stream);
+    h->frames.assign(h->maxF, FrameHost());
+    h->pair_src.assign(h->maxB, -1); h->pair_tgt.assign(h->maxB, -1);
+    h->h_pairs.assign(h->maxB, PairPtrs{}); h->up_pairs.assign(h->maxB, PairPtrs{});
+    (void)hipMemsetAsync(h->f_counts, 0, sizeof(int) * 4 * F, h->stream);
     (void)hipMemsetAsync(h->perm_d, 0xFF, sizeof(int) * (size_t)h->maxB * h->nn_gx_d * NN_WAVES, h->stream);
     (void)hipMemsetAsync(h->perm, 0xFF, sizeof(int) * (size_t)h->maxB * h->nn_gx * NN_WAVES, h->stream);   // -1: interleaved default
+    (void)hipMemsetAsync(h->hint, 0xFF, sizeof(int) * (size_t)h->maxB * tg.ntiles, h->stream);
     (void)hipMemsetAsync(h->acc, 0, sizeof(long long) * (size_t)h->maxB * ACC_R * ACC_STRIDE, h->stream);   // k_solve_acc re-zeroes after every launch
     *out = h;
     return SLAM3D_OK;
 }
 
-// ------------------------------------------------------------------------------ inputs
+// ------------------------------------------------------------------------------ frames
+static inline bool slot_ok(const slam3d_icp_handle *h, int slot) { return h && slot >= 0 && slot < h->maxB; }
+static inline bool frame_ok(const slam3d_icp_handle *h, int f) { return h && f >= 0 && f < h->maxF; }
+static inline float4 *frame_pool_cloud(slam3d_icp_handle *h, int f) { return h->f_cloud + (size_t)f * h->N; }
+
+// Frame uploads run on the handle's stream.  A run that was queued on a caller stream is not ordered with it, so the
+// handle's stream first waits for that run's end event: a frame is never overwritten under a run that still reads it.
+static int order_after_foreign_run(slam3d_icp_handle *h)
+{
+    if (h->ran && h->run_stream && h->run_stream != h->stream) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev[2], 0));
+    return SLAM3D_OK;
+}
+
+static void frame_touch(slam3d_icp_handle *h, int f, const float4 *cloud)
+{
+    FrameHost &fr = h->frames[f];
+    fr.cloud = cloud;
+    fr.epoch += 1;                 // both roles are stale now
+}
+
 static int upload_cloud(slam3d_icp_handle *h, const slam3d_cloud_view *v, float4 *dst)
 {
     if (!v || !v->data || v->width != h->p.width || v->height != h->p.height || v->stride_bytes < 12) return SLAM3D_E_INVALID;
@@ -291,22 +330,6 @@ static int upload_cloud(slam3d_icp_handle *h, const slam3d_cloud_view *v, float4
     return SLAM3D_OK;
 }
 
-static inline bool slot_ok(const slam3d_icp_handle *h, int slot) { return h && slot >= 0 && slot < h->maxB; }
-
-extern "C" int slam3d_icp_set_clouds_host(slam3d_icp_handle *h, int32_t slot, const slam3d_cloud_view *src,
-                                          const slam3d_cloud_view *tgt)
-{
-    if (!slot_ok(h, slot)) return SLAM3D_E_INVALID;
-    HIPCHK(h, hipSetDevice(h->p.device));
-    float4 *ds = h->own_src + (size_t)slot * h->N, *dt = h->own_tgt + (size_t)slot * h->N;
-    int rc = upload_cloud(h, src, ds);
-    if (rc) return rc;
-    rc = upload_cloud(h, tgt, dt);
-    if (rc) return rc;
-    h->h_slots[slot] = SlotPtrs{ ds, dt };
-    return SLAM3D_OK;
-}
-
 static int backproject_dev(slam3d_icp_handle *h, const uint16_t *d_depth, float4 *dst)
 {
     hipLaunchKernelGGL(k_backproject, dim3((h->N + 255) / 256), dim3(256), 0, h->stream, d_depth, dst, h->g);
@@ -314,40 +337,98 @@ static int backproject_dev(slam3d_icp_handle *h, const uint16_t *d_depth, float4
     return SLAM3D_OK;
 }
 
+extern "C" int slam3d_icp_frame_count(const slam3d_icp_handle *h) { return h ? h->maxF : 0; }
+
+extern "C" int slam3d_icp_frame_set_cloud_host(slam3d_icp_handle *h, int32_t frame, const slam3d_cloud_view *cloud)
+{
+    if (!frame_ok(h, frame)) return SLAM3D_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    if (order_after_foreign_run(h)) return SLAM3D_E_HIP;
+    const int rc = upload_cloud(h, cloud, frame_pool_cloud(h, frame));
+    if (rc) return rc;
+    frame_touch(h, frame, frame_pool_cloud(h, frame));
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_frame_set_cloud_device(slam3d_icp_handle *h, int32_t frame, const void *d_xyz4)
+{
+    if (!frame_ok(h, frame) || !d_xyz4) return SLAM3D_E_INVALID;
+    frame_touch(h, frame, static_cast<const float4 *>(d_xyz4));
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_frame_set_depth_host(slam3d_icp_handle *h, int32_t frame, const uint16_t *depth)
+{
+    if (!frame_ok(h, frame) || !depth) return SLAM3D_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    if (order_after_foreign_run(h)) return SLAM3D_E_HIP;
+    // one staging image on the handle's stream: the copy of frame k+1 is ordered behind the back-projection of frame k
+    HIPCHK(h, hipMemcpyAsync(h->d_depth, depth, sizeof(uint16_t) * h->N, hipMemcpyHostToDevice, h->stream));
+    const int rc = backproject_dev(h, h->d_depth, frame_pool_cloud(h, frame));
+    if (rc) return rc;
+    frame_touch(h, frame, frame_pool_cloud(h, frame));
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_frame_set_depth_device(slam3d_icp_handle *h, int32_t frame, const void *d_depth)
+{
+    if (!frame_ok(h, frame) || !d_depth) return SLAM3D_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    if (order_after_foreign_run(h)) return SLAM3D_E_HIP;
+    const int rc = backproject_dev(h, static_cast<const uint16_t *>(d_depth), frame_pool_cloud(h, frame));
+    if (rc) return rc;
+    frame_touch(h, frame, frame_pool_cloud(h, frame));
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_set_pair(slam3d_icp_handle *h, int32_t slot, int32_t src_frame, int32_t tgt_frame)
+{
+    if (!slot_ok(h, slot) || !frame_ok(h, src_frame) || !frame_ok(h, tgt_frame)) return SLAM3D_E_INVALID;
+    h->pair_src[slot] = src_frame; h->pair_tgt[slot] = tgt_frame;
+    return SLAM3D_OK;
+}
+
+// ---- the slot-wise input calls: slot b owns the implicit frames 2b (source) and 2b + 1 (target)
+extern "C" int slam3d_icp_set_clouds_host(slam3d_icp_handle *h, int32_t slot, const slam3d_cloud_view *src,
+                                          const slam3d_cloud_view *tgt)
+{
+    if (!slot_ok(h, slot)) return SLAM3D_E_INVALID;
+    int rc = slam3d_icp_frame_set_cloud_host(h, 2 * slot, src);
+    if (rc) return rc;
+    rc = slam3d_icp_frame_set_cloud_host(h, 2 * slot + 1, tgt);
+    if (rc) return rc;
+    return slam3d_icp_set_pair(h, slot, 2 * slot, 2 * slot + 1);
+}
+
 extern "C" int slam3d_icp_set_depth_host(slam3d_icp_handle *h, int32_t slot, const uint16_t *src_depth,
                                          const uint16_t *tgt_depth)
 {
     if (!slot_ok(h, slot) || !src_depth || !tgt_depth) return SLAM3D_E_INVALID;
-    HIPCHK(h, hipSetDevice(h->p.device));
-    float4 *ds = h->own_src + (size_t)slot * h->N, *dt = h->own_tgt + (size_t)slot * h->N;
-    HIPCHK(h, hipMemcpyAsync(h->d_depth, src_depth, sizeof(uint16_t) * h->N, hipMemcpyHostToDevice, h->stream));
-    int rc = backproject_dev(h, h->d_depth, ds);
+    int rc = slam3d_icp_frame_set_depth_host(h, 2 * slot, src_depth);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->d_depth + h->N, tgt_depth, sizeof(uint16_t) * h->N, hipMemcpyHostToDevice, h->stream));
-    rc = backproject_dev(h, h->d_depth + h->N, dt);
+    rc = slam3d_icp_frame_set_depth_host(h, 2 * slot + 1, tgt_depth);
     if (rc) return rc;
-    h->h_slots[slot] = SlotPtrs{ ds, dt };
-    return SLAM3D_OK;
+    return slam3d_icp_set_pair(h, slot, 2 * slot, 2 * slot + 1);
 }
 
 extern "C" int slam3d_icp_set_clouds_device(slam3d_icp_handle *h, int32_t slot, const void *d_src_xyz4, const void *d_tgt_xyz4)
 {
     if (!slot_ok(h, slot) || !d_src_xyz4 || !d_tgt_xyz4) return SLAM3D_E_INVALID;
-    h->h_slots[slot] = SlotPtrs{ (const float4 *)d_src_xyz4, (const float4 *)d_tgt_xyz4 };
-    return SLAM3D_OK;
+    int rc = slam3d_icp_frame_set_cloud_device(h, 2 * slot, d_src_xyz4);
+    if (rc) return rc;
+    rc = slam3d_icp_frame_set_cloud_device(h, 2 * slot + 1, d_tgt_xyz4);
+    if (rc) return rc;
+    return slam3d_icp_set_pair(h, slot, 2 * slot, 2 * slot + 1);
 }
 
 extern "C" int slam3d_icp_set_depth_device(slam3d_icp_handle *h, int32_t slot, const void *d_src_depth, const void *d_tgt_depth)
 {
     if (!slot_ok(h, slot) || !d_src_depth || !d_tgt_depth) return SLAM3D_E_INVALID;
-    HIPCHK(h, hipSetDevice(h->p.device));
-    float4 *ds = h->own_src + (size_t)slot * h->N, *dt = h->own_tgt + (size_t)slot * h->N;
-    int rc = backproject_dev(h, (const uint16_t *)d_src_depth, ds);
+    int rc = slam3d_icp_frame_set_depth_device(h, 2 * slot, d_src_depth);
     if (rc) return rc;
-    rc = backproject_dev(h, (const uint16_t *)d_tgt_depth, dt);
+    rc = slam3d_icp_frame_set_depth_device(h, 2 * slot + 1, d_tgt_depth);
     if (rc) return rc;
-    h->h_slots[slot] = SlotPtrs{ ds, dt };
-    return SLAM3D_OK;
+    return slam3d_icp_set_pair(h, slot, 2 * slot, 2 * slot + 1);
 }
 
 // ------------------------------------------------------------------------------ run
@@ -361,52 +442,93 @@ static int pick_nsplit(const slam3d_icp_handle *h, int B)
     return ns;
 }
 
-// host-side staging of a run: the slot table (kernel arguments, only when it changed) and T_init into pinned memory
-static int stage_inputs(slam3d_icp_handle *h, int B, const double *T_init, hipStream_t s)
-{
-    bool same = B <= h->slots_uploaded;                 // the device copy of the slot table is still current
-    for (int b = 0; b < B; ++b) {
-        if (!h->h_slots[b].src || !h->h_slots[b].tgt) return SLAM3D_E_STATE;
-        same = same && memcmp(&h->pin_slots[b], &h->h_slots[b], sizeof(SlotPtrs)) == 0;
-    }
-    if (!same) {                                        // by kernel argument: nothing in flight reads host memory
-        for (int b0 = 0; b0 < B; b0 += SLOT_ARGS) {
-            SlotArgs a;
-            const int n = B - b0 < SLOT_ARGS ? B - b0 : SLOT_ARGS;
-            for (int k = 0; k < n; ++k) a.p[k] = h->pin_slots[b0 + k] = h->h_slots[b0 + k];
-            hipLaunchKernelGGL(k_set_slots, dim3(1), dim3(64), 0, s, h->d_slots + b0, a, n);
-        }
-        h->slots_uploaded = B;
-    }
-    if (T_init) memcpy(h->pin_T, T_init, sizeof(double) * 16 * B);
-    HIPCHK(h, hipGetLastError());
-    return SLAM3D_OK;
-}
-
-// device-side part of the preprocessing (everything here has launch-invariant arguments: it can live in a graph)
-static int enqueue_preprocess_dev(slam3d_icp_handle *h, int B, bool has_T, hipStream_t s)
+// Preprocessing of a run: every (frame, role) the pairs [0,B) use and that is stale is rebuilt ONCE (normals, tile
+// records, boxes / source slots), the pair table is refreshed when it changed (kernel arguments: nothing in flight
+// reads host memory), and the pairs' iteration state is reset (T_init by kernel argument too).
+static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init, hipStream_t s)
 {
     const Geometry &g = h->g;
-    const double *dT = nullptr;
-    if (has_T) {
-        HIPCHK(h, hipMemcpyAsync(h->d_Tinit, h->pin_T, sizeof(double) * 16 * B, hipMemcpyHostToDevice, s));
-        dT = h->d_Tinit;
-    }
-    const bool brute = nn_mode_of(h) != SLAM3D_NN_TILES;
     const TileGrid &tg = h->tg;
     const int use_normals = h->p.estimator == SLAM3D_EST_POINT2PLANE ? 1 : 0;
-    if (use_normals) {
-        dim3 grid((g.W + NRM_BX - 1) / NRM_BX, (g.H + NRM_BY - 1) / NRM_BY, B);
-        if (g.win_r == 3) hipLaunchKernelGGL(k_normals<3>, grid, dim3(NRM_BX, NRM_BY), 0, s, h->d_slots, h->nrm, g);
-        else hipLaunchKernelGGL(k_normals<0>, grid, dim3(NRM_BX, NRM_BY), 0, s, h->d_slots, h->nrm, g);
+    std::vector<FrameTask> tasks, ntasks;
+    auto task_of = [&](int f, int role) {
+        FrameTask t;
+        t.cloud = h->frames[f].cloud;
+        t.nrm = h->f_nrm + (size_t)f * h->N;
+        t.tiles = role == 0 ? h->f_srcT + (size_t)f * tg.ntiles * TILE_SLOTS : h->f_tgtT + (size_t)f * tg.ntiles * TILE_REC;
+        t.tbox = h->f_tbox + (size_t)f * tg.ntiles * 2;
+        t.cbox = h->f_cbox + (size_t)f * tg.ncoarse * 2;
+        t.scount = h->f_scount + ((size_t)f * 2 + role) * tg.ntiles;
+        t.counts = h->f_counts + (size_t)f * 4;
+        t.role = role; t.row0 = h->row0; t.row1 = h->row1; t.use_normals = use_normals;
+        return t;
+    };
+    for (int b = 0; b < B; ++b) {
+        const int fs = h->pair_src[b], ft = h->pair_tgt[b];
+        if (fs < 0 || ft < 0 || h->frames[fs].epoch == 0 || h->frames[ft].epoch == 0) return SLAM3D_E_STATE;
+        FrameHost &S = h->frames[fs], &T = h->frames[ft];
+        if (S.src_epoch != S.epoch || S.src_row0 != h->row0 || S.src_row1 != h->row1) {
+            tasks.push_back(task_of(fs, 0));
+            S.src_epoch = S.epoch; S.src_row0 = h->row0; S.src_row1 = h->row1;
+        }
+        if (T.tgt_epoch != T.epoch || T.tgt_normals != use_normals) {
+            if (use_normals) ntasks.push_back(task_of(ft, 1));
+            tasks.push_back(task_of(ft, 1));
+            T.tgt_epoch = T.epoch; T.tgt_normals = use_normals;
+        }
+        PairPtrs &pp = h->h_pairs[b];
+        pp.src = S.cloud; pp.tgt = T.cloud;
+        pp.nrm = h->f_nrm + (size_t)ft * h->N;
+        pp.srcT = h->f_srcT + (size_t)fs * tg.ntiles * TILE_SLOTS;
+        pp.tgtT = h->f_tgtT + (size_t)ft * tg.ntiles * TILE_REC;
+        pp.tbox = h->f_tbox + (size_t)ft * tg.ntiles * 2;
+        pp.cbox = h->f_cbox + (size_t)ft * tg.ncoarse * 2;
+        pp.src_counts = h->f_counts + (size_t)fs * 4;
+        pp.tgt_counts = h->f_counts + (size_t)ft * 4;
     }
-    hipLaunchKernelGGL(k_build_tiles, dim3(tg.ntiles, 2, B), dim3(64), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT, h->tbox,
-                       h->scount, h->corr, h->prevq, h->hint, h->counts, g, tg, use_normals, h->row0, h->row1,
-                       dT, h->Tcur, h->trace_T, h->flags, h->acc, h->p.iterations > 0 ? h->p.iterations : 1);
-    hipLaunchKernelGGL(k_coarse_boxes, dim3(tg.ncoarse, B), dim3(64), 0, s, h->tbox, h->scount, h->cbox, h->counts, tg);
-    if (brute) {
+    for (size_t k0 = 0; k0 < ntasks.size(); k0 += FRAME_ARGS) {
+        FrameTasks a;
+        const int n = (int)std::min<size_t>(FRAME_ARGS, ntasks.size() - k0);
+        for (int k = 0; k < n; ++k) a.t[k] = ntasks[k0 + k];
+        dim3 grid((g.W + NRM_BX - 1) / NRM_BX, (g.H + NRM_BY - 1) / NRM_BY, n);
+        if (g.win_r == 3) hipLaunchKernelGGL(k_normals<3>, grid, dim3(NRM_BX, NRM_BY), 0, s, a, g);
+        else hipLaunchKernelGGL(k_normals<0>, grid, dim3(NRM_BX, NRM_BY), 0, s, a, g);
+    }
+    for (size_t k0 = 0; k0 < tasks.size(); k0 += FRAME_ARGS) {
+        FrameTasks a;
+        const int n = (int)std::min<size_t>(FRAME_ARGS, tasks.size() - k0);
+        for (int k = 0; k < n; ++k) a.t[k] = tasks[k0 + k];
+        hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(64), 0, s, a, n);
+        hipLaunchKernelGGL(k_frame_tiles, dim3(tg.ntiles, n), dim3(64), 0, s, a, g, tg);
+        hipLaunchKernelGGL(k_coarse_boxes, dim3(tg.ncoarse, n), dim3(64), 0, s, a, tg);
+    }
+    bool same = B <= h->pairs_uploaded;                 // the device copy of the pair table is still current
+    for (int b = 0; b < B && same; ++b) same = memcmp(&h->up_pairs[b], &h->h_pairs[b], sizeof(PairPtrs)) == 0;
+    if (!same) {
+        for (int b0 = 0; b0 < B; b0 += PAIR_ARGS) {
+            PairArgs a;
+            const int n = B - b0 < PAIR_ARGS ? B - b0 : PAIR_ARGS;
+            for (int k = 0; k < n; ++k) a.p[k] = h->up_pairs[b0 + k] = h->h_pairs[b0 + k];
+            hipLaunchKernelGGL(k_set_pairs, dim3(1), dim3(64), 0, s, h->d_pairs + b0, a, n);
+        }
+        h->pairs_uploaded = B;
+    }
+    const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
+    if (T_init) {
+        for (int b0 = 0; b0 < B; b0 += TINIT_ARGS) {
+            TinitArgs ti;
+            const int n = B - b0 < TINIT_ARGS ? B - b0 : TINIT_ARGS;
+            memcpy(ti.T, T_init + (size_t)b0 * 16, sizeof(double) * 16 * n);
+            hipLaunchKernelGGL(k_pair_init, dim3(n), dim3(64), 0, s, ti, 1, b0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters);
+        }
+    } else {
+        TinitArgs ti;
+        memset(&ti, 0, sizeof ti);
+        hipLaunchKernelGGL(k_pair_init, dim3(B), dim3(64), 0, s, ti, 0, 0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters);
+    }
+    if (nn_mode_of(h) != SLAM3D_NN_TILES) {
         HIPCHK(h, hipMemsetAsync(h->best, 0xFF, sizeof(unsigned long long) * (size_t)B * tg.nslots, s));
-        hipLaunchKernelGGL(k_compact, dim3(2, B), dim3(1024), 0, s, h->d_slots, h->nrm, h->src_c, h->tgt_c, h->ccounts, g, tg,
+        hipLaunchKernelGGL(k_compact, dim3(2, B), dim3(1024), 0, s, h->d_pairs, h->src_c, h->tgt_c, h->ccounts, g, tg,
                            use_normals, h->row0, h->row1);
         if (nn_mode_of(h) == SLAM3D_NN_BRUTE_MFMA) {
             HIPCHK(h, hipMemsetAsync(h->qmax2, 0, sizeof(unsigned int) * (size_t)B, s));
@@ -418,19 +540,13 @@ static int enqueue_preprocess_dev(slam3d_icp_handle *h, int B, bool has_T, hipSt
     return SLAM3D_OK;
 }
 
-static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init, hipStream_t s)
-{
-    const int rc = stage_inputs(h, B, T_init, s);
-    return rc ? rc : enqueue_preprocess_dev(h, B, T_init != nullptr, s);
-}
-
 // one iteration's data-parallel part: NN search + normal-equation chunks, then the 29-sum reduction
 // (+ solve and SE(3) update when do_solve)
 #ifndef S3D_COOP_WPE
 #define S3D_COOP_WPE 8
 #endif
 static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int it, int do_solve,
-                             long long *raw_out = nullptr, int balance = 0)
+                             long long *raw_out = nullptr, int balance = 0, int first = 0)
 {
     const TileGrid &tg = h->tg;
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
@@ -439,13 +555,13 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         // few pairs: cooperative blocks (latency bound); from 8 pairs per launch: every wave on its
         // own, 8 waves per SIMD (throughput bound); three staged tile records per wave in both
         const bool dense = B >= h->dense_batch;
-        const int write_out = (!do_solve || it == iters - 1) ? 1 : 0;      // corr / cd2: only the last iteration's are read
+        const int write_out = (!do_solve || it == iters - 1 || h->want_corr_trace) ? 1 : 0;      // corr / cd2: only the last iteration's are read
         int *perm = dense ? h->perm_d : h->perm;
         const int gx = dense ? h->nn_gx_d : h->nn_gx;
         // four instances: {throughput, cooperative} x {production, instrumented (SLAM3D_NN_DEBUG: per-tile clocks and counters)}
         auto launch = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_slots, h->nrm, h->srcT, h->tgtT,
-                               h->tbox, h->cbox, h->Tcur, h->corr, h->cd2, h->prevq, h->hint, perm, h->cost, h->acc, h->g, tg, h->dbg, write_out);
+            hipLaunchKernelGGL(kern, dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_pairs, h->Tcur, h->corr, h->cd2, h->prevq, h->hint,
+                               perm, h->cost, h->acc, h->g, tg, h->dbg, write_out, first);
         };
         if (dense) { if (h->dbg) launch(k_nn_tiles_acc<3, 8, false, true>); else launch(k_nn_tiles_acc<3, 8, false, false>); }
         else       { if (h->dbg) launch(k_nn_tiles_acc<3, S3D_COOP_WPE, true, true>);  else launch(k_nn_tiles_acc<3, S3D_COOP_WPE, true, false>); }
@@ -458,9 +574,9 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
             int msplit = (8 * 1024 + (h->N / MF_Q) * B - 1) / ((h->N / MF_Q) * B);
             if (msplit < 1) msplit = 1;
             if (msplit > 16) msplit = 16;
-            hipLaunchKernelGGL(k_nn_mfma, dim3((h->N + MF_Q - 1) / MF_Q, msplit, B), dim3(64), 0, s, h->d_slots, h->nrm, h->src_c, h->tgt_c,
+            hipLaunchKernelGGL(k_nn_mfma, dim3((h->N + MF_Q - 1) / MF_Q, msplit, B), dim3(64), 0, s, h->d_pairs, h->src_c, h->tgt_c,
                                h->tgtB, h->qmax2, h->ccounts, h->prevq, h->Tcur, h->best, h->g, tg, h->npad, 0.5f * h->g.zmax,
-                               msplit);
+                               msplit, first);
         } else {
             const int nsplit = pick_nsplit(h, B);
             const int qblocks = (h->N + NN_BLOCK * NN_QPT - 1) / (NN_BLOCK * NN_QPT);
@@ -468,10 +584,13 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
                                h->best, h->N, tg.nslots, nsplit);
         }
         if (e1) HIPCHK(h, hipEventRecord(e1, s));
-        hipLaunchKernelGGL(k_accumulate, dim3(tg.nchunks, B), dim3(CHUNK), 0, s, h->d_slots, h->nrm, h->srcT, h->Tcur, h->best,
+        hipLaunchKernelGGL(k_accumulate, dim3(tg.nchunks, B), dim3(CHUNK), 0, s, h->d_pairs, h->Tcur, h->best,
                            h->corr, h->cd2, h->prevq, h->acc, h->g, tg);
     }
-    hipLaunchKernelGGL(k_solve_acc, dim3(B), dim3(64), 0, s, h->acc, raw_out, h->Tcur, h->trace_T, h->trace_S, h->flags, h->counts,
+    if (h->want_corr_trace && do_solve)          // this iteration's slot-order indices (index parity per iteration)
+        HIPCHK(h, hipMemcpyAsync(h->corr_trace + (size_t)it * h->maxB * tg.nslots, h->corr, sizeof(int) * (size_t)B * tg.nslots,
+                                 hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_solve_acc, dim3(B), dim3(64), 0, s, h->acc, raw_out, h->Tcur, h->trace_T, h->trace_S, h->flags, h->d_pairs,
                        do_solve ? h->d_res : nullptr, it, iters, h->p.estimator, do_solve);
     HIPCHK(h, hipGetLastError());
     return SLAM3D_OK;
@@ -488,34 +607,34 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
     }
     HIPCHK(h, hipEventRecord(h->ev[0], s));
     const int iters = h->p.iterations;
-    int rc;
-    if (!h->profiling && h->use_graph) {
-        // The whole run (preprocessing + iterations x {NN, solve}) has launch-invariant arguments: it is captured once
-        // per (B, T_init given) into a HIP graph and replayed with one hipGraphLaunch; only the slot table (kernel
-        // arguments) and T_init (pinned staging) change from run to run and stay outside.
-        rc = stage_inputs(h, B, T_init, s);
-        if (rc) return rc;
-        const bool has_T = T_init != nullptr;
-        if (!h->graph_exec || h->graph_B != B || h->graph_T != has_T || h->graph_rows[0] != h->row0 || h->graph_rows[1] != h->row1) {
+    if (h->want_corr_trace && !h->corr_trace) {
+        const size_t n = (size_t)(iters > 0 ? iters : 1) * h->maxB * h->tg.nslots;
+        if (hipMalloc((void **)&h->corr_trace, sizeof(int) * n) != hipSuccess) { (void)hipGetLastError(); return SLAM3D_E_NOMEM; }
+    }
+    int rc = enqueue_preprocess(h, B, T_init, s);
+    if (rc) return rc;
+    if (iters > 0 && !h->profiling && h->use_graph && !h->want_corr_trace) {
+        // The iteration loop (iterations x {NN, solve}) has launch-invariant arguments: it is captured once per B into
+        // a HIP graph and replayed with one hipGraphLaunch.  What changes from run to run -- which frames need their
+        // preprocessing, the pair table, T_init -- stays outside (a handful of direct launches above).
+        if (!h->graph_exec || h->graph_B != B) {
             if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
             hipGraph_t graph = nullptr;
             HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            rc = enqueue_preprocess_dev(h, B, has_T, s);
-            for (int it = 0; it < iters && !rc; ++it) rc = enqueue_iteration(h, B, s, nullptr, nullptr, it, 1);
+            for (int it = 0; it < iters && !rc; ++it) rc = enqueue_iteration(h, B, s, nullptr, nullptr, it, 1, nullptr, 0, it == 0);
             const hipError_t ce = hipStreamEndCapture(s, &graph);
             if (rc || ce != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); (void)hipGetLastError(); return rc ? rc : SLAM3D_E_HIP; }
             const hipError_t ie = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             if (ie != hipSuccess) { h->graph_exec = nullptr; (void)hipGetLastError(); return SLAM3D_E_HIP; }
-            h->graph_B = B; h->graph_T = has_T; h->graph_rows[0] = h->row0; h->graph_rows[1] = h->row1;
+            h->graph_B = B;
         }
         HIPCHK(h, hipGraphLaunch(h->graph_exec, s));
     } else {
-        rc = enqueue_preprocess(h, B, T_init, s);
-        if (rc) return rc;
         if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[1], s));
         for (int it = 0; it < iters; ++it) {
-            rc = enqueue_iteration(h, B, s, h->profiling ? h->ev[3 + 2 * it] : nullptr, h->profiling ? h->ev[4 + 2 * it] : nullptr, it, 1);
+            rc = enqueue_iteration(h, B, s, h->profiling ? h->ev[3 + 2 * it] : nullptr, h->profiling ? h->ev[4 + 2 * it] : nullptr, it, 1,
+                                   nullptr, 0, it == 0);
             if (rc) return rc;
         }
     }
@@ -524,6 +643,7 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
     h->run_stream = s;
     h->ran = true;
     h->ran_profiled = h->profiling;
+    h->ran_corr_trace = h->want_corr_trace;
     h->res_mapped = iters > 0;
     h->last_B = B;
     return SLAM3D_OK;
@@ -533,6 +653,13 @@ extern "C" int slam3d_icp_set_profiling(slam3d_icp_handle *h, int32_t on)
 {
     if (!h) return SLAM3D_E_INVALID;
     h->profiling = on != 0;
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_set_corr_trace(slam3d_icp_handle *h, int32_t on)
+{
+    if (!h) return SLAM3D_E_INVALID;
+    h->want_corr_trace = on != 0;
     return SLAM3D_OK;
 }
 
@@ -560,13 +687,17 @@ static void finish_result(const slam3d_icp_params &p, const double *T, const dou
     if (r->status != SLAM3D_OK) identity16(r->T);
 }
 
+static int pair_counts(slam3d_icp_handle *h, int b, int which /* 0 n_src, 1 n_tgt */)
+{
+    return h->pin_int[4 * b + which];
+}
+
 extern "C" int slam3d_icp_fetch_results(slam3d_icp_handle *h, int32_t B, slam3d_icp_result *out)
 {
     if (!h || !out || B <= 0 || B > h->maxB) return SLAM3D_E_INVALID;
     if (!h->ran || B > h->last_B) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = h->run_stream;
-    const int iters = h->p.iterations;
     if (h->res_mapped) {        // the final k_solve_acc wrote the records into host-mapped memory
         // wait for THIS run only (its end event), not for whatever else the caller queued on the stream since:
         // two handles can then alternate on one stream and the host never leaves the GPU idle between runs
@@ -578,17 +709,15 @@ extern "C" int slam3d_icp_fetch_results(slam3d_icp_handle *h, int32_t B, slam3d_
         return SLAM3D_OK;
     }
     HIPCHK(h, hipMemcpyAsync(h->pin_out, h->Tcur, sizeof(double) * 16 * B, hipMemcpyDeviceToHost, s));
-    double *ps = h->pin_out + 16 * (size_t)h->maxB;
-    if (iters > 0)
-        for (int b = 0; b < B; ++b)
-            HIPCHK(h, hipMemcpyAsync(ps + (size_t)b * NSUMS, h->trace_S + ((size_t)b * iters + (iters - 1)) * NSUMS,
-                                     sizeof(double) * NSUMS, hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipMemcpyAsync(h->pin_int, h->counts, sizeof(int) * 4 * B, hipMemcpyDeviceToHost, s));
+    for (int b = 0; b < B; ++b) {
+        HIPCHK(h, hipMemcpyAsync(h->pin_int + 4 * b, h->f_counts + (size_t)h->pair_src[b] * 4, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(h->pin_int + 4 * b + 1, h->f_counts + (size_t)h->pair_tgt[b] * 4 + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    }
     HIPCHK(h, hipMemcpyAsync(h->pin_int + 4 * (size_t)h->maxB, h->flags, sizeof(int) * B, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     for (int b = 0; b < B; ++b)
-        finish_result(h->p, h->pin_out + 16 * (size_t)b, iters > 0 ? ps + (size_t)b * NSUMS : nullptr,
-                      h->pin_int[4 * (size_t)h->maxB + b], h->pin_int[4 * b], h->pin_int[4 * b + 1], out + b);
+        finish_result(h->p, h->pin_out + 16 * (size_t)b, nullptr, h->pin_int[4 * (size_t)h->maxB + b], pair_counts(h, b, 0),
+                      pair_counts(h, b, 1), out + b);
     return SLAM3D_OK;
 }
 
@@ -637,22 +766,35 @@ extern "C" int slam3d_icp_align_depth_batch(slam3d_icp_handle *h, int32_t B, con
 }
 
 // ------------------------------------------------------------------------------ introspection
-extern "C" int slam3d_icp_get_correspondences(slam3d_icp_handle *h, int32_t slot, int32_t *idx, float *d2)
+static int corr_to_host(slam3d_icp_handle *h, int slot, const int *corr_slot, const float *cd2_slot, int32_t *idx, float *d2)
 {
-    if (!slot_ok(h, slot)) return SLAM3D_E_INVALID;
-    if (!h->ran || slot >= h->last_B) return SLAM3D_E_STATE;
-    HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = h->run_stream;
     const int N = h->N;
     hipLaunchKernelGGL(k_fill_corr, dim3((N + 255) / 256), dim3(256), 0, s, h->d_idx, h->d_d2, N);
     if (h->p.iterations > 0)
-        hipLaunchKernelGGL(k_scatter_corr, dim3((h->tg.nslots + 255) / 256), dim3(256), 0, s, h->srcT, h->corr, h->cd2,
+        hipLaunchKernelGGL(k_scatter_corr, dim3((h->tg.nslots + 255) / 256), dim3(256), 0, s, h->d_pairs, corr_slot, cd2_slot,
                            slot, h->tg, h->d_idx, h->d_d2);
     HIPCHK(h, hipGetLastError());
     if (idx) HIPCHK(h, hipMemcpyAsync(idx, h->d_idx, sizeof(int) * N, hipMemcpyDeviceToHost, s));
     if (d2) HIPCHK(h, hipMemcpyAsync(d2, h->d_d2, sizeof(float) * N, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_get_correspondences(slam3d_icp_handle *h, int32_t slot, int32_t *idx, float *d2)
+{
+    if (!slot_ok(h, slot)) return SLAM3D_E_INVALID;
+    if (!h->ran || slot >= h->last_B) return SLAM3D_E_STATE;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    return corr_to_host(h, slot, h->corr + (size_t)slot * h->tg.nslots, h->cd2 + (size_t)slot * h->tg.nslots, idx, d2);
+}
+
+extern "C" int slam3d_icp_get_correspondences_at(slam3d_icp_handle *h, int32_t slot, int32_t it, int32_t *idx)
+{
+    if (!slot_ok(h, slot) || !idx || it < 0 || it >= h->p.iterations) return SLAM3D_E_INVALID;
+    if (!h->ran || !h->ran_corr_trace || !h->corr_trace || slot >= h->last_B) return SLAM3D_E_STATE;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    return corr_to_host(h, slot, h->corr_trace + ((size_t)it * h->maxB + slot) * h->tg.nslots, nullptr, idx, nullptr);
 }
 
 extern "C" int slam3d_icp_get_trace(slam3d_icp_handle *h, int32_t slot, double *T_trace, double *sums_trace)
@@ -674,16 +816,18 @@ extern "C" int slam3d_icp_get_trace(slam3d_icp_handle *h, int32_t slot, double *
 
 extern "C" int slam3d_icp_get_clouds(slam3d_icp_handle *h, int32_t slot, float *src_xyz4, float *tgt_xyz4, float *tgt_nrm4)
 {
-    if (!slot_ok(h, slot) || !h->h_slots[slot].src) return SLAM3D_E_INVALID;
+    if (!slot_ok(h, slot) || h->pair_src[slot] < 0 || h->pair_tgt[slot] < 0) return SLAM3D_E_INVALID;
+    const FrameHost &S = h->frames[h->pair_src[slot]], &T = h->frames[h->pair_tgt[slot]];
+    if (!S.cloud || !T.cloud) return SLAM3D_E_INVALID;
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = h->ran ? h->run_stream : h->stream;
     const size_t bytes = sizeof(float) * 4 * (size_t)h->N;
     if (s != h->stream) HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (src_xyz4) HIPCHK(h, hipMemcpyAsync(src_xyz4, h->h_slots[slot].src, bytes, hipMemcpyDeviceToHost, s));
-    if (tgt_xyz4) HIPCHK(h, hipMemcpyAsync(tgt_xyz4, h->h_slots[slot].tgt, bytes, hipMemcpyDeviceToHost, s));
+    if (src_xyz4) HIPCHK(h, hipMemcpyAsync(src_xyz4, S.cloud, bytes, hipMemcpyDeviceToHost, s));
+    if (tgt_xyz4) HIPCHK(h, hipMemcpyAsync(tgt_xyz4, T.cloud, bytes, hipMemcpyDeviceToHost, s));
     if (tgt_nrm4) {
         if (!h->ran || h->p.estimator != SLAM3D_EST_POINT2PLANE) return SLAM3D_E_STATE;
-        HIPCHK(h, hipMemcpyAsync(tgt_nrm4, h->nrm + (size_t)slot * h->N, bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(tgt_nrm4, h->f_nrm + (size_t)h->pair_tgt[slot] * h->N, bytes, hipMemcpyDeviceToHost, s));
     }
     HIPCHK(h, hipStreamSynchronize(s));
     return SLAM3D_OK;
@@ -1041,7 +1185,7 @@ extern "C" int slam3d_icp_dense_partial(slam3d_icp_handle *h, int64_t sums[SLAM3
     if (!h->ran) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
-    const int rc = enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0, h->sums, h->dense_it == 1);
+    const int rc = enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0, h->sums, h->dense_it == 1, h->dense_it == 0);
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(h->pin_out, h->sums, sizeof(int64_t) * NSUMS, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
@@ -1074,7 +1218,7 @@ extern "C" int slam3d_icp_dense_partial_device(slam3d_icp_handle *h, int64_t *d_
     if (!h->ran) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
-    return enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0, reinterpret_cast<long long *>(d_sums), h->dense_it == 1);
+    return enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0, reinterpret_cast<long long *>(d_sums), h->dense_it == 1, h->dense_it == 0);
 }
 
 extern "C" int slam3d_icp_dense_update_device(slam3d_icp_handle *h, const int64_t *d_sums, void *stream)
@@ -1101,7 +1245,8 @@ extern "C" int slam3d_icp_dense_finish_device(slam3d_icp_handle *h, const int64_
     double *ps = h->pin_out + 16;
     HIPCHK(h, hipMemcpyAsync(h->pin_out, h->Tcur, sizeof(double) * 16, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(ps, d_last_sums, sizeof(int64_t) * NSUMS, hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipMemcpyAsync(h->pin_int, h->counts, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->pin_int, h->f_counts + (size_t)h->pair_src[0] * 4, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->pin_int + 1, h->f_counts + (size_t)h->pair_tgt[0] * 4 + 1, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(h->pin_int + 4, h->flags, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     double ls[NSUMS];
@@ -1118,7 +1263,8 @@ extern "C" int slam3d_icp_dense_finish(slam3d_icp_handle *h, const int64_t last_
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = h->run_stream;
     HIPCHK(h, hipMemcpyAsync(h->pin_out, h->Tcur, sizeof(double) * 16, hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipMemcpyAsync(h->pin_int, h->counts, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->pin_int, h->f_counts + (size_t)h->pair_src[0] * 4, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->pin_int + 1, h->f_counts + (size_t)h->pair_tgt[0] * 4 + 1, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(h->pin_int + 4, h->flags, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     double ls[NSUMS];
@@ -1126,4 +1272,36 @@ extern "C" int slam3d_icp_dense_finish(slam3d_icp_handle *h, const int64_t last_
     finish_result(h->p, h->pin_out, ls, h->pin_int[4], h->pin_int[0], h->pin_int[1], out);
     out->iterations = h->dense_it;
     return SLAM3D_OK;
+}
+
+// BASELINE config 5 inside the library: source rows sharded over the ranks of `comm`, one ncclAllReduce(SUM) of the 29
+// int64 sums per iteration on the handle's own stream -- partial -> all-reduce -> update are three consecutive
+// enqueues on ONE stream, so no ordering is left to the caller (the round-1 Python form relied on torch's current
+// stream being the launch stream, which it was not).  SLAM3D_DENSE_FORCE_COLLECTIVE=1 runs the collective with one
+// rank too (developer knob: exercises RCCL on a single GPU).
+extern "C" int slam3d_icp_dense_run(slam3d_icp_handle *h, slam3d_comm *comm, const double *T_init, slam3d_icp_result *out)
+{
+    if (!h || !out) return SLAM3D_E_INVALID;
+    if (comm && comm->device != h->p.device) return SLAM3D_E_INVALID;
+    const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
+    const bool collective = comm && (world > 1 || getenv("SLAM3D_DENSE_FORCE_COLLECTIVE"));
+    int r0 = 0, r1 = h->p.height;
+    slam3d_shard_range(h->p.height, world, rank, &r0, &r1);
+    int rc = slam3d_icp_dense_set_rows(h, r0, r1);
+    if (rc) return rc;
+    hipStream_t s = h->stream;
+    rc = slam3d_icp_dense_begin(h, T_init, s);
+    int64_t *d_sums = reinterpret_cast<int64_t *>(h->sums);
+    for (int it = 0; it < h->p.iterations && !rc; ++it) {
+        rc = slam3d_icp_dense_partial_device(h, d_sums, s);
+        if (rc) break;
+        if (collective) {
+            const ncclResult_t nr = s3d::rccl().AllReduce(d_sums, d_sums, NSUMS, ncclInt64, ncclSum, comm->comm, s);
+            if (nr != ncclSuccess) { h->err = std::string("ncclAllReduce failed: ") + s3d::rccl().GetErrorString(nr); rc = SLAM3D_E_COMM; break; }
+        }
+        rc = slam3d_icp_dense_update_device(h, d_sums, s);
+    }
+    if (!rc) rc = slam3d_icp_dense_finish_device(h, d_sums, s, out);
+    (void)slam3d_icp_dense_set_rows(h, 0, h->p.height);
+    return rc;
 }

@@ -3,7 +3,7 @@
 // Stage map (DESIGN.md section 3 / SURVEY.md section 8a):
 //   S1 k_backproject      u16 depth -> organized float4 cloud      src/convert2PCD.cpp:54-72
 //   S2 k_normals          7x7 window covariance -> normal          src/planarFeatures.cpp:88-136 (a7)
-//   S3 k_build_tiles      8x8-pixel tiles (one wavefront each) of source / target + target AABBs
+//   S3 k_frame_tiles      8x8-pixel tiles (one wavefront each) of a frame as source / as target + target AABBs
 //      k_compact          raster-ordered dense lists (only the full brute-force modes need them)
 //   S4 k_nn_tiles_acc     exact tile-pruned 1-NN fused with the normal-equation accumulation
 //      k_nn_valu          exact full brute-force 1-NN (replaces FLANN matching, src/GraphicEnd.cpp:486-520)
@@ -27,18 +27,43 @@ constexpr int NN_TILE = 1024;      // targets staged in LDS per tile (brute-forc
 constexpr int NN_QPT = 4;          // queries per thread (brute-force VALU kernel)
 constexpr int NN_BLOCK = 256;
 
-struct SlotPtrs {                  // per frame-pair device pointers (organized float4 clouds)
-    const float4 *src;
-    const float4 *tgt;
+// A FRAME is the resident unit: its organized cloud and what the two roles need of it -- as an ICP *target* the
+// normals, tile records and boxes, as a *source* the tile-major slots.  They are built once per frame (and role), not
+// once per pair: the 32 loop-closure candidates of src/GraphicEnd.cpp:685-762 share one target frame, and the
+// keyframe of GraphicEnd::run (src/GraphicEnd.cpp:168) stays the source of many consecutive pairs.
+// A PAIR is two frame references plus its own iteration state (T, accumulators, prevq / hint / ownership map).
+struct PairPtrs {                  // per frame-pair device pointers: the resident products of its two frames
+    const float4 *src;             // organized source cloud (only the brute-force compaction reads it)
+    const float4 *tgt;             // organized target cloud
+    const float4 *nrm;             // target normals
+    const float4 *srcT;            // source tile slots   [ntiles * 64]
+    const float4 *tgtT;            // target tile records [ntiles * TILE_REC]
+    const float4 *tbox;            // target tile boxes   [ntiles * 2]
+    const float4 *cbox;            // target coarse boxes [ncoarse * 2]
+    const int *src_counts;         // [0] = valid source points of the source frame (inside its row shard)
+    const int *tgt_counts;         // [1] = valid target points of the target frame
 };
 constexpr int RES_REC = 48;        // doubles per pair in the host-mapped result record
-constexpr int SLOT_ARGS = 32;
-struct SlotArgs { SlotPtrs p[SLOT_ARGS]; };
-// the slot table travels as a kernel argument (copied at launch), not through pinned host memory
-__global__ void k_set_slots(SlotPtrs *__restrict__ dst, SlotArgs a, int n)
+constexpr int PAIR_ARGS = 32;
+struct PairArgs { PairPtrs p[PAIR_ARGS]; };
+// the pair table travels as a kernel argument (copied at launch), not through pinned host memory
+__global__ void k_set_pairs(PairPtrs *__restrict__ dst, PairArgs a, int n)
 {
     if ((int)threadIdx.x < n) dst[threadIdx.x] = a.p[threadIdx.x];
 }
+
+// one (frame, role) to (re)build; role 0 = source (tile-major slots of rows [row0, row1)), 1 = target
+struct FrameTask {
+    const float4 *cloud;
+    float4 *nrm;                   // target role: the frame's normals (read by the tile build when use_normals)
+    float4 *tiles;                 // srcT or tgtT of the frame
+    float4 *tbox, *cbox;           // target role only
+    int *scount;                   // per-tile valid counts (scratch of the frame), totalled by k_coarse_boxes
+    int *counts;                   // the frame's totals: [0] source role, [1] target role
+    int role, row0, row1, use_normals;
+};
+constexpr int FRAME_ARGS = 32;
+struct FrameTasks { FrameTask t[FRAME_ARGS]; };
 
 struct Geometry {
     int W, H, N;
@@ -137,13 +162,11 @@ constexpr int NRM_BX = 32, NRM_BY = 8, NRM_RMAX = 4;
 // centre's, so they add exact zeros to every sum (no accumulator can be -0.0: all start at +0.0), and a lane mask
 // keeps them out of the counts -- the same bits as the skip, one LDS read per neighbour and no divergence.
 template <int RT>
-__global__ __launch_bounds__(NRM_BX * NRM_BY) void k_normals(const SlotPtrs *__restrict__ slots,
-                                                             float4 *__restrict__ nrm_all, Geometry g)
+__global__ __launch_bounds__(NRM_BX * NRM_BY) void k_normals(FrameTasks a, Geometry g)
 {
     __shared__ float4 tile[(NRM_BY + 2 * NRM_RMAX) * (NRM_BX + 2 * NRM_RMAX)];
-    const int b = blockIdx.z;
-    const float4 *__restrict__ cloud = slots[b].tgt;
-    float4 *__restrict__ nrm = nrm_all + (size_t)b * g.N;
+    const float4 *__restrict__ cloud = a.t[blockIdx.z].cloud;
+    float4 *__restrict__ nrm = a.t[blockIdx.z].nrm;
     const int r = RT > 0 ? RT : g.win_r;
     constexpr int UN = RT > 0 ? 2 * RT + 1 : 1;       // one window row per trip of the outer loop
     const int tw = NRM_BX + 2 * r, th = NRM_BY + 2 * r;
@@ -260,51 +283,16 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
-// grid (ntiles, 2, B), block 64.  srcT slot w = pixel index (int bits) or -1; rows outside
-// [row0,row1) hold no source (dense multi-GPU mode).  A target tile record (TILE_REC float4) holds its four
-// 4x4-pixel quadrants, each compacted (valid slots first; a slot is (pixel index, x, y, z)) into 16 slots, followed by the
-// quadrants' AABBs (lo.xyz, count | hi.xyz); the tile AABB goes to box[2t] = (min, count), box[2t+1] = (max, 0).
-// All boxes are taken from the data (no camera model).
-__global__ __launch_bounds__(64) void k_build_tiles(const SlotPtrs *__restrict__ slots,
-                                                    const float4 *__restrict__ nrm_all,
-                                                    float4 *__restrict__ srcT, float4 *__restrict__ tgtT,
-                                                    float4 *__restrict__ tbox, int *__restrict__ scount,
-                                                    int *__restrict__ corr, float4 *__restrict__ prevq,
-                                                    int *__restrict__ hint,
-                                                    int *__restrict__ counts,
-                                                    Geometry g, TileGrid tg, int use_normals, int row0, int row1,
-                                                    const double *__restrict__ T_init, double *__restrict__ Tcur,
-                                                    double *__restrict__ trace_T, int *__restrict__ flags,
-                                                    long long *__restrict__ acc, int iters)
+// grid (ntiles, ntasks), block 64: one (frame, role) per blockIdx.y.  Source role: srcT slot w = pixel index (int
+// bits) or -1; rows outside [row0,row1) hold no source (dense multi-GPU mode).  Target role: a tile record (TILE_REC
+// float4) holds its four 4x4-pixel quadrants, each compacted (valid slots first; a slot is (pixel index, x, y, z))
+// into 16 slots, followed by the quadrants' AABBs (lo.xyz, count | hi.xyz); the tile AABB goes to
+// box[2t] = (min, count), box[2t+1] = (max, 0).  All boxes are taken from the data (no camera model).
+__global__ __launch_bounds__(64) void k_frame_tiles(FrameTasks a, Geometry g, TileGrid tg)
 {
-    const int t = blockIdx.x, which = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
-    if (which == 0 && t == 0) {
-        // start of the run for pair b: T = T_init (or Identity), trace row 0, flags, clean accumulators
-        for (int j = lane; j < ACC_R * ACC_STRIDE; j += 64) acc[(size_t)b * ACC_R * ACC_STRIDE + j] = 0;
-        if (lane < 16) {
-            const double v = T_init ? T_init[b * 16 + lane] : ((lane % 5 == 0) ? 1.0 : 0.0);
-            Tcur[b * 16 + lane] = v;
-            trace_T[((size_t)b * (iters + 1)) * 16 + lane] = v;
-        }
-        if (lane == 0) flags[b] = 0;
-    }
-    if (which == 0) {
-        // per-run state of the iteration kernels, reset here instead of by five memset launches: no previous
-        // match (corr = -1, prevq.w = -1 bits), no hint tile, default tile ownership, zero totals
-        const size_t slot = (size_t)b * tg.nslots + (size_t)t * TILE_SLOTS + lane;
-        const float ones = __int_as_float(-1);
-        corr[slot] = -1;
-        prevq[slot] = make_float4(ones, ones, ones, ones);
-        if (lane == 0) hint[(size_t)b * tg.ntiles + t] = -1;
-        // (perm is NOT reset: the cost-balanced ownership of the previous run on this slot is the best guess for the
-        // first two iterations of the next one -- consecutive frame pairs look alike; any map gives the same bits)
-        if (t == 0 && lane < 4) counts[b * 4 + lane] = 0;
-        if (t == tg.ntiles - 1)                                       // slot padding up to a whole launch block
-            for (int k = tg.ntiles * TILE_SLOTS + lane; k < tg.nslots; k += 64) {
-                corr[(size_t)b * tg.nslots + k] = -1;
-                prevq[(size_t)b * tg.nslots + k] = make_float4(ones, ones, ones, ones);
-            }
-    }
+    const int t = blockIdx.x, lane = threadIdx.x;
+    const FrameTask &ft = a.t[blockIdx.y];
+    const int which = ft.role;
     const int tx = t % tg.ntx, ty = t / tg.ntx;
     const int u = tx * TILE_PX + (lane & 7), v = ty * TILE_PX + (lane >> 3);
     const float inf = __int_as_float(0x7f800000);
@@ -312,26 +300,27 @@ __global__ __launch_bounds__(64) void k_build_tiles(const SlotPtrs *__restrict__
     bool ok = false;
     if (u < g.W && v < g.H) {
         const int pix = v * g.W + u;
-        const float4 c = (which == 0 ? slots[b].src : slots[b].tgt)[pix];
+        const float4 c = ft.cloud[pix];
         ok = pt_valid(c.x, c.y, c.z, g.zmax);
-        if (which == 0) ok = ok && v >= row0 && v < row1;
-        else if (ok && use_normals) ok = nrm_all[(size_t)b * g.N + pix].w > 0.5f;
+        if (which == 0) ok = ok && v >= ft.row0 && v < ft.row1;
+        else if (ok && ft.use_normals) ok = ft.nrm[pix].w > 0.5f;
         if (ok) q = make_float4(c.x, c.y, c.z, __int_as_float(pix));
     }
     const unsigned long long m = __ballot(ok);
     const int cnt = __popcll(m);
+    if (lane == 0) ft.scount[t] = cnt;                                // summed per coarse cell (no hot atomic)
     if (which == 0) {
-        srcT[((size_t)b * tg.ntiles + t) * TILE_SLOTS + lane] = q;
-        if (lane == 0) scount[(size_t)b * tg.ntiles + t] = cnt;     // summed per coarse cell (no hot atomic)
+        ft.tiles[(size_t)t * TILE_SLOTS + lane] = q;
         return;
     }
+    float4 *__restrict__ tgtT = ft.tiles;
     // quadrant of this lane's pixel: (row >= 4) * 2 + (col >= 4); lanes of one quadrant differ in bits 0,1,3,4
     const int qd = ((lane >> 5) << 1) | ((lane >> 2) & 1);
     const unsigned long long qmask = (qd & 1 ? 0xF0F0F0F0ull : 0x0F0F0F0Full) << (qd & 2 ? 32 : 0);
     const unsigned long long below = (1ull << lane) - 1ull;
     const int cntq = __popcll(m & qmask);
     const int rank = ok ? __popcll(m & qmask & below) : cntq + __popcll(~m & qmask & below);
-    const size_t base = ((size_t)b * tg.ntiles + t) * TILE_REC;
+    const size_t base = (size_t)t * TILE_REC;
     // stored as (pixel, x, y, z): the scan's 64-bit key (d2 bits << 32 | pixel) then forms in place -- the
     // distance lands in the register next to the pixel index, no move per candidate
     tgtT[base + qd * 16 + rank] = make_float4(q.w, q.x, q.y, q.z);
@@ -352,48 +341,73 @@ __global__ __launch_bounds__(64) void k_build_tiles(const SlotPtrs *__restrict__
         mxx = fmaxf(mxx, __shfl_xor(mxx, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o));
     }
     if (lane == 0) {
-        tbox[((size_t)b * tg.ntiles + t) * 2] = make_float4(mnx, mny, mnz, __int_as_float(cnt));
-        tbox[((size_t)b * tg.ntiles + t) * 2 + 1] = make_float4(mxx, mxy, mxz, 0.0f);
+        ft.tbox[(size_t)t * 2] = make_float4(mnx, mny, mnz, __int_as_float(cnt));
+        ft.tbox[(size_t)t * 2 + 1] = make_float4(mxx, mxy, mxz, 0.0f);
     }
 }
 
-// grid (ncoarse, B), block 64: AABB of the 8x8 child tiles; also totals the valid source / target counts
-__global__ __launch_bounds__(64) void k_coarse_boxes(const float4 *__restrict__ tbox, const int *__restrict__ scount,
-                                                     float4 *__restrict__ cbox, int *__restrict__ counts, TileGrid tg)
+// grid (ncoarse, ntasks), block 64: totals the valid points of the task's role into the frame's counts (which the
+// host zeroed through k_frame_begin); target role: also the AABB of the 8x8 child tiles
+__global__ __launch_bounds__(64) void k_coarse_boxes(FrameTasks a, TileGrid tg)
 {
-    const int c = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const FrameTask &ft = a.t[blockIdx.y];
     const int tx = (c % tg.ncx) * COARSE_TILES + (lane & 7), ty = (c / tg.ncx) * COARSE_TILES + (lane >> 3);
     const float inf = __int_as_float(0x7f800000);
     float4 lo = make_float4(inf, inf, inf, 0.0f), hi = make_float4(-inf, -inf, -inf, 0.0f);
-    int ns = 0, nt = 0;
+    int n = 0;
     if (tx < tg.ntx && ty < tg.nty) {
-        const size_t t = (size_t)b * tg.ntiles + (size_t)ty * tg.ntx + tx;
-        lo = tbox[t * 2]; hi = tbox[t * 2 + 1];
-        ns = scount[t]; nt = __float_as_int(lo.w);
+        const size_t t = (size_t)ty * tg.ntx + tx;
+        n = ft.scount[t];
+        if (ft.role == 1) { lo = ft.tbox[t * 2]; hi = ft.tbox[t * 2 + 1]; }
     }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { ns += __shfl_xor(ns, o); nt += __shfl_xor(nt, o); }
-    if (lane == 0) { if (ns) atomicAdd(counts + b * 4, ns); if (nt) atomicAdd(counts + b * 4 + 1, nt); }
+    for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o);
+    if (lane == 0 && n) atomicAdd(ft.counts + ft.role, n);
+    if (ft.role == 0) return;
     const float mnx = wave_min(lo.x), mny = wave_min(lo.y), mnz = wave_min(lo.z);
     const float mxx = wave_max(hi.x), mxy = wave_max(hi.y), mxz = wave_max(hi.z);
     if (lane == 0) {
-        cbox[((size_t)b * tg.ncoarse + c) * 2] = make_float4(mnx, mny, mnz, 0.0f);
-        cbox[((size_t)b * tg.ncoarse + c) * 2 + 1] = make_float4(mxx, mxy, mxz, 0.0f);
+        ft.cbox[(size_t)c * 2] = make_float4(mnx, mny, mnz, 0.0f);
+        ft.cbox[(size_t)c * 2 + 1] = make_float4(mxx, mxy, mxz, 0.0f);
     }
+}
+
+// zero the role totals of the tasks' frames before they are rebuilt (block 64, one task per lane)
+__global__ void k_frame_begin(FrameTasks a, int n)
+{
+    if ((int)threadIdx.x < n) a.t[threadIdx.x].counts[a.t[threadIdx.x].role] = 0;
+}
+
+// start of a run for the pairs [b0, b0 + n): T = T_init (kernel argument) or Identity, trace row 0, flags, clean
+// accumulators.  grid (n), block 64.  (prevq / hint / corr need no reset: the first iteration ignores them.)
+constexpr int TINIT_ARGS = 16;
+struct TinitArgs { double T[TINIT_ARGS][16]; };
+__global__ __launch_bounds__(64) void k_pair_init(TinitArgs ti, int has_T, int b0, double *__restrict__ Tcur,
+                                                  double *__restrict__ trace_T, int *__restrict__ flags,
+                                                  long long *__restrict__ acc, unsigned int *__restrict__ ticket, int iters)
+{
+    const int k = blockIdx.x, b = b0 + k, lane = threadIdx.x;
+    for (int j = lane; j < ACC_R * ACC_STRIDE; j += 64) acc[(size_t)b * ACC_R * ACC_STRIDE + j] = 0;
+    if (lane < 16) {
+        const double v = has_T ? ti.T[k % TINIT_ARGS][lane] : ((lane % 5 == 0) ? 1.0 : 0.0);
+        Tcur[b * 16 + lane] = v;
+        trace_T[((size_t)b * (iters + 1)) * 16 + lane] = v;
+    }
+    if (lane == 0) { flags[b] = 0; ticket[b] = 0u; }
 }
 
 // stable raster-order stream compaction, one 1024-thread block per (pair, src|tgt).  Only the full
 // brute-force modes use these lists.  src w = SLOT id of the pixel, tgt w = pixel index.
-__global__ __launch_bounds__(1024) void k_compact(const SlotPtrs *__restrict__ slots,
-                                                  const float4 *__restrict__ nrm_all,
+__global__ __launch_bounds__(1024) void k_compact(const PairPtrs *__restrict__ pairs,
                                                   float4 *__restrict__ src_c, float4 *__restrict__ tgt_c,
                                                   int *__restrict__ ccounts, Geometry g, TileGrid tg,
                                                   int use_normals, int row0, int row1)
 {
     __shared__ int wave_tot[16];
     const int which = blockIdx.x, b = blockIdx.y;
-    const float4 *__restrict__ cloud = which == 0 ? slots[b].src : slots[b].tgt;
-    const float4 *__restrict__ nrm = nrm_all + (size_t)b * g.N;
+    const float4 *__restrict__ cloud = which == 0 ? pairs[b].src : pairs[b].tgt;
+    const float4 *__restrict__ nrm = pairs[b].nrm;
     float4 *__restrict__ outp = (which == 0 ? src_c : tgt_c) + (size_t)b * g.N;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i_begin = which == 0 ? row0 * g.W : 0;
@@ -568,12 +582,12 @@ constexpr int MF_AHEAD = 8;
 constexpr int MF_RB = 8;                 // row blocks (of 16 queries) per wave
 constexpr int MF_Q = 16 * MF_RB;         // queries per wave
 
-__global__ __launch_bounds__(64) void k_nn_mfma(const SlotPtrs *__restrict__ slots, const float4 *__restrict__ nrm_all,
+__global__ __launch_bounds__(64) void k_nn_mfma(const PairPtrs *__restrict__ pairs,
                                                 const float4 *__restrict__ src_c, const float4 *__restrict__ tgt_c,
                                                 const float *__restrict__ tgtB, const unsigned int *__restrict__ qmax2_bits,
                                                 const int *__restrict__ ccounts, const float4 *__restrict__ prevq,
                                                 const double *__restrict__ Tcur, unsigned long long *__restrict__ best,
-                                                Geometry g, TileGrid tg, int npad, float cz, int nsplit)
+                                                Geometry g, TileGrid tg, int npad, float cz, int nsplit, int first)
 {
     __shared__ float4 qpos[MF_Q];
     __shared__ float4 qrel[MF_Q];
@@ -586,8 +600,8 @@ __global__ __launch_bounds__(64) void k_nn_mfma(const SlotPtrs *__restrict__ slo
     if (i0 >= ns) return;
     const float4 *__restrict__ Q = tgt_c + (size_t)b * N;
     const float *__restrict__ Bb = tgtB + (size_t)b * 4 * npad;
-    const float4 *__restrict__ tcloud = slots[b].tgt;
-    const float4 *__restrict__ tnrm = nrm_all + (size_t)b * N;
+    const float4 *__restrict__ tcloud = pairs[b].tgt;
+    const float4 *__restrict__ tnrm = pairs[b].nrm;
     // ---- each lane prepares MF_Q/64 queries: transformed point, upper bound, filter threshold
     const Rt m = load_rt(Tcur + b * 16);
     const float qmax2 = __int_as_float((int)qmax2_bits[b]);
@@ -604,7 +618,8 @@ __global__ __launch_bounds__(64) void k_nn_mfma(const SlotPtrs *__restrict__ slo
         xform(m, s4.x, s4.y, s4.z, px, py, pz);
         unsigned long long bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
         if (valid) {
-            const float4 pq = prevq[(size_t)b * tg.nslots + slot];
+            float4 pq = prevq[(size_t)b * tg.nslots + slot];
+            if (first) pq.w = __int_as_float(-1);                  // a run's first iteration has no previous match
             const int jprev = __float_as_int(pq.w);
             float4 qg = pq;
             int jg = jprev;
@@ -852,9 +867,7 @@ __device__ __forceinline__ void finish_slot(bool valid, unsigned long long key, 
 }
 
 // accumulation for the brute-force modes: grid (nchunks, B), one thread per source slot, one wave per tile
-__global__ __launch_bounds__(CHUNK) void k_accumulate(const SlotPtrs *__restrict__ slots,
-                                                      const float4 *__restrict__ nrm_all,
-                                                      const float4 *__restrict__ srcT,
+__global__ __launch_bounds__(CHUNK) void k_accumulate(const PairPtrs *__restrict__ pairs,
                                                       const double *__restrict__ Tcur,
                                                       unsigned long long *__restrict__ best,
                                                       int *__restrict__ corr, float *__restrict__ cd2,
@@ -866,7 +879,7 @@ __global__ __launch_bounds__(CHUNK) void k_accumulate(const SlotPtrs *__restrict
     if (t >= tg.ntiles) return;
     const int slot = c * CHUNK + threadIdx.x;
     const size_t gs = (size_t)b * tg.nslots + slot;
-    const float4 sp = srcT[(size_t)b * tg.ntiles * TILE_SLOTS + slot];
+    const float4 sp = pairs[b].srcT[slot];
     const bool valid = __float_as_int(sp.w) >= 0;
     const Rt m = load_rt(Tcur + b * 16);
     float px, py, pz;
@@ -874,7 +887,7 @@ __global__ __launch_bounds__(CHUNK) void k_accumulate(const SlotPtrs *__restrict
     const unsigned long long key = best[gs];
     best[gs] = ~0ull;
     RowBasis rb;
-    finish_slot(valid, key, px, py, pz, slots[b].tgt, nrm_all + (size_t)b * g.N, g.gate2, g.estimator, corr + gs, cd2 + gs,
+    finish_slot(valid, key, px, py, pz, pairs[b].tgt, pairs[b].nrm, g.gate2, g.estimator, corr + gs, cd2 + gs,
                 prevq + gs, rb);
     tile_accumulate(g.estimator, rb, acc + ((size_t)b * ACC_R + (c % ACC_R)) * ACC_STRIDE);
 }
@@ -953,19 +966,15 @@ constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (
 //   4. every wave finishes its own tile: gate, row products, level-1 reduction, hint for the next iteration.
 // The result is independent of which wave processes which item (keys are merged by an exact minimum).
 template <int NN_STAGE, int WPE, bool COOP, bool DBG>
-__global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_nn_tiles_acc(const SlotPtrs *__restrict__ slots,
-                                                        const float4 *__restrict__ nrm_all,
-                                                        const float4 *__restrict__ srcT,
-                                                        const float4 *__restrict__ tgtT,
-                                                        const float4 *__restrict__ tbox,
-                                                        const float4 *__restrict__ cbox,
+__global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_nn_tiles_acc(const PairPtrs *__restrict__ pairs,
                                                         const double *__restrict__ Tcur,
                                                         int *__restrict__ corr, float *__restrict__ cd2,
                                                         float4 *__restrict__ prevq, int *__restrict__ hint,
                                                         const int *__restrict__ perm, int *__restrict__ cost,
                                                         long long *__restrict__ acc, Geometry g, TileGrid tg,
                                                         long long *__restrict__ dbg /* DBG builds only: 8 x int64 per tile */,
-                                                        int write_out /* corr / cd2 wanted (last iteration) */)
+                                                        int write_out /* corr / cd2 wanted (last iteration) */,
+                                                        int first /* a run's first iteration: no previous match, no hint */)
 {
     __shared__ float4 stage_all[NN_WAVES][NN_STAGE * TILE_REC];
     __shared__ int wcost[NN_WAVES];                                    // cycles spent for each owner (all helpers)
@@ -994,11 +1003,12 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     float4 *__restrict__ st = stage_all[w];
     const size_t gs = (size_t)b * tg.nslots + (size_t)(has_tile ? t : 0) * TILE_SLOTS + lane;
     const float inf = __int_as_float(0x7f800000);
-    const float4 *__restrict__ tcloud = slots[b].tgt;
-    const float4 *__restrict__ tnrm = nrm_all + (size_t)b * g.N;
-    const float4 *__restrict__ TB = tbox + (size_t)b * tg.ntiles * 2;
-    const float4 *__restrict__ CB = cbox + (size_t)b * tg.ncoarse * 2;
-    const float4 *__restrict__ TT = tgtT + (size_t)b * tg.ntiles * TILE_REC;
+    const PairPtrs &pp = pairs[b];                    // wave-uniform: scalar loads
+    const float4 *__restrict__ tcloud = pp.tgt;
+    const float4 *__restrict__ tnrm = pp.nrm;
+    const float4 *__restrict__ TB = pp.tbox;
+    const float4 *__restrict__ CB = pp.cbox;
+    const float4 *__restrict__ TT = pp.tgtT;
     if (threadIdx.x == 0) { n_items = 0; next_item = 0; }
     if (threadIdx.x < NN_WAVES) wcost[threadIdx.x] = 0;
     __syncthreads();
@@ -1149,7 +1159,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     };
 
     // ================= step 1: own tile =================
-    const float4 s4 = has_tile ? srcT[((size_t)b * tg.ntiles + t) * TILE_SLOTS + lane] : make_float4(0, 0, 0, __int_as_float(-1));
+    const float4 s4 = has_tile ? pp.srcT[(size_t)t * TILE_SLOTS + lane] : make_float4(0, 0, 0, __int_as_float(-1));
     const int pix = __float_as_int(s4.w);
     const bool own_valid = pix >= 0;
     float opx = 0.0f, opy = 0.0f, opz = 0.0f;
@@ -1159,7 +1169,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         // hint = the (up to 2x2) block of target tiles that the 8x8 source patch covered in the previous iteration
         // (top-left tile | extends in x << 24 | extends in y << 25); without one: the same image location and its
         // four edge neighbours
-        const int th = __builtin_amdgcn_readfirstlane(hint[(size_t)b * tg.ntiles + t]);
+        const int th = first ? -1 : __builtin_amdgcn_readfirstlane(hint[(size_t)b * tg.ntiles + t]);
         if (th >= 0 && (th & 0xffffff) < tg.ntiles) {
             const int base = th & 0xffffff, fx = (th >> 24) & 1, fy = (th >> 25) & 1;
             tt[0] = base;
@@ -1178,7 +1188,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
 #pragma unroll
         for (int k = 0; k < NN_STAGE; ++k) ta[k] = tt[k];
         fetch_batch();                                             // one round of independent loads ...
-        const float4 pq = prevq[gs];
+        float4 pq = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+        if (!first) pq = prevq[gs];                                // (a run's first iteration: whatever an earlier run left there is ignored)
         float4 qs = make_float4(0, 0, 0, 0);
         float ws = 1.0f;
         if (__float_as_int(pq.w) < 0) {   // no previous match (first iteration): fall back to the target at the same pixel
@@ -1304,6 +1315,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     {   // hint for the next iteration: the tile holding the match of a lane near the tile centre
         const bool ok = rb.v[7] != 0.0;
         const unsigned long long mm = __ballot(ok);
+        if (!mm && first && lane == 0) hint[(size_t)b * tg.ntiles + t] = -1;       // no stale hint from an earlier run
         if (mm) {
             const unsigned long long ctr = mm & 0x0000001818000000ull;      // lanes 27,28,35,36
             const int src_lane = __builtin_ctzll(ctr ? ctr : mm);
@@ -1597,7 +1609,9 @@ __device__ inline void solve_update_one(const double *__restrict__ sums, double 
     if (rc) {
         compose(dR, dt, T);
         for (int k = 0; k < 16; ++k) Tcur_b[k] = T[k];
-        if (rc == 2) *flag = 1;
+        if (rc == 2) *flag = *flag | 1;
+    } else {
+        *flag = *flag | 2;       // no update in this iteration (too few rows, or the system could not be solved): never a silent "ok"
     }
     for (int k = 0; k < 16; ++k) trace_T_b[(size_t)(it + 1) * 16 + k] = T[k];
 }
@@ -1609,7 +1623,7 @@ __device__ inline void solve_update_one(const double *__restrict__ sums, double 
 __global__ __launch_bounds__(64) void k_solve_acc(long long *__restrict__ acc, long long *__restrict__ raw_out,
                                                   double *__restrict__ Tcur, double *__restrict__ trace_T,
                                                   double *__restrict__ trace_S, int *__restrict__ flags,
-                                                  const int *__restrict__ counts, double *__restrict__ res_host,
+                                                  const PairPtrs *__restrict__ pairs, double *__restrict__ res_host,
                                                   int it, int iters, int estimator, int do_solve)
 {
     __shared__ double tot[NSUMS];
@@ -1632,7 +1646,7 @@ __global__ __launch_bounds__(64) void k_solve_acc(long long *__restrict__ acc, l
             double *__restrict__ r = res_host + (size_t)b * RES_REC;
             for (int j = 0; j < 16; ++j) r[j] = Tcur[b * 16 + j];
             for (int j = 0; j < NSUMS; ++j) r[16 + j] = tot[j];
-            r[45] = (double)flags[b]; r[46] = (double)counts[b * 4]; r[47] = (double)counts[b * 4 + 1];
+            r[45] = (double)flags[b]; r[46] = (double)pairs[b].src_counts[0]; r[47] = (double)pairs[b].tgt_counts[1];
         }
     }
 }
@@ -1657,16 +1671,16 @@ __global__ __launch_bounds__(256) void k_fill_corr(int *__restrict__ idx, float 
     if (i < N) { idx[i] = -1; d2[i] = __int_as_float(0x7f800000); }
 }
 
-__global__ __launch_bounds__(256) void k_scatter_corr(const float4 *__restrict__ srcT, const int *__restrict__ corr,
-                                                      const float *__restrict__ cd2, int b, TileGrid tg,
+__global__ __launch_bounds__(256) void k_scatter_corr(const PairPtrs *__restrict__ pairs, const int *__restrict__ corr /* [nslots] of the pair */,
+                                                      const float *__restrict__ cd2 /* nullable */, int b, TileGrid tg,
                                                       int *__restrict__ idx, float *__restrict__ d2)
 {
     const int slot = blockIdx.x * 256 + threadIdx.x;
     if (slot >= tg.ntiles * TILE_SLOTS) return;
-    const int pix = __float_as_int(srcT[(size_t)b * tg.ntiles * TILE_SLOTS + slot].w);
+    const int pix = __float_as_int(pairs[b].srcT[slot].w);
     if (pix < 0) return;
-    idx[pix] = corr[(size_t)b * tg.nslots + slot];
-    d2[pix] = cd2[(size_t)b * tg.nslots + slot];
+    idx[pix] = corr[slot];
+    if (cd2) d2[pix] = cd2[slot];
 }
 
 } // namespace s3d

@@ -49,21 +49,46 @@ def dense_align(handle, world: int, rank: int, T_init=None, allreduce: Optional[
     return res
 
 
-def dense_align_device(handle, world: int, rank: int, d_sums, T_init=None, stream: int = 0) -> dict:
-    """dense_align with the exchange kept on the device: `d_sums` is a torch int64 tensor of 29 elements on the
-    handle's GPU; per iteration partial -> in-place all-reduce (RCCL, same stream) -> update, with no host
-    synchronisation until the final fetch."""
+def dense_align_device(handle, world: int, rank: int, d_sums, T_init=None, stream: int = None, force_collective: bool = False) -> dict:
+    """dense_align with the exchange kept on the device, through torch.distributed: `d_sums` is a torch int64 tensor
+    of 29 elements on the handle's GPU; per iteration partial -> in-place all-reduce -> update, with no host
+    synchronisation until the final fetch.
+
+    Stream contract (round-1 bug: the kernels went to the handle's private non-blocking stream while ProcessGroupNCCL
+    ordered the all-reduce against torch's CURRENT stream, so the collective could read the sums before they were
+    written).  The three steps must share one stream that is also torch's current stream: by default an explicit
+    non-default torch stream is created, made current for the loop and passed down as the launch stream.  A caller
+    stream is accepted when it is a real (non-null) stream; the null stream with more than one rank is refused.
+    `slam3d_icp_dense_run` (capi.IcpHandle.dense_run) does the same loop inside the library with RCCL called from C
+    and is what bench.py uses."""
+    import torch
     import torch.distributed as dist
+    on = dist.is_initialized() and (dist.get_world_size() > 1 or force_collective)
+    if stream is not None and stream == 0 and (world > 1 or force_collective):
+        raise ValueError("dense_align_device: the null stream cannot order the all-reduce with the handle's kernels; "
+                         "pass a non-default stream (or None to let this function create one)")
     r0, r1 = shard.dense_row_range(handle.params.height, world, rank)
     handle.dense_set_rows(r0, r1)
-    handle.dense_begin(T_init, stream)
-    on = dist.is_initialized() and dist.get_world_size() > 1
+    side = None
+    if stream is None:
+        side = torch.cuda.Stream(device=d_sums.device)
+        side.wait_stream(torch.cuda.current_stream(d_sums.device))
+        stream = side.cuda_stream
+    if side is not None:
+        ctx = torch.cuda.stream(side)
+    elif stream == 0:
+        import contextlib
+        ctx = contextlib.nullcontext()          # one rank, no collective: the legacy default stream orders nothing else
+    else:
+        ctx = torch.cuda.stream(torch.cuda.ExternalStream(stream, device=d_sums.device))
     ptr = d_sums.data_ptr()
-    for _ in range(handle.params.iterations):
-        handle.dense_partial_device(ptr, stream)
-        if on:
-            dist.all_reduce(d_sums, op=dist.ReduceOp.SUM)
-        handle.dense_update_device(ptr, stream)
-    res = handle.dense_finish_device(ptr, stream)
+    with ctx:
+        handle.dense_begin(T_init, stream)
+        for _ in range(handle.params.iterations):
+            handle.dense_partial_device(ptr, stream)
+            if on:
+                dist.all_reduce(d_sums, op=dist.ReduceOp.SUM)       # enqueued on the current stream == `stream`
+            handle.dense_update_device(ptr, stream)
+        res = handle.dense_finish_device(ptr, stream)
     handle.dense_set_rows(0, handle.params.height)
     return res

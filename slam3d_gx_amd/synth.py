@@ -219,3 +219,53 @@ def backproject_numpy(depth: np.ndarray, intr: Intrinsics, z_filter: float = 7.0
     out[..., 0] = x; out[..., 1] = y; out[..., 2] = z; out[..., 3] = 1.0
     out[bad] = (np.nan, np.nan, np.nan, 0.0)
     return out
+
+
+def _make_pair_spec(spec):
+    seed, width, height, sigma = spec
+    return make_pair(seed, width, height, noise_sigma=sigma)
+
+
+def make_pairs(specs, workers: int = 0):
+    """[(seed, width, height, noise_sigma), ...] -> {spec: FramePair}, rendered by parallel worker PROCESSES started
+    with subprocess (`python -m slam3d_gx_amd.synth render ...`: no fork of a process that may hold a HIP context, no
+    re-import of the caller's __main__).  The ray caster is pure numpy, ~1 s per 640x480 pair on one core; results
+    are bit-identical to make_pair."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    specs = list(dict.fromkeys(specs))
+    workers = workers or min(len(specs), max(1, (os.cpu_count() or 2) // 2), 48)
+    if workers <= 1 or len(specs) <= 1:
+        return {sp: _make_pair_spec(sp) for sp in specs}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = []
+        for w in range(workers):
+            chunk = specs[w::workers]
+            if not chunk:
+                continue
+            path = os.path.join(tmp, f"part{w}.npz")
+            args = [sys.executable, "-m", "slam3d_gx_amd.synth", "render", path] + [f"{s},{wd},{ht},{sg!r}" for s, wd, ht, sg in chunk]
+            env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+            procs.append((subprocess.Popen(args, cwd=root, env=env), path, chunk))
+        for pr, path, chunk in procs:
+            if pr.wait(timeout=1800) != 0:
+                raise RuntimeError("synthetic frame renderer failed")
+            with np.load(path) as z:
+                for k, sp in enumerate(chunk):
+                    out[sp] = FramePair(sp[0], Intrinsics.scaled(sp[1], sp[2]), z[f"s{k}"], z[f"t{k}"], z[f"T{k}"])
+    return out
+
+
+if __name__ == "__main__":
+    import sys
+    if len(sys.argv) >= 4 and sys.argv[1] == "render":
+        arrs = {}
+        for k, a in enumerate(sys.argv[3:]):
+            seed, wd, ht, sg = a.split(",")
+            pr = make_pair(int(seed), int(wd), int(ht), noise_sigma=float(sg))
+            arrs[f"s{k}"], arrs[f"t{k}"], arrs[f"T{k}"] = pr.depth_src, pr.depth_tgt, pr.T_gt
+        np.savez(sys.argv[2], **arrs)

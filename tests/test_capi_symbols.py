@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 def test_abi_version_and_strerror_without_gpu():
     lib = capi.load_library()
-    assert lib.slam3d_icp_abi_version() == 2
+    assert lib.slam3d_icp_abi_version() == 3
     assert b"no gfx950" in lib.slam3d_strerror(-4)
     assert lib.slam3d_strerror(0) == b"ok"
 
@@ -40,16 +40,37 @@ def test_struct_layouts_match_header_sizes(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "slam3d_icp.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(slam3d_icp_params), sizeof(slam3d_icp_result),'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(slam3d_icp_params), sizeof(slam3d_icp_result),'
         ' sizeof(slam3d_cloud_view), sizeof(slam3d_plane), offsetof(slam3d_icp_params, nn_mode),'
         ' offsetof(slam3d_icp_result, rmse), offsetof(slam3d_icp_result, T_raw), sizeof(slam3d_seg_params),'
-        ' offsetof(slam3d_seg_params, seed));return 0;}\n')
+        ' offsetof(slam3d_seg_params, seed), offsetof(slam3d_icp_params, extra_frames), sizeof(slam3d_pose_record),'
+        ' offsetof(slam3d_pose_record, rmse));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert got == [ctypes.sizeof(capi.Params), ctypes.sizeof(capi.Result), ctypes.sizeof(capi.CloudView),
                    ctypes.sizeof(capi.Plane), capi.Params.nn_mode.offset, capi.Result.rmse.offset, capi.Result.T_raw.offset,
-                   ctypes.sizeof(capi.SegParams), capi.SegParams.seed.offset]
+                   ctypes.sizeof(capi.SegParams), capi.SegParams.seed.offset, capi.Params.extra_frames.offset,
+                   ctypes.sizeof(capi.PoseRecord), capi.PoseRecord.rmse.offset]
+    assert ctypes.sizeof(capi.PoseRecord) == 160       # 160-byte pose records
+
+
+def test_shard_range_and_comm_entry_points_without_gpu():
+    """The multi-GPU entry points are exported and the ones that need no device behave: contiguous pair / row
+    blocks, remainder to the lowest ranks; the communicator refuses bad arguments."""
+    for n, world in ((64, 8), (10, 3), (3, 8), (0, 4), (480, 7)):
+        cover = []
+        for r in range(world):
+            b, e = capi.shard_range(n, world, r)
+            assert 0 <= b <= e <= n
+            cover += list(range(b, e))
+        assert cover == list(range(n))
+    assert capi.shard_range(10, 3, 0) == (0, 4) and capi.shard_range(10, 3, 2) == (7, 10)
+    lib = capi.load_library()
+    out = ctypes.c_void_p()
+    assert lib.slam3d_comm_init(None, 0, 1, 0, ctypes.byref(out)) == -1          # SLAM3D_E_INVALID
+    buf = (ctypes.c_ubyte * 128)()
+    assert lib.slam3d_comm_init(buf, 3, 2, 0, ctypes.byref(out)) == -1           # rank >= world
 
 
 def test_create_fails_loudly_without_device_or_with_bad_params():

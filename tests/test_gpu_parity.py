@@ -453,10 +453,10 @@ def test_two_handles_in_flight_give_the_sequential_results(gpu_lib):
         assert np.array_equal(lone[k]["T_raw"], ro["T_trace"][-1])
 
 
-@pytest.mark.parametrize("mode", ["batch", "dense"])
-def test_bench_two_ranks_on_one_device(gpu_lib, mode):
-    """bench.py's N>1 code path (pair sharding + pipelined pose all-gather / dense integer all-reduce) with two ranks
-    sharing this GPU over gloo: RCCL needs one GPU per rank, everything else is the code the driver runs."""
+def test_bench_two_ranks_on_one_device(gpu_lib):
+    """bench.py's N>1 code path (pairs per rank, per-step pose gather, max over ranks) with two ranks sharing this GPU
+    over gloo: RCCL needs one GPU per rank, everything else is the code the driver runs.  (The dense N>1 form needs
+    RCCL; its loop is covered by test_frames_comm.py with a one-rank communicator and by tests/test_shard_gloo.py.)"""
     import json, os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with socket.socket() as s:
@@ -465,13 +465,30 @@ def test_bench_two_ranks_on_one_device(gpu_lib, mode):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--width", "320", "--height", "240", "--iterations", "6", "--no-cpu-baseline", "--no-bruteforce",
-           "--dist-backend", "gloo", "--one-device"] + (["--mode", "dense"] if mode == "dense" else [])
+           "--pairs-per-step", "6", "--pool", "4", "--profile-aligns", "4", "--dist-backend", "gloo", "--one-device"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["status"][0] == 0
-    assert d["scaling"] == ("strong" if mode == "dense" else "weak")
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["status"][0] == 0 and d["scaling"] == "weak"
+    assert d["config"]["gathered_pose_records"] == 12 and d["config"]["pairs_per_step_per_gpu"] == 6
+
+
+def test_bench_single_gpu_line_has_the_contract_fields(gpu_lib):
+    """The default code path of bench.py at a small size: one JSON line with roofline, cpu_baseline, parity and the
+    RCCL pose gather forced on (one rank)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--width", "320", "--height", "240",
+           "--iterations", "6", "--pairs-per-step", "6", "--pool", "4", "--profile-aligns", "4", "--force-collective"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["n_gpus"] == 1 and d["value"] > 0
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0 and 0 < d["roofline"]["frac"] < 1
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["kind"] == "port"
+    assert d["parity_vs_oracle"]["idx_mismatches"] == 0 and d["parity_vs_oracle"]["T_bit_identical"]
+    assert d["config"]["gathered_pose_records"] == 6 and "workload" in d["config"]
 
 
 @pytest.mark.parametrize("estimator", [0, 1])
