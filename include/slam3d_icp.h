@@ -204,6 +204,17 @@ int slam3d_fit_planes(slam3d_icp_handle *h, const slam3d_cloud_view *cloud, cons
 int slam3d_match_planes(const slam3d_plane *p1, int32_t n1, const slam3d_plane *p2, int32_t n2, int32_t *train_idx,
                         float *distance);
 
+/* Plane-association GATE built on the match above ("plane pairing gates correspondences
+ * (optional)", the outlier-rejection role of src/GraphicEnd.cpp:522-554): the planes of frame 1 are carried into frame 2
+ * by the estimated T (X_2 = T X_1: n' = R n, d' = d - n'.t, sign rule d' >= 0 of src/GraphicEnd.cpp:383-387), matched
+ * to the planes of frame 2 exactly as GraphicEnd::match does, and a pair counts when its (a, b, c, d) distance is at
+ * most max_dist.  *n_matched = number of such pairs.  A pose that maps no plane of frame 1 onto a plane of frame 2 is
+ * geometrically unsupported however many point inliers it has.  Host code, needs no device. */
+int slam3d_plane_gate(const slam3d_plane *p1, int32_t n1, const slam3d_plane *p2, int32_t n2, const double *T /* 16, row-major */,
+                      float max_dist, int32_t *n_matched);
+/* number of HIP devices visible (0 when none): lets a host front end shard a loop-closure batch, one handle per GPU */
+int slam3d_device_count(void);
+
 /* ---- frame ingestion filters of GraphicEnd::readimage (src/GraphicEnd.cpp:283-295): pcl::PassThrough on
  * z in [0, z_filter] followed by pcl::VoxelGrid with a cubic leaf (grid_leaf, 0.03), on n 16-byte records
  * {float x, y, z; uint32 rgba} -- the layout of the reference's binary PCD files (data/exp1/pcd/1.pcd header).

@@ -10,7 +10,12 @@
  * here (F3), so no golden vector of the reference pins this oracle.  What IS
  * pinned against reference artefacts:
  *   - orc_backproject vs data/exp1/pcd/{1,2}.pcd (written by the reference's
- *     src/convert2PCD.cpp:54-72) -- tests/test_oracle_reference_fixtures.py
+ *     src/convert2PCD.cpp:54-72) -- tests/test_golden.py::test_backprojection_pinned_by_reference_pcd
+ * What hardens the rest although the reference cannot pin it: an INDEPENDENT numpy / scipy restatement of
+ * the iteration (cKDTree candidates + canonical float32 re-evaluation for the indices, numpy lstsq on the
+ * explicit [p x n, n] rows, numpy SVD for Kabsch, numpy eigh for the normals) must give the same indices
+ * exactly and the same sums / poses to the fixed-point bound / 1e-9 at every iterate --
+ * tests/test_oracle_independent.py, tests/golden/make_independent_golden.py.
  * Everything else follows the normative restatement in DESIGN.md section 3
  * (SURVEY.md App. C), which re-uses the reference's conventions:
  *   - pinhole back-projection         src/convert2PCD.cpp:65-69,

@@ -34,6 +34,7 @@ EXPORTED_SYMBOLS = [
     "slam3d_comm_get_unique_id", "slam3d_comm_init", "slam3d_comm_destroy", "slam3d_comm_rank", "slam3d_comm_world",
     "slam3d_comm_last_error", "slam3d_shard_range", "slam3d_icp_dense_run", "slam3d_pose_gather_submit",
     "slam3d_pose_gather_collect", "slam3d_pose_gather", "slam3d_pose_record_from_result",
+    "slam3d_plane_gate", "slam3d_device_count",
 ]
 COMM_ID_BYTES = 128
 
@@ -144,6 +145,23 @@ def match_planes(coeffs1, coeffs2):
     if rc:
         raise Slam3dError(rc, "slam3d_match_planes")
     return idx[: a.shape[0]], dist[: a.shape[0]]
+
+
+def plane_gate(coeffs1, coeffs2, T, max_dist: float = 0.15) -> int:
+    """planes of frame 1 carried into frame 2 by T and matched like GraphicEnd::match: number of pairs within max_dist"""
+    a = np.ascontiguousarray(coeffs1, dtype=np.float32).reshape(-1, 4)
+    b = np.ascontiguousarray(coeffs2, dtype=np.float32).reshape(-1, 4)
+    pa, pb = (Plane * max(1, a.shape[0]))(), (Plane * max(1, b.shape[0]))()
+    for i in range(a.shape[0]):
+        pa[i].coeff[:] = a[i].tolist()
+    for j in range(b.shape[0]):
+        pb[j].coeff[:] = b[j].tolist()
+    Tm = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+    n = C.c_int32(0)
+    rc = load_library().slam3d_plane_gate(pa, C.c_int32(a.shape[0]), pb, C.c_int32(b.shape[0]), _vp(Tm), C.c_float(max_dist), C.byref(n))
+    if rc:
+        raise Slam3dError(rc, "slam3d_plane_gate")
+    return n.value
 
 
 def default_params(intr=None, **kw) -> Params:

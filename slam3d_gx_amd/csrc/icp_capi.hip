@@ -939,6 +939,38 @@ extern "C" int slam3d_match_planes(const slam3d_plane *p1, int32_t n1, const sla
     return SLAM3D_OK;
 }
 
+extern "C" int slam3d_plane_gate(const slam3d_plane *p1, int32_t n1, const slam3d_plane *p2, int32_t n2, const double *T,
+                                 float max_dist, int32_t *n_matched)
+{
+    if (!T || !n_matched || n1 < 0 || n2 < 0 || n1 > 8 || (n1 > 0 && !p1) || (n2 > 0 && !p2)) return SLAM3D_E_INVALID;
+    *n_matched = 0;
+    if (n1 == 0 || n2 == 0) return SLAM3D_OK;
+    slam3d_plane moved[8];
+    for (int i = 0; i < n1; ++i) {
+        const double a = p1[i].coeff[0], b = p1[i].coeff[1], c = p1[i].coeff[2], d = p1[i].coeff[3];
+        // plane n.X + d = 0 in frame 1; X_2 = R X_1 + t  =>  n' = R n, d' = d - n'.t
+        double n[3];
+        for (int r = 0; r < 3; ++r) n[r] = (T[r * 4] * a + T[r * 4 + 1] * b) + T[r * 4 + 2] * c;
+        double dd = d - ((n[0] * T[3] + n[1] * T[7]) + n[2] * T[11]);
+        if (dd < 0.0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; dd = -dd; }        // src/GraphicEnd.cpp:383-387
+        moved[i] = p1[i];
+        moved[i].coeff[0] = (float)n[0]; moved[i].coeff[1] = (float)n[1]; moved[i].coeff[2] = (float)n[2]; moved[i].coeff[3] = (float)dd;
+    }
+    int32_t idx[8];
+    float dist[8];
+    const int rc = slam3d_match_planes(moved, n1, p2, n2, idx, dist);
+    if (rc) return rc;
+    for (int i = 0; i < n1; ++i) if (idx[i] >= 0 && dist[i] <= max_dist) *n_matched += 1;
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
 // ------------------------------------------------------------------------------ frame ingestion filters (f-1)
 static int vox_alloc(slam3d_icp_handle *h)
 {

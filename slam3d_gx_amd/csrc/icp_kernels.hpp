@@ -1335,7 +1335,12 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         d[0] = clk0; d[1] = clk1; d[2] = clk2; d[3] = clk3; d[4] = clock64();
         d[5] = n_scanned | ((long long)n_chit << 32); d[6] = n_cand | ((long long)n_fhit << 32);
         d[7] = n_batches | ((long long)n_refined << 32);
-        dbg[(size_t)tg.ntiles * 8 + (size_t)t * 2] = clk2; dbg[(size_t)tg.ntiles * 8 + (size_t)t * 2 + 1] = clk2;
+        // where the wave ran: HW_ID (wave / simd / cu / sh / se fields) and the XCC id
+        unsigned int hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        dbg[(size_t)tg.ntiles * 8 + (size_t)t * 2] = (long long)hw_id | ((long long)xcc_id << 32);
+        dbg[(size_t)tg.ntiles * 8 + (size_t)t * 2 + 1] = (long long)c * NN_WAVES + w;
     }
 }
 

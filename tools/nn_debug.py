@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Developer tool: per-wave statistics of the tile-pruned NN kernel (needs SLAM3D_NN_DEBUG=1)."""
+"""Developer tool: per-wave statistics of the tile-pruned NN kernel (needs SLAM3D_NN_DEBUG=1): phase durations, work
+counters, and WHERE / WHEN every wave ran (XCD, CU, start and end relative to the launch) -- the launch lasts as long
+as its last wave, so the end-time distribution per XCD / CU is what explains the kernel time."""
 import os, sys
 os.environ["SLAM3D_NN_DEBUG"] = "1"
 import numpy as np
@@ -7,7 +9,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slam3d_gx_amd import capi, synth
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-pr = synth.make_pair(1000)
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+pr = synth.make_pair(seed)
 s4 = synth.backproject_numpy(pr.depth_src, pr.intr); t4 = synth.backproject_numpy(pr.depth_tgt, pr.intr)
 for it in (1, iters):
     with capi.IcpHandle(capi.default_params(pr.intr, iterations=it)) as h:
@@ -15,12 +18,33 @@ for it in (1, iters):
         d = h.get_nn_debug()
     act = d[:, 4] > 0
     d = d[act]
-    life = d[:, 4] - d[:, 0]
-    print(f"--- last of {it} iteration(s): {act.sum()} active waves; kernel span {d[:,4].max()-d[:,0].min()} clk")
-    d = d[d[:, 1] > 0]
+    t0 = d[:, 0].min()
+    print(f"--- last of {it} iteration(s): {act.sum()} active waves; launch span (first start -> last end) {d[:, 4].max() - t0} clk")
+    d1 = d[d[:, 1] > 0]
     lo32 = lambda x: x & 0xffffffff
     hi32 = lambda x: x >> 32
-    for name, v in (("lifetime", d[:, 4] - d[:, 0]), ("prologue", d[:, 1] - d[:, 0]), ("own 5 tiles", d[:, 2] - d[:, 1]), ("publish+items (to barrier 2)", d[:, 3] - d[:, 2]),
-                    ("epilogue", d[:, 4] - d[:, 3]), ("tiles scanned", lo32(d[:, 5])), ("candidates", lo32(d[:, 6])), ("batches", lo32(d[:, 7])),
-                    ("cells swept", hi32(d[:, 5])), ("fine hits", hi32(d[:, 6])), ("refined hits", hi32(d[:, 7]))):
+    for name, v in (("lifetime", d1[:, 4] - d1[:, 0]), ("start - t0", d1[:, 0] - t0), ("end - t0", d1[:, 4] - t0), ("prologue", d1[:, 1] - d1[:, 0]), ("own 5 tiles", d1[:, 2] - d1[:, 1]),
+                    ("publish+items (to barrier 2)", d1[:, 3] - d1[:, 2]),
+                    ("epilogue", d1[:, 4] - d1[:, 3]), ("tiles scanned", lo32(d1[:, 5])), ("candidates", lo32(d1[:, 6])), ("batches", lo32(d1[:, 7])),
+                    ("cells swept", hi32(d1[:, 5])), ("fine hits", hi32(d1[:, 6])), ("refined hits", hi32(d1[:, 7]))):
         print(f"{name:14s} mean {v.mean():10.1f}  p50 {np.percentile(v,50):9.0f}  p90 {np.percentile(v,90):9.0f}  p99 {np.percentile(v,99):9.0f}  max {v.max():9.0f}")
+    hw = d[:, 8] & 0xffffffff
+    xcc = (d[:, 8] >> 32) & 0xf
+    cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 0x1; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 0x3
+    cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    end = d[:, 4] - t0
+    print("per XCD: waves, mean end, max end, sum lifetime")
+    for x in range(8):
+        m = xcc == x
+        if m.any():
+            print(f"  xcd {x}: {m.sum():5d} waves  end mean {end[m].mean():9.0f} max {end[m].max():9.0f}  work {(d[m, 4] - d[m, 0]).sum():12d}")
+    ids, inv = np.unique(cuid, return_inverse=True)
+    cu_end = np.array([end[inv == k].max() for k in range(len(ids))]); cu_n = np.array([(inv == k).sum() for k in range(len(ids))])
+    cu_work = np.array([(d[inv == k, 4] - d[inv == k, 0]).sum() for k in range(len(ids))])
+    print(f"CUs seen {len(ids)}; waves per CU min {cu_n.min()} mean {cu_n.mean():.1f} max {cu_n.max()}; CU end time: min {cu_end.min()} p10 {np.percentile(cu_end,10):.0f} "
+          f"p50 {np.percentile(cu_end,50):.0f} p90 {np.percentile(cu_end,90):.0f} max {cu_end.max()}; CU work (sum of wave lifetimes) min {cu_work.min()} p50 {np.percentile(cu_work,50):.0f} max {cu_work.max()}")
+    print(f"corr(CU end, waves per CU) = {np.corrcoef(cu_end, cu_n)[0,1]:.2f}   corr(CU end, CU work) = {np.corrcoef(cu_end, cu_work)[0,1]:.2f}")
+    late = np.argsort(end)[-12:]
+    print("latest waves: (end, lifetime, items-phase, fine hits, candidates, xcd, cu)")
+    for i in late:
+        print(f"   {end[i]:8d} {d[i,4]-d[i,0]:8d} {d[i,3]-d[i,2]:8d} {hi32(d[i,6]):4d} {lo32(d[i,6]):5d}  xcd {xcc[i]} cu {cuid[i]}")
