@@ -184,8 +184,9 @@ int slam3d_icp_get_timings(slam3d_icp_handle *h, float ms[4]);
 /* duration of each iteration's NN launch of the last run (ms), nn_ms[iterations]; SLAM3D_E_STATE unless the
  * run was profiled */
 int slam3d_icp_get_iteration_timings(slam3d_icp_handle *h, float *nn_ms);
-/* developer statistics of the LAST NN launch (slot 0), 8 int64 per source tile: clock at start / after
- * prologue / after the 3x3 scan / after the wide scan / at the end, tiles scanned, candidates, batches.
+/* developer statistics of the LAST NN launch (slot 0), 20 int64 per source tile: clock at start / after
+ * prologue / after the own scan / after the wide scan / at the end, tiles scanned, candidates, batches, where the
+ * wave ran (HW_ID | XCC_ID << 32), its launch slot, real-time counter at start / end (100 MHz), clocks around the two block barriers, items drained.
  * Only available when the handle was created with SLAM3D_NN_DEBUG=1 in the environment. */
 int slam3d_icp_get_nn_debug(slam3d_icp_handle *h, int64_t *out, int32_t n);
 

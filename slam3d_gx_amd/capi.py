@@ -96,7 +96,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    so = path or _build.LIB
+    so = path or os.environ.get("SLAM3D_LIB") or _build.LIB        # SLAM3D_LIB: developer knob (kernel variants side by side)
     if not os.path.exists(so):
         raise FileNotFoundError(
             f"{so} not found: build it with `python -m slam3d_gx_amd.build` (hipcc, gfx950). "
@@ -352,9 +352,9 @@ class IcpHandle:
 
     def get_nn_debug(self) -> np.ndarray:
         nt = ((self.params.width + 7) // 8) * ((self.params.height + 7) // 8)
-        out = np.zeros(nt * 10, dtype=np.int64)
+        out = np.zeros(nt * 20, dtype=np.int64)
         self._check(self.lib.slam3d_icp_get_nn_debug(self._h, _vp(out), C.c_int32(out.size)), False)
-        return np.concatenate([out[: nt * 8].reshape(nt, 8), out[nt * 8:].reshape(nt, 2)], axis=1)
+        return out.reshape(nt, 20)
 
     # ---- building blocks ---------------------------------------------------------------
     def backproject_u16(self, depth: np.ndarray) -> np.ndarray:

@@ -253,10 +253,14 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
         if (getenv("SLAM3D_XCD_BANDS")) h->xcd_bands = atoi(getenv("SLAM3D_XCD_BANDS"));
         const long long waves = ((long long)tg.ntiles * (100 + (slack < 0 ? 0 : slack)) + 99) / 100;
         h->nn_gx = (int)(((waves + NN_WAVES - 1) / NN_WAVES + 7) / 8 * 8);
+        if (getenv("SLAM3D_NN_GX")) {                      // developer knob: grid width of the single-pair build
+            const int gx = atoi(getenv("SLAM3D_NN_GX")) / 8 * 8;
+            if ((long long)gx * NN_WAVES >= tg.ntiles) h->nn_gx = gx;
+        }
         h->nn_gx_d = ((tg.ntiles + NN_WAVES - 1) / NN_WAVES + 7) / 8 * 8;
     }
     A(dalloc(h->perm, (size_t)h->maxB * h->nn_gx * NN_WAVES)); A(dalloc(h->perm_d, (size_t)h->maxB * h->nn_gx_d * NN_WAVES));
-    if (getenv("SLAM3D_NN_DEBUG")) A(dalloc(h->dbg, (size_t)tg.ntiles * 10));
+    if (getenv("SLAM3D_NN_DEBUG")) A(dalloc(h->dbg, (size_t)tg.ntiles * 20));
     if (getenv("SLAM3D_NO_GRAPH") || getenv("SLAM3D_NN_DEBUG")) h->use_graph = false;
     if (getenv("SLAM3D_DENSE_BATCH")) h->dense_batch = atoi(getenv("SLAM3D_DENSE_BATCH"));
     A(dalloc(h->sums, (size_t)h->maxB * NSUMS)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
@@ -543,7 +547,7 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
 // one iteration's data-parallel part: NN search + normal-equation chunks, then the 29-sum reduction
 // (+ solve and SE(3) update when do_solve)
 #ifndef S3D_COOP_WPE
-#define S3D_COOP_WPE 8
+#define S3D_COOP_WPE 7
 #endif
 static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int it, int do_solve,
                              long long *raw_out = nullptr, int balance = 0, int first = 0)
@@ -854,10 +858,10 @@ extern "C" int slam3d_icp_get_timings(slam3d_icp_handle *h, float ms[4])
 extern "C" int slam3d_icp_get_nn_debug(slam3d_icp_handle *h, int64_t *out /* ntiles*8 */, int32_t n)
 {
     if (!h || !out) return SLAM3D_E_INVALID;
-    if (!h->dbg || !h->ran || n < h->tg.ntiles * 10) return SLAM3D_E_STATE;
+    if (!h->dbg || !h->ran || n < h->tg.ntiles * 20) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     HIPCHK(h, hipStreamSynchronize(h->run_stream));
-    HIPCHK(h, hipMemcpy(out, h->dbg, sizeof(long long) * (size_t)h->tg.ntiles * 10, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out, h->dbg, sizeof(long long) * (size_t)h->tg.ntiles * 20, hipMemcpyDeviceToHost));
     return SLAM3D_OK;
 }
 

@@ -950,7 +950,11 @@ __device__ __forceinline__ int lds_fetch_add_uniform(int *p, int v)
 // pairs (latency bound: the slowest block ends the launch).  <3, 8, not cooperative>: every wave sweeps its own cells
 // -- no shared lists, no block barriers, 14 KB of LDS, 55 VGPRs -- at the full 8 waves per SIMD; it wins when many
 // pairs fill the chip (throughput bound: 64 pairs 44 k -> 55 k it/s).
-constexpr int NN_MAX_ITEMS = 256;    // (owner wave, coarse cell) work items shared by the waves of a block
+#ifndef S3D_OWN_HOME_CELL
+#define S3D_OWN_HOME_CELL 0          // the owner refines its (prefetched) home cell itself instead of listing it
+#endif
+constexpr int NN_MAX_ITEMS = 128;    // (owner wave, coarse cell) work items shared by the waves of a block
+constexpr int NN_MAX_TITEMS = 384;   // (owner wave, target tile) work items: the tiles the cell sweeps found worth scanning
 constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (8 measured slower: 2 blocks per CU)
 
 // grid (G, B), block 256 = 4 waves; G = a multiple of 8 >= ntiles/4 (+ slack, see k_balance).  Wave w of block c
@@ -972,7 +976,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                                                         float4 *__restrict__ prevq, int *__restrict__ hint,
                                                         const int *__restrict__ perm, int *__restrict__ cost,
                                                         long long *__restrict__ acc, Geometry g, TileGrid tg,
-                                                        long long *__restrict__ dbg /* DBG builds only: 8 x int64 per tile */,
+                                                        long long *__restrict__ dbg /* DBG builds only: 20 x int64 per tile */,
                                                         int write_out /* corr / cd2 wanted (last iteration) */,
                                                         int first /* a run's first iteration: no previous match, no hint */)
 {
@@ -983,10 +987,13 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     __shared__ unsigned long long qkey[NN_WAVES][TILE_SLOTS];
     __shared__ int wcentre[NN_WAVES][8];                               // the step-1 tiles of each owner (NN_STAGE used)
     __shared__ float wbox[NN_WAVES][16];                               // each owner's tight / loose query boxes + flag
-    __shared__ int items[NN_MAX_ITEMS];
-    __shared__ int n_items, next_item;
+    __shared__ int items[NN_MAX_ITEMS];                                // phase A work: (owner wave << 16 | coarse cell)
+    __shared__ int titems[NN_MAX_TITEMS];                              // phase B work: (owner wave << 24 | target tile)
+    __shared__ int n_items, next_item, n_titems, next_titem;
     const long long clk0 = DBG ? clock64() : 0;
-    long long clk1 = 0, clk2 = 0, clk3 = 0;
+    const long long rt0 = DBG ? (long long)wall_clock64() : 0;
+    long long clk1 = 0, clk2 = 0, clk3 = 0, clkP = 0, clkB1 = 0, clkD = 0, clkM = 0, clkE = 0;
+    int n_my_items = 0;
     // per-tile work counters and clocks of the instrumented (DBG) instances; compiled out of the production ones
     int n_scanned = 0, n_cand = 0, n_batches = 0, n_chit = 0, n_fhit = 0, n_refined = 0;
     const int lane = threadIdx.x & 63;
@@ -1009,7 +1016,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     const float4 *__restrict__ TB = pp.tbox;
     const float4 *__restrict__ CB = pp.cbox;
     const float4 *__restrict__ TT = pp.tgtT;
-    if (threadIdx.x == 0) { n_items = 0; next_item = 0; }
+    if (threadIdx.x == 0) { n_items = 0; next_item = 0; n_titems = 0; next_titem = 0; }
     if (threadIdx.x < NN_WAVES) wcost[threadIdx.x] = 0;
     __syncthreads();
 
@@ -1068,7 +1075,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         for (int k = 0; k < NN_STAGE; ++k)
             r[k] = tt[k] >= 0 ? TT[(size_t)tt[k] * TILE_REC + lane] : make_float4(__int_as_float(-1), inf, inf, inf);
     };
-    auto park_and_scan = [&]() __attribute__((always_inline)) {
+    auto park = [&]() __attribute__((always_inline)) {
         if constexpr (DBG) n_batches += 1;
         // lanes 0..39 fetch the quadrant boxes of the staged tiles (8 float4 per tile) with one load
         int my_tile = -1;
@@ -1083,6 +1090,9 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto park_and_scan = [&]() __attribute__((always_inline)) {
+        park();
 #pragma unroll
         for (int k = 0; k < NN_STAGE; ++k)
             if (tt[k] >= 0) scan_staged(k, tt[k]);
@@ -1114,13 +1124,19 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         thr_t = wave_max(tight ? cur : 0.0f) * 1.00001f + 1e-30f;    // covers the rounding of box_gap2 and of canon_d2
         thr_l = any_loose ? wave_max(loose ? cur : 0.0f) * 1.00001f + 1e-30f : 0.0f;
     };
-    // fine level: ballot the children of coarse cell cc against the wave boxes, re-test per lane, stage + scan
-    auto sweep_cell = [&](int cc) __attribute__((always_inline)) {
+    // fine level of coarse cell cc, in three pieces so that the cooperative build can keep several loads in flight:
+    // (1) the child boxes (lane k holds child tile k of the 8x8 cell) ...
+    auto cell_boxes = [&](int cc, float4 &lo, float4 &hi, int &ctx, int &cty) __attribute__((always_inline)) {
         const int ccy = tg.ncx == 1 ? cc : (int)__umulhi((unsigned int)cc, tg.mag_ncx);     // (2^32 / 1 has no 32-bit magic)
-        const int ctx = (cc - ccy * tg.ncx) * COARSE_TILES, cty = ccy * COARSE_TILES;
+        ctx = (cc - ccy * tg.ncx) * COARSE_TILES; cty = ccy * COARSE_TILES;
         const int tx = ctx + (lane & 7), ty = cty + (lane >> 3);
-        float4 lo = make_float4(inf, inf, inf, 0), hi = make_float4(-inf, -inf, -inf, 0);
+        lo = make_float4(inf, inf, inf, 0); hi = make_float4(-inf, -inf, -inf, 0);
         if (tx < tg.ntx && ty < tg.nty) { lo = TB[2 * (ty * tg.ntx + tx)]; hi = TB[2 * (ty * tg.ntx + tx) + 1]; }
+    };
+    // (2) ballot against the wave's query boxes, then the per-lane re-test BEFORE anything is fetched: a tile survives
+    // only if some lane's own ball reaches its box (lane k2 holds the box of child k2 -> broadcast with v_readlane)
+    auto cell_refine = [&](const float4 lo, const float4 hi, int ctx, int cty) __attribute__((always_inline)) {
+        const int tx = ctx + (lane & 7), ty = cty + (lane >> 3);
         float thr_t, thr_l;
         class_thr(thr_t, thr_l);
         bool hit2 = false;
@@ -1133,8 +1149,6 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         }
         unsigned long long tm0 = __ballot(hit2), tm = 0ull;
         if constexpr (DBG) { n_chit += 1; n_fhit += __popcll(tm0); }
-        // refine BEFORE fetching anything: a tile is staged only if some lane's own ball reaches its box
-        // (lane k2 holds the box of child k2 -> broadcast it with v_readlane)
         while (tm0) {
             const int k2 = __builtin_ctzll(tm0);
             tm0 &= tm0 - 1;
@@ -1143,6 +1157,10 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             if (__ballot(lane_gap_ok(blo, bhi)) != 0ull) tm |= 1ull << k2;
         }
         if constexpr (DBG) n_refined += __popcll(tm);
+        return tm;
+    };
+    // (3) stage + scan the surviving tiles right here (throughput build; list overflow of the cooperative build)
+    auto scan_cell_tiles = [&](unsigned long long tm, int ctx, int cty) __attribute__((always_inline)) {
         while (tm) {
 #pragma unroll
             for (int k = 0; k < NN_STAGE; ++k) {
@@ -1157,8 +1175,34 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             park_and_scan();
         }
     };
+    auto sweep_cell = [&](int cc) __attribute__((always_inline)) {
+        float4 lo, hi;
+        int ctx, cty;
+        cell_boxes(cc, lo, hi, ctx, cty);
+        scan_cell_tiles(cell_refine(lo, hi, ctx, cty), ctx, cty);
+    };
+    // cooperative build: the surviving tiles of a cell become tile items (owner wave << 24 | tile) of the block's
+    // shared list; what does not fit is scanned right here (the caller publishes the improved keys).  Returns true
+    // when it scanned.  The current query context must be `owner`'s.
+    auto append_tiles = [&](int owner, unsigned long long tm, int ctx, int cty) __attribute__((always_inline)) {
+        const int cnt = __popcll(tm);
+        if (!cnt) return false;
+        const int base = lds_fetch_add_uniform(&n_titems, cnt);                // cnt is wave-uniform
+        if ((tm >> lane) & 1ull) {                                             // lane k2 writes the entry of child k2
+            const int pos = base + __popcll(tm & ((1ull << lane) - 1ull));
+            if (pos < NN_MAX_TITEMS) titems[pos] = (owner << 24) | ((cty + (lane >> 3)) * tg.ntx + ctx + (lane & 7));
+        }
+        if (base + cnt <= NN_MAX_TITEMS) return false;
+        int keep = NN_MAX_TITEMS - base; if (keep < 0) keep = 0;
+        unsigned long long over = tm;
+        for (int k = 0; k < keep; ++k) over &= over - 1;                        // the `keep` lowest set bits were listed
+        scan_cell_tiles(over, ctx, cty);
+        return true;
+    };
 
     // ================= step 1: own tile =================
+    int hc = -1, hctx = 0, hcty = 0;                  // cooperative build: the prefetched "home" coarse cell and its child boxes
+    float4 hlo = make_float4(inf, inf, inf, 0), hhi = make_float4(-inf, -inf, -inf, 0);
     const float4 s4 = has_tile ? pp.srcT[(size_t)t * TILE_SLOTS + lane] : make_float4(0, 0, 0, __int_as_float(-1));
     const int pix = __float_as_int(s4.w);
     const bool own_valid = pix >= 0;
@@ -1188,6 +1232,12 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
 #pragma unroll
         for (int k = 0; k < NN_STAGE; ++k) ta[k] = tt[k];
         fetch_batch();                                             // one round of independent loads ...
+        if constexpr (COOP && S3D_OWN_HOME_CELL) {   // ... including the child boxes of the coarse cell around the first tile: nearly every wave sweeps it
+            const int t0 = tt[0] >= 0 ? tt[0] : t;
+            const int ty0 = t0 / tg.ntx, tx0 = t0 - ty0 * tg.ntx;
+            hc = (ty0 / COARSE_TILES) * tg.ncx + tx0 / COARSE_TILES;
+            cell_boxes(hc, hlo, hhi, hctx, hcty);
+        }
         float4 pq = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
         if (!first) pq = prevq[gs];                                // (a run's first iteration: whatever an earlier run left there is ignored)
         float4 qs = make_float4(0, 0, 0, 0);
@@ -1256,15 +1306,25 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                 }
                 continue;
             }
-            const int cnt = __popcll(cm);
+            // The owner refines its home cell itself, right now: its context is in registers and the child boxes were
+            // prefetched with the first round of loads (a wave sweeps 1.2 cells on average and the home cell is nearly
+            // always one of them, so for most blocks nothing is left for the shared cell list: no phase A).
+            unsigned long long rest0 = cm;
+            if (S3D_OWN_HOME_CELL && hc >= c0 && hc < c0 + 64 && ((cm >> (hc - c0)) & 1ull)) {          // the home cell: no load to wait for
+                rest0 &= ~(1ull << (hc - c0));
+                if constexpr (DBG) n_my_items += 1;
+                if (append_tiles(w, cell_refine(hlo, hhi, hctx, hcty), hctx, hcty)) qkey[w][lane] = bkey;
+            }
+            const unsigned long long cml = rest0;                                  // what is left goes to the shared cell list
+            const int cnt = __popcll(cml);
             const int base = cnt ? lds_fetch_add_uniform(&n_items, cnt) : 0;       // cnt is wave-uniform
-            if (hit) {
-                const int pos = base + __popcll(cm & ((1ull << lane) - 1ull));
+            if ((cml >> lane) & 1ull) {
+                const int pos = base + __popcll(cml & ((1ull << lane) - 1ull));
                 if (pos < NN_MAX_ITEMS) items[pos] = (w << 16) | cidx;
             }
             // cells that do not fit in the shared list are swept right here by their owner
             if (base + cnt > NN_MAX_ITEMS) {
-                unsigned long long rest = cm;
+                unsigned long long rest = cml;
                 int skip = NN_MAX_ITEMS - base; if (skip < 0) skip = 0;
                 while (rest) {
                     const int k = __builtin_ctzll(rest);
@@ -1277,19 +1337,23 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         }
     }
     if (lane == 0) atomicAdd(&wcost[w], (int)(clock64() - cw0));
+    if constexpr (DBG) clkP = clock64();
     if constexpr (COOP) __syncthreads();
-    // ================= step 3: drain the shared item list =================
+    if constexpr (DBG) clkB1 = clock64();
+    // ================= step 3: drain the shared work, two decoupled phases =================
+    // Measured on the round-1 form (one wave took an item = (owner, cell) and ran its whole dependent chain -- child
+    // boxes -> refine -> fetch a batch of tiles -> scan -> next batch ...): 7 k cycles per item, nearly all of it the
+    // latency of serial global round trips, and the blocks with a dozen items ended the launch (wave lifetime mean 42 k
+    // cycles, launch 72 k).  Now phase A turns cell items into tile items (two cells per trip: both child-box loads in
+    // flight together), phase B consumes tile items of ANY owner three per trip (three records in flight), so a heavy
+    // owner's tiles spread over all four waves and every wave waits for about one load round per phase.
     if constexpr (COOP) {
-        const int total = __builtin_amdgcn_readfirstlane(min(n_items, NN_MAX_ITEMS));     // same in every lane: keep the loop scalar
-        while (true) {
-            const int it = lds_fetch_add_uniform(&next_item, 1);
-            if (it >= total) break;
-            const int item = __builtin_amdgcn_readfirstlane(items[it]);           // one address for the wave: owner and cell are scalars
-            const int owner = item >> 16, cc = item & 0xffff;
-            const long long ci0 = clock64();
+        auto load_owner = [&](int owner) __attribute__((always_inline)) {
             px = qpos[owner][0][lane]; py = qpos[owner][1][lane]; pz = qpos[owner][2][lane];
             valid = (qcls[owner][0] >> lane) & 1ull; tight = (qcls[owner][1] >> lane) & 1ull; loose = valid && !tight;
             bkey = qkey[owner][lane];
+        };
+        auto load_owner_boxes = [&](int owner) __attribute__((always_inline)) {
 #pragma unroll
             for (int k = 0; k < NN_STAGE; ++k) ta[k] = wcentre[owner][k];
             qminx = wbox[owner][0]; qminy = wbox[owner][1]; qminz = wbox[owner][2];
@@ -1297,11 +1361,72 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             lminx = wbox[owner][6]; lminy = wbox[owner][7]; lminz = wbox[owner][8];
             lmaxx = wbox[owner][9]; lmaxy = wbox[owner][10]; lmaxz = wbox[owner][11];
             any_loose = wbox[owner][12] != 0.0f;
-            sweep_cell(cc);
-            if (valid) atomicMin(&qkey[owner][lane], bkey);
-            if (lane == 0) atomicAdd(&wcost[owner], (int)(clock64() - ci0));
+        };
+        // ---- phase A: listed cell items -> tile items (blocks without listed cells skip it and its barrier)
+        const int ncell = __builtin_amdgcn_readfirstlane(min(n_items, NN_MAX_ITEMS));     // same in every wave of the block
+        const int achunk = ncell > NN_WAVES ? 2 : 1;
+        while (ncell > 0) {
+            const int it = lds_fetch_add_uniform(&next_item, achunk);
+            if (it >= ncell) break;
+            const long long ci0 = clock64();
+            const int item0 = __builtin_amdgcn_readfirstlane(items[it]);          // one address for the wave: owner and cell are scalars
+            const bool two = achunk == 2 && it + 1 < ncell;
+            const int item1 = two ? __builtin_amdgcn_readfirstlane(items[it + 1]) : item0;
+            float4 lo0, hi0, lo1 = make_float4(inf, inf, inf, 0), hi1 = make_float4(-inf, -inf, -inf, 0);
+            int ctx0, cty0, ctx1 = 0, cty1 = 0;
+            cell_boxes(item0 & 0xffff, lo0, hi0, ctx0, cty0);
+            if (two) cell_boxes(item1 & 0xffff, lo1, hi1, ctx1, cty1);            // both loads in flight before the first use
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                if (half == 1 && !two) break;
+                const int owner = (half ? item1 : item0) >> 16;
+                if constexpr (DBG) n_my_items += 1;
+                load_owner(owner);
+                load_owner_boxes(owner);
+                const int ctx = half ? ctx1 : ctx0, cty = half ? cty1 : cty0;
+                if (append_tiles(owner, cell_refine(half ? lo1 : lo0, half ? hi1 : hi0, ctx, cty), ctx, cty) && valid)
+                    atomicMin(&qkey[owner][lane], bkey);
+            }
+            if (lane == 0) atomicAdd(&wcost[item0 >> 16], (int)(clock64() - ci0));
+        }
+        if constexpr (DBG) clkD = clock64();
+        if (ncell > 0) __syncthreads();               // ncell is uniform over the block (read after barrier 1)
+    }
+    if constexpr (DBG) clkM = clock64();
+    if constexpr (COOP) {
+        // ---- phase B: tile items of any owner, NN_STAGE records in flight per trip
+        const int ntile = __builtin_amdgcn_readfirstlane(min(n_titems, NN_MAX_TITEMS));
+        // tiles per trip: enough for every wave to get a share, at most NN_STAGE records in flight
+        const int bchunk = ntile <= NN_WAVES ? 1 : (ntile <= 2 * NN_WAVES ? 2 : NN_STAGE);
+        while (true) {
+            const int it = lds_fetch_add_uniform(&next_titem, bchunk);
+            if (it >= ntile) break;
+            const long long ci0 = clock64();
+            int own[NN_STAGE];
+#pragma unroll
+            for (int k = 0; k < NN_STAGE; ++k) {
+                const int e = (k < bchunk && it + k < ntile) ? __builtin_amdgcn_readfirstlane(titems[it + k]) : -1;
+                tt[k] = e >= 0 ? (e & 0xffffff) : -1;
+                own[k] = e >= 0 ? (e >> 24) : 0;
+            }
+            fetch_batch();
+            park();
+            hinted = true;              // the cell sweep already tested these tiles' boxes: go straight to the quadrant tests
+#pragma unroll
+            for (int k = 0; k < NN_STAGE; ++k) {
+                if (tt[k] < 0) continue;
+                px = qpos[own[k]][0][lane]; py = qpos[own[k]][1][lane]; pz = qpos[own[k]][2][lane];
+                valid = (qcls[own[k]][0] >> lane) & 1ull;
+                bkey = qkey[own[k]][lane];                     // the owner's best so far, every earlier merge included
+                scan_staged(k, tt[k]);
+                if (valid) atomicMin(&qkey[own[k]][lane], bkey);
+            }
+            hinted = false;
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) atomicAdd(&wcost[own[0]], (int)(clock64() - ci0));
         }
     }
+    if constexpr (DBG) clkE = clock64();
     if constexpr (COOP) __syncthreads();
     if constexpr (DBG) clk3 = clock64();
     if (!has_tile) return;
@@ -1331,16 +1456,20 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         }
     }
     if (DBG && dbg && b == 0 && lane == 0) {
-        long long *d = dbg + (size_t)t * 8;
+        long long *d = dbg + (size_t)t * 20;
         d[0] = clk0; d[1] = clk1; d[2] = clk2; d[3] = clk3; d[4] = clock64();
         d[5] = n_scanned | ((long long)n_chit << 32); d[6] = n_cand | ((long long)n_fhit << 32);
         d[7] = n_batches | ((long long)n_refined << 32);
-        // where the wave ran: HW_ID (wave / simd / cu / sh / se fields) and the XCC id
+        // where the wave ran: HW_ID (wave / simd / cu / sh / se fields) and the XCC id; when: the constant-rate
+        // (100 MHz) real-time counter, which unlike s_memtime is common to all dies
         unsigned int hw_id, xcc_id;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
-        dbg[(size_t)tg.ntiles * 8 + (size_t)t * 2] = (long long)hw_id | ((long long)xcc_id << 32);
-        dbg[(size_t)tg.ntiles * 8 + (size_t)t * 2 + 1] = (long long)c * NN_WAVES + w;
+        d[8] = (long long)hw_id | ((long long)xcc_id << 32);
+        d[9] = (long long)c * NN_WAVES + w;
+        d[10] = rt0; d[11] = (long long)wall_clock64();
+        d[12] = clkP; d[13] = clkB1; d[14] = clkD; d[15] = (long long)n_my_items | ((long long)(COOP ? n_items : 0) << 32);
+        d[16] = clkM; d[17] = clkE; d[18] = COOP ? n_titems : 0; d[19] = 0;
     }
 }
 

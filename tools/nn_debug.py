@@ -17,14 +17,19 @@ for it in (1, iters):
         h.align(s4, t4)
         d = h.get_nn_debug()
     act = d[:, 4] > 0
-    d = d[act]
-    t0 = d[:, 0].min()
-    print(f"--- last of {it} iteration(s): {act.sum()} active waves; launch span (first start -> last end) {d[:, 4].max() - t0} clk")
+    d = d[act].copy()
+    rt0 = d[:, 10].min()
+    rs, re_ = (d[:, 10] - rt0) * 10, (d[:, 11] - rt0) * 10          # ns since the first wave started (100 MHz counter)
+    t0 = 0
+    print(f"--- last of {it} iteration(s): {act.sum()} active waves; launch span (first start -> last end) {re_.max()} ns")
     d1 = d[d[:, 1] > 0]
     lo32 = lambda x: x & 0xffffffff
     hi32 = lambda x: x >> 32
-    for name, v in (("lifetime", d1[:, 4] - d1[:, 0]), ("start - t0", d1[:, 0] - t0), ("end - t0", d1[:, 4] - t0), ("prologue", d1[:, 1] - d1[:, 0]), ("own 5 tiles", d1[:, 2] - d1[:, 1]),
+    for name, v in (("lifetime", d1[:, 4] - d1[:, 0]), ("start ns", rs[d[:, 1] > 0]), ("end ns", re_[d[:, 1] > 0]), ("prologue", d1[:, 1] - d1[:, 0]), ("own 5 tiles", d1[:, 2] - d1[:, 1]),
                     ("publish+items (to barrier 2)", d1[:, 3] - d1[:, 2]),
+                    ("  publish", d1[:, 12] - d1[:, 2]), ("  wait barrier 1", d1[:, 13] - d1[:, 12]), ("  phase A (cells)", d1[:, 14] - d1[:, 13]),
+                    ("  wait barrier A", d1[:, 16] - d1[:, 14]), ("  phase B (tiles)", d1[:, 17] - d1[:, 16]), ("  wait barrier 2", d1[:, 3] - d1[:, 17]),
+                    ("  cells done by wave", lo32(d1[:, 15])), ("  cell items of block", hi32(d1[:, 15])), ("  tile items of block", d1[:, 18]),
                     ("epilogue", d1[:, 4] - d1[:, 3]), ("tiles scanned", lo32(d1[:, 5])), ("candidates", lo32(d1[:, 6])), ("batches", lo32(d1[:, 7])),
                     ("cells swept", hi32(d1[:, 5])), ("fine hits", hi32(d1[:, 6])), ("refined hits", hi32(d1[:, 7]))):
         print(f"{name:14s} mean {v.mean():10.1f}  p50 {np.percentile(v,50):9.0f}  p90 {np.percentile(v,90):9.0f}  p99 {np.percentile(v,99):9.0f}  max {v.max():9.0f}")
@@ -32,7 +37,7 @@ for it in (1, iters):
     xcc = (d[:, 8] >> 32) & 0xf
     cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 0x1; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 0x3
     cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
-    end = d[:, 4] - t0
+    end = re_
     print("per XCD: waves, mean end, max end, sum lifetime")
     for x in range(8):
         m = xcc == x
