@@ -8,12 +8,13 @@
 #include <cstring>
 #include <iostream>
 #include <sstream>
+#include <thread>
 
 #include "png16.h"
 
 using namespace std;
 
-RESULT_OF_MULTIPNP::RESULT_OF_MULTIPNP() : norm(0.0), inliers(0) { mat4_identity(T); }
+RESULT_OF_MULTIPNP::RESULT_OF_MULTIPNP() : norm(0.0), inliers(0), rmse(0.0), n_src(0) { mat4_identity(T); }
 
 bool RESULT_OF_MULTIPNP::isIdentity() const
 {
@@ -56,7 +57,7 @@ GraphicEndICP::GraphicEndICP()
 
 GraphicEndICP::~GraphicEndICP()
 {
-    if (_icp) slam3d_icp_destroy(_icp);
+    for (size_t k = 0; k < _devs.size(); ++k) if (_devs[k].icp) slam3d_icp_destroy(_devs[k].icp);
     delete _reader;
     if (g_pParaReader == _reader) g_pParaReader = nullptr;
 }
@@ -108,12 +109,40 @@ void GraphicEndICP::init(const string &param_file)
     _max_batch = _loopclosure_frames + 2;              // random candidates + the two adjacent keyframes, one launch
     if (_max_batch < 1) _max_batch = 1;
     _params.max_batch = _max_batch;
-    _params.device = _reader->GetInt("hip_device", 0);
-    const int rc = slam3d_icp_create(&_params, &_icp);
-    if (rc != SLAM3D_OK) {
-        cerr << "slam3d_icp_create failed: " << slam3d_strerror(rc) << endl;
-        exit(1);                                                   // the reference exits on fatal config errors (:113)
+    // ICP-meaningful acceptance: overlap ratio inliers / n_src and the RMS residual, beside the reference's
+    // inlier-count / norm thresholds; 0 switches a gate off
+    _min_inlier_ratio = _reader->GetDouble("icp_min_inlier_ratio", 0.3);
+    _max_rmse = _reader->GetDouble("icp_max_rmse", 0.05);
+    _loop_min_inlier_ratio = _reader->GetDouble("icp_loop_min_inlier_ratio", 0.6);
+    _loop_max_rmse = _reader->GetDouble("icp_loop_max_rmse", 0.02);
+    _plane_gate = _reader->Has("icp_plane_gate") && _reader->GetPara("icp_plane_gate") == "yes";
+    _plane_match_dist = _reader->GetDouble("icp_plane_match_dist", 0.15);
+    // one handle per GPU: hip_devices = N (or "all"), starting at hip_device; resident frame slots beyond the batch
+    const int first_dev = _reader->GetInt("hip_device", 0);
+    int ndev = 1;
+    if (_reader->Has("hip_devices"))
+        ndev = _reader->GetPara("hip_devices") == "all" ? slam3d_device_count() - first_dev : _reader->GetInt("hip_devices", 1);
+    if (ndev < 1) ndev = 1;
+    _params.extra_frames = _max_batch + 8;
+    // hip_devices_share: yes (tests): all handles on the first GPU -- the threaded sharding path on a one-GPU box
+    const bool share = _reader->Has("hip_devices_share") && _reader->GetPara("hip_devices_share") == "yes";
+    for (int k = 0; k < ndev; ++k) {
+        Device d;
+        d.device = share ? first_dev : first_dev + k;
+        _params.device = d.device;
+        const int rc = slam3d_icp_create(&_params, &d.icp);
+        if (rc != SLAM3D_OK) {
+            cerr << "slam3d_icp_create (device " << d.device << ") failed: " << slam3d_strerror(rc) << endl;
+            if (k == 0) exit(1);                                   // the reference exits on fatal config errors (:113)
+            break;                                                 // fewer GPUs than asked for: go on with what there is
+        }
+        d.first_frame = 2 * _max_batch;
+        d.key.assign(_params.extra_frames, -1);
+        d.used.assign(_params.extra_frames, 0);
+        _devs.push_back(d);
     }
+    _icp = _devs[0].icp;
+    cout << "ICP front end on " << _devs.size() << " GPU(s)" << endl;
     _errorfile.open("./data/error_of_transform.log");              // src/GraphicEnd.cpp:153
     _trajfile.open("./data/trajectory_icp.txt");
     _lcfile.open("./data/lc.txt");                                 // displayLC, src/GraphicEnd.cpp:843
@@ -199,64 +228,144 @@ int GraphicEndICP::readimage()
     return 0;
 }
 
-RESULT_OF_MULTIPNP GraphicEndICP::multiPnP(FRAME &frame1, FRAME &frame2, bool /*loopclosure*/, int /*frame_index*/,
+RESULT_OF_MULTIPNP GraphicEndICP::multiPnP(FRAME &frame1, FRAME &frame2, bool loopclosure, int /*frame_index*/,
                                            int minimum_inliers)
 {
     vector<const FRAME *> a(1, &frame1), b(1, &frame2);
-    return multiPnPBatch(a, b, minimum_inliers)[0];
+    return multiPnPBatch(a, b, minimum_inliers, loopclosure)[0];
+}
+
+// resident slot of frame f on device d (uploaded when absent; least recently used slot evicted, never one of the
+// current batch: those carry the stamp `pin`)
+int GraphicEndICP::residentFrame(Device &d, const FRAME &f, unsigned long long pin)
+{
+    int free_slot = -1, lru = -1;
+    for (size_t k = 0; k < d.key.size(); ++k) {
+        if (d.key[k] == f.frame_index) { d.used[k] = pin; return d.first_frame + (int)k; }
+        if (d.key[k] < 0) { if (free_slot < 0) free_slot = (int)k; }
+        else if (d.used[k] != pin && (lru < 0 || d.used[k] < d.used[lru])) lru = (int)k;
+    }
+    const int victim = free_slot >= 0 ? free_slot : lru;
+    if (victim < 0) return -1;
+    if (slam3d_icp_frame_set_depth_host(d.icp, d.first_frame + victim, f.depth.data()) != SLAM3D_OK) return -1;
+    d.key[victim] = f.frame_index;
+    d.used[victim] = pin;
+    return d.first_frame + victim;
+}
+
+void GraphicEndICP::alignOnDevice(Device &d, const vector<const FRAME *> &f1, const vector<const FRAME *> &f2, int b0, int b1,
+                                  int minimum_inliers, bool loopclosure, vector<RESULT_OF_MULTIPNP> &out)
+{
+    for (int c0 = b0; c0 < b1; c0 += _max_batch) {
+        const int nb = min(_max_batch, b1 - c0);
+        const unsigned long long pin = ++d.clock;
+        bool ok = true;
+        for (int k = 0; k < nb && ok; ++k) {
+            const int fs = residentFrame(d, *f1[c0 + k], pin), ft = residentFrame(d, *f2[c0 + k], pin);
+            ok = fs >= 0 && ft >= 0 && slam3d_icp_set_pair(d.icp, k, fs, ft) == SLAM3D_OK;
+        }
+        vector<slam3d_icp_result> res(nb);
+        int rc = ok ? slam3d_icp_run(d.icp, nb, nullptr, nullptr) : SLAM3D_E_STATE;
+        if (rc == SLAM3D_OK) rc = slam3d_icp_fetch_results(d.icp, nb, res.data());
+        if (rc < 0) {
+            cerr << "slam3d_icp (device " << d.device << "): " << slam3d_strerror(rc) << " " << slam3d_last_error(d.icp) << endl;
+            continue;                                              // results stay Identity = "not matched"
+        }
+        const double min_ratio = loopclosure ? _loop_min_inlier_ratio : _min_inlier_ratio;
+        const double max_rmse = loopclosure ? _loop_max_rmse : _max_rmse;
+        for (int k = 0; k < nb; ++k) {
+            RESULT_OF_MULTIPNP &r = out[c0 + k];
+            r.inliers = res[k].inliers;
+            r.norm = res[k].norm;
+            r.rmse = res[k].rmse;
+            r.n_src = res[k].n_src;
+            // thresholds of multiPnP: inliers (src/GraphicEnd.cpp:599), norm (:621); plus what makes an ICP result
+            // trustworthy: enough of the source overlaps (ratio) and the residual is at noise level (rmse)
+            bool good = res[k].status == SLAM3D_OK && res[k].inliers >= minimum_inliers;
+            if (good && min_ratio > 0.0 && r.n_src > 0 && (double)r.inliers < min_ratio * (double)r.n_src) good = false;
+            if (good && max_rmse > 0.0 && r.rmse > max_rmse) good = false;
+            if (good && !planeGate(*f1[c0 + k], *f2[c0 + k], res[k].T)) good = false;
+            if (good) memcpy(r.T, res[k].T, sizeof r.T);
+        }
+    }
 }
 
 vector<RESULT_OF_MULTIPNP> GraphicEndICP::multiPnPBatch(const vector<const FRAME *> &f1, const vector<const FRAME *> &f2,
-                                                        int minimum_inliers)
+                                                        int minimum_inliers, bool loopclosure)
 {
     const int B = (int)f1.size();
     vector<RESULT_OF_MULTIPNP> out(B);
-    for (int b0 = 0; b0 < B; b0 += _max_batch) {
-        const int nb = min(_max_batch, B - b0);
-        vector<const uint16_t *> s(nb), t(nb);
-        for (int k = 0; k < nb; ++k) { s[k] = f1[b0 + k]->depth.data(); t[k] = f2[b0 + k]->depth.data(); }
-        vector<slam3d_icp_result> res(nb);
-        const int rc = slam3d_icp_align_depth_batch(_icp, nb, s.data(), t.data(), nullptr, res.data());
-        if (rc < 0) {
-            cerr << "slam3d_icp_align_depth_batch: " << slam3d_strerror(rc) << " " << slam3d_last_error(_icp) << endl;
-            continue;                                              // results stay Identity = "not matched"
+    const int ndev = (int)min<size_t>(_devs.size(), (size_t)max(B, 1));
+    if (ndev <= 1) {
+        alignOnDevice(_devs[0], f1, f2, 0, B, minimum_inliers, loopclosure, out);
+    } else {
+        // pairs are independent: contiguous blocks per GPU, one host thread each, no exchange but
+        // the results (host memory shared by the threads -- the in-process counterpart of the RCCL pose gather)
+        vector<thread> th;
+        for (int k = 0; k < ndev; ++k) {
+            int b0 = 0, b1 = 0;
+            slam3d_shard_range(B, ndev, k, &b0, &b1);
+            th.emplace_back([this, k, b0, b1, &f1, &f2, minimum_inliers, loopclosure, &out]() {
+                alignOnDevice(_devs[k], f1, f2, b0, b1, minimum_inliers, loopclosure, out);
+            });
         }
-        for (int k = 0; k < nb; ++k) {
-            RESULT_OF_MULTIPNP &r = out[b0 + k];
-            r.inliers = res[k].inliers;
-            r.norm = res[k].norm;
-            // thresholds of multiPnP: inliers (src/GraphicEnd.cpp:599), norm (:621); library used params.min_inliers
-            const bool ok = res[k].status == SLAM3D_OK && res[k].inliers >= minimum_inliers;
-            if (ok) memcpy(r.T, res[k].T, sizeof r.T);
-            cout << "multiICP::inliers = " << r.inliers << ", norm = " << r.norm << ", status = " << res[k].status << endl;
-        }
+        for (size_t k = 0; k < th.size(); ++k) th[k].join();
     }
+    for (int b = 0; b < B; ++b)
+        cout << "multiICP::inliers = " << out[b].inliers << " / " << out[b].n_src << ", norm = " << out[b].norm << ", rmse = " << out[b].rmse
+             << (out[b].isIdentity() ? " (rejected)" : "") << endl;
     return out;
 }
 
-void GraphicEndICP::generateKeyFrame(const double *T)
+bool GraphicEndICP::planeGate(const FRAME &frame1, const FRAME &frame2, const double *T)
+{
+    if (!_plane_gate || frame1.planes.empty() || frame2.planes.empty()) return true;
+    // planes of frame 1 in frame-2 coordinates: X_2 = R X_1 + t  =>  n' = R n, d' = d - n'.t, sign rule d' >= 0 (:383-387)
+    vector<slam3d_plane> moved(frame1.planes);
+    for (size_t i = 0; i < moved.size(); ++i) {
+        const float *c = frame1.planes[i].coeff;
+        double n[3];
+        for (int r = 0; r < 3; ++r) n[r] = (T[r * 4] * c[0] + T[r * 4 + 1] * c[1]) + T[r * 4 + 2] * c[2];
+        double d = c[3] - ((n[0] * T[3] + n[1] * T[7]) + n[2] * T[11]);
+        if (d < 0.0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; d = -d; }
+        moved[i].coeff[0] = (float)n[0]; moved[i].coeff[1] = (float)n[1]; moved[i].coeff[2] = (float)n[2]; moved[i].coeff[3] = (float)d;
+    }
+    const vector<int> idx = match(moved, frame2.planes);           // GraphicEnd::match(vector<PLANE>&, vector<PLANE>&), :459-484
+    int matched = 0;
+    for (size_t i = 0; i < moved.size(); ++i) {
+        if (idx[i] < 0) continue;
+        double d2 = 0.0;
+        for (int k = 0; k < 4; ++k) { const double e = (double)moved[i].coeff[k] - frame2.planes[idx[i]].coeff[k]; d2 += e * e; }
+        if (sqrt(d2) <= _plane_match_dist) matched++;
+    }
+    return matched >= 1;
+}
+
+void GraphicEndICP::generateKeyFrame(const double *T, int frame_index)
 {
     // T maps the current keyframe's pose to the present one (src/GraphicEnd.cpp:304-351); the g2o vertex/edge the
     // reference adds there becomes a stored pose here (pose-graph back end is out of scope)
     _currKF = _present;
     _currKF.id = (int)_keyframes.size();
-    _currKF.frame_index = _index;
+    _currKF.frame_index = frame_index >= 0 ? frame_index : _index;      // (the last-frame branch stamps _index - 1, :198)
+    // T = inverse of the multiPnP result = pose of this camera in the previous keyframe's frame, so the
+    // camera-to-world chain is kf_pos * T -- the EdgeSE3 convention the g2o vertices below use.  (The reference
+    // writes T * _kf_pos, :231,:245; there the value only feeds the viewer.)
     double P[16];
-    mat4_mul(T, _kf_pos, P);
+    mat4_mul(_kf_pos, T, P);
     memcpy(_kf_pos, P, sizeof P);
     _keyframes.push_back(_currKF);
     _kf_poses.push_back(vector<double>(_kf_pos, _kf_pos + 16));
     // VertexSE3 + EdgeSE3(previous keyframe -> this one, measurement T, information 100) (:319-338).  The
     // reference starts every vertex at Identity (:325); here the initial estimate is the chain of the edge
     // measurements (V_new = V_prev * T, the EdgeSE3 convention), so the file is consistent before optimisation.
-    mat4_mul(_graph_pose, T, _graph_pose);
+    memcpy(_graph_pose, _kf_pos, sizeof _graph_pose);
     _graph.addVertex(_currKF.id, _graph_pose);
     _graph.addEdge(_currKF.id - 1, _currKF.id, T, 100.0);
 }
 
 vector<int> GraphicEndICP::match(const vector<slam3d_plane> &p1, const vector<slam3d_plane> &p2)
 {
-    cout << "GraphicEnd::match two planes" << endl;                // src/GraphicEnd.cpp:461
     vector<int> idx(p1.size(), -1);
     if (!p1.empty()) slam3d_match_planes(p1.data(), (int)p1.size(), p2.data(), (int)p2.size(), idx.data(), nullptr);
     return idx;
@@ -264,6 +373,8 @@ vector<int> GraphicEndICP::match(const vector<slam3d_plane> &p1, const vector<sl
 
 bool GraphicEndICP::acceptLoop(const RESULT_OF_MULTIPNP &r) const
 {
+    // the reference's three tests (:701-706); the overlap-ratio / rmse / plane gates were applied by multiPnPBatch
+    // (loopclosure = true) and show up here as T == Identity
     return !r.isIdentity() && r.norm <= _loop_closure_error && r.inliers >= _loop_closure_inliers;
 }
 
@@ -293,7 +404,7 @@ void GraphicEndICP::loopClosure()
     }
     vector<const FRAME *> f1(cand.size()), f2(cand.size(), &_currKF);
     for (size_t k = 0; k < cand.size(); ++k) f1[k] = &_keyframes[cand[k]];
-    vector<RESULT_OF_MULTIPNP> res = multiPnPBatch(f1, f2, _loop_closure_inliers);
+    vector<RESULT_OF_MULTIPNP> res = multiPnPBatch(f1, f2, _loop_closure_inliers, true);
     for (size_t k = 0; k < cand.size(); ++k) {
         if (!acceptLoop(res[k])) continue;
         double Ti[16];
@@ -320,12 +431,13 @@ void GraphicEndICP::lostRecovery()
     fout.close();
     _keyframes.push_back(_currKF);
     _kf_poses.push_back(vector<double>(_kf_pos, _kf_pos + 16));
+    memcpy(_graph_pose, _kf_pos, sizeof _graph_pose);
     _graph.addVertex(_currKF.id, _graph_pose);                     // no edge to the predecessor: position unknown (:793)
     // against every earlier keyframe (:808-836): independent pairs, batched
     const int n = (int)_keyframes.size() - 1;
     vector<const FRAME *> f1(n), f2(n, &_currKF);
     for (int i = 0; i < n; ++i) f1[i] = &_keyframes[i];
-    vector<RESULT_OF_MULTIPNP> res = multiPnPBatch(f1, f2);
+    vector<RESULT_OF_MULTIPNP> res = multiPnPBatch(f1, f2, _loop_closure_inliers, true);
     for (int i = 0; i < n; ++i) {
         if (!acceptLoop(res[i])) continue;
         double Ti[16];
@@ -403,7 +515,7 @@ int GraphicEndICP::run()
             mat4_inverse_rigid(rr.T, Tl);
             FRAME keep = _present;
             _present = _last;
-            generateKeyFrame(Tl);
+            generateKeyFrame(Tl, _last.frame_index);                // _index - 1 in the reference (:198)
             _present = keep;
             double Tp[16];
             mat4_inverse_rigid(r.T, Tp);
@@ -413,14 +525,14 @@ int GraphicEndICP::run()
         }
     } else if (result.norm > _max_pos_change) {
         _errorfile << result.norm << endl;                          // :232
-        mat4_mul(T, _kf_pos, _robot);
+        mat4_mul(_kf_pos, T, _robot);
         generateKeyFrame(T);
         if (_loop_closure_detection) loopClosure();                // :236-237
         _lost = 0;
         _last = _present;
     } else {
         _errorfile << result.norm << endl;                          // :243
-        mat4_mul(T, _kf_pos, _robot);
+        mat4_mul(_kf_pos, T, _robot);
         _lost = 0;
         _last = _present;
     }

@@ -25,6 +25,10 @@ struct RESULT_OF_MULTIPNP {
     double T[16];
     double norm;
     int inliers;
+    // what an ICP "inlier" count needs beside it to be discriminative: the reference's inliers were
+    // descriptor matches that survived PnP RANSAC, an ICP inlier is any source pixel with a target within the gate
+    double rmse;                      // point-to-plane RMS residual of the inliers at the last iteration
+    int n_src;                        // valid source points: inliers / n_src is the overlap ratio
     bool isIdentity() const;          // the reference's failure test (src/GraphicEnd.cpp:173)
 };
 
@@ -49,7 +53,7 @@ class GraphicEndICP {
     virtual void init(const std::string &param_file = "./parameters.yaml");   // src/GraphicEnd.cpp:77-148
     virtual int run();                                                         // src/GraphicEnd.cpp:150-264
     virtual int readimage();                                                   // src/GraphicEnd.cpp:266-302
-    virtual void generateKeyFrame(const double *T);                            // src/GraphicEnd.cpp:304-351
+    virtual void generateKeyFrame(const double *T, int frame_index = -1);      // src/GraphicEnd.cpp:304-351 (-1: the current _index)
     virtual void saveFinalResult(const std::string &fileaddr);                 // src/GraphicEnd.cpp:661-682
     virtual void loopClosure();                                                // src/GraphicEnd.cpp:685-762
     virtual void lostRecovery();                                               // src/GraphicEnd.cpp:764-838
@@ -63,9 +67,14 @@ class GraphicEndICP {
     // same call shape and defaults as GraphicEnd::multiPnP (src/GraphicEnd.h:134)
     virtual RESULT_OF_MULTIPNP multiPnP(FRAME &frame1, FRAME &frame2, bool loopclosure = false, int frame_index = 0,
                                         int minimum_inliers = 12);
-    // loop-closure candidates are independent pairs: one batched call (src/GraphicEnd.cpp:685-762)
+    // loop-closure candidates are independent pairs (src/GraphicEnd.cpp:685-762): one batched launch per GPU, the
+    // batch dealt over the GPUs in contiguous blocks (slam3d_shard_range), one host thread per GPU
     std::vector<RESULT_OF_MULTIPNP> multiPnPBatch(const std::vector<const FRAME *> &f1, const std::vector<const FRAME *> &f2,
-                                                  int minimum_inliers = 12);
+                                                  int minimum_inliers = 12, bool loopclosure = false);
+    // plane-association gate (rows a9/a11): the planes of frame1 carried into frame2 by T must meet planes of frame2
+    // (GraphicEnd::match on (a,b,c,d), src/GraphicEnd.cpp:459-484); true when the gate is off or a frame has no planes
+    virtual bool planeGate(const FRAME &frame1, const FRAME &frame2, const double *T);
+    int deviceCount() const { return (int)_devs.size(); }
 
     int index() const { return _index; }
     const double *robot() const { return _robot; }
@@ -76,7 +85,23 @@ class GraphicEndICP {
 
  protected:
     ParameterReader *_reader = nullptr;
-    slam3d_icp_handle *_icp = nullptr;
+    slam3d_icp_handle *_icp = nullptr;               // = _devs[0].icp: the single-frame calls (planes, voxel grid)
+    // one handle per GPU (hip_devices); each keeps the depth frames it has seen RESIDENT (frame id = frame_index):
+    // a keyframe is uploaded and preprocessed once, not once per multiPnP call
+    struct Device {
+        slam3d_icp_handle *icp = nullptr;
+        int device = 0, first_frame = 0;
+        std::vector<int> key;                        // resident slot -> frame_index (-1 free)
+        std::vector<unsigned long long> used;        // LRU stamps
+        unsigned long long clock = 0;
+    };
+    std::vector<Device> _devs;
+    int residentFrame(Device &d, const FRAME &f, unsigned long long pin);
+    void alignOnDevice(Device &d, const std::vector<const FRAME *> &f1, const std::vector<const FRAME *> &f2, int b0, int b1,
+                       int minimum_inliers, bool loopclosure, std::vector<RESULT_OF_MULTIPNP> &out);
+    double _min_inlier_ratio = 0.3, _max_rmse = 0.05;             // tracking gates (icp_min_inlier_ratio, icp_max_rmse)
+    double _loop_min_inlier_ratio = 0.6, _loop_max_rmse = 0.02;   // loop-closure gates (icp_loop_min_inlier_ratio, icp_loop_max_rmse)
+    bool _plane_gate = false; double _plane_match_dist = 0.15;    // icp_plane_gate, icp_plane_match_dist
     slam3d_icp_params _params;
     std::string _depPath;
     std::ofstream _errorfile, _trajfile;

@@ -132,3 +132,61 @@ def test_oracle_reproduces_reference_golden():
     c = G["real_pair_dep1_to_dep2"]["0"]
     r = O.icp(c1, c2, O.params(intr, estimator=0, iterations=c["iterations"], nn_method=1))
     _check(c, r["n_src"], r["n_tgt"], r["inliers"], r["status"], r["norm"], r["T_trace"][-1], r["sums_trace"][-1], r["idx"], r["d2"])
+
+
+KINECT = os.path.join(HERE, "golden", "kinect")
+
+
+def _kinect():
+    return (_read_png16(os.path.join(KINECT, "exp1_dep_1.png")), _read_png16(os.path.join(KINECT, "exp1_dep_2.png")),
+            _read_png16(os.path.join(KINECT, "bin_dep_1.png")))
+
+
+def test_oracle_on_committed_kinect_frames_reproduces_reference_golden():
+    """The same check as above on the committed copies of the reference's three depth images (runs everywhere)."""
+    G = json.load(open(os.path.join(HERE, "golden", "reference_golden.json")))
+    d1, d2, db = _kinect()
+    assert int((d1 > 0).sum()) == 221202 and int((d2 > 0).sum()) == 236128 and int((db > 0).sum()) == 201063
+    p = O.params(synth.Intrinsics())
+    c1, c2, cb = (O.backproject(d, p) for d in (d1, d2, db))
+    assert sha(c1) == G["backproject_sha256"]["dep1"] and sha(c2) == G["backproject_sha256"]["dep2"]
+    nb = O.normals(cb, p)
+    assert sha(nb) == G["config1_bin_dep_1"]["normals_sha256"]
+
+
+@pytest.mark.gpu
+def test_hip_path_on_real_kinect_frames(gpu_lib):
+    """SURVEY.md 8(c) golden (3): the HIP path on REAL sensor frames.  dep/1 -> dep/2 is a wide-baseline pair (plain ICP
+    from identity does not converge to a unique answer there), so this is an EQUALITY test, not an
+    accuracy test: every iterate, the 29 sums of every iteration and the last correspondences bit-identical to the
+    oracle, for both estimators; the target normals of BASELINE config 1's frame (bin/dep_1.png) through k_normals
+    bit-identical too."""
+    from slam3d_gx_amd import capi
+    G = json.load(open(os.path.join(HERE, "golden", "reference_golden.json")))
+    d1, d2, db = _kinect()
+    intr = synth.Intrinsics()
+    for est in (0, 1):
+        c = G["real_pair_dep1_to_dep2"][str(est)] if str(est) in G["real_pair_dep1_to_dep2"] else None
+        iters = c["iterations"] if c else 12
+        with capi.IcpHandle(capi.default_params(intr, estimator=est, iterations=iters)) as h:
+            r = h.align_depth_batch([d1], [d2])[0]
+            Tt, St = h.get_trace(0)
+            idx, d2c = h.get_correspondences(0)
+            s_dev, t_dev, n_dev = h.get_clouds(0, normals=(est == 0))
+        p = O.params(intr, estimator=est, iterations=iters, nn_method=1)
+        c1, c2 = O.backproject(d1, p), O.backproject(d2, p)
+        assert np.array_equal(s_dev.view(np.uint32), c1.view(np.uint32)) and np.array_equal(t_dev.view(np.uint32), c2.view(np.uint32))
+        ro = O.icp(c1, c2, p)
+        assert np.array_equal(ro["T_trace"], Tt) and np.array_equal(ro["sums_trace"], St)
+        assert np.array_equal(ro["idx"], idx) and np.array_equal(ro["d2"].view(np.uint32), d2c.view(np.uint32))
+        assert r["inliers"] == ro["inliers"] and r["status"] == ro["status"] and r["n_src"] == ro["n_src"] and r["n_tgt"] == ro["n_tgt"]
+        if est == 0:
+            assert sha(n_dev) == sha(O.normals(c2, p))
+        if c:
+            _check(c, r["n_src"], r["n_tgt"], r["inliers"], r["status"], r["norm"], Tt[-1], St[-1], idx, d2c)
+    # config 1's frame: normals of bin/dep_1.png on the device == the golden hash the oracle produced
+    with capi.IcpHandle(capi.default_params(intr, iterations=1)) as h:
+        h.align_depth_batch([db], [db])
+        _, _, nb = h.get_clouds(0)
+    assert sha(nb) == G["config1_bin_dep_1"]["normals_sha256"]
+    assert int((nb[..., 3] > 0).sum()) == G["config1_bin_dep_1"]["planar_pixels"]

@@ -41,6 +41,7 @@ image_height: {h}
 icp_iterations: 15
 icp_extract_planes: {planes}
 icp_read_pcd: {pcd}
+{extra}
 """
 
 
@@ -61,7 +62,7 @@ def test_png_and_parameter_readers(tmp_path):
     png = tmp_path / "d.png"
     _write_png16(str(png), pr.depth_src)
     yml = tmp_path / "parameters.yaml"
-    yml.write_text(PARAMS.format(src="/data/x", mpc=0.25, fx=517.0, fy=517.0, cx=318.6, cy=255.3, w=320, h=240, lc="no", planes="no", pcd="no"))
+    yml.write_text(PARAMS.format(src="/data/x", mpc=0.25, fx=517.0, fy=517.0, cx=318.6, cy=255.3, w=320, h=240, lc="no", planes="no", pcd="no", extra=""))
     out = subprocess.run([os.path.join(HOST, "host_selftest"), str(png), str(yml)], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     lines = out.stdout.strip().splitlines()
@@ -126,7 +127,7 @@ def test_generate_trajectory_tool(tmp_path):
     (tmp_path / "ds").mkdir()
     (tmp_path / "ds" / "associate.txt").write_text("".join(f"{1305031102.1 + 0.03 * k:.6f} rgb/{k}.png {1305031102.2 + 0.03 * k:.6f} depth/{k}.png\n" for k in range(6)))
     (tmp_path / "parameters.yaml").write_text(PARAMS.format(src=str(tmp_path / "ds"), mpc=0.25, fx=525.0, fy=525.0, cx=319.5, cy=239.5,
-                                                            w=640, h=480, lc="no", planes="no", pcd="no"))
+                                                            w=640, h=480, lc="no", planes="no", pcd="no", extra=""))
     h = np.sqrt(0.5)
     (tmp_path / "final.g2o").write_text(
         "VERTEX_SE3:QUAT 0 0 0 0 0 0 0 1\nVERTEX_SE3:QUAT 1 0.5 -0.25 1.5 0 0 %.17g %.17g\nFIX 0\n"
@@ -159,7 +160,7 @@ def test_run_slam_driver_tracks_synthetic_sequence(gpu_lib, tmp_path):
         d = synth.render_depth(P, intr, 4242, 10 + k, hole_block=hb)
         _write_png16(str(data / "dep_index" / f"{k + 1}.png"), d)
     (tmp_path / "parameters.yaml").write_text(
-        PARAMS.format(src=str(data), mpc=10.0, fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=W, h=H, lc="no", planes="no", pcd="no"))
+        PARAMS.format(src=str(data), mpc=10.0, fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=W, h=H, lc="no", planes="no", pcd="no", extra=""))
     out = subprocess.run([os.path.join(HOST, "run_SLAM"), "4"], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     norms = [float(x) for x in (tmp_path / "data" / "error_of_transform.log").read_text().split()]
@@ -218,7 +219,7 @@ def test_run_slam_keyframes_loop_closure_and_g2o_handoff(gpu_lib, tmp_path):
         voxels.append((c.shape[0], O.voxel_grid(c, 0.03, 7.0).shape[0]))
         pcd_clouds.append(c)
     (tmp_path / "parameters.yaml").write_text(
-        PARAMS.format(src=str(data), mpc=0.005, fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=W, h=H, lc="yes", planes="yes", pcd="yes"))
+        PARAMS.format(src=str(data), mpc=0.005, fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=W, h=H, lc="yes", planes="yes", pcd="yes", extra="icp_plane_gate: yes\nhip_devices: 2\nhip_devices_share: yes"))
     out = subprocess.run([os.path.join(HOST, "run_SLAM"), str(len(poses) - 1)], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     kf = np.loadtxt(str(tmp_path / "data" / "keyframe.txt"), dtype=int)
@@ -278,3 +279,109 @@ def test_run_slam_keyframes_loop_closure_and_g2o_handoff(gpu_lib, tmp_path):
     if got.shape[0] == want.shape[0]:
         assert np.abs(got - want[:, :3]).max() < 0.035
     assert "final result saved" in out.stdout
+
+
+def _sequence(tmp_path, poses, W=320, H=240, seed=4242, blank=()):
+    intr = synth.Intrinsics.scaled(W, H)
+    data = tmp_path / "ds"
+    (data / "dep_index").mkdir(parents=True)
+    (tmp_path / "data").mkdir()
+    hb = max(2, int(round(32 * W / 640.0)))
+    for k, P in enumerate(poses):
+        d = synth.render_depth(P, intr, seed, 10 + k, hole_block=hb)
+        if k in blank:
+            d = np.zeros_like(d)                                    # a frame with no valid depth: cannot be aligned
+        _write_png16(str(data / "dep_index" / f"{k + 1}.png"), d)
+    return intr, data
+
+
+@pytest.mark.gpu
+def test_run_slam_lost_frames_and_lost_recovery(gpu_lib, tmp_path):
+    """The lost branch of GraphicEnd::run (src/GraphicEnd.cpp:173-229) and lostRecovery (:764-838): frames 4, 5, 6 carry
+    no depth -> each aligns to neither the keyframe nor the last frame -> '9999' in error_of_transform.log and _lost++;
+    with lost_frames = 2 the third lost frame triggers 'Lost Recovery': the present frame becomes a keyframe without an
+    odometry edge (lost.txt, keyframe.txt), and tracking resumes against it."""
+    _build_host()
+    step = synth.pose_from_seed(4242, max_angle_deg=1.0, max_trans=0.02)
+    poses = [np.eye(4)]
+    for k in range(8):
+        poses.append(step @ poses[-1])
+    intr, data = _sequence(tmp_path, poses, blank=(3, 4, 5))
+    (tmp_path / "parameters.yaml").write_text(
+        PARAMS.format(src=str(data), mpc=10.0, fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=320, h=240, lc="no", planes="no", pcd="no",
+                      extra="").replace("lost_frames: 10", "lost_frames: 2"))
+    out = subprocess.run([os.path.join(HOST, "run_SLAM"), "8"], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    log = (tmp_path / "data" / "error_of_transform.log").read_text().split()
+    assert len(log) == 8
+    assert log[2:5] == ["9999", "9999", "9999"]                     # frames 4, 5, 6 (:176)
+    assert all(0 < float(x) < 0.5 for x in log[:2])                 # frames 2, 3 track the first keyframe
+    assert out.stdout.count("This frame lost") >= 3 and "Lost Recovery..." in out.stdout
+    lost = (tmp_path / "data" / "lost.txt").read_text().split()
+    assert lost == ["1", "6"]                                       # keyframe id 1 = frame 6, the third lost one (:774-776)
+    kf = np.loadtxt(str(tmp_path / "data" / "keyframe.txt"), dtype=int).reshape(-1, 2)
+    assert kf[0].tolist() == [0, 1] and kf[1].tolist() == [1, 6]
+    # frame 7 is lost against the blank keyframe too, but frame 8 matches frame 7 (the last frame): the reference's
+    # "add last as a new keyframe" branch (:188-228) -- last (frame 7, stamped _index - 1) and present both become keyframes
+    assert "9999" in log[5:]
+    if len(kf) >= 4:
+        assert kf[2].tolist() == [2, 7] and kf[3].tolist() == [3, 8]       # ADVICE r1: the first of the two carries frame 7, not 8
+    edges = [ln.split() for ln in (tmp_path / "data" / "final.g2o").read_text().splitlines() if ln.startswith("EDGE_SE3")]
+    assert not any(e[1] == "0" and e[2] == "1" for e in edges)        # no odometry edge into the recovery keyframe (:793)
+
+
+@pytest.mark.gpu
+def test_trajectory_over_several_rotated_keyframes(gpu_lib, tmp_path):
+    """camera-to-world poses chain as kf_pos * T over several keyframes with real rotation; the TUM lines of
+    trajectory_icp.txt and the g2o vertices must follow the ground truth, not only for kf_pos = I."""
+    _build_host()
+    step = synth.pose_from_seed(99, max_angle_deg=3.0, max_trans=0.05)
+    poses = [np.eye(4)]
+    for k in range(6):
+        poses.append(step @ poses[-1])
+    intr, data = _sequence(tmp_path, poses, seed=99)
+    (tmp_path / "parameters.yaml").write_text(
+        PARAMS.format(src=str(data), mpc=0.03, fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=320, h=240, lc="no", planes="no", pcd="no", extra=""))
+    out = subprocess.run([os.path.join(HOST, "run_SLAM"), "6"], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    kf = np.loadtxt(str(tmp_path / "data" / "keyframe.txt"), dtype=int).reshape(-1, 2)
+    assert len(kf) >= 3                                               # several keyframes, each rotated w.r.t. the first
+    traj = np.loadtxt(str(tmp_path / "data" / "trajectory_icp.txt"))
+    assert traj.shape == (7, 8)
+    for k in range(1, 7):
+        want = np.linalg.inv(poses[k])                                # camera-to-world of frame k
+        got = _se3(traj[k, 1:8])
+        err = np.linalg.inv(want) @ got
+        ang = np.arccos(np.clip((np.trace(err[:3, :3]) - 1) / 2, -1, 1))
+        assert ang < 0.02 and np.linalg.norm(err[:3, 3]) < 0.05, (k, ang, err[:3, 3])
+
+
+def test_plane_gate_twin_without_gpu():
+    """slam3d_plane_gate (host code of the library, what GraphicEndICP::planeGate does through match()): planes of
+    frame 1 carried into frame 2 by T and matched on (a, b, c, d); numpy twin."""
+    from slam3d_gx_amd import capi
+    rng = np.random.default_rng(5)
+
+    def unit_planes(n):
+        p = rng.normal(size=(n, 4))
+        p[:, :3] /= np.linalg.norm(p[:, :3], axis=1, keepdims=True)
+        p[:, 3] = np.abs(p[:, 3]) + 0.5
+        return p.astype(np.float32)
+
+    def moved(p, T):
+        n = p[:, :3].astype(np.float64) @ T[:3, :3].T
+        d = p[:, 3].astype(np.float64) - n @ T[:3, 3]
+        s = np.where(d < 0, -1.0, 1.0)
+        return np.concatenate([n * s[:, None], (d * s)[:, None]], axis=1).astype(np.float32)
+
+    for trial in range(20):
+        T = synth.pose_from_seed(100 + trial, max_angle_deg=20.0, max_trans=0.5)
+        p1 = unit_planes(3)
+        p2 = moved(p1, T)[[2, 0]] + rng.normal(scale=0.01, size=(2, 4)).astype(np.float32)      # two of them seen again
+        assert capi.plane_gate(p1, p2, T, 0.15) == 2
+        assert capi.plane_gate(p1, p2, np.eye(4), 0.02) == int(sum(
+            np.linalg.norm(moved(p1, np.eye(4))[:, None, :].astype(np.float64) - p2[None], axis=2).min(1) <= 0.02))
+        wrong = synth.pose_from_seed(500 + trial, max_angle_deg=60.0, max_trans=1.5)
+        d = np.linalg.norm(moved(p1, wrong)[:, None, :].astype(np.float64) - p2[None].astype(np.float64), axis=2).min(1)
+        assert capi.plane_gate(p1, p2, wrong, 0.15) == int((d <= 0.15).sum())
+    assert capi.plane_gate(np.zeros((0, 4), np.float32), unit_planes(2), np.eye(4)) == 0
