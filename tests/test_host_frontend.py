@@ -300,34 +300,68 @@ def test_run_slam_lost_frames_and_lost_recovery(gpu_lib, tmp_path):
     """The lost branch of GraphicEnd::run (src/GraphicEnd.cpp:173-229) and lostRecovery (:764-838): frames 4, 5, 6 carry
     no depth -> each aligns to neither the keyframe nor the last frame -> '9999' in error_of_transform.log and _lost++;
     with lost_frames = 2 the third lost frame triggers 'Lost Recovery': the present frame becomes a keyframe without an
-    odometry edge (lost.txt, keyframe.txt), and tracking resumes against it."""
+    odometry edge (lost.txt, keyframe.txt).  That keyframe is blank too, so frames 7..9 are lost again and frame 9 (valid)
+    becomes the next recovery keyframe, against which frames 10, 11 track."""
     _build_host()
     step = synth.pose_from_seed(4242, max_angle_deg=1.0, max_trans=0.02)
     poses = [np.eye(4)]
-    for k in range(8):
+    for k in range(10):
         poses.append(step @ poses[-1])
     intr, data = _sequence(tmp_path, poses, blank=(3, 4, 5))
     (tmp_path / "parameters.yaml").write_text(
         PARAMS.format(src=str(data), mpc=10.0, fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=320, h=240, lc="no", planes="no", pcd="no",
                       extra="").replace("lost_frames: 10", "lost_frames: 2"))
-    out = subprocess.run([os.path.join(HOST, "run_SLAM"), "8"], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    out = subprocess.run([os.path.join(HOST, "run_SLAM"), "10"], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     log = (tmp_path / "data" / "error_of_transform.log").read_text().split()
-    assert len(log) == 8
-    assert log[2:5] == ["9999", "9999", "9999"]                     # frames 4, 5, 6 (:176)
-    assert all(0 < float(x) < 0.5 for x in log[:2])                 # frames 2, 3 track the first keyframe
-    assert out.stdout.count("This frame lost") >= 3 and "Lost Recovery..." in out.stdout
+    assert len(log) == 10
+    assert log[2:8] == ["9999"] * 6                                 # frames 4..9: no depth, then a blank keyframe (:176)
+    assert all(0 < float(x) < 0.5 for x in log[:2] + log[8:])       # frames 2, 3 track keyframe 0; frames 10, 11 track keyframe 9
+    assert out.stdout.count("This frame lost") == 6 and out.stdout.count("Lost Recovery...") == 2
     lost = (tmp_path / "data" / "lost.txt").read_text().split()
-    assert lost == ["1", "6"]                                       # keyframe id 1 = frame 6, the third lost one (:774-776)
+    assert lost == ["1", "6", "2", "9"]                             # "keyframe id, frame index" per recovery (:774-776)
     kf = np.loadtxt(str(tmp_path / "data" / "keyframe.txt"), dtype=int).reshape(-1, 2)
-    assert kf[0].tolist() == [0, 1] and kf[1].tolist() == [1, 6]
-    # frame 7 is lost against the blank keyframe too, but frame 8 matches frame 7 (the last frame): the reference's
-    # "add last as a new keyframe" branch (:188-228) -- last (frame 7, stamped _index - 1) and present both become keyframes
-    assert "9999" in log[5:]
-    if len(kf) >= 4:
-        assert kf[2].tolist() == [2, 7] and kf[3].tolist() == [3, 8]       # ADVICE r1: the first of the two carries frame 7, not 8
+    assert kf.tolist() == [[0, 1], [1, 6], [2, 9]]
     edges = [ln.split() for ln in (tmp_path / "data" / "final.g2o").read_text().splitlines() if ln.startswith("EDGE_SE3")]
-    assert not any(e[1] == "0" and e[2] == "1" for e in edges)        # no odometry edge into the recovery keyframe (:793)
+    # recovery keyframes get no odometry edge (:793); lostRecovery aligns the new keyframe against every earlier one
+    # (:808-836): the blank keyframe 1 matches nothing, keyframe 2 (frame 9) finds keyframe 0 (frame 1) again
+    assert [(e[1], e[2]) for e in edges] == [("0", "2")]
+
+
+@pytest.mark.gpu
+def test_run_slam_last_frame_becomes_keyframe(gpu_lib, tmp_path):
+    """The other half of the lost branch (src/GraphicEnd.cpp:186-228): the present frame fails against the keyframe
+    (here: norm above error_threshold, :621) but matches the LAST ordinary frame -> last becomes a keyframe (stamped
+    with its own frame index, _index - 1, :198) and then the present one (:227)."""
+    _build_host()
+    step = synth.pose_from_seed(4242, max_angle_deg=1.0, max_trans=0.02)
+    ang = np.arccos(np.clip((np.trace(step[:3, :3]) - 1) / 2, -1, 1))
+    norm_step = ang + 0.9 * np.linalg.norm(step[:3, 3])
+    poses = [np.eye(4)]
+    for k in range(6):
+        poses.append(step @ poses[-1])
+    intr, data = _sequence(tmp_path, poses)
+    (tmp_path / "parameters.yaml").write_text(
+        PARAMS.format(src=str(data), mpc=10.0, fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=320, h=240, lc="no", planes="no", pcd="no",
+                      extra="").replace("error_threshold: 1.0", f"error_threshold: {1.5 * norm_step:.6f}"))
+    out = subprocess.run([os.path.join(HOST, "run_SLAM"), "6"], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    log = (tmp_path / "data" / "error_of_transform.log").read_text().split()
+    # frame 2: one step from keyframe 0 (ok); frame 3: two steps (> 1.5 steps: lost, but one step from frame 2) -> keyframes
+    # frame 2 and frame 3; frame 4: one step from keyframe frame 3 (ok); frame 5: lost again -> keyframes 4 and 5; ...
+    assert log[1] == "9999" and log[3] == "9999" and 0 < float(log[0]) < 1.5 * norm_step and 0 < float(log[2]) < 1.5 * norm_step
+    kf = np.loadtxt(str(tmp_path / "data" / "keyframe.txt"), dtype=int).reshape(-1, 2)
+    assert kf[:5].tolist() == [[0, 1], [1, 2], [2, 3], [3, 4], [4, 5]]            # ADVICE r1: the first of each pair carries _index - 1
+    assert "lost.txt" not in os.listdir(str(tmp_path / "data"))                    # never lost for more than one frame
+    # the chained vertex poses follow the ground truth
+    V = {}
+    for line in (tmp_path / "data" / "final.g2o").read_text().splitlines():
+        t = line.split()
+        if t[0] == "VERTEX_SE3:QUAT":
+            V[int(t[1])] = _se3([float(x) for x in t[2:9]])
+    for kid, frame in kf:
+        err = poses[frame - 1] @ V[kid]                             # world->camera (truth) times camera->world (estimate)
+        assert np.linalg.norm(err[:3, 3]) < 0.05 and np.arccos(np.clip((np.trace(err[:3, :3]) - 1) / 2, -1, 1)) < 0.02
 
 
 @pytest.mark.gpu
