@@ -67,6 +67,7 @@ struct slam3d_icp_handle {
     int *vox_lslot = nullptr, *vox_gslot = nullptr, *vox_m = nullptr, *vox_hist = nullptr;   // hist | start | cursor
     float4 *vox_out = nullptr;
     int *pin_vox_m = nullptr;
+    bool vox_dirty = true;        // table / histogram need a full clear before the next voxel call
     // 8x8-pixel tiles (slot order of the sums; target tiles + boxes for the pruned NN)
     TileGrid tg;
     float4 *prevq = nullptr;
@@ -980,10 +981,13 @@ static int vox_alloc(slam3d_icp_handle *h)
 {
     if (h->vox_mem) return SLAM3D_OK;
     int cap = 1024;
-    while (cap < 2 * h->N) cap <<= 1;                     // load factor <= 0.5
-    const size_t bytes = (size_t)cap * (8 + 3 * 8 + 5 * 4);
-    if (hipMalloc((void **)&h->vox_mem, bytes) != hipSuccess || hipMalloc((void **)&h->vox_lkey, sizeof(unsigned long long) * h->N) != hipSuccess ||
-        hipMalloc((void **)&h->vox_lslot, sizeof(int) * h->N) != hipSuccess || hipMalloc((void **)&h->vox_m, sizeof(int)) != hipSuccess ||
+    while (cap < h->N) cap <<= 1;                         // every point its own voxel still fits; typical load ~ 0.1
+    // insert blocks: runs of 256 records, or 16x16 tiles of the organized image (ragged edges need a few more)
+    const int nblk = std::max((h->N + VOX_BLOCK - 1) / VOX_BLOCK, ((h->p.width + VOX_TW - 1) / VOX_TW) * ((h->p.height + VOX_TW - 1) / VOX_TW));
+    if (hipMalloc((void **)&h->vox_mem, (size_t)cap * sizeof(VoxSlot)) != hipSuccess ||
+        hipMalloc((void **)&h->vox_lkey, sizeof(unsigned long long) * (size_t)nblk * VOX_BLOCK) != hipSuccess ||
+        hipMalloc((void **)&h->vox_lslot, sizeof(int) * (size_t)nblk * VOX_BLOCK) != hipSuccess ||
+        hipMalloc((void **)&h->vox_m, sizeof(int) * (size_t)(nblk + 1)) != hipSuccess ||            // [0] kept-count of pass_transform, [1..] claims per insert block
         hipMalloc((void **)&h->vox_gkey, sizeof(unsigned long long) * h->N) != hipSuccess ||
         hipMalloc((void **)&h->vox_gslot, sizeof(int) * h->N) != hipSuccess ||
         hipMalloc((void **)&h->vox_hist, sizeof(int) * (3 * VOX_BINS + 8 + VOX_SCAN_BLOCKS)) != hipSuccess ||
@@ -992,18 +996,9 @@ static int vox_alloc(slam3d_icp_handle *h)
         (void)hipGetLastError();
         return SLAM3D_E_NOMEM;
     }
-    unsigned char *p = h->vox_mem;
-    VoxTable &t = h->vox;
-    t.cap = cap;
-    t.key = reinterpret_cast<unsigned long long *>(p); p += (size_t)cap * 8;
-    t.sx = reinterpret_cast<long long *>(p); p += (size_t)cap * 8;
-    t.sy = reinterpret_cast<long long *>(p); p += (size_t)cap * 8;
-    t.sz = reinterpret_cast<long long *>(p); p += (size_t)cap * 8;
-    t.c0 = reinterpret_cast<unsigned int *>(p); p += (size_t)cap * 4;
-    t.c1 = reinterpret_cast<unsigned int *>(p); p += (size_t)cap * 4;
-    t.c2 = reinterpret_cast<unsigned int *>(p); p += (size_t)cap * 4;
-    t.c3 = reinterpret_cast<unsigned int *>(p); p += (size_t)cap * 4;
-    t.n = reinterpret_cast<unsigned int *>(p);
+    h->vox.slot = reinterpret_cast<VoxSlot *>(h->vox_mem);
+    h->vox.cap = cap;
+    h->vox_dirty = true;                                  // first use: slots and histogram are cleared once
     return SLAM3D_OK;
 }
 
@@ -1014,28 +1009,32 @@ static int voxel_grid_impl(slam3d_icp_handle *h, const void *d_points16, int32_t
     HIPCHK(h, hipSetDevice(h->p.device));
     int rc = vox_alloc(h);
     if (rc) return rc;
+    *n_out = 0;
+    if (n == 0) return SLAM3D_OK;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     const VoxTable &t = h->vox;
-    HIPCHK(h, hipMemsetAsync(t.key, 0xFF, (size_t)t.cap * 8, s));
-    HIPCHK(h, hipMemsetAsync(t.sx, 0, (size_t)t.cap * (3 * 8 + 5 * 4), s));
-    HIPCHK(h, hipMemsetAsync(h->vox_m, 0, sizeof(int), s));
-    HIPCHK(h, hipMemsetAsync(h->vox_hist, 0, sizeof(int) * VOX_BINS, s));
-    int *start = h->vox_hist + VOX_BINS, *cursor = start + VOX_BINS + 8, *btot = cursor + VOX_BINS;
-    if (n > 0) {
-        hipLaunchKernelGGL(k_voxel_insert, dim3((n + VOX_BLOCK - 1) / VOX_BLOCK), dim3(VOX_BLOCK), 0, s,
-                           static_cast<const float4 *>(d_points16), n, 1.0f / leaf, zmin, zmax, t);
-        hipLaunchKernelGGL(k_voxel_compact, dim3((t.cap + VOX_BLOCK * VOX_SPT - 1) / (VOX_BLOCK * VOX_SPT)), dim3(VOX_BLOCK), 0, s, t,
-                           h->vox_lkey, h->vox_lslot, h->vox_m, h->vox_hist);
-        hipLaunchKernelGGL(k_voxel_scan1, dim3(VOX_SCAN_BLOCKS), dim3(1024), 0, s, h->vox_hist, start, cursor, btot);
-        hipLaunchKernelGGL(k_voxel_scan2, dim3(VOX_SCAN_BLOCKS), dim3(1024), 0, s, start, btot);
-        hipLaunchKernelGGL(k_voxel_scatter, dim3((n + VOX_BLOCK - 1) / VOX_BLOCK), dim3(VOX_BLOCK), 0, s, h->vox_lkey, h->vox_lslot,
-                           h->vox_m, start, cursor, h->vox_gkey, h->vox_gslot);
-        hipLaunchKernelGGL(k_voxel_rank, dim3((n + VOX_BLOCK - 1) / VOX_BLOCK), dim3(VOX_BLOCK), 0, s, t, h->vox_gkey, h->vox_gslot,
-                           h->vox_m, start, static_cast<float4 *>(d_out16));
+    if (h->vox_dirty) {      // allocation, or an earlier call failed half way: from then on every call cleans up after itself
+        hipLaunchKernelGGL(k_voxel_clear, dim3((t.cap + VOX_BLOCK - 1) / VOX_BLOCK), dim3(VOX_BLOCK), 0, s, t);
+        HIPCHK(h, hipMemsetAsync(h->vox_hist, 0, sizeof(int) * VOX_BINS, s));
     }
+    h->vox_dirty = true;     // until this call has run to its end
+    int *start = h->vox_hist + VOX_BINS, *cursor = start + VOX_BINS + 8, *btot = cursor + VOX_BINS, *bcount = h->vox_m + 1;
+    // an organized cloud (all width x height records present) is cut into 16x16-pixel tiles, anything else into runs of 256
+    const bool org = n == h->N;
+    const int nblk = org ? ((h->p.width + VOX_TW - 1) / VOX_TW) * ((h->p.height + VOX_TW - 1) / VOX_TW) : (n + VOX_BLOCK - 1) / VOX_BLOCK;
+    if (org) hipLaunchKernelGGL(k_voxel_insert<true>, dim3(nblk), dim3(VOX_BLOCK), 0, s, static_cast<const float4 *>(d_points16), n, h->p.width,
+                                h->p.height, 1.0f / leaf, zmin, zmax, t, h->vox_lkey, h->vox_lslot, bcount, h->vox_hist);
+    else hipLaunchKernelGGL(k_voxel_insert<false>, dim3(nblk), dim3(VOX_BLOCK), 0, s, static_cast<const float4 *>(d_points16), n, h->p.width,
+                            h->p.height, 1.0f / leaf, zmin, zmax, t, h->vox_lkey, h->vox_lslot, bcount, h->vox_hist);
+    hipLaunchKernelGGL(k_voxel_scan1, dim3(VOX_SCAN_BLOCKS), dim3(1024), 0, s, h->vox_hist, start, cursor, btot);
+    hipLaunchKernelGGL(k_voxel_scan2, dim3(VOX_SCAN_BLOCKS), dim3(1024), 0, s, start, btot);
+    hipLaunchKernelGGL(k_voxel_scatter, dim3(nblk), dim3(VOX_BLOCK), 0, s, h->vox_lkey, h->vox_lslot, bcount, start, cursor, h->vox_gkey,
+                       h->vox_gslot);
+    hipLaunchKernelGGL(k_voxel_rank, dim3(nblk), dim3(VOX_BLOCK), 0, s, t, h->vox_gkey, h->vox_gslot, start, static_cast<float4 *>(d_out16));
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(h->pin_vox_m, h->vox_m, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->pin_vox_m, start + VOX_BINS, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
+    h->vox_dirty = false;
     *n_out = *h->pin_vox_m;
     return SLAM3D_OK;
 }

@@ -6,12 +6,17 @@
 // integer colour sums, so the atomics below give the same bits whatever order they land in.
 //
 //   k_voxel_insert   one thread per point: 64-bit voxel key (iz,iy,ix) -> open-addressing hash table in HBM
-//                    (capacity >= 2n, linear probing, atomicCAS on the key), atomic adds into the entry
-//   k_voxel_compact  occupied slots -> dense list (one global ticket per block) + histogram of the (iz, iy) rows
-//   k_voxel_scan1/2 / k_voxel_scatter   counting sort of the list by row (iz, iy are the most significant key fields)
+//                    (64-byte slots: key, sums, colour sums and count of a voxel share ONE cache line, so the nine
+//                    atomics of an update touch one line instead of nine), atomicCAS on the key.  The lane that claims a
+//                    slot also lists it -- per block, through an LDS counter -- and bumps the histogram of the
+//                    (iz, iy) rows: no pass over the table is ever needed.
+//   k_voxel_scan1/2 / k_voxel_scatter   counting sort of the listed slots by row (iz, iy are the most significant fields)
 //   k_voxel_rank     output order = ascending key, like PCL's sorted linear voxel index: rank = start of the
 //                    rows a block touches + number of smaller keys among them (LDS-tiled compares), centroid
-//                    written at that rank.  No host round trip anywhere: the entry count stays on the device.
+//                    written at that rank; the slot is reset as it is read.
+// The table is SELF-CLEANING: every call leaves every slot empty and the histogram zero (round 1 cleared 52 MB of
+// table per call and scanned its 2^20 slots for the occupied ones: 0.4 % of the HBM roofline).  No host round trip
+// until the final count.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -23,12 +28,15 @@ constexpr unsigned long long VOX_EMPTY = ~0ull;
 constexpr int VOX_BLOCK = 256;
 constexpr int VOX_TILE = 2048;        // keys staged in LDS per step of the ranking kernel
 
-struct VoxTable {                     // SoA hash table, `cap` slots (power of two)
-    unsigned long long *key;
-    long long *sx, *sy, *sz;
-    unsigned int *c0, *c1, *c2, *c3, *n;
-    int cap;
+struct __attribute__((aligned(64))) VoxSlot {      // one cache line per voxel
+    unsigned long long key;
+    long long sx, sy, sz;                          // fixed-point coordinate sums (2^-20 m)
+    unsigned long long c01, c23;                   // colour channel sums, two per word (c0 | c1 << 32), (c2 | c3 << 32): each < 2^27
+    unsigned int n;                                // point count
+    unsigned int pad[3];
 };
+static_assert(sizeof(VoxSlot) == 64, "a voxel slot is one 64-byte line");
+struct VoxTable { VoxSlot *slot; int cap; };       // `cap` slots (power of two)
 
 __device__ __forceinline__ unsigned long long vox_key(float x, float y, float z, float inv_leaf)
 {
@@ -47,6 +55,16 @@ __device__ __forceinline__ unsigned int vox_hash(unsigned long long k)
     return (unsigned int)(k ^ (k >> 31));
 }
 
+// every slot empty, every sum zero: at allocation and after a call that failed half way
+__global__ __launch_bounds__(VOX_BLOCK) void k_voxel_clear(VoxTable t)
+{
+    const int s = blockIdx.x * VOX_BLOCK + threadIdx.x;
+    if (s >= t.cap) return;
+    uint4 *q = reinterpret_cast<uint4 *>(t.slot + s);
+    q[0] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
+    q[1] = make_uint4(0u, 0u, 0u, 0u); q[2] = make_uint4(0u, 0u, 0u, 0u); q[3] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // inclusive sum over the lanes of the same run (runs = maximal stretches of consecutive lanes with equal keys,
 // numbered by `seg`): Hillis-Steele with a segment test; integer adds, so exact
 template <typename T> __device__ __forceinline__ T run_scan(T v, int seg)
@@ -61,53 +79,9 @@ template <typename T> __device__ __forceinline__ T run_scan(T v, int seg)
     return v;
 }
 
-// One thread per point.  Neighbouring pixels of an organized cloud fall into the same voxel 3-10 times in a row,
-// and atomics of one wave to one address serialise, so each run of equal keys inside the wave is summed first
-// (integers: same bits) and only the last lane of the run touches the table.
-__global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(const float4 *__restrict__ pts, int n, float inv_leaf, float zmin, float zmax,
-                                                            VoxTable t)
-{
-    const int i = blockIdx.x * VOX_BLOCK + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    float4 p = make_float4(0.0f, 0.0f, -1.0f, 0.0f);
-    if (i < n) p = pts[i];
-    const bool ok = i < n && isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && p.z >= zmin && p.z <= zmax;     // PassThrough
-    const unsigned long long key = ok ? vox_key(p.x, p.y, p.z, inv_leaf) : VOX_EMPTY;
-    const unsigned long long prev = __shfl_up(key, 1);
-    const bool head = lane == 0 || prev != key;
-    const unsigned long long heads = __ballot(head);
-    const int seg = __popcll(heads & ((2ull << lane) - 1ull));                  // run number of this lane
-    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
-    const unsigned int rgba = (unsigned int)__float_as_int(p.w);
-    const long long qx = run_scan(ok ? __double2ll_rn((double)p.x * 1048576.0) : 0ll, seg);
-    const long long qy = run_scan(ok ? __double2ll_rn((double)p.y * 1048576.0) : 0ll, seg);
-    const long long qz = run_scan(ok ? __double2ll_rn((double)p.z * 1048576.0) : 0ll, seg);
-    // colour channels and the count travel packed: (c0 | c1 << 32), (c2 | c3 << 32) and the count stay below 2^32 each
-    // inside a wave (64 x 255)
-    const unsigned long long c01 = run_scan((unsigned long long)(rgba & 0xffu) | ((unsigned long long)((rgba >> 8) & 0xffu) << 32), seg);
-    const unsigned long long c23 = run_scan((unsigned long long)((rgba >> 16) & 0xffu) | ((unsigned long long)(rgba >> 24) << 32), seg);
-    const int cnt = run_scan(1, seg);
-    if (!ok || !tail) return;
-    unsigned int s = vox_hash(key) & (unsigned int)(t.cap - 1);
-    for (;;) {
-        const unsigned long long was = atomicCAS(t.key + s, VOX_EMPTY, key);
-        if (was == VOX_EMPTY || was == key) break;
-        s = (s + 1) & (unsigned int)(t.cap - 1);
-    }
-    atomicAdd(reinterpret_cast<unsigned long long *>(t.sx + s), (unsigned long long)qx);
-    atomicAdd(reinterpret_cast<unsigned long long *>(t.sy + s), (unsigned long long)qy);
-    atomicAdd(reinterpret_cast<unsigned long long *>(t.sz + s), (unsigned long long)qz);
-    atomicAdd(t.c0 + s, (unsigned int)c01);
-    atomicAdd(t.c1 + s, (unsigned int)(c01 >> 32));
-    atomicAdd(t.c2 + s, (unsigned int)c23);
-    atomicAdd(t.c3 + s, (unsigned int)(c23 >> 32));
-    atomicAdd(t.n + s, (unsigned int)cnt);
-}
-
 constexpr int VOX_BZ = 512, VOX_BY = 256;   // ordering bins: (iz, iy) rows, both clamped (the order stays monotone)
 constexpr int zbias = 128;                   // iz in [-128, 383] has its own slab (-3.8 m .. 11.5 m at a 3 cm leaf)
 constexpr int VOX_BINS = VOX_BZ * VOX_BY;
-constexpr int VOX_SPT = 16;           // table slots per thread in k_voxel_compact
 
 // bin = the (iz, iy) row of the voxel: a monotone function of the key (clamping only merges rows at the ends), so
 // bins are ordered like keys and a row holds at most one voxel per ix -- a few hundred entries even for a wall
@@ -123,54 +97,112 @@ __device__ __forceinline__ int vox_bin(unsigned long long key)
     return iz * VOX_BY + by;
 }
 
-// occupied slots -> dense (key, slot) list + histogram of the (iz, iy) rows.  Each block scans 4096 slots and
-// takes ONE ticket from the global counter (same-address global atomics serialise: one per wave cost 166 us).
-__global__ __launch_bounds__(VOX_BLOCK) void k_voxel_compact(VoxTable t, unsigned long long *__restrict__ lkey, int *__restrict__ lslot,
-                                                             int *__restrict__ m, int *__restrict__ hist)
+// One thread per point, one block per 16x16-pixel tile of an organized cloud (ORG; a voxel of the 3 cm grid covers
+// ~6x6 pixels at 2.5 m, so a tile holds about a dozen voxels) or per 256 consecutive records otherwise.
+//   1. runs of equal keys inside a wave are summed with a segmented scan (integers: same bits);
+//   2. the run tails add into a block-local hash table in LDS (512 entries; LDS atomics);
+//   3. every occupied LDS entry becomes ONE update of the global table: atomicCAS on the key + six atomic adds into
+//      the voxel's cache line.  Returning global atomics are the scarce resource here (~1-2 per ns scattered): the
+//      two aggregation levels cut them from one per point run (77 k per 640x480 frame) to one per (tile, voxel) (~15 k).
+// The lane whose CAS claims an empty global slot lists it at lkey / lslot[block * VOX_BLOCK + k] (k from an LDS
+// counter; bcount[block] = entries listed) and bumps the row histogram.
+constexpr int VOX_LH = 512;            // LDS hash entries per block (256 points: load <= 0.5)
+constexpr int VOX_TW = 16;             // tile edge in pixels (ORG)
+
+template <bool ORG>
+__global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(const float4 *__restrict__ pts, int n, int W, int H, float inv_leaf, float zmin,
+                                                            float zmax, VoxTable t, unsigned long long *__restrict__ lkey,
+                                                            int *__restrict__ lslot, int *__restrict__ bcount, int *__restrict__ hist)
 {
-    __shared__ int wsum[VOX_BLOCK / 64], base_sh;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int s0 = blockIdx.x * VOX_BLOCK * VOX_SPT;
-    unsigned long long k[VOX_SPT];
-    int mine = 0;
-#pragma unroll
-    for (int j = 0; j < VOX_SPT; ++j) {
-        const int s = s0 + j * VOX_BLOCK + threadIdx.x;
-        k[j] = s < t.cap ? t.key[s] : VOX_EMPTY;
-        mine += k[j] != VOX_EMPTY ? 1 : 0;
-    }
-    int incl = mine;                                             // inclusive prefix over the wave
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-    if (lane == 63) wsum[w] = incl;
+    __shared__ unsigned long long hk[VOX_LH], hc01[VOX_LH], hc23[VOX_LH];
+    __shared__ long long hsx[VOX_LH], hsy[VOX_LH], hsz[VOX_LH];
+    __shared__ unsigned int hn[VOX_LH];
+    __shared__ int bcnt;
+    for (int k = threadIdx.x; k < VOX_LH; k += VOX_BLOCK) { hk[k] = VOX_EMPTY; hc01[k] = 0; hc23[k] = 0; hsx[k] = 0; hsy[k] = 0; hsz[k] = 0; hn[k] = 0; }
+    if (threadIdx.x == 0) bcnt = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        base_sh = tot ? atomicAdd(m, tot) : 0;
+    int i = -1;
+    if constexpr (ORG) {
+        const int tiles_x = (W + VOX_TW - 1) / VOX_TW;
+        const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+        const int u = tx * VOX_TW + (threadIdx.x & (VOX_TW - 1)), v = ty * VOX_TW + (threadIdx.x / VOX_TW);
+        if (u < W && v < H) i = v * W + u;
+    } else {
+        i = blockIdx.x * VOX_BLOCK + threadIdx.x;
+        if (i >= n) i = -1;
+    }
+    const int lane = threadIdx.x & 63;
+    float4 p = make_float4(0.0f, 0.0f, -1.0f, 0.0f);
+    if (i >= 0) p = pts[i];
+    const bool ok = i >= 0 && isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && p.z >= zmin && p.z <= zmax;     // PassThrough
+    const unsigned long long key = ok ? vox_key(p.x, p.y, p.z, inv_leaf) : VOX_EMPTY;
+    const unsigned long long prev = __shfl_up(key, 1);
+    const bool head = lane == 0 || prev != key;
+    const unsigned long long heads = __ballot(head);
+    const int seg = __popcll(heads & ((2ull << lane) - 1ull));                  // run number of this lane
+    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+    const unsigned int rgba = (unsigned int)__float_as_int(p.w);
+    const long long qx = run_scan(ok ? __double2ll_rn((double)p.x * 1048576.0) : 0ll, seg);
+    const long long qy = run_scan(ok ? __double2ll_rn((double)p.y * 1048576.0) : 0ll, seg);
+    const long long qz = run_scan(ok ? __double2ll_rn((double)p.z * 1048576.0) : 0ll, seg);
+    const unsigned long long c01 = run_scan((unsigned long long)(rgba & 0xffu) | ((unsigned long long)((rgba >> 8) & 0xffu) << 32), seg);
+    const unsigned long long c23 = run_scan((unsigned long long)((rgba >> 16) & 0xffu) | ((unsigned long long)(rgba >> 24) << 32), seg);
+    const int cnt = run_scan(1, seg);
+    if (ok && tail) {                                            // level 2: the block's LDS table
+        unsigned int s = vox_hash(key) & (VOX_LH - 1);
+        for (;;) {
+            const unsigned long long was = atomicCAS(&hk[s], VOX_EMPTY, key);
+            if (was == VOX_EMPTY || was == key) break;
+            s = (s + 1) & (VOX_LH - 1);
+        }
+        atomicAdd(reinterpret_cast<unsigned long long *>(&hsx[s]), (unsigned long long)qx);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&hsy[s]), (unsigned long long)qy);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&hsz[s]), (unsigned long long)qz);
+        atomicAdd(&hc01[s], c01);
+        atomicAdd(&hc23[s], c23);
+        atomicAdd(&hn[s], (unsigned int)cnt);
     }
     __syncthreads();
-    int pos = base_sh + incl - mine;
-    for (int q = 0; q < w; ++q) pos += wsum[q];
-#pragma unroll
-    for (int j = 0; j < VOX_SPT; ++j) {
-        if (k[j] != VOX_EMPTY) {
-            lkey[pos] = k[j];
-            lslot[pos] = s0 + j * VOX_BLOCK + threadIdx.x;
-            atomicAdd(hist + vox_bin(k[j]), 1);                  // 65536 rows, hashed order: no address is hot
-            ++pos;
+    for (int k = threadIdx.x; k < VOX_LH; k += VOX_BLOCK) {      // level 3: one global update per (block, voxel)
+        const unsigned long long gk = hk[k];
+        if (gk == VOX_EMPTY) continue;
+        unsigned int s = vox_hash(gk) & (unsigned int)(t.cap - 1);
+        bool claimed = false;
+        for (;;) {
+            const unsigned long long was = atomicCAS(&t.slot[s].key, VOX_EMPTY, gk);
+            if (was == VOX_EMPTY) { claimed = true; break; }
+            if (was == gk) break;
+            s = (s + 1) & (unsigned int)(t.cap - 1);
+        }
+        VoxSlot *q = t.slot + s;
+        atomicAdd(reinterpret_cast<unsigned long long *>(&q->sx), (unsigned long long)hsx[k]);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&q->sy), (unsigned long long)hsy[k]);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&q->sz), (unsigned long long)hsz[k]);
+        atomicAdd(&q->c01, hc01[k]);
+        atomicAdd(&q->c23, hc23[k]);
+        atomicAdd(&q->n, hn[k]);
+        if (claimed) {
+            const int c = atomicAdd(&bcnt, 1);                       // LDS: at most VOX_BLOCK claims per block
+            lkey[(size_t)blockIdx.x * VOX_BLOCK + c] = gk;
+            lslot[(size_t)blockIdx.x * VOX_BLOCK + c] = (int)s;
+            atomicAdd(hist + vox_bin(gk), 1);                        // 131072 rows: no address is hot
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) bcount[blockIdx.x] = bcnt;
 }
 
-// exclusive prefix of the row histogram -> start[]; cursor[] reset.  Two launches of VOX_BINS / 1024 blocks:
-// scan1 scans 1024 rows per block (wave shuffles + one LDS step) and leaves the block totals, scan2 adds to every
-// block the sum of the totals before it (128 values, read by every block).
+// exclusive prefix of the row histogram -> start[]; cursor[] and the histogram itself reset for the next call.  Two
+// launches of VOX_BINS / 1024 blocks: scan1 scans 1024 rows per block (wave shuffles + one LDS step) and leaves the
+// block totals, scan2 adds to every block the sum of the totals before it (128 values, read by every block).
 constexpr int VOX_SCAN_BLOCKS = VOX_BINS / 1024;
-__global__ __launch_bounds__(1024) void k_voxel_scan1(const int *__restrict__ hist, int *__restrict__ start, int *__restrict__ cursor,
+__global__ __launch_bounds__(1024) void k_voxel_scan1(int *__restrict__ hist, int *__restrict__ start, int *__restrict__ cursor,
                                                       int *__restrict__ btot)
 {
     __shared__ int wtot[16];
     const int i = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int v = hist[i];
+    if (v) hist[i] = 0;
     int incl = v;
     for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
     if (lane == 63) wtot[w] = incl;
@@ -192,21 +224,40 @@ __global__ __launch_bounds__(1024) void k_voxel_scan2(int *__restrict__ start, c
     }
     __syncthreads();
     start[blockIdx.x * 1024 + threadIdx.x] += off_sh;
-    if (blockIdx.x == VOX_SCAN_BLOCKS - 1 && threadIdx.x == 1023) start[VOX_BINS] = off_sh + btot[blockIdx.x];
+    if (blockIdx.x == VOX_SCAN_BLOCKS - 1 && threadIdx.x == 1023) start[VOX_BINS] = off_sh + btot[blockIdx.x];     // = number of voxels
 }
 
-// group the list by row (order inside a row is arbitrary; k_voxel_rank fixes it)
+// group the listed slots by row (order inside a row is arbitrary; k_voxel_rank fixes it).  Thread e looks at entry
+// e % VOX_BLOCK of insert block e / VOX_BLOCK.  The claims of one insert block come from one image tile, i.e. from a
+// handful of rows: lanes with the same row share ONE returning atomic on its cursor.
 __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_scatter(const unsigned long long *__restrict__ lkey, const int *__restrict__ lslot,
-                                                             const int *__restrict__ m, const int *__restrict__ start,
+                                                             const int *__restrict__ bcount, const int *__restrict__ start,
                                                              int *__restrict__ cursor, unsigned long long *__restrict__ gkey,
                                                              int *__restrict__ gslot)
 {
-    const int e = blockIdx.x * VOX_BLOCK + threadIdx.x;
-    const bool live = e < *m;
+    const int nb = bcount[blockIdx.x];
+    if ((int)(threadIdx.x & ~63u) >= nb) return;                       // whole wave beyond the list
+    const bool live = (int)threadIdx.x < nb;
+    const int lane = threadIdx.x & 63;
+    const size_t e = (size_t)blockIdx.x * VOX_BLOCK + threadIdx.x;
     const unsigned long long k = live ? lkey[e] : 0ull;
-    const int b = live ? vox_bin(k) : 0;
+    const int b = live ? vox_bin(k) : -1;
+    // group the lanes by row WITHOUT touching memory (leader lane, rank in the group, group size), then all leaders issue
+    // their returning atomics in one instruction: one round trip per wave instead of one per distinct row
+    int leader = lane, rank = 0, size = 1;
+    unsigned long long rest = __ballot(live);
+    while (rest) {
+        const int l0 = __builtin_ctzll(rest);
+        const int b0 = __shfl(b, l0);
+        const unsigned long long same = __ballot(b == b0) & rest;
+        if (b == b0) { leader = l0; rank = __popcll(same & ((1ull << lane) - 1ull)); size = __popcll(same); }
+        rest &= ~same;
+    }
+    int base = 0;
+    if (live && leader == lane) base = atomicAdd(cursor + b, size);
+    base = __shfl(base, leader);
+    const int pos = live ? start[b] + base + rank : 0;
     if (!live) return;
-    const int pos = start[b] + atomicAdd(cursor + b, 1);
     gkey[pos] = k;
     gslot[pos] = lslot[e];
 }
@@ -214,14 +265,14 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_scatter(const unsigned long
 // Output order = ascending key, like PCL's sorted linear voxel index.  Keys are grouped by (iz, iy) row and rows
 // are ordered, so an entry's rank = start of the first row its block touches + the keys of the block's rows below
 // its own: the block stages the union of its entries' rows through LDS.  grid covers the worst case (n entries);
-// blocks beyond *m leave at once.
+// blocks beyond the voxel count leave at once.  Every slot is reset as it is read (self-cleaning table).
 __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_rank(VoxTable t, const unsigned long long *__restrict__ gkey,
-                                                          const int *__restrict__ gslot, const int *__restrict__ m,
-                                                          const int *__restrict__ start, float4 *__restrict__ out)
+                                                          const int *__restrict__ gslot, const int *__restrict__ start,
+                                                          float4 *__restrict__ out)
 {
     __shared__ unsigned long long tile[VOX_TILE];
     __shared__ int lo_sh, hi_sh;
-    const int M = *m;
+    const int M = start[VOX_BINS];
     const int e0 = blockIdx.x * VOX_BLOCK;
     if (e0 >= M) return;
     const int e = e0 + threadIdx.x;
@@ -249,16 +300,25 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_rank(VoxTable t, const unsi
         }
     }
     if (!live) return;
-    const int s = gslot[e];
-    const unsigned int ni = t.n[s];
+    VoxSlot *q = t.slot + gslot[e];
+    const uint4 a0 = reinterpret_cast<const uint4 *>(q)[0], a1 = reinterpret_cast<const uint4 *>(q)[1],
+                a2 = reinterpret_cast<const uint4 *>(q)[2];
+    const long long sx = (long long)(((unsigned long long)a0.w << 32) | a0.z);
+    const long long sy = (long long)(((unsigned long long)a1.y << 32) | a1.x);
+    const long long sz = (long long)(((unsigned long long)a1.w << 32) | a1.z);
+    const uint4 a3 = reinterpret_cast<const uint4 *>(q)[3];
+    const unsigned int ni = a3.x;
     const double cnt = (double)ni;
     float4 o;
-    o.x = (float)(((double)t.sx[s] / cnt) / 1048576.0);
-    o.y = (float)(((double)t.sy[s] / cnt) / 1048576.0);
-    o.z = (float)(((double)t.sz[s] / cnt) / 1048576.0);
-    const unsigned int rgba = (t.c0[s] / ni) | ((t.c1[s] / ni) << 8) | ((t.c2[s] / ni) << 16) | ((t.c3[s] / ni) << 24);
+    o.x = (float)(((double)sx / cnt) / 1048576.0);
+    o.y = (float)(((double)sy / cnt) / 1048576.0);
+    o.z = (float)(((double)sz / cnt) / 1048576.0);
+    const unsigned int rgba = (a2.x / ni) | ((a2.y / ni) << 8) | ((a2.z / ni) << 16) | ((a2.w / ni) << 24);     // c0, c1 | c2, c3
     o.w = __int_as_float((int)rgba);
     out[rank] = o;
+    uint4 *w = reinterpret_cast<uint4 *>(q);                              // leave the slot empty for the next call
+    w[0] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
+    w[1] = make_uint4(0u, 0u, 0u, 0u); w[2] = make_uint4(0u, 0u, 0u, 0u); w[3] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // src/saveOutput.cpp:84-92: PassThrough z in [0, z_max] on a (down-sampled) keyframe cloud, then
