@@ -83,6 +83,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bruteforce", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the config-3 / config-5 / survey-noise / resident legs")
+    ap.add_argument("--timed-only", action="store_true", help="stop after the timed region (kernel traces of the pipelined regime alone)")
     ap.add_argument("--profile-aligns", type=int, default=48, help="alignments of the event-profiled pass (roofline launch time)")
     ap.add_argument("--seed0", type=int, default=1000)
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
@@ -682,6 +683,17 @@ def main():
         out["config"]["gathered_pose_records"] = len(table)
 
     tiles = args.nn_mode in (capi.NN_AUTO, capi.NN_TILES)
+    if args.timed_only:
+        if rank == 0:
+            _FINAL.append(json.dumps(out))
+        for hh in handles:
+            hh.close()
+        if comm is not None:
+            comm.close()
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        _emit_final()
+        return
     # ---- un-overlapped latency and the event-profiled pass (rank-local; reported by rank 0)
     st1 = Streamer([handles[0]], [pools[0]], P)
     nl = min(32, max(4, aligns))

@@ -1,17 +1,25 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (via gpurun): default bench line, rocprofv3 kernel stats and the PMC passes the roofline
-# object cites; everything lands under gpurun_out/refresh/ (copy into profiles/ afterwards with
-# tools/collect_profiles.py).  usage: bash tools/refresh_profiles.sh <tag>
+# Runs ON THE GPU BOX (via gpurun): the default bench line, rocprofv3 kernel stats, the kernel trace of the pipelined
+# regime and the PMC passes the roofline objects cite; everything lands under gpurun_out/refresh_<tag>/ (turn it into
+# profiles/<tag>_* afterwards with tools/collect_profiles.py <tag>).  usage: bash tools/refresh_profiles.sh r02
 set -u
-TAG=${1:-r01_final}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/refresh
-mkdir -p $OUT
+OUT=$R/gpurun_out/refresh_$TAG
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 900 python $R/bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+Q="--no-extra-configs --no-cpu-baseline --no-bruteforce"
+timeout 1200 python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $R/bench.py --steps 2 --warmup 1 --no-extra-configs --no-cpu-baseline > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace -d $OUT/pipe -o pipe -- python $R/bench.py --steps 3 --warmup 1 $Q --timed-only > $OUT/pipe_bench.json 2> /dev/null
+timeout 600 rocprofv3 --kernel-trace -d $OUT/solo -o solo -- python $R/bench.py --steps 1 --warmup 1 --pairs-per-step 96 --no-pipeline $Q --timed-only > $OUT/solo_bench.json 2> /dev/null
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY"; do
     n=$(echo $set | cut -d" " -f1)
-    timeout 300 rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc_$n -o pmc -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-bruteforce > /dev/null 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc_P1_$n -o pmc -- python $R/bench.py --steps 1 --warmup 1 --pairs-per-step 24 --no-pipeline $Q --timed-only > /dev/null 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc_P64_$n -o pmc -- python $R/bench.py --steps 1 --warmup 1 --pairs 64 --pairs-per-step 64 --pool 64 --no-pipeline $Q --timed-only > /dev/null 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc $set -d $OUT/pmc_D_$n -o pmc -- python $R/bench.py --mode dense --width 1280 --height 960 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done
-ls -R $OUT | head -40
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/vox -o vox -- python $R/bench.py --mode voxel --steps 50 --warmup 5 --no-cpu-baseline > $OUT/voxel_bench.json 2> /dev/null
+timeout 300 python $R/bench.py --mode voxel --steps 200 --warmup 20 > $OUT/voxel_bench.json 2> /dev/null
+timeout 300 python $R/bench.py --mode seg --pairs 64 --steps 20 --warmup 3 > $OUT/seg64_bench.json 2> /dev/null
+ls -R $OUT | head -60
