@@ -419,3 +419,59 @@ def test_plane_gate_twin_without_gpu():
         d = np.linalg.norm(moved(p1, wrong)[:, None, :].astype(np.float64) - p2[None].astype(np.float64), axis=2).min(1)
         assert capi.plane_gate(p1, p2, wrong, 0.15) == int((d <= 0.15).sum())
     assert capi.plane_gate(np.zeros((0, 4), np.float32), unit_planes(2), np.eye(4)) == 0
+
+
+@pytest.mark.gpu
+def test_control_flow_against_python_twin(gpu_lib, tmp_path):
+    """Row f-4 with an ORACLE for the control flow (the loop-closure test was property-only): tests/
+    slam_twin.py re-states run / generateKeyFrame / loopClosure / lostRecovery / findMoreLoops in Python over the same
+    C-ABI.  A there-and-back sequence with two blank frames (lost branch, recovery) and loop-closure detection on must
+    give the SAME keyframes, lost list, log lines, loop-closure lines and graph edges from run_SLAM and from the twin."""
+    import slam_twin
+    _build_host()
+    step = synth.pose_from_seed(4242, max_angle_deg=1.0, max_trans=0.02)
+    fwd = [np.eye(4)]
+    for k in range(5):
+        fwd.append(step @ fwd[-1])
+    poses = fwd + fwd[-2::-1] + fwd[1:4]                             # 0..5, back to 0, out again to 3: 14 frames
+    blank = (7, 8)
+    intr, data = _sequence(tmp_path, poses, blank=blank)
+    cfg = dict(max_pos_change=0.005, lost_frames=0, loop_closure_detection=True, loopclosure_frames=4, icp_iterations=15)
+    (tmp_path / "parameters.yaml").write_text(
+        PARAMS.format(src=str(data), mpc=cfg["max_pos_change"], fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=320, h=240, lc="yes", planes="no",
+                      pcd="no", extra="").replace("lost_frames: 10", "lost_frames: 0"))
+    n = len(poses) - 1
+    out = subprocess.run([os.path.join(HOST, "run_SLAM"), str(n)], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+
+    from PIL import Image
+    depth_of = lambda i: np.array(Image.open(str(data / "dep_index" / f"{i}.png"))).astype(np.uint16)
+    tw = slam_twin.Twin(intr, depth_of, cfg)
+    try:
+        for _ in range(n):
+            tw.run()
+        tw.find_more_loops()
+    finally:
+        tw.close()
+
+    kf = np.loadtxt(str(tmp_path / "data" / "keyframe.txt"), dtype=int).reshape(-1, 2)
+    assert kf.tolist() == [[k["id"], k["frame_index"]] for k in tw.keyframes]
+    log = (tmp_path / "data" / "error_of_transform.log").read_text().split()
+    assert len(log) == len(tw.err_log)
+    for a, b in zip(log, tw.err_log):
+        assert a == b if isinstance(b, str) else abs(float(a) - b) <= 1e-5 * max(1.0, abs(b)), (a, b)
+    assert "9999" in log                                              # the blank frames took the lost branch
+    lost_path = tmp_path / "data" / "lost.txt"
+    lost = [int(x) for x in lost_path.read_text().split()] if lost_path.exists() else []
+    assert lost == [v for pair in tw.lost_lines for v in pair] and len(lost) >= 2
+    lc = [ln.split() for ln in (tmp_path / "data" / "lc.txt").read_text().splitlines()]
+    assert [(int(t[0]), int(t[1]), int(t[3])) for t in lc] == [(a, b, d) for a, b, _, d in tw.lc_lines]
+    for t, (_, _, nrm, _) in zip(lc, tw.lc_lines):
+        assert abs(float(t[2]) - nrm) <= 1e-5 * max(1.0, nrm)
+    assert len(lc) >= 3
+    edges = [(int(t[1]), int(t[2])) for t in (ln.split() for ln in (tmp_path / "data" / "final.g2o").read_text().splitlines()) if t[0] == "EDGE_SE3:QUAT"]
+    assert edges == tw.edges
+    traj = np.loadtxt(str(tmp_path / "data" / "trajectory_icp.txt"))
+    assert traj.shape[0] == len(tw.traj)
+    for row, (idx, T) in zip(traj, tw.traj):
+        assert int(row[0]) == idx and np.abs(row[1:4] - T[:3, 3]).max() < 1e-6

@@ -18,7 +18,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(ROOT, "gpurun_out", f"refresh_{tag}")
-dst = os.path.join(ROOT, "profiles")
+# the rocpd databases are too large to travel back from the GPU box: refresh_profiles.sh runs this script THERE with a
+# destination under gpurun_out/ (which is merged back); copy those small files into profiles/ afterwards
+dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
 
 
 def last_json(path):
