@@ -281,6 +281,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
         delete h;
         return oom ? SLAM3D_E_NOMEM : SLAM3D_E_HIP;
     }
+    (void)hipMemsetAsync(h->ticket, 0, sizeof(unsigned int) * (size_t)h->maxB, h->stream);
     h->frames.assign(h->maxF, FrameHost());
     h->pair_src.assign(h->maxB, -1); h->pair_tgt.assign(h->maxB, -1);
     h->h_pairs.assign(h->maxB, PairPtrs{}); h->up_pairs.assign(h->maxB, PairPtrs{});
@@ -503,7 +504,6 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         FrameTasks a;
         const int n = (int)std::min<size_t>(FRAME_ARGS, tasks.size() - k0);
         for (int k = 0; k < n; ++k) a.t[k] = tasks[k0 + k];
-        hipLaunchKernelGGL(k_frame_begin, dim3(1), dim3(64), 0, s, a, n);
         hipLaunchKernelGGL(k_frame_tiles, dim3(tg.ntiles, n), dim3(64), 0, s, a, g, tg);
         hipLaunchKernelGGL(k_coarse_boxes, dim3(tg.ncoarse, n), dim3(64), 0, s, a, tg);
     }
@@ -570,7 +570,9 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         };
         if (dense) { if (h->dbg) launch(k_nn_tiles_acc<3, 8, false, true>); else launch(k_nn_tiles_acc<3, 8, false, false>); }
         else       { if (h->dbg) launch(k_nn_tiles_acc<3, S3D_COOP_WPE, true, true>);  else launch(k_nn_tiles_acc<3, S3D_COOP_WPE, true, false>); }
-        if ((it == 1 && do_solve) || balance)      // costs are stable from the second iteration on: balance the blocks once
+        // costs are stable from the second iteration on: balance the blocks once per run (re-balancing only every n-th
+        // run was measured: the 12 us saved are lost again to 1 us longer NN launches)
+        if ((it == 1 && do_solve) || balance)
             hipLaunchKernelGGL(k_balance, dim3(B), dim3(1024), 0, s, h->cost, perm, tg, gx, dense ? 0 : h->xcd_bands);
         if (e1) HIPCHK(h, hipEventRecord(e1, s));
     } else {
@@ -595,8 +597,12 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
     if (h->want_corr_trace && do_solve)          // this iteration's slot-order indices (index parity per iteration)
         HIPCHK(h, hipMemcpyAsync(h->corr_trace + (size_t)it * h->maxB * tg.nslots, h->corr, sizeof(int) * (size_t)B * tg.nslots,
                                  hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_solve_acc, dim3(B), dim3(64), 0, s, h->acc, raw_out, h->Tcur, h->trace_T, h->trace_S, h->flags, h->d_pairs,
-                       do_solve ? h->d_res : nullptr, it, iters, h->p.estimator, do_solve);
+    if (h->p.estimator == SLAM3D_EST_POINT2PLANE)
+        hipLaunchKernelGGL(k_solve_acc<0>, dim3(B), dim3(64), 0, s, h->acc, raw_out, h->Tcur, h->trace_T, h->trace_S, h->flags, h->d_pairs,
+                           do_solve ? h->d_res : nullptr, it, iters, do_solve);
+    else
+        hipLaunchKernelGGL(k_solve_acc<1>, dim3(B), dim3(64), 0, s, h->acc, raw_out, h->Tcur, h->trace_T, h->trace_S, h->flags, h->d_pairs,
+                           do_solve ? h->d_res : nullptr, it, iters, do_solve);
     HIPCHK(h, hipGetLastError());
     return SLAM3D_OK;
 }

@@ -283,6 +283,32 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
+// FOUR all-lanes minima for the price of one: v_permlane32_swap(a, b) lays a's lower / upper halves beside b's, so ONE
+// v_min yields min(a[i], a[i+32]) in lanes 0..31 and the same for b in lanes 32..63; v_permlane16_swap does it again for
+// two such registers; the four in-row DPP steps finish all four at once.  Result: every lane of row 0 holds min(a), row 1
+// min(c), row 2 min(b), row 3 min(d) -- read them with v_readlane at lanes 0 / 16 / 32 / 48.  (A maximum is the negated
+// minimum of the negated values.)  10 VALU instructions instead of 40.  Inputs are never NaN.
+__device__ __forceinline__ float pair32_min(float a, float b)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_int(a), __float_as_int(b), false, false);
+    float v;
+    asm("v_min_f32 %0, %1, %2" : "=v"(v) : "v"(r[0]), "v"(r[1]));
+    return v;
+}
+__device__ __forceinline__ float pair16_min(float x, float y)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_int(x), __float_as_int(y), false, false);
+    float v;
+    asm("v_min_f32 %0, %1, %2" : "=v"(v) : "v"(r[0]), "v"(r[1]));
+    return v;
+}
+__device__ __forceinline__ float wave_min_x4(float a, float b, float c, float d)
+{
+    float x = pair16_min(pair32_min(a, b), pair32_min(c, d));
+    S3D_DPP4("v_min_f32_dpp", x);
+    return x;      // row 0: a, row 1: c, row 2: b, row 3: d
+}
+
 // grid (ntiles, ntasks), block 64: one (frame, role) per blockIdx.y.  Source role: srcT slot w = pixel index (int
 // bits) or -1; rows outside [row0,row1) hold no source (dense multi-GPU mode).  Target role: a tile record (TILE_REC
 // float4) holds its four 4x4-pixel quadrants, each compacted (valid slots first; a slot is (pixel index, x, y, z))
@@ -309,6 +335,7 @@ __global__ __launch_bounds__(64) void k_frame_tiles(FrameTasks a, Geometry g, Ti
     const unsigned long long m = __ballot(ok);
     const int cnt = __popcll(m);
     if (lane == 0) ft.scount[t] = cnt;                                // summed per coarse cell (no hot atomic)
+    if (t == 0 && lane == 0) ft.counts[which] = 0;                    // the role's total: k_coarse_boxes (next launch) adds to it
     if (which == 0) {
         ft.tiles[(size_t)t * TILE_SLOTS + lane] = q;
         return;
@@ -346,8 +373,8 @@ __global__ __launch_bounds__(64) void k_frame_tiles(FrameTasks a, Geometry g, Ti
     }
 }
 
-// grid (ncoarse, ntasks), block 64: totals the valid points of the task's role into the frame's counts (which the
-// host zeroed through k_frame_begin); target role: also the AABB of the 8x8 child tiles
+// grid (ncoarse, ntasks), block 64: totals the valid points of the task's role into the frame's counts (zeroed by
+// k_frame_tiles, the launch before); target role: also the AABB of the 8x8 child tiles
 __global__ __launch_bounds__(64) void k_coarse_boxes(FrameTasks a, TileGrid tg)
 {
     const int c = blockIdx.x, lane = threadIdx.x;
@@ -371,12 +398,6 @@ __global__ __launch_bounds__(64) void k_coarse_boxes(FrameTasks a, TileGrid tg)
         ft.cbox[(size_t)c * 2] = make_float4(mnx, mny, mnz, 0.0f);
         ft.cbox[(size_t)c * 2 + 1] = make_float4(mxx, mxy, mxz, 0.0f);
     }
-}
-
-// zero the role totals of the tasks' frames before they are rebuilt (block 64, one task per lane)
-__global__ void k_frame_begin(FrameTasks a, int n)
-{
-    if ((int)threadIdx.x < n) a.t[threadIdx.x].counts[a.t[threadIdx.x].role] = 0;
 }
 
 // start of a run for the pairs [b0, b0 + n): T = T_init (kernel argument) or Identity, trace row 0, flags, clean
@@ -1103,14 +1124,24 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     // inflate the search region of the whole wave.
     float qminx, qminy, qminz, qmaxx, qmaxy, qmaxz, lminx, lminy, lminz, lmaxx, lmaxy, lmaxz;
     bool any_loose = false;
-    auto class_boxes = [&]() __attribute__((always_inline)) {
-        qminx = wave_min(tight ? px : inf); qminy = wave_min(tight ? py : inf); qminz = wave_min(tight ? pz : inf);
-        qmaxx = wave_max(tight ? px : -inf); qmaxy = wave_max(tight ? py : -inf); qmaxz = wave_max(tight ? pz : -inf);
+    // both classes' boxes AND their thresholds (largest current bound of the class) from packed reductions: seven values
+    // per class in two wave_min_x4 (maxima as negated minima)
+    auto class_boxes_thr = [&](float &thr_t, float &thr_l) __attribute__((always_inline)) {
+        const float cur = __int_as_float((int)(unsigned int)(bkey >> 32));
+        const float a = wave_min_x4(tight ? px : inf, tight ? py : inf, tight ? pz : inf, tight ? -px : inf);
+        const float c = wave_min_x4(tight ? -py : inf, tight ? -pz : inf, tight ? -cur : 0.0f, 0.0f);
+        qminx = rdlane(a, 0); qminy = rdlane(a, 32); qminz = rdlane(a, 16); qmaxx = -rdlane(a, 48);
+        qmaxy = -rdlane(c, 0); qmaxz = -rdlane(c, 32);
+        thr_t = -rdlane(c, 16) * 1.00001f + 1e-30f;                // covers the rounding of box_gap2 and of canon_d2
         any_loose = __ballot(loose) != 0ull;
         lminx = lminy = lminz = inf; lmaxx = lmaxy = lmaxz = -inf;
+        thr_l = 0.0f;
         if (any_loose) {
-            lminx = wave_min(loose ? px : inf); lminy = wave_min(loose ? py : inf); lminz = wave_min(loose ? pz : inf);
-            lmaxx = wave_max(loose ? px : -inf); lmaxy = wave_max(loose ? py : -inf); lmaxz = wave_max(loose ? pz : -inf);
+            const float e = wave_min_x4(loose ? px : inf, loose ? py : inf, loose ? pz : inf, loose ? -px : inf);
+            const float f = wave_min_x4(loose ? -py : inf, loose ? -pz : inf, loose ? -cur : 0.0f, 0.0f);
+            lminx = rdlane(e, 0); lminy = rdlane(e, 32); lminz = rdlane(e, 16); lmaxx = -rdlane(e, 48);
+            lmaxy = -rdlane(f, 0); lmaxz = -rdlane(f, 32);
+            thr_l = -rdlane(f, 16) * 1.00001f + 1e-30f;
         }
     };
     // gap test of a box against both query boxes with the CURRENT class bounds (empty class -> never hits)
@@ -1121,8 +1152,9 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     };
     auto class_thr = [&](float &thr_t, float &thr_l) __attribute__((always_inline)) {
         const float cur = __int_as_float((int)(unsigned int)(bkey >> 32));
-        thr_t = wave_max(tight ? cur : 0.0f) * 1.00001f + 1e-30f;    // covers the rounding of box_gap2 and of canon_d2
-        thr_l = any_loose ? wave_max(loose ? cur : 0.0f) * 1.00001f + 1e-30f : 0.0f;
+        const float m = wave_min_x4(tight ? -cur : 0.0f, loose ? -cur : 0.0f, 0.0f, 0.0f);     // both maxima in one pass
+        thr_t = -rdlane(m, 0) * 1.00001f + 1e-30f;                   // covers the rounding of box_gap2 and of canon_d2
+        thr_l = any_loose ? -rdlane(m, 32) * 1.00001f + 1e-30f : 0.0f;
     };
     // fine level of coarse cell cc, in three pieces so that the cooperative build can keep several loads in flight:
     // (1) the child boxes (lane k holds child tile k of the 8x8 cell) ...
@@ -1282,7 +1314,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                 wcentre[w][lane] = v;
             }
         }
-        class_boxes();
+        float thr_t, thr_l;
+        class_boxes_thr(thr_t, thr_l);
         if (COOP && lane < 13) {   // the boxes do not change while the items are drained: helpers read them instead of redoing 12 wave reductions
             const float bx[13] = { qminx, qminy, qminz, qmaxx, qmaxy, qmaxz, lminx, lminy, lminz, lmaxx, lmaxy, lmaxz, any_loose ? 1.0f : 0.0f };
             float v = bx[0];
@@ -1290,8 +1323,6 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             for (int k = 1; k < 13; ++k) if (lane == k) v = bx[k];
             wbox[w][lane] = v;
         }
-        float thr_t, thr_l;
-        class_thr(thr_t, thr_l);
         for (int c0 = 0; c0 < tg.ncoarse; c0 += 64) {
             const int cidx = c0 + lane;
             bool hit = false;
@@ -1750,17 +1781,140 @@ __device__ inline void solve_update_one(const double *__restrict__ sums, double 
     for (int k = 0; k < 16; ++k) trace_T_b[(size_t)(it + 1) * 16 + k] = T[k];
 }
 
+// ---- wave-parallel form of solve_update_one for the point-to-plane estimator (k_solve_acc's single wave).  Same
+// operations in the same order per value as the serial code above (which the svd estimator and the dense mode's k_solve
+// still run, and which the oracle restates), so every bit of T is the same -- but no 6x6 arrays in one lane's registers
+// (the serial form needed 124 VGPRs and 192 B of scratch):
+//   LDL^T       lane i < 6 owns row i of A and of L; at step j every lane forms v_i = A_ij - sum_k (L_ik L_jk) D_k with
+//               L_jk broadcast from lane j -- for i == j that is the pivot d_j, for i > j it is L_ij d_j;
+//   forward     y_i -= L_ik y_k with y_k broadcast, k ascending (the serial order per row);
+//   backward    x_5 .. x_0 on broadcast values, terms k ascending (the serial order);
+//   sin / cos   lanes 0, 1, 2; compose: lane l < 12 forms entry l of the new T.
+// (Tried and dropped: running this in the tail of the NN launch, by the block that takes the pair's last ticket.  The
+// chain ticket -> collect the accumulators -> solve is as long as the launch it replaces (un-overlapped latency 0.91 ->
+// 0.94 ms) and the call cost the throughput build 40 SGPR spills: 58 k -> 54 k it/s at 64 pairs per launch.)
+__device__ __forceinline__ double bcast_d(double v, int src_lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// tot: the 29 sums (LDS), sh: T of the pair (LDS, 16 doubles); all 64 lanes of the wave call this
+__device__ __forceinline__ void wave_solve_update_point2plane(const double *tot, const double *sh, double *__restrict__ Tcur_b,
+                                                              double *__restrict__ trace_T_b, double *__restrict__ trace_S_b,
+                                                              int *__restrict__ flag_b, int it, double *__restrict__ res_rec /* nullable */,
+                                                              const PairPtrs &pp)
+{
+    const int lane = threadIdx.x & 63;
+    if (lane < NSUMS) trace_S_b[(size_t)it * NSUMS + lane] = tot[lane];
+    const int i = lane < 6 ? lane : 5;                      // lanes >= 6 shadow row 5 (their values are never used)
+    int rc = 0;
+    double x0 = 0, x1 = 0, x2 = 0, x3 = 0, x4 = 0, x5 = 0;
+    if (!(tot[27] < 6.0)) {
+        // row i of the symmetric matrix from the 21 upper-triangle sums: entry (r, c), r <= c, sits at first[r] + (c - r)
+        double Ar[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int r0 = i < c ? i : c, c0 = i < c ? c : i;
+            const int first = r0 == 0 ? 0 : (r0 == 1 ? 6 : (r0 == 2 ? 11 : (r0 == 3 ? 15 : (r0 == 4 ? 18 : 20))));
+            Ar[c] = tot[first + (c0 - r0)];
+        }
+        const double bi = tot[21 + i];
+        double tr = 0.0;
+        tr += tot[0]; tr += tot[6]; tr += tot[11]; tr += tot[15]; tr += tot[18]; tr += tot[20];
+        if (tr > 0.0) {
+            const double floor_piv = 1e-12 * tr / 6.0;
+#pragma unroll 1
+            for (int attempt = 0; attempt < 2 && rc == 0; ++attempt) {
+                if (attempt == 1) {                          // A[r][r] = A[r][r] + lam on every diagonal entry
+                    const double lam = 1e-9 * tr / 6.0;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) if (c == i) Ar[c] = Ar[c] + lam;
+                }
+                double L[6] = { 0, 0, 0, 0, 0, 0 }, D[6] = { 0, 0, 0, 0, 0, 0 };
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    if (ok) {
+                        double v = Ar[j];
+#pragma unroll
+                        for (int k = 0; k < j; ++k) v -= (L[k] * bcast_d(L[k], j)) * D[k];
+                        const double d = bcast_d(v, j);
+                        if (!(d > floor_piv)) ok = false;
+                        else { D[j] = d; L[j] = v / d; }
+                    }
+                }
+                if (!ok) continue;
+                double yv = bi;                              // forward: y_i = b_i - sum_{k<i} L_ik y_k
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const double yk = bcast_d(yv, k);
+                    if (i > k) yv -= L[k] * yk;
+                }
+                {                                            // y_i = y_i / D_i
+                    double Di = D[0];
+#pragma unroll
+                    for (int k = 1; k < 6; ++k) if (i == k) Di = D[k];
+                    yv = yv / Di;
+                }
+                // backward on broadcast values: x_i = y_i - sum_{k>i} L_ki x_k, k ascending
+                x5 = bcast_d(yv, 5);
+                x4 = bcast_d(yv, 4); x4 -= bcast_d(L[4], 5) * x5;
+                x3 = bcast_d(yv, 3); x3 -= bcast_d(L[3], 4) * x4; x3 -= bcast_d(L[3], 5) * x5;
+                x2 = bcast_d(yv, 2); x2 -= bcast_d(L[2], 3) * x3; x2 -= bcast_d(L[2], 4) * x4; x2 -= bcast_d(L[2], 5) * x5;
+                x1 = bcast_d(yv, 1); x1 -= bcast_d(L[1], 2) * x2; x1 -= bcast_d(L[1], 3) * x3; x1 -= bcast_d(L[1], 4) * x4; x1 -= bcast_d(L[1], 5) * x5;
+                x0 = bcast_d(yv, 0); x0 -= bcast_d(L[0], 1) * x1; x0 -= bcast_d(L[0], 2) * x2; x0 -= bcast_d(L[0], 3) * x3; x0 -= bcast_d(L[0], 4) * x4;
+                x0 -= bcast_d(L[0], 5) * x5;
+                rc = attempt == 0 ? 1 : 2;
+            }
+        }
+    }
+    double Tn = lane < 16 ? sh[lane] : 0.0;                 // unchanged when the solve failed
+    if (rc) {
+        double s_, c_;
+        spec_sincos(lane == 0 ? x0 : (lane == 1 ? x1 : x2), s_, c_);
+        const double sa = bcast_d(s_, 0), ca = bcast_d(c_, 0), sb = bcast_d(s_, 1), cb = bcast_d(c_, 1), sg = bcast_d(s_, 2), cg = bcast_d(c_, 2);
+        const int r = (lane >> 2) & 3, c = lane & 3;
+        // row r of dR = Rz(g) Ry(b) Rx(a), the expressions of solve_update_one
+        const double d0 = r == 0 ? cg * cb : (r == 1 ? sg * cb : -sb);
+        const double d1 = r == 0 ? (cg * sb) * sa - sg * ca : (r == 1 ? (sg * sb) * sa + cg * ca : cb * sa);
+        const double d2 = r == 0 ? (cg * sb) * ca + sg * sa : (r == 1 ? (sg * sb) * ca - cg * sa : cb * ca);
+        const double dtr = r == 0 ? x3 : (r == 1 ? x4 : x5);
+        if (lane < 12) {
+            Tn = (d0 * sh[c] + d1 * sh[4 + c]) + d2 * sh[8 + c];
+            if (c == 3) Tn = Tn + dtr;
+        } else if (lane < 16) {
+            Tn = lane == 15 ? 1.0 : 0.0;
+        }
+        if (lane < 16) Tcur_b[lane] = Tn;
+    }
+    if (lane < 16) trace_T_b[(size_t)(it + 1) * 16 + lane] = Tn;
+    int flag = 0;
+    if (lane == 0) {
+        flag = *flag_b;
+        if (rc == 2) flag |= 1;
+        if (rc == 0) flag |= 2;        // no update in this iteration: never a silent "ok"
+        *flag_b = flag;
+    }
+    if (res_rec) {
+        if (lane < 16) res_rec[lane] = Tn;
+        if (lane < NSUMS) res_rec[16 + lane] = tot[lane];
+        if (lane == 0) { res_rec[45] = (double)flag; res_rec[46] = (double)pp.src_counts[0]; res_rec[47] = (double)pp.tgt_counts[1]; }
+    }
+}
+
 // The iteration's tail: grid (B), block 64.  Lane k adds the replicas of component k (integers: any order),
 // converts to double, clears the accumulators for the next launch; lane 0 solves and updates T (do_solve) or the
 // raw integer sums go to `raw_out` for the caller's all-reduce (dense mode).  In the final iteration the pose
 // record goes straight to host-mapped memory, so fetch_results is a stream synchronisation with no copies.
+template <int EST>
 __global__ __launch_bounds__(64) void k_solve_acc(long long *__restrict__ acc, long long *__restrict__ raw_out,
                                                   double *__restrict__ Tcur, double *__restrict__ trace_T,
                                                   double *__restrict__ trace_S, int *__restrict__ flags,
                                                   const PairPtrs *__restrict__ pairs, double *__restrict__ res_host,
-                                                  int it, int iters, int estimator, int do_solve)
+                                                  int it, int iters, int do_solve)
 {
-    __shared__ double tot[NSUMS];
+    __shared__ double tot[32], Tsh[16];
     const int b = blockIdx.x, k = threadIdx.x;
     long long *__restrict__ A = acc + (size_t)b * ACC_R * ACC_STRIDE;
     if (k < NSUMS) {
@@ -1772,10 +1926,17 @@ __global__ __launch_bounds__(64) void k_solve_acc(long long *__restrict__ acc, l
         if (raw_out) raw_out[b * NSUMS + k] = q;
         tot[k] = (double)q / FIX_SCALE;
     }
+    if (k < 16) Tsh[k] = Tcur[b * 16 + k];
     __syncthreads();
+    if constexpr (EST == 0) {                 // point-to-plane: the whole wave solves (lane-parallel LDL^T, no scratch)
+        if (do_solve)
+            wave_solve_update_point2plane(tot, Tsh, Tcur + b * 16, trace_T + (size_t)b * (iters + 1) * 16, trace_S + (size_t)b * iters * NSUMS,
+                                          flags + b, it, (res_host && it == iters - 1) ? res_host + (size_t)b * RES_REC : nullptr, pairs[b]);
+        return;
+    }
     if (k == 0 && do_solve) {
         solve_update_one(tot, Tcur + b * 16, trace_T + (size_t)b * (iters + 1) * 16, trace_S + (size_t)b * iters * NSUMS,
-                         flags + b, it, estimator);
+                         flags + b, it, EST);
         if (res_host && it == iters - 1) {
             double *__restrict__ r = res_host + (size_t)b * RES_REC;
             for (int j = 0; j < 16; ++j) r[j] = Tcur[b * 16 + j];
