@@ -865,7 +865,7 @@ __device__ __forceinline__ void finish_slot(bool valid, unsigned long long key, 
                                             const float4 *__restrict__ tcloud, const float4 *__restrict__ tnrm,
                                             float gate2, int estimator, int *__restrict__ corr_out,
                                             float *__restrict__ cd2_out, float4 *__restrict__ prevq_out,
-                                            RowBasis &B, bool write_out = true)
+                                            RowBasis &B, bool write_out = true, int jprev = -2 /* match the slot already holds (-2: unknown) */)
 {
 #pragma unroll
     for (int k = 0; k < 8; ++k) B.v[k] = 0.0;
@@ -884,7 +884,9 @@ __device__ __forceinline__ void finish_slot(bool valid, unsigned long long key, 
         row_basis(estimator, px, py, pz, q4, n4, B);
         pq = make_float4(q4.x, q4.y, q4.z, __int_as_float(j));
     }
-    *prevq_out = pq;        // next iteration's upper bound comes from this point (no dependent gather)
+    // next iteration's upper bound comes from this point (no dependent gather).  Once the pose has settled most matches
+    // repeat: a slot that already holds this very match is not written again (same bits, 16 B of traffic less)
+    if (__float_as_int(pq.w) != jprev) *prevq_out = pq;
 }
 
 // accumulation for the brute-force modes: grid (nchunks, B), one thread per source slot, one wave per tile
@@ -1233,6 +1235,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     };
 
     // ================= step 1: own tile =================
+    int own_jprev = -2;                               // what prevq holds for this lane's slot (-2: nothing known, always write)
     int hc = -1, hctx = 0, hcty = 0;                  // cooperative build: the prefetched "home" coarse cell and its child boxes
     float4 hlo = make_float4(inf, inf, inf, 0), hhi = make_float4(-inf, -inf, -inf, 0);
     const float4 s4 = has_tile ? pp.srcT[(size_t)t * TILE_SLOTS + lane] : make_float4(0, 0, 0, __int_as_float(-1));
@@ -1281,6 +1284,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         const Rt m = load_rt(Tcur + b * 16);
         xform(m, s4.x, s4.y, s4.z, px, py, pz);
         valid = own_valid;
+        if (!first) own_jprev = __float_as_int(pq.w);
         // ---- upper bound: previous match, else the target at the same pixel, else the gate
         {
             const int jprev = __float_as_int(pq.w);
@@ -1466,7 +1470,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     if constexpr (COOP) bkey = qkey[w][lane];
     if (__ballot(own_valid) == 0ull) bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
     RowBasis rb;
-    finish_slot(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, prevq + gs, rb, write_out != 0);
+    finish_slot(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, prevq + gs, rb, write_out != 0, own_jprev);
     tile_accumulate(g.estimator, rb, acc + ((size_t)b * ACC_R + (c % ACC_R)) * ACC_STRIDE);
     {   // hint for the next iteration: the tile holding the match of a lane near the tile centre
         const bool ok = rb.v[7] != 0.0;
