@@ -73,9 +73,9 @@ struct slam3d_icp_handle {
     float4 *prevq = nullptr;
     long long *dbg = nullptr;     // per-tile NN statistics, only with SLAM3D_NN_DEBUG=1
     int *hint = nullptr;          // per source tile: target tile where the previous matches were
-    int *perm = nullptr, *cost = nullptr;   // balanced tile->(block,wave) assignment and its input (cycles per tile)
-    int *perm_d = nullptr;                  // the same for the throughput build (no bands, no slack)
-    int nn_gx = 0, nn_gx_d = 0, xcd_bands = 1;   // k_nn_tiles_acc grid widths (multiples of 8; nn_gx with slack for the equal-cost XCD bands)
+    int *cost = nullptr;                    // cycles per tile of the last launch: input of k_balance (throughput build)
+    int *perm_d = nullptr;                  // its cost-balanced tile->(block,wave) assignment
+    int nn_gx = 0, nn_gx_d = 0;             // k_nn_tiles_acc grid widths (multiples of 8): cooperative / throughput build
     float *tgtB = nullptr;        // BRUTE_MFMA: B-layout targets [B][4][npad]
     unsigned int *qmax2 = nullptr; int npad = 0;
     // host
@@ -157,7 +157,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->src_c); F(h->tgt_c); F(h->ccounts); F(h->corr); F(h->ticket);
     F(h->flags); F(h->best); F(h->cd2); F(h->acc); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
     F(h->d_pairs); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4); F(h->corr_trace);
-    F(h->dbg); F(h->prevq); F(h->hint); F(h->perm); F(h->perm_d); F(h->cost); F(h->tgtB); F(h->qmax2);
+    F(h->dbg); F(h->prevq); F(h->hint); F(h->perm_d); F(h->cost); F(h->tgtB); F(h->qmax2);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->pin_res) (void)hipHostFree(h->pin_res);
     if (h->pin_seg) (void)hipHostFree(h->pin_seg);
@@ -249,18 +249,19 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     A(dalloc(h->acc, (size_t)h->maxB * ACC_R * ACC_STRIDE));
     A(dalloc(h->hint, (size_t)h->maxB * tg.ntiles));
     A(dalloc(h->cost, (size_t)h->maxB * tg.ntiles));
-    {   // grid width of the NN kernel: one wave per tile + slack (equal-cost XCD bands differ in tile count), multiple of 8
-        const int slack = getenv("SLAM3D_NN_SLACK") ? atoi(getenv("SLAM3D_NN_SLACK")) : 20;     // 20 %: measured best (10: band spill, 30: more empty waves)
-        if (getenv("SLAM3D_XCD_BANDS")) h->xcd_bands = atoi(getenv("SLAM3D_XCD_BANDS"));
+    {   // grid widths of the NN kernel, multiples of 8.  Cooperative build: 20 % more waves than tiles (interleaved
+        // ownership tile c + w * G: with G = 1440 three of four blocks own three tiles; measured equal to G = 1280 and
+        // better than the exact 1200 for a pair alone: 0.86 vs 0.91 ms).  Throughput build: exactly one wave per tile.
+        const int slack = getenv("SLAM3D_NN_SLACK") ? atoi(getenv("SLAM3D_NN_SLACK")) : 20;
         const long long waves = ((long long)tg.ntiles * (100 + (slack < 0 ? 0 : slack)) + 99) / 100;
         h->nn_gx = (int)(((waves + NN_WAVES - 1) / NN_WAVES + 7) / 8 * 8);
-        if (getenv("SLAM3D_NN_GX")) {                      // developer knob: grid width of the single-pair build
+        if (getenv("SLAM3D_NN_GX")) {                      // developer knob: grid width of the cooperative build
             const int gx = atoi(getenv("SLAM3D_NN_GX")) / 8 * 8;
             if ((long long)gx * NN_WAVES >= tg.ntiles) h->nn_gx = gx;
         }
         h->nn_gx_d = ((tg.ntiles + NN_WAVES - 1) / NN_WAVES + 7) / 8 * 8;
     }
-    A(dalloc(h->perm, (size_t)h->maxB * h->nn_gx * NN_WAVES)); A(dalloc(h->perm_d, (size_t)h->maxB * h->nn_gx_d * NN_WAVES));
+    A(dalloc(h->perm_d, (size_t)h->maxB * h->nn_gx_d * NN_WAVES));
     if (getenv("SLAM3D_NN_DEBUG")) A(dalloc(h->dbg, (size_t)tg.ntiles * 20));
     if (getenv("SLAM3D_NO_GRAPH") || getenv("SLAM3D_NN_DEBUG")) h->use_graph = false;
     if (getenv("SLAM3D_DENSE_BATCH")) h->dense_batch = atoi(getenv("SLAM3D_DENSE_BATCH"));
@@ -287,7 +288,6 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     h->h_pairs.assign(h->maxB, PairPtrs{}); h->up_pairs.assign(h->maxB, PairPtrs{});
     (void)hipMemsetAsync(h->f_counts, 0, sizeof(int) * 4 * F, h->stream);
     (void)hipMemsetAsync(h->perm_d, 0xFF, sizeof(int) * (size_t)h->maxB * h->nn_gx_d * NN_WAVES, h->stream);
-    (void)hipMemsetAsync(h->perm, 0xFF, sizeof(int) * (size_t)h->maxB * h->nn_gx * NN_WAVES, h->stream);   // -1: interleaved default
     (void)hipMemsetAsync(h->hint, 0xFF, sizeof(int) * (size_t)h->maxB * tg.ntiles, h->stream);
     (void)hipMemsetAsync(h->acc, 0, sizeof(long long) * (size_t)h->maxB * ACC_R * ACC_STRIDE, h->stream);   // k_solve_acc re-zeroes after every launch
     *out = h;
@@ -561,7 +561,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         // own, 8 waves per SIMD (throughput bound); three staged tile records per wave in both
         const bool dense = B >= h->dense_batch;
         const int write_out = (!do_solve || it == iters - 1 || h->want_corr_trace) ? 1 : 0;      // corr / cd2: only the last iteration's are read
-        int *perm = dense ? h->perm_d : h->perm;
+        int *perm = dense ? h->perm_d : nullptr;            // the cooperative build owns tiles by the interleaved default
         const int gx = dense ? h->nn_gx_d : h->nn_gx;
         // four instances: {throughput, cooperative} x {production, instrumented (SLAM3D_NN_DEBUG: per-tile clocks and counters)}
         auto launch = [&](auto kern) {
@@ -570,10 +570,12 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         };
         if (dense) { if (h->dbg) launch(k_nn_tiles_acc<3, 8, false, true>); else launch(k_nn_tiles_acc<3, 8, false, false>); }
         else       { if (h->dbg) launch(k_nn_tiles_acc<3, S3D_COOP_WPE, true, true>);  else launch(k_nn_tiles_acc<3, S3D_COOP_WPE, true, false>); }
-        // costs are stable from the second iteration on: balance the blocks once per run (re-balancing only every n-th
-        // run was measured: the 12 us saved are lost again to 1 us longer NN launches)
-        if ((it == 1 && do_solve) || balance)
-            hipLaunchKernelGGL(k_balance, dim3(B), dim3(1024), 0, s, h->cost, perm, tg, gx, dense ? 0 : h->xcd_bands);
+        // Throughput build: costs are stable from the second iteration on, balance the blocks once per run (+6 % at 64
+        // pairs).  Cooperative build: never -- on a stream of DISTINCT pairs the interleaved default ownership is as good
+        // as the measured-cost deal and the 12 us of k_balance are saved: +4 % pipelined, +11 % at 1280x960 (round 1
+        // measured the deal on one pair repeated, where the previous run's map was already this pair's).
+        if (dense && do_solve && it == 1)
+            hipLaunchKernelGGL(k_balance, dim3(B), dim3(1024), 0, s, h->cost, perm, tg, gx);
         if (e1) HIPCHK(h, hipEventRecord(e1, s));
     } else {
         if (nn_mode_of(h) == SLAM3D_NN_BRUTE_MFMA) {
@@ -1226,7 +1228,7 @@ extern "C" int slam3d_icp_dense_partial(slam3d_icp_handle *h, int64_t sums[SLAM3
     if (!h->ran) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
-    const int rc = enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0, h->sums, h->dense_it == 1, h->dense_it == 0);
+    const int rc = enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0, h->sums, 0, h->dense_it == 0);
     if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(h->pin_out, h->sums, sizeof(int64_t) * NSUMS, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
@@ -1259,7 +1261,7 @@ extern "C" int slam3d_icp_dense_partial_device(slam3d_icp_handle *h, int64_t *d_
     if (!h->ran) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
-    return enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0, reinterpret_cast<long long *>(d_sums), h->dense_it == 1, h->dense_it == 0);
+    return enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0, reinterpret_cast<long long *>(d_sums), 0, h->dense_it == 0);
 }
 
 extern "C" int slam3d_icp_dense_update_device(slam3d_icp_handle *h, const int64_t *d_sums, void *stream)

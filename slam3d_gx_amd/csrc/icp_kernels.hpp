@@ -980,10 +980,9 @@ constexpr int NN_MAX_ITEMS = 128;    // (owner wave, coarse cell) work items sha
 constexpr int NN_MAX_TITEMS = 384;   // (owner wave, target tile) work items: the tiles the cell sweeps found worth scanning
 constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (8 measured slower: 2 blocks per CU)
 
-// grid (G, B), block 256 = 4 waves; G = a multiple of 8 >= ntiles/4 (+ slack, see k_balance).  Wave w of block c
-// OWNS one source tile: perm[b][c][w] once k_balance has run (cost-balanced; for few pairs per launch also
-// XCD-local: block c runs on XCD c % 8 and takes its tiles from the c % 8-th band of the frame), before that
-// tile c + w * G.
+// grid (G, B), block 256 = 4 waves; G = a multiple of 8 >= ntiles/4.  Wave w of block c OWNS one source tile: tile
+// c + w * G (interleaved: every block owns tiles of four image bands); in the throughput build perm[b][c][w] once
+// k_balance has run (cost-balanced).
 //   1. every wave: one round of loads, upper bounds, exhaustive scan of the 5 tiles around its hint tile;
 //   2. every wave publishes its queries (point, running key, tight/loose class) in LDS and appends one work
 //      item per coarse cell its two query boxes can reach;                                   -- barrier --
@@ -1024,12 +1023,14 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // ownership: the measured-cost balanced assignment once k_balance has run (perm >= 0 tile, -2 none),
     // before that (-1) tiles interleaved over the image bands
-    const int pt = __builtin_amdgcn_readfirstlane(perm[((size_t)b * gridDim.x + c) * NN_WAVES + w]);
+    // (the cooperative build always uses the interleaved default: on a stream of distinct pairs the measured-cost deal
+    // bought nothing and its kernel cost 12 us per run; no map to load either -- one dependent round trip less per wave)
+    const int pt = COOP ? -1 : __builtin_amdgcn_readfirstlane(perm[((size_t)b * gridDim.x + c) * NN_WAVES + w]);
     // default (-1, a handle's first two iterations): interleaved, tile c + w * G -- no locality, but even over the XCDs
     // whatever part of the frame holds the work (row shards of the dense mode)
     const int t = pt == -1 ? c + w * (int)gridDim.x : (pt < 0 ? tg.ntiles : pt);
     const bool has_tile = t < tg.ntiles;
-    const long long cw0 = clock64();
+    const long long cw0 = COOP ? 0 : clock64();         // per-tile cost: input of k_balance (throughput build only)
     float4 *__restrict__ st = stage_all[w];
     const size_t gs = (size_t)b * tg.nslots + (size_t)(has_tile ? t : 0) * TILE_SLOTS + lane;
     const float inf = __int_as_float(0x7f800000);
@@ -1371,7 +1372,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             }
         }
     }
-    if (lane == 0) atomicAdd(&wcost[w], (int)(clock64() - cw0));
+    if constexpr (!COOP) { if (lane == 0) atomicAdd(&wcost[w], (int)(clock64() - cw0)); }
     if constexpr (DBG) clkP = clock64();
     if constexpr (COOP) __syncthreads();
     if constexpr (DBG) clkB1 = clock64();
@@ -1403,7 +1404,6 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         while (ncell > 0) {
             const int it = lds_fetch_add_uniform(&next_item, achunk);
             if (it >= ncell) break;
-            const long long ci0 = clock64();
             const int item0 = __builtin_amdgcn_readfirstlane(items[it]);          // one address for the wave: owner and cell are scalars
             const bool two = achunk == 2 && it + 1 < ncell;
             const int item1 = two ? __builtin_amdgcn_readfirstlane(items[it + 1]) : item0;
@@ -1411,18 +1411,15 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             int ctx0, cty0, ctx1 = 0, cty1 = 0;
             cell_boxes(item0 & 0xffff, lo0, hi0, ctx0, cty0);
             if (two) cell_boxes(item1 & 0xffff, lo1, hi1, ctx1, cty1);            // both loads in flight before the first use
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                if (half == 1 && !two) break;
-                const int owner = (half ? item1 : item0) >> 16;
+            auto refine_item = [&](int item, const float4 lo, const float4 hi, int ctx, int cty) __attribute__((always_inline)) {
+                const int owner = item >> 16;
                 if constexpr (DBG) n_my_items += 1;
                 load_owner(owner);
                 load_owner_boxes(owner);
-                const int ctx = half ? ctx1 : ctx0, cty = half ? cty1 : cty0;
-                if (append_tiles(owner, cell_refine(half ? lo1 : lo0, half ? hi1 : hi0, ctx, cty), ctx, cty) && valid)
-                    atomicMin(&qkey[owner][lane], bkey);
-            }
-            if (lane == 0) atomicAdd(&wcost[item0 >> 16], (int)(clock64() - ci0));
+                if (append_tiles(owner, cell_refine(lo, hi, ctx, cty), ctx, cty) && valid) atomicMin(&qkey[owner][lane], bkey);
+            };
+            refine_item(item0, lo0, hi0, ctx0, cty0);
+            if (two) refine_item(item1, lo1, hi1, ctx1, cty1);
         }
         if constexpr (DBG) clkD = clock64();
         if (ncell > 0) __syncthreads();               // ncell is uniform over the block (read after barrier 1)
@@ -1436,7 +1433,6 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         while (true) {
             const int it = lds_fetch_add_uniform(&next_titem, bchunk);
             if (it >= ntile) break;
-            const long long ci0 = clock64();
             int own[NN_STAGE];
 #pragma unroll
             for (int k = 0; k < NN_STAGE; ++k) {
@@ -1458,14 +1454,13 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             }
             hinted = false;
             __builtin_amdgcn_wave_barrier();
-            if (lane == 0) atomicAdd(&wcost[own[0]], (int)(clock64() - ci0));
         }
     }
     if constexpr (DBG) clkE = clock64();
     if constexpr (COOP) __syncthreads();
     if constexpr (DBG) clk3 = clock64();
     if (!has_tile) return;
-    if (lane == 0) cost[(size_t)b * tg.ntiles + t] = wcost[w];           // input of k_balance
+    if constexpr (!COOP) { if (lane == 0) cost[(size_t)b * tg.ntiles + t] = wcost[w]; }          // input of k_balance
     // ================= step 4: this wave's own tile: fused S4 accumulation =================
     if constexpr (COOP) bkey = qkey[w][lane];
     if (__ballot(own_valid) == 0ull) bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
@@ -1508,77 +1503,36 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     }
 }
 
-// Cost-balanced, XCD-local tile -> (block, wave) assignment for the following iterations.  grid (B), block 1024.
-// Workgroup c runs on XCD c % 8 (measured; the grid width G is a multiple of 8), and every XCD has its own L2: the
-// tiles are cut, in raster order, into eight bands of equal measured COST (cycles the previous launch spent on
-// them), band x goes to the blocks of XCD x, so an XCD touches one eighth of the target frame (+ halo) instead of
-// all of it.  Inside a band the tiles are ranked by cost (256 buckets, counting sort, heaviest first) and dealt
-// to the XCD's blocks in serpentine order, so every block receives one tile of each quartile and the block sums
-// even out.  G carries slack over ntiles / NN_WAVES because equal-cost bands differ in tile count.  With
-// banded == 0 (the throughput build: many pairs per launch) the whole frame is dealt over all blocks.  Any assignment gives
-// identical results (partials are order-free integer sums); this only shapes time and L2 traffic.
-__global__ __launch_bounds__(1024) void k_balance(const int *__restrict__ cost, int *__restrict__ perm, TileGrid tg, int G, int banded)
+// Cost-balanced tile -> (block, wave) assignment of the THROUGHPUT build for the following iterations.  grid (B), block
+// 1024.  The tiles are ranked by measured cost (cycles the previous launch spent on them; 256 buckets, counting sort,
+// heaviest first) and dealt to the blocks in serpentine order, so every block receives one tile of each cost quartile
+// and the block sums even out (+6 % at 64 pairs per launch).  Any assignment gives identical results (partials are
+// order-free integer sums); this only shapes time.  (Round 1 also cut the frame into eight equal-cost bands, one per XCD
+// and its L2, for launches of few pairs: -42 % fetch traffic on ONE pair repeated -- but on a stream of distinct pairs
+// the map is always the previous pair's, the deal bought nothing and its launch cost 12 us per run: the cooperative
+// build now keeps the interleaved default ownership, and the banded mode is gone.)
+__global__ __launch_bounds__(1024) void k_balance(const int *__restrict__ cost, int *__restrict__ perm, TileGrid tg, int G)
 {
-    __shared__ int hist[8][256], start[8][256], bstart[9], cmax;
-    __shared__ double wsum[16];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ int hist[256], start[256], cmax;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int *__restrict__ C = cost + (size_t)b * tg.ntiles;
     int *__restrict__ P = perm + (size_t)b * G * NN_WAVES;
-    for (int k = tid; k < 8 * 256; k += 1024) (&hist[0][0])[k] = 0;
+    if (tid < 256) hist[tid] = 0;
     if (tid == 0) cmax = 1;
-    if (tid < 9) bstart[tid] = tid == 0 ? 0 : tg.ntiles;
     __syncthreads();
-    // thread tid owns the raster segment [t0, t1): cost sum (exact in a double: < 2^53) and maximum
-    const int seg = (tg.ntiles + 1023) / 1024, t0 = min(tid * seg, tg.ntiles), t1 = min(t0 + seg, tg.ntiles);
     int m = 1;
-    double v = 0.0;
-    for (int t = t0; t < t1; ++t) { const int c = max(C[t], 0); m = max(m, c); v += (double)c; }
+    for (int t = tid; t < tg.ntiles; t += 1024) m = max(m, C[t]);
     atomicMax(&cmax, m);
     for (int s = tid; s < G * NN_WAVES; s += 1024) P[s] = -2;
-    double inc = v;                                                   // inclusive scan inside the wave
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += o;
-    }
-    if (lane == 63) wsum[wv] = inc;
     __syncthreads();
     const float bscale = 255.0f / (float)cmax;
     auto bucket_of = [&](int t) { return 255 - min(255, (int)((float)max(C[t], 0) * bscale)); };        // bucket 0 = heaviest
-    const int nbx = G >> 3, cap = nbx * NN_WAVES;
-    if (banded) {
-        // band boundaries: tile t is in band floor(8 * (cost before t) / total) -- any monotone map would do
-        double before = 0.0, total = 0.0;
-        for (int k = 0; k < 16; ++k) { if (k < wv) before += wsum[k]; total += wsum[k]; }
-        const double inv = 8.0 / (total > 0.0 ? total : 1.0);
-        double run = before + inc - v;
-        for (int t = t0; t < t1; ++t) {
-            const int lo = min(7, (int)(run * inv));
-            run += (double)max(C[t], 0);
-            const int hi = min(7, (int)(run * inv));
-            for (int x = lo + 1; x <= hi; ++x) bstart[x] = t + 1;
-        }
-        __syncthreads();
-        // a band that outgrows its XCD's slots spills into the next one (and the last bands must be able to hold
-        // what is left): as balanced as the slack allows, always a valid assignment since 8 * cap >= ntiles
-        if (tid == 0)
-            for (int x = 0; x < 7; ++x)
-                bstart[x + 1] = max(min(bstart[x + 1], bstart[x] + cap), tg.ntiles - (7 - x) * cap);
-        __syncthreads();
-    }
-    const bool bands = banded != 0;
-    auto band_of = [&](int t) {
-        int x = 0;
-#pragma unroll
-        for (int k = 1; k < 8; ++k) x += t >= bstart[k] ? 1 : 0;
-        return bands ? x : 0;
-    };
-    for (int t = tid; t < tg.ntiles; t += 1024) atomicAdd(&hist[band_of(t)][bucket_of(t)], 1);
+    for (int t = tid; t < tg.ntiles; t += 1024) atomicAdd(&hist[bucket_of(t)], 1);
     __syncthreads();
-    if (wv < 8) {      // exclusive scan of band wv's 256 buckets: four per lane
+    if (tid < 64) {      // exclusive scan of the 256 buckets: four per lane
         int h[4], a = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { h[k] = hist[wv][4 * lane + k]; a += h[k]; }
+        for (int k = 0; k < 4; ++k) { h[k] = hist[4 * lane + k]; a += h[k]; }
         int incl = a;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -1587,16 +1541,14 @@ __global__ __launch_bounds__(1024) void k_balance(const int *__restrict__ cost, 
         }
         int e = incl - a;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { start[wv][4 * lane + k] = e; e += h[k]; }
+        for (int k = 0; k < 4; ++k) { start[4 * lane + k] = e; e += h[k]; }
     }
     __syncthreads();
     for (int t = tid; t < tg.ntiles; t += 1024) {
-        const int x = band_of(t);
-        const int r = atomicAdd(&start[x][bucket_of(t)], 1);          // rank in the band, heaviest first
-        const int nb = bands ? nbx : G;
-        const int q = r / nb, i = r - q * nb;
-        const int k = (q & 1) ? nb - 1 - i : i;
-        P[(bands ? x + 8 * k : k) * NN_WAVES + q] = t;
+        const int r = atomicAdd(&start[bucket_of(t)], 1);             // rank, heaviest first
+        const int q = r / G, i = r - q * G;
+        const int k = (q & 1) ? G - 1 - i : i;
+        P[k * NN_WAVES + q] = t;
     }
 }
 
