@@ -91,7 +91,8 @@ def parse_args():
     ap.add_argument("--one-device", action="store_true")
     ap.add_argument("--force-collective", action="store_true", help="developer knob: run the RCCL exchanges even with one rank")
     ap.add_argument("--no-pipeline", action="store_true", help="one handle, every alignment fetched before the next is queued")
-    ap.add_argument("--in-flight", type=int, default=3, help="alignments in flight (handles taking turns, one HIP stream each)")
+    ap.add_argument("--in-flight", type=int, default=4, help="alignments in flight (handles taking turns, one HIP stream each; the runtime has "
+                    "four hardware queues by default: 4 -> 54 k, 3 -> 51 k, 5 -> 44 k, 6 -> 49 k it/s)")
     return ap.parse_args()
 
 
@@ -513,9 +514,18 @@ def dense_leg(args, torch, dist, capi, synth, world, rank, local_rank, comm, wid
     fence()
     elapsed = time.perf_counter() - t0
     out = dict(elapsed=elapsed, res=res, pool=pool, handle=h, last_j=(k[0] - 1) % len(pool))
+    # the roofline's launch time: the same loop again with per-launch HIP events (slam3d_icp_dense_run brackets every NN
+    # launch when profiling is on); algorithmic bytes of THIS rank's share (its source rows, the whole target)
+    h.set_profiling(True)
+    nn, alg, flops = [], [], []
+    for _ in range(min(6, max(2, steps))):
+        r = step()
+        nn.append(float(np.sum(h.get_iteration_timings())))
+        alg.append((12 + 4) * r["n_src"] + (12 + (12 if est == 0 else 0)) * r["n_tgt"])
+        flops.append(8.0 * r["n_src"] * r["n_tgt"])
+    h.set_profiling(False)
+    out["prof"] = dict(nn_ms=statistics.mean(nn), alg_bytes=statistics.mean(alg), flops=statistics.mean(flops))
     if world == 1:
-        # same kernels through the batch entry (rows = all rows) with per-launch events: the roofline's launch time
-        out["prof"] = profiled_pass(h, pool, 1, min(8, max(2, steps)), est)
         if want_cpu:
             j = out["last_j"]
             pr = pool.pairs[j]

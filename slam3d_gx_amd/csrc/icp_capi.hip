@@ -1218,7 +1218,9 @@ extern "C" int slam3d_icp_dense_begin(slam3d_icp_handle *h, const double *T_init
     const int rc = enqueue_preprocess(h, 1, T_init, s);
     if (rc) return rc;
     h->dense_it = 0;
-    h->run_stream = s; h->ran = true; h->last_B = 1; h->res_mapped = false; h->ran_profiled = false;
+    HIPCHK(h, hipEventRecord(h->ev[0], s));
+    if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[1], s));
+    h->run_stream = s; h->ran = true; h->last_B = 1; h->res_mapped = false; h->ran_profiled = h->profiling;
     return SLAM3D_OK;
 }
 
@@ -1261,7 +1263,11 @@ extern "C" int slam3d_icp_dense_partial_device(slam3d_icp_handle *h, int64_t *d_
     if (!h->ran) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
-    return enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0, reinterpret_cast<long long *>(d_sums), 0, h->dense_it == 0);
+    // with profiling on, the NN launch of iteration dense_it is bracketed by HIP events like in slam3d_icp_run
+    const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
+    const bool ev = h->ran_profiled && h->dense_it < iters;
+    return enqueue_iteration(h, 1, s, ev ? h->ev[3 + 2 * h->dense_it] : nullptr, ev ? h->ev[4 + 2 * h->dense_it] : nullptr, 0, 0,
+                             reinterpret_cast<long long *>(d_sums), 0, h->dense_it == 0);
 }
 
 extern "C" int slam3d_icp_dense_update_device(slam3d_icp_handle *h, const int64_t *d_sums, void *stream)
@@ -1288,6 +1294,7 @@ extern "C" int slam3d_icp_dense_finish_device(slam3d_icp_handle *h, const int64_
     double *ps = h->pin_out + 16;
     HIPCHK(h, hipMemcpyAsync(h->pin_out, h->Tcur, sizeof(double) * 16, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(ps, d_last_sums, sizeof(int64_t) * NSUMS, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipEventRecord(h->ev[2], s));
     HIPCHK(h, hipMemcpyAsync(h->pin_int, h->f_counts + (size_t)h->pair_src[0] * 4, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(h->pin_int + 1, h->f_counts + (size_t)h->pair_tgt[0] * 4 + 1, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(h->pin_int + 4, h->flags, sizeof(int), hipMemcpyDeviceToHost, s));
