@@ -4,7 +4,7 @@
 What is timed ("wall = first H2D enqueue -> last pose on host"):
 
   A *step* is one pass of the hot path over one batch of synthetic input: `--pairs-per-step` S frame pairs (default
-  256), processed as S / P consecutive alignments of P pairs each (P = `--pairs`, default 1 = BASELINE config 2:
+  320: the driver's 20 steps then time 6,400 alignments, > 2 s), processed as S / P consecutive alignments of P pairs each (P = `--pairs`, default 1 = BASELINE config 2:
   a single 640x480 pair, 20 iterations, point-to-plane).  EVERY alignment inside the timed region consists of
       H2D of BOTH u16 depth images of the pair from pinned host memory (2 x 614 KB)
       -> back-projection -> target normals -> tile records of both frames -> 20 ICP iterations -> pose record on the host.
@@ -69,7 +69,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=1, help="frame pairs per launch sequence and GPU (config 3: 64)")
-    ap.add_argument("--pairs-per-step", type=int, default=256, help="frame pairs one step processes per GPU (S / --pairs alignments)")
+    ap.add_argument("--pairs-per-step", type=int, default=320, help="frame pairs one step processes per GPU (S / --pairs alignments)")
     ap.add_argument("--pool", type=int, default=16, help="distinct seeded pairs per in-flight handle that the stream cycles through")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
@@ -847,18 +847,18 @@ def extra_legs(args, torch, dist, capi, synth, local_rank, est, handles, pools, 
     P3 = 64
     pool3 = Pool(torch, synth, [args.seed0 + k for k in range(P3)], args.width, args.height, args.noise_sigma)
     p3 = capi.default_params(intr, estimator=est, iterations=args.iterations, max_batch=P3, device=local_rank)
-    h3 = [capi.IcpHandle(p3) for _ in range(2)]
-    st3 = Streamer(h3, [pool3, pool3], P3)
-    st3.run(2)
+    h3 = [capi.IcpHandle(p3) for _ in range(3)]
+    st3 = Streamer(h3, [pool3, pool3, pool3], P3)
+    st3.run(3)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    k3 = 24
+    k3 = 36
     res3 = st3.run(k3)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof3 = profiled_pass(h3[0], pool3, P3, 3, est)
     c3 = {"workload": f"BASELINE config 3: {P3} pairs (seeds {args.seed0}..{args.seed0 + P3 - 1}) per launch sequence, {k3} alignments timed, "
-                      "2 in flight, H2D of all 128 depth images inside every alignment",
+                      "3 in flight, H2D of all 128 depth images inside every alignment",
           "value": k3 * P3 * args.iterations / dt, "unit": "ICP iterations/s", "ms_per_alignment": 1e3 * dt / k3,
           "kernel_only_value": P3 * args.iterations / (prof3["total_ms"] * 1e-3),
           "roofline": tiles_roofline(prof3, args.iterations, "k_nn_tiles_acc_640x480_P64",

@@ -259,6 +259,11 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
             const int gx = atoi(getenv("SLAM3D_NN_GX")) / 8 * 8;
             if ((long long)gx * NN_WAVES >= tg.ntiles) h->nn_gx = gx;
         }
+        {   // row-interleaved XCD ownership: every XCD needs a slot for each tile of its rows
+            const int per_xcd = ((tg.nty + 7) / 8) * tg.ntx;
+            const int min_gx = 8 * ((per_xcd + NN_WAVES - 1) / NN_WAVES);
+            if (h->nn_gx < min_gx) h->nn_gx = min_gx;
+        }
         h->nn_gx_d = ((tg.ntiles + NN_WAVES - 1) / NN_WAVES + 7) / 8 * 8;
     }
     A(dalloc(h->perm_d, (size_t)h->maxB * h->nn_gx_d * NN_WAVES));

@@ -973,6 +973,9 @@ __device__ __forceinline__ int lds_fetch_add_uniform(int *p, int v)
 // pairs (latency bound: the slowest block ends the launch).  <3, 8, not cooperative>: every wave sweeps its own cells
 // -- no shared lists, no block barriers, 14 KB of LDS, 55 VGPRs -- at the full 8 waves per SIMD; it wins when many
 // pairs fill the chip (throughput bound: 64 pairs 44 k -> 55 k it/s).
+#ifndef S3D_OWNERSHIP_ROWS
+#define S3D_OWNERSHIP_ROWS 1         // cooperative build: XCD x owns the tile rows r = x (mod 8) (0: tile c + w * G, no locality)
+#endif
 #ifndef S3D_OWN_HOME_CELL
 #define S3D_OWN_HOME_CELL 0          // the owner refines its (prefetched) home cell itself instead of listing it
 #endif
@@ -1028,7 +1031,18 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     const int pt = COOP ? -1 : __builtin_amdgcn_readfirstlane(perm[((size_t)b * gridDim.x + c) * NN_WAVES + w]);
     // default (-1, a handle's first two iterations): interleaved, tile c + w * G -- no locality, but even over the XCDs
     // whatever part of the frame holds the work (row shards of the dense mode)
-    const int t = pt == -1 ? c + w * (int)gridDim.x : (pt < 0 ? tg.ntiles : pt);
+    int t = pt == -1 ? c + w * (int)gridDim.x : (pt < 0 ? tg.ntiles : pt);
+#if S3D_OWNERSHIP_ROWS
+    if constexpr (COOP) {
+        // XCD-local AND balanced without a map: workgroup c runs on XCD c % 8 (observed; only speed depends on it), and XCD x
+        // owns the tile ROWS r = x (mod 8) -- a uniform sample of the whole frame (depth edges, the row shard of the dense
+        // mode), while its L2 sees 3/8 of the target frame (rows r-1 .. r+1) instead of all of it.  Inside the XCD's row list
+        // (raster order) wave w of the XCD's i-th block takes entry i + w * G/8.
+        const int x = c & 7, k = (c >> 3) + w * ((int)gridDim.x >> 3);
+        const int rl = k / tg.ntx, col = k - rl * tg.ntx, row = x + 8 * rl;
+        t = row < tg.nty ? row * tg.ntx + col : tg.ntiles;
+    }
+#endif
     const bool has_tile = t < tg.ntiles;
     const long long cw0 = COOP ? 0 : clock64();         // per-tile cost: input of k_balance (throughput build only)
     float4 *__restrict__ st = stage_all[w];
