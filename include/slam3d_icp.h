@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SLAM3D_ICP_ABI_VERSION 3
+#define SLAM3D_ICP_ABI_VERSION 4
 #define SLAM3D_ICP_NSUMS 29   /* 21 upper-tri AtA + 6 Atb + count + sum r^2 */
 
 /* return codes: 0 ok; >0 algorithmic (result.T == Identity); <0 usage / runtime errors */
@@ -70,6 +70,13 @@ typedef struct slam3d_icp_params {
     int32_t device;                 /* HIP device ordinal                                            */
     int32_t nn_mode;                /* SLAM3D_NN_*                                                   */
     int32_t extra_frames;           /* resident frames beyond the 2*max_batch implicit ones (keyframes) */
+    /* optional correspondence gates of the point-to-plane estimator, 0 = off:
+     *   max_plane_residual2  drop a correspondence whose squared point-to-plane residual e*e exceeds it -- the
+     *                        per-pixel test of src/GraphicEnd.cpp~:484-489 with parameters.yaml:45 min_error_plane (0.02);
+     *   min_normal_cos       drop it when the source pixel has no normal or (R n_src).n_tgt is below it -- the
+     *                        outlier-rejection role of solvePnPRansac's inlier subset, src/GraphicEnd.cpp:522-554.    */
+    float   max_plane_residual2;
+    float   min_normal_cos;
 } slam3d_icp_params;
 
 /* a borrowed view of an organized cloud: `data` points at width*height records of

@@ -28,6 +28,8 @@ void orc_default_params(orc_params *p)
     p->z_filter = 7.0;                 /* parameters.yaml:65 */
     p->iterations = 20;
     p->max_corr_dist = 0.10;
+    p->max_plane_residual2 = 0.0;
+    p->min_normal_cos = 0.0;
     p->estimator = ORC_EST_POINT2PLANE;
     p->normal_window = 7;              /* src/planarFeatures.cpp:92 */
     p->normal_min_inliers = 41;        /* src/planarFeatures.cpp:128  (> 40) */
@@ -484,6 +486,46 @@ static void nn_pass(const clist *src, const clist *tgt, const kdtree *kd, const 
     }
 }
 
+/* ------------------------------------------------ S4g optional gates (point-to-plane only)
+ * Applied to the correspondences the distance gate kept; a rejected source gets no correspondence (no second-nearest
+ * fallback).  Residual: e = (nx*dx + ny*dy) + nz*dz in double -- the b of row_sums --, kept iff e*e <= (double)(float)r2
+ * (src/GraphicEnd.cpp~:484-489).  Normal angle: the source pixel's own normal (S2 on the source frame) rotated by the
+ * float rotation of xform_pt with the same fma chain, c = fma(rz,tz, fma(ry,ty, rx*tx)) in float, kept iff the source
+ * normal is valid and c >= (float)min_normal_cos (stands in for src/GraphicEnd.cpp:542's RANSAC inlier subset). */
+static void apply_gates(const clist *src, const clist *tgt, const double *T, const orc_params *p,
+                        const float *snrm4, int nt, int *corr, float *d2c)
+{
+    const float r2f = (float)p->max_plane_residual2, cminf = (float)p->min_normal_cos;
+    if (p->estimator != ORC_EST_POINT2PLANE || (!(r2f > 0.0f) && !(cminf > 0.0f))) return;
+    float Rf[9], tf[3];
+    transform_f(T, Rf, tf);
+    (void)nt;
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (int i = 0; i < src->n; ++i) {
+        const int j = corr[i];
+        if (j < 0) continue;
+        int keep = 1;
+        if (r2f > 0.0f) {
+            float pf[3];
+            xform_pt(Rf, tf, src->x[i], src->y[i], src->z[i], pf);
+            const double dx = (double)tgt->x[j] - (double)pf[0], dy = (double)tgt->y[j] - (double)pf[1],
+                         dz = (double)tgt->z[j] - (double)pf[2];
+            const double nx = tgt->nx[j], ny = tgt->ny[j], nz = tgt->nz[j];
+            const double e = (nx * dx + ny * dy) + nz * dz;
+            keep = e * e <= (double)r2f;
+        }
+        if (keep && cminf > 0.0f) {
+            const float *ns = snrm4 + 4 * (size_t)src->orig[i];
+            const float rx = fmaf(Rf[2], ns[2], fmaf(Rf[1], ns[1], Rf[0] * ns[0]));
+            const float ry = fmaf(Rf[5], ns[2], fmaf(Rf[4], ns[1], Rf[3] * ns[0]));
+            const float rz = fmaf(Rf[8], ns[2], fmaf(Rf[7], ns[1], Rf[6] * ns[0]));
+            const float c = fmaf(rz, tgt->nz[j], fmaf(ry, tgt->ny[j], rx * tgt->nx[j]));
+            keep = ns[3] > 0.5f && c >= cminf;
+        }
+        if (!keep) { corr[i] = -1; d2c[i] = INFINITY; }
+    }
+}
+
 /* ------------------------------------------------ S4 rows + tree reduction */
 static void row_sums(const clist *src, const clist *tgt, const float Rf[9], const float tf[3],
                      int estimator, int i, int j, double *s /*29*/)
@@ -626,10 +668,14 @@ int orc_icp(const float *src4, const float *tgt4, const orc_params *p, const dou
     const int N = p->width * p->height;
     const float zmax = (float)p->z_filter;
     const int nt = n_threads(p);
-    float *nrm4 = NULL;
+    float *nrm4 = NULL, *snrm4 = NULL;
     if (p->estimator == ORC_EST_POINT2PLANE) {
         nrm4 = malloc(sizeof(float) * 4 * (size_t)N);
         orc_normals(tgt4, p, nrm4);
+        if ((float)p->min_normal_cos > 0.0f) {          /* the normal-angle gate needs the source frame's normals too */
+            snrm4 = malloc(sizeof(float) * 4 * (size_t)N);
+            orc_normals(src4, p, snrm4);
+        }
     }
     clist src, tgt;
     clist_build(&src, src4, NULL, N, zmax);
@@ -648,6 +694,7 @@ int orc_icp(const float *src4, const float *tgt4, const orc_params *p, const dou
     if (T_trace) memcpy(T_trace, T, sizeof(T));
     for (int it = 0; it < p->iterations; ++it) {
         nn_pass(&src, &tgt, &kd, T, g2, p->nn_method, nt, corr, d2c);
+        apply_gates(&src, &tgt, T, p, snrm4, nt, corr, d2c);
         accumulate(&src, &tgt, T, p->estimator, corr, p->width, p->height, nt, sums);
         have_sums = 1;
         if (sums_trace) memcpy(sums_trace + (size_t)it * ORC_NSUMS, sums, sizeof(sums));
@@ -669,7 +716,7 @@ int orc_icp(const float *src4, const float *tgt4, const orc_params *p, const dou
     res->iterations = p->iterations;
     res->n_src = src.n; res->n_tgt = tgt.n;
     if (p->nn_method == ORC_NN_KDTREE) kd_free(&kd);
-    free(corr); free(d2c); free(nrm4);
+    free(corr); free(d2c); free(nrm4); free(snrm4);
     clist_free(&src); clist_free(&tgt);
     return res->status;
 }

@@ -58,6 +58,14 @@ typedef struct orc_params {
     double error_threshold;               /* 1.0, parameters.yaml:39               */
     int    nn_method;                     /* ORC_NN_*  (identical results)         */
     int    threads;                       /* OpenMP threads, <=0 -> all            */
+    /* optional correspondence gates of the point-to-plane estimator (0 = off; spec S4g).  A correspondence that
+     * passed the distance gate is dropped when
+     *   max_plane_residual2 > 0 and e*e > max_plane_residual2, e = n.(q - p') the signed point-to-plane residual
+     *     (the per-pixel test of src/GraphicEnd.cpp~:448-502, `e*=e; if (e > _min_error_plane)`, parameters.yaml:45);
+     *   min_normal_cos > 0 and (R n_src).n_tgt < min_normal_cos, or the source pixel has no valid normal
+     *     (the outlier-rejection role of solvePnPRansac's inlier subset, src/GraphicEnd.cpp:522-554).           */
+    double max_plane_residual2;
+    double min_normal_cos;
 } orc_params;
 
 typedef struct orc_result {

@@ -48,6 +48,7 @@ class Params(C.Structure):
         ("normal_window", C.c_int32), ("normal_min_inliers", C.c_int32), ("normal_inlier_dist", C.c_double),
         ("min_inliers", C.c_int32), ("error_threshold", C.c_double),
         ("max_batch", C.c_int32), ("device", C.c_int32), ("nn_mode", C.c_int32), ("extra_frames", C.c_int32),
+        ("max_plane_residual2", C.c_float), ("min_normal_cos", C.c_float),
     ]
 
 

@@ -26,6 +26,7 @@ struct FrameHost {
     uint64_t epoch = 0;                // bumped by every set_*; 0 = never set
     uint64_t src_epoch = 0; int src_row0 = -1, src_row1 = -1;    // source role: built for this epoch and row shard
     uint64_t tgt_epoch = 0; int tgt_normals = -1;                // target role: built for this epoch with/without normals
+    uint64_t nrm_epoch = 0;                                      // the frame's normals were computed for this epoch
 };
 
 struct slam3d_icp_handle {
@@ -129,6 +130,7 @@ extern "C" void slam3d_icp_default_params(slam3d_icp_params *p)
     p->min_inliers = 12; p->error_threshold = 1.0;
     p->max_batch = 1; p->device = 0; p->nn_mode = SLAM3D_NN_AUTO;
     p->extra_frames = 0;
+    p->max_plane_residual2 = 0.0f; p->min_normal_cos = 0.0f;      // optional gates off
 }
 
 extern "C" const char *slam3d_strerror(int code)
@@ -214,6 +216,8 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     g.zmax = (float)p->z_filter;
     g.win_r = p->normal_window / 2; g.min_in = p->normal_min_inliers; g.in_dist = p->normal_inlier_dist;
     g.gate2 = (float)(p->max_corr_dist * p->max_corr_dist);
+    g.resid2 = p->max_plane_residual2 > 0.0f ? p->max_plane_residual2 : 0.0f;
+    g.min_ncos = p->min_normal_cos > 0.0f ? p->min_normal_cos : 0.0f;
     g.estimator = p->estimator;
     g.fx = p->fx; g.fy = p->fy; g.cx = p->cx; g.cy = p->cy; g.factor = p->depth_factor; g.zf = p->z_filter;
     h->row0 = 0; h->row1 = p->height;
@@ -461,6 +465,7 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
     const Geometry &g = h->g;
     const TileGrid &tg = h->tg;
     const int use_normals = h->p.estimator == SLAM3D_EST_POINT2PLANE ? 1 : 0;
+    const bool src_normals = use_normals && g.min_ncos > 0.0f;       // the normal-angle gate reads the source frame's normals
     std::vector<FrameTask> tasks, ntasks;
     auto task_of = [&](int f, int role) {
         FrameTask t;
@@ -482,14 +487,16 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
             tasks.push_back(task_of(fs, 0));
             S.src_epoch = S.epoch; S.src_row0 = h->row0; S.src_row1 = h->row1;
         }
+        if (src_normals && S.nrm_epoch != S.epoch) { ntasks.push_back(task_of(fs, 1)); S.nrm_epoch = S.epoch; }
         if (T.tgt_epoch != T.epoch || T.tgt_normals != use_normals) {
-            if (use_normals) ntasks.push_back(task_of(ft, 1));
+            if (use_normals && T.nrm_epoch != T.epoch) { ntasks.push_back(task_of(ft, 1)); T.nrm_epoch = T.epoch; }
             tasks.push_back(task_of(ft, 1));
             T.tgt_epoch = T.epoch; T.tgt_normals = use_normals;
         }
         PairPtrs &pp = h->h_pairs[b];
         pp.src = S.cloud; pp.tgt = T.cloud;
         pp.nrm = h->f_nrm + (size_t)ft * h->N;
+        pp.snrm = h->f_nrm + (size_t)fs * h->N;
         pp.srcT = h->f_srcT + (size_t)fs * tg.ntiles * TILE_SLOTS;
         pp.tgtT = h->f_tgtT + (size_t)ft * tg.ntiles * TILE_REC;
         pp.tbox = h->f_tbox + (size_t)ft * tg.ntiles * 2;
@@ -573,7 +580,10 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
             hipLaunchKernelGGL(kern, dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_pairs, h->Tcur, h->corr, h->cd2, h->prevq, h->hint,
                                perm, h->cost, h->acc, h->g, tg, h->dbg, write_out, first);
         };
-        if (dense) { if (h->dbg) launch(k_nn_tiles_acc<3, 8, false, true>); else launch(k_nn_tiles_acc<3, 8, false, false>); }
+        // (+ two with the optional S4g gates compiled in: the production instances carry none of that code)
+        const bool gated = h->p.estimator == SLAM3D_EST_POINT2PLANE && (h->g.resid2 > 0.0f || h->g.min_ncos > 0.0f);
+        if (gated) { if (dense) launch(k_nn_tiles_acc<3, 8, false, false, true>); else launch(k_nn_tiles_acc<3, S3D_COOP_WPE, true, false, true>); }
+        else if (dense) { if (h->dbg) launch(k_nn_tiles_acc<3, 8, false, true>); else launch(k_nn_tiles_acc<3, 8, false, false>); }
         else       { if (h->dbg) launch(k_nn_tiles_acc<3, S3D_COOP_WPE, true, true>);  else launch(k_nn_tiles_acc<3, S3D_COOP_WPE, true, false>); }
         // Throughput build: costs are stable from the second iteration on, balance the blocks once per run (+6 % at 64
         // pairs).  Cooperative build: never -- on a stream of DISTINCT pairs the interleaved default ownership is as good

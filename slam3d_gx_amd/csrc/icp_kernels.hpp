@@ -36,6 +36,7 @@ struct PairPtrs {                  // per frame-pair device pointers: the reside
     const float4 *src;             // organized source cloud (only the brute-force compaction reads it)
     const float4 *tgt;             // organized target cloud
     const float4 *nrm;             // target normals
+    const float4 *snrm;            // source frame's normals (only the optional normal-angle gate reads them)
     const float4 *srcT;            // source tile slots   [ntiles * 64]
     const float4 *tgtT;            // target tile records [ntiles * TILE_REC]
     const float4 *tbox;            // target tile boxes   [ntiles * 2]
@@ -71,6 +72,7 @@ struct Geometry {
     int win_r, min_in;
     double in_dist;
     float gate2;
+    float resid2, min_ncos;        // optional gates of the point-to-plane estimator (spec S4g), 0 = off
     int estimator;
     double fx, fy, cx, cy, factor, zf;
 };
@@ -860,21 +862,35 @@ __device__ __forceinline__ void tile_accumulate(int estimator, const RowBasis &B
     else tile_accumulate_est<1>(B, acc);
 }
 
-// decode a packed NN key, apply the gate, record the correspondence and form the row products
+// decode a packed NN key, apply the gate(s), record the correspondence and form the row products.
+// GATED instances also apply the optional gates of spec S4g (point-to-plane only): the squared point-to-plane residual
+// e^2 <= resid2 (src/GraphicEnd.cpp~:484-489) and the angle between the rotated source normal and the target normal
+// (R n_s).n_t >= min_ncos (role of the RANSAC inlier subset, src/GraphicEnd.cpp:542).  A rejected slot has no
+// correspondence, but its nearest neighbour still serves as the next iteration's upper bound (prevq).
+struct SlotGates {
+    float resid2, min_ncos;
+    const float4 *snrm;            // source normals, indexed by source pixel
+    int spix;                      // this slot's source pixel
+    float r[9];                    // the float rotation of the current pose (xform's)
+};
+template <bool GATED>
 __device__ __forceinline__ void finish_slot(bool valid, unsigned long long key, float px, float py, float pz,
                                             const float4 *__restrict__ tcloud, const float4 *__restrict__ tnrm,
                                             float gate2, int estimator, int *__restrict__ corr_out,
                                             float *__restrict__ cd2_out, float4 *__restrict__ prevq_out,
-                                            RowBasis &B, bool write_out = true, int jprev = -2 /* match the slot already holds (-2: unknown) */)
+                                            RowBasis &B, bool write_out, int jprev /* match the slot already holds (-2: unknown) */,
+                                            const SlotGates *sg = nullptr)
 {
 #pragma unroll
     for (int k = 0; k < 8; ++k) B.v[k] = 0.0;
     const int j = (int)(unsigned int)(key & 0xffffffffull);
     const float d2 = __int_as_float((int)(unsigned int)(key >> 32));
-    const bool ok = valid && (j >= 0) && (d2 <= gate2);
-    if (write_out) {        // the caller-visible correspondence arrays: only the last iteration's are ever read
-        *corr_out = ok ? j : -1;
-        *cd2_out = ok ? d2 : __int_as_float(0x7f800000);
+    bool ok = valid && (j >= 0) && (d2 <= gate2);
+    if constexpr (!GATED) {
+        if (write_out) {    // the caller-visible correspondence arrays: only the last iteration's are ever read
+            *corr_out = ok ? j : -1;
+            *cd2_out = ok ? d2 : __int_as_float(0x7f800000);
+        }
     }
     float4 pq = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
     if (ok) {
@@ -883,6 +899,34 @@ __device__ __forceinline__ void finish_slot(bool valid, unsigned long long key, 
         if (estimator == 0) n4 = tnrm[j];
         row_basis(estimator, px, py, pz, q4, n4, B);
         pq = make_float4(q4.x, q4.y, q4.z, __int_as_float(j));
+        if constexpr (GATED) {
+            if (estimator == 0) {
+                bool keep = true;
+                if (sg->resid2 > 0.0f) {
+                    const double e = B.v[6] * (1.0 / 65536.0);          // exact: b of the row (a power-of-two scale)
+                    keep = e * e <= (double)sg->resid2;
+                }
+                if (keep && sg->min_ncos > 0.0f) {
+                    const float4 ns = sg->snrm[sg->spix];
+                    const float rx = __fmaf_rn(sg->r[2], ns.z, __fmaf_rn(sg->r[1], ns.y, sg->r[0] * ns.x));
+                    const float ry = __fmaf_rn(sg->r[5], ns.z, __fmaf_rn(sg->r[4], ns.y, sg->r[3] * ns.x));
+                    const float rz = __fmaf_rn(sg->r[8], ns.z, __fmaf_rn(sg->r[7], ns.y, sg->r[6] * ns.x));
+                    const float c = __fmaf_rn(rz, n4.z, __fmaf_rn(ry, n4.y, rx * n4.x));
+                    keep = ns.w > 0.5f && c >= sg->min_ncos;
+                }
+                if (!keep) {
+                    ok = false;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) B.v[k] = 0.0;
+                }
+            }
+        }
+    }
+    if constexpr (GATED) {
+        if (write_out) {
+            *corr_out = ok ? j : -1;
+            *cd2_out = ok ? d2 : __int_as_float(0x7f800000);
+        }
     }
     // next iteration's upper bound comes from this point (no dependent gather).  Once the pose has settled most matches
     // repeat: a slot that already holds this very match is not written again (same bits, 16 B of traffic less)
@@ -910,8 +954,12 @@ __global__ __launch_bounds__(CHUNK) void k_accumulate(const PairPtrs *__restrict
     const unsigned long long key = best[gs];
     best[gs] = ~0ull;
     RowBasis rb;
-    finish_slot(valid, key, px, py, pz, pairs[b].tgt, pairs[b].nrm, g.gate2, g.estimator, corr + gs, cd2 + gs,
-                prevq + gs, rb);
+    SlotGates sg;
+    sg.resid2 = g.resid2; sg.min_ncos = g.min_ncos; sg.snrm = pairs[b].snrm; sg.spix = max(__float_as_int(sp.w), 0);
+    sg.r[0] = m.r00; sg.r[1] = m.r01; sg.r[2] = m.r02; sg.r[3] = m.r10; sg.r[4] = m.r11; sg.r[5] = m.r12;
+    sg.r[6] = m.r20; sg.r[7] = m.r21; sg.r[8] = m.r22;
+    finish_slot<true>(valid, key, px, py, pz, pairs[b].tgt, pairs[b].nrm, g.gate2, g.estimator, corr + gs, cd2 + gs,
+                      prevq + gs, rb, true, -2, &sg);
     tile_accumulate(g.estimator, rb, acc + ((size_t)b * ACC_R + (c % ACC_R)) * ACC_STRIDE);
 }
 
@@ -994,7 +1042,7 @@ constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (
 //      quadrants), merged into the owner's keys with ds_min_u64;                             -- barrier --
 //   4. every wave finishes its own tile: gate, row products, level-1 reduction, hint for the next iteration.
 // The result is independent of which wave processes which item (keys are merged by an exact minimum).
-template <int NN_STAGE, int WPE, bool COOP, bool DBG>
+template <int NN_STAGE, int WPE, bool COOP, bool DBG, bool GATED = false>
 __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_nn_tiles_acc(const PairPtrs *__restrict__ pairs,
                                                         const double *__restrict__ Tcur,
                                                         int *__restrict__ corr, float *__restrict__ cd2,
@@ -1479,7 +1527,17 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     if constexpr (COOP) bkey = qkey[w][lane];
     if (__ballot(own_valid) == 0ull) bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
     RowBasis rb;
-    finish_slot(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, prevq + gs, rb, write_out != 0, own_jprev);
+    if constexpr (GATED) {             // the optional S4g gates: their own instances, the production ones carry none of this
+        SlotGates sg;
+        const Rt m = load_rt(Tcur + b * 16);
+        sg.resid2 = g.resid2; sg.min_ncos = g.min_ncos; sg.snrm = pp.snrm; sg.spix = max(pix, 0);
+        sg.r[0] = m.r00; sg.r[1] = m.r01; sg.r[2] = m.r02; sg.r[3] = m.r10; sg.r[4] = m.r11; sg.r[5] = m.r12;
+        sg.r[6] = m.r20; sg.r[7] = m.r21; sg.r[8] = m.r22;
+        finish_slot<true>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, prevq + gs, rb,
+                          write_out != 0, own_jprev, &sg);
+    } else
+        finish_slot<false>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, prevq + gs, rb,
+                           write_out != 0, own_jprev);
     tile_accumulate(g.estimator, rb, acc + ((size_t)b * ACC_R + (c % ACC_R)) * ACC_STRIDE);
     {   // hint for the next iteration: the tile holding the match of a lane near the tile centre
         const bool ok = rb.v[7] != 0.0;

@@ -104,6 +104,16 @@ void GraphicEndICP::init(const string &param_file)
     _params.estimator = (_reader->Has("icp_estimator") && _reader->GetPara("icp_estimator") == "svd") ? SLAM3D_EST_SVD
                                                                                                        : SLAM3D_EST_POINT2PLANE;
     _params.normal_window = _reader->GetInt("icp_normal_window", 7);
+    // optional correspondence gates, off unless asked for:
+    //   icp_plane_residual_gate: yes -> e^2 <= min_error_plane, the reference's own key and test (src/GraphicEnd.cpp~:484-489,
+    //                            parameters.yaml:45; src/GraphicEnd.cpp:91 reads it and never uses it)
+    //   icp_normal_angle_deg: d  -> angle(R n_src, n_tgt) <= d degrees (role of the RANSAC inlier subset, src/GraphicEnd.cpp:542)
+    if (_reader->Has("icp_plane_residual_gate") && _reader->GetPara("icp_plane_residual_gate") == "yes")
+        _params.max_plane_residual2 = (float)_reader->GetDouble("min_error_plane", 0.02);
+    {
+        const double deg = _reader->GetDouble("icp_normal_angle_deg", 0.0);
+        if (deg > 0.0 && deg < 90.0) _params.min_normal_cos = (float)cos(deg * M_PI / 180.0);
+    }
     _params.min_inliers = _reader->GetInt("icp_min_inliers", 12);
     _params.error_threshold = _error_threshold;
     _max_batch = _loopclosure_frames + 2;              // random candidates + the two adjacent keyframes, one launch

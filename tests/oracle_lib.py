@@ -24,6 +24,7 @@ class OrcParams(C.Structure):
         ("normal_window", C.c_int), ("normal_min_inliers", C.c_int), ("normal_inlier_dist", C.c_double),
         ("min_inliers", C.c_int), ("error_threshold", C.c_double),
         ("nn_method", C.c_int), ("threads", C.c_int),
+        ("max_plane_residual2", C.c_double), ("min_normal_cos", C.c_double),
     ]
 
 

@@ -1,0 +1,167 @@
+"""Optional correspondence gates of the point-to-plane estimator (spec S4g).
+
+a8: `min_error_plane` -- the reference's per-pixel signed point-to-plane residual test `e*=e; if (e > _min_error_plane)`
+    (src/GraphicEnd.cpp~:484-489, parameters.yaml:45) as a gate on e = n.(q - p').
+a11: the outlier-rejection role of solvePnPRansac's inlier subset (src/GraphicEnd.cpp:522-554) as a gate on the angle
+    between the rotated source normal and the target normal.
+
+CPU part: the oracle's gates against a numpy restatement of their definition.  GPU part: HIP == oracle, bit for bit, in every
+search mode and both kernel builds.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from slam3d_gx_amd import synth
+
+R2 = 9e-6          # (3 mm)^2: bites on the synthetic sensor noise
+CMIN = 0.94        # ~20 degrees
+
+
+def _pair(seed, w, h, **kw):
+    pr = synth.make_pair(seed, w, h, **kw)
+    return pr, synth.backproject_numpy(pr.depth_src, pr.intr), synth.backproject_numpy(pr.depth_tgt, pr.intr)
+
+
+def _xform32(T, xyz):
+    """p' of spec S3 up to the last float32 rounding: float32 operands, float64 arithmetic (products exact)"""
+    R = T[:3, :3].astype(np.float32).astype(np.float64)
+    t = T[:3, 3].astype(np.float32).astype(np.float64)
+    return (xyz.astype(np.float64) @ R.T + t).astype(np.float32)
+
+
+@pytest.mark.parametrize("r2,cmin", [(R2, 0.0), (0.0, CMIN), (R2, CMIN)])
+def test_oracle_gates_follow_their_definition(r2, cmin):
+    pr, s4, t4 = _pair(2100, 160, 120)
+    iters = 3
+    p0 = O.params(pr.intr, estimator=0, iterations=iters, nn_method=0)
+    pg = O.params(pr.intr, estimator=0, iterations=iters, nn_method=0, max_plane_residual2=r2, min_normal_cos=cmin)
+    r0, rg = O.icp(s4, t4, p0), O.icp(s4, t4, pg)
+    assert rg["inliers"] < r0["inliers"], "the gate must bite on this scene"
+    assert rg["inliers"] == int(rg["sums_trace"][-1][27])
+    # the last iteration's search ran at T_trace[iters - 1]: ungated NN at that pose, then the definition in numpy
+    T = rg["T_trace"][iters - 1]
+    idx_nn, _, _ = O.nn_once(s4, t4, p0, T=T, use_normals=True)
+    tn = O.normals(t4, p0).reshape(-1, 4)
+    sn = O.normals(s4, p0).reshape(-1, 4)
+    S, Q = s4.reshape(-1, 4)[:, :3], t4.reshape(-1, 4)[:, :3]
+    have = idx_nn >= 0
+    i = np.nonzero(have)[0]
+    j = idx_nn[i]
+    pp = _xform32(T, S[i]).astype(np.float64)
+    n = tn[j, :3].astype(np.float64)
+    e = np.einsum("ij,ij->i", n, Q[j].astype(np.float64) - pp)
+    keep = np.ones(len(i), bool)
+    border = np.zeros(len(i), bool)
+    if r2 > 0:
+        r2f = float(np.float32(r2))
+        keep &= e * e <= r2f
+        border |= np.abs(e * e - r2f) < 1e-4 * r2f
+    if cmin > 0:
+        Rf = T[:3, :3].astype(np.float32).astype(np.float64)
+        c = np.einsum("ij,ij->i", sn[i, :3].astype(np.float64) @ Rf.T, n)
+        keep &= (sn[i, 3] > 0.5) & (c >= float(np.float32(cmin)))
+        border |= np.abs(c - cmin) < 1e-5
+    got = rg["idx"][i]
+    assert np.all((got == j) | (got == -1))
+    bad = ((got == j) != keep) & ~border
+    assert not bad.any(), f"{bad.sum()} of {len(i)} correspondences gated differently from the definition"
+    assert np.all(rg["idx"][~have] == -1)
+    assert (got == j).sum() > 500 and (got == -1).sum() > 100
+
+
+def test_oracle_gates_off_and_svd_ignore_them():
+    pr, s4, t4 = _pair(2101, 104, 72)
+    a = O.icp(s4, t4, O.params(pr.intr, estimator=0, iterations=2, nn_method=0))
+    b = O.icp(s4, t4, O.params(pr.intr, estimator=0, iterations=2, nn_method=0, max_plane_residual2=0.0, min_normal_cos=0.0))
+    assert np.array_equal(a["idx"], b["idx"]) and np.array_equal(a["T_trace"], b["T_trace"])
+    c = O.icp(s4, t4, O.params(pr.intr, estimator=1, iterations=2, nn_method=0))
+    d = O.icp(s4, t4, O.params(pr.intr, estimator=1, iterations=2, nn_method=0, max_plane_residual2=R2, min_normal_cos=CMIN))
+    assert np.array_equal(c["idx"], d["idx"]) and np.array_equal(c["T_trace"], d["T_trace"])   # gates are point-to-plane only
+
+
+# ------------------------------------------------------------------------------------------------ GPU parity
+def _hip_vs_oracle(capi, pr, s4, t4, iters, r2, cmin, nn_mode=None, T_init=None):
+    kw = dict(estimator=0, iterations=iters, max_plane_residual2=r2, min_normal_cos=cmin)
+    ro = O.icp(s4, t4, O.params(pr.intr, nn_method=0, **kw), T_init=T_init)
+    extra = {} if nn_mode is None else dict(nn_mode=nn_mode)
+    with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1, **kw, **extra)) as h:
+        rg = h.align(s4, t4, T_init)
+        idx, d2 = h.get_correspondences(0)
+        Tt, St = h.get_trace(0)
+    assert np.array_equal(idx, ro["idx"]), f"{(idx != ro['idx']).sum()} index mismatches"
+    assert np.array_equal(d2.view(np.uint32), ro["d2"].view(np.uint32))
+    assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:iters], ro["sums_trace"])
+    assert rg["inliers"] == ro["inliers"] and rg["status"] == ro["status"]
+    return ro, rg
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("r2,cmin", [(R2, 0.0), (0.0, CMIN), (R2, CMIN), (0.02, 0.0)])
+@pytest.mark.parametrize("build", ["cooperative", "throughput"])
+def test_gated_tiles_search_is_bit_identical(gpu_lib, r2, cmin, build, monkeypatch):
+    from slam3d_gx_amd import capi
+    if build == "throughput":
+        monkeypatch.setenv("SLAM3D_DENSE_BATCH", "1")
+    pr, s4, t4 = _pair(2102, 320, 240)
+    ro, _ = _hip_vs_oracle(capi, pr, s4, t4, 5, r2, cmin)
+    r0 = O.icp(s4, t4, O.params(pr.intr, estimator=0, iterations=5, nn_method=0))
+    if r2 == 0.02:      # the reference's own value: e^2 <= 0.02 always holds inside the 0.10 m distance gate
+        assert ro["inliers"] == r0["inliers"]
+    else:
+        assert ro["inliers"] < r0["inliers"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["valu", "mfma"])
+def test_gated_brute_force_modes_are_bit_identical(gpu_lib, mode):
+    from slam3d_gx_amd import capi
+    pr, s4, t4 = _pair(2103, 160, 120)
+    _hip_vs_oracle(capi, pr, s4, t4, 3, R2, CMIN, nn_mode=capi.NN_BRUTE_VALU if mode == "valu" else capi.NN_BRUTE_MFMA)
+
+
+@pytest.mark.gpu
+def test_gates_with_initial_guess_holes_and_per_iteration_indices(gpu_lib):
+    from slam3d_gx_amd import capi
+    pr, s4, t4 = _pair(2104, 200, 150, holes=True)
+    Ti = synth.pose_from_seed(77, max_angle_deg=3.0, max_trans=0.05)
+    iters = 4
+    kw = dict(estimator=0, iterations=iters, max_plane_residual2=R2, min_normal_cos=CMIN)
+    with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1, **kw)) as h:
+        h.set_corr_trace(True)
+        h.align(s4, t4, Ti)
+        Tt, _ = h.get_trace(0)
+        per_it = [h.get_correspondences_at(it, 0) for it in range(iters)]
+    for it in range(iters):      # iteration `it` of a run == a 1-iteration oracle run started at the trace pose
+        ro = O.icp(s4, t4, O.params(pr.intr, nn_method=0, **{**kw, "iterations": 1}), T_init=Tt.reshape(-1, 4, 4)[it])
+        assert np.array_equal(per_it[it], ro["idx"]), (it, int((per_it[it] != ro["idx"]).sum()))
+
+
+@pytest.mark.gpu
+def test_gated_batch_and_resident_frames_in_both_roles(gpu_lib):
+    """Eight pairs per launch (throughput build) over resident frames that serve as source in one pair and as target in
+    another: the source role's normals are the frame's own, computed once per frame whichever role asked first."""
+    from slam3d_gx_amd import capi
+    prs = [synth.make_pair(2200 + k, 160, 120) for k in range(4)]
+    intr = prs[0].intr
+    kw = dict(estimator=0, iterations=3, max_plane_residual2=R2, min_normal_cos=CMIN)
+    frames = []
+    for pr in prs:
+        frames += [pr.depth_src, pr.depth_tgt]
+    pairs = [(0, 1), (1, 0), (2, 3), (3, 2), (4, 5), (5, 4), (6, 7), (7, 6)]
+    with capi.IcpHandle(capi.default_params(intr, max_batch=8, **kw)) as h:
+        for f, d in enumerate(frames):
+            h.frame_set_depth_host(f, d)
+        for b, (fs, ft) in enumerate(pairs):
+            h.set_pair(b, fs, ft)
+        h.run(8)
+        res = h.fetch_results(8)
+        got = [h.get_correspondences(b)[0] for b in range(8)]
+        traces = [h.get_trace(b)[0] for b in range(8)]
+    po = O.params(intr, nn_method=0, **kw)
+    clouds = [O.backproject(d, po) for d in frames]
+    for b, (fs, ft) in enumerate(pairs):
+        ro = O.icp(clouds[fs], clouds[ft], po)
+        assert np.array_equal(got[b], ro["idx"]), b
+        assert np.array_equal(traces[b].reshape(-1, 4, 4), ro["T_trace"]), b
+        assert res[b]["inliers"] == ro["inliers"]
