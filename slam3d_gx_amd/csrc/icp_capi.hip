@@ -253,10 +253,12 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     A(dalloc(h->acc, (size_t)h->maxB * ACC_R * ACC_STRIDE));
     A(dalloc(h->hint, (size_t)h->maxB * tg.ntiles));
     A(dalloc(h->cost, (size_t)h->maxB * tg.ntiles));
-    {   // grid widths of the NN kernel, multiples of 8.  Cooperative build: 20 % more waves than tiles (interleaved
-        // ownership tile c + w * G: with G = 1440 three of four blocks own three tiles; measured equal to G = 1280 and
-        // better than the exact 1200 for a pair alone: 0.86 vs 0.91 ms).  Throughput build: exactly one wave per tile.
-        const int slack = getenv("SLAM3D_NN_SLACK") ? atoi(getenv("SLAM3D_NN_SLACK")) : 20;
+    {   // grid widths of the NN kernel, multiples of 8.  Cooperative build: as many waves as tiles -- with the row ownership every
+        // XCD's list is then exactly full (640x480: 1,200 blocks of four tiles).  More, smaller-loaded blocks (20 % slack: 1,440)
+        // end a pair ALONE 1.5 % sooner, but with several alignments in flight the extra blocks hold LDS and wave slots that the
+        // next stream's launch could use: 56.1 k -> 60.6 k it/s pipelined (SLAM3D_NN_SLACK = percent of extra waves, developer knob).
+        // Throughput build: exactly one wave per tile.
+        const int slack = getenv("SLAM3D_NN_SLACK") ? atoi(getenv("SLAM3D_NN_SLACK")) : 0;
         const long long waves = ((long long)tg.ntiles * (100 + (slack < 0 ? 0 : slack)) + 99) / 100;
         h->nn_gx = (int)(((waves + NN_WAVES - 1) / NN_WAVES + 7) / 8 * 8);
         if (getenv("SLAM3D_NN_GX")) {                      // developer knob: grid width of the cooperative build
@@ -264,7 +266,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
             if ((long long)gx * NN_WAVES >= tg.ntiles) h->nn_gx = gx;
         }
         {   // row-interleaved XCD ownership: every XCD needs a slot for each tile of its rows
-            const int per_xcd = ((tg.nty + 7) / 8) * tg.ntx;
+            const int per_xcd = (tg.nty / 8) * tg.ntx + ((tg.nty % 8) * tg.ntx + 7) / 8;
             const int min_gx = 8 * ((per_xcd + NN_WAVES - 1) / NN_WAVES);
             if (h->nn_gx < min_gx) h->nn_gx = min_gx;
         }

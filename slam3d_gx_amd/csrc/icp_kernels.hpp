@@ -1027,6 +1027,15 @@ __device__ __forceinline__ int lds_fetch_add_uniform(int *p, int v)
 #ifndef S3D_OWN_HOME_CELL
 #define S3D_OWN_HOME_CELL 0          // the owner refines its (prefetched) home cell itself instead of listing it
 #endif
+#ifndef S3D_DEPTH_SPLIT
+#define S3D_DEPTH_SPLIT 1            // waves on a depth edge class their lanes near / far instead of tight / loose
+#endif
+#ifndef S3D_LANE_SCAN
+#define S3D_LANE_SCAN 1              // every lane scans only the quadrants ITS ball reaches (0: the wave scans their union)
+#endif
+constexpr int QSTRIDE = S3D_LANE_SCAN ? 17 : 16;   // float4 per staged quadrant: 16 candidates (+ 1 pad: lane-specific reads of
+                                                   // different quadrants then fall into different banks)
+constexpr int STAGE_REC = 4 * QSTRIDE + 8;         // LDS image of a tile record (TILE_REC in global memory)
 constexpr int NN_MAX_ITEMS = 128;    // (owner wave, coarse cell) work items shared by the waves of a block
 constexpr int NN_MAX_TITEMS = 384;   // (owner wave, target tile) work items: the tiles the cell sweeps found worth scanning
 constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (8 measured slower: 2 blocks per CU)
@@ -1053,7 +1062,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                                                         int write_out /* corr / cd2 wanted (last iteration) */,
                                                         int first /* a run's first iteration: no previous match, no hint */)
 {
-    __shared__ float4 stage_all[NN_WAVES][NN_STAGE * TILE_REC];
+    __shared__ float4 stage_all[NN_WAVES][NN_STAGE * STAGE_REC];
     __shared__ int wcost[NN_WAVES];                                    // cycles spent for each owner (all helpers)
     __shared__ float qpos[NN_WAVES][3][TILE_SLOTS];                   // p'.x / .y / .z of each owner's queries (SoA: 3 KB, not 4)
     __shared__ unsigned long long qcls[NN_WAVES][2];                  // lane masks: valid, tight (loose = valid & ~tight)
@@ -1086,9 +1095,18 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         // owns the tile ROWS r = x (mod 8) -- a uniform sample of the whole frame (depth edges, the row shard of the dense
         // mode), while its L2 sees 3/8 of the target frame (rows r-1 .. r+1) instead of all of it.  Inside the XCD's row list
         // (raster order) wave w of the XCD's i-th block takes entry i + w * G/8.
+        // The nty % 8 rows left over after the whole rounds are dealt in eight equal raster chunks, so every XCD owns the same
+        // number of tiles (60 rows: 7 rows + half a row each, not 8 rows for four XCDs and 7 for the others).
         const int x = c & 7, k = (c >> 3) + w * ((int)gridDim.x >> 3);
-        const int rl = k / tg.ntx, col = k - rl * tg.ntx, row = x + 8 * rl;
-        t = row < tg.nty ? row * tg.ntx + col : tg.ntiles;
+        const int full_rows = tg.nty & ~7, n_full = (full_rows >> 3) * tg.ntx;
+        if (k < n_full) {
+            const int rl = k / tg.ntx, col = k - rl * tg.ntx;
+            t = (x + 8 * rl) * tg.ntx + col;
+        } else {
+            const int n_rem = (tg.nty - full_rows) * tg.ntx, chunk = (n_rem + 7) >> 3, j = k - n_full;
+            const int idx = x * chunk + j;
+            t = (j < chunk && idx < n_rem) ? full_rows * tg.ntx + idx : tg.ntiles;
+        }
     }
 #endif
     const bool has_tile = t < tg.ntiles;
@@ -1129,20 +1147,62 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         return valid && __fmaf_rn(gz, gz, __fmaf_rn(gy, gy, gx * gx)) <= thr;
     };
     auto lane_gap_ok = [&](const float4 lo, const float4 hi) __attribute__((always_inline)) { return lane_gap_le(lo, hi, lane_thr()); };
+    bool hinted = false;        // step 1 scans tiles that the hint picked: their tile-level test nearly always passes, skip it
+    // which quadrants of staged tile k (bits 4k .. 4k+3) this lane has to scan: tile box first (wave level), then its own
+    // ball against each quadrant box
+    auto quad_mask = [&](int k, int tile) __attribute__((always_inline)) {
+        const float thr = lane_thr();          // once per tile: the quadrant tests below may use this (larger) value
+        unsigned int m = 0u;
+        if (!hinted && __ballot(lane_gap_le(TB[2 * tile], TB[2 * tile + 1], thr)) == 0ull) return m;     // uniform -> scalar loads
+        if constexpr (DBG) n_scanned += 1;
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const float4 lo = st[k * STAGE_REC + 4 * QSTRIDE + 2 * qd], hi = st[k * STAGE_REC + 4 * QSTRIDE + 2 * qd + 1];
+            const int cnt = __builtin_amdgcn_readfirstlane(__float_as_int(lo.w));
+            if (cnt != 0 && lane_gap_le(lo, hi, thr)) m |= 1u << (4 * k + qd);
+        }
+        return m;
+    };
+    // Exactness does not need more: a lane whose ball misses a quadrant's box cannot find a winner or a tie there.  A
+    // wave's lanes reach 7.6 quadrants between them but 3.0 at most each (1.4 on average; bench pair, mid-run), so the
+    // wave iterates max-over-lanes times instead of union-over-lanes times: 16 candidates per trip, each lane reading
+    // ITS quadrant (same slot index, quadrant stride 17 float4: distinct quadrants sit in distinct banks).
+    auto scan_lanes = [&](unsigned int m) __attribute__((always_inline)) {
+        while (__ballot(m != 0u) != 0ull) {
+            if constexpr (DBG) n_cand += 16;
+            if (m != 0u) {
+                const int q = __builtin_ctz(m);
+                m &= m - 1u;
+                const float4 *__restrict__ cand = st + (q >> 2) * STAGE_REC + (q & 3) * QSTRIDE;
+                // the padding slots of a quadrant hold (+inf, +inf, +inf): d2 = +inf never wins
+#pragma unroll 1
+                for (int i = 0; i < 16; i += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float4 c4 = cand[i + u];
+                        const float d2 = canon_d2(px, py, pz, c4.y, c4.z, c4.w);     // record = (pixel, x, y, z)
+                        const unsigned long long key =
+                            ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(c4.x);
+                        bkey = key_min(bkey, key);
+                    }
+                }
+            }
+        }
+    };
     // scan staged tile k (tile id tile, both wave-uniform): tile box first, then its four 4x4-pixel quadrants,
     // each only if some lane can still improve/tie inside that box
-    bool hinted = false;        // step 1 scans tiles that the hint picked: their tile-level test nearly always passes, skip it
     auto scan_staged = [&](int k, int tile) __attribute__((always_inline)) {
+        if constexpr (S3D_LANE_SCAN) { scan_lanes(quad_mask(k, tile)); return; }
         const float thr = lane_thr();          // once per tile: the quadrant tests below may use this (larger) value
         if (!hinted && __ballot(lane_gap_le(TB[2 * tile], TB[2 * tile + 1], thr)) == 0ull) return;     // uniform -> scalar loads
         if constexpr (DBG) n_scanned += 1;
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) {
-            const float4 lo = st[k * TILE_REC + TILE_SLOTS + 2 * qd], hi = st[k * TILE_REC + TILE_SLOTS + 2 * qd + 1];
+            const float4 lo = st[k * STAGE_REC + 4 * QSTRIDE + 2 * qd], hi = st[k * STAGE_REC + 4 * QSTRIDE + 2 * qd + 1];
             const int cnt = __builtin_amdgcn_readfirstlane(__float_as_int(lo.w));
             if (cnt == 0 || __ballot(lane_gap_le(lo, hi, thr)) == 0ull) continue;
             if constexpr (DBG) n_cand += cnt;
-            const float4 *__restrict__ cand = st + k * TILE_REC + qd * 16;
+            const float4 *__restrict__ cand = st + k * STAGE_REC + qd * QSTRIDE;
             // four candidates per trip; the padding slots of a quadrant hold (+inf, +inf, +inf): d2 = +inf never wins
             for (int i = 0; i < cnt; i += 4) {
 #pragma unroll
@@ -1171,17 +1231,25 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         if (my_tile >= 0) qb = TT[(size_t)my_tile * TILE_REC + TILE_SLOTS + (lane & 7)];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < NN_STAGE; ++k) st[k * TILE_REC + lane] = r[k];
-        if (lane < NN_STAGE * 8) st[(lane >> 3) * TILE_REC + TILE_SLOTS + (lane & 7)] = qb;
+        for (int k = 0; k < NN_STAGE; ++k) st[k * STAGE_REC + (lane >> 4) * QSTRIDE + (lane & 15)] = r[k];
+        if (lane < NN_STAGE * 8) st[(lane >> 3) * STAGE_REC + 4 * QSTRIDE + (lane & 7)] = qb;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     auto park_and_scan = [&]() __attribute__((always_inline)) {
         park();
+        if constexpr (S3D_LANE_SCAN) {          // one owner for the whole batch: one lane loop over the quadrants of all its tiles
+            unsigned int m = 0u;
 #pragma unroll
-        for (int k = 0; k < NN_STAGE; ++k)
-            if (tt[k] >= 0) scan_staged(k, tt[k]);
+            for (int k = 0; k < NN_STAGE; ++k)
+                if (tt[k] >= 0) m |= quad_mask(k, tt[k]);
+            scan_lanes(m);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NN_STAGE; ++k)
+                if (tt[k] >= 0) scan_staged(k, tt[k]);
+        }
         __builtin_amdgcn_wave_barrier();
     };
     // The wave-level tests use TWO query boxes: lanes whose bound is already small ("tight", radius below a
@@ -1367,6 +1435,19 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         // ---- step 2: publish the queries and one work item per reachable coarse cell
         const float bnd0 = __int_as_float((int)(unsigned int)(bkey >> 32));
         tight = valid && bnd0 <= 0.0625f * g.gate2; loose = valid && !tight;
+#if S3D_DEPTH_SPLIT
+        {   // A tile that straddles a depth edge holds foreground AND background points: one box around them spans the whole
+            // depth range and meets every target tile in between, none of which any lane's ball reaches (bench pair: the
+            // heaviest 3 % of the tiles hit 52 target tiles with tight/loose boxes, 15 with near/far boxes, 12 are needed).
+            // Such a wave classes its lanes by depth instead -- the two classes are only boxes and thresholds, any split is exact.
+            const float zz = wave_min_x4(valid ? pz : inf, valid ? -pz : inf, valid ? -bnd0 : 0.0f, 0.0f);
+            const float zmin = rdlane(zz, 0), zmax = -rdlane(zz, 32), bmax = -rdlane(zz, 16);
+            if (zmax - zmin > 4.0f * sqrtf(bmax) + 0.05f) {
+                const float zmid = 0.5f * (zmin + zmax);
+                tight = valid && pz <= zmid; loose = valid && !tight;
+            }
+        }
+#endif
         if constexpr (COOP) {
             qpos[w][0][lane] = px; qpos[w][1][lane] = py; qpos[w][2][lane] = pz;
             {
