@@ -1431,7 +1431,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         park_and_scan();
         hinted = false;
         if constexpr (DBG) clk2 = clock64();
-        opx = px; opy = py; opz = pz;
+        if constexpr (!COOP) { opx = px; opy = py; opz = pz; }     // (cooperative build: re-read from qpos in step 4 -- three registers less across the drain)
         // ---- step 2: publish the queries and one work item per reachable coarse cell
         const float bnd0 = __int_as_float((int)(unsigned int)(bkey >> 32));
         tight = valid && bnd0 <= 0.0625f * g.gate2; loose = valid && !tight;
@@ -1605,8 +1605,17 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     if (!has_tile) return;
     if constexpr (!COOP) { if (lane == 0) cost[(size_t)b * tg.ntiles + t] = wcost[w]; }          // input of k_balance
     // ================= step 4: this wave's own tile: fused S4 accumulation =================
-    if constexpr (COOP) bkey = qkey[w][lane];
+    if constexpr (COOP) {
+        bkey = qkey[w][lane];
+        if (__ballot(own_valid) != 0ull) { opx = qpos[w][0][lane]; opy = qpos[w][1][lane]; opz = qpos[w][2][lane]; }     // published in step 2
+    }
     if (__ballot(own_valid) == 0ull) bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
+    size_t gs_ep;                      // the slot index again, recomputed behind an opaque copy of t: kept live from the top of
+    {                                  // the kernel it cost a register pair across the drain (one scratch spill per wave)
+        int t_ep = t;
+        asm volatile("" : "+s"(t_ep));
+        gs_ep = (size_t)b * tg.nslots + (size_t)t_ep * TILE_SLOTS + lane;
+    }
     RowBasis rb;
     if constexpr (GATED) {             // the optional S4g gates: their own instances, the production ones carry none of this
         SlotGates sg;
@@ -1614,10 +1623,10 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         sg.resid2 = g.resid2; sg.min_ncos = g.min_ncos; sg.snrm = pp.snrm; sg.spix = max(pix, 0);
         sg.r[0] = m.r00; sg.r[1] = m.r01; sg.r[2] = m.r02; sg.r[3] = m.r10; sg.r[4] = m.r11; sg.r[5] = m.r12;
         sg.r[6] = m.r20; sg.r[7] = m.r21; sg.r[8] = m.r22;
-        finish_slot<true>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, prevq + gs, rb,
+        finish_slot<true>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs_ep, cd2 + gs_ep, prevq + gs_ep, rb,
                           write_out != 0, own_jprev, &sg);
     } else
-        finish_slot<false>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs, cd2 + gs, prevq + gs, rb,
+        finish_slot<false>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs_ep, cd2 + gs_ep, prevq + gs_ep, rb,
                            write_out != 0, own_jprev);
     tile_accumulate(g.estimator, rb, acc + ((size_t)b * ACC_R + (c % ACC_R)) * ACC_STRIDE);
     {   // hint for the next iteration: the tile holding the match of a lane near the tile centre
