@@ -433,7 +433,11 @@ def voxel_mode(args, torch, dist, capi, synth, world, rank, local_rank, dev):
     d = torch.from_numpy(c).to(dev)
     out_d = torch.zeros_like(d)
     h = capi.IcpHandle(capi.default_params(pr.intr, max_batch=1, device=local_rank))
-    stream = torch.cuda.current_stream().cuda_stream
+    # a stream of the caller's: the call returns once the voxel count is known, the records follow in stream order, so the
+    # next call's launches are queued while this one's tail still runs (the fence below drains the stream inside the timed region)
+    ts = torch.cuda.Stream(device=dev)
+    ts.wait_stream(torch.cuda.current_stream())
+    stream = ts.cuda_stream
 
     def fence():
         torch.cuda.synchronize()

@@ -227,7 +227,10 @@ int slam3d_device_count(void);
  * z in [0, z_filter] followed by pcl::VoxelGrid with a cubic leaf (grid_leaf, 0.03), on n 16-byte records
  * {float x, y, z; uint32 rgba} -- the layout of the reference's binary PCD files (data/exp1/pcd/1.pcd header).
  * One output record per occupied voxel (centroid of all fields), ordered by voxel index (iz, iy, ix) like PCL.
- * n <= width*height of the handle; out has room for n records. */
+ * n <= width*height of the handle; out has room for n records.
+ * _device with a caller's stream: the call returns as soon as *n_out is known; the records in d_out16 are ready IN
+ * STREAM ORDER (work queued on that stream afterwards sees them; synchronise the stream before touching them from
+ * anywhere else).  With stream == NULL the handle's own stream is used and drained before the call returns. */
 int slam3d_voxel_grid(slam3d_icp_handle *h, const void *points16, int32_t n, float leaf, void *out16, int32_t *n_out);
 int slam3d_voxel_grid_device(slam3d_icp_handle *h, const void *d_points16, int32_t n, float leaf, void *d_out16,
                              int32_t *n_out, void *stream);

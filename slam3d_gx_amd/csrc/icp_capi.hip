@@ -67,7 +67,7 @@ struct slam3d_icp_handle {
     unsigned long long *vox_lkey = nullptr, *vox_gkey = nullptr;
     int *vox_lslot = nullptr, *vox_gslot = nullptr, *vox_m = nullptr, *vox_hist = nullptr;   // hist | start | cursor
     float4 *vox_out = nullptr;
-    int *pin_vox_m = nullptr;
+    int *pin_vox_m = nullptr, *pin_vox_m_dev = nullptr;     // host-mapped: k_voxel_scan writes the voxel count there
     bool vox_dirty = true;        // table / histogram need a full clear before the next voxel call
     // 8x8-pixel tiles (slot order of the sums; target tiles + boxes for the pruned NN)
     TileGrid tg;
@@ -1015,9 +1015,10 @@ static int vox_alloc(slam3d_icp_handle *h)
         hipMalloc((void **)&h->vox_m, sizeof(int) * (size_t)(nblk + 1)) != hipSuccess ||            // [0] kept-count of pass_transform, [1..] claims per insert block
         hipMalloc((void **)&h->vox_gkey, sizeof(unsigned long long) * h->N) != hipSuccess ||
         hipMalloc((void **)&h->vox_gslot, sizeof(int) * h->N) != hipSuccess ||
-        hipMalloc((void **)&h->vox_hist, sizeof(int) * (3 * VOX_BINS + 8 + VOX_SCAN_BLOCKS)) != hipSuccess ||
+        hipMalloc((void **)&h->vox_hist, sizeof(int) * (3 * VOX_BINS + 16 + 2 * VOX_SCAN_BLOCKS)) != hipSuccess ||
         hipMalloc((void **)&h->vox_out, sizeof(float4) * h->N) != hipSuccess ||
-        hipHostMalloc((void **)&h->pin_vox_m, sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void **)&h->pin_vox_m, sizeof(int), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&h->pin_vox_m_dev, h->pin_vox_m, 0) != hipSuccess) {
         (void)hipGetLastError();
         return SLAM3D_E_NOMEM;
     }
@@ -1040,10 +1041,11 @@ static int voxel_grid_impl(slam3d_icp_handle *h, const void *d_points16, int32_t
     const VoxTable &t = h->vox;
     if (h->vox_dirty) {      // allocation, or an earlier call failed half way: from then on every call cleans up after itself
         hipLaunchKernelGGL(k_voxel_clear, dim3((t.cap + VOX_BLOCK - 1) / VOX_BLOCK), dim3(VOX_BLOCK), 0, s, t);
-        HIPCHK(h, hipMemsetAsync(h->vox_hist, 0, sizeof(int) * VOX_BINS, s));
+        HIPCHK(h, hipMemsetAsync(h->vox_hist, 0, sizeof(int) * (3 * VOX_BINS + 16 + 2 * VOX_SCAN_BLOCKS), s));     // histogram AND the scan ticket
     }
     h->vox_dirty = true;     // until this call has run to its end
-    int *start = h->vox_hist + VOX_BINS, *cursor = start + VOX_BINS + 8, *btot = cursor + VOX_BINS, *bcount = h->vox_m + 1;
+    int *start = h->vox_hist + VOX_BINS, *cursor = start + VOX_BINS + 8, *btot = cursor + VOX_BINS, *boff = btot + VOX_SCAN_BLOCKS,
+        *ticket = boff + VOX_SCAN_BLOCKS, *bcount = h->vox_m + 1;
     // an organized cloud (all width x height records present) is cut into 16x16-pixel tiles, anything else into runs of 256
     const bool org = n == h->N;
     const int nblk = org ? ((h->p.width + VOX_TW - 1) / VOX_TW) * ((h->p.height + VOX_TW - 1) / VOX_TW) : (n + VOX_BLOCK - 1) / VOX_BLOCK;
@@ -1051,16 +1053,31 @@ static int voxel_grid_impl(slam3d_icp_handle *h, const void *d_points16, int32_t
                                 h->p.height, 1.0f / leaf, zmin, zmax, t, h->vox_lkey, h->vox_lslot, bcount, h->vox_hist);
     else hipLaunchKernelGGL(k_voxel_insert<false>, dim3(nblk), dim3(VOX_BLOCK), 0, s, static_cast<const float4 *>(d_points16), n, h->p.width,
                             h->p.height, 1.0f / leaf, zmin, zmax, t, h->vox_lkey, h->vox_lslot, bcount, h->vox_hist);
-    hipLaunchKernelGGL(k_voxel_scan1, dim3(VOX_SCAN_BLOCKS), dim3(1024), 0, s, h->vox_hist, start, cursor, btot);
-    hipLaunchKernelGGL(k_voxel_scan2, dim3(VOX_SCAN_BLOCKS), dim3(1024), 0, s, start, btot);
-    hipLaunchKernelGGL(k_voxel_scatter, dim3(nblk), dim3(VOX_BLOCK), 0, s, h->vox_lkey, h->vox_lslot, bcount, start, cursor, h->vox_gkey,
+    *(volatile int *)h->pin_vox_m = -1;
+    hipLaunchKernelGGL(k_voxel_scan, dim3(VOX_SCAN_BLOCKS), dim3(1024), 0, s, h->vox_hist, start, cursor, btot, boff, ticket, h->pin_vox_m_dev);
+    hipLaunchKernelGGL(k_voxel_scatter, dim3(nblk), dim3(VOX_BLOCK), 0, s, h->vox_lkey, h->vox_lslot, bcount, start, boff, cursor, h->vox_gkey,
                        h->vox_gslot);
-    hipLaunchKernelGGL(k_voxel_rank, dim3(nblk), dim3(VOX_BLOCK), 0, s, t, h->vox_gkey, h->vox_gslot, start, static_cast<float4 *>(d_out16));
+    hipLaunchKernelGGL(k_voxel_rank, dim3(nblk), dim3(VOX_BLOCK), 0, s, t, h->vox_gkey, h->vox_gslot, start, boff, static_cast<float4 *>(d_out16));
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(h->pin_vox_m, start + VOX_BINS, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipStreamSynchronize(s));
+    if (stream) {
+        // A caller's stream: the records are ready IN STREAM ORDER, and the call returns as soon as the count is known --
+        // k_voxel_scan writes it into host-mapped memory while the scatter and rank launches are still queued behind it.
+        int m = -1;
+        for (unsigned spins = 1; (m = *(volatile int *)h->pin_vox_m) < 0; ++spins) {
+            if ((spins & 0x3ff) != 0) continue;
+            const hipError_t q = hipStreamQuery(s);                 // a failed launch must not leave us spinning
+            if (q == hipErrorNotReady) continue;
+            HIPCHK(h, q);
+            m = *(volatile int *)h->pin_vox_m;
+            if (m < 0) { h->err = "voxel grid: the stream drained without a count"; return SLAM3D_E_HIP; }
+            break;
+        }
+        *n_out = m;
+    } else {
+        HIPCHK(h, hipStreamSynchronize(s));      // the voxel count is in host-mapped memory by now (written by k_voxel_scan)
+        *n_out = *(volatile int *)h->pin_vox_m;
+    }
     h->vox_dirty = false;
-    *n_out = *h->pin_vox_m;
     return SLAM3D_OK;
 }
 
@@ -1080,7 +1097,8 @@ static int voxel_host(slam3d_icp_handle *h, const void *points16, int32_t n, flo
     if (n > 0) HIPCHK(h, hipMemcpyAsync(h->d_scratch4, points16, (size_t)n * 16, hipMemcpyHostToDevice, h->stream));
     rc = voxel_grid_impl(h, h->d_scratch4, n, leaf, zmin, zmax, h->vox_out, n_out, h->stream);
     if (rc) return rc;
-    if (*n_out > 0) HIPCHK(h, hipMemcpy(out16, h->vox_out, (size_t)*n_out * 16, hipMemcpyDeviceToHost));
+    if (*n_out > 0) HIPCHK(h, hipMemcpyAsync(out16, h->vox_out, (size_t)*n_out * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return SLAM3D_OK;
 }
 

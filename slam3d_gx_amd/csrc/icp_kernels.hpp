@@ -1027,6 +1027,9 @@ __device__ __forceinline__ int lds_fetch_add_uniform(int *p, int v)
 #ifndef S3D_OWN_HOME_CELL
 #define S3D_OWN_HOME_CELL 0          // the owner refines its (prefetched) home cell itself instead of listing it
 #endif
+#ifndef S3D_PROJ_HINT
+#define S3D_PROJ_HINT 1              // first tiles of a wave: where its patch PROJECTS into the target image under the current pose
+#endif                               // (0: where its matches were in the previous iteration, kept in hint[])
 #ifndef S3D_DEPTH_SPLIT
 #define S3D_DEPTH_SPLIT 1            // waves on a depth edge class their lanes near / far instead of tight / loose
 #endif
@@ -1379,7 +1382,35 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         // hint = the (up to 2x2) block of target tiles that the 8x8 source patch covered in the previous iteration
         // (top-left tile | extends in x << 24 | extends in y << 25); without one: the same image location and its
         // four edge neighbours
+#if S3D_PROJ_HINT
+        // Both clouds are organized depth images of one camera, so the source patch under the current pose lands where its
+        // points project: the pinhole of the frame geometry gives the target pixel of a lane near the patch centre, and the
+        // (up to 2x2) block of tiles the 8x8 patch covers around it.  Unlike last iteration's matches this follows the pose:
+        // the second and third iteration of a run, where the pose still moves by centimetres, start in the right tiles.
+        const Rt m = load_rt(Tcur + b * 16);
+        xform(m, s4.x, s4.y, s4.z, px, py, pz);
+        int th = -1;
+        {
+            const unsigned long long mm = __ballot(own_valid);
+            const unsigned long long ctr = mm & 0x0000001818000000ull;      // lanes 27,28,35,36
+            const int src_lane = __builtin_ctzll(ctr ? ctr : mm);
+            const float hx = rdlane(px, src_lane), hy = rdlane(py, src_lane), hz = rdlane(pz, src_lane);
+            if (hz > 0.0f) {
+                const float iz = 1.0f / hz;
+                const float uf = (float)g.fx * hx * iz + (float)g.cx, vf = (float)g.fy * hy * iz + (float)g.cy;
+                if (uf > -1.0e6f && uf < 1.0e6f && vf > -1.0e6f && vf < 1.0e6f) {
+                    const int pu0 = (int)rintf(uf) - (src_lane & 7), pv0 = (int)rintf(vf) - (src_lane >> 3);   // the patch's top-left pixel
+                    if (pu0 + 7 >= 0 && pu0 < g.W && pv0 + 7 >= 0 && pv0 < g.H) {
+                        const int u0 = max(0, pu0), u1 = min(g.W - 1, pu0 + 7), v0 = max(0, pv0), v1 = min(g.H - 1, pv0 + 7);
+                        const int ax0 = u0 / TILE_PX, ay0 = v0 / TILE_PX;
+                        th = (ay0 * tg.ntx + ax0) | ((u1 / TILE_PX > ax0) << 24) | ((v1 / TILE_PX > ay0) << 25);
+                    }
+                }
+            }
+        }
+#else
         const int th = first ? -1 : __builtin_amdgcn_readfirstlane(hint[(size_t)b * tg.ntiles + t]);
+#endif
         if (th >= 0 && (th & 0xffffff) < tg.ntiles) {
             const int base = th & 0xffffff, fx = (th >> 24) & 1, fy = (th >> 25) & 1;
             tt[0] = base;
@@ -1412,8 +1443,10 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             const int ug = (t % tg.ntx) * TILE_PX + (lane & 7), vg = (t / tg.ntx) * TILE_PX + (lane >> 3);
             if (ug < g.W && vg < g.H) { qs = tcloud[vg * g.W + ug]; if (g.estimator == 0) ws = tnrm[vg * g.W + ug].w; }
         }
+#if !S3D_PROJ_HINT
         const Rt m = load_rt(Tcur + b * 16);
         xform(m, s4.x, s4.y, s4.z, px, py, pz);
+#endif
         valid = own_valid;
         if (!first) own_jprev = __float_as_int(pq.w);
         // ---- upper bound: previous match, else the target at the same pixel, else the gate
@@ -1629,6 +1662,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         finish_slot<false>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs_ep, cd2 + gs_ep, prevq + gs_ep, rb,
                            write_out != 0, own_jprev);
     tile_accumulate(g.estimator, rb, acc + ((size_t)b * ACC_R + (c % ACC_R)) * ACC_STRIDE);
+#if !S3D_PROJ_HINT
     {   // hint for the next iteration: the tile holding the match of a lane near the tile centre
         const bool ok = rb.v[7] != 0.0;
         const unsigned long long mm = __ballot(ok);
@@ -1647,6 +1681,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             }
         }
     }
+#endif
     if (DBG && dbg && b == 0 && lane == 0) {
         long long *d = dbg + (size_t)t * 20;
         d[0] = clk0; d[1] = clk1; d[2] = clk2; d[3] = clk3; d[4] = clock64();

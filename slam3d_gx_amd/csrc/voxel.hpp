@@ -67,14 +67,36 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_clear(VoxTable t)
 
 // inclusive sum over the lanes of the same run (runs = maximal stretches of consecutive lanes with equal keys,
 // numbered by `seg`): Hillis-Steele with a segment test; integer adds, so exact
+template <int CTRL> __device__ __forceinline__ int vox_dpp(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ long long vox_dpp(long long x)
+{
+    const int lo = vox_dpp<CTRL>((int)(unsigned int)((unsigned long long)x & 0xffffffffull)), hi = vox_dpp<CTRL>((int)((unsigned long long)x >> 32));
+    return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
+}
+template <int CTRL> __device__ __forceinline__ unsigned long long vox_dpp(unsigned long long x) { return (unsigned long long)vox_dpp<CTRL>((long long)x); }
+__device__ __forceinline__ int vox_rdlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+__device__ __forceinline__ long long vox_rdlane(long long x, int l)
+{
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)x & 0xffffffffull), l);
+    const int hi = __builtin_amdgcn_readlane((int)((unsigned long long)x >> 32), l);
+    return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ unsigned long long vox_rdlane(unsigned long long x, int l) { return (unsigned long long)vox_rdlane((long long)x, l); }
+// No LDS traffic: a segmented Hillis-Steele scan inside each 16-lane row with DPP row_shr moves (lanes shifted in from
+// outside the row are excluded by the lane test), then the rows are chained in order -- a run that continues from the
+// previous row adds that row's last, already final, value (v_readlane broadcasts).
 template <typename T> __device__ __forceinline__ T run_scan(T v, int seg)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, rl = lane & 15;
+    { const T u = vox_dpp<0x111>(v); const int su = vox_dpp<0x111>(seg); if (rl >= 1 && su == seg) v += u; }
+    { const T u = vox_dpp<0x112>(v); const int su = vox_dpp<0x112>(seg); if (rl >= 2 && su == seg) v += u; }
+    { const T u = vox_dpp<0x114>(v); const int su = vox_dpp<0x114>(seg); if (rl >= 4 && su == seg) v += u; }
+    { const T u = vox_dpp<0x118>(v); const int su = vox_dpp<0x118>(seg); if (rl >= 8 && su == seg) v += u; }
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const T u = __shfl_up(v, o);
-        const int su = __shfl_up(seg, o);
-        if (lane >= o && su == seg) v += u;
+    for (int r = 1; r < 4; ++r) {
+        const T carry = vox_rdlane(v, 16 * r - 1);
+        const int cseg = vox_rdlane(seg, 16 * r - 1);
+        if ((lane >> 4) == r && seg == cseg) v += carry;
     }
     return v;
 }
@@ -117,9 +139,10 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(const float4 *__rest
     __shared__ unsigned long long hk[VOX_LH], hc01[VOX_LH], hc23[VOX_LH];
     __shared__ long long hsx[VOX_LH], hsy[VOX_LH], hsz[VOX_LH];
     __shared__ unsigned int hn[VOX_LH];
-    __shared__ int bcnt;
+    __shared__ int occ[VOX_LH];                                  // the occupied entries, compacted
+    __shared__ int bcnt, nocc;
     for (int k = threadIdx.x; k < VOX_LH; k += VOX_BLOCK) { hk[k] = VOX_EMPTY; hc01[k] = 0; hc23[k] = 0; hsx[k] = 0; hsy[k] = 0; hsz[k] = 0; hn[k] = 0; }
-    if (threadIdx.x == 0) bcnt = 0;
+    if (threadIdx.x == 0) { bcnt = 0; nocc = 0; }
     __syncthreads();
     int i = -1;
     if constexpr (ORG) {
@@ -163,9 +186,16 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(const float4 *__rest
         atomicAdd(&hn[s], (unsigned int)cnt);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < VOX_LH; k += VOX_BLOCK) {      // level 3: one global update per (block, voxel)
+    // level 3: one global update per (block, voxel).  The few dozen occupied entries are compacted first, so that each has
+    // a thread of its own and the block pays ONE round of returning-atomic latency (thread t looking at entries t and
+    // t + 256 in turn paid two whenever any thread held two).
+    for (int k = threadIdx.x; k < VOX_LH; k += VOX_BLOCK)
+        if (hk[k] != VOX_EMPTY) occ[atomicAdd(&nocc, 1)] = k;
+    __syncthreads();
+    const int n_occ = nocc;
+    for (int e = threadIdx.x; e < n_occ; e += VOX_BLOCK) {
+        const int k = occ[e];
         const unsigned long long gk = hk[k];
-        if (gk == VOX_EMPTY) continue;
         unsigned int s = vox_hash(gk) & (unsigned int)(t.cap - 1);
         bool claimed = false;
         for (;;) {
@@ -192,14 +222,18 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(const float4 *__rest
     if (threadIdx.x == 0) bcount[blockIdx.x] = bcnt;
 }
 
-// exclusive prefix of the row histogram -> start[]; cursor[] and the histogram itself reset for the next call.  Two
-// launches of VOX_BINS / 1024 blocks: scan1 scans 1024 rows per block (wave shuffles + one LDS step) and leaves the
-// block totals, scan2 adds to every block the sum of the totals before it (128 values, read by every block).
+// exclusive prefix of the row histogram; cursor[] and the histogram itself reset for the next call.  ONE launch of
+// VOX_BINS / 1024 blocks: every block scans its 1024 rows (wave shuffles + one LDS step) into start[] (prefix inside the
+// block) and leaves its total; the block that arrives last at the ticket (no spinning: it is simply the last one) turns
+// the 128 totals into the blocks' exclusive offsets boff[] and the voxel count M = start[VOX_BINS], which it also writes
+// straight into host-mapped memory (no copy launch behind the pipeline).  Consumers read vox_start(): start[b] + boff[b / 1024].
 constexpr int VOX_SCAN_BLOCKS = VOX_BINS / 1024;
-__global__ __launch_bounds__(1024) void k_voxel_scan1(int *__restrict__ hist, int *__restrict__ start, int *__restrict__ cursor,
-                                                      int *__restrict__ btot)
+__global__ __launch_bounds__(1024) void k_voxel_scan(int *__restrict__ hist, int *__restrict__ start, int *__restrict__ cursor,
+                                                     int *__restrict__ btot, int *__restrict__ boff, int *__restrict__ ticket,
+                                                     int *__restrict__ m_host)
 {
     __shared__ int wtot[16];
+    __shared__ int last_sh;
     const int i = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int v = hist[i];
     if (v) hist[i] = 0;
@@ -211,20 +245,42 @@ __global__ __launch_bounds__(1024) void k_voxel_scan1(int *__restrict__ hist, in
     for (int q = 0; q < w; ++q) before += wtot[q];
     start[i] = before + incl - v;                      // exclusive prefix inside the block
     cursor[i] = 0;
-    if (threadIdx.x == 1023) btot[blockIdx.x] = before + incl;
-}
-__global__ __launch_bounds__(1024) void k_voxel_scan2(int *__restrict__ start, const int *__restrict__ btot)
-{
-    __shared__ int off_sh;
-    if (threadIdx.x < 64) {
-        int a = 0;
-        for (int q = threadIdx.x; q < (int)blockIdx.x; q += 64) a += btot[q];
-        for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
-        if (threadIdx.x == 0) off_sh = a;
+    if (threadIdx.x == 1023) {
+        __hip_atomic_store(btot + blockIdx.x, before + incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last_sh = atomicAdd(ticket, 1) == VOX_SCAN_BLOCKS - 1;
     }
     __syncthreads();
-    start[blockIdx.x * 1024 + threadIdx.x] += off_sh;
-    if (blockIdx.x == VOX_SCAN_BLOCKS - 1 && threadIdx.x == 1023) start[VOX_BINS] = off_sh + btot[blockIdx.x];     // = number of voxels
+    if (!last_sh || threadIdx.x >= 64) return;
+    __threadfence();
+    // the last block: exclusive scan of the VOX_SCAN_BLOCKS totals by one wave (two values per lane at 128 blocks)
+    constexpr int PER = (VOX_SCAN_BLOCKS + 63) / 64;
+    int tv[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int q = lane * PER + k;
+        tv[k] = q < VOX_SCAN_BLOCKS ? __hip_atomic_load(btot + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        sum += tv[k];
+    }
+    int inc = sum;
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    int run = inc - sum;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int q = lane * PER + k;
+        if (q < VOX_SCAN_BLOCKS) boff[q] = run;
+        run += tv[k];
+    }
+    if (lane == 63) {
+        start[VOX_BINS] = inc;                         // = number of voxels
+        *m_host = inc;
+        *ticket = 0;                                   // ready for the next call
+        __threadfence_system();
+    }
+}
+__device__ __forceinline__ int vox_start(const int *__restrict__ start, const int *__restrict__ boff, int b)
+{
+    return b >= VOX_BINS ? start[VOX_BINS] : start[b] + boff[b >> 10];
 }
 
 // group the listed slots by row (order inside a row is arbitrary; k_voxel_rank fixes it).  Thread e looks at entry
@@ -232,8 +288,8 @@ __global__ __launch_bounds__(1024) void k_voxel_scan2(int *__restrict__ start, c
 // handful of rows: lanes with the same row share ONE returning atomic on its cursor.
 __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_scatter(const unsigned long long *__restrict__ lkey, const int *__restrict__ lslot,
                                                              const int *__restrict__ bcount, const int *__restrict__ start,
-                                                             int *__restrict__ cursor, unsigned long long *__restrict__ gkey,
-                                                             int *__restrict__ gslot)
+                                                             const int *__restrict__ boff, int *__restrict__ cursor,
+                                                             unsigned long long *__restrict__ gkey, int *__restrict__ gslot)
 {
     const int nb = bcount[blockIdx.x];
     if ((int)(threadIdx.x & ~63u) >= nb) return;                       // whole wave beyond the list
@@ -256,7 +312,7 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_scatter(const unsigned long
     int base = 0;
     if (live && leader == lane) base = atomicAdd(cursor + b, size);
     base = __shfl(base, leader);
-    const int pos = live ? start[b] + base + rank : 0;
+    const int pos = live ? vox_start(start, boff, b) + base + rank : 0;
     if (!live) return;
     gkey[pos] = k;
     gslot[pos] = lslot[e];
@@ -268,7 +324,7 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_scatter(const unsigned long
 // blocks beyond the voxel count leave at once.  Every slot is reset as it is read (self-cleaning table).
 __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_rank(VoxTable t, const unsigned long long *__restrict__ gkey,
                                                           const int *__restrict__ gslot, const int *__restrict__ start,
-                                                          float4 *__restrict__ out)
+                                                          const int *__restrict__ boff, float4 *__restrict__ out)
 {
     __shared__ unsigned long long tile[VOX_TILE];
     __shared__ int lo_sh, hi_sh;
@@ -279,7 +335,7 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_rank(VoxTable t, const unsi
     const bool live = e < M;
     const unsigned long long mine = live ? gkey[e] : 0ull;
     const int b = live ? vox_bin(mine) : 0;
-    const int my_lo = live ? start[b] : 0, my_hi = live ? start[b + 1] : 0;
+    const int my_lo = live ? vox_start(start, boff, b) : 0, my_hi = live ? vox_start(start, boff, b + 1) : 0;
     // (dead lanes: mine = 0 is below every key, their count is unused)
     if (threadIdx.x == 0) lo_sh = my_lo;                                   // first entry's slab starts the union
     if (e == min(M, e0 + VOX_BLOCK) - 1) hi_sh = my_hi;                    // last entry's slab ends it

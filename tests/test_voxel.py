@@ -150,6 +150,28 @@ def test_hip_voxel_grid_device_resident(gpu_lib):
     assert np.array_equal(out[:m].cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.gpu
+def test_hip_voxel_grid_device_on_a_caller_stream_is_stream_ordered(gpu_lib):
+    """With a caller's stream the call returns as soon as the count is known (host-mapped, written by the scan kernel);
+    the records are ready in stream order.  Back-to-back calls reuse the table (self-cleaning) while the previous
+    call's tail is still queued."""
+    import torch
+    from slam3d_gx_amd import capi
+    clouds = [_cloud(s, 320, 240) for s in (11, 12, 13)]
+    st = torch.cuda.Stream()
+    with capi.IcpHandle(capi.default_params(clouds[0][0].intr, max_batch=1)) as h:
+        with torch.cuda.stream(st):
+            ds = [torch.from_numpy(c).to("cuda:0", non_blocking=False) for _, c in clouds]
+            outs = [torch.zeros_like(d) for d in ds]
+            ms = [h.voxel_grid_device(d.data_ptr(), d.shape[0], o.data_ptr(), 0.03, st.cuda_stream) for d, o in zip(ds, outs)]
+            got = [o[:m].cpu().numpy() for o, m in zip(outs, ms)]       # queued on the same stream: ordered after the records
+        st.synchronize()
+    for (_, c), m, g in zip(clouds, ms, got):
+        want = O.voxel_grid(c)
+        assert m == want.shape[0]
+        assert np.array_equal(g.view(np.uint32), want.view(np.uint32))
+
+
 # ---- keyframe cloud merge of saveOutput (src/saveOutput.cpp:47-103), row f-3 ---------------------------------
 def _merge_oracle(clouds, poses, leaf=0.03, pass_z=5.0):
     parts = []

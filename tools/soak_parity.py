@@ -32,6 +32,11 @@ for case in range(n_cases):
     elif mode == 3:
         k = rng.random(t4.shape[:2]) < 0.9; t4 = t4.copy(); t4[k] = np.nan
     kw = dict(estimator=est, iterations=iters, max_corr_dist=gate)
+    g = int(rng.integers(0, 6))      # one case in three also runs the optional correspondence gates (spec S4g)
+    if g == 0:
+        kw.update(max_plane_residual2=float(rng.choice([4e-6, 2.5e-5, 1e-4])), min_normal_cos=float(rng.choice([0.0, 0.9, 0.97])))
+    elif g == 1:
+        kw.update(min_normal_cos=float(rng.choice([0.8, 0.94, 0.985])))
     ro = O.icp(s4, t4, O.params(pr.intr, nn_method=0, **kw), T_init=Ti)
     with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1, nn_mode=nn_mode, **kw)) as h:
         rg = h.align(s4, t4, Ti)
@@ -42,7 +47,7 @@ for case in range(n_cases):
           and rg["status"] == ro["status"] and rg["inliers"] == ro["inliers"])
     if not ok:
         bad += 1
-        print("MISMATCH", dict(case=case, W=W, H=H, seed=seed, est=est, iters=iters, gate=gate, mode=int(mode)),
+        print("MISMATCH", dict(case=case, W=W, H=H, seed=seed, est=est, iters=iters, gate=gate, mode=int(mode), kw=kw),
               "idx", int((idx != ro["idx"]).sum()), flush=True)
 print(f"{n_cases} cases, {bad} mismatches, {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)
