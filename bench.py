@@ -572,7 +572,7 @@ def main():
             uid = [capi.comm_unique_id() if rank == 0 else None]
             if world > 1:
                 dist.broadcast_object_list(uid, src=0)
-            comm = capi.Comm(uid[0], rank, world, local_rank)
+            comm = _checked_comm(capi, torch, dist, uid[0], rank, world, local_rank, dev)
 
     if args.mode in ("seg", "voxel"):
         (seg_mode if args.mode == "seg" else voxel_mode)(args, torch, dist, capi, synth, world, rank, local_rank, dev)
@@ -652,12 +652,12 @@ def main():
     gather = None
     if comm is not None:
         gather = comm
-    elif host_comm and world > 1:
+    elif world > 1 and (host_comm or _COMM_FALLBACK[0]):
         from slam3d_gx_amd import shard
 
-        class _HostGather:        # tests only (gloo): same submit/collect contract through torch.distributed on the host
+        class _HostGather:        # gloo (tests), or the RCCL fallback of _checked_comm: same submit/collect contract through torch.distributed
             def __init__(self):
-                self.g = shard.PoseGatherer(world * S, device=None)
+                self.g = shard.PoseGatherer(world * S, device=None if host_comm else dev)
 
             def gather_submit(self, results):
                 self.g.submit(shard.pack_records(results))
@@ -766,6 +766,41 @@ def main():
     if dist.is_initialized():
         dist.destroy_process_group()
     _emit_final()
+
+
+_COMM_FALLBACK = [False]
+
+
+def _checked_comm(capi, torch, dist, uid, rank, world, local_rank, dev, timeout_s=90.0):
+    """The library's own RCCL communicator, created and exercised (one tiny pose gather) in a helper thread with a deadline.
+    This box has one GPU, so the multi-rank form of slam3d_comm_* first runs on the driver's node: if it does not answer in
+    time on ANY rank, every rank falls back to the same exchange through torch.distributed (slam3d_gx_amd/shard.py) instead
+    of hanging the run, and the JSON line says so (`config.pose_exchange`)."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            c = capi.Comm(uid, rank, world, local_rank)
+            r = c.gather([dict(T=np.eye(4) * (rank + 1), norm=float(rank), inliers=rank, status=0, rmse=0.0)])
+            if len(r) == world and all(int(r[k]["inliers"]) == k for k in range(world)):
+                box["comm"] = c
+        except Exception as e:      # noqa: BLE001 -- reported below
+            box["error"] = repr(e)
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    ok = torch.tensor([1 if ("comm" in box and not t.is_alive()) else 0], dtype=torch.int32, device=dev)
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 1:
+        return box["comm"]
+    _COMM_FALLBACK[0] = True
+    if rank == 0:
+        print(f"bench.py: slam3d_comm self-test failed ({box.get('error', 'no answer within %.0f s' % timeout_s)}); "
+              "pose records go through torch.distributed instead", file=sys.stderr)
+    return None
 
 
 def extra_legs(args, torch, dist, capi, synth, local_rank, est, handles, pools, out):
