@@ -40,7 +40,9 @@ class Twin:
                       icp_min_inlier_ratio=0.3, icp_max_rmse=0.05, icp_loop_min_inlier_ratio=0.6, icp_loop_max_rmse=0.02, start_index=1)
         self.c.update(cfg)
         self.h = capi.IcpHandle(capi.default_params(intr, iterations=self.c["icp_iterations"], min_inliers=self.c["icp_min_inliers"],
-                                                    error_threshold=self.c["error_threshold"], max_batch=1))
+                                                    error_threshold=self.c["error_threshold"], max_batch=1,
+                                                    max_plane_residual2=self.c.get("max_plane_residual2", 0.0),
+                                                    min_normal_cos=self.c.get("min_normal_cos", 0.0)))
         self.index = self.c["start_index"]
         self.lost = 0
         self.lc_state = self.c["loopclosure_seed"]

@@ -475,3 +475,41 @@ def test_control_flow_against_python_twin(gpu_lib, tmp_path):
     assert traj.shape[0] == len(tw.traj)
     for row, (idx, T) in zip(traj, tw.traj):
         assert int(row[0]) == idx and np.abs(row[1:4] - T[:3, 3]).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_correspondence_gates_reach_the_device_from_parameters_yaml(gpu_lib, tmp_path):
+    """Rows a8 / a11: `icp_plane_residual_gate: yes` applies the reference's own `min_error_plane` key to the squared
+    point-to-plane residual, `icp_normal_angle_deg` the normal-angle gate; run_SLAM with both == the Python twin over the
+    C-ABI with the same two numbers, and the gated log differs from the ungated one (the gates bite)."""
+    import slam_twin
+    _build_host()
+    step = synth.pose_from_seed(777, max_angle_deg=1.0, max_trans=0.02)
+    poses = [np.eye(4)]
+    for k in range(4):
+        poses.append(step @ poses[-1])
+    intr, data = _sequence(tmp_path, poses)
+    r2, deg = 1e-5, 20.0
+    cfg = dict(max_pos_change=0.005, icp_iterations=15)
+    (tmp_path / "parameters.yaml").write_text(
+        PARAMS.format(src=str(data), mpc=cfg["max_pos_change"], fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=320, h=240, lc="no", planes="no",
+                      pcd="no", extra=f"icp_plane_residual_gate: yes\nmin_error_plane: {r2}\nicp_normal_angle_deg: {deg}\n"))
+    n = len(poses) - 1
+    out = subprocess.run([os.path.join(HOST, "run_SLAM"), str(n)], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    log = [float(x) for x in (tmp_path / "data" / "error_of_transform.log").read_text().split()]
+
+    from PIL import Image
+    depth_of = lambda i: np.array(Image.open(str(data / "dep_index" / f"{i}.png"))).astype(np.uint16)
+    logs = {}
+    for name, extra in (("gated", dict(max_plane_residual2=r2, min_normal_cos=float(np.cos(np.deg2rad(deg))))), ("plain", {})):
+        tw = slam_twin.Twin(intr, depth_of, dict(cfg, **extra))
+        try:
+            for _ in range(n):
+                tw.run()
+        finally:
+            tw.close()
+        logs[name] = [float(x) for x in tw.err_log]
+    assert len(log) == len(logs["gated"]) == n
+    assert all(abs(a - b) <= 1e-5 * max(1.0, abs(b)) for a, b in zip(log, logs["gated"])), (log, logs["gated"])
+    assert any(abs(a - b) > 1e-7 for a, b in zip(logs["gated"], logs["plain"]))
