@@ -154,7 +154,10 @@ int slam3d_icp_set_depth_device(slam3d_icp_handle *h, int32_t slot, const void *
  * src/GraphicEnd.cpp:685-762 all align against the same new keyframe.  Frame ids: slot b's implicit frames are 2b
  * (source) and 2b+1 (target) -- what set_clouds_* / set_depth_* above fill --, ids 2*max_batch .. 2*max_batch +
  * extra_frames - 1 are free for the caller (keyframe store).  All frame uploads and runs of one handle are ordered on
- * the handle's stream (or the stream given to run). */
+ * the handle's stream (or the stream given to run).
+ * A frame set from a DEPTH image is back-projected by the library with the handle's intrinsics; as a target it also
+ * serves the projective window search (same results, fewer candidates).  A frame set from a CLOUD is taken as it is:
+ * no camera model is assumed for it, the tile search alone runs. */
 int slam3d_icp_frame_count(const slam3d_icp_handle *h);
 int slam3d_icp_frame_set_depth_host(slam3d_icp_handle *h, int32_t frame, const uint16_t *depth);      /* H2D + back-projection */
 int slam3d_icp_frame_set_depth_device(slam3d_icp_handle *h, int32_t frame, const void *d_depth);

@@ -27,6 +27,7 @@ struct FrameHost {
     uint64_t src_epoch = 0; int src_row0 = -1, src_row1 = -1;    // source role: built for this epoch and row shard
     uint64_t tgt_epoch = 0; int tgt_normals = -1;                // target role: built for this epoch with/without normals
     uint64_t nrm_epoch = 0;                                      // the frame's normals were computed for this epoch
+    bool from_depth = false;           // the cloud is OUR back-projection of a depth image with the handle's intrinsics
 };
 
 struct slam3d_icp_handle {
@@ -36,7 +37,7 @@ struct slam3d_icp_handle {
     hipStream_t stream = nullptr;
     hipStream_t run_stream = nullptr;
     // ---- frames (device pools, maxF entries each)
-    float4 *f_cloud = nullptr, *f_nrm = nullptr, *f_srcT = nullptr, *f_tgtT = nullptr, *f_tbox = nullptr, *f_cbox = nullptr;
+    float4 *f_cloud = nullptr, *f_nrm = nullptr, *f_srcT = nullptr, *f_tgtT = nullptr, *f_tbox = nullptr, *f_cbox = nullptr, *f_tq = nullptr;
     int *f_scount = nullptr, *f_counts = nullptr;        // [maxF][2][ntiles] per-tile counts of each role; [maxF][4] totals
     std::vector<FrameHost> frames;
     // ---- pairs
@@ -76,6 +77,7 @@ struct slam3d_icp_handle {
     int *hint = nullptr;          // per source tile: target tile where the previous matches were
     int *cost = nullptr;                    // cycles per tile of the last launch: input of k_balance (throughput build)
     int *perm_d = nullptr;                  // its cost-balanced tile->(block,wave) assignment
+    bool proj_search = true;                // SLAM3D_PROJ_SEARCH=0: developer knob, the hierarchical search alone
     int nn_gx = 0, nn_gx_d = 0;             // k_nn_tiles_acc grid widths (multiples of 8): cooperative / throughput build
     float *tgtB = nullptr;        // BRUTE_MFMA: B-layout targets [B][4][npad]
     unsigned int *qmax2 = nullptr; int npad = 0;
@@ -155,7 +157,7 @@ extern "C" const char *slam3d_last_error(const slam3d_icp_handle *h) { return h 
 static void free_all(slam3d_icp_handle *h)
 {
     auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    F(h->f_cloud); F(h->f_nrm); F(h->f_srcT); F(h->f_tgtT); F(h->f_tbox); F(h->f_cbox); F(h->f_scount); F(h->f_counts);
+    F(h->f_cloud); F(h->f_nrm); F(h->f_srcT); F(h->f_tgtT); F(h->f_tbox); F(h->f_cbox); F(h->f_tq); F(h->f_scount); F(h->f_counts);
     F(h->src_c); F(h->tgt_c); F(h->ccounts); F(h->corr); F(h->ticket);
     F(h->flags); F(h->best); F(h->cd2); F(h->acc); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
     F(h->d_pairs); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4); F(h->corr_trace);
@@ -216,6 +218,13 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     g.zmax = (float)p->z_filter;
     g.win_r = p->normal_window / 2; g.min_in = p->normal_min_inliers; g.in_dist = p->normal_inlier_dist;
     g.gate2 = (float)(p->max_corr_dist * p->max_corr_dist);
+    {   // projective window search: the constant of its radius bound, from the image corners' rays
+        const double a0 = fabs((0.0 - p->cx) / p->fx), a1 = fabs(((double)p->width - 1.0 - p->cx) / p->fx);
+        const double b0 = fabs((0.0 - p->cy) / p->fy), b1 = fabs(((double)p->height - 1.0 - p->cy) / p->fy);
+        const double am = a0 > a1 ? a0 : a1, bm = b0 > b1 ? b0 : b1;
+        g.proj_c = (float)((p->fx > p->fy ? p->fx : p->fy) * sqrt(1.0 + am * am + bm * bm) * 1.001);
+        h->proj_search = !(getenv("SLAM3D_PROJ_SEARCH") && atoi(getenv("SLAM3D_PROJ_SEARCH")) == 0);
+    }
     g.resid2 = p->max_plane_residual2 > 0.0f ? p->max_plane_residual2 : 0.0f;
     g.min_ncos = p->min_normal_cos > 0.0f ? p->min_normal_cos : 0.0f;
     g.estimator = p->estimator;
@@ -241,6 +250,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     // frame pools: 16 B cloud + 16 B normals + 16 B source slots + 18 B target records per pixel and frame
     A(dalloc(h->f_cloud, F * h->N)); A(dalloc(h->f_nrm, F * h->N));
     A(dalloc(h->f_srcT, F * tg.ntiles * TILE_SLOTS)); A(dalloc(h->f_tgtT, F * tg.ntiles * TILE_REC));
+    A(dalloc(h->f_tq, F * (size_t)h->N));
     A(dalloc(h->f_tbox, F * tg.ntiles * 2)); A(dalloc(h->f_cbox, F * tg.ncoarse * 2));
     A(dalloc(h->f_scount, F * 2 * tg.ntiles)); A(dalloc(h->f_counts, F * 4));
     if (brute) { A(dalloc(h->src_c, BN)); A(dalloc(h->tgt_c, BN)); A(dalloc(h->best, BS)); }
@@ -318,10 +328,11 @@ static int order_after_foreign_run(slam3d_icp_handle *h)
     return SLAM3D_OK;
 }
 
-static void frame_touch(slam3d_icp_handle *h, int f, const float4 *cloud)
+static void frame_touch(slam3d_icp_handle *h, int f, const float4 *cloud, bool from_depth = false)
 {
     FrameHost &fr = h->frames[f];
     fr.cloud = cloud;
+    fr.from_depth = from_depth;
     fr.epoch += 1;                 // both roles are stale now
 }
 
@@ -383,7 +394,7 @@ extern "C" int slam3d_icp_frame_set_depth_host(slam3d_icp_handle *h, int32_t fra
     HIPCHK(h, hipMemcpyAsync(h->d_depth, depth, sizeof(uint16_t) * h->N, hipMemcpyHostToDevice, h->stream));
     const int rc = backproject_dev(h, h->d_depth, frame_pool_cloud(h, frame));
     if (rc) return rc;
-    frame_touch(h, frame, frame_pool_cloud(h, frame));
+    frame_touch(h, frame, frame_pool_cloud(h, frame), true);
     return SLAM3D_OK;
 }
 
@@ -394,7 +405,7 @@ extern "C" int slam3d_icp_frame_set_depth_device(slam3d_icp_handle *h, int32_t f
     if (order_after_foreign_run(h)) return SLAM3D_E_HIP;
     const int rc = backproject_dev(h, static_cast<const uint16_t *>(d_depth), frame_pool_cloud(h, frame));
     if (rc) return rc;
-    frame_touch(h, frame, frame_pool_cloud(h, frame));
+    frame_touch(h, frame, frame_pool_cloud(h, frame), true);
     return SLAM3D_OK;
 }
 
@@ -474,6 +485,7 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         t.cloud = h->frames[f].cloud;
         t.nrm = h->f_nrm + (size_t)f * h->N;
         t.tiles = role == 0 ? h->f_srcT + (size_t)f * tg.ntiles * TILE_SLOTS : h->f_tgtT + (size_t)f * tg.ntiles * TILE_REC;
+        t.tq = h->f_tq + (size_t)f * h->N;
         t.tbox = h->f_tbox + (size_t)f * tg.ntiles * 2;
         t.cbox = h->f_cbox + (size_t)f * tg.ncoarse * 2;
         t.scount = h->f_scount + ((size_t)f * 2 + role) * tg.ntiles;
@@ -499,6 +511,7 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         pp.src = S.cloud; pp.tgt = T.cloud;
         pp.nrm = h->f_nrm + (size_t)ft * h->N;
         pp.snrm = h->f_nrm + (size_t)fs * h->N;
+        pp.tq = (T.from_depth && h->proj_search) ? h->f_tq + (size_t)ft * h->N : nullptr;
         pp.srcT = h->f_srcT + (size_t)fs * tg.ntiles * TILE_SLOTS;
         pp.tgtT = h->f_tgtT + (size_t)ft * tg.ntiles * TILE_REC;
         pp.tbox = h->f_tbox + (size_t)ft * tg.ntiles * 2;

@@ -37,6 +37,8 @@ struct PairPtrs {                  // per frame-pair device pointers: the reside
     const float4 *tgt;             // organized target cloud
     const float4 *nrm;             // target normals
     const float4 *snrm;            // source frame's normals (only the optional normal-angle gate reads them)
+    const float4 *tq;              // target frame in image order, records (pixel, x, y, z), invalid = (-1, +inf ...): the
+                                   // projective window search; null unless the target cloud is a back-projected depth image
     const float4 *srcT;            // source tile slots   [ntiles * 64]
     const float4 *tgtT;            // target tile records [ntiles * TILE_REC]
     const float4 *tbox;            // target tile boxes   [ntiles * 2]
@@ -58,6 +60,7 @@ struct FrameTask {
     const float4 *cloud;
     float4 *nrm;                   // target role: the frame's normals (read by the tile build when use_normals)
     float4 *tiles;                 // srcT or tgtT of the frame
+    float4 *tq;                    // target role: the frame in image order for the projective window search
     float4 *tbox, *cbox;           // target role only
     int *scount;                   // per-tile valid counts (scratch of the frame), totalled by k_coarse_boxes
     int *counts;                   // the frame's totals: [0] source role, [1] target role
@@ -73,6 +76,8 @@ struct Geometry {
     double in_dist;
     float gate2;
     float resid2, min_ncos;        // optional gates of the point-to-plane estimator (spec S4g), 0 = off
+    float proj_c;                  // projective window search: pixels of radius r around a query's projection cover every target
+                                   // closer than (r + 0.49) * z / proj_c  (= fmax * sqrt(1 + amax^2 + bmax^2) * 1.001), DESIGN.md 5
     int estimator;
     double fx, fy, cx, cy, factor, zf;
 };
@@ -333,6 +338,7 @@ __global__ __launch_bounds__(64) void k_frame_tiles(FrameTasks a, Geometry g, Ti
         if (which == 0) ok = ok && v >= ft.row0 && v < ft.row1;
         else if (ok && ft.use_normals) ok = ft.nrm[pix].w > 0.5f;
         if (ok) q = make_float4(c.x, c.y, c.z, __int_as_float(pix));
+        if (which != 0) ft.tq[pix] = make_float4(q.w, q.x, q.y, q.z);    // image order, invalid = (-1, +inf, +inf, +inf)
     }
     const unsigned long long m = __ballot(ok);
     const int cnt = __popcll(m);
@@ -1030,6 +1036,10 @@ __device__ __forceinline__ int lds_fetch_add_uniform(int *p, int v)
 #ifndef S3D_PROJ_HINT
 #define S3D_PROJ_HINT 1              // first tiles of a wave: where its patch PROJECTS into the target image under the current pose
 #endif                               // (0: where its matches were in the previous iteration, kept in hint[])
+#ifndef S3D_PROJ_SEARCH
+#define S3D_PROJ_SEARCH 1            // lanes whose bound is a few pixels wide find their neighbour in a window around their projection
+#endif
+constexpr int PROJ_RMAX = 3;         // largest window radius the projective search takes on (7x7 pixels)
 #ifndef S3D_DEPTH_SPLIT
 #define S3D_DEPTH_SPLIT 1            // waves on a depth edge class their lanes near / far instead of tight / loose
 #endif
@@ -1240,8 +1250,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    auto park_and_scan = [&]() __attribute__((always_inline)) {
-        park();
+    auto scan_parked = [&]() __attribute__((always_inline)) {
         if constexpr (S3D_LANE_SCAN) {          // one owner for the whole batch: one lane loop over the quadrants of all its tiles
             unsigned int m = 0u;
 #pragma unroll
@@ -1255,6 +1264,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         }
         __builtin_amdgcn_wave_barrier();
     };
+    auto park_and_scan = [&]() __attribute__((always_inline)) { park(); scan_parked(); };
     // The wave-level tests use TWO query boxes: lanes whose bound is already small ("tight", radius below a
     // quarter of the gate) and the rest ("loose": no match yet / far match), so that a few loose lanes do not
     // inflate the search region of the whole wave.
@@ -1390,16 +1400,18 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         const Rt m = load_rt(Tcur + b * 16);
         xform(m, s4.x, s4.y, s4.z, px, py, pz);
         int th = -1;
+        int rox = 0, roy = 0;                                     // origin of the window region of S3D_PROJ_SEARCH
         {
             const unsigned long long mm = __ballot(own_valid);
             const unsigned long long ctr = mm & 0x0000001818000000ull;      // lanes 27,28,35,36
             const int src_lane = __builtin_ctzll(ctr ? ctr : mm);
             const float hx = rdlane(px, src_lane), hy = rdlane(py, src_lane), hz = rdlane(pz, src_lane);
             if (hz > 0.0f) {
-                const float iz = 1.0f / hz;
+                const float iz = __builtin_amdgcn_rcpf(hz);
                 const float uf = (float)g.fx * hx * iz + (float)g.cx, vf = (float)g.fy * hy * iz + (float)g.cy;
                 if (uf > -1.0e6f && uf < 1.0e6f && vf > -1.0e6f && vf < 1.0e6f) {
                     const int pu0 = (int)rintf(uf) - (src_lane & 7), pv0 = (int)rintf(vf) - (src_lane >> 3);   // the patch's top-left pixel
+                    rox = pu0 - 4; roy = pv0 - 4;
                     if (pu0 + 7 >= 0 && pu0 < g.W && pv0 + 7 >= 0 && pv0 < g.H) {
                         const int u0 = max(0, pu0), u1 = min(g.W - 1, pu0 + 7), v0 = max(0, pv0), v1 = min(g.H - 1, pv0 + 7);
                         const int ax0 = u0 / TILE_PX, ay0 = v0 / TILE_PX;
@@ -1461,7 +1473,88 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         }
         if constexpr (DBG) clk1 = clock64();
         hinted = th >= 0;
+#if S3D_PROJ_SEARCH
+        // ---- projective window search.  The target cloud is OUR back-projection of a depth image: the target of pixel
+        // (u, v) is z * (a, b, 1) with a = (u - cx) / fx, b = (v - cy) / fy, up to float rounding.  For a query p' (z' > 0)
+        // that projects to the real pixel (u*, v*), the distance to ANY point of the ray of pixel (u, v) is
+        //     |p' x r| / |r|  >=  z' * sqrt(da^2 + db^2) / sqrt(1 + a^2 + b^2),   da = (u - u*) / fx, db = (v - v*) / fy,
+        // so every target outside the (2r+1)^2 window around the rounded projection is farther than
+        // z' * (r + 0.49) / (fmax * sqrt(K)), K = max of 1 + a^2 + b^2 over the image.  A lane whose current bound U fits a
+        // window of radius <= PROJ_RMAX therefore finds its exact neighbour (ties included: everything outside is strictly
+        // farther, with a 0.1 % + 10 um margin over every rounding) by looking at that window alone: ring by ring, the
+        // radius shrinking with the bound.  Mid-run 3/4 of the lanes and 5/8 of the waves are settled this way with ~22
+        // candidates; settled lanes take no part in the tile search below, and a wave without other lanes skips it.
+        // The windows of a wave's lanes lie in the 15x15-pixel region around the projected patch (8 pixels + 3 on one side, 4
+        // on the other); the region is staged once in the wave's LDS slab (four coalesced loads per lane, one round trip) and
+        // probed from there with lane-specific addresses; a lane whose window leaves the region is simply not settled here.
+        bool done = false;
+        if (pp.tq != nullptr && th >= 0) {
+            const float4 *__restrict__ TQ = pp.tq;
+            constexpr int RW = 15;                                       // region edge; RW * RW float4 fit the stage slab
+            static_assert(RW * RW <= NN_STAGE * STAGE_REC, "the window region must fit the wave's stage slab");
+            bool sane = valid && pz > 0.05f;
+            const float izp = __builtin_amdgcn_rcpf(sane ? pz : 1.0f);      // (1 ulp: the 0.1 % margin of proj_c covers it, and the 0.49 the pixel)
+            const float uf = (float)g.fx * px * izp + (float)g.cx, vf = (float)g.fy * py * izp + (float)g.cy;
+            sane = sane && uf > -1.0e6f && uf < 1.0e6f && vf > -1.0e6f && vf < 1.0e6f;
+            const int ru = (sane ? (int)rintf(uf) : 0) - rox, rv = (sane ? (int)rintf(vf) : 0) - roy;     // region coordinates of the window centre
+            const float kz = g.proj_c * izp;
+            auto radius = [&]() __attribute__((always_inline)) {         // window radius the lane's CURRENT bound needs
+                const float U = __int_as_float((int)(unsigned int)(bkey >> 32));
+                return kz * (__builtin_amdgcn_sqrtf(U) + 1.0e-5f) - 0.49f;
+            };
+            float rn = sane ? radius() : 1.0e9f;
+            int r_l = rn > 0.0f ? (int)ceilf(fminf(rn, 1.0e6f)) : 0;
+            const bool settled = sane && r_l <= PROJ_RMAX && ru - r_l >= 0 && ru + r_l < RW && rv - r_l >= 0 && rv + r_l < RW;
+            // all or nothing: a wave with even one lane left for the tile search pays that search in full anyway (its cost is the
+            // maximum over the lanes), so the window phase only runs where it replaces it
+            if (__ballot(valid && !settled) == 0ull) {
+                if (!settled) r_l = -1;
+#pragma unroll
+                for (int i = 0; i < (RW * RW + 63) / 64; ++i) {
+                    const int idx = lane + 64 * i, ry = idx / RW, rx = idx - ry * RW;
+                    const int u = rox + rx, v = roy + ry;
+                    float4 c4 = make_float4(__int_as_float(-1), inf, inf, inf);
+                    if (idx < RW * RW && u >= 0 && u < g.W && v >= 0 && v < g.H) c4 = TQ[v * g.W + u];
+                    if (idx < RW * RW) st[idx] = c4;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const float4 *__restrict__ wc = st + rv * RW + ru;        // the lane's window centre in the slab
+                auto probe = [&](int dx, int dy, bool on) __attribute__((always_inline)) {
+                    if (on) {
+                        const float4 c4 = wc[dy * RW + dx];
+                        const float d2 = canon_d2(px, py, pz, c4.y, c4.z, c4.w);          // record = (pixel, x, y, z)
+                        const unsigned long long key =
+                            ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(c4.x);
+                        bkey = key_min(bkey, key);
+                    }
+                };
+                probe(0, 0, r_l >= 0);
+                for (int rho = 1; rho <= PROJ_RMAX; ++rho) {
+                    rn = radius();
+                    if (settled) r_l = min(r_l, rn > 0.0f ? (int)ceilf(rn) : 0);
+                    const bool on = r_l >= rho;
+                    if (__ballot(on) == 0ull) break;
+                    if constexpr (DBG) n_cand += 8 * rho;
+#pragma unroll 1
+                    for (int k = 0; k < 2 * rho; ++k) {                  // the four sides of the ring, one pixel of each per trip
+                        probe(-rho + k, -rho, on);
+                        probe(rho, -rho + k, on);
+                        probe(rho - k, rho, on);
+                        probe(-rho, rho - k, on);
+                    }
+                }
+                done = settled;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        park();                      // the staged tile records take the slab over
+        valid = own_valid && !done;
+        if (__ballot(valid) != 0ull) scan_parked();
+#else
         park_and_scan();
+#endif
         hinted = false;
         if constexpr (DBG) clk2 = clock64();
         if constexpr (!COOP) { opx = px; opy = py; opz = pz; }     // (cooperative build: re-read from qpos in step 4 -- three registers less across the drain)
@@ -1496,6 +1589,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             }
         }
         float thr_t, thr_l;
+        if (__ballot(valid) != 0ull) {       // (a wave whose lanes were all settled by the window search has nothing to publish)
         class_boxes_thr(thr_t, thr_l);
         if (COOP && lane < 13) {   // the boxes do not change while the items are drained: helpers read them instead of redoing 12 wave reductions
             const float bx[13] = { qminx, qminy, qminz, qmaxx, qmaxy, qmaxz, lminx, lminy, lminz, lmaxx, lmaxy, lmaxz, any_loose ? 1.0f : 0.0f };
@@ -1546,6 +1640,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                 }
                 qkey[w][lane] = bkey;
             }
+        }
         }
     }
     if constexpr (!COOP) { if (lane == 0) atomicAdd(&wcost[w], (int)(clock64() - cw0)); }

@@ -545,3 +545,33 @@ def test_tiny_frames_and_ownership_map_reuse(gpu_lib, force_throughput_build, mo
                 assert np.array_equal(d2.view(np.uint32), ro["d2"].view(np.uint32)), ctx
                 assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:4], ro["sums_trace"]), ctx
                 assert rg["status"] == ro["status"] and rg["inliers"] == ro["inliers"], ctx
+
+
+@pytest.mark.parametrize("size,estimator,guess", [((640, 480), 0, False), ((640, 480), 1, True), ((200, 150), 0, True), ((104, 72), 0, False)])
+@pytest.mark.parametrize("window_search", ["on", "off"])
+def test_depth_frames_with_and_without_the_projective_window_search(gpu_lib, size, estimator, guess, window_search, monkeypatch):
+    """Frames that enter as depth images are back-projected by the library, so their targets are camera-consistent and the
+    lanes whose bound is a few pixels wide find their neighbour in a window around their projection (DESIGN.md section 5;
+    the bound itself: tests/test_gap_bound.py).  Same bits as the brute-force oracle with the window search on and off
+    (SLAM3D_PROJ_SEARCH=0), per iteration, with holes and with a poor initial guess."""
+    if window_search == "off":
+        monkeypatch.setenv("SLAM3D_PROJ_SEARCH", "0")
+    pr = synth.make_pair(3100 + size[0], *size, holes=True)
+    iters = 6
+    kw = dict(estimator=estimator, iterations=iters)
+    po = O.params(pr.intr, nn_method=0, **kw)
+    s4, t4 = O.backproject(pr.depth_src, po), O.backproject(pr.depth_tgt, po)
+    Ti = synth.pose_from_seed(5, max_angle_deg=2.0, max_trans=0.04) if guess else None
+    ro = O.icp(s4, t4, po, T_init=Ti)
+    with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1, **kw)) as h:
+        h.set_corr_trace(True)
+        rg = h.align_depth_batch([pr.depth_src], [pr.depth_tgt], None if Ti is None else [Ti])[0]
+        idx, d2 = h.get_correspondences(0)
+        Tt, St = h.get_trace(0)
+        mid = h.get_correspondences_at(2, 0)
+    assert np.array_equal(idx, ro["idx"]), int((idx != ro["idx"]).sum())
+    assert np.array_equal(d2.view(np.uint32), ro["d2"].view(np.uint32))
+    assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:iters], ro["sums_trace"])
+    assert rg["inliers"] == ro["inliers"] and rg["status"] == ro["status"]
+    r1 = O.icp(s4, t4, O.params(pr.intr, nn_method=0, **{**kw, "iterations": 1}), T_init=ro["T_trace"][2])
+    assert np.array_equal(mid, r1["idx"])

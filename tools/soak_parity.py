@@ -31,15 +31,25 @@ for case in range(n_cases):
         k = rng.random(s4.shape[:2]) < 0.7; s4 = s4.copy(); s4[k] = np.nan
     elif mode == 3:
         k = rng.random(t4.shape[:2]) < 0.9; t4 = t4.copy(); t4[k] = np.nan
+    # half of the cases enter as DEPTH images (the library back-projects them: the target is then camera-consistent and the
+    # projective window search takes part), the other half as clouds (tile search alone)
+    as_depth = bool(rng.integers(0, 2))
+    if as_depth:
+        ds, dt = pr.depth_src.copy(), pr.depth_tgt.copy()
+        if mode == 2: ds[rng.random(ds.shape) < 0.7] = 0
+        if mode == 3: dt[rng.random(dt.shape) < 0.9] = 0
     kw = dict(estimator=est, iterations=iters, max_corr_dist=gate)
     g = int(rng.integers(0, 6))      # one case in three also runs the optional correspondence gates (spec S4g)
     if g == 0:
         kw.update(max_plane_residual2=float(rng.choice([4e-6, 2.5e-5, 1e-4])), min_normal_cos=float(rng.choice([0.0, 0.9, 0.97])))
     elif g == 1:
         kw.update(min_normal_cos=float(rng.choice([0.8, 0.94, 0.985])))
-    ro = O.icp(s4, t4, O.params(pr.intr, nn_method=0, **kw), T_init=Ti)
+    po = O.params(pr.intr, nn_method=0, **kw)
+    if as_depth:
+        s4, t4 = O.backproject(ds, po), O.backproject(dt, po)
+    ro = O.icp(s4, t4, po, T_init=Ti)
     with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1, nn_mode=nn_mode, **kw)) as h:
-        rg = h.align(s4, t4, Ti)
+        rg = h.align_depth_batch([ds], [dt], None if Ti is None else [Ti])[0] if as_depth else h.align(s4, t4, Ti)
         idx, d2 = h.get_correspondences(0)
         Tt, St = h.get_trace(0)
     ok = (np.array_equal(idx, ro["idx"]) and np.array_equal(d2.view(np.uint32), ro["d2"].view(np.uint32))
@@ -47,7 +57,7 @@ for case in range(n_cases):
           and rg["status"] == ro["status"] and rg["inliers"] == ro["inliers"])
     if not ok:
         bad += 1
-        print("MISMATCH", dict(case=case, W=W, H=H, seed=seed, est=est, iters=iters, gate=gate, mode=int(mode), kw=kw),
+        print("MISMATCH", dict(case=case, W=W, H=H, seed=seed, est=est, iters=iters, gate=gate, mode=int(mode), as_depth=as_depth, kw=kw),
               "idx", int((idx != ro["idx"]).sum()), flush=True)
 print(f"{n_cases} cases, {bad} mismatches, {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)
