@@ -1549,9 +1549,11 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        park();                      // the staged tile records take the slab over
         valid = own_valid && !done;
-        if (__ballot(valid) != 0ull) scan_parked();
+        if (__ballot(valid) != 0ull) {
+            park();                  // the staged tile records take the slab over
+            scan_parked();
+        }
 #else
         park_and_scan();
 #endif
