@@ -126,6 +126,7 @@ void GraphicEndICP::init(const string &param_file)
     _loop_min_inlier_ratio = _reader->GetDouble("icp_loop_min_inlier_ratio", 0.6);
     _loop_max_rmse = _reader->GetDouble("icp_loop_max_rmse", 0.02);
     _plane_gate = _reader->Has("icp_plane_gate") && _reader->GetPara("icp_plane_gate") == "yes";
+    _motion_model = _reader->Has("icp_motion_model") && _reader->GetPara("icp_motion_model") == "yes";
     _plane_match_dist = _reader->GetDouble("icp_plane_match_dist", 0.15);
     // one handle per GPU: hip_devices = N (or "all"), starting at hip_device; resident frame slots beyond the batch
     const int first_dev = _reader->GetInt("hip_device", 0);
@@ -264,7 +265,7 @@ int GraphicEndICP::residentFrame(Device &d, const FRAME &f, unsigned long long p
 }
 
 void GraphicEndICP::alignOnDevice(Device &d, const vector<const FRAME *> &f1, const vector<const FRAME *> &f2, int b0, int b1,
-                                  int minimum_inliers, bool loopclosure, vector<RESULT_OF_MULTIPNP> &out)
+                                  int minimum_inliers, bool loopclosure, vector<RESULT_OF_MULTIPNP> &out, const double *T_init)
 {
     for (int c0 = b0; c0 < b1; c0 += _max_batch) {
         const int nb = min(_max_batch, b1 - c0);
@@ -275,7 +276,7 @@ void GraphicEndICP::alignOnDevice(Device &d, const vector<const FRAME *> &f1, co
             ok = fs >= 0 && ft >= 0 && slam3d_icp_set_pair(d.icp, k, fs, ft) == SLAM3D_OK;
         }
         vector<slam3d_icp_result> res(nb);
-        int rc = ok ? slam3d_icp_run(d.icp, nb, nullptr, nullptr) : SLAM3D_E_STATE;
+        int rc = ok ? slam3d_icp_run(d.icp, nb, T_init ? T_init + (size_t)c0 * 16 : nullptr, nullptr) : SLAM3D_E_STATE;
         if (rc == SLAM3D_OK) rc = slam3d_icp_fetch_results(d.icp, nb, res.data());
         if (rc < 0) {
             cerr << "slam3d_icp (device " << d.device << "): " << slam3d_strerror(rc) << " " << slam3d_last_error(d.icp) << endl;
@@ -301,13 +302,13 @@ void GraphicEndICP::alignOnDevice(Device &d, const vector<const FRAME *> &f1, co
 }
 
 vector<RESULT_OF_MULTIPNP> GraphicEndICP::multiPnPBatch(const vector<const FRAME *> &f1, const vector<const FRAME *> &f2,
-                                                        int minimum_inliers, bool loopclosure)
+                                                        int minimum_inliers, bool loopclosure, const double *T_init)
 {
     const int B = (int)f1.size();
     vector<RESULT_OF_MULTIPNP> out(B);
     const int ndev = (int)min<size_t>(_devs.size(), (size_t)max(B, 1));
     if (ndev <= 1) {
-        alignOnDevice(_devs[0], f1, f2, 0, B, minimum_inliers, loopclosure, out);
+        alignOnDevice(_devs[0], f1, f2, 0, B, minimum_inliers, loopclosure, out, T_init);
     } else {
         // pairs are independent: contiguous blocks per GPU, one host thread each, no exchange but
         // the results (host memory shared by the threads -- the in-process counterpart of the RCCL pose gather)
@@ -315,8 +316,8 @@ vector<RESULT_OF_MULTIPNP> GraphicEndICP::multiPnPBatch(const vector<const FRAME
         for (int k = 0; k < ndev; ++k) {
             int b0 = 0, b1 = 0;
             slam3d_shard_range(B, ndev, k, &b0, &b1);
-            th.emplace_back([this, k, b0, b1, &f1, &f2, minimum_inliers, loopclosure, &out]() {
-                alignOnDevice(_devs[k], f1, f2, b0, b1, minimum_inliers, loopclosure, out);
+            th.emplace_back([this, k, b0, b1, &f1, &f2, minimum_inliers, loopclosure, &out, T_init]() {
+                alignOnDevice(_devs[k], f1, f2, b0, b1, minimum_inliers, loopclosure, out, T_init);
             });
         }
         for (size_t k = 0; k < th.size(); ++k) th[k].join();
@@ -508,9 +509,15 @@ int GraphicEndICP::run()
     cout << "********************" << endl;
     readimage();
     // present -> current keyframe (src/GraphicEnd.cpp:168-170: the result is inverted by the caller)
-    RESULT_OF_MULTIPNP result = multiPnP(_currKF, _present);
+    RESULT_OF_MULTIPNP result;
+    if (_motion_model && _have_guess) {              // start from the previous frame's pose against this keyframe
+        vector<const FRAME *> a(1, &_currKF), b(1, &_present);
+        result = multiPnPBatch(a, b, 12, false, _T_guess)[0];
+    } else
+        result = multiPnP(_currKF, _present);
     double T[16];
     mat4_inverse_rigid(result.T, T);
+    _have_guess = false;                              // only an ordinary tracked frame (last branch) leaves a guess behind
     if (result.isIdentity()) {
         _errorfile << "9999" << endl;                               // :176
         cout << "This frame lost" << endl;
@@ -545,6 +552,8 @@ int GraphicEndICP::run()
         mat4_mul(_kf_pos, T, _robot);
         _lost = 0;
         _last = _present;
+        memcpy(_T_guess, result.T, sizeof _T_guess);
+        _have_guess = true;
     }
     if (_lost > _lost_frames) {                                     // :250-255
         cerr << "the robot lost. Perform lost recovery." << endl;

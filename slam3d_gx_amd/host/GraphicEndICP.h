@@ -69,8 +69,9 @@ class GraphicEndICP {
                                         int minimum_inliers = 12);
     // loop-closure candidates are independent pairs (src/GraphicEnd.cpp:685-762): one batched launch per GPU, the
     // batch dealt over the GPUs in contiguous blocks (slam3d_shard_range), one host thread per GPU
+    // T_init: optional initial guesses, 16 doubles per pair (row-major, X_frame2 = T X_frame1); null = Identity
     std::vector<RESULT_OF_MULTIPNP> multiPnPBatch(const std::vector<const FRAME *> &f1, const std::vector<const FRAME *> &f2,
-                                                  int minimum_inliers = 12, bool loopclosure = false);
+                                                  int minimum_inliers = 12, bool loopclosure = false, const double *T_init = nullptr);
     // plane-association gate (rows a9/a11): the planes of frame1 carried into frame2 by T must meet planes of frame2
     // (GraphicEnd::match on (a,b,c,d), src/GraphicEnd.cpp:459-484); true when the gate is off or a frame has no planes
     virtual bool planeGate(const FRAME &frame1, const FRAME &frame2, const double *T);
@@ -98,7 +99,12 @@ class GraphicEndICP {
     std::vector<Device> _devs;
     int residentFrame(Device &d, const FRAME &f, unsigned long long pin);
     void alignOnDevice(Device &d, const std::vector<const FRAME *> &f1, const std::vector<const FRAME *> &f2, int b0, int b1,
-                       int minimum_inliers, bool loopclosure, std::vector<RESULT_OF_MULTIPNP> &out);
+                       int minimum_inliers, bool loopclosure, std::vector<RESULT_OF_MULTIPNP> &out, const double *T_init);
+    // icp_motion_model: the pose of the previous frame against the SAME keyframe starts the present frame's alignment
+    // (an ICP needs a starting pose where the reference's PnP did not; the first iterations of a run, whose neighbours are
+    // centimetres away, are the expensive ones).  Off by default; reset whenever the keyframe changes.
+    bool _motion_model = false, _have_guess = false;
+    double _T_guess[16];
     double _min_inlier_ratio = 0.3, _max_rmse = 0.05;             // tracking gates (icp_min_inlier_ratio, icp_max_rmse)
     double _loop_min_inlier_ratio = 0.6, _loop_max_rmse = 0.02;   // loop-closure gates (icp_loop_min_inlier_ratio, icp_loop_max_rmse)
     bool _plane_gate = false; double _plane_match_dist = 0.15;    // icp_plane_gate, icp_plane_match_dist

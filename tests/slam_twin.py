@@ -64,9 +64,9 @@ class Twin:
         self.h.close()
 
     # ---- multiPnP with the gates of GraphicEndICP::alignOnDevice
-    def multi_pnp(self, f1, f2, loop=False, min_inliers=None):
+    def multi_pnp(self, f1, f2, loop=False, min_inliers=None, T_init=None):
         min_inliers = self.c["icp_min_inliers"] if min_inliers is None else min_inliers
-        r = self.h.align_depth_batch([self.depth_of(f1)], [self.depth_of(f2)])[0]
+        r = self.h.align_depth_batch([self.depth_of(f1)], [self.depth_of(f2)], None if T_init is None else [T_init])[0]
         ratio = self.c["icp_loop_min_inlier_ratio"] if loop else self.c["icp_min_inlier_ratio"]
         rmse = self.c["icp_loop_max_rmse"] if loop else self.c["icp_max_rmse"]
         good = r["status"] == 0 and r["inliers"] >= min_inliers
@@ -125,7 +125,9 @@ class Twin:
 
     def run(self):
         self.present = self.index
-        res = self.multi_pnp(self.cur["frame_index"], self.present)
+        guess = getattr(self, "guess", None) if self.c.get("icp_motion_model") else None      # GraphicEndICP::_T_guess
+        res = self.multi_pnp(self.cur["frame_index"], self.present, T_init=guess)
+        self.guess = None
         T = inv_rigid(res["T"])
         if res["identity"]:
             self.err_log.append("9999")
@@ -152,6 +154,7 @@ class Twin:
             self.robot = self.kf_pos @ T
             self.lost = 0
             self.last = self.present
+            self.guess = res["T"]          # an ordinary tracked frame leaves its pose as the next frame's starting guess
         if self.lost > self.c["lost_frames"]:
             self.lost_recovery()
             self.last = self.present

@@ -513,3 +513,41 @@ def test_correspondence_gates_reach_the_device_from_parameters_yaml(gpu_lib, tmp
     assert len(log) == len(logs["gated"]) == n
     assert all(abs(a - b) <= 1e-5 * max(1.0, abs(b)) for a, b in zip(log, logs["gated"])), (log, logs["gated"])
     assert any(abs(a - b) > 1e-7 for a, b in zip(logs["gated"], logs["plain"]))
+
+
+@pytest.mark.gpu
+def test_motion_model_initial_guess_matches_the_twin_and_tracks(gpu_lib, tmp_path):
+    """`icp_motion_model: yes`: the previous frame's pose against the same keyframe starts the present frame's alignment
+    (reset at every keyframe change).  run_SLAM == the Python twin with the same rule, and the trajectory still follows
+    the ground truth."""
+    import slam_twin
+    _build_host()
+    step = synth.pose_from_seed(91, max_angle_deg=0.8, max_trans=0.015)
+    poses = [np.eye(4)]
+    for k in range(7):
+        poses.append(step @ poses[-1])
+    intr, data = _sequence(tmp_path, poses)
+    cfg = dict(max_pos_change=0.06, icp_iterations=15, icp_motion_model=True)       # a keyframe every few frames
+    (tmp_path / "parameters.yaml").write_text(
+        PARAMS.format(src=str(data), mpc=cfg["max_pos_change"], fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=320, h=240, lc="no", planes="no",
+                      pcd="no", extra="icp_motion_model: yes\n"))
+    n = len(poses) - 1
+    out = subprocess.run([os.path.join(HOST, "run_SLAM"), str(n)], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    log = [float(x) for x in (tmp_path / "data" / "error_of_transform.log").read_text().split()]
+    from PIL import Image
+    depth_of = lambda i: np.array(Image.open(str(data / "dep_index" / f"{i}.png"))).astype(np.uint16)
+    tw = slam_twin.Twin(intr, depth_of, cfg)
+    try:
+        for _ in range(n):
+            tw.run()
+    finally:
+        tw.close()
+    assert len(log) == len(tw.err_log) == n
+    assert all(abs(a - float(b)) <= 1e-5 * max(1.0, abs(float(b))) for a, b in zip(log, tw.err_log)), (log, tw.err_log)
+    kf = np.loadtxt(str(tmp_path / "data" / "keyframe.txt"), dtype=int).reshape(-1, 2)
+    assert kf.tolist() == [[k["id"], k["frame_index"]] for k in tw.keyframes] and 2 <= len(kf) < n
+    traj = np.loadtxt(str(tmp_path / "data" / "trajectory_icp.txt"))
+    # the camera's pose in frame-0 coordinates is the inverse of the scene motion the sequence was rendered with
+    for row, P in zip(traj[1:], poses[1:]):
+        assert np.abs(row[1:4] - np.linalg.inv(P)[:3, 3]).max() < 5e-3
