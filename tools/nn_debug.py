@@ -14,7 +14,7 @@ pr = synth.make_pair(seed)
 s4 = synth.backproject_numpy(pr.depth_src, pr.intr); t4 = synth.backproject_numpy(pr.depth_tgt, pr.intr)
 for it in (1, iters):
     with capi.IcpHandle(capi.default_params(pr.intr, iterations=it)) as h:
-        h.align(s4, t4)
+        h.align_depth_batch([pr.depth_src], [pr.depth_tgt])      # depth inputs: the projective window search takes part
         d = h.get_nn_debug()
     act = d[:, 4] > 0
     d = d[act].copy()
