@@ -74,7 +74,6 @@ struct slam3d_icp_handle {
     TileGrid tg;
     float4 *prevq = nullptr;
     long long *dbg = nullptr;     // per-tile NN statistics, only with SLAM3D_NN_DEBUG=1
-    int *hint = nullptr;          // per source tile: target tile where the previous matches were
     int *cost = nullptr;                    // cycles per tile of the last launch: input of k_balance (throughput build)
     int *perm_d = nullptr;                  // its cost-balanced tile->(block,wave) assignment
     bool proj_search = true;                // SLAM3D_PROJ_SEARCH=0: developer knob, the hierarchical search alone
@@ -161,7 +160,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->src_c); F(h->tgt_c); F(h->ccounts); F(h->corr); F(h->ticket);
     F(h->flags); F(h->best); F(h->cd2); F(h->acc); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
     F(h->d_pairs); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4); F(h->corr_trace);
-    F(h->dbg); F(h->prevq); F(h->hint); F(h->perm_d); F(h->cost); F(h->tgtB); F(h->qmax2);
+    F(h->dbg); F(h->prevq); F(h->perm_d); F(h->cost); F(h->tgtB); F(h->qmax2);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->pin_res) (void)hipHostFree(h->pin_res);
     if (h->pin_seg) (void)hipHostFree(h->pin_seg);
@@ -261,7 +260,6 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     A(dalloc(h->ccounts, (size_t)h->maxB * 4)); A(dalloc(h->ticket, (size_t)h->maxB));
     A(dalloc(h->corr, BS)); A(dalloc(h->flags, (size_t)h->maxB)); A(dalloc(h->cd2, BS)); A(dalloc(h->prevq, BS));
     A(dalloc(h->acc, (size_t)h->maxB * ACC_R * ACC_STRIDE));
-    A(dalloc(h->hint, (size_t)h->maxB * tg.ntiles));
     A(dalloc(h->cost, (size_t)h->maxB * tg.ntiles));
     {   // grid widths of the NN kernel, multiples of 8.  Cooperative build: as many waves as tiles -- with the row ownership every
         // XCD's list is then exactly full (640x480: 1,200 blocks of four tiles).  More, smaller-loaded blocks (20 % slack: 1,440)
@@ -309,7 +307,6 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     h->h_pairs.assign(h->maxB, PairPtrs{}); h->up_pairs.assign(h->maxB, PairPtrs{});
     (void)hipMemsetAsync(h->f_counts, 0, sizeof(int) * 4 * F, h->stream);
     (void)hipMemsetAsync(h->perm_d, 0xFF, sizeof(int) * (size_t)h->maxB * h->nn_gx_d * NN_WAVES, h->stream);
-    (void)hipMemsetAsync(h->hint, 0xFF, sizeof(int) * (size_t)h->maxB * tg.ntiles, h->stream);
     (void)hipMemsetAsync(h->acc, 0, sizeof(long long) * (size_t)h->maxB * ACC_R * ACC_STRIDE, h->stream);   // k_solve_acc re-zeroes after every launch
     *out = h;
     return SLAM3D_OK;
@@ -592,7 +589,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         const int gx = dense ? h->nn_gx_d : h->nn_gx;
         // four instances: {throughput, cooperative} x {production, instrumented (SLAM3D_NN_DEBUG: per-tile clocks and counters)}
         auto launch = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_pairs, h->Tcur, h->corr, h->cd2, h->prevq, h->hint,
+            hipLaunchKernelGGL(kern, dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_pairs, h->Tcur, h->corr, h->cd2, h->prevq,
                                perm, h->cost, h->acc, h->g, tg, h->dbg, write_out, first);
         };
         // (+ two with the optional S4g gates compiled in: the production instances carry none of that code)

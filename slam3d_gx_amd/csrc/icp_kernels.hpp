@@ -31,7 +31,7 @@ constexpr int NN_BLOCK = 256;
 // normals, tile records and boxes, as a *source* the tile-major slots.  They are built once per frame (and role), not
 // once per pair: the 32 loop-closure candidates of src/GraphicEnd.cpp:685-762 share one target frame, and the
 // keyframe of GraphicEnd::run (src/GraphicEnd.cpp:168) stays the source of many consecutive pairs.
-// A PAIR is two frame references plus its own iteration state (T, accumulators, prevq / hint / ownership map).
+// A PAIR is two frame references plus its own iteration state (T, accumulators, prevq, ownership map).
 struct PairPtrs {                  // per frame-pair device pointers: the resident products of its two frames
     const float4 *src;             // organized source cloud (only the brute-force compaction reads it)
     const float4 *tgt;             // organized target cloud
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(64) void k_coarse_boxes(FrameTasks a, TileGrid tg)
 }
 
 // start of a run for the pairs [b0, b0 + n): T = T_init (kernel argument) or Identity, trace row 0, flags, clean
-// accumulators.  grid (n), block 64.  (prevq / hint / corr need no reset: the first iteration ignores them.)
+// accumulators.  grid (n), block 64.  (prevq / corr need no reset: the first iteration ignores them.)
 constexpr int TINIT_ARGS = 16;
 struct TinitArgs { double T[TINIT_ARGS][16]; };
 __global__ __launch_bounds__(64) void k_pair_init(TinitArgs ti, int has_T, int b0, double *__restrict__ Tcur,
@@ -1022,58 +1022,41 @@ __device__ __forceinline__ int lds_fetch_add_uniform(int *p, int v)
     return __builtin_amdgcn_readfirstlane(old);
 }
 
-// Two builds of the kernel, three staged tile records per wave in both.  <3, 8 waves per SIMD, cooperative>: the four
-// waves of a block share their work items (20,440 B of LDS per block -- eight blocks fit the 160 KB of a CU --, 62 VGPRs); the faster one while a launch holds few
-// pairs (latency bound: the slowest block ends the launch).  <3, 8, not cooperative>: every wave sweeps its own cells
-// -- no shared lists, no block barriers, 14 KB of LDS, 55 VGPRs -- at the full 8 waves per SIMD; it wins when many
-// pairs fill the chip (throughput bound: 64 pairs 44 k -> 55 k it/s).
-#ifndef S3D_OWNERSHIP_ROWS
-#define S3D_OWNERSHIP_ROWS 1         // cooperative build: XCD x owns the tile rows r = x (mod 8) (0: tile c + w * G, no locality)
-#endif
-#ifndef S3D_OWN_HOME_CELL
-#define S3D_OWN_HOME_CELL 0          // the owner refines its (prefetched) home cell itself instead of listing it
-#endif
-#ifndef S3D_PROJ_HINT
-#define S3D_PROJ_HINT 1              // first tiles of a wave: where its patch PROJECTS into the target image under the current pose
-#endif                               // (0: where its matches were in the previous iteration, kept in hint[])
-#ifndef S3D_PROJ_SEARCH
-#define S3D_PROJ_SEARCH 1            // lanes whose bound is a few pixels wide find their neighbour in a window around their projection
-#endif
+// Two builds of the kernel, three staged tile records per wave in both.  <3, 7 waves per SIMD, cooperative>: the four
+// waves of a block share their work items (22 KB of LDS per block -- seven blocks fit the 160 KB of a CU --, 72 VGPRs);
+// the faster one while a launch holds few pairs (latency bound: the slowest block ends the launch).  <3, 8, not
+// cooperative>: every wave sweeps its own cells -- no shared lists, no block barriers, 14 KB of LDS, 49 VGPRs -- at the
+// full 8 waves per SIMD; it wins when many pairs fill the chip (throughput bound; from 8 pairs per launch on).
 constexpr int PROJ_RMAX = 3;         // largest window radius the projective search takes on (7x7 pixels)
-#ifndef S3D_DEPTH_SPLIT
-#define S3D_DEPTH_SPLIT 1            // waves on a depth edge class their lanes near / far instead of tight / loose
-#endif
-#ifndef S3D_LANE_SCAN
-#define S3D_LANE_SCAN 1              // every lane scans only the quadrants ITS ball reaches (0: the wave scans their union)
-#endif
-constexpr int QSTRIDE = S3D_LANE_SCAN ? 17 : 16;   // float4 per staged quadrant: 16 candidates (+ 1 pad: lane-specific reads of
-                                                   // different quadrants then fall into different banks)
+constexpr int QSTRIDE = 17;                        // float4 per staged quadrant: 16 candidates + 1 pad: lane-specific reads of
+                                                   // different quadrants then fall into different banks
 constexpr int STAGE_REC = 4 * QSTRIDE + 8;         // LDS image of a tile record (TILE_REC in global memory)
 constexpr int NN_MAX_ITEMS = 128;    // (owner wave, coarse cell) work items shared by the waves of a block
 constexpr int NN_MAX_TITEMS = 384;   // (owner wave, target tile) work items: the tiles the cell sweeps found worth scanning
 constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (8 measured slower: 2 blocks per CU)
 
-// grid (G, B), block 256 = 4 waves; G = a multiple of 8 >= ntiles/4.  Wave w of block c OWNS one source tile: tile
-// c + w * G (interleaved: every block owns tiles of four image bands); in the throughput build perm[b][c][w] once
-// k_balance has run (cost-balanced).
-//   1. every wave: one round of loads, upper bounds, exhaustive scan of the 5 tiles around its hint tile;
+// grid (G, B), block 256 = 4 waves; G = a multiple of 8 >= ntiles/4.  Wave w of block c OWNS one source tile: in the
+// cooperative build entry (c >> 3) + w * G/8 of the tile rows of XCD c & 7 (rows r = x mod 8), in the throughput build
+// tile c + w * G, then perm[b][c][w] once k_balance has run (cost-balanced).
+//   1. every wave: one round of loads, upper bounds; projective window search where every lane of the wave is settled by
+//      it (depth-image targets), else scan of the tiles its patch projects onto;
 //   2. every wave publishes its queries (point, running key, tight/loose class) in LDS and appends one work
 //      item per coarse cell its two query boxes can reach;                                   -- barrier --
 //   3. all four waves drain the item list together: an item = sweep one coarse cell for one owner (child
 //      boxes -> ballot -> per-lane re-test -> stage tiles in this wave's LDS slab -> scan the needed
 //      quadrants), merged into the owner's keys with ds_min_u64;                             -- barrier --
-//   4. every wave finishes its own tile: gate, row products, level-1 reduction, hint for the next iteration.
+//   4. every wave finishes its own tile: gate, row products, level-1 reduction.
 // The result is independent of which wave processes which item (keys are merged by an exact minimum).
 template <int NN_STAGE, int WPE, bool COOP, bool DBG, bool GATED = false>
 __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_nn_tiles_acc(const PairPtrs *__restrict__ pairs,
                                                         const double *__restrict__ Tcur,
                                                         int *__restrict__ corr, float *__restrict__ cd2,
-                                                        float4 *__restrict__ prevq, int *__restrict__ hint,
+                                                        float4 *__restrict__ prevq,
                                                         const int *__restrict__ perm, int *__restrict__ cost,
                                                         long long *__restrict__ acc, Geometry g, TileGrid tg,
                                                         long long *__restrict__ dbg /* DBG builds only: 20 x int64 per tile */,
                                                         int write_out /* corr / cd2 wanted (last iteration) */,
-                                                        int first /* a run's first iteration: no previous match, no hint */)
+                                                        int first /* a run's first iteration: no previous match */)
 {
     __shared__ float4 stage_all[NN_WAVES][NN_STAGE * STAGE_REC];
     __shared__ int wcost[NN_WAVES];                                    // cycles spent for each owner (all helpers)
@@ -1102,7 +1085,6 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     // default (-1, a handle's first two iterations): interleaved, tile c + w * G -- no locality, but even over the XCDs
     // whatever part of the frame holds the work (row shards of the dense mode)
     int t = pt == -1 ? c + w * (int)gridDim.x : (pt < 0 ? tg.ntiles : pt);
-#if S3D_OWNERSHIP_ROWS
     if constexpr (COOP) {
         // XCD-local AND balanced without a map: workgroup c runs on XCD c % 8 (observed; only speed depends on it), and XCD x
         // owns the tile ROWS r = x (mod 8) -- a uniform sample of the whole frame (depth edges, the row shard of the dense
@@ -1121,7 +1103,6 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             t = (j < chunk && idx < n_rem) ? full_rows * tg.ntx + idx : tg.ntiles;
         }
     }
-#endif
     const bool has_tile = t < tg.ntiles;
     const long long cw0 = COOP ? 0 : clock64();         // per-tile cost: input of k_balance (throughput build only)
     float4 *__restrict__ st = stage_all[w];
@@ -1202,33 +1183,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             }
         }
     };
-    // scan staged tile k (tile id tile, both wave-uniform): tile box first, then its four 4x4-pixel quadrants,
-    // each only if some lane can still improve/tie inside that box
-    auto scan_staged = [&](int k, int tile) __attribute__((always_inline)) {
-        if constexpr (S3D_LANE_SCAN) { scan_lanes(quad_mask(k, tile)); return; }
-        const float thr = lane_thr();          // once per tile: the quadrant tests below may use this (larger) value
-        if (!hinted && __ballot(lane_gap_le(TB[2 * tile], TB[2 * tile + 1], thr)) == 0ull) return;     // uniform -> scalar loads
-        if constexpr (DBG) n_scanned += 1;
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const float4 lo = st[k * STAGE_REC + 4 * QSTRIDE + 2 * qd], hi = st[k * STAGE_REC + 4 * QSTRIDE + 2 * qd + 1];
-            const int cnt = __builtin_amdgcn_readfirstlane(__float_as_int(lo.w));
-            if (cnt == 0 || __ballot(lane_gap_le(lo, hi, thr)) == 0ull) continue;
-            if constexpr (DBG) n_cand += cnt;
-            const float4 *__restrict__ cand = st + k * STAGE_REC + qd * QSTRIDE;
-            // four candidates per trip; the padding slots of a quadrant hold (+inf, +inf, +inf): d2 = +inf never wins
-            for (int i = 0; i < cnt; i += 4) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float4 q = cand[i + u];                            // same address in every lane: LDS broadcast
-                    const float d2 = canon_d2(px, py, pz, q.y, q.z, q.w);     // record = (pixel, x, y, z)
-                    const unsigned long long key =
-                        ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(q.x);
-                    bkey = key_min(bkey, key);
-                }
-            }
-        }
-    };
+    // scan staged tile k (tile id tile, both wave-uniform): tile box first, then every lane the quadrants it reaches
+    auto scan_staged = [&](int k, int tile) __attribute__((always_inline)) { scan_lanes(quad_mask(k, tile)); };
     auto fetch_batch = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NN_STAGE; ++k)
@@ -1251,17 +1207,11 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
     auto scan_parked = [&]() __attribute__((always_inline)) {
-        if constexpr (S3D_LANE_SCAN) {          // one owner for the whole batch: one lane loop over the quadrants of all its tiles
-            unsigned int m = 0u;
+        unsigned int m = 0u;                    // one owner for the whole batch: one lane loop over the quadrants of all its tiles
 #pragma unroll
-            for (int k = 0; k < NN_STAGE; ++k)
-                if (tt[k] >= 0) m |= quad_mask(k, tt[k]);
-            scan_lanes(m);
-        } else {
-#pragma unroll
-            for (int k = 0; k < NN_STAGE; ++k)
-                if (tt[k] >= 0) scan_staged(k, tt[k]);
-        }
+        for (int k = 0; k < NN_STAGE; ++k)
+            if (tt[k] >= 0) m |= quad_mask(k, tt[k]);
+        scan_lanes(m);
         __builtin_amdgcn_wave_barrier();
     };
     auto park_and_scan = [&]() __attribute__((always_inline)) { park(); scan_parked(); };
@@ -1380,19 +1330,14 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
 
     // ================= step 1: own tile =================
     int own_jprev = -2;                               // what prevq holds for this lane's slot (-2: nothing known, always write)
-    int hc = -1, hctx = 0, hcty = 0;                  // cooperative build: the prefetched "home" coarse cell and its child boxes
-    float4 hlo = make_float4(inf, inf, inf, 0), hhi = make_float4(-inf, -inf, -inf, 0);
     const float4 s4 = has_tile ? pp.srcT[(size_t)t * TILE_SLOTS + lane] : make_float4(0, 0, 0, __int_as_float(-1));
     const int pix = __float_as_int(s4.w);
     const bool own_valid = pix >= 0;
     float opx = 0.0f, opy = 0.0f, opz = 0.0f;
     if (__ballot(own_valid) != 0ull) {
-        // centre of the first scan: where this tile's matches were in the previous iteration (a hint only --
-        // exactness never depends on it); initially the same image location
-        // hint = the (up to 2x2) block of target tiles that the 8x8 source patch covered in the previous iteration
-        // (top-left tile | extends in x << 24 | extends in y << 25); without one: the same image location and its
-        // four edge neighbours
-#if S3D_PROJ_HINT
+        // first tiles (a hint only -- exactness never depends on it): th = top-left tile | extends in x << 24 | extends in y << 25
+        // of the (up to 2x2) block of target tiles the 8x8 source patch lands on; without one: the same image location and its
+        // left / right neighbours
         // Both clouds are organized depth images of one camera, so the source patch under the current pose lands where its
         // points project: the pinhole of the frame geometry gives the target pixel of a lane near the patch centre, and the
         // (up to 2x2) block of tiles the 8x8 patch covers around it.  Unlike last iteration's matches this follows the pose:
@@ -1420,9 +1365,6 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                 }
             }
         }
-#else
-        const int th = first ? -1 : __builtin_amdgcn_readfirstlane(hint[(size_t)b * tg.ntiles + t]);
-#endif
         if (th >= 0 && (th & 0xffffff) < tg.ntiles) {
             const int base = th & 0xffffff, fx = (th >> 24) & 1, fy = (th >> 25) & 1;
             tt[0] = base;
@@ -1441,12 +1383,6 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
 #pragma unroll
         for (int k = 0; k < NN_STAGE; ++k) ta[k] = tt[k];
         fetch_batch();                                             // one round of independent loads ...
-        if constexpr (COOP && S3D_OWN_HOME_CELL) {   // ... including the child boxes of the coarse cell around the first tile: nearly every wave sweeps it
-            const int t0 = tt[0] >= 0 ? tt[0] : t;
-            const int ty0 = t0 / tg.ntx, tx0 = t0 - ty0 * tg.ntx;
-            hc = (ty0 / COARSE_TILES) * tg.ncx + tx0 / COARSE_TILES;
-            cell_boxes(hc, hlo, hhi, hctx, hcty);
-        }
         float4 pq = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
         if (!first) pq = prevq[gs];                                // (a run's first iteration: whatever an earlier run left there is ignored)
         float4 qs = make_float4(0, 0, 0, 0);
@@ -1455,10 +1391,6 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             const int ug = (t % tg.ntx) * TILE_PX + (lane & 7), vg = (t / tg.ntx) * TILE_PX + (lane >> 3);
             if (ug < g.W && vg < g.H) { qs = tcloud[vg * g.W + ug]; if (g.estimator == 0) ws = tnrm[vg * g.W + ug].w; }
         }
-#if !S3D_PROJ_HINT
-        const Rt m = load_rt(Tcur + b * 16);
-        xform(m, s4.x, s4.y, s4.z, px, py, pz);
-#endif
         valid = own_valid;
         if (!first) own_jprev = __float_as_int(pq.w);
         // ---- upper bound: previous match, else the target at the same pixel, else the gate
@@ -1473,7 +1405,6 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         }
         if constexpr (DBG) clk1 = clock64();
         hinted = th >= 0;
-#if S3D_PROJ_SEARCH
         // ---- projective window search.  The target cloud is OUR back-projection of a depth image: the target of pixel
         // (u, v) is z * (a, b, 1) with a = (u - cx) / fx, b = (v - cy) / fy, up to float rounding.  For a query p' (z' > 0)
         // that projects to the real pixel (u*, v*), the distance to ANY point of the ray of pixel (u, v) is
@@ -1554,16 +1485,12 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             park();                  // the staged tile records take the slab over
             scan_parked();
         }
-#else
-        park_and_scan();
-#endif
         hinted = false;
         if constexpr (DBG) clk2 = clock64();
         if constexpr (!COOP) { opx = px; opy = py; opz = pz; }     // (cooperative build: re-read from qpos in step 4 -- three registers less across the drain)
         // ---- step 2: publish the queries and one work item per reachable coarse cell
         const float bnd0 = __int_as_float((int)(unsigned int)(bkey >> 32));
         tight = valid && bnd0 <= 0.0625f * g.gate2; loose = valid && !tight;
-#if S3D_DEPTH_SPLIT
         {   // A tile that straddles a depth edge holds foreground AND background points: one box around them spans the whole
             // depth range and meets every target tile in between, none of which any lane's ball reaches (bench pair: the
             // heaviest 3 % of the tiles hit 52 target tiles with tight/loose boxes, 15 with near/far boxes, 12 are needed).
@@ -1575,7 +1502,6 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                 tight = valid && pz <= zmid; loose = valid && !tight;
             }
         }
-#endif
         if constexpr (COOP) {
             qpos[w][0][lane] = px; qpos[w][1][lane] = py; qpos[w][2][lane] = pz;
             {
@@ -1614,16 +1540,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                 }
                 continue;
             }
-            // The owner refines its home cell itself, right now: its context is in registers and the child boxes were
-            // prefetched with the first round of loads (a wave sweeps 1.2 cells on average and the home cell is nearly
-            // always one of them, so for most blocks nothing is left for the shared cell list: no phase A).
-            unsigned long long rest0 = cm;
-            if (S3D_OWN_HOME_CELL && hc >= c0 && hc < c0 + 64 && ((cm >> (hc - c0)) & 1ull)) {          // the home cell: no load to wait for
-                rest0 &= ~(1ull << (hc - c0));
-                if constexpr (DBG) n_my_items += 1;
-                if (append_tiles(w, cell_refine(hlo, hhi, hctx, hcty), hctx, hcty)) qkey[w][lane] = bkey;
-            }
-            const unsigned long long cml = rest0;                                  // what is left goes to the shared cell list
+            const unsigned long long cml = cm;                                     // the reachable cells go to the block's shared cell list
             const int cnt = __popcll(cml);
             const int base = cnt ? lds_fetch_add_uniform(&n_items, cnt) : 0;       // cnt is wave-uniform
             if ((cml >> lane) & 1ull) {
@@ -1759,26 +1676,6 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         finish_slot<false>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs_ep, cd2 + gs_ep, prevq + gs_ep, rb,
                            write_out != 0, own_jprev);
     tile_accumulate(g.estimator, rb, acc + ((size_t)b * ACC_R + (c % ACC_R)) * ACC_STRIDE);
-#if !S3D_PROJ_HINT
-    {   // hint for the next iteration: the tile holding the match of a lane near the tile centre
-        const bool ok = rb.v[7] != 0.0;
-        const unsigned long long mm = __ballot(ok);
-        if (!mm && first && lane == 0) hint[(size_t)b * tg.ntiles + t] = -1;       // no stale hint from an earlier run
-        if (mm) {
-            const unsigned long long ctr = mm & 0x0000001818000000ull;      // lanes 27,28,35,36
-            const int src_lane = __builtin_ctzll(ctr ? ctr : mm);
-            const int jm = __builtin_amdgcn_readlane((int)(unsigned int)(bkey & 0xffffffffull), src_lane);
-            if (lane == 0) {
-                // the 8x8 patch seen from that lane's match: pixels [um - lx, um - lx + 7] x [vm - ly, vm - ly + 7]
-                const int vm = g.W == 1 ? jm : (int)__umulhi((unsigned int)jm, tg.mag_W), um = jm - vm * g.W;
-                const int u0 = max(0, um - (src_lane & 7)), u1 = min(g.W - 1, um - (src_lane & 7) + 7);
-                const int v0 = max(0, vm - (src_lane >> 3)), v1 = min(g.H - 1, vm - (src_lane >> 3) + 7);
-                const int ax0 = u0 / TILE_PX, ay0 = v0 / TILE_PX;
-                hint[(size_t)b * tg.ntiles + t] = (ay0 * tg.ntx + ax0) | ((u1 / TILE_PX > ax0) << 24) | ((v1 / TILE_PX > ay0) << 25);
-            }
-        }
-    }
-#endif
     if (DBG && dbg && b == 0 && lane == 0) {
         long long *d = dbg + (size_t)t * 20;
         d[0] = clk0; d[1] = clk1; d[2] = clk2; d[3] = clk3; d[4] = clock64();
