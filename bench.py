@@ -69,7 +69,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=1, help="frame pairs per launch sequence and GPU (config 3: 64)")
-    ap.add_argument("--pairs-per-step", type=int, default=320, help="frame pairs one step processes per GPU (S / --pairs alignments)")
+    ap.add_argument("--pairs-per-step", type=int, default=480, help="frame pairs one step processes per GPU (S / --pairs alignments)")
     ap.add_argument("--pool", type=int, default=16, help="distinct seeded pairs per in-flight handle that the stream cycles through")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
@@ -80,6 +80,9 @@ def parse_args():
                     help="seg: row f-2, batched RANSAC plane segmentation of --pairs frames per GPU; "
                          "voxel: row f-1, PassThrough + VoxelGrid(0.03) of one resident cloud per step")
     ap.add_argument("--noise-sigma", type=float, default=0.0002, help="depth noise sigma/z^2 of the synthetic frames (survey: 0.0012)")
+    ap.add_argument("--hole-block", type=int, default=32, help="edge of the invalid-pixel blocks at 640x480 (survey: 8)")
+    ap.add_argument("--hole-prob", type=float, default=0.2, help="probability of an invalid block (survey: 0.25)")
+    ap.add_argument("--overlap-aligns", type=int, default=256, help="alignments of the stamped pass that measures how many NN launches are resident at once")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bruteforce", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the config-3 / config-5 / survey-noise / resident legs")
@@ -114,17 +117,21 @@ def kernel_src_sha16():
 
 def committed_traffic(tag):
     """HBM bytes per launch of the dominant kernel from the committed PMC profile of THIS kernel source (the profile
-    records the SHA-256 of icp_kernels.hpp it was taken on; a stale profile yields null, never a stale number)."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        e = d[tag]
-        if d.get("kernel_src_sha16") != kernel_src_sha16():
-            return None, os.path.relpath(path, ROOT) + " (stale: kernel source changed since the PMC pass)", {}
-        return e["hbm_bytes_per_launch"], os.path.relpath(path, ROOT), e
-    except Exception:
-        return None, None, {}
+    records the SHA-256 of icp_kernels.hpp it was taken on; a stale profile yields null, never a stale number).  The
+    newest profiles/rNN_traffic.json whose hash matches is used."""
+    import glob
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            e = d[tag]
+        except Exception:
+            continue
+        if d.get("kernel_src_sha16") == kernel_src_sha16():
+            return e["hbm_bytes_per_launch"], os.path.relpath(path, ROOT), e
+        stale = stale or os.path.relpath(path, ROOT) + " (stale: kernel source changed since the PMC pass)"
+    return None, stale, {}
 
 
 # ------------------------------------------------------------------------------------------------ workload
@@ -140,11 +147,18 @@ class Pool:
         if todo:
             cls.CACHE.update(synth.make_pairs(todo))
 
-    def __init__(self, torch, synth, seeds, width, height, sigma):
-        self.prefetch(synth, [(s, width, height, sigma) for s in seeds])
-        self.pairs = [self.CACHE[(s, width, height, sigma)] for s in seeds]
+    @staticmethod
+    def spec(seed, width, height, sigma, mask=None):
+        """mask = (hole_block, hole_prob) or None for the default 32 / 0.2"""
+        return (seed, width, height, sigma) + (tuple(mask) if mask and tuple(mask) != (32, 0.2) else ())
+
+    def __init__(self, torch, synth, seeds, width, height, sigma, mask=None, pairs=None):
+        if pairs is None:
+            self.prefetch(synth, [self.spec(s, width, height, sigma, mask) for s in seeds])
+            pairs = [self.CACHE[self.spec(s, width, height, sigma, mask)] for s in seeds]
+        self.pairs = list(pairs)
         self.intr = self.pairs[0].intr
-        self.depth = torch.empty((len(seeds), 2, height, width), dtype=torch.int16).pin_memory()     # u16 bits
+        self.depth = torch.empty((len(self.pairs), 2, height, width), dtype=torch.int16).pin_memory()     # u16 bits
         arr = self.depth.numpy().view(np.uint16)
         for i, p in enumerate(self.pairs):
             arr[i, 0] = p.depth_src
@@ -167,8 +181,10 @@ class Streamer:
     """Software-pipelined stream of alignments over `handles`: alignment k uploads both depth images of its P pairs,
     runs, and its poses are fetched after the following len(handles)-1 alignments were queued."""
 
-    def __init__(self, handles, pools, P):
+    def __init__(self, handles, pools, P, on_fetch=None, T_init=None):
         self.handles, self.pools, self.P = handles, pools, P
+        self.on_fetch = on_fetch    # called as on_fetch(handle_index, handle) after every fetch (the stamped pass reads the launch stamps there)
+        self.T_init = T_init        # optional initial guess of every alignment (the real-frame leg)
         self.k = 0
         self.queue = []             # handles with a run in flight, oldest first
         self.last = None
@@ -182,7 +198,7 @@ class Streamer:
             h.frame_set_depth_host_ptr(2 * i, pool.src_ptr(j))
             h.frame_set_depth_host_ptr(2 * i + 1, pool.tgt_ptr(j))
             h.set_pair(i, 2 * i, 2 * i + 1)
-        h.run(self.P)
+        h.run(self.P, self.T_init)
         self.queue.append(hi)
         self.k += 1
 
@@ -200,6 +216,8 @@ class Streamer:
     def _drain_one(self, sink):
         hi = self.queue.pop(0)
         self.last = self.handles[hi].fetch_results(self.P)
+        if self.on_fetch is not None:
+            self.on_fetch(hi, self.handles[hi])
         if sink is not None:
             sink.extend(self.last)
 
@@ -313,6 +331,84 @@ def tiles_roofline(prof, iterations, tag, note_extra=""):
         "note": ("streaming accounting (each array once per iteration); the kernel is VALU-issue/latency bound, not HBM bound "
                  "(DESIGN.md section 6); equivalent_bruteforce_tflops = flops of a full scan / this launch time" + note_extra),
     }
+
+
+def overlap_pass(torch, handles, pools, P, n_align, iterations):
+    """How many NN launches of the in-flight alignments are really resident at once -- measured WITHOUT a tracer.  Every
+    handle stamps its launches (first block's start, last wave's end) with the GPU's constant-rate 100 MHz real-time
+    counter, common to all streams (slam3d_icp_set_stamping: fire-and-forget atomics, no stream serialisation; a kernel
+    tracer serialises the four streams and halves the overlap it is supposed to show).  The same pipelined stream as the
+    timed region runs for n_align alignments; the stamps of every alignment are read at its fetch."""
+    recs = []
+    for h in handles:
+        h.set_stamping(True)
+    st = Streamer(handles, pools, P, on_fetch=lambda hi, h: recs.append((hi, h.get_stamps().astype(np.int64))))
+    st.run(4 * len(handles))          # re-capture the graphs with the stamp rows, fill the pipeline
+    recs.clear()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st.run(n_align)
+    torch.cuda.synchronize()
+    host_s = time.perf_counter() - t0
+    for h in handles:
+        h.set_stamping(False)
+    nh = len(handles)
+    trim = 2 * nh
+    body = recs[trim:len(recs) - trim] if len(recs) > 4 * trim else recs
+    TICK = 1e-8
+    nn = np.array([r[1][:iterations] for r in body])                  # [align][it][2]
+    sv = np.array([r[1][iterations:2 * iterations] for r in body])
+    ok_sv = (sv[..., 1] > 0) & (sv[..., 0] < (1 << 62))
+    a_start = nn[:, 0, 0]
+    a_end = np.maximum(nn[:, -1, 1], np.where(ok_sv[:, -1], sv[:, -1, 1], 0))
+    lo, hi = int(a_start.min()), int(a_end.max())
+    iv = nn.reshape(-1, 2)
+    dur = (iv[:, 1] - iv[:, 0]).astype(np.float64)
+    # sweep line: time spent with k NN launches resident
+    ev = np.concatenate([np.stack([iv[:, 0], np.ones(len(iv), np.int64)], 1), np.stack([iv[:, 1], -np.ones(len(iv), np.int64)], 1)])
+    ev = ev[np.lexsort((ev[:, 1], ev[:, 0]))]
+    level_t = {}
+    cur, last = 0, lo
+    for t, d in ev:
+        if t > last:
+            level_t[cur] = level_t.get(cur, 0) + (t - last)
+            last = t
+        cur += d
+    window = float(hi - lo)
+    busy = window - level_t.get(0, 0)
+    n_al = len(body)
+    per_align_wall_us = window * TICK * 1e6 / n_al               # device clock: window / alignments completed in it
+    sum_nn_per_align_us = dur.sum() * TICK * 1e6 / n_al
+    conc_window = dur.sum() / window
+    out = {
+        "method": ("launch stamps: wall_clock64 (100 MHz real-time counter, common to all XCDs and streams) folded by every block of "
+                   "every NN launch into (min start, max end) with fire-and-forget atomics; no tracer, no HIP events, all handles live"),
+        "alignments_analysed": n_al, "in_flight": nh, "pairs_per_alignment": P,
+        "value_while_stamping": n_align * P * iterations / host_s,
+        "nn_launch_us_overlapped": {"mean": float(dur.mean() * TICK * 1e6), "p50": float(np.percentile(dur, 50) * TICK * 1e6),
+                                    "p90": float(np.percentile(dur, 90) * TICK * 1e6), "max": float(dur.max() * TICK * 1e6)},
+        "nn_launch_us_overlapped_by_iteration": [round(float(x) * TICK * 1e6, 2) for x in (nn[:, :, 1] - nn[:, :, 0]).mean(axis=0)],
+        "mean_resident_nn_kernels": conc_window,
+        "mean_resident_nn_kernels_while_any": dur.sum() / busy if busy > 0 else None,
+        "time_frac_with_n_resident": {str(k): round(v / window, 4) for k, v in sorted(level_t.items())},
+        "sum_nn_us_per_alignment": sum_nn_per_align_us,
+        "per_alignment_wall_us_device_clock": per_align_wall_us,
+        "per_alignment_wall_us_host_clock": host_s * 1e6 / n_align,
+        "identity": "sum_nn_us_per_alignment / mean_resident_nn_kernels == per_alignment_wall_us_device_clock (by construction); the "
+                    "measured quantities are the two on the left, the host clock on the right is the independent check",
+        "alignment_latency_us": {"mean": float(((a_end - a_start) * TICK * 1e6).mean()), "p90": float(np.percentile((a_end - a_start) * TICK * 1e6, 90))},
+        "iterations_per_s_device_clock": P * iterations / (per_align_wall_us * 1e-6),
+    }
+    if ok_sv.any():
+        sd = (sv[..., 1] - sv[..., 0])[ok_sv].astype(np.float64)
+        out["solve_launch_us"] = {"mean": float(sd.mean() * TICK * 1e6), "launches_per_alignment": float(ok_sv.sum() / n_al)}
+        # the gap between an iteration's NN end and the next iteration's NN start (solve launch + launch boundaries)
+        gap = (nn[:, 1:, 0] - nn[:, :-1, 1]).astype(np.float64)
+        out["nn_to_nn_gap_us"] = {"mean": float(gap.mean() * TICK * 1e6), "p90": float(np.percentile(gap, 90) * TICK * 1e6)}
+    else:
+        gap = (nn[:, 1:, 0] - nn[:, :-1, 1]).astype(np.float64)
+        out["nn_to_nn_gap_us"] = {"mean": float(gap.mean() * TICK * 1e6), "p90": float(np.percentile(gap, 90) * TICK * 1e6)}
+    return out
 
 
 def timed_stream(torch, dist, world, streamer, steps, warmup, aligns_per_step, comm=None, P=1):
@@ -547,11 +643,22 @@ def main():
     import torch.distributed as dist
     from slam3d_gx_amd import capi, synth
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched as a plain process: start the N ranks ourselves through the same launcher the driver uses
+        # (one rank per GPU, rendezvous on 127.0.0.1) and hand its output and exit code through
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the ICP path)")
     if args.one_device:
@@ -598,6 +705,11 @@ def main():
     if args.mode == "dense":
         if host_comm and world > 1:
             raise SystemExit("--mode dense needs RCCL (one GPU per rank); the gloo form is covered by tests/test_shard_gloo.py")
+        if world > 1 and comm is None:
+            # without the library's communicator slam3d_icp_dense_run would align the WHOLE pair on every rank while the
+            # line below says "sharded": refuse instead of mislabelling
+            raise SystemExit("--mode dense: the C-side RCCL communicator is unavailable (slam3d_comm self-test failed); "
+                             "refusing to run unsharded under a 'sharded' label")
         d = dense_leg(args, torch, dist, capi, synth, world, rank, local_rank, comm, args.width, args.height, args.steps, args.warmup,
                       want_cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
         elapsed = tmax(d["elapsed"])
@@ -636,15 +748,17 @@ def main():
     # every in-flight handle streams its own distinct pairs: seeds seed0 + (rank * n_handles + hi) * pool_n + k
     want_extra = (rank == 0 and world == 1 and not args.no_extra_configs and args.nn_mode in (capi.NN_AUTO, capi.NN_TILES)
                   and size_tag == "640x480" and P == 1)
-    specs = [(args.seed0 + (rank * n_handles + hi) * pool_n + k, args.width, args.height, args.noise_sigma)
+    mask = (args.hole_block, args.hole_prob)
+    specs = [Pool.spec(args.seed0 + (rank * n_handles + hi) * pool_n + k, args.width, args.height, args.noise_sigma, mask)
              for hi in range(n_handles) for k in range(pool_n)]
     if want_extra:       # render everything the extra legs need in the same parallel batch
         specs += [(args.seed0 + k, 640, 480, args.noise_sigma) for k in range(64)]
         specs += [(args.seed0 + hi * pool_n + k, 640, 480, 0.0012) for hi in range(n_handles) for k in range(min(pool_n, 8))]
+        specs += [Pool.spec(args.seed0 + hi * pool_n + k, 640, 480, args.noise_sigma, (8, 0.25)) for hi in range(n_handles) for k in range(min(pool_n, 8))]
         specs += [(2000 + k, 1280, 960, args.noise_sigma) for k in range(min(args.pool, 4))]
     Pool.prefetch(synth, specs)
     pools = [Pool(torch, synth, [args.seed0 + (rank * n_handles + hi) * pool_n + k for k in range(pool_n)], args.width, args.height,
-                  args.noise_sigma) for hi in range(n_handles)]
+                  args.noise_sigma, mask) for hi in range(n_handles)]
     intr = pools[0].intr
     params = capi.default_params(intr, estimator=est, iterations=args.iterations, max_batch=P, device=local_rank, nn_mode=args.nn_mode)
     handles = [capi.IcpHandle(params) for _ in range(n_handles)]
@@ -665,6 +779,8 @@ def main():
             def gather_collect(self, n):
                 return shard.unpack_records(self.g.collect())
         gather = _HostGather()
+    pose_exchange = ("none (1 rank)" if gather is None else "rccl: ncclAllGather behind the C-ABI (slam3d_pose_gather_*)" if comm is not None
+                     else "gloo through torch.distributed (tests)" if host_comm else "torch.distributed fallback (slam3d_comm self-test failed)")
     elapsed, res, table = timed_stream(torch, dist, world, streamer, args.steps, args.warmup, aligns, gather, P)
     elapsed = tmax(elapsed)
     total_iters = world * S * args.iterations * args.steps
@@ -679,7 +795,8 @@ def main():
                          f"alignment(s) of {P} pair(s), {args.iterations} ICP iterations each, {args.estimator}, exact NN (tile-pruned brute "
                          f"force); EVERY alignment uploads both u16 depth images of its pair(s) from pinned host memory and rebuilds "
                          f"normals + tiles (nothing cached between alignments); pairs cycle through {pool_n} distinct seeds per in-flight "
-                         f"handle (seeds {pools[0].pairs[0].seed}..{pools[-1].pairs[-1].seed}), noise sigma {args.noise_sigma} z^2"),
+                         f"handle (seeds {pools[0].pairs[0].seed}..{pools[-1].pairs[-1].seed}), noise sigma {args.noise_sigma} z^2, invalid-pixel blocks "
+                         f"{args.hole_block}x{args.hole_block} px with p = {args.hole_prob}"),
             "pairs_per_step_per_gpu": S, "pairs_per_launch": P, "alignments_per_step": aligns, "iterations": args.iterations,
             "estimator": args.estimator, "distinct_pairs_per_handle": pool_n, "noise_sigma_over_z2": args.noise_sigma,
             "h2d_bytes_per_pair": 2 * pools[0].frame_bytes,
@@ -692,6 +809,7 @@ def main():
         },
         "status": [r["status"] for r in res][:8],
         "timed_region_s": elapsed,
+        "rccl_ranks": (comm.world if comm is not None else 0), "pose_exchange": pose_exchange,
     }
     if table is not None:
         out["config"]["gathered_pose_records"] = len(table)
@@ -718,6 +836,9 @@ def main():
     torch.cuda.synchronize()
     out["single_step_latency_ms"] = 1e3 * (time.perf_counter() - tl) / nl
     out["single_step_latency_note"] = f"one alignment ({P} pair(s)) at a time incl. H2D of both depth images, mean of {nl}"
+    if tiles and n_handles > 1 and args.overlap_aligns > 0:
+        out["overlap"] = overlap_pass(torch, handles, pools, P, max(8 * n_handles, min(args.overlap_aligns, 4 * aligns)), args.iterations)
+        out["overlap"]["value_unstamped"] = value / world
     prof = profiled_pass(handles[0], pools[0], P, max(4, min(args.profile_aligns, 4 * aligns)), est)
     out["kernel_ms_per_alignment"] = {"preprocess": prof["preprocess_ms"], "nn": prof["nn_ms"], "total": prof["total_ms"]}
     out["kernel_only_value"] = P * args.iterations / (prof["total_ms"] * 1e-3)
@@ -745,7 +866,9 @@ def main():
             out["cpu_baseline"], out["parity_vs_oracle"] = cpu_baseline_leg(pr0, s4, t4, args.iterations, est, r0, idx)
         if want_extra:
             extra_legs(args, torch, dist, capi, synth, local_rank, est, handles, pools, out)
-        # the flat report SURVEY.md 8(d) lists, assembled from the objects above
+    if rank == 0:
+        # the flat report SURVEY.md 8(d) lists, assembled from the objects above (for N > 1 the single-GPU legs -- CPU
+        # baseline, brute-force rooflines, parity -- are not re-run and read null)
         rb, rf, cb_, pv = out.get("roofline_bruteforce", {}), out.get("roofline", {}), out.get("cpu_baseline", {}), out.get("parity_vs_oracle") or {}
         out["survey_8d"] = {
             "gpus": world, "pairs": world * S * args.steps, "iters": args.iterations, "wall_s": elapsed,
@@ -882,6 +1005,75 @@ def extra_legs(args, torch, dist, capi, synth, local_rank, est, handles, pools, 
                                "n_tgt": st.last[0]["n_tgt"], "inliers": st.last[0]["inliers"],
                                "note": "same streaming regime (H2D + distinct pairs); with iid noise at this level the reference's 0.01 m / "
                                        "41-of-49 planarity rule keeps far fewer target normals (DESIGN.md section 3, deviation ii)"}
+    # ---- (ii-b) the invalid-pixel mask SURVEY.md 8(d) specifies: 8x8-pixel Bernoulli holes at p = 0.25 (four to five times the
+    # hole-border length of the default 32x32 / 0.2 mask), same streaming regime; launch time from its own event-profiled pass
+    def stream_leg(hs, lpools, k, T_init=None, warm=32):
+        st = Streamer(hs, lpools, 1, T_init=T_init)
+        st.run(warm)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st.run(k)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        st1 = Streamer([hs[0]], [lpools[0]], 1, T_init=T_init)
+        st1.run(2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        st1.run(16)
+        torch.cuda.synchronize()
+        lat = (time.perf_counter() - t0) / 16
+        hs[0].set_profiling(True)
+        nn = []
+        for _ in range(6):
+            st1.run(1)
+            nn.append(hs[0].get_timings()["nn_ms"])
+        hs[0].set_profiling(False)
+        v = k * args.iterations / dt
+        return st.last[0], {"value": v, "ratio_to_headline": v / out["value"], "alignments": k, "single_step_latency_ms": 1e3 * lat,
+                            "nn_launch_us": 1e3 * statistics.mean(nn) / max(args.iterations, 1)}
+
+    if (args.hole_block, args.hole_prob) != (8, 0.25):
+        pools_m = [Pool(torch, synth, [p.seed for p in pool.pairs[:8]], args.width, args.height, args.noise_sigma, (8, 0.25)) for pool in pools]
+        r, leg = stream_leg(handles, pools_m, 768)
+        leg.update({"hole_block": 8, "hole_prob": 0.25, "n_src": r["n_src"], "n_tgt": r["n_tgt"], "inliers": r["inliers"], "status": r["status"],
+                    "note": "SURVEY.md 8(d)'s mask (8x8-pixel Bernoulli holes, p = 0.25) in the same streaming regime (H2D + distinct pairs, "
+                            f"{len(handles)} in flight); nn_launch_us by HIP events one alignment at a time"})
+        out["survey_mask"] = leg
+    # ---- (ii-c) real sensor frames: the reference's Kinect depth images (tests/golden/kinect, data fixtures).  dep1 -> dep2 is a
+    # wide-baseline pair (an equality test elsewhere, here only a timing on real hole / edge geometry); dep_k -> dep_k from a small
+    # initial guess converges to the identity
+    kin = os.path.join(ROOT, "tests", "golden", "kinect")
+    try:
+        from PIL import Image
+        d1 = np.array(Image.open(os.path.join(kin, "exp1_dep_1.png"))).astype(np.uint16)
+        d2 = np.array(Image.open(os.path.join(kin, "exp1_dep_2.png"))).astype(np.uint16)
+    except Exception as e:      # noqa: BLE001 -- the leg is optional
+        d1 = d2 = None
+        out["real_pair"] = {"skipped": repr(e)}
+    if d1 is not None and (args.width, args.height) == (640, 480):
+        kintr = synth.Intrinsics()            # the fixtures' intrinsics: 525 / 525 / 319.5 / 235.5 / 1000 (src/convert2PCD.cpp:19-23)
+        kparams = capi.default_params(kintr, estimator=est, iterations=args.iterations, max_batch=1, device=local_rank)
+        khandles = [capi.IcpHandle(kparams) for _ in handles]
+        try:
+            real = {}
+            wide = synth.FramePair(-1, kintr, d1, d2, np.eye(4))
+            r, leg = stream_leg(khandles, [Pool(torch, synth, None, 640, 480, 0.0, pairs=[wide]) for _ in khandles], 512)
+            leg.update({"n_src": r["n_src"], "n_tgt": r["n_tgt"], "inliers": r["inliers"], "status": r["status"], "norm": r["norm"]})
+            real["dep1_to_dep2_wide_baseline"] = leg
+            Ti = synth.pose_from_seed(77, 2.0, 0.03)
+            for name, d in (("dep1_to_dep1_perturbed", d1), ("dep2_to_dep2_perturbed", d2)):
+                same = synth.FramePair(-1, kintr, d, d, np.eye(4))
+                r, leg = stream_leg(khandles, [Pool(torch, synth, None, 640, 480, 0.0, pairs=[same]) for _ in khandles], 512, T_init=Ti.reshape(1, 16))
+                rot = float(np.arccos(min(1.0, max(-1.0, (np.trace(np.array(r["T_raw"]).reshape(4, 4)[:3, :3]) - 1.0) / 2.0))))
+                leg.update({"n_src": r["n_src"], "inliers": r["inliers"], "status": r["status"], "residual_rot_rad": rot,
+                            "residual_trans_m": float(np.linalg.norm(np.array(r["T_raw"]).reshape(4, 4)[:3, 3]))})
+                real[name] = leg
+            real["note"] = ("the reference's 640x480 Kinect depth images (tests/golden/kinect), H2D of both images inside every alignment, "
+                            f"{len(khandles)} in flight; perturbed legs start 2 deg / 3 cm away from the identity and must return to it")
+            out["real_pair"] = real
+        finally:
+            for hh in khandles:
+                hh.close()
     # ---- (iii) BASELINE config 3: 64 pairs per launch sequence
     P3 = 64
     pool3 = Pool(torch, synth, [args.seed0 + k for k in range(P3)], args.width, args.height, args.noise_sigma)

@@ -23,7 +23,7 @@ EXPORTED_SYMBOLS = [
     "slam3d_icp_align_depth_batch", "slam3d_icp_set_clouds_host", "slam3d_icp_set_depth_host",
     "slam3d_icp_set_clouds_device", "slam3d_icp_set_depth_device", "slam3d_icp_run",
     "slam3d_icp_fetch_results", "slam3d_icp_get_correspondences", "slam3d_icp_get_trace",
-    "slam3d_icp_get_clouds", "slam3d_icp_set_profiling", "slam3d_icp_get_timings", "slam3d_icp_get_iteration_timings", "slam3d_icp_get_nn_debug", "slam3d_backproject_u16", "slam3d_fit_planes",
+    "slam3d_icp_get_clouds", "slam3d_icp_set_profiling", "slam3d_icp_get_timings", "slam3d_icp_get_iteration_timings", "slam3d_icp_set_stamping", "slam3d_icp_get_stamps", "slam3d_icp_get_nn_debug", "slam3d_backproject_u16", "slam3d_fit_planes",
     "slam3d_match_planes", "slam3d_voxel_grid", "slam3d_voxel_grid_device", "slam3d_voxel_grid_only", "slam3d_pass_transform", "slam3d_seg_default_params", "slam3d_segment_planes", "slam3d_segment_planes_device",
     "slam3d_icp_dense_set_rows", "slam3d_icp_dense_begin", "slam3d_icp_dense_partial",
     "slam3d_icp_dense_update", "slam3d_icp_dense_finish",
@@ -350,6 +350,17 @@ class IcpHandle:
         ms = np.zeros(max(self.params.iterations, 1), dtype=np.float32)
         self._check(self.lib.slam3d_icp_get_iteration_timings(self._h, _vp(ms)), False)
         return ms[: self.params.iterations]
+
+    def set_stamping(self, on: bool = True):
+        self._check(self.lib.slam3d_icp_set_stamping(self._h, int(bool(on))), False)
+
+    def get_stamps(self) -> np.ndarray:
+        """(start, end) ticks (10 ns, device real-time counter) of the last run's launches: [2 * iterations, 2] uint64,
+        rows [0, iterations) NN launches, then the solve launches"""
+        rows = 2 * max(self.params.iterations, 1)
+        out = np.zeros((rows, 2), dtype=np.uint64)
+        self._check(self.lib.slam3d_icp_get_stamps(self._h, _vp(out), C.c_int32(rows)), False)
+        return out
 
     def get_nn_debug(self) -> np.ndarray:
         nt = ((self.params.width + 7) // 8) * ((self.params.height + 7) // 8)

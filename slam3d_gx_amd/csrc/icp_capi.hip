@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 using namespace s3d;
@@ -91,6 +92,8 @@ struct slam3d_icp_handle {
     int graph_B = 0;
     bool use_graph = true;
     bool profiling = false;       // record the per-iteration events (each costs ~6 us of stream serialisation)
+    bool stamping = false;        // launch stamps (slam3d_icp_set_stamping): device rows + their pinned copy of the last run
+    unsigned long long *d_stamps = nullptr, *pin_stamps = nullptr; int stamp_rows = 0; bool ran_stamped = false;
     bool ran_profiled = false;
     bool ran = false; int last_B = 0;
     int row0 = 0, row1 = 0; int dense_it = 0;
@@ -160,6 +163,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->src_c); F(h->tgt_c); F(h->ccounts); F(h->corr); F(h->ticket);
     F(h->flags); F(h->best); F(h->cd2); F(h->acc); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
     F(h->d_pairs); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4); F(h->corr_trace);
+    F(h->d_stamps); if (h->pin_stamps) (void)hipHostFree(h->pin_stamps);
     F(h->dbg); F(h->prevq); F(h->perm_d); F(h->cost); F(h->tgtB); F(h->qmax2);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->pin_res) (void)hipHostFree(h->pin_res);
@@ -490,20 +494,42 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         t.role = role; t.row0 = h->row0; t.row1 = h->row1; t.use_normals = use_normals;
         return t;
     };
+    // every pair is validated before anything is planned, and the per-frame "built for this epoch" marks are kept in a
+    // local plan that is committed only after every launch of this function was enqueued without error: a failing call
+    // leaves the frames stale, so the caller's retry rebuilds them (marks set inside the loop survived an
+    // E_STATE / HIP error further down and the retry aligned against unbuilt tiles)
     for (int b = 0; b < B; ++b) {
         const int fs = h->pair_src[b], ft = h->pair_tgt[b];
-        if (fs < 0 || ft < 0 || h->frames[fs].epoch == 0 || h->frames[ft].epoch == 0) return SLAM3D_E_STATE;
-        FrameHost &S = h->frames[fs], &T = h->frames[ft];
-        if (S.src_epoch != S.epoch || S.src_row0 != h->row0 || S.src_row1 != h->row1) {
-            tasks.push_back(task_of(fs, 0));
-            S.src_epoch = S.epoch; S.src_row0 = h->row0; S.src_row1 = h->row1;
+        if (fs < 0 || ft < 0 || h->frames[fs].epoch == 0 || h->frames[ft].epoch == 0) {
+            h->err = "slam3d_icp_run: pair " + std::to_string(b) + " has no frames set";
+            return SLAM3D_E_STATE;
         }
-        if (src_normals && S.nrm_epoch != S.epoch) { ntasks.push_back(task_of(fs, 1)); S.nrm_epoch = S.epoch; }
-        if (T.tgt_epoch != T.epoch || T.tgt_normals != use_normals) {
-            if (use_normals && T.nrm_epoch != T.epoch) { ntasks.push_back(task_of(ft, 1)); T.nrm_epoch = T.epoch; }
-            tasks.push_back(task_of(ft, 1));
-            T.tgt_epoch = T.epoch; T.tgt_normals = use_normals;
+    }
+    std::unordered_map<int, FrameHost> plan;
+    auto planned = [&](int f) -> FrameHost & {
+        auto it = plan.find(f);
+        if (it == plan.end()) it = plan.emplace(f, h->frames[f]).first;
+        return it->second;
+    };
+    for (int b = 0; b < B; ++b) {
+        const int fs = h->pair_src[b], ft = h->pair_tgt[b];
+        {
+            FrameHost &S = planned(fs);
+            if (S.src_epoch != S.epoch || S.src_row0 != h->row0 || S.src_row1 != h->row1) {
+                tasks.push_back(task_of(fs, 0));
+                S.src_epoch = S.epoch; S.src_row0 = h->row0; S.src_row1 = h->row1;
+            }
+            if (src_normals && S.nrm_epoch != S.epoch) { ntasks.push_back(task_of(fs, 1)); S.nrm_epoch = S.epoch; }
         }
+        {
+            FrameHost &T = planned(ft);
+            if (T.tgt_epoch != T.epoch || T.tgt_normals != use_normals) {
+                if (use_normals && T.nrm_epoch != T.epoch) { ntasks.push_back(task_of(ft, 1)); T.nrm_epoch = T.epoch; }
+                tasks.push_back(task_of(ft, 1));
+                T.tgt_epoch = T.epoch; T.tgt_normals = use_normals;
+            }
+        }
+        const FrameHost &S = planned(fs), &T = planned(ft);
         PairPtrs &pp = h->h_pairs[b];
         pp.src = S.cloud; pp.tgt = T.cloud;
         pp.nrm = h->f_nrm + (size_t)ft * h->N;
@@ -548,12 +574,14 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
             TinitArgs ti;
             const int n = B - b0 < TINIT_ARGS ? B - b0 : TINIT_ARGS;
             memcpy(ti.T, T_init + (size_t)b0 * 16, sizeof(double) * 16 * n);
-            hipLaunchKernelGGL(k_pair_init, dim3(n), dim3(64), 0, s, ti, 1, b0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters);
+            hipLaunchKernelGGL(k_pair_init, dim3(n), dim3(64), 0, s, ti, 1, b0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters,
+                               (h->stamping && b0 == 0) ? h->d_stamps : nullptr, h->stamp_rows);
         }
     } else {
         TinitArgs ti;
         memset(&ti, 0, sizeof ti);
-        hipLaunchKernelGGL(k_pair_init, dim3(B), dim3(64), 0, s, ti, 0, 0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters);
+        hipLaunchKernelGGL(k_pair_init, dim3(B), dim3(64), 0, s, ti, 0, 0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters,
+                               h->stamping ? h->d_stamps : nullptr, h->stamp_rows);
     }
     if (nn_mode_of(h) != SLAM3D_NN_TILES) {
         HIPCHK(h, hipMemsetAsync(h->best, 0xFF, sizeof(unsigned long long) * (size_t)B * tg.nslots, s));
@@ -566,6 +594,7 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         }
     }
     HIPCHK(h, hipGetLastError());
+    for (const auto &kv : plan) h->frames[kv.first] = kv.second;      // everything was enqueued: the frames count as built
     return SLAM3D_OK;
 }
 
@@ -590,7 +619,8 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         // four instances: {throughput, cooperative} x {production, instrumented (SLAM3D_NN_DEBUG: per-tile clocks and counters)}
         auto launch = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_pairs, h->Tcur, h->corr, h->cd2, h->prevq,
-                               perm, h->cost, h->acc, h->g, tg, h->dbg, write_out, first);
+                               perm, h->cost, h->acc, h->g, tg, h->dbg, write_out, first,
+                               (h->stamping && do_solve) ? h->d_stamps + (size_t)it * STAMP_ROW : nullptr);
         };
         // (+ two with the optional S4g gates compiled in: the production instances carry none of that code)
         const bool gated = h->p.estimator == SLAM3D_EST_POINT2PLANE && (h->g.resid2 > 0.0f || h->g.min_ncos > 0.0f);
@@ -628,10 +658,12 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
                                  hipMemcpyDeviceToDevice, s));
     if (h->p.estimator == SLAM3D_EST_POINT2PLANE)
         hipLaunchKernelGGL(k_solve_acc<0>, dim3(B), dim3(64), 0, s, h->acc, raw_out, h->Tcur, h->trace_T, h->trace_S, h->flags, h->d_pairs,
-                           do_solve ? h->d_res : nullptr, it, iters, do_solve);
+                           do_solve ? h->d_res : nullptr, it, iters, do_solve,
+                           (h->stamping && do_solve) ? h->d_stamps + (size_t)(iters + it) * STAMP_ROW : nullptr);
     else
         hipLaunchKernelGGL(k_solve_acc<1>, dim3(B), dim3(64), 0, s, h->acc, raw_out, h->Tcur, h->trace_T, h->trace_S, h->flags, h->d_pairs,
-                           do_solve ? h->d_res : nullptr, it, iters, do_solve);
+                           do_solve ? h->d_res : nullptr, it, iters, do_solve,
+                           (h->stamping && do_solve) ? h->d_stamps + (size_t)(iters + it) * STAMP_ROW : nullptr);
     HIPCHK(h, hipGetLastError());
     return SLAM3D_OK;
 }
@@ -679,6 +711,9 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
         }
     }
     HIPCHK(h, hipGetLastError());
+    if (h->stamping && iters > 0)
+        HIPCHK(h, hipMemcpyAsync(h->pin_stamps, h->d_stamps, sizeof(unsigned long long) * (size_t)h->stamp_rows * STAMP_ROW, hipMemcpyDeviceToHost, s));
+    h->ran_stamped = h->stamping && iters > 0;
     HIPCHK(h, hipEventRecord(h->ev[2], s));
     h->run_stream = s;
     h->ran = true;
@@ -693,6 +728,40 @@ extern "C" int slam3d_icp_set_profiling(slam3d_icp_handle *h, int32_t on)
 {
     if (!h) return SLAM3D_E_INVALID;
     h->profiling = on != 0;
+    return SLAM3D_OK;
+}
+
+// Launch stamps: every NN / solve launch of the following runs records when its first block started and its last wave
+// ended on the GPU's constant-rate 100 MHz real-time counter, common to all handles and streams of the device: the
+// host can then tell how many launches really were resident at once without a tracer (profiles/r03_overlap.md).
+extern "C" int slam3d_icp_set_stamping(slam3d_icp_handle *h, int32_t on)
+{
+    if (!h) return SLAM3D_E_INVALID;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    if (on && !h->d_stamps) {
+        h->stamp_rows = 2 * (h->p.iterations > 0 ? h->p.iterations : 1);
+        const size_t n = sizeof(unsigned long long) * (size_t)h->stamp_rows * STAMP_ROW;
+        HIPCHK(h, hipMalloc((void **)&h->d_stamps, n));
+        HIPCHK(h, hipHostMalloc((void **)&h->pin_stamps, n, hipHostMallocDefault));
+    }
+    if (h->stamping != (on != 0)) h->graph_B = 0;        // the stamp rows are kernel arguments of the captured launches
+    h->stamping = on != 0;
+    return SLAM3D_OK;
+}
+
+// (start, end) ticks of the last FETCHED run's launches: rows [0, iterations) the NN launches, [iterations, 2 iterations)
+// the solve launches; a launch that did not run (or was not stamped) reads (~0, 0).  10 ns per tick.
+extern "C" int slam3d_icp_get_stamps(slam3d_icp_handle *h, uint64_t *out /* [rows][2] */, int32_t rows)
+{
+    if (!h || !out) return SLAM3D_E_INVALID;
+    if (!h->ran || !h->ran_stamped || rows > h->stamp_rows) return SLAM3D_E_STATE;
+    HIPCHK(h, hipEventSynchronize(h->ev[2]));
+    for (int r = 0; r < rows; ++r) {
+        const unsigned long long *row = h->pin_stamps + (size_t)r * STAMP_ROW;
+        unsigned long long t0 = ~0ull, t1 = 0ull;
+        for (int k = 0; k < STAMP_R; ++k) { if (row[k] < t0) t0 = row[k]; if (row[STAMP_R + k] > t1) t1 = row[STAMP_R + k]; }
+        out[2 * r] = t0; out[2 * r + 1] = t1;
+    }
     return SLAM3D_OK;
 }
 

@@ -47,6 +47,20 @@ struct PairPtrs {                  // per frame-pair device pointers: the reside
     const int *tgt_counts;         // [1] = valid target points of the target frame
 };
 constexpr int RES_REC = 48;        // doubles per pair in the host-mapped result record
+// Launch stamps (opt-in, slam3d_icp_set_stamping): every block of a stamped launch folds the constant-rate 100 MHz
+// real-time counter (common to all XCDs, unlike s_memtime) into the launch's row -- STAMP_R replicas of the earliest
+// start (atomic min) followed by STAMP_R replicas of the latest end (atomic max), fire-and-forget atomics spread
+// over the replicas.  They tell WHEN a launch really occupied the chip without a tracer serialising the streams
+// (profiles/r03_overlap.md).  A null pointer (the default) costs one scalar branch.
+constexpr int STAMP_R = 16, STAMP_ROW = 2 * STAMP_R;
+__device__ __forceinline__ void stamp_start(unsigned long long *__restrict__ row, int c)
+{
+    if (row) atomicMin(row + (c & (STAMP_R - 1)), (unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void stamp_end(unsigned long long *__restrict__ row, int c)
+{
+    if (row) atomicMax(row + STAMP_R + (c & (STAMP_R - 1)), (unsigned long long)wall_clock64());
+}
 constexpr int PAIR_ARGS = 32;
 struct PairArgs { PairPtrs p[PAIR_ARGS]; };
 // the pair table travels as a kernel argument (copied at launch), not through pinned host memory
@@ -414,9 +428,12 @@ constexpr int TINIT_ARGS = 16;
 struct TinitArgs { double T[TINIT_ARGS][16]; };
 __global__ __launch_bounds__(64) void k_pair_init(TinitArgs ti, int has_T, int b0, double *__restrict__ Tcur,
                                                   double *__restrict__ trace_T, int *__restrict__ flags,
-                                                  long long *__restrict__ acc, unsigned int *__restrict__ ticket, int iters)
+                                                  long long *__restrict__ acc, unsigned int *__restrict__ ticket, int iters,
+                                                  unsigned long long *__restrict__ stamps /* nullable */, int stamp_rows)
 {
     const int k = blockIdx.x, b = b0 + k, lane = threadIdx.x;
+    if (stamps && k == 0)          // launch stamps (opt-in): start = min over the blocks -> ~0, end = max -> 0
+        for (int j = lane; j < stamp_rows * STAMP_ROW; j += 64) stamps[j] = (j % STAMP_ROW) < STAMP_R ? ~0ull : 0ull;
     for (int j = lane; j < ACC_R * ACC_STRIDE; j += 64) acc[(size_t)b * ACC_R * ACC_STRIDE + j] = 0;
     if (lane < 16) {
         const double v = has_T ? ti.T[k % TINIT_ARGS][lane] : ((lane % 5 == 0) ? 1.0 : 0.0);
@@ -1056,7 +1073,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                                                         long long *__restrict__ acc, Geometry g, TileGrid tg,
                                                         long long *__restrict__ dbg /* DBG builds only: 20 x int64 per tile */,
                                                         int write_out /* corr / cd2 wanted (last iteration) */,
-                                                        int first /* a run's first iteration: no previous match */)
+                                                        int first /* a run's first iteration: no previous match */,
+                                                        unsigned long long *__restrict__ stamp /* this launch's stamp row, nullable */)
 {
     __shared__ float4 stage_all[NN_WAVES][NN_STAGE * STAGE_REC];
     __shared__ int wcost[NN_WAVES];                                    // cycles spent for each owner (all helpers)
@@ -1077,6 +1095,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.y, c = blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) stamp_start(stamp, c);
     // ownership: the measured-cost balanced assignment once k_balance has run (perm >= 0 tile, -2 none),
     // before that (-1) tiles interleaved over the image bands
     // (the cooperative build always uses the interleaved default: on a stream of distinct pairs the measured-cost deal
@@ -1649,7 +1668,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     if constexpr (DBG) clkE = clock64();
     if constexpr (COOP) __syncthreads();
     if constexpr (DBG) clk3 = clock64();
-    if (!has_tile) return;
+    if (!has_tile) { if (lane == 0) stamp_end(stamp, c); return; }
     if constexpr (!COOP) { if (lane == 0) cost[(size_t)b * tg.ntiles + t] = wcost[w]; }          // input of k_balance
     // ================= step 4: this wave's own tile: fused S4 accumulation =================
     if constexpr (COOP) {
@@ -1676,6 +1695,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         finish_slot<false>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs_ep, cd2 + gs_ep, prevq + gs_ep, rb,
                            write_out != 0, own_jprev);
     tile_accumulate(g.estimator, rb, acc + ((size_t)b * ACC_R + (c % ACC_R)) * ACC_STRIDE);
+    if (lane == 0) stamp_end(stamp, c + w);
     if (DBG && dbg && b == 0 && lane == 0) {
         long long *d = dbg + (size_t)t * 20;
         d[0] = clk0; d[1] = clk1; d[2] = clk2; d[3] = clk3; d[4] = clock64();
@@ -2059,10 +2079,11 @@ __global__ __launch_bounds__(64) void k_solve_acc(long long *__restrict__ acc, l
                                                   double *__restrict__ Tcur, double *__restrict__ trace_T,
                                                   double *__restrict__ trace_S, int *__restrict__ flags,
                                                   const PairPtrs *__restrict__ pairs, double *__restrict__ res_host,
-                                                  int it, int iters, int do_solve)
+                                                  int it, int iters, int do_solve, unsigned long long *__restrict__ stamp /* nullable */)
 {
     __shared__ double tot[32], Tsh[16];
     const int b = blockIdx.x, k = threadIdx.x;
+    if (k == 0) stamp_start(stamp, b);
     long long *__restrict__ A = acc + (size_t)b * ACC_R * ACC_STRIDE;
     if (k < NSUMS) {
         long long q = 0;
@@ -2079,6 +2100,7 @@ __global__ __launch_bounds__(64) void k_solve_acc(long long *__restrict__ acc, l
         if (do_solve)
             wave_solve_update_point2plane(tot, Tsh, Tcur + b * 16, trace_T + (size_t)b * (iters + 1) * 16, trace_S + (size_t)b * iters * NSUMS,
                                           flags + b, it, (res_host && it == iters - 1) ? res_host + (size_t)b * RES_REC : nullptr, pairs[b]);
+        if (k == 0) stamp_end(stamp, b);
         return;
     }
     if (k == 0 && do_solve) {
@@ -2091,6 +2113,7 @@ __global__ __launch_bounds__(64) void k_solve_acc(long long *__restrict__ acc, l
             r[45] = (double)flags[b]; r[46] = (double)pairs[b].src_counts[0]; r[47] = (double)pairs[b].tgt_counts[1];
         }
     }
+    if (k == 0) stamp_end(stamp, b);
 }
 
 // dense mode: solve from externally reduced sums (one thread per pair)

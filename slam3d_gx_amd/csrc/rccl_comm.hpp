@@ -23,6 +23,7 @@ struct RcclApi {
     decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommAbort) CommAbort = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -31,31 +32,40 @@ struct RcclApi {
     bool ok = false;
 };
 
+// resolved once per process, thread-safe: the C++ front end creates its communicators from one host thread per GPU
+// (function-local static initialised by a lambda: the language guarantees a single, completed initialisation)
 inline RcclApi &rccl()
 {
-    static RcclApi api;
-    if (api.ok || !api.err.empty()) return api;
-    const char *names[] = { "librccl.so.1", "librccl.so" };
-    for (const char *n : names) {                                  // a copy that is already mapped (e.g. torch's)
-        api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-        if (api.lib) break;
-    }
-    if (!api.lib) {
-        const char *paths[] = { "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so" };
-        for (const char *n : paths) {
-            api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (api.lib) break;
+    static RcclApi api = [] {
+        RcclApi a;
+        const char *names[] = { "librccl.so.1", "librccl.so" };
+        for (const char *n : names) {                                  // a copy that is already mapped (e.g. torch's)
+            a.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+            if (a.lib) break;
         }
-    }
-    if (!api.lib) { api.err = std::string("librccl not loadable: ") + (dlerror() ? dlerror() : "?"); return api; }
-    auto sym = [&](const char *name) { void *p = dlsym(api.lib, name); if (!p && api.err.empty()) api.err = std::string("missing symbol ") + name; return p; };
-    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
-    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
-    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
-    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
-    api.AllGather = reinterpret_cast<decltype(api.AllGather)>(sym("ncclAllGather"));
-    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
-    api.ok = api.err.empty();
+        if (!a.lib) {
+            const char *paths[] = { "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so" };
+            for (const char *n : paths) {
+                a.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+                if (a.lib) break;
+            }
+        }
+        if (!a.lib) {
+            const char *why = dlerror();                               // read ONCE: the call clears the pending error
+            a.err = std::string("librccl not loadable: ") + (why ? why : "?");
+            return a;
+        }
+        auto sym = [&](const char *name) { void *p = dlsym(a.lib, name); if (!p && a.err.empty()) a.err = std::string("missing symbol ") + name; return p; };
+        a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+        a.CommAbort = reinterpret_cast<decltype(a.CommAbort)>(dlsym(a.lib, "ncclCommAbort"));      // optional
+        a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+        a.AllGather = reinterpret_cast<decltype(a.AllGather)>(sym("ncclAllGather"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+        a.ok = a.err.empty();
+        return a;
+    }();
     return api;
 }
 

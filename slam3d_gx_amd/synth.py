@@ -196,13 +196,16 @@ class FramePair:
 
 
 def make_pair(seed: int, width: int = 640, height: int = 480, noise: bool = True, holes: bool = True,
-              max_angle_deg: float = 3.0, max_trans: float = 0.05, noise_sigma: float = 0.0002) -> FramePair:
-    """Pair ``seed`` of the BASELINE workloads (C2 = seed 1000, C3 = 1000..1063, C5 = seed 2000 @1280x960)."""
+              max_angle_deg: float = 3.0, max_trans: float = 0.05, noise_sigma: float = 0.0002,
+              hole_block: int = 32, hole_prob: float = 0.2) -> FramePair:
+    """Pair ``seed`` of the BASELINE workloads (C2 = seed 1000, C3 = 1000..1063, C5 = seed 2000 @1280x960).
+    ``hole_block`` (pixels at 640x480, scaled with the width) / ``hole_prob``: the invalid-pixel mask; SURVEY.md 8(d)
+    specifies 8 / 0.25 (the `survey_mask` workload), the default 32 / 0.2 is DESIGN.md section 3's deviation (ii)."""
     intr = Intrinsics.scaled(width, height)
     T_gt = pose_from_seed(seed, max_angle_deg, max_trans)
-    hb = max(2, int(round(32 * width / 640.0)))
-    d1 = render_depth(np.eye(4), intr, seed, 1, noise, holes, hole_block=hb, noise_sigma=noise_sigma)
-    d2 = render_depth(T_gt, intr, seed, 2, noise, holes, hole_block=hb, noise_sigma=noise_sigma)
+    hb = max(2, int(round(hole_block * width / 640.0)))
+    d1 = render_depth(np.eye(4), intr, seed, 1, noise, holes, hole_block=hb, hole_prob=hole_prob, noise_sigma=noise_sigma)
+    d2 = render_depth(T_gt, intr, seed, 2, noise, holes, hole_block=hb, hole_prob=hole_prob, noise_sigma=noise_sigma)
     return FramePair(seed, intr, d1, d2, T_gt)
 
 
@@ -222,8 +225,10 @@ def backproject_numpy(depth: np.ndarray, intr: Intrinsics, z_filter: float = 7.0
 
 
 def _make_pair_spec(spec):
-    seed, width, height, sigma = spec
-    return make_pair(seed, width, height, noise_sigma=sigma)
+    """spec = (seed, width, height, noise_sigma[, hole_block, hole_prob])"""
+    seed, width, height, sigma = spec[:4]
+    kw = dict(hole_block=spec[4], hole_prob=spec[5]) if len(spec) >= 6 else {}
+    return make_pair(seed, width, height, noise_sigma=sigma, **kw)
 
 
 def make_pairs(specs, workers: int = 0):
@@ -248,7 +253,7 @@ def make_pairs(specs, workers: int = 0):
             if not chunk:
                 continue
             path = os.path.join(tmp, f"part{w}.npz")
-            args = [sys.executable, "-m", "slam3d_gx_amd.synth", "render", path] + [f"{s},{wd},{ht},{sg!r}" for s, wd, ht, sg in chunk]
+            args = [sys.executable, "-m", "slam3d_gx_amd.synth", "render", path] + [",".join(repr(x) for x in sp) for sp in chunk]
             env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
             procs.append((subprocess.Popen(args, cwd=root, env=env), path, chunk))
         for pr, path, chunk in procs:
@@ -265,7 +270,7 @@ if __name__ == "__main__":
     if len(sys.argv) >= 4 and sys.argv[1] == "render":
         arrs = {}
         for k, a in enumerate(sys.argv[3:]):
-            seed, wd, ht, sg = a.split(",")
-            pr = make_pair(int(seed), int(wd), int(ht), noise_sigma=float(sg))
+            f = a.split(",")
+            pr = _make_pair_spec((int(f[0]), int(f[1]), int(f[2]), float(f[3])) + ((int(f[4]), float(f[5])) if len(f) >= 6 else ()))
             arrs[f"s{k}"], arrs[f"t{k}"], arrs[f"T{k}"] = pr.depth_src, pr.depth_tgt, pr.T_gt
         np.savez(sys.argv[2], **arrs)

@@ -90,6 +90,26 @@ def test_full_640x480_config2(gpu_lib, estimator):
         assert rot_gt < 2e-3 and tr_gt < 5e-3
 
 
+@pytest.mark.parametrize("seed", [1000, 1001])
+def test_full_640x480_survey_mask(gpu_lib, seed):
+    """SURVEY.md 8(d)'s invalid-pixel mask (8x8-pixel Bernoulli holes, p = 0.25: four to five times the hole-border
+    length of the default mask) at full size, 20 iterations, as depth images (the projective window search takes part)
+    and as clouds: every iterate, the sums and the last indices bit-identical to the oracle (kd-tree)."""
+    pr, s4, t4 = _pair(seed, 640, 480, hole_block=8, hole_prob=0.25)
+    ro = O.icp(s4, t4, O.params(pr.intr, iterations=20, nn_method=1))
+    with capi.IcpHandle(capi.default_params(pr.intr, iterations=20)) as h:
+        for depth in (True, False):
+            rg = h.align_depth_batch([pr.depth_src], [pr.depth_tgt])[0] if depth else h.align(s4, t4)
+            idx, d2 = h.get_correspondences(0)
+            Tt, St = h.get_trace(0)
+            assert np.array_equal(idx, ro["idx"]), f"depth={depth}: {(idx != ro['idx']).sum()} index mismatches"
+            assert np.array_equal(d2.view(np.uint32), ro["d2"].view(np.uint32))
+            assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:20], ro["sums_trace"])
+            assert rg["inliers"] == ro["inliers"] and rg["status"] == ro["status"] == 0
+    rot_gt, tr_gt = O.pose_error(pr.T_gt, rg["T"])
+    assert rot_gt < 3e-3 and tr_gt < 8e-3
+
+
 def test_batch_equals_single(gpu_lib):
     """Batch mode (config 3 shape, reduced): every pair of a batch equals its single-pair run."""
     seeds = [1000, 1001, 1002, 1003]
@@ -474,6 +494,52 @@ def test_bench_two_ranks_on_one_device(gpu_lib):
     assert d["config"]["gathered_pose_records"] == 12 and d["config"]["pairs_per_step_per_gpu"] == 6
 
 
+def test_bench_gpus2_launched_as_a_plain_process(gpu_lib):
+    """`python bench.py --gpus 2 ...` with NO launcher must start its own ranks (it re-executes itself
+    through torch.distributed.run on 127.0.0.1) instead of exiting non-zero; two ranks on this one GPU over gloo."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--width", "320", "--height", "240", "--iterations", "6", "--no-cpu-baseline", "--no-bruteforce",
+           "--pairs-per-step", "6", "--pool", "4", "--profile-aligns", "4", "--overlap-aligns", "0", "--dist-backend", "gloo", "--one-device"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["status"][0] == 0
+    assert d["survey_8d"]["gpus"] == 2 and d["survey_8d"]["icp_iters_per_s"] == d["value"]
+    assert d["rccl_ranks"] == 0 and d["pose_exchange"].startswith("gloo")
+
+
+def test_launch_stamps_are_ordered_and_change_nothing(gpu_lib):
+    """slam3d_icp_set_stamping: every NN / solve launch reports (start, end) on the device's real-time counter; the
+    launches of a run follow each other, two handles in flight share the clock, and the results are bit-identical with
+    the stamps on and off."""
+    pr, s4, t4 = _pair(1000, 320, 240)
+    iters = 6
+    with capi.IcpHandle(capi.default_params(pr.intr, iterations=iters)) as h, capi.IcpHandle(capi.default_params(pr.intr, iterations=iters)) as h2:
+        want = h.align(s4, t4)
+        with pytest.raises(capi.Slam3dError):
+            h.get_stamps()                                            # that run was not stamped
+        h.set_stamping(True); h2.set_stamping(True)
+        h.set_clouds_host(0, s4, t4); h2.set_clouds_host(0, s4, t4)
+        h.run(1); h2.run(1)
+        got, got2 = h.fetch_results(1)[0], h2.fetch_results(1)[0]
+        st, st2 = h.get_stamps().astype(np.int64), h2.get_stamps().astype(np.int64)
+        h.set_stamping(False)
+        again = h.align(s4, t4)
+    for g in (got, got2, again):
+        assert np.array_equal(g["T_raw"], want["T_raw"]) and g["inliers"] == want["inliers"]
+    for s in (st, st2):
+        nn = s[:iters]
+        assert (nn[:, 0] > 0).all() and (nn[:, 1] > nn[:, 0]).all()                   # every NN launch ran, end after start
+        assert (nn[1:, 0] >= nn[:-1, 1]).all()                                       # iteration k+1 starts after iteration k ended
+        dur_us = (nn[:, 1] - nn[:, 0]) * 0.01
+        assert (dur_us > 1).all() and (dur_us < 5000).all()
+    # one clock for both handles: the two runs were queued back to back, so they lie within a few milliseconds of each other
+    assert abs(int(st[0, 0]) - int(st2[0, 0])) * 1e-8 < 0.05
+
+
 def test_bench_single_gpu_line_has_the_contract_fields(gpu_lib):
     """The default code path of bench.py at a small size: one JSON line with roofline, cpu_baseline, parity and the
     RCCL pose gather forced on (one rank)."""
@@ -489,6 +555,10 @@ def test_bench_single_gpu_line_has_the_contract_fields(gpu_lib):
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["kind"] == "port"
     assert d["parity_vs_oracle"]["idx_mismatches"] == 0 and d["parity_vs_oracle"]["T_bit_identical"]
     assert d["config"]["gathered_pose_records"] == 6 and "workload" in d["config"]
+    assert d["rccl_ranks"] == 1 and d["pose_exchange"].startswith("rccl")
+    ov = d["overlap"]
+    assert ov["mean_resident_nn_kernels"] > 0 and ov["nn_launch_us_overlapped"]["mean"] > 0 and ov["in_flight"] == 4
+    assert abs(ov["sum_nn_us_per_alignment"] / ov["mean_resident_nn_kernels"] - ov["per_alignment_wall_us_device_clock"]) < 1e-6 * ov["per_alignment_wall_us_device_clock"]
 
 
 @pytest.mark.parametrize("estimator", [0, 1])
