@@ -339,20 +339,23 @@ def overlap_pass(torch, handles, pools, P, n_align, iterations):
     counter, common to all streams (slam3d_icp_set_stamping: fire-and-forget atomics, no stream serialisation; a kernel
     tracer serialises the four streams and halves the overlap it is supposed to show).  The same pipelined stream as the
     timed region runs for n_align alignments; the stamps of every alignment are read at its fetch."""
-    recs = []
+    nh = len(handles)
+    per_handle = (n_align + nh - 1) // nh
+    n_align = per_handle * nh
+    st = Streamer(handles, pools, P)
     for h in handles:
-        h.set_stamping(True)
-    st = Streamer(handles, pools, P, on_fetch=lambda hi, h: recs.append((hi, h.get_stamps().astype(np.int64))))
-    st.run(4 * len(handles))          # re-capture the graphs with the stamp rows, fill the pipeline
-    recs.clear()
+        h.set_stamping(per_handle)            # the ring holds exactly the measured runs of this handle: nothing is copied meanwhile
+    st.run(2 * nh)                            # re-capture the graphs with the stamp ring, fill the pipeline (these runs fall out of the ring)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     st.run(n_align)
     torch.cuda.synchronize()
     host_s = time.perf_counter() - t0
+    per = [h.get_stamps().astype(np.int64) for h in handles]          # [runs, 2 iterations, 2] per handle, oldest first
     for h in handles:
-        h.set_stamping(False)
-    nh = len(handles)
+        h.set_stamping(0)
+    # alignment k of the stream ran on handle k % nh as that handle's run k // nh
+    recs = [(k % nh, per[k % nh][k // nh]) for k in range(n_align) if k // nh < len(per[k % nh])]
     trim = 2 * nh
     body = recs[trim:len(recs) - trim] if len(recs) > 4 * trim else recs
     TICK = 1e-8

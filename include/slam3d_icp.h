@@ -194,14 +194,17 @@ int slam3d_icp_get_timings(slam3d_icp_handle *h, float ms[4]);
 /* duration of each iteration's NN launch of the last run (ms), nn_ms[iterations]; SLAM3D_E_STATE unless the
  * run was profiled */
 int slam3d_icp_get_iteration_timings(slam3d_icp_handle *h, float *nn_ms);
-/* Launch stamps (measurement aid, off by default; no reference counterpart): when on, every NN and solve launch of the
- * following runs records when its first block started and its last wave ended on the device's constant-rate 100 MHz
- * real-time counter (one clock for all handles and streams of a GPU), with fire-and-forget atomics -- unlike HIP
- * events or a tracer this does not serialise the streams, so it shows how many launches of concurrent handles are
- * really resident at once.  get_stamps: (start, end) ticks (10 ns) of the last run's launches, out[rows][2]; rows
- * [0, iterations) = NN launches, [iterations, 2*iterations) = solve launches (unused rows read (~0, 0)). */
-int slam3d_icp_set_stamping(slam3d_icp_handle *h, int32_t on);
-int slam3d_icp_get_stamps(slam3d_icp_handle *h, uint64_t *out, int32_t rows);
+/* Launch stamps (measurement aid, off by default; no reference counterpart): with ring_runs > 0 every NN and solve
+ * launch of the following runs records when its first block started and its last wave ended on the device's
+ * constant-rate 100 MHz real-time counter (one clock for all handles and streams of a GPU), with fire-and-forget
+ * atomics into a device-resident ring of the last ring_runs runs -- unlike HIP events or a tracer this neither
+ * serialises the streams nor copies anything while runs are in flight, so it shows how many launches of concurrent
+ * handles are really resident at once.  ring_runs = 0 turns it off.
+ * get_stamps: (start, end) ticks (10 ns) of the launches of the last runs, oldest first, out[run][2*iterations][2]; rows
+ * [0, iterations) = NN launches, [iterations, 2*iterations) = solve launches (unused rows read (~0, 0)); *n_runs = runs
+ * written (<= max_runs, <= ring_runs).  Waits for the handle's stream. */
+int slam3d_icp_set_stamping(slam3d_icp_handle *h, int32_t ring_runs);
+int slam3d_icp_get_stamps(slam3d_icp_handle *h, uint64_t *out, int32_t max_runs, int32_t *n_runs);
 /* developer statistics of the LAST NN launch (slot 0), 20 int64 per source tile: clock at start / after
  * prologue / after the own scan / after the wide scan / at the end, tiles scanned, candidates, batches, where the
  * wave ran (HW_ID | XCC_ID << 32), its launch slot, real-time counter at start / end (100 MHz), clocks around the two block barriers, items drained.

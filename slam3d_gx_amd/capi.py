@@ -351,16 +351,20 @@ class IcpHandle:
         self._check(self.lib.slam3d_icp_get_iteration_timings(self._h, _vp(ms)), False)
         return ms[: self.params.iterations]
 
-    def set_stamping(self, on: bool = True):
-        self._check(self.lib.slam3d_icp_set_stamping(self._h, int(bool(on))), False)
+    def set_stamping(self, ring_runs: int = 64):
+        """launch stamps of the last `ring_runs` runs stay on the device (0: off)"""
+        self._check(self.lib.slam3d_icp_set_stamping(self._h, C.c_int32(int(ring_runs))), False)
+        self._stamp_ring = int(ring_runs)
 
-    def get_stamps(self) -> np.ndarray:
-        """(start, end) ticks (10 ns, device real-time counter) of the last run's launches: [2 * iterations, 2] uint64,
-        rows [0, iterations) NN launches, then the solve launches"""
+    def get_stamps(self, max_runs: int = 0) -> np.ndarray:
+        """(start, end) ticks (10 ns, device real-time counter) of the launches of the last runs, oldest first:
+        [runs, 2 * iterations, 2] uint64, rows [0, iterations) NN launches, then the solve launches"""
+        max_runs = max_runs or getattr(self, "_stamp_ring", 0) or 1
         rows = 2 * max(self.params.iterations, 1)
-        out = np.zeros((rows, 2), dtype=np.uint64)
-        self._check(self.lib.slam3d_icp_get_stamps(self._h, _vp(out), C.c_int32(rows)), False)
-        return out
+        out = np.zeros((max_runs, rows, 2), dtype=np.uint64)
+        n = C.c_int32(0)
+        self._check(self.lib.slam3d_icp_get_stamps(self._h, _vp(out), C.c_int32(max_runs), C.byref(n)), False)
+        return out[: n.value]
 
     def get_nn_debug(self) -> np.ndarray:
         nt = ((self.params.width + 7) // 8) * ((self.params.height + 7) // 8)

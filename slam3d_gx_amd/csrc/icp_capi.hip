@@ -91,9 +91,11 @@ struct slam3d_icp_handle {
     hipGraphExec_t graph_exec = nullptr;   // the captured iteration loop (slam3d_icp_run without profiling)
     int graph_B = 0;
     bool use_graph = true;
+    int nsets = 1;                // accumulator sets per pair (= iterations: one per launch when the solve runs at the head of the next)
+    int head_solve = 1;           // developer knob SLAM3D_HEAD_SOLVE: 0 every iteration as two launches (NN, k_solve_acc); 2 head solve without polling
     bool profiling = false;       // record the per-iteration events (each costs ~6 us of stream serialisation)
-    bool stamping = false;        // launch stamps (slam3d_icp_set_stamping): device rows + their pinned copy of the last run
-    unsigned long long *d_stamps = nullptr, *pin_stamps = nullptr; int stamp_rows = 0; bool ran_stamped = false;
+    bool stamping = false;        // launch stamps (slam3d_icp_set_stamping): a device ring of the last stamp_ring runs' rows
+    unsigned long long *d_stamps = nullptr; unsigned int *d_stamp_seq = nullptr; int stamp_rows = 0, stamp_ring = 0;
     bool ran_profiled = false;
     bool ran = false; int last_B = 0;
     int row0 = 0, row1 = 0; int dense_it = 0;
@@ -110,6 +112,13 @@ struct slam3d_icp_handle {
             return SLAM3D_E_HIP;                                                                \
         }                                                                                       \
     } while (0)
+
+static inline StampRing stamp_ring_of(const slam3d_icp_handle *h, bool on = true)
+{
+    StampRing sr;
+    sr.rows = (h->stamping && on) ? h->d_stamps : nullptr; sr.seq = h->d_stamp_seq; sr.ring = h->stamp_ring; sr.rows_per_run = h->stamp_rows;
+    return sr;
+}
 
 static inline int nn_mode_of(const slam3d_icp_handle *h)
 {
@@ -163,7 +172,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->src_c); F(h->tgt_c); F(h->ccounts); F(h->corr); F(h->ticket);
     F(h->flags); F(h->best); F(h->cd2); F(h->acc); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
     F(h->d_pairs); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4); F(h->corr_trace);
-    F(h->d_stamps); if (h->pin_stamps) (void)hipHostFree(h->pin_stamps);
+    F(h->d_stamps); F(h->d_stamp_seq);
     F(h->dbg); F(h->prevq); F(h->perm_d); F(h->cost); F(h->tgtB); F(h->qmax2);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->pin_res) (void)hipHostFree(h->pin_res);
@@ -263,7 +272,8 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     }
     A(dalloc(h->ccounts, (size_t)h->maxB * 4)); A(dalloc(h->ticket, (size_t)h->maxB));
     A(dalloc(h->corr, BS)); A(dalloc(h->flags, (size_t)h->maxB)); A(dalloc(h->cd2, BS)); A(dalloc(h->prevq, BS));
-    A(dalloc(h->acc, (size_t)h->maxB * ACC_R * ACC_STRIDE));
+    h->nsets = p->iterations > 0 ? p->iterations : 1;
+    A(dalloc(h->acc, (size_t)h->maxB * h->nsets * ACC_R * ACC_STRIDE));
     A(dalloc(h->cost, (size_t)h->maxB * tg.ntiles));
     {   // grid widths of the NN kernel, multiples of 8.  Cooperative build: as many waves as tiles -- with the row ownership every
         // XCD's list is then exactly full (640x480: 1,200 blocks of four tiles).  More, smaller-loaded blocks (20 % slack: 1,440)
@@ -288,6 +298,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     if (getenv("SLAM3D_NN_DEBUG")) A(dalloc(h->dbg, (size_t)tg.ntiles * 20));
     if (getenv("SLAM3D_NO_GRAPH") || getenv("SLAM3D_NN_DEBUG")) h->use_graph = false;
     if (getenv("SLAM3D_DENSE_BATCH")) h->dense_batch = atoi(getenv("SLAM3D_DENSE_BATCH"));
+    if (getenv("SLAM3D_HEAD_SOLVE")) h->head_solve = atoi(getenv("SLAM3D_HEAD_SOLVE"));
     A(dalloc(h->sums, (size_t)h->maxB * NSUMS)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
     A(dalloc(h->trace_T, (size_t)h->maxB * (iters + 1) * 16)); A(dalloc(h->trace_S, (size_t)h->maxB * iters * NSUMS));
     A(dalloc(h->d_pairs, (size_t)h->maxB));
@@ -311,7 +322,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     h->h_pairs.assign(h->maxB, PairPtrs{}); h->up_pairs.assign(h->maxB, PairPtrs{});
     (void)hipMemsetAsync(h->f_counts, 0, sizeof(int) * 4 * F, h->stream);
     (void)hipMemsetAsync(h->perm_d, 0xFF, sizeof(int) * (size_t)h->maxB * h->nn_gx_d * NN_WAVES, h->stream);
-    (void)hipMemsetAsync(h->acc, 0, sizeof(long long) * (size_t)h->maxB * ACC_R * ACC_STRIDE, h->stream);   // k_solve_acc re-zeroes after every launch
+    (void)hipMemsetAsync(h->acc, 0, sizeof(long long) * (size_t)h->maxB * h->nsets * ACC_R * ACC_STRIDE, h->stream);   // k_pair_init re-zeroes at every run
     *out = h;
     return SLAM3D_OK;
 }
@@ -574,14 +585,14 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
             TinitArgs ti;
             const int n = B - b0 < TINIT_ARGS ? B - b0 : TINIT_ARGS;
             memcpy(ti.T, T_init + (size_t)b0 * 16, sizeof(double) * 16 * n);
-            hipLaunchKernelGGL(k_pair_init, dim3(n), dim3(64), 0, s, ti, 1, b0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters,
-                               (h->stamping && b0 == 0) ? h->d_stamps : nullptr, h->stamp_rows);
+            hipLaunchKernelGGL(k_pair_init, dim3(n), dim3(64), 0, s, ti, 1, b0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters, h->nsets,
+                               stamp_ring_of(h, b0 == 0));
         }
     } else {
         TinitArgs ti;
         memset(&ti, 0, sizeof ti);
-        hipLaunchKernelGGL(k_pair_init, dim3(B), dim3(64), 0, s, ti, 0, 0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters,
-                               h->stamping ? h->d_stamps : nullptr, h->stamp_rows);
+        hipLaunchKernelGGL(k_pair_init, dim3(B), dim3(64), 0, s, ti, 0, 0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters, h->nsets,
+                               stamp_ring_of(h));
     }
     if (nn_mode_of(h) != SLAM3D_NN_TILES) {
         HIPCHK(h, hipMemsetAsync(h->best, 0xFF, sizeof(unsigned long long) * (size_t)B * tg.nslots, s));
@@ -608,19 +619,22 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
 {
     const TileGrid &tg = h->tg;
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
+    bool head = false;           // this iteration's solve runs at the head of the NEXT NN launch (icp_kernels.hpp)
     if (e0) HIPCHK(h, hipEventRecord(e0, s));
     if (nn_mode_of(h) == SLAM3D_NN_TILES) {
         // few pairs: cooperative blocks (latency bound); from 8 pairs per launch: every wave on its
         // own, 8 waves per SIMD (throughput bound); three staged tile records per wave in both
         const bool dense = B >= h->dense_batch;
+        head = h->head_solve != 0 && !dense && do_solve && h->p.estimator == SLAM3D_EST_POINT2PLANE;
         const int write_out = (!do_solve || it == iters - 1 || h->want_corr_trace) ? 1 : 0;      // corr / cd2: only the last iteration's are read
         int *perm = dense ? h->perm_d : nullptr;            // the cooperative build owns tiles by the interleaved default
         const int gx = dense ? h->nn_gx_d : h->nn_gx;
         // four instances: {throughput, cooperative} x {production, instrumented (SLAM3D_NN_DEBUG: per-tile clocks and counters)}
         auto launch = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_pairs, h->Tcur, h->corr, h->cd2, h->prevq,
-                               perm, h->cost, h->acc, h->g, tg, h->dbg, write_out, first,
-                               (h->stamping && do_solve) ? h->d_stamps + (size_t)it * STAMP_ROW : nullptr);
+                               perm, h->cost, h->acc, h->g, tg, h->dbg, write_out, head ? it : (first ? 0 : 1),
+                               stamp_ring_of(h, do_solve != 0), it,
+                               head ? h->head_solve : 0, h->trace_T, h->trace_S, h->flags, iters, h->nsets);
         };
         // (+ two with the optional S4g gates compiled in: the production instances carry none of that code)
         const bool gated = h->p.estimator == SLAM3D_EST_POINT2PLANE && (h->g.resid2 > 0.0f || h->g.min_ncos > 0.0f);
@@ -651,19 +665,23 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         }
         if (e1) HIPCHK(h, hipEventRecord(e1, s));
         hipLaunchKernelGGL(k_accumulate, dim3(tg.nchunks, B), dim3(CHUNK), 0, s, h->d_pairs, h->Tcur, h->best,
-                           h->corr, h->cd2, h->prevq, h->acc, h->g, tg);
+                           h->corr, h->cd2, h->prevq, h->acc, h->g, tg, h->nsets);
     }
     if (h->want_corr_trace && do_solve)          // this iteration's slot-order indices (index parity per iteration)
         HIPCHK(h, hipMemcpyAsync(h->corr_trace + (size_t)it * h->maxB * tg.nslots, h->corr, sizeof(int) * (size_t)B * tg.nslots,
                                  hipMemcpyDeviceToDevice, s));
-    if (h->p.estimator == SLAM3D_EST_POINT2PLANE)
+    if (head && it < iters - 1) {
+        // solved at the head of the next NN launch; only the run's last iteration keeps its k_solve_acc (result record)
+    } else if (h->p.estimator == SLAM3D_EST_POINT2PLANE)
         hipLaunchKernelGGL(k_solve_acc<0>, dim3(B), dim3(64), 0, s, h->acc, raw_out, h->Tcur, h->trace_T, h->trace_S, h->flags, h->d_pairs,
                            do_solve ? h->d_res : nullptr, it, iters, do_solve,
-                           (h->stamping && do_solve) ? h->d_stamps + (size_t)(iters + it) * STAMP_ROW : nullptr);
+                           stamp_ring_of(h, do_solve != 0), iters + it,
+                           h->nsets, head ? it : 0, head ? 1 : 0);
     else
         hipLaunchKernelGGL(k_solve_acc<1>, dim3(B), dim3(64), 0, s, h->acc, raw_out, h->Tcur, h->trace_T, h->trace_S, h->flags, h->d_pairs,
                            do_solve ? h->d_res : nullptr, it, iters, do_solve,
-                           (h->stamping && do_solve) ? h->d_stamps + (size_t)(iters + it) * STAMP_ROW : nullptr);
+                           stamp_ring_of(h, do_solve != 0), iters + it,
+                           h->nsets, 0, 0);
     HIPCHK(h, hipGetLastError());
     return SLAM3D_OK;
 }
@@ -711,9 +729,6 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
         }
     }
     HIPCHK(h, hipGetLastError());
-    if (h->stamping && iters > 0)
-        HIPCHK(h, hipMemcpyAsync(h->pin_stamps, h->d_stamps, sizeof(unsigned long long) * (size_t)h->stamp_rows * STAMP_ROW, hipMemcpyDeviceToHost, s));
-    h->ran_stamped = h->stamping && iters > 0;
     HIPCHK(h, hipEventRecord(h->ev[2], s));
     h->run_stream = s;
     h->ran = true;
@@ -734,34 +749,52 @@ extern "C" int slam3d_icp_set_profiling(slam3d_icp_handle *h, int32_t on)
 // Launch stamps: every NN / solve launch of the following runs records when its first block started and its last wave
 // ended on the GPU's constant-rate 100 MHz real-time counter, common to all handles and streams of the device: the
 // host can then tell how many launches really were resident at once without a tracer (profiles/r03_overlap.md).
-extern "C" int slam3d_icp_set_stamping(slam3d_icp_handle *h, int32_t on)
+// The rows of the last `ring_runs` runs stay in device memory; nothing is copied or synchronised while runs are in flight.
+extern "C" int slam3d_icp_set_stamping(slam3d_icp_handle *h, int32_t ring_runs)
 {
-    if (!h) return SLAM3D_E_INVALID;
+    if (!h || ring_runs < 0 || ring_runs > 4096) return SLAM3D_E_INVALID;
     HIPCHK(h, hipSetDevice(h->p.device));
-    if (on && !h->d_stamps) {
+    HIPCHK(h, hipStreamSynchronize(h->run_stream ? h->run_stream : h->stream));
+    if (ring_runs > 0 && ring_runs != h->stamp_ring) {
+        if (h->d_stamps) { (void)hipFree(h->d_stamps); h->d_stamps = nullptr; }
         h->stamp_rows = 2 * (h->p.iterations > 0 ? h->p.iterations : 1);
-        const size_t n = sizeof(unsigned long long) * (size_t)h->stamp_rows * STAMP_ROW;
-        HIPCHK(h, hipMalloc((void **)&h->d_stamps, n));
-        HIPCHK(h, hipHostMalloc((void **)&h->pin_stamps, n, hipHostMallocDefault));
+        h->stamp_ring = ring_runs;
+        HIPCHK(h, hipMalloc((void **)&h->d_stamps, sizeof(unsigned long long) * (size_t)ring_runs * h->stamp_rows * STAMP_ROW));
+        if (!h->d_stamp_seq) HIPCHK(h, hipMalloc((void **)&h->d_stamp_seq, sizeof(unsigned int)));
     }
-    if (h->stamping != (on != 0)) h->graph_B = 0;        // the stamp rows are kernel arguments of the captured launches
-    h->stamping = on != 0;
+    if (ring_runs > 0) {        // a fresh ring: no run recorded yet
+        HIPCHK(h, hipMemset(h->d_stamps, 0, sizeof(unsigned long long) * (size_t)h->stamp_ring * h->stamp_rows * STAMP_ROW));
+        HIPCHK(h, hipMemset(h->d_stamp_seq, 0, sizeof(unsigned int)));
+    }
+    if (h->stamping != (ring_runs > 0)) h->graph_B = 0;  // the ring is a kernel argument of the captured launches
+    h->stamping = ring_runs > 0;
     return SLAM3D_OK;
 }
 
-// (start, end) ticks of the last FETCHED run's launches: rows [0, iterations) the NN launches, [iterations, 2 iterations)
-// the solve launches; a launch that did not run (or was not stamped) reads (~0, 0).  10 ns per tick.
-extern "C" int slam3d_icp_get_stamps(slam3d_icp_handle *h, uint64_t *out /* [rows][2] */, int32_t rows)
+// (start, end) ticks (10 ns) of the launches of the last runs, oldest first: out[run][row][2], rows [0, iterations) the NN
+// launches, [iterations, 2 iterations) the solve launches (a launch that did not run reads (~0, 0)).  Returns through
+// n_runs how many runs were written (at most max_runs and the ring size).  Synchronises the handle's stream.
+extern "C" int slam3d_icp_get_stamps(slam3d_icp_handle *h, uint64_t *out, int32_t max_runs, int32_t *n_runs)
 {
-    if (!h || !out) return SLAM3D_E_INVALID;
-    if (!h->ran || !h->ran_stamped || rows > h->stamp_rows) return SLAM3D_E_STATE;
-    HIPCHK(h, hipEventSynchronize(h->ev[2]));
-    for (int r = 0; r < rows; ++r) {
-        const unsigned long long *row = h->pin_stamps + (size_t)r * STAMP_ROW;
-        unsigned long long t0 = ~0ull, t1 = 0ull;
-        for (int k = 0; k < STAMP_R; ++k) { if (row[k] < t0) t0 = row[k]; if (row[STAMP_R + k] > t1) t1 = row[STAMP_R + k]; }
-        out[2 * r] = t0; out[2 * r + 1] = t1;
+    if (!h || !out || !n_runs || max_runs <= 0) return SLAM3D_E_INVALID;
+    if (!h->d_stamps) return SLAM3D_E_STATE;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    HIPCHK(h, hipStreamSynchronize(h->run_stream ? h->run_stream : h->stream));
+    unsigned int seq = 0;
+    HIPCHK(h, hipMemcpy(&seq, h->d_stamp_seq, sizeof seq, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> ring((size_t)h->stamp_ring * h->stamp_rows * STAMP_ROW);
+    HIPCHK(h, hipMemcpy(ring.data(), h->d_stamps, ring.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    int n = (int)std::min<unsigned int>(seq, (unsigned int)std::min(max_runs, h->stamp_ring));
+    for (int k = 0; k < n; ++k) {
+        const unsigned int run = (seq - (unsigned int)(n - 1 - k)) % (unsigned int)h->stamp_ring;      // run numbers start at 1
+        for (int r = 0; r < h->stamp_rows; ++r) {
+            const unsigned long long *row = ring.data() + ((size_t)run * h->stamp_rows + r) * STAMP_ROW;
+            unsigned long long t0 = ~0ull, t1 = 0ull;
+            for (int j = 0; j < STAMP_R; ++j) { if (row[j] < t0) t0 = row[j]; if (row[STAMP_R + j] > t1) t1 = row[STAMP_R + j]; }
+            out[((size_t)k * h->stamp_rows + r) * 2] = t0; out[((size_t)k * h->stamp_rows + r) * 2 + 1] = t1;
+        }
     }
+    *n_runs = n;
     return SLAM3D_OK;
 }
 

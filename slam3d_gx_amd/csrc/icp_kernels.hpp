@@ -50,9 +50,19 @@ constexpr int RES_REC = 48;        // doubles per pair in the host-mapped result
 // Launch stamps (opt-in, slam3d_icp_set_stamping): every block of a stamped launch folds the constant-rate 100 MHz
 // real-time counter (common to all XCDs, unlike s_memtime) into the launch's row -- STAMP_R replicas of the earliest
 // start (atomic min) followed by STAMP_R replicas of the latest end (atomic max), fire-and-forget atomics spread
-// over the replicas.  They tell WHEN a launch really occupied the chip without a tracer serialising the streams
-// (profiles/r03_overlap.md).  A null pointer (the default) costs one scalar branch.
+// over the replicas, ONE of each per block (the block's last wave stamps the end).  They tell WHEN a launch really
+// occupied the chip without a tracer serialising the streams (profiles/r03_overlap.md).  The rows of the last
+// `ring` runs stay on the device (StampRing: k_pair_init advances `seq` and resets the new run's rows; a launch finds
+// its row through seq), so nothing is copied while the measurement runs.  A null pointer (the default) costs one
+// scalar branch.
 constexpr int STAMP_R = 16, STAMP_ROW = 2 * STAMP_R;
+struct StampRing { unsigned long long *rows; unsigned int *seq; int ring, rows_per_run; };
+__device__ __forceinline__ unsigned long long *stamp_row(const StampRing &sr, int row)
+{
+    if (!sr.rows) return nullptr;
+    const unsigned int run = __builtin_amdgcn_readfirstlane(*sr.seq) % (unsigned int)sr.ring;
+    return sr.rows + ((size_t)run * sr.rows_per_run + row) * STAMP_ROW;
+}
 __device__ __forceinline__ void stamp_start(unsigned long long *__restrict__ row, int c)
 {
     if (row) atomicMin(row + (c & (STAMP_R - 1)), (unsigned long long)wall_clock64());
@@ -61,6 +71,7 @@ __device__ __forceinline__ void stamp_end(unsigned long long *__restrict__ row, 
 {
     if (row) atomicMax(row + STAMP_R + (c & (STAMP_R - 1)), (unsigned long long)wall_clock64());
 }
+
 constexpr int PAIR_ARGS = 32;
 struct PairArgs { PairPtrs p[PAIR_ARGS]; };
 // the pair table travels as a kernel argument (copied at launch), not through pinned host memory
@@ -428,18 +439,28 @@ constexpr int TINIT_ARGS = 16;
 struct TinitArgs { double T[TINIT_ARGS][16]; };
 __global__ __launch_bounds__(64) void k_pair_init(TinitArgs ti, int has_T, int b0, double *__restrict__ Tcur,
                                                   double *__restrict__ trace_T, int *__restrict__ flags,
-                                                  long long *__restrict__ acc, unsigned int *__restrict__ ticket, int iters,
-                                                  unsigned long long *__restrict__ stamps /* nullable */, int stamp_rows)
+                                                  long long *__restrict__ acc, unsigned int *__restrict__ ticket, int iters, int nsets,
+                                                  StampRing sr /* rows null: no stamps */)
 {
     const int k = blockIdx.x, b = b0 + k, lane = threadIdx.x;
-    if (stamps && k == 0)          // launch stamps (opt-in): start = min over the blocks -> ~0, end = max -> 0
-        for (int j = lane; j < stamp_rows * STAMP_ROW; j += 64) stamps[j] = (j % STAMP_ROW) < STAMP_R ? ~0ull : 0ull;
-    for (int j = lane; j < ACC_R * ACC_STRIDE; j += 64) acc[(size_t)b * ACC_R * ACC_STRIDE + j] = 0;
+    if (sr.rows && k == 0) {       // launch stamps (opt-in): this run takes the next slot of the ring; start = min -> ~0, end = max -> 0
+        const unsigned int run = (*sr.seq + 1u) % (unsigned int)sr.ring;
+        unsigned long long *__restrict__ rows = sr.rows + (size_t)run * sr.rows_per_run * STAMP_ROW;
+        for (int j = lane; j < sr.rows_per_run * STAMP_ROW; j += 64) rows[j] = (j % STAMP_ROW) < STAMP_R ? ~0ull : 0ull;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) *sr.seq = *sr.seq + 1u;
+    }
+    {   // every accumulator set of the pair (one per iteration when the solve runs at the head of the next launch)
+        longlong2 *__restrict__ a2 = reinterpret_cast<longlong2 *>(acc + (size_t)b * nsets * ACC_R * ACC_STRIDE);
+        for (int j = lane; j < nsets * ACC_R * ACC_STRIDE / 2; j += 64) a2[j] = make_longlong2(0, 0);
+    }
     if (lane < 16) {
         const double v = has_T ? ti.T[k % TINIT_ARGS][lane] : ((lane % 5 == 0) ? 1.0 : 0.0);
         Tcur[b * 16 + lane] = v;
         trace_T[((size_t)b * (iters + 1)) * 16 + lane] = v;
     }
+    // entry 15 of a pose row is the head solve's ready flag: not ready
+    for (int j = 1 + lane; j <= iters; j += 64) trace_T[((size_t)b * (iters + 1) + j) * 16 + 15] = 0.0;
     if (lane == 0) { flags[b] = 0; ticket[b] = 0u; }
 }
 
@@ -498,6 +519,17 @@ __device__ __forceinline__ Rt load_rt(const double *__restrict__ T)
     m.r00 = (float)T[0]; m.r01 = (float)T[1]; m.r02 = (float)T[2];  m.t0 = (float)T[3];
     m.r10 = (float)T[4]; m.r11 = (float)T[5]; m.r12 = (float)T[6];  m.t1 = (float)T[7];
     m.r20 = (float)T[8]; m.r21 = (float)T[9]; m.r22 = (float)T[10]; m.t2 = (float)T[11];
+    return m;
+}
+
+// the same from LDS (wave-uniform values: moved to SGPRs, so the pose costs no VGPR across the kernel)
+__device__ __forceinline__ float uni_f(double v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)v))); }
+__device__ __forceinline__ Rt load_rt_lds(const double *T)
+{
+    Rt m;
+    m.r00 = uni_f(T[0]); m.r01 = uni_f(T[1]); m.r02 = uni_f(T[2]);  m.t0 = uni_f(T[3]);
+    m.r10 = uni_f(T[4]); m.r11 = uni_f(T[5]); m.r12 = uni_f(T[6]);  m.t1 = uni_f(T[7]);
+    m.r20 = uni_f(T[8]); m.r21 = uni_f(T[9]); m.r22 = uni_f(T[10]); m.t2 = uni_f(T[11]);
     return m;
 }
 
@@ -962,7 +994,7 @@ __global__ __launch_bounds__(CHUNK) void k_accumulate(const PairPtrs *__restrict
                                                       unsigned long long *__restrict__ best,
                                                       int *__restrict__ corr, float *__restrict__ cd2,
                                                       float4 *__restrict__ prevq,
-                                                      long long *__restrict__ acc, Geometry g, TileGrid tg)
+                                                      long long *__restrict__ acc, Geometry g, TileGrid tg, int nsets)
 {
     const int b = blockIdx.y, c = blockIdx.x;
     const int t = c * TILES_PER_CHUNK + (threadIdx.x >> 6);
@@ -983,7 +1015,7 @@ __global__ __launch_bounds__(CHUNK) void k_accumulate(const PairPtrs *__restrict
     sg.r[6] = m.r20; sg.r[7] = m.r21; sg.r[8] = m.r22;
     finish_slot<true>(valid, key, px, py, pz, pairs[b].tgt, pairs[b].nrm, g.gate2, g.estimator, corr + gs, cd2 + gs,
                       prevq + gs, rb, true, -2, &sg);
-    tile_accumulate(g.estimator, rb, acc + ((size_t)b * ACC_R + (c % ACC_R)) * ACC_STRIDE);
+    tile_accumulate(g.estimator, rb, acc + ((size_t)b * nsets * ACC_R + (c % ACC_R)) * ACC_STRIDE);
 }
 
 // ------------------------------------------------------------------ S4, tile-pruned exact NN
@@ -1044,6 +1076,25 @@ __device__ __forceinline__ int lds_fetch_add_uniform(int *p, int v)
 // the faster one while a launch holds few pairs (latency bound: the slowest block ends the launch).  <3, 8, not
 // cooperative>: every wave sweeps its own cells -- no shared lists, no block barriers, 14 KB of LDS, 49 VGPRs -- at the
 // full 8 waves per SIMD; it wins when many pairs fill the chip (throughput bound; from 8 pairs per launch on).
+__device__ __forceinline__ double wave_solve_point2plane(const double *tot, const double *sh, int &rc_out);     // section S5 below
+
+// ---- the solve at the HEAD of the next launch (cooperative build, point-to-plane; `head` argument) -------------------
+// An iteration used to be two launches: the NN kernel and k_solve_acc (5.7 us of a 29 us iteration, plus two launch
+// boundaries).  With `head` set, launch k accumulates into ITS OWN accumulator set (acc[b][k], zeroed once per run by
+// k_pair_init, never cleared in between) and launch k+1 begins by turning set k into T_{k+1}:
+//   * block (0, b) -- the first workgroup of pair b the dispatcher places -- sums the 16 x 29 replicas, runs the
+//     lane-parallel LDL^T (wave_solve_point2plane, the code k_solve_acc runs), writes trace_S[k], the flags and the new
+//     pose into trace_T[k+1], entry 15 (always 1.0 in a pose) LAST with release semantics: it doubles as the ready flag
+//     (k_pair_init zeroes it for every row of the run);
+//   * the other blocks' wave 0 polls that flag (agent-scope loads, s_sleep between) and reads the 16 doubles;
+//   * a poller that has not seen the flag after HEAD_POLLS tries (block 0 not resident yet -- the dispatch order is an
+//     observation, not a contract) simply solves for itself: same inputs, same code, same bits.  Nothing ever depends
+//     on another block for CORRECTNESS or termination, only for speed;
+//   * every wave of the block then takes T from LDS.
+// One k_solve_acc launch remains, after the last NN launch (T_iters, the result record).  Iterations x 2 launches become
+// iterations + 1.
+constexpr int HEAD_POLLS = 400;      // x ~0.15 us: ~60 us until a poller gives up on block 0 and solves by itself
+
 constexpr int PROJ_RMAX = 3;         // largest window radius the projective search takes on (7x7 pixels)
 constexpr int QSTRIDE = 17;                        // float4 per staged quadrant: 16 candidates + 1 pad: lane-specific reads of
                                                    // different quadrants then fall into different banks
@@ -1073,9 +1124,13 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                                                         long long *__restrict__ acc, Geometry g, TileGrid tg,
                                                         long long *__restrict__ dbg /* DBG builds only: 20 x int64 per tile */,
                                                         int write_out /* corr / cd2 wanted (last iteration) */,
-                                                        int first /* a run's first iteration: no previous match */,
-                                                        unsigned long long *__restrict__ stamp /* this launch's stamp row, nullable */)
+                                                        int it /* iteration of the run; 0: no previous match to start from */,
+                                                        StampRing sring /* launch stamps; rows null (the default): none */, int stamp_idx,
+                                                        int head /* solve iteration it-1 at the head of this launch (see above) */,
+                                                        double *__restrict__ trace_T, double *__restrict__ trace_S, int *__restrict__ flags,
+                                                        int iters, int nsets /* accumulator sets per pair */)
 {
+    const int first = it == 0;
     __shared__ float4 stage_all[NN_WAVES][NN_STAGE * STAGE_REC];
     __shared__ int wcost[NN_WAVES];                                    // cycles spent for each owner (all helpers)
     __shared__ float qpos[NN_WAVES][3][TILE_SLOTS];                   // p'.x / .y / .z of each owner's queries (SoA: 3 KB, not 4)
@@ -1086,6 +1141,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     __shared__ int items[NN_MAX_ITEMS];                                // phase A work: (owner wave << 16 | coarse cell)
     __shared__ int titems[NN_MAX_TITEMS];                              // phase B work: (owner wave << 24 | target tile)
     __shared__ int n_items, next_item, n_titems, next_titem;
+    __shared__ double head_T[16];                                     // the pose of this launch when it was solved at the head
     const long long clk0 = DBG ? clock64() : 0;
     const long long rt0 = DBG ? (long long)wall_clock64() : 0;
     long long clk1 = 0, clk2 = 0, clk3 = 0, clkP = 0, clkB1 = 0, clkD = 0, clkM = 0, clkE = 0;
@@ -1095,7 +1151,9 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.y, c = blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x == 0) stamp_start(stamp, c);
+    __shared__ int waves_done;
+    unsigned long long *const stamp = stamp_row(sring, stamp_idx);
+    if (threadIdx.x == 0) { stamp_start(stamp, c); waves_done = 0; }
     // ownership: the measured-cost balanced assignment once k_balance has run (perm >= 0 tile, -2 none),
     // before that (-1) tiles interleaved over the image bands
     // (the cooperative build always uses the interleaved default: on a stream of distinct pairs the measured-cost deal
@@ -1135,6 +1193,53 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     const float4 *__restrict__ TT = pp.tgtT;
     if (threadIdx.x == 0) { n_items = 0; next_item = 0; n_titems = 0; next_titem = 0; }
     if (threadIdx.x < NN_WAVES) wcost[threadIdx.x] = 0;
+    // the launch's pose goes through LDS in both cases: read from Tcur (k_solve_acc wrote it), or solved right here
+    if (!(COOP && head && it > 0)) { if (threadIdx.x < 16) head_T[threadIdx.x] = Tcur[b * 16 + threadIdx.x]; }
+    if constexpr (COOP) {
+        if (head && it > 0) {
+            if (w == 0) {
+                double *__restrict__ Tnew = trace_T + ((size_t)b * (iters + 1) + it) * 16;
+                double *tot = reinterpret_cast<double *>(stage_all[0]);          // 32 + 16 doubles of this wave's (still unused) stage slab
+                double *tsh = tot + 32;
+                bool have = false;
+                if (c != 0 && head == 1) {          // (head == 2, a developer knob: nobody polls, every block solves for itself)
+                    for (int poll = 0; poll < HEAD_POLLS; ++poll) {
+                        const unsigned long long f = __hip_atomic_load(reinterpret_cast<unsigned long long *>(Tnew + 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__builtin_amdgcn_readfirstlane((int)(f >> 32)) != 0) { have = true; break; }      // 1.0 = 0x3ff00000'00000000
+                        __builtin_amdgcn_s_sleep(5);
+                    }
+                }
+                if (have) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    if (lane < 16)
+                        head_T[lane] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(Tnew + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                } else {
+                    const long long *__restrict__ A = acc + ((size_t)b * nsets + (it - 1)) * ACC_R * ACC_STRIDE;
+                    if (lane < NSUMS) {
+                        long long q = 0;
+#pragma unroll
+                        for (int r = 0; r < ACC_R; ++r) q += __hip_atomic_load(A + r * ACC_STRIDE + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        tot[lane] = (double)q / FIX_SCALE;
+                    }
+                    if (lane < 16) tsh[lane] = trace_T[((size_t)b * (iters + 1) + (it - 1)) * 16 + lane];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    int rc;
+                    const double Tn = wave_solve_point2plane(tot, tsh, rc);
+                    if (lane < 16) head_T[lane] = Tn;
+                    if (c == 0) {                                   // the one block that publishes
+                        if (lane < NSUMS) trace_S[((size_t)b * iters + (it - 1)) * NSUMS + lane] = tot[lane];
+                        if (lane == 0 && rc != 1) flags[b] = flags[b] | (rc == 2 ? 1 : 2);
+                        if (lane < 15) __hip_atomic_store(reinterpret_cast<unsigned long long *>(Tnew + lane), (unsigned long long)__double_as_longlong(Tn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        if (lane == 15) __hip_atomic_store(reinterpret_cast<unsigned long long *>(Tnew + 15), (unsigned long long)__double_as_longlong(Tn), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+    }
     __syncthreads();
 
     // ---- "current query" context: the wave's own tile in step 1, an item's owner in step 3
@@ -1361,7 +1466,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         // points project: the pinhole of the frame geometry gives the target pixel of a lane near the patch centre, and the
         // (up to 2x2) block of tiles the 8x8 patch covers around it.  Unlike last iteration's matches this follows the pose:
         // the second and third iteration of a run, where the pose still moves by centimetres, start in the right tiles.
-        const Rt m = load_rt(Tcur + b * 16);
+        const Rt m = load_rt_lds(head_T);
         xform(m, s4.x, s4.y, s4.z, px, py, pz);
         int th = -1;
         int rox = 0, roy = 0;                                     // origin of the window region of S3D_PROJ_SEARCH
@@ -1668,7 +1773,11 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     if constexpr (DBG) clkE = clock64();
     if constexpr (COOP) __syncthreads();
     if constexpr (DBG) clk3 = clock64();
-    if (!has_tile) { if (lane == 0) stamp_end(stamp, c); return; }
+    // (end stamp: the last of the block's four waves to get here, found with an LDS counter -- one atomic per block)
+    auto stamp_wave_end = [&]() __attribute__((always_inline)) {
+        if (stamp && lane == 0 && atomicAdd(&waves_done, 1) == NN_WAVES - 1) stamp_end(stamp, c);
+    };
+    if (!has_tile) { stamp_wave_end(); return; }
     if constexpr (!COOP) { if (lane == 0) cost[(size_t)b * tg.ntiles + t] = wcost[w]; }          // input of k_balance
     // ================= step 4: this wave's own tile: fused S4 accumulation =================
     if constexpr (COOP) {
@@ -1685,7 +1794,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     RowBasis rb;
     if constexpr (GATED) {             // the optional S4g gates: their own instances, the production ones carry none of this
         SlotGates sg;
-        const Rt m = load_rt(Tcur + b * 16);
+        const Rt m = load_rt_lds(head_T);
         sg.resid2 = g.resid2; sg.min_ncos = g.min_ncos; sg.snrm = pp.snrm; sg.spix = max(pix, 0);
         sg.r[0] = m.r00; sg.r[1] = m.r01; sg.r[2] = m.r02; sg.r[3] = m.r10; sg.r[4] = m.r11; sg.r[5] = m.r12;
         sg.r[6] = m.r20; sg.r[7] = m.r21; sg.r[8] = m.r22;
@@ -1694,8 +1803,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     } else
         finish_slot<false>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs_ep, cd2 + gs_ep, prevq + gs_ep, rb,
                            write_out != 0, own_jprev);
-    tile_accumulate(g.estimator, rb, acc + ((size_t)b * ACC_R + (c % ACC_R)) * ACC_STRIDE);
-    if (lane == 0) stamp_end(stamp, c + w);
+    tile_accumulate(g.estimator, rb, acc + (((size_t)b * nsets + (head ? it : 0)) * ACC_R + (c % ACC_R)) * ACC_STRIDE);
+    stamp_wave_end();
     if (DBG && dbg && b == 0 && lane == 0) {
         long long *d = dbg + (size_t)t * 20;
         d[0] = clk0; d[1] = clk1; d[2] = clk2; d[3] = clk3; d[4] = clock64();
@@ -1966,14 +2075,12 @@ __device__ __forceinline__ double bcast_d(double v, int src_lane)
     return __hiloint2double(hi, lo);
 }
 
-// tot: the 29 sums (LDS), sh: T of the pair (LDS, 16 doubles); all 64 lanes of the wave call this
-__device__ __forceinline__ void wave_solve_update_point2plane(const double *tot, const double *sh, double *__restrict__ Tcur_b,
-                                                              double *__restrict__ trace_T_b, double *__restrict__ trace_S_b,
-                                                              int *__restrict__ flag_b, int it, double *__restrict__ res_rec /* nullable */,
-                                                              const PairPtrs &pp)
+// tot: the 29 sums (LDS), sh: T of the pair (LDS, 16 doubles); all 64 lanes of the wave call this.  Returns in lane
+// l < 16 entry l of the updated pose (the old one when the solve failed) and rc: 1 solved, 2 solved after damping, 0 no
+// update.  Values only -- who stores what is the caller's business (k_solve_acc; the head of the NN launch).
+__device__ __forceinline__ double wave_solve_point2plane(const double *tot, const double *sh, int &rc_out)
 {
     const int lane = threadIdx.x & 63;
-    if (lane < NSUMS) trace_S_b[(size_t)it * NSUMS + lane] = tot[lane];
     const int i = lane < 6 ? lane : 5;                      // lanes >= 6 shadow row 5 (their values are never used)
     int rc = 0;
     double x0 = 0, x1 = 0, x2 = 0, x3 = 0, x4 = 0, x5 = 0;
@@ -2053,8 +2160,21 @@ __device__ __forceinline__ void wave_solve_update_point2plane(const double *tot,
         } else if (lane < 16) {
             Tn = lane == 15 ? 1.0 : 0.0;
         }
-        if (lane < 16) Tcur_b[lane] = Tn;
     }
+    rc_out = rc;
+    return Tn;
+}
+
+__device__ __forceinline__ void wave_solve_update_point2plane(const double *tot, const double *sh, double *__restrict__ Tcur_b,
+                                                              double *__restrict__ trace_T_b, double *__restrict__ trace_S_b,
+                                                              int *__restrict__ flag_b, int it, double *__restrict__ res_rec /* nullable */,
+                                                              const PairPtrs &pp)
+{
+    const int lane = threadIdx.x & 63;
+    if (lane < NSUMS) trace_S_b[(size_t)it * NSUMS + lane] = tot[lane];
+    int rc;
+    const double Tn = wave_solve_point2plane(tot, sh, rc);
+    if (lane < 16) Tcur_b[lane] = Tn;                    // (a failed solve returns the old pose)
     if (lane < 16) trace_T_b[(size_t)(it + 1) * 16 + lane] = Tn;
     int flag = 0;
     if (lane == 0) {
@@ -2079,12 +2199,15 @@ __global__ __launch_bounds__(64) void k_solve_acc(long long *__restrict__ acc, l
                                                   double *__restrict__ Tcur, double *__restrict__ trace_T,
                                                   double *__restrict__ trace_S, int *__restrict__ flags,
                                                   const PairPtrs *__restrict__ pairs, double *__restrict__ res_host,
-                                                  int it, int iters, int do_solve, unsigned long long *__restrict__ stamp /* nullable */)
+                                                  int it, int iters, int do_solve, StampRing sring, int stamp_idx,
+                                                  int nsets, int set /* which accumulator set of the pair: 0, or `it` after head-solved launches */,
+                                                  int from_trace /* T_it from trace_T[it] (head-solved launches leave Tcur at T_0) */)
 {
     __shared__ double tot[32], Tsh[16];
     const int b = blockIdx.x, k = threadIdx.x;
+    unsigned long long *const stamp = stamp_row(sring, stamp_idx);
     if (k == 0) stamp_start(stamp, b);
-    long long *__restrict__ A = acc + (size_t)b * ACC_R * ACC_STRIDE;
+    long long *__restrict__ A = acc + ((size_t)b * nsets + set) * ACC_R * ACC_STRIDE;
     if (k < NSUMS) {
         long long q = 0;
 #pragma unroll
@@ -2094,7 +2217,7 @@ __global__ __launch_bounds__(64) void k_solve_acc(long long *__restrict__ acc, l
         if (raw_out) raw_out[b * NSUMS + k] = q;
         tot[k] = (double)q / FIX_SCALE;
     }
-    if (k < 16) Tsh[k] = Tcur[b * 16 + k];
+    if (k < 16) Tsh[k] = from_trace ? trace_T[((size_t)b * (iters + 1) + it) * 16 + k] : Tcur[b * 16 + k];
     __syncthreads();
     if constexpr (EST == 0) {                 // point-to-plane: the whole wave solves (lane-parallel LDL^T, no scratch)
         if (do_solve)

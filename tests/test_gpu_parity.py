@@ -511,6 +511,38 @@ def test_bench_gpus2_launched_as_a_plain_process(gpu_lib):
     assert d["rccl_ranks"] == 0 and d["pose_exchange"].startswith("gloo")
 
 
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_head_solve_modes_are_bit_identical(gpu_lib, mode, monkeypatch):
+    """The solve at the head of the next NN launch (default, 1), the same with every block solving for itself instead of
+    polling block 0 (2: the fallback path of a poller that gives up) and the two-launch form (0): every iterate, every
+    sum, the flags and the result record equal the oracle's -- single pair, a 3-pair launch, and a solve that fails."""
+    monkeypatch.setenv("SLAM3D_HEAD_SOLVE", mode)
+    iters = 9
+    prs = [_pair(3000 + i, 320, 240) for i in range(3)]
+    intr = prs[0][0].intr
+    with capi.IcpHandle(capi.default_params(intr, iterations=iters, max_batch=3)) as h:
+        for rep in range(2):                                          # second time: graph replay on cached frames
+            res = h.align_batch([p[1] for p in prs], [p[2] for p in prs])
+            for b, (pr, s4, t4) in enumerate(prs):
+                ro = O.icp(s4, t4, O.params(intr, iterations=iters, nn_method=1))
+                Tt, St = h.get_trace(b)
+                assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:iters], ro["sums_trace"]), (mode, rep, b)
+                assert np.array_equal(res[b]["T_raw"], ro["T_trace"][-1]) and res[b]["inliers"] == ro["inliers"] and res[b]["status"] == ro["status"]
+                assert np.array_equal(h.get_correspondences(b)[0], ro["idx"])
+        one = h.align(prs[1][1], prs[1][2])                           # B = 1 on the same handle (another graph)
+        assert np.array_equal(one["T_raw"], res[1]["T_raw"])
+    w, hh = 160, 120
+    intr = synth.Intrinsics.scaled(w, hh)
+    wall = synth.backproject_numpy(np.full((hh, w), 2000, dtype=np.uint16), intr)
+    Ti = np.eye(4); Ti[0, 3] = 0.01
+    with capi.IcpHandle(capi.default_params(intr, iterations=3)) as hd:
+        r = hd.align(wall, wall, Ti)
+        Tt, St = hd.get_trace(0)
+    ro = O.icp(wall, wall, O.params(intr, iterations=3, nn_method=0), T_init=Ti)
+    assert r["status"] == ro["status"] == 3 and np.array_equal(r["T_raw"], ro["T_trace"][-1])
+    assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:3], ro["sums_trace"])
+
+
 def test_launch_stamps_are_ordered_and_change_nothing(gpu_lib):
     """slam3d_icp_set_stamping: every NN / solve launch reports (start, end) on the device's real-time counter; the
     launches of a run follow each other, two handles in flight share the clock, and the results are bit-identical with
@@ -520,13 +552,17 @@ def test_launch_stamps_are_ordered_and_change_nothing(gpu_lib):
     with capi.IcpHandle(capi.default_params(pr.intr, iterations=iters)) as h, capi.IcpHandle(capi.default_params(pr.intr, iterations=iters)) as h2:
         want = h.align(s4, t4)
         with pytest.raises(capi.Slam3dError):
-            h.get_stamps()                                            # that run was not stamped
-        h.set_stamping(True); h2.set_stamping(True)
+            h.get_stamps()                                            # no ring yet
+        h.set_stamping(3); h2.set_stamping(3)
         h.set_clouds_host(0, s4, t4); h2.set_clouds_host(0, s4, t4)
-        h.run(1); h2.run(1)
-        got, got2 = h.fetch_results(1)[0], h2.fetch_results(1)[0]
-        st, st2 = h.get_stamps().astype(np.int64), h2.get_stamps().astype(np.int64)
-        h.set_stamping(False)
+        for _ in range(5):                                            # five runs through a ring of three
+            h.run(1); h2.run(1)
+            got, got2 = h.fetch_results(1)[0], h2.fetch_results(1)[0]
+        ring, ring2 = h.get_stamps().astype(np.int64), h2.get_stamps().astype(np.int64)
+        assert ring.shape == (3, 2 * iters, 2) and ring2.shape == (3, 2 * iters, 2)
+        assert (ring[1:, 0, 0] > ring[:-1, iters - 1, 1]).all()       # oldest first: run k+1 starts after run k's last NN launch ended
+        st, st2 = ring[-1], ring2[-1]
+        h.set_stamping(0)
         again = h.align(s4, t4)
     for g in (got, got2, again):
         assert np.array_equal(g["T_raw"], want["T_raw"]) and g["inliers"] == want["inliers"]
