@@ -92,7 +92,7 @@ struct slam3d_icp_handle {
     int graph_B = 0;
     bool use_graph = true;
     int nsets = 1;                // accumulator sets per pair (= iterations: one per launch when the solve runs at the head of the next)
-    int head_solve = 1;           // developer knob SLAM3D_HEAD_SOLVE: 0 every iteration as two launches (NN, k_solve_acc); 2 head solve without polling
+    int head_solve = 1;           // 1: head solve, polling while other runs are in flight; developer knob SLAM3D_HEAD_SOLVE: 0 two launches per iteration, 2 never poll, 3 always poll
     bool profiling = false;       // record the per-iteration events (each costs ~6 us of stream serialisation)
     bool stamping = false;        // launch stamps (slam3d_icp_set_stamping): a device ring of the last stamp_ring runs' rows
     unsigned long long *d_stamps = nullptr; unsigned int *d_stamp_seq = nullptr; int stamp_rows = 0, stamp_ring = 0;
@@ -485,7 +485,7 @@ static int pick_nsplit(const slam3d_icp_handle *h, int B)
 // Preprocessing of a run: every (frame, role) the pairs [0,B) use and that is stale is rebuilt ONCE (normals, tile
 // records, boxes / source slots), the pair table is refreshed when it changed (kernel arguments: nothing in flight
 // reads host memory), and the pairs' iteration state is reset (T_init by kernel argument too).
-static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init, hipStream_t s)
+static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init, hipStream_t s, int count_run = 0)
 {
     const Geometry &g = h->g;
     const TileGrid &tg = h->tg;
@@ -586,13 +586,13 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
             const int n = B - b0 < TINIT_ARGS ? B - b0 : TINIT_ARGS;
             memcpy(ti.T, T_init + (size_t)b0 * 16, sizeof(double) * 16 * n);
             hipLaunchKernelGGL(k_pair_init, dim3(n), dim3(64), 0, s, ti, 1, b0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters, h->nsets,
-                               stamp_ring_of(h, b0 == 0));
+                               stamp_ring_of(h, b0 == 0), (count_run && b0 == 0) ? 1 : 0);
         }
     } else {
         TinitArgs ti;
         memset(&ti, 0, sizeof ti);
         hipLaunchKernelGGL(k_pair_init, dim3(B), dim3(64), 0, s, ti, 0, 0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters, h->nsets,
-                               stamp_ring_of(h));
+                               stamp_ring_of(h), count_run);
     }
     if (nn_mode_of(h) != SLAM3D_NN_TILES) {
         HIPCHK(h, hipMemsetAsync(h->best, 0xFF, sizeof(unsigned long long) * (size_t)B * tg.nslots, s));
@@ -615,7 +615,7 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
 #define S3D_COOP_WPE 7
 #endif
 static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int it, int do_solve,
-                             long long *raw_out = nullptr, int balance = 0, int first = 0)
+                             long long *raw_out = nullptr, int balance = 0, int first = 0, int counted_run = 0)
 {
     const TileGrid &tg = h->tg;
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
@@ -676,12 +676,12 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         hipLaunchKernelGGL(k_solve_acc<0>, dim3(B), dim3(64), 0, s, h->acc, raw_out, h->Tcur, h->trace_T, h->trace_S, h->flags, h->d_pairs,
                            do_solve ? h->d_res : nullptr, it, iters, do_solve,
                            stamp_ring_of(h, do_solve != 0), iters + it,
-                           h->nsets, head ? it : 0, head ? 1 : 0);
+                           h->nsets, head ? it : 0, head ? 1 : 0, (counted_run && it == iters - 1) ? 1 : 0);
     else
         hipLaunchKernelGGL(k_solve_acc<1>, dim3(B), dim3(64), 0, s, h->acc, raw_out, h->Tcur, h->trace_T, h->trace_S, h->flags, h->d_pairs,
                            do_solve ? h->d_res : nullptr, it, iters, do_solve,
                            stamp_ring_of(h, do_solve != 0), iters + it,
-                           h->nsets, 0, 0);
+                           h->nsets, 0, 0, (counted_run && it == iters - 1) ? 1 : 0);
     HIPCHK(h, hipGetLastError());
     return SLAM3D_OK;
 }
@@ -701,7 +701,7 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
         const size_t n = (size_t)(iters > 0 ? iters : 1) * h->maxB * h->tg.nslots;
         if (hipMalloc((void **)&h->corr_trace, sizeof(int) * n) != hipSuccess) { (void)hipGetLastError(); return SLAM3D_E_NOMEM; }
     }
-    int rc = enqueue_preprocess(h, B, T_init, s);
+    int rc = enqueue_preprocess(h, B, T_init, s, iters > 0 ? 1 : 0);       // (counted as in flight until the last k_solve_acc)
     if (rc) return rc;
     if (iters > 0 && !h->profiling && h->use_graph && !h->want_corr_trace) {
         // The iteration loop (iterations x {NN, solve}) has launch-invariant arguments: it is captured once per B into
@@ -711,7 +711,7 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
             if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
             hipGraph_t graph = nullptr;
             HIPCHK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-            for (int it = 0; it < iters && !rc; ++it) rc = enqueue_iteration(h, B, s, nullptr, nullptr, it, 1, nullptr, 0, it == 0);
+            for (int it = 0; it < iters && !rc; ++it) rc = enqueue_iteration(h, B, s, nullptr, nullptr, it, 1, nullptr, 0, it == 0, 1);
             const hipError_t ce = hipStreamEndCapture(s, &graph);
             if (rc || ce != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); (void)hipGetLastError(); return rc ? rc : SLAM3D_E_HIP; }
             const hipError_t ie = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
@@ -724,7 +724,7 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
         if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[1], s));
         for (int it = 0; it < iters; ++it) {
             rc = enqueue_iteration(h, B, s, h->profiling ? h->ev[3 + 2 * it] : nullptr, h->profiling ? h->ev[4 + 2 * it] : nullptr, it, 1,
-                                   nullptr, 0, it == 0);
+                                   nullptr, 0, it == 0, 1);
             if (rc) return rc;
         }
     }

@@ -47,6 +47,7 @@ struct PairPtrs {                  // per frame-pair device pointers: the reside
     const int *tgt_counts;         // [1] = valid target points of the target frame
 };
 constexpr int RES_REC = 48;        // doubles per pair in the host-mapped result record
+constexpr unsigned long long HEAD_EMPTY = 0x7ff8dead0badc0deull;     // a pose entry "not published yet" (head solve): a quiet NaN with a payload no arithmetic produces
 // Launch stamps (opt-in, slam3d_icp_set_stamping): every block of a stamped launch folds the constant-rate 100 MHz
 // real-time counter (common to all XCDs, unlike s_memtime) into the launch's row -- STAMP_R replicas of the earliest
 // start (atomic min) followed by STAMP_R replicas of the latest end (atomic max), fire-and-forget atomics spread
@@ -55,6 +56,14 @@ constexpr int RES_REC = 48;        // doubles per pair in the host-mapped result
 // `ring` runs stay on the device (StampRing: k_pair_init advances `seq` and resets the new run's rows; a launch finds
 // its row through seq), so nothing is copied while the measurement runs.  A null pointer (the default) costs one
 // scalar branch.
+// (head solve, see k_nn_tiles_acc) Poll or solve?  Measured on the MI355X (640x480, 20 iterations): with ONE alignment on the chip every block solving for
+// itself is fastest (0.761 ms per alignment; polling 0.78; two launches per iteration 0.80) -- the solve is ~1.6 us, a
+// published pose needs that plus a trip through memory; with FOUR alignments in flight the 1,200 redundant solves of a
+// launch are VALU work the other alignments want (63 k it/s against 68 k polling).  So the blocks poll only while other
+// runs are in flight on the device: k_pair_init / the run's last k_solve_acc keep the count (slam3d_icp_run's launches
+// only).  A stale count (a run that died between the two) costs speed, never correctness.
+__device__ int g_runs_in_flight = 0;
+
 constexpr int STAMP_R = 16, STAMP_ROW = 2 * STAMP_R;
 struct StampRing { unsigned long long *rows; unsigned int *seq; int ring, rows_per_run; };
 __device__ __forceinline__ unsigned long long *stamp_row(const StampRing &sr, int row)
@@ -440,9 +449,10 @@ struct TinitArgs { double T[TINIT_ARGS][16]; };
 __global__ __launch_bounds__(64) void k_pair_init(TinitArgs ti, int has_T, int b0, double *__restrict__ Tcur,
                                                   double *__restrict__ trace_T, int *__restrict__ flags,
                                                   long long *__restrict__ acc, unsigned int *__restrict__ ticket, int iters, int nsets,
-                                                  StampRing sr /* rows null: no stamps */)
+                                                  StampRing sr /* rows null: no stamps */, int count_run /* slam3d_icp_run: one more run in flight */)
 {
     const int k = blockIdx.x, b = b0 + k, lane = threadIdx.x;
+    if (count_run && k == 0 && lane == 0) atomicAdd(&g_runs_in_flight, 1);
     if (sr.rows && k == 0) {       // launch stamps (opt-in): this run takes the next slot of the ring; start = min -> ~0, end = max -> 0
         const unsigned int run = (*sr.seq + 1u) % (unsigned int)sr.ring;
         unsigned long long *__restrict__ rows = sr.rows + (size_t)run * sr.rows_per_run * STAMP_ROW;
@@ -459,8 +469,9 @@ __global__ __launch_bounds__(64) void k_pair_init(TinitArgs ti, int has_T, int b
         Tcur[b * 16 + lane] = v;
         trace_T[((size_t)b * (iters + 1)) * 16 + lane] = v;
     }
-    // entry 15 of a pose row is the head solve's ready flag: not ready
-    for (int j = 1 + lane; j <= iters; j += 64) trace_T[((size_t)b * (iters + 1) + j) * 16 + 15] = 0.0;
+    // the pose rows the head solves will publish: every entry "not published yet"
+    for (int j = 16 + lane; j < (iters + 1) * 16; j += 64)
+        reinterpret_cast<unsigned long long *>(trace_T)[(size_t)b * (iters + 1) * 16 + j] = HEAD_EMPTY;
     if (lane == 0) { flags[b] = 0; ticket[b] = 0u; }
 }
 
@@ -1084,16 +1095,16 @@ __device__ __forceinline__ double wave_solve_point2plane(const double *tot, cons
 // k_pair_init, never cleared in between) and launch k+1 begins by turning set k into T_{k+1}:
 //   * block (0, b) -- the first workgroup of pair b the dispatcher places -- sums the 16 x 29 replicas, runs the
 //     lane-parallel LDL^T (wave_solve_point2plane, the code k_solve_acc runs), writes trace_S[k], the flags and the new
-//     pose into trace_T[k+1], entry 15 (always 1.0 in a pose) LAST with release semantics: it doubles as the ready flag
-//     (k_pair_init zeroes it for every row of the run);
-//   * the other blocks' wave 0 polls that flag (agent-scope loads, s_sleep between) and reads the 16 doubles;
+//     pose into trace_T[k+1]: sixteen 8-byte agent-scope stores into entries that k_pair_init reset to HEAD_EMPTY, so
+//     every entry validates itself and no store ordering (no L2-wide release / acquire) is needed;
+//   * the other blocks' wave 0 polls the row (lane l watches entry l; agent-scope loads, s_sleep between);
 //   * a poller that has not seen the flag after HEAD_POLLS tries (block 0 not resident yet -- the dispatch order is an
 //     observation, not a contract) simply solves for itself: same inputs, same code, same bits.  Nothing ever depends
 //     on another block for CORRECTNESS or termination, only for speed;
 //   * every wave of the block then takes T from LDS.
 // One k_solve_acc launch remains, after the last NN launch (T_iters, the result record).  Iterations x 2 launches become
 // iterations + 1.
-constexpr int HEAD_POLLS = 400;      // x ~0.15 us: ~60 us until a poller gives up on block 0 and solves by itself
+constexpr int HEAD_POLLS = 200;      // x (a memory round trip + s_sleep): ~100 us until a poller gives up on block 0 and solves by itself
 
 constexpr int PROJ_RMAX = 3;         // largest window radius the projective search takes on (7x7 pixels)
 constexpr int QSTRIDE = 17;                        // float4 per staged quadrant: 16 candidates + 1 pad: lane-specific reads of
@@ -1202,18 +1213,21 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                 double *tot = reinterpret_cast<double *>(stage_all[0]);          // 32 + 16 doubles of this wave's (still unused) stage slab
                 double *tsh = tot + 32;
                 bool have = false;
-                if (c != 0 && head == 1) {          // (head == 2, a developer knob: nobody polls, every block solves for itself)
+                // head: 1 poll while other runs are in flight on the device, else solve locally; developer knobs: 2 never poll, 3 always
+                if (c != 0 && (head == 3 || (head == 1 && __hip_atomic_load(&g_runs_in_flight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 1))) {
+                    // lane l < 16 watches entry l of the row: every entry is ONE 8-byte agent-scope store of the publisher and was
+                    // reset to HEAD_EMPTY (a NaN pattern no arithmetic produces) by k_pair_init, so each entry validates itself --
+                    // no ordering between the stores is needed, hence no release / acquire fence (on gfx950 those write back and
+                    // invalidate the L2: measured +10 us per launch)
+                    unsigned long long v = HEAD_EMPTY;
                     for (int poll = 0; poll < HEAD_POLLS; ++poll) {
-                        const unsigned long long f = __hip_atomic_load(reinterpret_cast<unsigned long long *>(Tnew + 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (__builtin_amdgcn_readfirstlane((int)(f >> 32)) != 0) { have = true; break; }      // 1.0 = 0x3ff00000'00000000
-                        __builtin_amdgcn_s_sleep(5);
+                        if (lane < 16) v = __hip_atomic_load(reinterpret_cast<unsigned long long *>(Tnew + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__ballot(lane < 16 && v == HEAD_EMPTY) == 0ull) { have = true; break; }
+                        __builtin_amdgcn_s_sleep(4);
                     }
+                    if (have && lane < 16) head_T[lane] = __longlong_as_double((long long)v);
                 }
-                if (have) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    if (lane < 16)
-                        head_T[lane] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(Tnew + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                } else {
+                if (!have) {
                     const long long *__restrict__ A = acc + ((size_t)b * nsets + (it - 1)) * ACC_R * ACC_STRIDE;
                     if (lane < NSUMS) {
                         long long q = 0;
@@ -1231,9 +1245,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                     if (c == 0) {                                   // the one block that publishes
                         if (lane < NSUMS) trace_S[((size_t)b * iters + (it - 1)) * NSUMS + lane] = tot[lane];
                         if (lane == 0 && rc != 1) flags[b] = flags[b] | (rc == 2 ? 1 : 2);
-                        if (lane < 15) __hip_atomic_store(reinterpret_cast<unsigned long long *>(Tnew + lane), (unsigned long long)__double_as_longlong(Tn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                        if (lane == 15) __hip_atomic_store(reinterpret_cast<unsigned long long *>(Tnew + 15), (unsigned long long)__double_as_longlong(Tn), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane < 16) __hip_atomic_store(reinterpret_cast<unsigned long long *>(Tnew + lane), (unsigned long long)__double_as_longlong(Tn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
@@ -2201,8 +2213,10 @@ __global__ __launch_bounds__(64) void k_solve_acc(long long *__restrict__ acc, l
                                                   const PairPtrs *__restrict__ pairs, double *__restrict__ res_host,
                                                   int it, int iters, int do_solve, StampRing sring, int stamp_idx,
                                                   int nsets, int set /* which accumulator set of the pair: 0, or `it` after head-solved launches */,
-                                                  int from_trace /* T_it from trace_T[it] (head-solved launches leave Tcur at T_0) */)
+                                                  int from_trace /* T_it from trace_T[it] (head-solved launches leave Tcur at T_0) */,
+                                                  int end_run /* the last launch of a slam3d_icp_run: one run less in flight */)
 {
+    if (end_run && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_runs_in_flight, -1);
     __shared__ double tot[32], Tsh[16];
     const int b = blockIdx.x, k = threadIdx.x;
     unsigned long long *const stamp = stamp_row(sring, stamp_idx);

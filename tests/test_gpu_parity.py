@@ -511,7 +511,7 @@ def test_bench_gpus2_launched_as_a_plain_process(gpu_lib):
     assert d["rccl_ranks"] == 0 and d["pose_exchange"].startswith("gloo")
 
 
-@pytest.mark.parametrize("mode", ["0", "1", "2"])
+@pytest.mark.parametrize("mode", ["0", "1", "2", "3"])
 def test_head_solve_modes_are_bit_identical(gpu_lib, mode, monkeypatch):
     """The solve at the head of the next NN launch (default, 1), the same with every block solving for itself instead of
     polling block 0 (2: the fallback path of a poller that gives up) and the two-launch form (0): every iterate, every

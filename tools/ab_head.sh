@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 Q="--no-extra-configs --no-cpu-baseline --no-bruteforce --steps 10 --warmup 3"
-for m in 1 0 2 1 0; do
+for m in ${MODES:-1 0 2 3 1}; do
     SLAM3D_HEAD_SOLVE=$m timeout 600 python bench.py $Q "$@" > $OUT/head$m.json 2> $OUT/head$m.err
     python - <<PY
 import json
