@@ -1159,6 +1159,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     int n_my_items = 0;
     // per-tile work counters and clocks of the instrumented (DBG) instances; compiled out of the production ones
     int n_scanned = 0, n_cand = 0, n_batches = 0, n_chit = 0, n_fhit = 0, n_refined = 0;
+    long long n_b_hist = 0;     // phase B items this wave processed: count | <=2 | <=4 | <=8 | <=16 active lanes (8 bits each) | sum of active lanes
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.y, c = blockIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1775,6 +1776,10 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                 px = qpos[own[k]][0][lane]; py = qpos[own[k]][1][lane]; pz = qpos[own[k]][2][lane];
                 valid = (qcls[own[k]][0] >> lane) & 1ull;
                 bkey = qkey[own[k]][lane];                     // the owner's best so far, every earlier merge included
+                if constexpr (DBG) {     // how many of the owner's lanes can reach this tile at all (the lanes the scan works for)
+                    const int na = __popcll(__ballot(lane_gap_le(TB[2 * tt[k]], TB[2 * tt[k] + 1], lane_thr())));
+                    n_b_hist += 1ll | ((long long)(na <= 2) << 8) | ((long long)(na <= 4) << 16) | ((long long)(na <= 8) << 24) | ((long long)(na <= 16) << 32) | ((long long)na << 40);
+                }
                 scan_staged(k, tt[k]);
                 if (valid) atomicMin(&qkey[own[k]][lane], bkey);
             }
@@ -1831,7 +1836,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         d[9] = (long long)c * NN_WAVES + w;
         d[10] = rt0; d[11] = (long long)wall_clock64();
         d[12] = clkP; d[13] = clkB1; d[14] = clkD; d[15] = (long long)n_my_items | ((long long)(COOP ? n_items : 0) << 32);
-        d[16] = clkM; d[17] = clkE; d[18] = COOP ? n_titems : 0; d[19] = 0;
+        d[16] = clkM; d[17] = clkE; d[18] = COOP ? n_titems : 0; d[19] = n_b_hist;
     }
 }
 

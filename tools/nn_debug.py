@@ -10,7 +10,13 @@ from slam3d_gx_amd import capi, synth
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-pr = synth.make_pair(seed)
+if seed < 0:      # the reference's Kinect pair (tests/golden/kinect): dep1 -> dep2
+    from PIL import Image
+    kin = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "kinect")
+    pr = synth.FramePair(-1, synth.Intrinsics(), np.array(Image.open(os.path.join(kin, "exp1_dep_1.png"))).astype(np.uint16),
+                         np.array(Image.open(os.path.join(kin, "exp1_dep_2.png" if seed == -1 else "exp1_dep_1.png"))).astype(np.uint16), np.eye(4))
+else:
+    pr = synth.make_pair(seed)
 s4 = synth.backproject_numpy(pr.depth_src, pr.intr); t4 = synth.backproject_numpy(pr.depth_tgt, pr.intr)
 for it in (1, iters):
     with capi.IcpHandle(capi.default_params(pr.intr, iterations=it)) as h:
@@ -33,6 +39,11 @@ for it in (1, iters):
                     ("epilogue", d1[:, 4] - d1[:, 3]), ("tiles scanned", lo32(d1[:, 5])), ("candidates", lo32(d1[:, 6])), ("batches", lo32(d1[:, 7])),
                     ("cells swept", hi32(d1[:, 5])), ("fine hits", hi32(d1[:, 6])), ("refined hits", hi32(d1[:, 7]))):
         print(f"{name:14s} mean {v.mean():10.1f}  p50 {np.percentile(v,50):9.0f}  p90 {np.percentile(v,90):9.0f}  p99 {np.percentile(v,99):9.0f}  max {v.max():9.0f}")
+    hb = d[:, 19]
+    nit = (hb & 0xff).sum()
+    if nit:
+        print(f"phase B items processed {nit}: active lanes per item <=2: {((hb >> 8) & 0xff).sum() / nit:.2f}  <=4: {((hb >> 16) & 0xff).sum() / nit:.2f}  "
+              f"<=8: {((hb >> 24) & 0xff).sum() / nit:.2f}  <=16: {((hb >> 32) & 0xff).sum() / nit:.2f}  mean {(hb >> 40).sum() / nit:.1f}")
     hw = d[:, 8] & 0xffffffff
     xcc = (d[:, 8] >> 32) & 0xf
     cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 0x1; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 0x3
