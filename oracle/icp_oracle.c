@@ -110,6 +110,48 @@ void orc_eig3(const double A[6], double evals[3], double V[9])
     for (int m = 0; m < 3; ++m) for (int k = 0; k < 3; ++k) V[m * 3 + k] = v[m][k]; /* column k = evec k */
 }
 
+/* ----------------------------------------- S2: direction of least variance
+ * Spec S2 (round 3): the unit eigenvector of the SMALLEST eigenvalue of the 3x3 window covariance C, by power iteration on
+ * the adjugate.  adj(C) has the eigenvectors of C with eigenvalues l1*l2, l0*l2, l0*l1, so its DOMINANT eigenvector is C's
+ * smallest one, and repeated squaring raises the dominance ratio l1/l0 to the power 2^K:
+ *   M = adj(C) (cofactors, each "product - product");
+ *   K = 5 times:  tr = (M00 + M11) + M22, must be a positive normal number; M *= 2^-ilogb(tr) (exact);  M = M * M;
+ *   column j of M with the largest diagonal entry (ties: lowest j), normalised.
+ * Only +, -, *, one sqrt and three divisions, every one an individually rounded IEEE operation: bit-identical on the CPU and
+ * in k_normals.  Error against the exact eigenvector: ~1e-15 + (l0/l1)^32 -- a planar patch has l1/l0 of 10 .. 1000.
+ * (Rounds 1-2 ran 8 sweeps of cyclic Jacobi here, 24 rotations with three divisions and two square roots each: 70 % of
+ * k_normals' time.  orc_eig3 stays for the plane fits, which need all three eigenpairs of a handful of matrices.) */
+int orc_smallest_evec3(const double C[6], double n[3])
+{
+    const double c00 = C[0], c01 = C[1], c02 = C[2], c11 = C[3], c12 = C[4], c22 = C[5];
+    double m00 = c11 * c22 - c12 * c12, m01 = c02 * c12 - c01 * c22, m02 = c01 * c12 - c02 * c11;
+    double m11 = c00 * c22 - c02 * c02, m12 = c01 * c02 - c00 * c12, m22 = c00 * c11 - c01 * c01;
+    for (int k = 0; k < 5; ++k) {
+        const double tr = (m00 + m11) + m22;
+        uint64_t bits;
+        memcpy(&bits, &tr, sizeof bits);
+        const int be = (int)((bits >> 52) & 0x7ff);
+        if ((bits >> 63) != 0 || be == 0 || be == 0x7ff) return 0;     /* not a positive normal number: no direction */
+        const uint64_t sb = (uint64_t)(2046 - be) << 52;                /* 2^-(be - 1023) */
+        double sc;
+        memcpy(&sc, &sb, sizeof sc);
+        const double a00 = m00 * sc, a01 = m01 * sc, a02 = m02 * sc, a11 = m11 * sc, a12 = m12 * sc, a22 = m22 * sc;
+        m00 = (a00 * a00 + a01 * a01) + a02 * a02;
+        m01 = (a00 * a01 + a01 * a11) + a02 * a12;
+        m02 = (a00 * a02 + a01 * a12) + a02 * a22;
+        m11 = (a01 * a01 + a11 * a11) + a12 * a12;
+        m12 = (a01 * a02 + a11 * a12) + a12 * a22;
+        m22 = (a02 * a02 + a12 * a12) + a22 * a22;
+    }
+    double nx = m00, ny = m01, nz = m02, best = m00;
+    if (m11 > best) { best = m11; nx = m01; ny = m11; nz = m12; }
+    if (m22 > best) { best = m22; nx = m02; ny = m12; nz = m22; }
+    const double len = sqrt((nx * nx + ny * ny) + nz * nz);
+    if (!(len > 0.0) || !isfinite(len)) return 0;
+    n[0] = nx / len; n[1] = ny / len; n[2] = nz / len;
+    return 1;
+}
+
 /* ------------------------------------------------------------- S2 normals */
 static void normal_at(const float *xyz4, int W, int H, int u, int v, int r,
                       float zmax, int min_in, double in_dist, float *out)
@@ -138,15 +180,12 @@ static void normal_at(const float *xyz4, int W, int H, int u, int v, int r,
     double C[6];
     C[0] = sxx * inv - mx * mx; C[1] = sxy * inv - mx * my; C[2] = sxz * inv - mx * mz;
     C[3] = syy * inv - my * my; C[4] = syz * inv - my * mz; C[5] = szz * inv - mz * mz;
-    double ev[3], V[9];
-    orc_eig3(C, ev, V);
-    int k = 0;
-    if (ev[1] < ev[k]) k = 1;
-    if (ev[2] < ev[k]) k = 2;
-    double nx = V[0 + k], ny = V[3 + k], nz = V[6 + k];
-    const double len = sqrt(nx * nx + ny * ny + nz * nz);
-    nx = nx / len; ny = ny / len; nz = nz / len;
+    double nv[3];
+    if (!orc_smallest_evec3(C, nv)) return;
+    double nx = nv[0], ny = nv[1], nz = nv[2];
     if (nx * cx0 + ny * cy0 + nz * cz0 > 0.0) { nx = -nx; ny = -ny; nz = -nz; } /* toward camera */
+    /* the LS plane passes through the window mean c0 + m: its offset along n, in camera coordinates */
+    const double dq = ((nx * cx0 + ny * cy0) + nz * cz0) + ((nx * mx + ny * my) + nz * mz);
     int cnt = 0;
     for (int dv = -r; dv <= r; ++dv)
         for (int du = -r; du <= r; ++du) {
@@ -154,8 +193,7 @@ static void normal_at(const float *xyz4, int W, int H, int u, int v, int r,
             if (uu < 0 || uu >= W || vv < 0 || vv >= H) continue;
             const float *q = xyz4 + 4 * ((size_t)vv * W + uu);
             if (!point_valid(q, zmax)) continue;
-            const double dx = (double)q[0] - cx0, dy = (double)q[1] - cy0, dz = (double)q[2] - cz0;
-            const double e = nx * (dx - mx) + ny * (dy - my) + nz * (dz - mz);
+            const double e = ((nx * (double)q[0] + ny * (double)q[1]) + nz * (double)q[2]) - dq;
             if (fabs(e) <= in_dist) ++cnt;
         }
     if (cnt < min_in) return;

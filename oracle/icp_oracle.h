@@ -131,6 +131,7 @@ void orc_pose_error(const double *Tref, const double *T, double *rot_err, double
 
 /* small solvers exposed for property tests */
 void orc_eig3(const double A[6] /*xx,xy,xz,yy,yz,zz*/, double evals[3], double evecs[9] /*cols*/);
+int  orc_smallest_evec3(const double C[6] /*xx,xy,xz,yy,yz,zz*/, double n[3]);   /* spec S2: 1 = unit vector written, 0 = no direction */
 int  orc_solve6(const double AtA21[21], const double Atb[6], double x[6]);
 void orc_svd3_rotation(const double H[9], double R[9]);
 void orc_sincos(double x, double *s, double *c);

@@ -193,6 +193,41 @@ __device__ __forceinline__ void eig3_smallest(Sym3 A, double &nx, double &ny, do
     nx = nx / len; ny = ny / len; nz = nz / len;
 }
 
+// Spec S2 (round 3): unit eigenvector of the smallest eigenvalue of the window covariance by power iteration on the adjugate
+// (oracle/icp_oracle.c::orc_smallest_evec3 is the same sequence of individually rounded operations): M = adj(C); five times
+// { scale by the exact power of two that brings the trace into [1, 2); M = M * M }; the column with the largest diagonal entry,
+// normalised.  ~200 fp64 operations, one sqrt and three divisions, against ~1,700 for the eight Jacobi sweeps it replaces
+// (k_normals sat on the fp64 floor: 50 us per 640x480 frame, 70 % of it here).  eig3_smallest stays for the plane fits.
+__device__ __forceinline__ bool smallest_evec3(const Sym3 &C, double &nx, double &ny, double &nz)
+{
+    double m00 = C.a11 * C.a22 - C.a12 * C.a12, m01 = C.a02 * C.a12 - C.a01 * C.a22, m02 = C.a01 * C.a12 - C.a02 * C.a11;
+    double m11 = C.a00 * C.a22 - C.a02 * C.a02, m12 = C.a01 * C.a02 - C.a00 * C.a12, m22 = C.a00 * C.a11 - C.a01 * C.a01;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const double tr = (m00 + m11) + m22;
+        const int hi = __double2hiint(tr);
+        const int be = (hi >> 20) & 0x7ff;
+        ok = ok && hi >= 0 && be != 0 && be != 0x7ff;                  // a positive normal number
+        const double sc = __hiloint2double((2046 - be) << 20, 0);      // 2^-(be - 1023), exact
+        const double a00 = m00 * sc, a01 = m01 * sc, a02 = m02 * sc, a11 = m11 * sc, a12 = m12 * sc, a22 = m22 * sc;
+        m00 = (a00 * a00 + a01 * a01) + a02 * a02;
+        m01 = (a00 * a01 + a01 * a11) + a02 * a12;
+        m02 = (a00 * a02 + a01 * a12) + a02 * a22;
+        m11 = (a01 * a01 + a11 * a11) + a12 * a12;
+        m12 = (a01 * a02 + a11 * a12) + a12 * a22;
+        m22 = (a02 * a02 + a12 * a12) + a22 * a22;
+    }
+    nx = m00; ny = m01; nz = m02;
+    double best = m00;
+    if (m11 > best) { best = m11; nx = m01; ny = m11; nz = m12; }
+    if (m22 > best) { best = m22; nx = m02; ny = m12; nz = m22; }
+    const double len = sqrt((nx * nx + ny * ny) + nz * nz);
+    ok = ok && len > 0.0 && isfinite(len);
+    nx = nx / len; ny = ny / len; nz = nz / len;
+    return ok;
+}
+
 // ------------------------------------------------------------------------------------ S2
 // one thread per target pixel; the (32+2r)x(8+2r) neighbourhood of a 32x8 pixel block is staged
 // in LDS once (coalesced float4 rows), then each thread walks its window twice (moments, inliers).
@@ -251,19 +286,20 @@ __global__ __launch_bounds__(NRM_BX * NRM_BY) void k_normals(FrameTasks a, Geome
             C.a00 = sxx * inv - mx * mx; C.a01 = sxy * inv - mx * my; C.a02 = sxz * inv - mx * mz;
             C.a11 = syy * inv - my * my; C.a12 = syz * inv - my * mz; C.a22 = szz * inv - mz * mz;
             double nx, ny, nz;
-            eig3_smallest(C, nx, ny, nz);
+            const bool have = smallest_evec3(C, nx, ny, nz);
             if (nx * cx0 + ny * cy0 + nz * cz0 > 0.0) { nx = -nx; ny = -ny; nz = -nz; }
+            // the LS plane passes through the window mean c0 + m: its offset along n, in camera coordinates
+            const double dq = ((nx * cx0 + ny * cy0) + nz * cz0) + ((nx * mx + ny * my) + nz * mz);
             int cnt = 0;
 #pragma unroll 1
             for (int dv = 0; dv <= 2 * r; ++dv)
 #pragma unroll UN
                 for (int du = 0; du <= 2 * r; ++du) {
                     const float4 q = win[dv * tw + du];
-                    const double dx = (double)q.x - cx0, dy = (double)q.y - cy0, dz = (double)q.z - cz0;
-                    const double e = nx * (dx - mx) + ny * (dy - my) + nz * (dz - mz);
+                    const double e = ((nx * (double)q.x + ny * (double)q.y) + nz * (double)q.z) - dq;
                     cnt += (q.w > 0.5f && fabs(e) <= g.in_dist) ? 1 : 0;       // NaN coordinates of an invalid point: e = NaN, not counted either way
                 }
-            if (cnt >= g.min_in) out = make_float4((float)nx, (float)ny, (float)nz, 1.0f);
+            if (have && cnt >= g.min_in) out = make_float4((float)nx, (float)ny, (float)nz, 1.0f);
         }
     }
     nrm[(size_t)v * g.W + u] = out;

@@ -190,6 +190,14 @@ def eig3(A6):
     return ev, V.reshape(3, 3)
 
 
+def smallest_evec3(A6):
+    """spec S2's direction of least variance (adjugate power iteration): (ok, unit vector)"""
+    A6 = np.ascontiguousarray(A6, dtype=np.float64)
+    n = np.zeros(3)
+    ok = lib().orc_smallest_evec3(_fp(A6, C.c_double), _fp(n, C.c_double))
+    return bool(ok), n
+
+
 def solve6(U21, b6):
     U21 = np.ascontiguousarray(U21, dtype=np.float64); b6 = np.ascontiguousarray(b6, dtype=np.float64)
     x = np.zeros(6)
