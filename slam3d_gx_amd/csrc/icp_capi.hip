@@ -615,7 +615,9 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
 #define S3D_COOP_WPE 7
 #endif
 static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int it, int do_solve,
-                             long long *raw_out = nullptr, int balance = 0, int first = 0, int counted_run = 0)
+                             long long *raw_out = nullptr, int balance = 0, int first = 0, int counted_run = 0,
+                             slam3d_comm *exchange = nullptr /* dense mode: all-reduce this iteration's accumulator set in place */,
+                             bool *used_head = nullptr)
 {
     const TileGrid &tg = h->tg;
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
@@ -670,6 +672,16 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
     if (h->want_corr_trace && do_solve)          // this iteration's slot-order indices (index parity per iteration)
         HIPCHK(h, hipMemcpyAsync(h->corr_trace + (size_t)it * h->maxB * tg.nslots, h->corr, sizeof(int) * (size_t)B * tg.nslots,
                                  hipMemcpyDeviceToDevice, s));
+    if (used_head) *used_head = head;
+    if (exchange && head) {
+        // Dense mode, several ranks: each rank accumulated the rows of ITS source shard into this iteration's set; summing the
+        // sets element-wise over the ranks (16 replicas x 32 int64, in place, on this stream) gives every rank the same
+        // integers, whose replica sum is the global total: the head of the next launch (or the final k_solve_acc) then solves
+        // the identical system on every rank.  ONE exchange per iteration, no reduction or solve launch beside it.
+        long long *set = h->acc + (size_t)it * ACC_R * ACC_STRIDE;
+        const ncclResult_t nr = s3d::rccl().AllReduce(set, set, (size_t)ACC_R * ACC_STRIDE, ncclInt64, ncclSum, exchange->comm, s);
+        if (nr != ncclSuccess) { h->err = std::string("ncclAllReduce failed: ") + s3d::rccl().GetErrorString(nr); return SLAM3D_E_COMM; }
+    }
     if (head && it < iters - 1) {
         // solved at the head of the next NN launch; only the run's last iteration keeps its k_solve_acc (result record)
     } else if (h->p.estimator == SLAM3D_EST_POINT2PLANE)
@@ -1471,11 +1483,18 @@ extern "C" int slam3d_icp_dense_finish(slam3d_icp_handle *h, const int64_t last_
     return SLAM3D_OK;
 }
 
-// BASELINE config 5 inside the library: source rows sharded over the ranks of `comm`, one ncclAllReduce(SUM) of the 29
-// int64 sums per iteration on the handle's own stream -- partial -> all-reduce -> update are three consecutive
-// enqueues on ONE stream, so no ordering is left to the caller (the round-1 Python form relied on torch's current
-// stream being the launch stream, which it was not).  SLAM3D_DENSE_FORCE_COLLECTIVE=1 runs the collective with one
-// rank too (developer knob: exercises RCCL on a single GPU).
+// BASELINE config 5 inside the library: source rows sharded over the ranks of `comm`, ONE ncclAllReduce(SUM) per iteration
+// on the handle's own stream and nothing else between two NN launches (round 3): launch k accumulates this rank's rows into
+// accumulator set k, the all-reduce sums set k over the ranks in place (16 x 32 int64), and the head of launch k+1 solves
+// -- the same integers, hence the same pose bits, on every rank (round 2: reduce launch -> all-reduce of 29 words -> solve
+// launch).  The svd estimator and SLAM3D_HEAD_SOLVE=0 keep that three-step form.  A rank that fails locally aborts the
+// communicator (ncclCommAbort) so that its peers' collectives return instead of waiting for ever.
+// SLAM3D_DENSE_FORCE_COLLECTIVE=1 runs the collective with one rank too (developer knob: exercises RCCL on a single GPU).
+//
+// What is NOT sharded, and why: the target's preprocessing (normals, tile records: ~0.15 ms of a 2.0 ms alignment at
+// 1280x960).  Its products are 62 MB (19.7 MB normals, 22 MB tile records, 19.7 MB image-order records, boxes) from 2.4 MB of
+// depth image: all-gathering them over xGMI costs several times what every rank needs to recompute them from the image it
+// already holds.  The same holds for the H2D of the pair (each rank uploads both images over its own PCIe link).
 extern "C" int slam3d_icp_dense_run(slam3d_icp_handle *h, slam3d_comm *comm, const double *T_init, slam3d_icp_result *out)
 {
     if (!h || !out) return SLAM3D_E_INVALID;
@@ -1488,17 +1507,42 @@ extern "C" int slam3d_icp_dense_run(slam3d_icp_handle *h, slam3d_comm *comm, con
     if (rc) return rc;
     hipStream_t s = h->stream;
     rc = slam3d_icp_dense_begin(h, T_init, s);
+    const int iters = h->p.iterations;
+    const bool head_flow = h->head_solve != 0 && h->p.estimator == SLAM3D_EST_POINT2PLANE && nn_mode_of(h) == SLAM3D_NN_TILES && 1 < h->dense_batch && iters > 0;
     int64_t *d_sums = reinterpret_cast<int64_t *>(h->sums);
-    for (int it = 0; it < h->p.iterations && !rc; ++it) {
-        rc = slam3d_icp_dense_partial_device(h, d_sums, s);
-        if (rc) break;
-        if (collective) {
-            const ncclResult_t nr = s3d::rccl().AllReduce(d_sums, d_sums, NSUMS, ncclInt64, ncclSum, comm->comm, s);
-            if (nr != ncclSuccess) { h->err = std::string("ncclAllReduce failed: ") + s3d::rccl().GetErrorString(nr); rc = SLAM3D_E_COMM; break; }
+    if (head_flow) {
+        for (int it = 0; it < iters && !rc; ++it) {
+            const bool ev = h->ran_profiled;
+            bool used = false;
+            rc = enqueue_iteration(h, 1, s, ev ? h->ev[3 + 2 * it] : nullptr, ev ? h->ev[4 + 2 * it] : nullptr, it, 1, nullptr, 0, it == 0, 0,
+                                   collective ? comm : nullptr, &used);
+            if (!rc && !used) rc = SLAM3D_E_STATE;
         }
-        rc = slam3d_icp_dense_update_device(h, d_sums, s);
+        if (!rc) {
+            h->dense_it = iters;
+            if (hipEventRecord(h->ev[2], s) != hipSuccess) rc = SLAM3D_E_HIP;
+            h->res_mapped = true;
+            if (!rc) rc = slam3d_icp_fetch_results(h, 1, out);
+            if (!rc) out->iterations = iters;
+        }
+    } else {
+        for (int it = 0; it < iters && !rc; ++it) {
+            rc = slam3d_icp_dense_partial_device(h, d_sums, s);
+            if (rc) break;
+            if (collective) {
+                const ncclResult_t nr = s3d::rccl().AllReduce(d_sums, d_sums, NSUMS, ncclInt64, ncclSum, comm->comm, s);
+                if (nr != ncclSuccess) { h->err = std::string("ncclAllReduce failed: ") + s3d::rccl().GetErrorString(nr); rc = SLAM3D_E_COMM; break; }
+            }
+            rc = slam3d_icp_dense_update_device(h, d_sums, s);
+        }
+        if (!rc) rc = slam3d_icp_dense_finish_device(h, d_sums, s, out);
     }
-    if (!rc) rc = slam3d_icp_dense_finish_device(h, d_sums, s, out);
+    if (rc < 0 && collective && world > 1 && s3d::rccl().CommAbort && comm->comm) {
+        // this rank is leaving the loop early: without the abort the other ranks would block in their next all-reduce
+        (void)s3d::rccl().CommAbort(comm->comm);
+        comm->comm = nullptr;
+        h->err += " (communicator aborted)";
+    }
     (void)slam3d_icp_dense_set_rows(h, 0, h->p.height);
     return rc;
 }

@@ -121,10 +121,13 @@ def _comm_one_rank(device=0):
     return capi.Comm(uid, 0, 1, device)
 
 
-def test_dense_run_through_rccl_allreduce_is_bit_identical(gpu_lib, monkeypatch):
-    """Config 5's loop inside the library: partial -> ncclAllReduce on the handle's stream -> update.  One rank on
-    this box, collective forced, so RCCL really runs between the kernels; bit-identical to the unsharded batch run
-    and to the host-synchronous dense loop."""
+@pytest.mark.parametrize("head", ["1", "0"])
+def test_dense_run_through_rccl_allreduce_is_bit_identical(gpu_lib, monkeypatch, head):
+    """Config 5's loop inside the library.  head = 1 (default): launch k accumulates into set k, ONE ncclAllReduce of that set
+    in place on the handle's stream, the head of launch k+1 solves; head = 0: partial -> ncclAllReduce of 29 words -> update.
+    One rank on this box, collective forced, so RCCL really runs between the kernels; bit-identical to the unsharded batch
+    run and to the host-synchronous dense loop."""
+    monkeypatch.setenv("SLAM3D_HEAD_SOLVE", head)
     pr, s4, t4 = _pair(2001, 320, 240)
     params = capi.default_params(pr.intr, iterations=10)
     with capi.IcpHandle(params) as hd:
