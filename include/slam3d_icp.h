@@ -101,7 +101,10 @@ typedef struct slam3d_icp_result {
     double  T_raw[16];              /* the converged estimate even when status != OK                */
 } slam3d_icp_result;
 
-/* plane of PLANE::coff (src/GraphicEnd.h:43): a,b,c,d with unit normal, d >= 0 (src/GraphicEnd.cpp:383-387) */
+/* plane of PLANE::coff (src/GraphicEnd.h:43): a,b,c,d with unit normal, d >= 0 (src/GraphicEnd.cpp:383-387).
+ * (SURVEY.md row a3 sketched a `cov[6]` member as well.  It is deliberately absent: the reference's PLANE carries no covariance
+ * (src/GraphicEnd.h:41-49), nothing on the path consumes one, and the fit's moments are integer fixed point inside the kernels --
+ * exporting them as six floats would freeze an internal representation into the ABI for no reader.) */
 typedef struct slam3d_plane {
     float   coeff[4];
     int32_t count;
@@ -163,6 +166,10 @@ int slam3d_icp_frame_set_depth_host(slam3d_icp_handle *h, int32_t frame, const u
 int slam3d_icp_frame_set_depth_device(slam3d_icp_handle *h, int32_t frame, const void *d_depth);
 int slam3d_icp_frame_set_cloud_host(slam3d_icp_handle *h, int32_t frame, const slam3d_cloud_view *cloud);
 int slam3d_icp_frame_set_cloud_device(slam3d_icp_handle *h, int32_t frame, const void *d_xyz4);       /* borrowed */
+/* A frame's normals / tiles are built once per SET and cached (the same keyframe serves many pairs).  After rewriting a
+ * BORROWED device buffer in place, call this (or set the frame again) before the next run; frames set from host memory or
+ * depth images are copies and need nothing. */
+int slam3d_icp_frame_invalidate(slam3d_icp_handle *h, int32_t frame);
 /* pair `slot` = (source frame, target frame); the frames must have been set before the run */
 int slam3d_icp_set_pair(slam3d_icp_handle *h, int32_t slot, int32_t src_frame, int32_t tgt_frame);
 

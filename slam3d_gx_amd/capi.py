@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "slam3d_icp_dense_update", "slam3d_icp_dense_finish",
     "slam3d_icp_dense_partial_device", "slam3d_icp_dense_update_device", "slam3d_icp_dense_finish_device",
     "slam3d_icp_frame_count", "slam3d_icp_frame_set_depth_host", "slam3d_icp_frame_set_depth_device",
-    "slam3d_icp_frame_set_cloud_host", "slam3d_icp_frame_set_cloud_device", "slam3d_icp_set_pair",
+    "slam3d_icp_frame_set_cloud_host", "slam3d_icp_frame_set_cloud_device", "slam3d_icp_frame_invalidate", "slam3d_icp_set_pair",
     "slam3d_icp_set_corr_trace", "slam3d_icp_get_correspondences_at",
     "slam3d_comm_get_unique_id", "slam3d_comm_init", "slam3d_comm_destroy", "slam3d_comm_rank", "slam3d_comm_world",
     "slam3d_comm_last_error", "slam3d_shard_range", "slam3d_icp_dense_run", "slam3d_pose_gather_submit",
@@ -298,6 +298,10 @@ class IcpHandle:
 
     def frame_set_cloud_device(self, frame: int, d_ptr: int):
         self._check(self.lib.slam3d_icp_frame_set_cloud_device(self._h, C.c_int32(frame), C.c_void_p(d_ptr)), False)
+
+    def frame_invalidate(self, frame: int):
+        """the contents of a borrowed device buffer changed in place: rebuild the frame's normals / tiles at the next run"""
+        self._check(self.lib.slam3d_icp_frame_invalidate(self._h, C.c_int32(frame)), False)
 
     def set_pair(self, slot: int, src_frame: int, tgt_frame: int):
         self._check(self.lib.slam3d_icp_set_pair(self._h, C.c_int32(slot), C.c_int32(src_frame), C.c_int32(tgt_frame)), False)

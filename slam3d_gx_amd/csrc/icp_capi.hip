@@ -71,6 +71,7 @@ struct slam3d_icp_handle {
     float4 *vox_out = nullptr;
     int *pin_vox_m = nullptr, *pin_vox_m_dev = nullptr;     // host-mapped: k_voxel_scan writes the voxel count there
     bool vox_dirty = true;        // table / histogram need a full clear before the next voxel call
+    hipEvent_t vox_done = nullptr; bool vox_done_valid = false;   // end of the last voxel call's launches: the next call (any stream) waits for it
     // 8x8-pixel tiles (slot order of the sums; target tiles + boxes for the pruned NN)
     TileGrid tg;
     float4 *prevq = nullptr;
@@ -173,6 +174,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->flags); F(h->best); F(h->cd2); F(h->acc); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
     F(h->d_pairs); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4); F(h->corr_trace);
     F(h->d_stamps); F(h->d_stamp_seq);
+    if (h->vox_done) (void)hipEventDestroy(h->vox_done);
     F(h->dbg); F(h->prevq); F(h->perm_d); F(h->cost); F(h->tgtB); F(h->qmax2);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->pin_res) (void)hipHostFree(h->pin_res);
@@ -394,6 +396,17 @@ extern "C" int slam3d_icp_frame_set_cloud_device(slam3d_icp_handle *h, int32_t f
 {
     if (!frame_ok(h, frame) || !d_xyz4) return SLAM3D_E_INVALID;
     frame_touch(h, frame, static_cast<const float4 *>(d_xyz4));
+    return SLAM3D_OK;
+}
+
+// A frame set from a borrowed device pointer (set_cloud_device / set_clouds_device) is preprocessed once per SET, not once per
+// run: a caller that rewrites the buffer in place must say so, or the next run aligns against the old normals and tiles.
+extern "C" int slam3d_icp_frame_invalidate(slam3d_icp_handle *h, int32_t frame)
+{
+    if (!frame_ok(h, frame)) return SLAM3D_E_INVALID;
+    FrameHost &fr = h->frames[frame];
+    if (fr.epoch == 0) return SLAM3D_E_STATE;
+    frame_touch(h, frame, fr.cloud, fr.from_depth);
     return SLAM3D_OK;
 }
 
@@ -1163,6 +1176,11 @@ static int voxel_grid_impl(slam3d_icp_handle *h, const void *d_points16, int32_t
     if (n == 0) return SLAM3D_OK;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     const VoxTable &t = h->vox;
+    // The handle's tables (hash slots, histogram, claim lists) serve one call at a time.  With a caller's stream a call returns
+    // as soon as the count is known, its scatter and rank launches still queued: whatever stream the NEXT call runs on first
+    // waits for the end of those launches (two streams raced on the tables).
+    if (!h->vox_done) HIPCHK(h, hipEventCreateWithFlags(&h->vox_done, hipEventDisableTiming));
+    if (h->vox_done_valid) HIPCHK(h, hipStreamWaitEvent(s, h->vox_done, 0));
     if (h->vox_dirty) {      // allocation, or an earlier call failed half way: from then on every call cleans up after itself
         hipLaunchKernelGGL(k_voxel_clear, dim3((t.cap + VOX_BLOCK - 1) / VOX_BLOCK), dim3(VOX_BLOCK), 0, s, t);
         HIPCHK(h, hipMemsetAsync(h->vox_hist, 0, sizeof(int) * (3 * VOX_BINS + 16 + 2 * VOX_SCAN_BLOCKS), s));     // histogram AND the scan ticket
@@ -1183,6 +1201,8 @@ static int voxel_grid_impl(slam3d_icp_handle *h, const void *d_points16, int32_t
                        h->vox_gslot);
     hipLaunchKernelGGL(k_voxel_rank, dim3(nblk), dim3(VOX_BLOCK), 0, s, t, h->vox_gkey, h->vox_gslot, start, boff, static_cast<float4 *>(d_out16));
     HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(h->vox_done, s));
+    h->vox_done_valid = true;
     if (stream) {
         // A caller's stream: the records are ready IN STREAM ORDER, and the call returns as soon as the count is known --
         // k_voxel_scan writes it into host-mapped memory while the scatter and rank launches are still queued behind it.

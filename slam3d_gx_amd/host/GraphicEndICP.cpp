@@ -134,7 +134,7 @@ void GraphicEndICP::init(const string &param_file)
     if (_reader->Has("hip_devices"))
         ndev = _reader->GetPara("hip_devices") == "all" ? slam3d_device_count() - first_dev : _reader->GetInt("hip_devices", 1);
     if (ndev < 1) ndev = 1;
-    _params.extra_frames = _max_batch + 8;
+    _params.extra_frames = 2 * _max_batch + 8;     // a chunk of max_batch pairs can name 2 * max_batch distinct frames (all pinned), + room for keyframes to stay
     // hip_devices_share: yes (tests): all handles on the first GPU -- the threaded sharding path on a one-GPU box
     const bool share = _reader->Has("hip_devices_share") && _reader->GetPara("hip_devices_share") == "yes";
     for (int k = 0; k < ndev; ++k) {

@@ -7,7 +7,7 @@ tests/test_oracle_independent.py::test_normals_vs_numpy_eigh); everything of the
 tests/test_oracle_independent.py then requires oracle/icp_oracle.c to reproduce these index hashes and poses, and
 tests/test_golden.py requires the HIP path to reproduce the oracle: HIP == oracle == scipy.
 
-usage: python tests/golden/make_independent_golden.py      (CPU only, ~1 minute)
+usage: python tests/golden/make_independent_golden.py      (CPU only, a few minutes)
 """
 import hashlib
 import json
@@ -24,7 +24,12 @@ import oracle_lib as O                                   # noqa: E402  (normals 
 import test_oracle_independent as R                      # noqa: E402  (the restatement)
 from slam3d_gx_amd import synth                          # noqa: E402
 
-CASES = [(1000, 160, 120, 0, 10), (1001, 160, 120, 1, 10), (1002, 320, 240, 0, 10), (1003, 320, 240, 1, 8), (1000, 640, 480, 0, 6)]
+# (seed, width, height, estimator, iterations); seed -1 = the reference's Kinect pair dep/1 -> dep/2 (tests/golden/kinect).
+# Round 3: the FULL BASELINE config-2 loop -- 640x480, 20 iterations -- for seeds 1000..1003, the real pair
+# for 20 iterations, and one iterate at config 5's 1280x960, all by the scipy restatement alone.
+CASES = [(1000, 160, 120, 0, 10), (1001, 160, 120, 1, 10), (1002, 320, 240, 0, 10), (1003, 320, 240, 1, 8),
+         (1000, 640, 480, 0, 20), (1001, 640, 480, 0, 20), (1002, 640, 480, 0, 20), (1003, 640, 480, 0, 20),
+         (-1, 640, 480, 0, 20), (2000, 1280, 960, 0, 1)]
 
 
 def icp_numpy(s4, t4, intr, estimator, iterations, gate=0.10):
@@ -46,14 +51,13 @@ def icp_numpy(s4, t4, intr, estimator, iterations, gate=0.10):
 def main():
     out = {"_comment": "written by tests/golden/make_independent_golden.py from the numpy/scipy restatement alone", "cases": []}
     for seed, w, h, est, iters in CASES:
-        pr = synth.make_pair(seed, w, h)
-        s4 = synth.backproject_numpy(pr.depth_src, pr.intr); t4 = synth.backproject_numpy(pr.depth_tgt, pr.intr)
+        pr, s4, t4 = R._case(seed, w, h)
         idx, T = icp_numpy(s4, t4, pr.intr, est, iters)
-        rot = np.arccos(np.clip((np.trace(np.linalg.inv(pr.T_gt)[:3, :3] @ T[:3, :3]) - 1) / 2, -1, 1))
+        rot = np.arccos(np.clip((np.trace(np.linalg.inv(pr.T_gt)[:3, :3] @ T[:3, :3]) - 1) / 2, -1, 1)) if seed >= 0 else None
         out["cases"].append(dict(seed=seed, width=w, height=h, estimator=est, iterations=iters,
                                  idx_sha256=hashlib.sha256(idx.astype("<i4").tobytes()).hexdigest(), inliers=int((idx >= 0).sum()),
-                                 T_final=T.tolist(), rot_err_vs_gt=float(rot)))
-        print(seed, w, h, est, int((idx >= 0).sum()), float(rot))
+                                 T_final=T.tolist(), rot_err_vs_gt=None if rot is None else float(rot)))
+        print(seed, w, h, est, int((idx >= 0).sum()), rot)
     json.dump(out, open(os.path.join(HERE, "independent_golden.json"), "w"), indent=1)
 
 

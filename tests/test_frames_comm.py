@@ -69,6 +69,30 @@ def test_frames_shared_by_many_pairs_equal_slotwise_runs(gpu_lib):
         assert np.array_equal(ro["T_trace"], tr[i]) and np.array_equal(ro["idx"], idx[i])
 
 
+def test_borrowed_device_frame_must_be_invalidated_after_an_in_place_update(gpu_lib):
+    """frames are preprocessed once per SET.  A borrowed device buffer rewritten in place keeps its old normals and
+    tiles until slam3d_icp_frame_invalidate (or a new set) says otherwise -- documented in the header, checked here."""
+    import torch
+    pa, sa4, ta4 = _pair(3101, 320, 240)
+    pb, sb4, tb4 = _pair(3102, 320, 240)
+    params = capi.default_params(pa.intr, iterations=6)
+    with capi.IcpHandle(params) as h:
+        want_a = h.align(sa4, ta4)["T_raw"].copy()
+        want_b = h.align(sb4, tb4)["T_raw"].copy()
+    d_s, d_t = torch.from_numpy(sa4).to("cuda:0"), torch.from_numpy(ta4).to("cuda:0")
+    with capi.IcpHandle(params) as h:
+        h.frame_set_cloud_device(0, d_s.data_ptr()); h.frame_set_cloud_device(1, d_t.data_ptr()); h.set_pair(0, 0, 1)
+        h.run(1)
+        assert np.array_equal(h.fetch_results(1)[0]["T_raw"], want_a)
+        d_s.copy_(torch.from_numpy(sb4)); d_t.copy_(torch.from_numpy(tb4))          # the caller rewrites both buffers in place
+        torch.cuda.synchronize()
+        h.frame_invalidate(0); h.frame_invalidate(1)
+        h.run(1)
+        assert np.array_equal(h.fetch_results(1)[0]["T_raw"], want_b)
+        with pytest.raises(capi.Slam3dError):
+            h.frame_invalidate(5)                                                    # never set
+
+
 def test_frame_api_rejects_bad_use(gpu_lib):
     pr = synth.make_pair(3, 160, 120)
     with capi.IcpHandle(capi.default_params(pr.intr, iterations=2, max_batch=2, extra_frames=1)) as hd:

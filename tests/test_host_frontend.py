@@ -551,3 +551,41 @@ def test_motion_model_initial_guess_matches_the_twin_and_tracks(gpu_lib, tmp_pat
     # the camera's pose in frame-0 coordinates is the inverse of the scene motion the sequence was rendered with
     for row, P in zip(traj[1:], poses[1:]):
         assert np.abs(row[1:4] - np.linalg.inv(P)[:3, 3]).max() < 5e-3
+
+
+@pytest.mark.gpu
+def test_planar_features_binary_on_config1_frame(gpu_lib, tmp_path):
+    """BASELINE config 1's binary (src/planarFeatures.cpp:26-136, minus OpenCV's window and FAST): `planarFeatures dep.png`
+    on the reference's bin/dep_1.png (tests/golden/kinect) through k_normals must count exactly what the oracle's spec S2
+    and a numpy reading of the reference's "no zero in the patch" rule give -- for every pixel, and for a key point list."""
+    _build_host()
+    from PIL import Image
+    png = os.path.join(ROOT, "tests", "golden", "kinect", "bin_dep_1.png")
+    dep = np.array(Image.open(png)).astype(np.uint16)
+    H, W = dep.shape
+    intr = synth.Intrinsics(W, H, 525.0, 525.0, 320.0, 235.5, 1000.0)           # src/planarFeatures.cpp:13-14
+    p = O.params(intr, z_filter=10.0)
+    nrm = O.normals(O.backproject(dep, p), p)
+    planar = nrm[..., 3] > 0.5
+    inner = np.zeros_like(planar); inner[3:H - 3, 3:W - 3] = True
+    from numpy.lib.stride_tricks import sliding_window_view
+    nozero = np.zeros_like(planar)
+    nozero[3:H - 3, 3:W - 3] = (sliding_window_view(dep, (7, 7)) != 0).all(axis=(2, 3))
+    exe = os.path.join(HOST, "planarFeatures")
+    out = subprocess.run([exe, png], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    want = f"total kp: {int(inner.sum())}, valid: {int((inner & (dep != 0)).sum())}, planar: {int((inner & planar).sum())}"
+    assert want in out.stdout, (want, out.stdout)
+    assert f"(the reference's rule): {int((inner & planar & nozero).sum())}" in out.stdout, out.stdout
+    assert int((inner & planar).sum()) > 50000                                   # the frame is mostly floor and walls
+    # a key point list (what cv::FAST would hand over), truncated like the reference does
+    rng = np.random.default_rng(5)
+    kps = np.stack([rng.uniform(0, W, 500), rng.uniform(0, H, 500)], 1)
+    kp_file = tmp_path / "kp.txt"
+    kp_file.write_text("\n".join(f"{u:.3f} {v:.3f}" for u, v in kps))
+    out = subprocess.run([exe, png, str(kp_file)], capture_output=True, text=True, timeout=300)
+    ui, vi = kps[:, 0].astype(int), kps[:, 1].astype(int)
+    ok = (ui >= 3) & (vi >= 3) & (ui + 3 < W) & (vi + 3 < H)
+    v_ = ok & (dep[np.clip(vi, 0, H - 1), np.clip(ui, 0, W - 1)] != 0)
+    pl = v_ & planar[np.clip(vi, 0, H - 1), np.clip(ui, 0, W - 1)]
+    assert f"total kp: 500, valid: {int(v_.sum())}, planar: {int(pl.sum())}" in out.stdout, out.stdout

@@ -148,7 +148,16 @@ def normals_numpy(c4, pix, w=7, min_in=41, in_dist=0.01):
 
 # ------------------------------------------------------------------------------------------------ the tests
 def _case(seed, w, h):
-    pr = synth.make_pair(seed, w, h)
+    """seed >= 0: the synthetic pair; seed -1: the reference's Kinect pair data/exp1/dep/1 -> dep/2 (tests/golden/kinect,
+    intrinsics of src/convert2PCD.cpp:19-23 = synth.Intrinsics' defaults)"""
+    if seed < 0:
+        from PIL import Image
+        kin = os.path.join(HERE, "golden", "kinect")
+        d1 = np.array(Image.open(os.path.join(kin, "exp1_dep_1.png"))).astype(np.uint16)
+        d2 = np.array(Image.open(os.path.join(kin, "exp1_dep_2.png"))).astype(np.uint16)
+        pr = synth.FramePair(-1, synth.Intrinsics(), d1, d2, np.eye(4))
+    else:
+        pr = synth.make_pair(seed, w, h)
     return pr, synth.backproject_numpy(pr.depth_src, pr.intr), synth.backproject_numpy(pr.depth_tgt, pr.intr)
 
 
@@ -247,5 +256,7 @@ def test_independent_golden_hashes_are_reproduced_by_the_oracle():
         for nn in (0, 1) if c["width"] <= 160 else (1,):
             ro = O.icp(s4, t4, O.params(pr.intr, estimator=c["estimator"], iterations=c["iterations"], nn_method=nn))
             assert hashlib.sha256(ro["idx"].astype("<i4").tobytes()).hexdigest() == c["idx_sha256"], c
-            assert np.allclose(ro["T_trace"][-1], np.array(c["T_final"]), rtol=0, atol=1e-8)
+            # 20 chained lstsq solves against 20 chained LDL^T solves of the fixed-point sums: the pose agrees far below the
+            # 1e-4 bar of the metric (1e-8 after <= 10 iterations; the real pair's long chain is looser)
+            assert np.allclose(ro["T_trace"][-1], np.array(c["T_final"]), rtol=0, atol=1e-8 if c["iterations"] <= 10 else 1e-7), c
             assert ro["inliers"] == c["inliers"]

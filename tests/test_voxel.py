@@ -172,6 +172,32 @@ def test_hip_voxel_grid_device_on_a_caller_stream_is_stream_ordered(gpu_lib):
         assert np.array_equal(g.view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.gpu
+def test_hip_voxel_grid_calls_on_different_streams_do_not_race(gpu_lib):
+    """a call on a caller's stream returns while its scatter / rank launches are still queued; the next call --
+    on ANOTHER stream, or a host-memory call on the handle's own stream -- reuses the handle's tables and must first wait
+    for them (hipStreamWaitEvent on the previous call's end event)."""
+    import torch
+    from slam3d_gx_amd import capi
+    clouds = [_cloud(s, 320, 240) for s in (21, 22, 23, 24, 25, 26)]
+    want = [O.voxel_grid(c) for _, c in clouds]
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    with capi.IcpHandle(capi.default_params(clouds[0][0].intr, max_batch=1)) as h:
+        ds = [torch.from_numpy(c).to("cuda:0") for _, c in clouds]
+        outs = [torch.zeros_like(d) for d in ds]
+        torch.cuda.synchronize()
+        for rep in range(3):
+            ms = []
+            for k, (d, o) in enumerate(zip(ds, outs)):
+                st = (sa, sb)[k % 2]                                  # alternate the two streams back to back
+                ms.append(h.voxel_grid_device(d.data_ptr(), d.shape[0], o.data_ptr(), 0.03, st.cuda_stream))
+            host = h.voxel_grid(clouds[0][1])                        # and one through the handle's own stream right behind
+            torch.cuda.synchronize()
+            assert np.array_equal(host.view(np.uint32), want[0].view(np.uint32))
+            for m, o, w in zip(ms, outs, want):
+                assert m == w.shape[0] and np.array_equal(o[:m].cpu().numpy().view(np.uint32), w.view(np.uint32)), rep
+
+
 # ---- keyframe cloud merge of saveOutput (src/saveOutput.cpp:47-103), row f-3 ---------------------------------
 def _merge_oracle(clouds, poses, leaf=0.03, pass_z=5.0):
     parts = []
