@@ -569,9 +569,10 @@ __device__ __forceinline__ Rt load_rt(const double *__restrict__ T)
     return m;
 }
 
-// the same from LDS (wave-uniform values: moved to SGPRs, so the pose costs no VGPR across the kernel)
-__device__ __forceinline__ float uni_f(double v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((float)v))); }
-__device__ __forceinline__ Rt load_rt_lds(const double *T)
+// the same from LDS, where the block keeps it already rounded to float (wave-uniform values: moved to SGPRs, so the pose
+// costs no VGPR across the kernel)
+__device__ __forceinline__ float uni_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ Rt load_rt_lds(const float *T)
 {
     Rt m;
     m.r00 = uni_f(T[0]); m.r01 = uni_f(T[1]); m.r02 = uni_f(T[2]);  m.t0 = uni_f(T[3]);
@@ -1142,12 +1143,47 @@ __device__ __forceinline__ double wave_solve_point2plane(const double *tot, cons
 // iterations + 1.
 constexpr int HEAD_POLLS = 200;      // x (a memory round trip + s_sleep): ~100 us until a poller gives up on block 0 and solves by itself
 
+// ---- clearance certificates: an iteration does not search again what the last one already proved ---------------------
+// Once the pose has settled, a query's nearest neighbour does not change from one iteration to the next -- and the kernel can
+// PROVE it without searching.  Every slot keeps a CLEARANCE c (metres, an array of the pair like prevq):
+//   * a slot with a match j:   every other valid target is at least c farther from the query than j is;
+//   * a slot without a match:  every valid target is at least c beyond the gate.
+// A full search yields it for free: the second-smallest distance among the candidates it scanned (tracked with one v_med3 and
+// one v_min per candidate) bounds the scanned ones, and every pruning test of the search is run with its radius inflated by
+// CERT_M, so everything it did NOT scan is at least sqrt(best) + CERT_M away.  Between two iterations the query moves by
+// delta = |p'_k - p'_(k-1)| (both from the float poses, the second recomputed from the previous pose), so by the triangle
+// inequality every distance changes by at most delta and the clearance by at most 2 delta: if c - 2 delta still exceeds the
+// rounding slack CERT_TAU of the canonical d2, the argmin -- ties included: the inequality is strict -- is the same target,
+// whose key is formed directly from the stored match point.  Such a lane takes no part in the search; a wave whose lanes are all
+// certified skips window, tiles and items altogether.  The clearance then shrinks by 2 delta per skipped iteration until a
+// search renews it.  Exact, and checked the way the pruning is: results bit-identical to the oracle with and without
+// (SLAM3D_CERT=0), soak, the tie-heavy duplicate-target cases (a tie has clearance 0: never certified).
+constexpr float CERT_M = 1.0e-4f;        // metres added to every pruning radius: the clearance of what a search does not scan
+constexpr int CERT_TRACK_IT = 6;         // first iteration that tracks second-best distances and inflates its radii (the launches before
+                                         // move the pose by millimetres: nothing they could certify would survive, and tracking costs
+                                         // two VALU operations per candidate where the candidates are most numerous)
+__device__ __forceinline__ float infl_thr(float U, float cm)       // (sqrt(U) + cm)^2 with room for the roundings of the gap tests and of sqrt
+{
+    if (cm == 0.0f) return U * 1.00001f + 1e-30f;            // (wave-uniform: launches that do not track pay no square root)
+    return (U + (2.0002f * cm) * __builtin_amdgcn_sqrtf(U) + 1.0002f * cm * cm) * 1.00001f + 1e-30f;
+}
+// Rounding budget: the canonical d2 carries at most 5 roundings (three differences squared, two fmas): relative error < 3.2e-7,
+// i.e. 1.6e-7 on the distance, + 1 ulp of v_sqrt_f32: every sqrt(fl d2) below is within 2.5e-7 (relative) of the true distance.
+// 1e-6 per quantity leaves a factor 4.  fl(d2(c)) > fl(d2(b)) follows from D(c) - D(b) > 3.5e-7 D(b): cert_tau.
+__device__ __forceinline__ float cert_tau(float sq) { return 1.0e-6f * sq + 2.0e-8f; }   // gap (m) that guarantees fl(d2) strictly ordered
+// (best, second) of the scanned candidates' d2: second = the median of (best, second, d2) -- inputs never NaN
+__device__ __forceinline__ void track2(float &b, float &s2, float d2)
+{
+    asm("v_med3_f32 %0, %1, %0, %2" : "+v"(s2) : "v"(b), "v"(d2));
+    asm("v_min_f32 %0, %0, %1" : "+v"(b) : "v"(d2));
+}
+
 constexpr int PROJ_RMAX = 3;         // largest window radius the projective search takes on (7x7 pixels)
 constexpr int QSTRIDE = 17;                        // float4 per staged quadrant: 16 candidates + 1 pad: lane-specific reads of
                                                    // different quadrants then fall into different banks
 constexpr int STAGE_REC = 4 * QSTRIDE + 8;         // LDS image of a tile record (TILE_REC in global memory)
-constexpr int NN_MAX_ITEMS = 128;    // (owner wave, coarse cell) work items shared by the waves of a block
-constexpr int NN_MAX_TITEMS = 384;   // (owner wave, target tile) work items: the tiles the cell sweeps found worth scanning
+constexpr int NN_MAX_ITEMS = 32;     // (owner wave, coarse cell) work items shared by the waves of a block (max seen 15; the rest is swept by its owner)
+constexpr int NN_MAX_TITEMS = 128;   // (owner wave, target tile) work items: the tiles the cell sweeps found worth scanning (max seen 31)
 constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (8 measured slower: 2 blocks per CU)
 
 // grid (G, B), block 256 = 4 waves; G = a multiple of 8 >= ntiles/4.  Wave w of block c OWNS one source tile: in the
@@ -1175,9 +1211,14 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                                                         StampRing sring /* launch stamps; rows null (the default): none */, int stamp_idx,
                                                         int head /* solve iteration it-1 at the head of this launch (see above) */,
                                                         double *__restrict__ trace_T, double *__restrict__ trace_S, int *__restrict__ flags,
-                                                        int iters, int nsets /* accumulator sets per pair */)
+                                                        int iters, int nsets /* accumulator sets per pair */,
+                                                        float *__restrict__ clear /* [pairs][nslots] clearance of every slot's last result */,
+                                                        int cert /* certify from it >= 1 on (needs `it` = the run's iteration and trace_T[it - 1]) */)
 {
     const int first = it == 0;
+    const bool trk = cert && it >= CERT_TRACK_IT;           // this launch tracks (best, second) and inflates its pruning radii: its results carry clearances
+    const bool certify = cert && it > CERT_TRACK_IT;        // ... so the NEXT one may certify from them
+    const float cm = trk ? CERT_M : 0.0f;
     __shared__ float4 stage_all[NN_WAVES][NN_STAGE * STAGE_REC];
     __shared__ int wcost[NN_WAVES];                                    // cycles spent for each owner (all helpers)
     __shared__ float qpos[NN_WAVES][3][TILE_SLOTS];                   // p'.x / .y / .z of each owner's queries (SoA: 3 KB, not 4)
@@ -1188,13 +1229,15 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     __shared__ int items[NN_MAX_ITEMS];                                // phase A work: (owner wave << 16 | coarse cell)
     __shared__ int titems[NN_MAX_TITEMS];                              // phase B work: (owner wave << 24 | target tile)
     __shared__ int n_items, next_item, n_titems, next_titem;
-    __shared__ double head_T[16];                                     // the pose of this launch when it was solved at the head
+    __shared__ float head_T[12], prev_T[12];                          // this launch's pose (R | t rows, rounded once to float) and the previous one
+    __shared__ unsigned int qbs[NN_WAVES][2][TILE_SLOTS];               // each owner's (best, second) d2 among the candidates scanned for it
     const long long clk0 = DBG ? clock64() : 0;
     const long long rt0 = DBG ? (long long)wall_clock64() : 0;
     long long clk1 = 0, clk2 = 0, clk3 = 0, clkP = 0, clkB1 = 0, clkD = 0, clkM = 0, clkE = 0;
     int n_my_items = 0;
     // per-tile work counters and clocks of the instrumented (DBG) instances; compiled out of the production ones
     int n_scanned = 0, n_cand = 0, n_batches = 0, n_chit = 0, n_fhit = 0, n_refined = 0;
+    int dbg_cert = 0;
     long long n_b_hist = 0;     // phase B items this wave processed: count | <=2 | <=4 | <=8 | <=16 active lanes (8 bits each) | sum of active lanes
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.y, c = blockIdx.x;
@@ -1242,7 +1285,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     if (threadIdx.x == 0) { n_items = 0; next_item = 0; n_titems = 0; next_titem = 0; }
     if (threadIdx.x < NN_WAVES) wcost[threadIdx.x] = 0;
     // the launch's pose goes through LDS in both cases: read from Tcur (k_solve_acc wrote it), or solved right here
-    if (!(COOP && head && it > 0)) { if (threadIdx.x < 16) head_T[threadIdx.x] = Tcur[b * 16 + threadIdx.x]; }
+    if (!(COOP && head && it > 0)) { if (threadIdx.x < 12) head_T[threadIdx.x] = (float)Tcur[b * 16 + threadIdx.x]; }
+    if (certify && threadIdx.x >= 64 && threadIdx.x < 76) prev_T[threadIdx.x - 64] = (float)trace_T[((size_t)b * (iters + 1) + (it - 1)) * 16 + (threadIdx.x - 64)];
     if constexpr (COOP) {
         if (head && it > 0) {
             if (w == 0) {
@@ -1262,7 +1306,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                         if (__ballot(lane < 16 && v == HEAD_EMPTY) == 0ull) { have = true; break; }
                         __builtin_amdgcn_s_sleep(4);
                     }
-                    if (have && lane < 16) head_T[lane] = __longlong_as_double((long long)v);
+                    if (have && lane < 12) head_T[lane] = (float)__longlong_as_double((long long)v);
                 }
                 if (!have) {
                     const long long *__restrict__ A = acc + ((size_t)b * nsets + (it - 1)) * ACC_R * ACC_STRIDE;
@@ -1278,7 +1322,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     int rc;
                     const double Tn = wave_solve_point2plane(tot, tsh, rc);
-                    if (lane < 16) head_T[lane] = Tn;
+                    if (lane < 12) head_T[lane] = (float)Tn;
                     if (c == 0) {                                   // the one block that publishes
                         if (lane < NSUMS) trace_S[((size_t)b * iters + (it - 1)) * NSUMS + lane] = tot[lane];
                         if (lane == 0 && rc != 1) flags[b] = flags[b] | (rc == 2 ? 1 : 2);
@@ -1295,6 +1339,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     float px = 0.0f, py = 0.0f, pz = 0.0f;
     bool valid = false, tight = false, loose = false;
     unsigned long long bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
+    float bsc = __int_as_float(0x7f800000), sec = __int_as_float(0x7f800000);     // (best, second) d2 of the candidates scanned in this context
     int ta[NN_STAGE];                                 // the tiles of the current owner's step 1
 #pragma unroll
     for (int k = 0; k < NN_STAGE; ++k) ta[k] = -1;
@@ -1305,7 +1350,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     // monotone), the sum has the canonical association, and the threshold is the lane's current best d2 with a 1e-5
     // margin over the few-ulp differences that remain; a threshold taken earlier is larger, hence still conservative.
     auto lane_thr = [&]() __attribute__((always_inline)) {
-        return __int_as_float((int)(unsigned int)(bkey >> 32)) * 1.00001f + 1e-30f;
+        return infl_thr(__int_as_float((int)(unsigned int)(bkey >> 32)), cm);      // (radius + CERT_M: what is NOT scanned has that clearance)
     };
     auto lane_gap_le = [&](const float4 lo, const float4 hi, float thr) __attribute__((always_inline)) {
         const float gx = fmaxf(0.0f, fmaxf(lo.x - px, px - hi.x));
@@ -1342,15 +1387,30 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                 m &= m - 1u;
                 const float4 *__restrict__ cand = st + (q >> 2) * STAGE_REC + (q & 3) * QSTRIDE;
                 // the padding slots of a quadrant hold (+inf, +inf, +inf): d2 = +inf never wins
+                if (trk) {
 #pragma unroll 1
-                for (int i = 0; i < 16; i += 4) {
+                    for (int i = 0; i < 16; i += 4) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float4 c4 = cand[i + u];
-                        const float d2 = canon_d2(px, py, pz, c4.y, c4.z, c4.w);     // record = (pixel, x, y, z)
-                        const unsigned long long key =
-                            ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(c4.x);
-                        bkey = key_min(bkey, key);
+                        for (int u = 0; u < 4; ++u) {
+                            const float4 c4 = cand[i + u];
+                            const float d2 = canon_d2(px, py, pz, c4.y, c4.z, c4.w);     // record = (pixel, x, y, z)
+                            const unsigned long long key =
+                                ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(c4.x);
+                            bkey = key_min(bkey, key);
+                            track2(bsc, sec, d2);
+                        }
+                    }
+                } else {
+#pragma unroll 1
+                    for (int i = 0; i < 16; i += 4) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float4 c4 = cand[i + u];
+                            const float d2 = canon_d2(px, py, pz, c4.y, c4.z, c4.w);
+                            const unsigned long long key =
+                                ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(c4.x);
+                            bkey = key_min(bkey, key);
+                        }
                     }
                 }
             }
@@ -1387,6 +1447,15 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         scan_lanes(m);
         __builtin_amdgcn_wave_barrier();
     };
+    // (best, second) of what this wave scanned for `owner` joins the owner's: the new best is the minimum, the new second the
+    // smallest of both seconds and of the LOSER of the two bests (non-negative floats order like their bit patterns)
+    auto merge_bs = [&](int owner) __attribute__((always_inline)) {
+        if (bsc < inf) {
+            const unsigned int old = atomicMin(&qbs[owner][0][lane], (unsigned int)__float_as_int(bsc));
+            const float loser = fmaxf(__int_as_float((int)old), bsc);
+            atomicMin(&qbs[owner][1][lane], (unsigned int)__float_as_int(fminf(sec, loser)));
+        }
+    };
     auto park_and_scan = [&]() __attribute__((always_inline)) { park(); scan_parked(); };
     // The wave-level tests use TWO query boxes: lanes whose bound is already small ("tight", radius below a
     // quarter of the gate) and the rest ("loose": no match yet / far match), so that a few loose lanes do not
@@ -1401,7 +1470,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         const float c = wave_min_x4(tight ? -py : inf, tight ? -pz : inf, tight ? -cur : 0.0f, 0.0f);
         qminx = rdlane(a, 0); qminy = rdlane(a, 32); qminz = rdlane(a, 16); qmaxx = -rdlane(a, 48);
         qmaxy = -rdlane(c, 0); qmaxz = -rdlane(c, 32);
-        thr_t = -rdlane(c, 16) * 1.00001f + 1e-30f;                // covers the rounding of box_gap2 and of canon_d2
+        thr_t = infl_thr(-rdlane(c, 16), cm);                          // covers the rounding of box_gap2 and of canon_d2, + CERT_M
         any_loose = __ballot(loose) != 0ull;
         lminx = lminy = lminz = inf; lmaxx = lmaxy = lmaxz = -inf;
         thr_l = 0.0f;
@@ -1410,7 +1479,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             const float f = wave_min_x4(loose ? -py : inf, loose ? -pz : inf, loose ? -cur : 0.0f, 0.0f);
             lminx = rdlane(e, 0); lminy = rdlane(e, 32); lminz = rdlane(e, 16); lmaxx = -rdlane(e, 48);
             lmaxy = -rdlane(f, 0); lmaxz = -rdlane(f, 32);
-            thr_l = -rdlane(f, 16) * 1.00001f + 1e-30f;
+            thr_l = infl_thr(-rdlane(f, 16), cm);
         }
     };
     // gap test of a box against both query boxes with the CURRENT class bounds (empty class -> never hits)
@@ -1422,8 +1491,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     auto class_thr = [&](float &thr_t, float &thr_l) __attribute__((always_inline)) {
         const float cur = __int_as_float((int)(unsigned int)(bkey >> 32));
         const float m = wave_min_x4(tight ? -cur : 0.0f, loose ? -cur : 0.0f, 0.0f, 0.0f);     // both maxima in one pass
-        thr_t = -rdlane(m, 0) * 1.00001f + 1e-30f;                   // covers the rounding of box_gap2 and of canon_d2
-        thr_l = any_loose ? -rdlane(m, 32) * 1.00001f + 1e-30f : 0.0f;
+        thr_t = infl_thr(-rdlane(m, 0), cm);                             // covers the rounding of box_gap2 and of canon_d2, + CERT_M
+        thr_l = any_loose ? infl_thr(-rdlane(m, 32), cm) : 0.0f;
     };
     // fine level of coarse cell cc, in three pieces so that the cooperative build can keep several loads in flight:
     // (1) the child boxes (lane k holds child tile k of the 8x8 cell) ...
@@ -1450,12 +1519,13 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         }
         unsigned long long tm0 = __ballot(hit2), tm = 0ull;
         if constexpr (DBG) { n_chit += 1; n_fhit += __popcll(tm0); }
+        const float lthr = lane_thr();                          // (the lane's bound does not change while the cell is refined)
         while (tm0) {
             const int k2 = __builtin_ctzll(tm0);
             tm0 &= tm0 - 1;
             const float4 blo = make_float4(rdlane(lo.x, k2), rdlane(lo.y, k2), rdlane(lo.z, k2), 0.0f);
             const float4 bhi = make_float4(rdlane(hi.x, k2), rdlane(hi.y, k2), rdlane(hi.z, k2), 0.0f);
-            if (__ballot(lane_gap_ok(blo, bhi)) != 0ull) tm |= 1ull << k2;
+            if (__ballot(lane_gap_le(blo, bhi, lthr)) != 0ull) tm |= 1ull << k2;
         }
         if constexpr (DBG) n_refined += __popcll(tm);
         return tm;
@@ -1502,6 +1572,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     };
 
     // ================= step 1: own tile =================
+    bool certd = false;                               // this lane's result is certified unchanged (no search)
+    unsigned long long cert_mask = 0ull;
     int own_jprev = -2;                               // what prevq holds for this lane's slot (-2: nothing known, always write)
     const float4 s4 = has_tile ? pp.srcT[(size_t)t * TILE_SLOTS + lane] : make_float4(0, 0, 0, __int_as_float(-1));
     const int pix = __float_as_int(s4.w);
@@ -1557,7 +1629,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         for (int k = 0; k < NN_STAGE; ++k) ta[k] = tt[k];
         fetch_batch();                                             // one round of independent loads ...
         float4 pq = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
-        if (!first) pq = prevq[gs];                                // (a run's first iteration: whatever an earlier run left there is ignored)
+        float cprev = -1.0f;                                       // the slot's clearance after the last iteration (metres; <= 0: none)
+        if (!first) { pq = prevq[gs]; if (certify) cprev = clear[gs]; }   // (a run's first iteration: whatever an earlier run left there is ignored)
         float4 qs = make_float4(0, 0, 0, 0);
         float ws = 1.0f;
         if (__float_as_int(pq.w) < 0) {   // no previous match (first iteration): fall back to the target at the same pixel
@@ -1575,7 +1648,31 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             const float4 qg = have_prev ? pq : qs;
             const float d2g = canon_d2(px, py, pz, qg.x, qg.y, qg.z);
             if (tv && d2g <= g.gate2) bkey = ((unsigned long long)(unsigned int)__float_as_int(d2g) << 32) | (unsigned int)jg;
+            // ---- clearance certificate (see CERT_M above): the slot's clearance minus twice the distance the query moved since the
+            // last iteration still exceeds the rounding slack => the argmin (or "nothing within the gate") is what it was
+            if (certify) {
+                const Rt mp = load_rt_lds(prev_T);
+                float ox_, oy_, oz_;
+                xform(mp, s4.x, s4.y, s4.z, ox_, oy_, oz_);
+                const float dl = __builtin_amdgcn_sqrtf(canon_d2(px, py, pz, ox_, oy_, oz_)) * 1.000001f + 1.0e-9f;
+                const float cn = cprev - 2.0f * dl;
+                const bool t_match = have_prev && d2g <= g.gate2;          // the previous match, still inside the gate
+                const bool t_none = valid && !have_prev;                     // no match last time: clearance is to the gate
+                const float base = t_match ? __builtin_amdgcn_sqrtf(d2g) : __builtin_amdgcn_sqrtf(g.gate2);
+                certd = (t_match || t_none) && cn > cert_tau(base * 1.000001f);
+                if constexpr (DBG) {     // why lanes are not certified: no clearance at all | match left the gate | clearance used up
+                    const bool nc0 = valid && !certd && !(cprev > 0.0f), nc1 = valid && !certd && cprev > 0.0f && have_prev && !(d2g <= g.gate2),
+                               nc2 = valid && !certd && cprev > 0.0f && !(have_prev && !(d2g <= g.gate2));
+                    dbg_cert = __popcll(__ballot(nc0)) | (__popcll(__ballot(nc1)) << 8) | (__popcll(__ballot(nc2)) << 16) | (__popcll(__ballot(valid)) << 24);
+                }
+                if (certd) {
+                    clear[gs] = cn;                                          // what is left of it for the next iteration
+                    if (t_none) bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;     // (not even the same-pixel target)
+                }
+            }
         }
+        cert_mask = __ballot(certd);
+        valid = own_valid && !certd;                               // certified lanes take no part in the search; their key stands
         if constexpr (DBG) clk1 = clock64();
         hinted = th >= 0;
         // ---- projective window search.  The target cloud is OUR back-projection of a depth image: the target of pixel
@@ -1592,7 +1689,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         // on the other); the region is staged once in the wave's LDS slab (four coalesced loads per lane, one round trip) and
         // probed from there with lane-specific addresses; a lane whose window leaves the region is simply not settled here.
         bool done = false;
-        if (pp.tq != nullptr && th >= 0) {
+        if (pp.tq != nullptr && th >= 0 && __ballot(valid) != 0ull) {
             const float4 *__restrict__ TQ = pp.tq;
             constexpr int RW = 15;                                       // region edge; RW * RW float4 fit the stage slab
             static_assert(RW * RW <= NN_STAGE * STAGE_REC, "the window region must fit the wave's stage slab");
@@ -1604,7 +1701,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             const float kz = g.proj_c * izp;
             auto radius = [&]() __attribute__((always_inline)) {         // window radius the lane's CURRENT bound needs
                 const float U = __int_as_float((int)(unsigned int)(bkey >> 32));
-                return kz * (__builtin_amdgcn_sqrtf(U) + 1.0e-5f) - 0.49f;
+                return kz * (__builtin_amdgcn_sqrtf(U) + (1.0e-5f + 1.0002f * cm)) - 0.49f;       // (+ CERT_M: the clearance of everything outside the window)
             };
             float rn = sane ? radius() : 1.0e9f;
             int r_l = rn > 0.0f ? (int)ceilf(fminf(rn, 1.0e6f)) : 0;
@@ -1632,6 +1729,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                         const unsigned long long key =
                             ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(c4.x);
                         bkey = key_min(bkey, key);
+                        track2(bsc, sec, d2);
                     }
                 };
                 probe(0, 0, r_l >= 0);
@@ -1653,7 +1751,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        valid = own_valid && !done;
+        valid = own_valid && !done && !certd;
         if (__ballot(valid) != 0ull) {
             park();                  // the staged tile records take the slab over
             scan_parked();
@@ -1734,6 +1832,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             }
         }
         }
+        if constexpr (COOP) { qbs[w][0][lane] = (unsigned int)__float_as_int(bsc); qbs[w][1][lane] = (unsigned int)__float_as_int(sec); }
     }
     if constexpr (!COOP) { if (lane == 0) atomicAdd(&wcost[w], (int)(clock64() - cw0)); }
     if constexpr (DBG) clkP = clock64();
@@ -1751,6 +1850,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             px = qpos[owner][0][lane]; py = qpos[owner][1][lane]; pz = qpos[owner][2][lane];
             valid = (qcls[owner][0] >> lane) & 1ull; tight = (qcls[owner][1] >> lane) & 1ull; loose = valid && !tight;
             bkey = qkey[owner][lane];
+            bsc = inf; sec = inf;                                   // what THIS wave scans for the owner, merged afterwards
         };
         auto load_owner_boxes = [&](int owner) __attribute__((always_inline)) {
 #pragma unroll
@@ -1779,7 +1879,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                 if constexpr (DBG) n_my_items += 1;
                 load_owner(owner);
                 load_owner_boxes(owner);
-                if (append_tiles(owner, cell_refine(lo, hi, ctx, cty), ctx, cty) && valid) atomicMin(&qkey[owner][lane], bkey);
+                if (append_tiles(owner, cell_refine(lo, hi, ctx, cty), ctx, cty) && valid) { atomicMin(&qkey[owner][lane], bkey); merge_bs(owner); }
             };
             refine_item(item0, lo0, hi0, ctx0, cty0);
             if (two) refine_item(item1, lo1, hi1, ctx1, cty1);
@@ -1812,12 +1912,13 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                 px = qpos[own[k]][0][lane]; py = qpos[own[k]][1][lane]; pz = qpos[own[k]][2][lane];
                 valid = (qcls[own[k]][0] >> lane) & 1ull;
                 bkey = qkey[own[k]][lane];                     // the owner's best so far, every earlier merge included
+                bsc = inf; sec = inf;
                 if constexpr (DBG) {     // how many of the owner's lanes can reach this tile at all (the lanes the scan works for)
                     const int na = __popcll(__ballot(lane_gap_le(TB[2 * tt[k]], TB[2 * tt[k] + 1], lane_thr())));
                     n_b_hist += 1ll | ((long long)(na <= 2) << 8) | ((long long)(na <= 4) << 16) | ((long long)(na <= 8) << 24) | ((long long)(na <= 16) << 32) | ((long long)na << 40);
                 }
                 scan_staged(k, tt[k]);
-                if (valid) atomicMin(&qkey[own[k]][lane], bkey);
+                if (valid) { atomicMin(&qkey[own[k]][lane], bkey); merge_bs(own[k]); }
             }
             hinted = false;
             __builtin_amdgcn_wave_barrier();
@@ -1840,9 +1941,9 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     if (__ballot(own_valid) == 0ull) bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
     size_t gs_ep;                      // the slot index again, recomputed behind an opaque copy of t: kept live from the top of
     {                                  // the kernel it cost a register pair across the drain (one scratch spill per wave)
-        int t_ep = t;
-        asm volatile("" : "+s"(t_ep));
-        gs_ep = (size_t)b * tg.nslots + (size_t)t_ep * TILE_SLOTS + lane;
+        int t_ep = t, b_ep = b;        // (b too: hipcc kept the common part b * nslots + lane of the two indices in a VGPR pair and spilled it)
+        asm volatile("" : "+s"(t_ep), "+s"(b_ep));
+        gs_ep = (size_t)b_ep * tg.nslots + (size_t)t_ep * TILE_SLOTS + lane;
     }
     RowBasis rb;
     if constexpr (GATED) {             // the optional S4g gates: their own instances, the production ones carry none of this
@@ -1856,6 +1957,18 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     } else
         finish_slot<false>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs_ep, cd2 + gs_ep, prevq + gs_ep, rb,
                            write_out != 0, own_jprev);
+    if (trk && own_valid && !((cert_mask >> lane) & 1ull)) {
+        // this lane searched: its clearance for the next iteration.  Scanned candidates other than the winner are at least
+        // sqrt(other) away (other = the second-smallest scanned d2, or the smallest when the winner itself was not among the
+        // scanned ones); everything the search did not scan is at least sqrt(best) + CERT_M away (every pruning radius was
+        // inflated by CERT_M and only shrank afterwards); 1e-6 covers the roundings of d2 and of sqrt (see cert_tau).
+        if constexpr (COOP) { bsc = __int_as_float((int)qbs[w][0][lane]); sec = __int_as_float((int)qbs[w][1][lane]); }
+        const float u1 = __int_as_float((int)(unsigned int)(bkey >> 32));
+        const bool real = (unsigned int)bkey != 0xffffffffu;                    // a match (else: nothing within the gate)
+        const float other = real ? (u1 == bsc ? sec : bsc) : bsc;
+        const float base = __builtin_amdgcn_sqrtf(real ? u1 : g.gate2);
+        clear[gs_ep] = fminf(__builtin_amdgcn_sqrtf(other), base + CERT_M) * (1.0f - 1.0e-6f) - base * (1.0f + 1.0e-6f) - 1.0e-9f;
+    }
     tile_accumulate(g.estimator, rb, acc + (((size_t)b * nsets + (head ? it : 0)) * ACC_R + (c % ACC_R)) * ACC_STRIDE);
     stamp_wave_end();
     if (DBG && dbg && b == 0 && lane == 0) {
@@ -1869,10 +1982,10 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
         d[8] = (long long)hw_id | ((long long)xcc_id << 32);
-        d[9] = (long long)c * NN_WAVES + w;
+        d[9] = ((long long)c * NN_WAVES + w) | ((long long)dbg_cert << 32);
         d[10] = rt0; d[11] = (long long)wall_clock64();
         d[12] = clkP; d[13] = clkB1; d[14] = clkD; d[15] = (long long)n_my_items | ((long long)(COOP ? n_items : 0) << 32);
-        d[16] = clkM; d[17] = clkE; d[18] = COOP ? n_titems : 0; d[19] = n_b_hist;
+        d[16] = clkM; d[17] = clkE; d[18] = (long long)(COOP ? n_titems : 0) | ((long long)__popcll(cert_mask) << 32); d[19] = n_b_hist;
     }
 }
 

@@ -543,6 +543,38 @@ def test_head_solve_modes_are_bit_identical(gpu_lib, mode, monkeypatch):
     assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:3], ro["sums_trace"])
 
 
+@pytest.mark.parametrize("cert", ["1", "0"])
+def test_clearance_certificates_change_no_bit(gpu_lib, cert, monkeypatch):
+    """Clearance certificates (icp_kernels.hpp: from the seventh iteration on a lane whose nearest neighbour provably did not
+    change is not searched again) on and off: every iterate, every sum, the indices and d2 of the last iteration equal the
+    oracle's over LONG runs (40 iterations: certificate chains of 30+ skipped searches), with exact ties (duplicated target
+    points: clearance 0, never certified), a tight and a wide gate, both estimators, a batch, and a poor initial guess."""
+    monkeypatch.setenv("SLAM3D_CERT", cert)
+    cases = [dict(seed=1000, w=320, h=240, est=0, iters=40, gate=0.10), dict(seed=1004, w=320, h=240, est=1, iters=40, gate=0.10),
+             dict(seed=1005, w=160, h=120, est=0, iters=40, gate=0.02), dict(seed=1006, w=320, h=240, est=0, iters=30, gate=0.5)]
+    for cse in cases:
+        pr, s4, t4 = _pair(cse["seed"], cse["w"], cse["h"])
+        t4 = t4.copy()
+        t4[:, 1::7, :] = t4[:, 0::7, :][:, : t4[:, 1::7, :].shape[1], :]        # every seventh column duplicates its neighbour: exact ties
+        Ti = synth.pose_from_seed(cse["seed"] + 7, 1.0, 0.02) if cse["seed"] % 2 else None
+        po = O.params(pr.intr, estimator=cse["est"], iterations=cse["iters"], nn_method=1, max_corr_dist=cse["gate"])
+        ro = O.icp(s4, t4, po, T_init=Ti)
+        with capi.IcpHandle(capi.default_params(pr.intr, estimator=cse["est"], iterations=cse["iters"], max_corr_dist=cse["gate"])) as h:
+            for rep in range(2):
+                rg = h.align(s4, t4, Ti)
+                idx, d2 = h.get_correspondences(0)
+                Tt, St = h.get_trace(0)
+                assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[: cse["iters"]], ro["sums_trace"]), (cse, rep)
+                assert np.array_equal(idx, ro["idx"]) and np.array_equal(d2.view(np.uint32), ro["d2"].view(np.uint32)), (cse, rep)
+                assert rg["inliers"] == ro["inliers"] and rg["status"] == ro["status"]
+    prs = [_pair(3200 + i, 320, 240) for i in range(3)]
+    with capi.IcpHandle(capi.default_params(prs[0][0].intr, iterations=25, max_batch=3)) as h:
+        res = h.align_batch([p[1] for p in prs], [p[2] for p in prs])
+        for b, (pr, s4, t4) in enumerate(prs):
+            ro = O.icp(s4, t4, O.params(pr.intr, iterations=25, nn_method=1))
+            assert np.array_equal(h.get_trace(b)[0].reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(h.get_correspondences(b)[0], ro["idx"]), b
+
+
 def test_launch_stamps_are_ordered_and_change_nothing(gpu_lib):
     """slam3d_icp_set_stamping: every NN / solve launch reports (start, end) on the device's real-time counter; the
     launches of a run follow each other, two handles in flight share the clock, and the results are bit-identical with

@@ -28,6 +28,10 @@ for it in (1, iters):
     rs, re_ = (d[:, 10] - rt0) * 10, (d[:, 11] - rt0) * 10          # ns since the first wave started (100 MHz counter)
     t0 = 0
     print(f"--- last of {it} iteration(s): {act.sum()} active waves; launch span (first start -> last end) {re_.max()} ns")
+    dc = d[:, 9] >> 32
+    nc_all, nv_all = ((d[:, 18] >> 32) & 0xff).copy(), ((dc >> 24) & 0xff).copy()
+    why = [int((dc & 0xff).sum()), int(((dc >> 8) & 0xff).sum()), int(((dc >> 16) & 0xff).sum())]
+    d[:, 18] &= 0xffffffff
     d1 = d[d[:, 1] > 0]
     lo32 = lambda x: x & 0xffffffff
     hi32 = lambda x: x >> 32
@@ -39,6 +43,12 @@ for it in (1, iters):
                     ("epilogue", d1[:, 4] - d1[:, 3]), ("tiles scanned", lo32(d1[:, 5])), ("candidates", lo32(d1[:, 6])), ("batches", lo32(d1[:, 7])),
                     ("cells swept", hi32(d1[:, 5])), ("fine hits", hi32(d1[:, 6])), ("refined hits", hi32(d1[:, 7]))):
         print(f"{name:14s} mean {v.mean():10.1f}  p50 {np.percentile(v,50):9.0f}  p90 {np.percentile(v,90):9.0f}  p99 {np.percentile(v,99):9.0f}  max {v.max():9.0f}")
+    nc, nv = nc_all, nv_all
+    if nv.sum():
+        full = (nc == nv) & (nv > 0)
+        print(f"certified lanes {nc.sum()} of {nv.sum()} valid ({100.0 * nc.sum() / nv.sum():.1f} %); waves with every valid lane certified: {full.sum()} of {(nv > 0).sum()} "
+              f"({100.0 * full.sum() / max(1, (nv > 0).sum()):.1f} %); uncertified lanes per not-fully-certified wave: mean {(nv - nc)[~full & (nv > 0)].mean() if (~full & (nv > 0)).any() else 0:.1f}; "
+              f"why not: no clearance {why[0]}, match left the gate {why[1]}, clearance used up {why[2]}")
     hb = d[:, 19]
     nit = (hb & 0xff).sum()
     if nit:
