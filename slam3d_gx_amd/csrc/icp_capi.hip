@@ -602,13 +602,13 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
             TinitArgs ti;
             const int n = B - b0 < TINIT_ARGS ? B - b0 : TINIT_ARGS;
             memcpy(ti.T, T_init + (size_t)b0 * 16, sizeof(double) * 16 * n);
-            hipLaunchKernelGGL(k_pair_init, dim3(n), dim3(64), 0, s, ti, 1, b0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters, h->nsets,
+            hipLaunchKernelGGL(k_pair_init, dim3(n), dim3(256), 0, s, ti, 1, b0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters, h->nsets,
                                stamp_ring_of(h, b0 == 0), (count_run && b0 == 0) ? 1 : 0);
         }
     } else {
         TinitArgs ti;
         memset(&ti, 0, sizeof ti);
-        hipLaunchKernelGGL(k_pair_init, dim3(B), dim3(64), 0, s, ti, 0, 0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters, h->nsets,
+        hipLaunchKernelGGL(k_pair_init, dim3(B), dim3(256), 0, s, ti, 0, 0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters, h->nsets,
                                stamp_ring_of(h), count_run);
     }
     if (nn_mode_of(h) != SLAM3D_NN_TILES) {

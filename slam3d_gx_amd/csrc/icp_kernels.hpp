@@ -479,17 +479,17 @@ __global__ __launch_bounds__(64) void k_coarse_boxes(FrameTasks a, TileGrid tg)
 }
 
 // start of a run for the pairs [b0, b0 + n): T = T_init (kernel argument) or Identity, trace row 0, flags, clean
-// accumulators.  grid (n), block 64.  (prevq / corr need no reset: the first iteration ignores them.)
+// accumulators.  grid (n), block 256.  (prevq / corr need no reset: the first iteration ignores them.)
 constexpr int TINIT_ARGS = 16;
 struct TinitArgs { double T[TINIT_ARGS][16]; };
-__global__ __launch_bounds__(64) void k_pair_init(TinitArgs ti, int has_T, int b0, double *__restrict__ Tcur,
+__global__ __launch_bounds__(256) void k_pair_init(TinitArgs ti, int has_T, int b0, double *__restrict__ Tcur,
                                                   double *__restrict__ trace_T, int *__restrict__ flags,
                                                   long long *__restrict__ acc, unsigned int *__restrict__ ticket, int iters, int nsets,
                                                   StampRing sr /* rows null: no stamps */, int count_run /* slam3d_icp_run: one more run in flight */)
 {
     const int k = blockIdx.x, b = b0 + k, lane = threadIdx.x;
     if (count_run && k == 0 && lane == 0) atomicAdd(&g_runs_in_flight, 1);
-    if (sr.rows && k == 0) {       // launch stamps (opt-in): this run takes the next slot of the ring; start = min -> ~0, end = max -> 0
+    if (sr.rows && k == 0 && lane < 64) {       // launch stamps (opt-in, first wave): this run takes the next slot of the ring; start = min -> ~0, end = max -> 0
         const unsigned int run = (*sr.seq + 1u) % (unsigned int)sr.ring;
         unsigned long long *__restrict__ rows = sr.rows + (size_t)run * sr.rows_per_run * STAMP_ROW;
         for (int j = lane; j < sr.rows_per_run * STAMP_ROW; j += 64) rows[j] = (j % STAMP_ROW) < STAMP_R ? ~0ull : 0ull;
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(64) void k_pair_init(TinitArgs ti, int has_T, int b
     }
     {   // every accumulator set of the pair (one per iteration when the solve runs at the head of the next launch)
         longlong2 *__restrict__ a2 = reinterpret_cast<longlong2 *>(acc + (size_t)b * nsets * ACC_R * ACC_STRIDE);
-        for (int j = lane; j < nsets * ACC_R * ACC_STRIDE / 2; j += 64) a2[j] = make_longlong2(0, 0);
+        for (int j = lane; j < nsets * ACC_R * ACC_STRIDE / 2; j += 256) a2[j] = make_longlong2(0, 0);       // (80 KB per pair: four waves)
     }
     if (lane < 16) {
         const double v = has_T ? ti.T[k % TINIT_ARGS][lane] : ((lane % 5 == 0) ? 1.0 : 0.0);
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(64) void k_pair_init(TinitArgs ti, int has_T, int b
         trace_T[((size_t)b * (iters + 1)) * 16 + lane] = v;
     }
     // the pose rows the head solves will publish: every entry "not published yet"
-    for (int j = 16 + lane; j < (iters + 1) * 16; j += 64)
+    for (int j = 16 + lane; j < (iters + 1) * 16; j += 256)
         reinterpret_cast<unsigned long long *>(trace_T)[(size_t)b * (iters + 1) * 16 + j] = HEAD_EMPTY;
     if (lane == 0) { flags[b] = 0; ticket[b] = 0u; }
 }

@@ -3,7 +3,7 @@
 # regime and the PMC passes the roofline objects cite; everything lands under gpurun_out/refresh_<tag>/ (turn it into
 # profiles/<tag>_* afterwards with tools/collect_profiles.py <tag>).  usage: bash tools/refresh_profiles.sh r02
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/refresh_$TAG
 rm -rf $OUT; mkdir -p $OUT
