@@ -1159,9 +1159,11 @@ constexpr int HEAD_POLLS = 200;      // x (a memory round trip + s_sleep): ~100 
 // search renews it.  Exact, and checked the way the pruning is: results bit-identical to the oracle with and without
 // (SLAM3D_CERT=0), soak, the tie-heavy duplicate-target cases (a tie has clearance 0: never certified).
 constexpr float CERT_M = 1.0e-4f;        // metres added to every pruning radius: the clearance of what a search does not scan
-constexpr int CERT_TRACK_IT = 6;         // first iteration that tracks second-best distances and inflates its radii (the launches before
-                                         // move the pose by millimetres: nothing they could certify would survive, and tracking costs
-                                         // two VALU operations per candidate where the candidates are most numerous)
+constexpr float CERT_TRACK_MOTION = 1.0e-3f;   // a launch tracks second-best distances and inflates its radii only once the pose moved less
+                                         // than this (metres, at the far end of the depth range) since the previous iteration: while it still
+                                         // moves by millimetres nothing a search could certify would survive the next update, tracking costs two
+                                         // VALU operations per candidate where the candidates are most numerous, and a pair that does not converge
+                                         // at all (the reference's wide-baseline Kinect pair) never pays for it
 __device__ __forceinline__ float infl_thr(float U, float cm)       // (sqrt(U) + cm)^2 with room for the roundings of the gap tests and of sqrt
 {
     if (cm == 0.0f) return U * 1.00001f + 1e-30f;            // (wave-uniform: launches that do not track pay no square root)
@@ -1216,9 +1218,9 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                                                         int cert /* certify from it >= 1 on (needs `it` = the run's iteration and trace_T[it - 1]) */)
 {
     const int first = it == 0;
-    const bool trk = cert && it >= CERT_TRACK_IT;           // this launch tracks (best, second) and inflates its pruning radii: its results carry clearances
-    const bool certify = cert && it > CERT_TRACK_IT;        // ... so the NEXT one may certify from them
-    const float cm = trk ? CERT_M : 0.0f;
+    const bool certify = cert && it > 0;                    // slots may carry a clearance from the previous launch (<= 0: none)
+    bool trk = false;                                       // this launch tracks (best, second) and inflates its pruning radii: decided below,
+    float cm = 0.0f;                                        // once this launch's pose is known (how far it moved since the last one)
     __shared__ float4 stage_all[NN_WAVES][NN_STAGE * STAGE_REC];
     __shared__ int wcost[NN_WAVES];                                    // cycles spent for each owner (all helpers)
     __shared__ float qpos[NN_WAVES][3][TILE_SLOTS];                   // p'.x / .y / .z of each owner's queries (SoA: 3 KB, not 4)
@@ -1334,6 +1336,17 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         }
     }
     __syncthreads();
+    if (certify) {      // how far can a point have moved since the previous iteration?  |R - R'| (max row sum) x depth range + |t - t'|
+        float mv = 0.0f, mt = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            mv = fmaxf(mv, (fabsf(uni_f(head_T[4 * r]) - uni_f(prev_T[4 * r])) + fabsf(uni_f(head_T[4 * r + 1]) - uni_f(prev_T[4 * r + 1]))) +
+                               fabsf(uni_f(head_T[4 * r + 2]) - uni_f(prev_T[4 * r + 2])));
+            mt = fmaxf(mt, fabsf(uni_f(head_T[4 * r + 3]) - uni_f(prev_T[4 * r + 3])));
+        }
+        trk = mv * g.zmax + mt < CERT_TRACK_MOTION;
+        cm = trk ? CERT_M : 0.0f;
+    }
 
     // ---- "current query" context: the wave's own tile in step 1, an item's owner in step 3
     float px = 0.0f, py = 0.0f, pz = 0.0f;
@@ -1379,15 +1392,15 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     // wave's lanes reach 7.6 quadrants between them but 3.0 at most each (1.4 on average; bench pair, mid-run), so the
     // wave iterates max-over-lanes times instead of union-over-lanes times: 16 candidates per trip, each lane reading
     // ITS quadrant (same slot index, quadrant stride 17 float4: distinct quadrants sit in distinct banks).
+    // two copies of the loop, chosen per call (wave-uniform): with and without the (best, second) tracking of the certificates
     auto scan_lanes = [&](unsigned int m) __attribute__((always_inline)) {
-        while (__ballot(m != 0u) != 0ull) {
-            if constexpr (DBG) n_cand += 16;
-            if (m != 0u) {
-                const int q = __builtin_ctz(m);
-                m &= m - 1u;
-                const float4 *__restrict__ cand = st + (q >> 2) * STAGE_REC + (q & 3) * QSTRIDE;
-                // the padding slots of a quadrant hold (+inf, +inf, +inf): d2 = +inf never wins
-                if (trk) {
+        if (trk) {
+            while (__ballot(m != 0u) != 0ull) {
+                if constexpr (DBG) n_cand += 16;
+                if (m != 0u) {
+                    const int q = __builtin_ctz(m);
+                    m &= m - 1u;
+                    const float4 *__restrict__ cand = st + (q >> 2) * STAGE_REC + (q & 3) * QSTRIDE;
 #pragma unroll 1
                     for (int i = 0; i < 16; i += 4) {
 #pragma unroll
@@ -1400,13 +1413,22 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                             track2(bsc, sec, d2);
                         }
                     }
-                } else {
+                }
+            }
+        } else {
+            while (__ballot(m != 0u) != 0ull) {
+                if constexpr (DBG) n_cand += 16;
+                if (m != 0u) {
+                    const int q = __builtin_ctz(m);
+                    m &= m - 1u;
+                    const float4 *__restrict__ cand = st + (q >> 2) * STAGE_REC + (q & 3) * QSTRIDE;
+                    // the padding slots of a quadrant hold (+inf, +inf, +inf): d2 = +inf never wins
 #pragma unroll 1
                     for (int i = 0; i < 16; i += 4) {
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const float4 c4 = cand[i + u];
-                            const float d2 = canon_d2(px, py, pz, c4.y, c4.z, c4.w);
+                            const float d2 = canon_d2(px, py, pz, c4.y, c4.z, c4.w);     // record = (pixel, x, y, z)
                             const unsigned long long key =
                                 ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(c4.x);
                             bkey = key_min(bkey, key);
@@ -1573,6 +1595,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
 
     // ================= step 1: own tile =================
     bool certd = false;                               // this lane's result is certified unchanged (no search)
+    bool had_clear = false;                           // the slot held a clearance when this launch began (an untracked search must void it)
     unsigned long long cert_mask = 0ull;
     int own_jprev = -2;                               // what prevq holds for this lane's slot (-2: nothing known, always write)
     const float4 s4 = has_tile ? pp.srcT[(size_t)t * TILE_SLOTS + lane] : make_float4(0, 0, 0, __int_as_float(-1));
@@ -1650,6 +1673,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             if (tv && d2g <= g.gate2) bkey = ((unsigned long long)(unsigned int)__float_as_int(d2g) << 32) | (unsigned int)jg;
             // ---- clearance certificate (see CERT_M above): the slot's clearance minus twice the distance the query moved since the
             // last iteration still exceeds the rounding slack => the argmin (or "nothing within the gate") is what it was
+            had_clear = cprev > 0.0f;
             if (certify) {
                 const Rt mp = load_rt_lds(prev_T);
                 float ox_, oy_, oz_;
@@ -1957,6 +1981,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     } else
         finish_slot<false>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs_ep, cd2 + gs_ep, prevq + gs_ep, rb,
                            write_out != 0, own_jprev);
+    if (cert && !trk && own_valid && !((cert_mask >> lane) & 1ull) && (first || had_clear)) clear[gs_ep] = -1.0f;      // searched without tracking: no clearance
     if (trk && own_valid && !((cert_mask >> lane) & 1ull)) {
         // this lane searched: its clearance for the next iteration.  Scanned candidates other than the winner are at least
         // sqrt(other) away (other = the second-smallest scanned d2, or the smallest when the winner itself was not among the
