@@ -171,8 +171,9 @@ static void normal_at(const float *xyz4, int W, int H, int u, int v, int r,
             const double dx = (double)q[0] - cx0, dy = (double)q[1] - cy0, dz = (double)q[2] - cz0;
             ++n;
             sx += dx; sy += dy; sz += dz;
-            sxx += dx * dx; sxy += dx * dy; sxz += dx * dz;
-            syy += dy * dy; syz += dy * dz; szz += dz * dz;
+            /* spec S2 (round 3): the second moments accumulate with fused multiply-adds (one rounding per term) */
+            sxx = fma(dx, dx, sxx); sxy = fma(dx, dy, sxy); sxz = fma(dx, dz, sxz);
+            syy = fma(dy, dy, syy); syz = fma(dy, dz, syz); szz = fma(dz, dz, szz);
         }
     if (n < min_in) return;
     const double inv = 1.0 / (double)n;
@@ -193,7 +194,7 @@ static void normal_at(const float *xyz4, int W, int H, int u, int v, int r,
             if (uu < 0 || uu >= W || vv < 0 || vv >= H) continue;
             const float *q = xyz4 + 4 * ((size_t)vv * W + uu);
             if (!point_valid(q, zmax)) continue;
-            const double e = ((nx * (double)q[0] + ny * (double)q[1]) + nz * (double)q[2]) - dq;
+            const double e = fma(nz, (double)q[2], fma(ny, (double)q[1], nx * (double)q[0])) - dq;
             if (fabs(e) <= in_dist) ++cnt;
         }
     if (cnt < min_in) return;

@@ -276,8 +276,8 @@ __global__ __launch_bounds__(NRM_BX * NRM_BY) void k_normals(FrameTasks a, Geome
                 const double dx = (double)(ok ? q.x : c0.x) - cx0, dy = (double)(ok ? q.y : c0.y) - cy0, dz = (double)(ok ? q.z : c0.z) - cz0;
                 n += ok ? 1 : 0;
                 sx += dx; sy += dy; sz += dz;
-                sxx += dx * dx; sxy += dx * dy; sxz += dx * dz;
-                syy += dy * dy; syz += dy * dz; szz += dz * dz;
+                sxx = __fma_rn(dx, dx, sxx); sxy = __fma_rn(dx, dy, sxy); sxz = __fma_rn(dx, dz, sxz);       // (spec S2, round 3: fused)
+                syy = __fma_rn(dy, dy, syy); syz = __fma_rn(dy, dz, syz); szz = __fma_rn(dz, dz, szz);
             }
         if (n >= g.min_in) {
             const double inv = 1.0 / (double)n;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(NRM_BX * NRM_BY) void k_normals(FrameTasks a, Geome
 #pragma unroll UN
                 for (int du = 0; du <= 2 * r; ++du) {
                     const float4 q = win[dv * tw + du];
-                    const double e = ((nx * (double)q.x + ny * (double)q.y) + nz * (double)q.z) - dq;
+                    const double e = __fma_rn(nz, (double)q.z, __fma_rn(ny, (double)q.y, nx * (double)q.x)) - dq;
                     cnt += (q.w > 0.5f && fabs(e) <= g.in_dist) ? 1 : 0;       // NaN coordinates of an invalid point: e = NaN, not counted either way
                 }
             if (have && cnt >= g.min_in) out = make_float4((float)nx, (float)ny, (float)nz, 1.0f);
