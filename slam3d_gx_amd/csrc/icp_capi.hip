@@ -716,6 +716,8 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
     return SLAM3D_OK;
 }
 
+static int enqueue_iterations(slam3d_icp_handle *h, int B, hipStream_t s, int iters);
+
 extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_init, void *stream)
 {
     if (!h || B <= 0 || B > h->maxB) return SLAM3D_E_INVALID;
@@ -733,6 +735,25 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
     }
     int rc = enqueue_preprocess(h, B, T_init, s, iters > 0 ? 1 : 0);       // (counted as in flight until the last k_solve_acc)
     if (rc) return rc;
+    rc = enqueue_iterations(h, B, s, iters);
+    if (rc) {                   // k_pair_init counted this run in; its last k_solve_acc, which counts it out, will not run
+        if (iters > 0) { hipLaunchKernelGGL(k_run_uncount, dim3(1), dim3(1), 0, s); (void)hipGetLastError(); }
+        return rc;
+    }
+    HIPCHK(h, hipEventRecord(h->ev[2], s));
+    h->run_stream = s;
+    h->ran = true;
+    h->ran_profiled = h->profiling;
+    h->ran_corr_trace = h->want_corr_trace;
+    h->res_mapped = iters > 0;
+    h->last_B = B;
+    return SLAM3D_OK;
+}
+
+// the iteration loop of slam3d_icp_run: a graph replay, or direct launches (profiling, correspondence trace, SLAM3D_NO_GRAPH)
+static int enqueue_iterations(slam3d_icp_handle *h, int B, hipStream_t s, int iters)
+{
+    int rc = SLAM3D_OK;
     if (iters > 0 && !h->profiling && h->use_graph && !h->want_corr_trace) {
         // The iteration loop (iterations x {NN, solve}) has launch-invariant arguments: it is captured once per B into
         // a HIP graph and replayed with one hipGraphLaunch.  What changes from run to run -- which frames need their
@@ -759,13 +780,6 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
         }
     }
     HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(h->ev[2], s));
-    h->run_stream = s;
-    h->ran = true;
-    h->ran_profiled = h->profiling;
-    h->ran_corr_trace = h->want_corr_trace;
-    h->res_mapped = iters > 0;
-    h->last_B = B;
     return SLAM3D_OK;
 }
 

@@ -511,6 +511,9 @@ __global__ __launch_bounds__(256) void k_pair_init(TinitArgs ti, int has_T, int 
     if (lane == 0) { flags[b] = 0; ticket[b] = 0u; }
 }
 
+// a run that was counted by k_pair_init but whose launches could not all be enqueued: take it out of the count again
+__global__ void k_run_uncount() { if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&g_runs_in_flight, -1); }
+
 // stable raster-order stream compaction, one 1024-thread block per (pair, src|tgt).  Only the full
 // brute-force modes use these lists.  src w = SLOT id of the pixel, tgt w = pixel index.
 __global__ __launch_bounds__(1024) void k_compact(const PairPtrs *__restrict__ pairs,
@@ -1371,7 +1374,6 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         const float gz = fmaxf(0.0f, fmaxf(lo.z - pz, pz - hi.z));
         return valid && __fmaf_rn(gz, gz, __fmaf_rn(gy, gy, gx * gx)) <= thr;
     };
-    auto lane_gap_ok = [&](const float4 lo, const float4 hi) __attribute__((always_inline)) { return lane_gap_le(lo, hi, lane_thr()); };
     bool hinted = false;        // step 1 scans tiles that the hint picked: their tile-level test nearly always passes, skip it
     // which quadrants of staged tile k (bits 4k .. 4k+3) this lane has to scan: tile box first (wave level), then its own
     // ball against each quadrant box
