@@ -22,6 +22,7 @@ constexpr int SEG_MAXP = 8;        // planes per frame
 constexpr int SEG_PTS = 4;         // points per thread in the consensus / moment kernels
 constexpr int SEG_BLOCK = 256;
 constexpr int SEG_HGROUP = 16;     // hypotheses per k_seg_count block (grid.z = SEG_H / SEG_HGROUP)
+constexpr int SEG_CR = 8;          // replicas of the consensus counts (block x adds into replica x % SEG_CR: atomics on one cache line serialise)
 
 struct SegParams { float thr, percent; int max_planes, hypotheses; unsigned long long seed; };
 
@@ -32,7 +33,7 @@ struct SegPlane { float a, b, c, d, cx, cy, cz; int count; };
 struct SegState {                  // one per frame, zeroed before k_seg_init
     int n_valid, remaining, nplanes, done;
     int best, lab_count, pad0, pad1;
-    int counts[SEG_H];
+    int counts[SEG_CR][SEG_H];
     long long mom[10];
     SegHyp hyp[SEG_H];
     SegPlane planes[SEG_MAXP];
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(64) void k_seg_hyp(const float4 *const *__restrict_
     __syncthreads();
     if (done) return;
     if (h < 10) s.mom[h] = 0;
-    s.counts[h] = 0;
+#pragma unroll
+    for (int c = 0; c < SEG_CR; ++c) s.counts[c][h] = 0;
     SegHyp hy;
     hy.nx = hy.ny = hy.nz = hy.dd = hy.thr2nn = 0.0f; hy.ok = 0; hy.p0x = hy.p0y = hy.p0z = 0.0f;
     if (h < sp.hypotheses) {
@@ -146,6 +148,15 @@ __global__ __launch_bounds__(64) void k_seg_hyp(const float4 *const *__restrict_
         }
     }
     s.hyp[h] = hy;
+}
+
+// consensus count of hypothesis h: the replicas' sum
+__device__ __forceinline__ int seg_count_of(const SegState &s, int h)
+{
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < SEG_CR; ++k) c += s.counts[k][h];
+    return c;
 }
 
 // P2: consensus counts.  grid (ceil(N/1024), B), block 256.  Each thread keeps SEG_PTS points in registers;
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(SEG_BLOCK) void k_seg_count(const float4 *const *__
     }
     if (mine) atomicAdd(&bc[lane], mine);
     __syncthreads();
-    if (threadIdx.x < SEG_H && bc[threadIdx.x]) atomicAdd(&s.counts[threadIdx.x], bc[threadIdx.x]);
+    if (threadIdx.x < SEG_H && bc[threadIdx.x]) atomicAdd(&s.counts[blockIdx.x % SEG_CR][threadIdx.x], bc[threadIdx.x]);
 }
 
 // P2 tail + P3: every block finds the best hypothesis (max count, smallest h on ties), block 0 records it, then
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(SEG_BLOCK) void k_seg_moments(const float4 *const *
     if (s.done) return;
     const int lane = threadIdx.x & 63;
     // argmax over (count desc, h asc): key = count * 64 + (63 - h)
-    int key = lane < H ? s.counts[lane] * 64 + (63 - lane) : -1;
+    int key = lane < H ? seg_count_of(s, lane) * 64 + (63 - lane) : -1;
     for (int o = 32; o >= 1; o >>= 1) key = max(key, __shfl_xor(key, o));
     const int best = 63 - (key & 63), bc = key >> 6;
     if (bc < 3) return;                       // k_seg_refine raises done
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(64) void k_seg_refine(SegState *__restrict__ st, in
     SegState &s = st[blockIdx.x];
     if (s.done) return;
     const int lane = threadIdx.x;
-    int key = lane < H ? s.counts[lane] * 64 + (63 - lane) : -1;
+    int key = lane < H ? seg_count_of(s, lane) * 64 + (63 - lane) : -1;
     for (int o = 32; o >= 1; o >>= 1) key = max(key, __shfl_xor(key, o));
     if (lane != 0) return;
     if ((key >> 6) < 3) { s.done = 1; return; }
