@@ -75,7 +75,7 @@ struct slam3d_icp_handle {
     // 8x8-pixel tiles (slot order of the sums; target tiles + boxes for the pruned NN)
     TileGrid tg;
     float4 *prevq = nullptr;
-    float *clear = nullptr;       // every slot's clearance after the last iteration (certificates, icp_kernels.hpp); [maxB][nslots]
+    float2 *slot_rec = nullptr;   // every slot's result after the last iteration of the tile search: (match, clearance) (icp_kernels.hpp); [maxB][nslots]
     bool cert_on = true;          // SLAM3D_CERT=0: developer knob, every iteration searches
     long long *dbg = nullptr;     // per-tile NN statistics, only with SLAM3D_NN_DEBUG=1
     int *cost = nullptr;                    // cycles per tile of the last launch: input of k_balance (throughput build)
@@ -177,7 +177,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->d_pairs); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4); F(h->corr_trace);
     F(h->d_stamps); F(h->d_stamp_seq);
     if (h->vox_done) (void)hipEventDestroy(h->vox_done);
-    F(h->dbg); F(h->prevq); F(h->clear); F(h->perm_d); F(h->cost); F(h->tgtB); F(h->qmax2);
+    F(h->dbg); F(h->prevq); F(h->slot_rec); F(h->perm_d); F(h->cost); F(h->tgtB); F(h->qmax2);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->pin_res) (void)hipHostFree(h->pin_res);
     if (h->pin_seg) (void)hipHostFree(h->pin_seg);
@@ -275,7 +275,8 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
         A(dalloc(h->tgtB, (size_t)h->maxB * 4 * h->npad)); A(dalloc(h->qmax2, (size_t)h->maxB));
     }
     A(dalloc(h->ccounts, (size_t)h->maxB * 4)); A(dalloc(h->ticket, (size_t)h->maxB));
-    A(dalloc(h->corr, BS)); A(dalloc(h->flags, (size_t)h->maxB)); A(dalloc(h->cd2, BS)); A(dalloc(h->prevq, BS));
+    A(dalloc(h->corr, BS)); A(dalloc(h->flags, (size_t)h->maxB)); A(dalloc(h->cd2, BS));
+    if (brute) A(dalloc(h->prevq, BS));      // (the tile search keeps 8-byte slot records instead: slot_rec)
     h->nsets = p->iterations > 0 ? p->iterations : 1;
     A(dalloc(h->acc, (size_t)h->maxB * h->nsets * ACC_R * ACC_STRIDE));
     A(dalloc(h->cost, (size_t)h->maxB * tg.ntiles));
@@ -304,7 +305,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     if (getenv("SLAM3D_DENSE_BATCH")) h->dense_batch = atoi(getenv("SLAM3D_DENSE_BATCH"));
     if (getenv("SLAM3D_HEAD_SOLVE")) h->head_solve = atoi(getenv("SLAM3D_HEAD_SOLVE"));
     if (getenv("SLAM3D_CERT")) h->cert_on = atoi(getenv("SLAM3D_CERT")) != 0;
-    A(dalloc(h->clear, (size_t)h->maxB * tg.nslots));
+    A(dalloc(h->slot_rec, (size_t)h->maxB * tg.nslots));
     A(dalloc(h->sums, (size_t)h->maxB * NSUMS)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
     A(dalloc(h->trace_T, (size_t)h->maxB * (iters + 1) * 16)); A(dalloc(h->trace_S, (size_t)h->maxB * iters * NSUMS));
     A(dalloc(h->d_pairs, (size_t)h->maxB));
@@ -650,11 +651,11 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         const int gx = dense ? h->nn_gx_d : h->nn_gx;
         // four instances: {throughput, cooperative} x {production, instrumented (SLAM3D_NN_DEBUG: per-tile clocks and counters)}
         auto launch = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_pairs, h->Tcur, h->corr, h->cd2, h->prevq,
+            hipLaunchKernelGGL(kern, dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_pairs, h->Tcur, h->corr, h->cd2,
                                perm, h->cost, h->acc, h->g, tg, h->dbg, write_out, do_solve ? it : (first ? 0 : 1),
                                stamp_ring_of(h, do_solve != 0), it,
                                head ? h->head_solve : 0, h->trace_T, h->trace_S, h->flags, iters, h->nsets,
-                               h->clear, (h->cert_on && do_solve) ? 1 : 0);
+                               h->slot_rec, (h->cert_on && do_solve) ? 1 : 0);
         };
         // (+ two with the optional S4g gates compiled in: the production instances carry none of that code)
         const bool gated = h->p.estimator == SLAM3D_EST_POINT2PLANE && (h->g.resid2 > 0.0f || h->g.min_ncos > 0.0f);

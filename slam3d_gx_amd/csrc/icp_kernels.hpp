@@ -985,7 +985,9 @@ __device__ __forceinline__ void finish_slot(bool valid, unsigned long long key, 
                                             float gate2, int estimator, int *__restrict__ corr_out,
                                             float *__restrict__ cd2_out, float4 *__restrict__ prevq_out,
                                             RowBasis &B, bool write_out, int jprev /* match the slot already holds (-2: unknown) */,
-                                            const SlotGates *sg = nullptr)
+                                            const SlotGates *sg = nullptr,
+                                            const float4 *__restrict__ tq = nullptr /* image-order (pixel, x, y, z) copy of the target, if the frame has one */,
+                                            int *jnn_out = nullptr /* the nearest neighbour the next iteration starts from (-1: none); prevq_out may then be null */)
 {
 #pragma unroll
     for (int k = 0; k < 8; ++k) B.v[k] = 0.0;
@@ -1000,7 +1002,11 @@ __device__ __forceinline__ void finish_slot(bool valid, unsigned long long key, 
     }
     float4 pq = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
     if (ok) {
-        const float4 q4 = tcloud[j];
+        // the matched point: from the image-order records the window search staged a moment ago where the frame has them (the same
+        // bits as tcloud[j], and the same cache lines as the window: the cloud itself is then never read by the iterations)
+        float4 q4;
+        if (tq) { const float4 r4 = tq[j]; q4 = make_float4(r4.y, r4.z, r4.w, 0.0f); }
+        else q4 = tcloud[j];
         float4 n4 = make_float4(0, 0, 0, 0);
         if (estimator == 0) n4 = tnrm[j];
         row_basis(estimator, px, py, pz, q4, n4, B);
@@ -1036,7 +1042,8 @@ __device__ __forceinline__ void finish_slot(bool valid, unsigned long long key, 
     }
     // next iteration's upper bound comes from this point (no dependent gather).  Once the pose has settled most matches
     // repeat: a slot that already holds this very match is not written again (same bits, 16 B of traffic less)
-    if (__float_as_int(pq.w) != jprev) *prevq_out = pq;
+    if (jnn_out) *jnn_out = __float_as_int(pq.w);
+    if (prevq_out && __float_as_int(pq.w) != jprev) *prevq_out = pq;
 }
 
 // accumulation for the brute-force modes: grid (nchunks, B), one thread per source slot, one wave per tile
@@ -1207,7 +1214,6 @@ template <int NN_STAGE, int WPE, bool COOP, bool DBG, bool GATED = false>
 __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_nn_tiles_acc(const PairPtrs *__restrict__ pairs,
                                                         const double *__restrict__ Tcur,
                                                         int *__restrict__ corr, float *__restrict__ cd2,
-                                                        float4 *__restrict__ prevq,
                                                         const int *__restrict__ perm, int *__restrict__ cost,
                                                         long long *__restrict__ acc, Geometry g, TileGrid tg,
                                                         long long *__restrict__ dbg /* DBG builds only: 20 x int64 per tile */,
@@ -1217,7 +1223,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                                                         int head /* solve iteration it-1 at the head of this launch (see above) */,
                                                         double *__restrict__ trace_T, double *__restrict__ trace_S, int *__restrict__ flags,
                                                         int iters, int nsets /* accumulator sets per pair */,
-                                                        float *__restrict__ clear /* [pairs][nslots] clearance of every slot's last result */,
+                                                        float2 *__restrict__ slot_rec /* [pairs][nslots] every slot's last result: (match j as int bits, -1: none | its clearance) */,
                                                         int cert /* certify from it >= 1 on (needs `it` = the run's iteration and trace_T[it - 1]) */)
 {
     const int first = it == 0;
@@ -1652,15 +1658,31 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         }
 #pragma unroll
         for (int k = 0; k < NN_STAGE; ++k) ta[k] = tt[k];
-        fetch_batch();                                             // one round of independent loads ...
+        // one round of independent loads: the first tile records are fetched on speculation -- except in a tracking launch (the pose
+        // has settled: nearly every wave ends certified or in the window), where the few waves that do scan tiles fetch them then
+        if (!trk) fetch_batch();
         float4 pq = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
         float cprev = -1.0f;                                       // the slot's clearance after the last iteration (metres; <= 0: none)
-        if (!first) { pq = prevq[gs]; if (certify) cprev = clear[gs]; }   // (a run's first iteration: whatever an earlier run left there is ignored)
+        if (!first) {    // (a run's first iteration: whatever an earlier run left there is ignored)
+            // the slot's record is 8 bytes (match, clearance); the matched POINT is gathered again -- from the records the window
+            // search and the epilogue read anyway -- instead of being kept per slot (16 B read and, where it changed, written
+            // per slot and iteration)
+            const float2 rec = slot_rec[gs];
+            const int jp = __float_as_int(rec.x);
+            if (certify) cprev = rec.y;
+            if (jp >= 0 && jp < g.W * g.H) {
+                if (pp.tq) { const float4 r4 = pp.tq[jp]; pq = make_float4(r4.y, r4.z, r4.w, rec.x); }
+                else { const float4 c4 = tcloud[jp]; pq = make_float4(c4.x, c4.y, c4.z, rec.x); }
+            }
+        }
         float4 qs = make_float4(0, 0, 0, 0);
         float ws = 1.0f;
         if (__float_as_int(pq.w) < 0) {   // no previous match (first iteration): fall back to the target at the same pixel
             const int ug = (t % tg.ntx) * TILE_PX + (lane & 7), vg = (t / tg.ntx) * TILE_PX + (lane >> 3);
-            if (ug < g.W && vg < g.H) { qs = tcloud[vg * g.W + ug]; if (g.estimator == 0) ws = tnrm[vg * g.W + ug].w; }
+            if (ug < g.W && vg < g.H) {
+                if (pp.tq) { const float4 r4 = pp.tq[vg * g.W + ug]; qs = make_float4(r4.y, r4.z, r4.w, 0.0f); }     // (+inf where the pixel is no target: eligibility is folded in)
+                else { qs = tcloud[vg * g.W + ug]; if (g.estimator == 0) ws = tnrm[vg * g.W + ug].w; }
+            }
         }
         valid = own_valid;
         if (!first) own_jprev = __float_as_int(pq.w);
@@ -1692,7 +1714,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                     dbg_cert = __popcll(__ballot(nc0)) | (__popcll(__ballot(nc1)) << 8) | (__popcll(__ballot(nc2)) << 16) | (__popcll(__ballot(valid)) << 24);
                 }
                 if (certd) {
-                    clear[gs] = cn;                                          // what is left of it for the next iteration
+                    slot_rec[gs].y = cn;                                     // what is left of it for the next iteration
                     if (t_none) bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;     // (not even the same-pixel target)
                 }
             }
@@ -1779,6 +1801,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         }
         valid = own_valid && !done && !certd;
         if (__ballot(valid) != 0ull) {
+            if (trk) fetch_batch();
             park();                  // the staged tile records take the slab over
             scan_parked();
         }
@@ -1972,29 +1995,39 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         gs_ep = (size_t)b_ep * tg.nslots + (size_t)t_ep * TILE_SLOTS + lane;
     }
     RowBasis rb;
+    int jnn = -1;
     if constexpr (GATED) {             // the optional S4g gates: their own instances, the production ones carry none of this
         SlotGates sg;
         const Rt m = load_rt_lds(head_T);
         sg.resid2 = g.resid2; sg.min_ncos = g.min_ncos; sg.snrm = pp.snrm; sg.spix = max(pix, 0);
         sg.r[0] = m.r00; sg.r[1] = m.r01; sg.r[2] = m.r02; sg.r[3] = m.r10; sg.r[4] = m.r11; sg.r[5] = m.r12;
         sg.r[6] = m.r20; sg.r[7] = m.r21; sg.r[8] = m.r22;
-        finish_slot<true>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs_ep, cd2 + gs_ep, prevq + gs_ep, rb,
-                          write_out != 0, own_jprev, &sg);
+        finish_slot<true>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs_ep, cd2 + gs_ep, nullptr, rb,
+                          write_out != 0, own_jprev, &sg, pp.tq, &jnn);
     } else
-        finish_slot<false>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs_ep, cd2 + gs_ep, prevq + gs_ep, rb,
-                           write_out != 0, own_jprev);
-    if (cert && !trk && own_valid && !((cert_mask >> lane) & 1ull) && (first || had_clear)) clear[gs_ep] = -1.0f;      // searched without tracking: no clearance
-    if (trk && own_valid && !((cert_mask >> lane) & 1ull)) {
-        // this lane searched: its clearance for the next iteration.  Scanned candidates other than the winner are at least
-        // sqrt(other) away (other = the second-smallest scanned d2, or the smallest when the winner itself was not among the
-        // scanned ones); everything the search did not scan is at least sqrt(best) + CERT_M away (every pruning radius was
-        // inflated by CERT_M and only shrank afterwards); 1e-6 covers the roundings of d2 and of sqrt (see cert_tau).
-        if constexpr (COOP) { bsc = __int_as_float((int)qbs[w][0][lane]); sec = __int_as_float((int)qbs[w][1][lane]); }
-        const float u1 = __int_as_float((int)(unsigned int)(bkey >> 32));
-        const bool real = (unsigned int)bkey != 0xffffffffu;                    // a match (else: nothing within the gate)
-        const float other = real ? (u1 == bsc ? sec : bsc) : bsc;
-        const float base = __builtin_amdgcn_sqrtf(real ? u1 : g.gate2);
-        clear[gs_ep] = fminf(__builtin_amdgcn_sqrtf(other), base + CERT_M) * (1.0f - 1.0e-6f) - base * (1.0f + 1.0e-6f) - 1.0e-9f;
+        finish_slot<false>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs_ep, cd2 + gs_ep, nullptr, rb,
+                           write_out != 0, own_jprev, nullptr, pp.tq, &jnn);
+    {   // the slot's record for the next iteration: the match where it changed, the clearance where this lane searched
+        const bool searched = own_valid && !((cert_mask >> lane) & 1ull);
+        const bool wr_j = jnn != own_jprev;
+        bool wr_c = cert && !trk && searched && (first || had_clear);          // searched without tracking: no clearance
+        float cnew = -1.0f;
+        if (trk && searched) {
+            // this lane searched: its clearance for the next iteration.  Scanned candidates other than the winner are at least
+            // sqrt(other) away (other = the second-smallest scanned d2, or the smallest when the winner itself was not among the
+            // scanned ones); everything the search did not scan is at least sqrt(best) + CERT_M away (every pruning radius was
+            // inflated by CERT_M and only shrank afterwards); 1e-6 covers the roundings of d2 and of sqrt (see cert_tau).
+            if constexpr (COOP) { bsc = __int_as_float((int)qbs[w][0][lane]); sec = __int_as_float((int)qbs[w][1][lane]); }
+            const float u1 = __int_as_float((int)(unsigned int)(bkey >> 32));
+            const bool real = (unsigned int)bkey != 0xffffffffu;                    // a match (else: nothing within the gate)
+            const float other = real ? (u1 == bsc ? sec : bsc) : bsc;
+            const float base = __builtin_amdgcn_sqrtf(real ? u1 : g.gate2);
+            cnew = fminf(__builtin_amdgcn_sqrtf(other), base + CERT_M) * (1.0f - 1.0e-6f) - base * (1.0f + 1.0e-6f) - 1.0e-9f;
+            wr_c = true;
+        }
+        if (wr_j && wr_c) slot_rec[gs_ep] = make_float2(__int_as_float(jnn), cnew);
+        else if (wr_j) slot_rec[gs_ep].x = __int_as_float(jnn);
+        else if (wr_c) slot_rec[gs_ep].y = cnew;
     }
     tile_accumulate(g.estimator, rb, acc + (((size_t)b * nsets + (head ? it : 0)) * ACC_R + (c % ACC_R)) * ACC_STRIDE);
     stamp_wave_end();
