@@ -75,6 +75,7 @@ struct slam3d_icp_handle {
     // 8x8-pixel tiles (slot order of the sums; target tiles + boxes for the pruned NN)
     TileGrid tg;
     float4 *prevq = nullptr;
+    float *tile_cum = nullptr;    // [maxB][ntiles] motion totals of the certificates (icp_kernels.hpp)
     float2 *slot_rec = nullptr;   // every slot's result after the last iteration of the tile search: (match, clearance) (icp_kernels.hpp); [maxB][nslots]
     bool cert_on = true;          // SLAM3D_CERT=0: developer knob, every iteration searches
     long long *dbg = nullptr;     // per-tile NN statistics, only with SLAM3D_NN_DEBUG=1
@@ -177,7 +178,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->d_pairs); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4); F(h->corr_trace);
     F(h->d_stamps); F(h->d_stamp_seq);
     if (h->vox_done) (void)hipEventDestroy(h->vox_done);
-    F(h->dbg); F(h->prevq); F(h->slot_rec); F(h->perm_d); F(h->cost); F(h->tgtB); F(h->qmax2);
+    F(h->dbg); F(h->prevq); F(h->slot_rec); F(h->tile_cum); F(h->perm_d); F(h->cost); F(h->tgtB); F(h->qmax2);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->pin_res) (void)hipHostFree(h->pin_res);
     if (h->pin_seg) (void)hipHostFree(h->pin_seg);
@@ -305,7 +306,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     if (getenv("SLAM3D_DENSE_BATCH")) h->dense_batch = atoi(getenv("SLAM3D_DENSE_BATCH"));
     if (getenv("SLAM3D_HEAD_SOLVE")) h->head_solve = atoi(getenv("SLAM3D_HEAD_SOLVE"));
     if (getenv("SLAM3D_CERT")) h->cert_on = atoi(getenv("SLAM3D_CERT")) != 0;
-    A(dalloc(h->slot_rec, (size_t)h->maxB * tg.nslots));
+    A(dalloc(h->slot_rec, (size_t)h->maxB * tg.nslots)); A(dalloc(h->tile_cum, (size_t)h->maxB * tg.ntiles));
     A(dalloc(h->sums, (size_t)h->maxB * NSUMS)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
     A(dalloc(h->trace_T, (size_t)h->maxB * (iters + 1) * 16)); A(dalloc(h->trace_S, (size_t)h->maxB * iters * NSUMS));
     A(dalloc(h->d_pairs, (size_t)h->maxB));
@@ -655,7 +656,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
                                perm, h->cost, h->acc, h->g, tg, h->dbg, write_out, do_solve ? it : (first ? 0 : 1),
                                stamp_ring_of(h, do_solve != 0), it,
                                head ? h->head_solve : 0, h->trace_T, h->trace_S, h->flags, iters, h->nsets,
-                               h->slot_rec, (h->cert_on && do_solve) ? 1 : 0);
+                               h->slot_rec, h->tile_cum, (h->cert_on && do_solve) ? 1 : 0);
         };
         // (+ two with the optional S4g gates compiled in: the production instances carry none of that code)
         const bool gated = h->p.estimator == SLAM3D_EST_POINT2PLANE && (h->g.resid2 > 0.0f || h->g.min_ncos > 0.0f);

@@ -1166,7 +1166,11 @@ constexpr int HEAD_POLLS = 200;      // x (a memory round trip + s_sleep): ~100 
 // rounding slack CERT_TAU of the canonical d2, the argmin -- ties included: the inequality is strict -- is the same target,
 // whose key is formed directly from the stored match point.  Such a lane takes no part in the search; a wave whose lanes are all
 // certified skips window, tiles and items altogether.  The clearance then shrinks by 2 delta per skipped iteration until a
-// search renews it.  Exact, and checked the way the pruning is: results bit-identical to the oracle with and without
+// search renews it -- without being rewritten: every source tile keeps ONE running total of the largest step its queries
+// took per launch (tile_cum), a slot records clearance + 2 x the total at the time of its search, and what is left of it
+// later is record - 2 x the current total (4 bytes written per tile and launch instead of 4 per certified slot).  Only
+// tracking launches certify and add to the total; a launch that does not track voids every clearance it meets (no
+// search of such a launch could produce one anyway: clearances never exceed CERT_M, its poses moved by more) and zeroes the totals.  Exact, and checked the way the pruning is: results bit-identical to the oracle with and without
 // (SLAM3D_CERT=0), soak, the tie-heavy duplicate-target cases (a tie has clearance 0: never certified).
 constexpr float CERT_M = 1.0e-4f;        // metres added to every pruning radius: the clearance of what a search does not scan
 constexpr float CERT_TRACK_MOTION = 1.0e-3f;   // a launch tracks second-best distances and inflates its radii only once the pose moved less
@@ -1223,7 +1227,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                                                         int head /* solve iteration it-1 at the head of this launch (see above) */,
                                                         double *__restrict__ trace_T, double *__restrict__ trace_S, int *__restrict__ flags,
                                                         int iters, int nsets /* accumulator sets per pair */,
-                                                        float2 *__restrict__ slot_rec /* [pairs][nslots] every slot's last result: (match j as int bits, -1: none | its clearance) */,
+                                                        float2 *__restrict__ slot_rec /* [pairs][nslots] every slot's last result: (match j as int bits, -1: none | its clearance record) */,
+                                                        float *__restrict__ tile_cum /* [pairs][ntiles] motion total of each source tile over the current stretch of tracking launches */,
                                                         int cert /* certify from it >= 1 on (needs `it` = the run's iteration and trace_T[it - 1]) */)
 {
     const int first = it == 0;
@@ -1603,7 +1608,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
 
     // ================= step 1: own tile =================
     bool certd = false;                               // this lane's result is certified unchanged (no search)
-    bool had_clear = false;                           // the slot held a clearance when this launch began (an untracked search must void it)
+    unsigned long long clear_mask = 0ull;             // lanes whose slot held a clearance when this launch began (an untracked search must void it)
+    int cum_bits = 0;                                 // tracking launches: the tile's motion total including this launch (float bits, held in an SGPR across the drain)
     unsigned long long cert_mask = 0ull;
     int own_jprev = -2;                               // what prevq holds for this lane's slot (-2: nothing known, always write)
     const float4 s4 = has_tile ? pp.srcT[(size_t)t * TILE_SLOTS + lane] : make_float4(0, 0, 0, __int_as_float(-1));
@@ -1660,16 +1666,19 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         for (int k = 0; k < NN_STAGE; ++k) ta[k] = tt[k];
         // one round of independent loads: the first tile records are fetched on speculation -- except in a tracking launch (the pose
         // has settled: nearly every wave ends certified or in the window), where the few waves that do scan tiles fetch them then
-        if (!trk) fetch_batch();
+        const bool spec_fetch = !trk && (first || pp.tq == nullptr || th < 0);      // (where the window search can run it settles most waves from the second launch on)
+        if (spec_fetch) fetch_batch();
         float4 pq = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
-        float cprev = -1.0f;                                       // the slot's clearance after the last iteration (metres; <= 0: none)
+        float yprev = -1.0f;                                       // the slot's clearance record (<= 0: none; see tile_cum)
+        float cum_prev = 0.0f;
+        if (trk) cum_prev = tile_cum[(size_t)b * tg.ntiles + t];   // (wave-uniform: a scalar load, in flight with the record)
         if (!first) {    // (a run's first iteration: whatever an earlier run left there is ignored)
             // the slot's record is 8 bytes (match, clearance); the matched POINT is gathered again -- from the records the window
             // search and the epilogue read anyway -- instead of being kept per slot (16 B read and, where it changed, written
             // per slot and iteration)
             const float2 rec = slot_rec[gs];
             const int jp = __float_as_int(rec.x);
-            if (certify) cprev = rec.y;
+            if (certify) yprev = rec.y;
             if (jp >= 0 && jp < g.W * g.H) {
                 if (pp.tq) { const float4 r4 = pp.tq[jp]; pq = make_float4(r4.y, r4.z, r4.w, rec.x); }
                 else { const float4 c4 = tcloud[jp]; pq = make_float4(c4.x, c4.y, c4.z, rec.x); }
@@ -1697,27 +1706,31 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             if (tv && d2g <= g.gate2) bkey = ((unsigned long long)(unsigned int)__float_as_int(d2g) << 32) | (unsigned int)jg;
             // ---- clearance certificate (see CERT_M above): the slot's clearance minus twice the distance the query moved since the
             // last iteration still exceeds the rounding slack => the argmin (or "nothing within the gate") is what it was
-            had_clear = cprev > 0.0f;
-            if (certify) {
+            const bool had_clear = yprev > 0.0f;
+            clear_mask = __ballot(had_clear);
+            if (trk) {
                 const Rt mp = load_rt_lds(prev_T);
                 float ox_, oy_, oz_;
                 xform(mp, s4.x, s4.y, s4.z, ox_, oy_, oz_);
                 const float dl = __builtin_amdgcn_sqrtf(canon_d2(px, py, pz, ox_, oy_, oz_)) * 1.000001f + 1.0e-9f;
-                const float cn = cprev - 2.0f * dl;
+                // the tile's motion total: no query of this tile has moved farther than cum_now since the stretch of tracking
+                // launches began (each launch adds the largest step of its lanes; the factor covers the rounding of the sum)
+                const float cum_now = uni_f((cum_prev + wave_max(own_valid ? dl : 0.0f)) * 1.0000003f);
+                cum_bits = __builtin_amdgcn_readfirstlane(__float_as_int(cum_now));
+                asm volatile("" : "+s"(cum_bits));                           // (else hipcc keeps 2 * cum_now in a VGPR: a scratch spill in the gated instance)
+                if (lane == 0) tile_cum[(size_t)b * tg.ntiles + t] = cum_now;
+                const float cn = (yprev - 2.0f * cum_now) * (1.0f - 1.0e-6f) - 1.0e-9f;      // what is left of the clearance (rounded down)
                 const bool t_match = have_prev && d2g <= g.gate2;          // the previous match, still inside the gate
                 const bool t_none = valid && !have_prev;                     // no match last time: clearance is to the gate
                 const float base = t_match ? __builtin_amdgcn_sqrtf(d2g) : __builtin_amdgcn_sqrtf(g.gate2);
-                certd = (t_match || t_none) && cn > cert_tau(base * 1.000001f);
+                certd = had_clear && (t_match || t_none) && cn > cert_tau(base * 1.000001f);
                 if constexpr (DBG) {     // why lanes are not certified: no clearance at all | match left the gate | clearance used up
-                    const bool nc0 = valid && !certd && !(cprev > 0.0f), nc1 = valid && !certd && cprev > 0.0f && have_prev && !(d2g <= g.gate2),
-                               nc2 = valid && !certd && cprev > 0.0f && !(have_prev && !(d2g <= g.gate2));
+                    const bool nc0 = valid && !certd && !had_clear, nc1 = valid && !certd && had_clear && have_prev && !(d2g <= g.gate2),
+                               nc2 = valid && !certd && had_clear && !(have_prev && !(d2g <= g.gate2));
                     dbg_cert = __popcll(__ballot(nc0)) | (__popcll(__ballot(nc1)) << 8) | (__popcll(__ballot(nc2)) << 16) | (__popcll(__ballot(valid)) << 24);
                 }
-                if (certd) {
-                    slot_rec[gs].y = cn;                                     // what is left of it for the next iteration
-                    if (t_none) bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;     // (not even the same-pixel target)
-                }
-            }
+                if (certd && t_none) bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;     // (not even the same-pixel target)
+            } else if (cert && lane == 0) tile_cum[(size_t)b * tg.ntiles + t] = 0.0f;       // no tracking: every clearance of the tile is voided below, the total starts over
         }
         cert_mask = __ballot(certd);
         valid = own_valid && !certd;                               // certified lanes take no part in the search; their key stands
@@ -1801,7 +1814,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         }
         valid = own_valid && !done && !certd;
         if (__ballot(valid) != 0ull) {
-            if (trk) fetch_batch();
+            if (!spec_fetch) fetch_batch();
             park();                  // the staged tile records take the slab over
             scan_parked();
         }
@@ -2010,7 +2023,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     {   // the slot's record for the next iteration: the match where it changed, the clearance where this lane searched
         const bool searched = own_valid && !((cert_mask >> lane) & 1ull);
         const bool wr_j = jnn != own_jprev;
-        bool wr_c = cert && !trk && searched && (first || had_clear);          // searched without tracking: no clearance
+        bool wr_c = cert && !trk && searched && (first || ((clear_mask >> lane) & 1ull));          // searched without tracking: no clearance
         float cnew = -1.0f;
         if (trk && searched) {
             // this lane searched: its clearance for the next iteration.  Scanned candidates other than the winner are at least
@@ -2023,6 +2036,9 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             const float other = real ? (u1 == bsc ? sec : bsc) : bsc;
             const float base = __builtin_amdgcn_sqrtf(real ? u1 : g.gate2);
             cnew = fminf(__builtin_amdgcn_sqrtf(other), base + CERT_M) * (1.0f - 1.0e-6f) - base * (1.0f + 1.0e-6f) - 1.0e-9f;
+            int cb = cum_bits;
+            asm volatile("" : "+s"(cb));                                  // (keeps the doubling down here: hoisted, it costs a VGPR across the drain)
+            cnew = cnew > 0.0f ? (cnew + 2.0f * __int_as_float(cb)) * (1.0f - 1.0e-6f) : -1.0f;      // recorded relative to the tile's motion total (rounded down)
             wr_c = true;
         }
         if (wr_j && wr_c) slot_rec[gs_ep] = make_float2(__int_as_float(jnn), cnew);
