@@ -31,7 +31,7 @@ constexpr int NN_BLOCK = 256;
 // normals, tile records and boxes, as a *source* the tile-major slots.  They are built once per frame (and role), not
 // once per pair: the 32 loop-closure candidates of src/GraphicEnd.cpp:685-762 share one target frame, and the
 // keyframe of GraphicEnd::run (src/GraphicEnd.cpp:168) stays the source of many consecutive pairs.
-// A PAIR is two frame references plus its own iteration state (T, accumulators, prevq, ownership map).
+// A PAIR is two frame references plus its own iteration state (T, accumulators, slot records / prevq, ownership map).
 struct PairPtrs {                  // per frame-pair device pointers: the resident products of its two frames
     const float4 *src;             // organized source cloud (only the brute-force compaction reads it)
     const float4 *tgt;             // organized target cloud
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(64) void k_coarse_boxes(FrameTasks a, TileGrid tg)
 }
 
 // start of a run for the pairs [b0, b0 + n): T = T_init (kernel argument) or Identity, trace row 0, flags, clean
-// accumulators.  grid (n), block 256.  (prevq / corr need no reset: the first iteration ignores them.)
+// accumulators.  grid (n), block 256.  (slot records / prevq / corr need no reset: the first iteration ignores them.)
 constexpr int TINIT_ARGS = 16;
 struct TinitArgs { double T[TINIT_ARGS][16]; };
 __global__ __launch_bounds__(256) void k_pair_init(TinitArgs ti, int has_T, int b0, double *__restrict__ Tcur,
@@ -972,7 +972,7 @@ __device__ __forceinline__ void tile_accumulate(int estimator, const RowBasis &B
 // GATED instances also apply the optional gates of spec S4g (point-to-plane only): the squared point-to-plane residual
 // e^2 <= resid2 (src/GraphicEnd.cpp~:484-489) and the angle between the rotated source normal and the target normal
 // (R n_s).n_t >= min_ncos (role of the RANSAC inlier subset, src/GraphicEnd.cpp:542).  A rejected slot has no
-// correspondence, but its nearest neighbour still serves as the next iteration's upper bound (prevq).
+// correspondence, but its nearest neighbour still serves as the next iteration's upper bound (prevq of the brute-force modes, slot_rec of the tile search).
 struct SlotGates {
     float resid2, min_ncos;
     const float4 *snrm;            // source normals, indexed by source pixel
@@ -1155,7 +1155,7 @@ constexpr int HEAD_POLLS = 200;      // x (a memory round trip + s_sleep): ~100 
 
 // ---- clearance certificates: an iteration does not search again what the last one already proved ---------------------
 // Once the pose has settled, a query's nearest neighbour does not change from one iteration to the next -- and the kernel can
-// PROVE it without searching.  Every slot keeps a CLEARANCE c (metres, an array of the pair like prevq):
+// PROVE it without searching.  Every slot keeps a CLEARANCE c (metres; the second word of its record, slot_rec):
 //   * a slot with a match j:   every other valid target is at least c farther from the query than j is;
 //   * a slot without a match:  every valid target is at least c beyond the gate.
 // A full search yields it for free: the second-smallest distance among the candidates it scanned (tracked with one v_med3 and
@@ -1611,7 +1611,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     unsigned long long clear_mask = 0ull;             // lanes whose slot held a clearance when this launch began (an untracked search must void it)
     int cum_bits = 0;                                 // tracking launches: the tile's motion total including this launch (float bits, held in an SGPR across the drain)
     unsigned long long cert_mask = 0ull;
-    int own_jprev = -2;                               // what prevq holds for this lane's slot (-2: nothing known, always write)
+    int own_jprev = -2;                               // the match this lane's slot record holds (-2: nothing known, always write)
     const float4 s4 = has_tile ? pp.srcT[(size_t)t * TILE_SLOTS + lane] : make_float4(0, 0, 0, __int_as_float(-1));
     const int pix = __float_as_int(s4.w);
     const bool own_valid = pix >= 0;
