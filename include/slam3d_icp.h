@@ -116,7 +116,8 @@ typedef struct slam3d_icp_handle slam3d_icp_handle;
 /* ---- lifecycle --------------------------------------------------------------------------- */
 void        slam3d_icp_default_params(slam3d_icp_params *p);
 /* SLAM3D_E_INVALID also when width*height*(z_filter*sqrt(1+tan^2))^2 >= 2^28: the normal-equation sums and plane moments
- * are int64 fixed point and such a configuration could overflow them (640x480 at z_filter 7 m is 11 times below). */
+ * are int64 fixed point and such a configuration could overflow them (640x480 at z_filter 7 m is 11 times below).
+ * A process may hold 256 handles at a time (each owns an entry of the search kernel's constant table); SLAM3D_E_NOMEM beyond. */
 int         slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle **out);
 void        slam3d_icp_destroy(slam3d_icp_handle *h);
 const char *slam3d_strerror(int code);

@@ -1214,23 +1214,39 @@ constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (
 //      quadrants), merged into the owner's keys with ds_min_u64;                             -- barrier --
 //   4. every wave finishes its own tile: gate, row products, level-1 reduction.
 // The result is independent of which wave processes which item (keys are merged by an exact minimum).
+// What does not change from launch to launch of a handle lives in CONSTANT memory, one entry per handle (slot given at
+// slam3d_icp_create): as kernel arguments these ~60 dwords sat in SGPRs from the first instruction on, and with the 102 a wave
+// has the compiler parked them in VGPR lanes and fetched them back with v_readlane wherever they were used -- 160 VALU
+// instructions per wave for nothing.  Loads from constant memory are scalar, invariant and re-issued where needed instead.
+struct NnStatic {
+    const double *Tcur; int *corr; float *cd2; int *cost; long long *acc; long long *dbg;
+    double *trace_T, *trace_S; int *flags; float2 *slot_rec; float *tile_cum;
+    Geometry g; TileGrid tg; int iters, nsets;
+};
+constexpr int NN_STATIC_SLOTS = 256;
+__constant__ NnStatic c_nn_static[NN_STATIC_SLOTS];
+
 template <int NN_STAGE, int WPE, bool COOP, bool DBG, bool GATED = false>
 __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_nn_tiles_acc(const PairPtrs *__restrict__ pairs,
-                                                        const double *__restrict__ Tcur,
-                                                        int *__restrict__ corr, float *__restrict__ cd2,
-                                                        const int *__restrict__ perm, int *__restrict__ cost,
-                                                        long long *__restrict__ acc, Geometry g, TileGrid tg,
-                                                        long long *__restrict__ dbg /* DBG builds only: 20 x int64 per tile */,
+                                                        int nn_slot /* the handle's entry of c_nn_static */,
+                                                        const int *__restrict__ perm,
                                                         int write_out /* corr / cd2 wanted (last iteration) */,
                                                         int it /* iteration of the run; 0: no previous match to start from */,
                                                         StampRing sring /* launch stamps; rows null (the default): none */, int stamp_idx,
                                                         int head /* solve iteration it-1 at the head of this launch (see above) */,
-                                                        double *__restrict__ trace_T, double *__restrict__ trace_S, int *__restrict__ flags,
-                                                        int iters, int nsets /* accumulator sets per pair */,
-                                                        float2 *__restrict__ slot_rec /* [pairs][nslots] every slot's last result: (match j as int bits, -1: none | its clearance record) */,
-                                                        float *__restrict__ tile_cum /* [pairs][ntiles] motion total of each source tile over the current stretch of tracking launches */,
                                                         int cert /* certify from it >= 1 on (needs `it` = the run's iteration and trace_T[it - 1]) */)
 {
+    // g / tg are used all over the kernel and stay with the compiler; the pointers and counts that only the head, the prologue
+    // and the epilogue need are fetched right there through SS(): an opaque copy of the entry's address, so that the loads
+    // cannot be merged with the ones of another phase, hoisted to the top and parked in VGPR lanes in between
+    const Geometry &g = c_nn_static[nn_slot].g;
+    const TileGrid &tg = c_nn_static[nn_slot].tg;
+    typedef const __attribute__((address_space(4))) NnStatic *nn_static_ptr;
+    auto SS = [&]() __attribute__((always_inline)) {
+        unsigned long long a = (unsigned long long)&c_nn_static[nn_slot];
+        asm volatile("" : "+s"(a));
+        return (nn_static_ptr)a;
+    };
     const int first = it == 0;
     const bool certify = cert && it > 0;                    // slots may carry a clearance from the previous launch (<= 0: none)
     bool trk = false;                                       // this launch tracks (best, second) and inflates its pruning radii: decided below,
@@ -1301,11 +1317,17 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     if (threadIdx.x == 0) { n_items = 0; next_item = 0; n_titems = 0; next_titem = 0; }
     if (threadIdx.x < NN_WAVES) wcost[threadIdx.x] = 0;
     // the launch's pose goes through LDS in both cases: read from Tcur (k_solve_acc wrote it), or solved right here
-    if (!(COOP && head && it > 0)) { if (threadIdx.x < 12) head_T[threadIdx.x] = (float)Tcur[b * 16 + threadIdx.x]; }
-    if (certify && threadIdx.x >= 64 && threadIdx.x < 76) prev_T[threadIdx.x - 64] = (float)trace_T[((size_t)b * (iters + 1) + (it - 1)) * 16 + (threadIdx.x - 64)];
+    if (!(COOP && head && it > 0)) { if (threadIdx.x < 12) head_T[threadIdx.x] = (float)SS()->Tcur[b * 16 + threadIdx.x]; }
+    if (certify && threadIdx.x >= 64 && threadIdx.x < 76) {
+        const nn_static_ptr S0 = SS();
+        prev_T[threadIdx.x - 64] = (float)S0->trace_T[((size_t)b * (S0->iters + 1) + (it - 1)) * 16 + (threadIdx.x - 64)];
+    }
     if constexpr (COOP) {
         if (head && it > 0) {
             if (w == 0) {
+                const nn_static_ptr SH = SS();
+                double *__restrict__ const trace_T = SH->trace_T;
+                const int iters = SH->iters;
                 double *__restrict__ Tnew = trace_T + ((size_t)b * (iters + 1) + it) * 16;
                 double *tot = reinterpret_cast<double *>(stage_all[0]);          // 32 + 16 doubles of this wave's (still unused) stage slab
                 double *tsh = tot + 32;
@@ -1325,7 +1347,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                     if (have && lane < 12) head_T[lane] = (float)__longlong_as_double((long long)v);
                 }
                 if (!have) {
-                    const long long *__restrict__ A = acc + ((size_t)b * nsets + (it - 1)) * ACC_R * ACC_STRIDE;
+                    const long long *__restrict__ A = SH->acc + ((size_t)b * SH->nsets + (it - 1)) * ACC_R * ACC_STRIDE;
                     if (lane < NSUMS) {
                         long long q = 0;
 #pragma unroll
@@ -1340,8 +1362,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                     const double Tn = wave_solve_point2plane(tot, tsh, rc);
                     if (lane < 12) head_T[lane] = (float)Tn;
                     if (c == 0) {                                   // the one block that publishes
-                        if (lane < NSUMS) trace_S[((size_t)b * iters + (it - 1)) * NSUMS + lane] = tot[lane];
-                        if (lane == 0 && rc != 1) flags[b] = flags[b] | (rc == 2 ? 1 : 2);
+                        if (lane < NSUMS) SH->trace_S[((size_t)b * iters + (it - 1)) * NSUMS + lane] = tot[lane];
+                        if (lane == 0 && rc != 1) SH->flags[b] = SH->flags[b] | (rc == 2 ? 1 : 2);
                         if (lane < 16) __hip_atomic_store(reinterpret_cast<unsigned long long *>(Tnew + lane), (unsigned long long)__double_as_longlong(Tn), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -1671,6 +1693,9 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         float4 pq = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
         float yprev = -1.0f;                                       // the slot's clearance record (<= 0: none; see tile_cum)
         float cum_prev = 0.0f;
+        const nn_static_ptr SP = SS();
+        float2 *__restrict__ const slot_rec = SP->slot_rec;
+        float *__restrict__ const tile_cum = SP->tile_cum;
         if (trk) cum_prev = tile_cum[(size_t)b * tg.ntiles + t];   // (wave-uniform: a scalar load, in flight with the record)
         if (!first) {    // (a run's first iteration: whatever an earlier run left there is ignored)
             // the slot's record is 8 bytes (match, clearance); the matched POINT is gathered again -- from the records the window
@@ -1994,7 +2019,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         if (stamp && lane == 0 && atomicAdd(&waves_done, 1) == NN_WAVES - 1) stamp_end(stamp, c);
     };
     if (!has_tile) { stamp_wave_end(); return; }
-    if constexpr (!COOP) { if (lane == 0) cost[(size_t)b * tg.ntiles + t] = wcost[w]; }          // input of k_balance
+    if constexpr (!COOP) { if (lane == 0) SS()->cost[(size_t)b * tg.ntiles + t] = wcost[w]; }          // input of k_balance
     // ================= step 4: this wave's own tile: fused S4 accumulation =================
     if constexpr (COOP) {
         bkey = qkey[w][lane];
@@ -2009,6 +2034,10 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     }
     RowBasis rb;
     int jnn = -1;
+    const nn_static_ptr SE = SS();
+    int *__restrict__ const corr = SE->corr;
+    float *__restrict__ const cd2 = SE->cd2;
+    float2 *__restrict__ const slot_rec = SE->slot_rec;
     if constexpr (GATED) {             // the optional S4g gates: their own instances, the production ones carry none of this
         SlotGates sg;
         const Rt m = load_rt_lds(head_T);
@@ -2045,10 +2074,10 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         else if (wr_j) slot_rec[gs_ep].x = __int_as_float(jnn);
         else if (wr_c) slot_rec[gs_ep].y = cnew;
     }
-    tile_accumulate(g.estimator, rb, acc + (((size_t)b * nsets + (head ? it : 0)) * ACC_R + (c % ACC_R)) * ACC_STRIDE);
+    tile_accumulate(g.estimator, rb, SE->acc + (((size_t)b * SE->nsets + (head ? it : 0)) * ACC_R + (c % ACC_R)) * ACC_STRIDE);
     stamp_wave_end();
-    if (DBG && dbg && b == 0 && lane == 0) {
-        long long *d = dbg + (size_t)t * 20;
+    if (DBG && SE->dbg && b == 0 && lane == 0) {
+        long long *d = SE->dbg + (size_t)t * 20;
         d[0] = clk0; d[1] = clk1; d[2] = clk2; d[3] = clk3; d[4] = clock64();
         d[5] = n_scanned | ((long long)n_chit << 32); d[6] = n_cand | ((long long)n_fhit << 32);
         d[7] = n_batches | ((long long)n_refined << 32);
