@@ -713,3 +713,35 @@ def test_depth_frames_with_and_without_the_projective_window_search(gpu_lib, siz
     assert rg["inliers"] == ro["inliers"] and rg["status"] == ro["status"]
     r1 = O.icp(s4, t4, O.params(pr.intr, nn_method=0, **{**kw, "iterations": 1}), T_init=ro["T_trace"][2])
     assert np.array_equal(mid, r1["idx"])
+
+
+def test_handles_of_different_geometry_side_by_side_and_slot_reuse(gpu_lib):
+    """The search kernel reads its per-handle constants (pointers, geometry, tile grid, iteration count) from a table in
+    constant memory, one entry per live handle: handles of DIFFERENT sizes / estimators / iteration counts alive together must
+    each get their own oracle result, in any order of use, and entries must be recycled (more create / destroy cycles than
+    the table has entries)."""
+    cfgs = [(64, 48, 0, 3), (104, 72, 1, 5), (160, 120, 0, 8), (40, 24, 0, 2)]
+    prs = [synth.make_pair(3100 + k, W, H) for k, (W, H, _, _) in enumerate(cfgs)]
+    hs = [capi.IcpHandle(capi.default_params(pr.intr, estimator=e, iterations=it, max_corr_dist=0.3)) for pr, (_, _, e, it) in zip(prs, cfgs)]
+    try:
+        for k in (2, 0, 3, 1, 0, 2):
+            pr, (W, H, e, it) = prs[k], cfgs[k]
+            s4 = synth.backproject_numpy(pr.depth_src, pr.intr); t4 = synth.backproject_numpy(pr.depth_tgt, pr.intr)
+            ro = O.icp(s4, t4, O.params(pr.intr, estimator=e, iterations=it, nn_method=0, max_corr_dist=0.3))
+            rg = hs[k].align(s4, t4)
+            idx, _ = hs[k].get_correspondences(0)
+            Tt, _ = hs[k].get_trace(0)
+            assert np.array_equal(idx, ro["idx"]) and np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]), (k, W, H)
+            assert rg["status"] == ro["status"] and rg["inliers"] == ro["inliers"], (k, W, H)
+    finally:
+        for h in hs:
+            h.close()
+    pr = prs[3]
+    s4 = synth.backproject_numpy(pr.depth_src, pr.intr); t4 = synth.backproject_numpy(pr.depth_tgt, pr.intr)
+    want = None
+    for n in range(300):
+        with capi.IcpHandle(capi.default_params(pr.intr, iterations=2, max_corr_dist=0.3)) as h:
+            if n % 50 == 0:
+                T = np.asarray(h.align(s4, t4)["T"])
+                want = T if want is None else want
+                assert np.array_equal(T, want), n
