@@ -904,14 +904,8 @@ template <int EST, int K> __device__ __forceinline__ double row_term(const RowBa
 //   level 32: v_permlane32_swap(a, b) puts a's lower/upper halves side by side with b's, so ONE add yields
 //             a[i]+a[i+32] in lanes 0..31 and b[i]+b[i+32] in lanes 32..63;
 //   level 16: v_permlane16_swap on two such registers -> rows 0..3 hold components (a, c, b, d);
-//   levels 8..1: DPP row_shl inside each 16-lane row.  Result: lanes 0,16,32,48 hold the sums of a,c,b,d.
+//   levels 8..1: DPP row_shl inside each 16-lane row, as 64-bit integer adds (below).  Result: lanes 0,16,32,48 hold the sums of a,c,b,d.
 
-template <int CTRL> __device__ __forceinline__ double dpp_d(double x)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ double swap32_add(double a, double b)
 {
     const auto rl = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
@@ -924,14 +918,30 @@ __device__ __forceinline__ double swap16_add(double x, double y)
     const auto rh = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
     return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);   // rows (x0|y0|x2|y2) + (x1|y1|x3|y3)
 }
-__device__ __forceinline__ double wave_sum_x4(double a, double b, double c, double d)
+// The wave's four sums as int64: the two cross-row levels in fp64 (one add per level and value pair), then the value -- an
+// integer below 2^46 in magnitude -- moves to two's complement (adding 1.5 * 2^52 leaves it in the low mantissa bits: three
+// instructions instead of the generic double -> int64 conversion) and the four in-row levels are 64-bit INTEGER adds with a DPP
+// operand: v_add_co_u32_dpp + v_addc_co_u32_dpp, two instructions per level where fp64 (no DPP form) needs two moves and an add.
+// Lanes a row_shl reaches past the row's end keep their value (no bound_ctrl): only lane 0 of each row is read.
+__device__ __forceinline__ long long wave_sum_x4_i64(double a, double b, double c, double d)
 {
-    double x = swap16_add(swap32_add(a, b), swap32_add(c, d));
-    x = x + dpp_d<0x108>(x);
-    x = x + dpp_d<0x104>(x);
-    x = x + dpp_d<0x102>(x);
-    x = x + dpp_d<0x101>(x);
-    return x;      // lane 0: a, lane 16: c, lane 32: b, lane 48: d
+    const double x = swap16_add(swap32_add(a, b), swap32_add(c, d));
+    const long long q = __double_as_longlong(x + 6755399441055744.0) - 0x4338000000000000ll;
+    unsigned int lo = (unsigned int)q, hi = (unsigned int)((unsigned long long)q >> 32);
+    asm("s_nop 1\n\t"
+        "v_add_co_u32_dpp %0, vcc, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_co_u32_dpp %0, vcc, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_co_u32_dpp %0, vcc, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_co_u32_dpp %0, vcc, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shl:1 row_mask:0xf bank_mask:0xf"
+        : "+v"(lo), "+v"(hi) : : "vcc");
+    return (long long)(((unsigned long long)hi << 32) | lo);      // lane 0: a, lane 16: c, lane 32: b, lane 48: d
 }
 // A slot's term in fixed-point units is an integer-valued double: row_term returns term * 2^32 exactly and rint
 // rounds it to nearest-even like the oracle's llrint.  |term| < 2^39, so the 64-lane sums stay under 2^53 and every
@@ -942,11 +952,8 @@ __device__ __forceinline__ double wave_sum_x4(double a, double b, double c, doub
 // instructions of four addresses each; tiles without a match issue none
 template <int EST, int K0> __device__ __forceinline__ void tile_accumulate_group(const RowBasis &B, long long *__restrict__ acc, int lane, int koff)
 {
-    const double x = wave_sum_x4(rint(row_term<EST, K0>(B)), rint(row_term<EST, K0 + 1>(B)), rint(row_term<EST, K0 + 2>(B)),
-                                 rint(row_term<EST, K0 + 3>(B)));
-    // x is an integer below 2^46 in magnitude: adding 1.5 * 2^52 leaves it in the low mantissa bits (two's complement),
-    // three instructions instead of the generic double -> int64 conversion
-    const long long q = __double_as_longlong(x + 6755399441055744.0) - 0x4338000000000000ll;
+    const long long q = wave_sum_x4_i64(rint(row_term<EST, K0>(B)), rint(row_term<EST, K0 + 1>(B)), rint(row_term<EST, K0 + 2>(B)),
+                                        rint(row_term<EST, K0 + 3>(B)));
     if ((lane & 15) == 0 && q != 0) atomicAdd(reinterpret_cast<unsigned long long *>(acc + K0 + koff), (unsigned long long)q);
 }
 template <int EST> __device__ __forceinline__ void tile_accumulate_est(const RowBasis &B, long long *__restrict__ acc)
