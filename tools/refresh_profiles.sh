@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (via gpurun): the default bench line, rocprofv3 kernel stats, the kernel trace of the pipelined
 # regime and the PMC passes the roofline objects cite; everything lands under gpurun_out/refresh_<tag>/ (turn it into
-# profiles/<tag>_* afterwards with tools/collect_profiles.py <tag>).  usage: bash tools/refresh_profiles.sh r02
+# profiles/<tag>_* afterwards with tools/collect_profiles.py <tag>).  usage: bash tools/refresh_profiles.sh r03
 set -u
 TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
