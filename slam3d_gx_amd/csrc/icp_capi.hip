@@ -350,8 +350,9 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
         st.trace_T = h->trace_T; st.trace_S = h->trace_S; st.flags = h->flags; st.slot_rec = h->slot_rec; st.tile_cum = h->tile_cum;
         st.g = h->g; st.tg = tg; st.iters = iters; st.nsets = h->nsets;
         h->nn_slot = nn_slot_take();
-        // (through the handle's own stream: hipMemcpyToSymbol brings the legacy default stream to life, which takes one of the four
-        // hardware queues the in-flight handles' streams are dealt over -- measured: 73 k -> 50 k it/s with four handles)
+        // (through the handle's own stream: with hipMemcpyToSymbol -- a default-stream operation between the creation of one handle's
+        // stream and the next -- four handles in flight reached 50 k it/s instead of 73 k, 1.7 launches resident instead of 3.0:
+        // presumably two of their streams then shared one of the runtime's four hardware queues)
         NnStatic *sym = nullptr;
         if (h->nn_slot < 0 || hipGetSymbolAddress((void **)&sym, HIP_SYMBOL(c_nn_static)) != hipSuccess ||
             hipMemcpyAsync(sym + h->nn_slot, &st, sizeof st, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
