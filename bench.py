@@ -94,6 +94,8 @@ def parse_args():
     ap.add_argument("--one-device", action="store_true")
     ap.add_argument("--force-collective", action="store_true", help="developer knob: run the RCCL exchanges even with one rank")
     ap.add_argument("--no-pipeline", action="store_true", help="one handle, every alignment fetched before the next is queued")
+    ap.add_argument("--dump-table", default="", help="rank 0 writes the LAST step's gathered pose table (pair order) with every record's seed "
+                    "to this JSON file (tests: BASELINE config 4's shape, --gpus 8 --pairs 64 --pairs-per-step 64 --in-flight 1 --pool 64)")
     ap.add_argument("--in-flight", type=int, default=4, help="alignments in flight (handles taking turns, one HIP stream each; the runtime has "
                     "four hardware queues by default: 4 -> 54 k, 3 -> 51 k, 5 -> 44 k, 6 -> 49 k it/s)")
     return ap.parse_args()
@@ -187,19 +189,24 @@ class Streamer:
         self.T_init = T_init        # optional initial guess of every alignment (the real-frame leg)
         self.k = 0
         self.queue = []             # handles with a run in flight, oldest first
+        self.seedq = []             # the seeds of their pairs, same order
         self.last = None
+        self.last_seeds = None
 
     def _enqueue(self, hi):
         h, pool = self.handles[hi], self.pools[hi]
         n = len(pool)
         base = (self.k // len(self.handles)) * self.P
+        seeds = []
         for i in range(self.P):
             j = (base + i) % n
+            seeds.append(pool.pairs[j].seed)
             h.frame_set_depth_host_ptr(2 * i, pool.src_ptr(j))
             h.frame_set_depth_host_ptr(2 * i + 1, pool.tgt_ptr(j))
             h.set_pair(i, 2 * i, 2 * i + 1)
         h.run(self.P, self.T_init)
         self.queue.append(hi)
+        self.seedq.append(seeds)
         self.k += 1
 
     def run(self, n_align, sink=None):
@@ -216,39 +223,83 @@ class Streamer:
     def _drain_one(self, sink):
         hi = self.queue.pop(0)
         self.last = self.handles[hi].fetch_results(self.P)
+        self.last_seeds = self.seedq.pop(0)
         if self.on_fetch is not None:
             self.on_fetch(hi, self.handles[hi])
         if sink is not None:
             sink.extend(self.last)
+            if hasattr(sink, "seeds"):
+                sink.seeds.extend(self.last_seeds)
 
 
 def cpu_baseline_leg(pair, s4, t4, iterations, est, gpu_result, gpu_idx, brute_sample=True):
     """Times the CPU oracle on the same pair and checks the GPU result against it.
-    (oracle use is confined to this leg: checker + CPU baseline, never the measured path)"""
+    (oracle use is confined to this leg: checker + CPU baseline, never the measured path)
+
+    VERDICT r3 item 7: the all-threads figure used to vary 2x between runs and scaled 2.6x from 1 to 256 threads (a serial
+    qsort-per-level kd-tree build was 60 % of it).  Now: the kd-tree is built by quickselect under OpenMP tasks, and `value` is
+    the BEST point of a 1 / 8 / 16 / 32 / 64 / physical cores / all hardware threads curve, each point the median of 7 runs after a
+    warm-up run.  Measured on the GPU host (2 x EPYC 9575F, 256 hardware threads; tools/cpu_scaling.py): 17 it/s on one
+    thread, 111 on 8, 198 on 16, 184 on 32, 173 on 64 (unstable), 68 on 128, 3 on 256 -- the 217 k queries of a pair do not feed
+    more than a few dozen threads, and a team as large as the machine is oversubscribed by the process's other threads
+    (libgomp's spinning barriers then cost ~100 ms per region); thread pinning (OMP_PROC_BIND close / spread) changes none of
+    it.  The baseline is therefore quoted at its fastest thread count, `cores`; the phase times of one run at that count
+    say where the CPU path's time goes."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     cores = os.cpu_count() or 1
     big = pair.intr.width * pair.intr.height > 640 * 480
-    p_all = O.params(pair.intr, estimator=est, iterations=iterations, nn_method=1, threads=0)
-    times = []
+    reps = 5 if big else 7
+    curve = {}
     ro = None
-    for _ in range(3 if big else 7):
+    counts = sorted({c for c in ((1, 16, 64) if big else (1, 8, 16, 32, 64, cores // 2, cores)) if 1 <= c <= cores})
+    best_t = None
+    for th in counts:
+        its = iterations if th > 1 else min(4 if big else 10, iterations)      # one thread: a bounded sample
+        pth = O.params(pair.intr, estimator=est, iterations=its, nn_method=1, threads=th)
         t0 = time.perf_counter()
-        ro = O.icp(s4, t4, p_all, trace=True)
-        times.append(time.perf_counter() - t0)
-    t_all = statistics.median(times)
-    # PCL's ICP is single-threaded: time one thread on a bounded sample
-    it1 = min(4 if big else 10, iterations)
-    p_one = O.params(pair.intr, estimator=est, iterations=it1, nn_method=1, threads=1)
-    t0 = time.perf_counter()
-    O.icp(s4, t4, p_one, trace=False)
-    t_one = time.perf_counter() - t0
+        r = O.icp(s4, t4, pth, trace=True)                                     # warm-up: thread team, page faults
+        t_warm = time.perf_counter() - t0
+        if ro is None or th == 16:
+            ro = r                                                             # (the checker's copy of the result; any thread count gives the same bits)
+        times = []
+        hopeless = th > 1 and best_t is not None and t_warm > 4.0 * best_t      # an oversubscribed team: one run says it all
+        for _ in range(1 if hopeless else (reps if th > 1 else 3)):
+            t0 = time.perf_counter()
+            O.icp(s4, t4, pth, trace=False)
+            times.append(time.perf_counter() - t0)
+        if th > 1:
+            best_t = min(best_t or 1e30, statistics.median(times))
+        curve[th] = {"value": its / statistics.median(times), "iterations": its, "runs": len(times),
+                     "spread": (max(times) - min(times)) / statistics.median(times)}
+    best = max((c for c in counts if c > 1), key=lambda c: curve[c]["value"], default=1)
+    phases = None
+    if not big:      # where one run at the best thread count spends its time (the oracle prints its phase times on request)
+        try:
+            import subprocess
+            import tempfile
+            with tempfile.TemporaryDirectory() as tmp:
+                np.savez(os.path.join(tmp, "pair.npz"), s4=s4, t4=t4)
+                code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r); import oracle_lib as O; from slam3d_gx_amd import synth; "
+                        "z = np.load(%r); intr = synth.Intrinsics.scaled(%d, %d); "
+                        "p = O.params(intr, estimator=%d, iterations=%d, nn_method=1, threads=%d); O.icp(z['s4'], z['t4'], p); O.icp(z['s4'], z['t4'], p)"
+                        % (os.path.join(ROOT, "tests"), ROOT, os.path.join(tmp, "pair.npz"), pair.intr.width, pair.intr.height, est, iterations, best))
+                pr_ = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, ORC_TIMING="1"))
+            ln = [l for l in pr_.stderr.splitlines() if l.startswith("orc_icp timing")]
+            if ln:
+                phases = ln[-1]
+        except Exception:       # noqa: BLE001 -- informational only
+            pass
     out = {
-        "value": iterations / t_all, "unit": "ICP iterations/s", "cores": cores, "kind": "port",
-        "sample": f"oracle/ cpu_B (exact kd-tree NN + same estimator, OpenMP on all {cores} hardware threads), 1 pair seed "
-                  f"{pair.seed} x {iterations} iterations incl. normals + kd-tree build, median of {len(times)}",
-        "single_thread_value": it1 / t_one,
-        "single_thread_sample": f"same, 1 thread, {it1} iterations (PCL's own ICP is single-threaded)",
+        "value": curve[best]["value"], "unit": "ICP iterations/s", "cores": best, "kind": "port", "host_hardware_threads": cores,
+        "sample": f"oracle/ cpu_B (exact kd-tree NN + same estimator, OpenMP, {best} pinned threads = the fastest point of the thread curve on "
+                  f"this {cores}-thread host), 1 pair seed {pair.seed} x {iterations} iterations incl. normals + kd-tree build, median of "
+                  f"{curve[best]['runs']} after a warm-up run",
+        "thread_curve": {str(k): round(v["value"], 2) for k, v in curve.items()},
+        "thread_curve_spread": {str(k): round(v["spread"], 3) for k, v in curve.items()},
+        "single_thread_value": curve[1]["value"] if 1 in curve else None,
+        "single_thread_sample": f"same, 1 thread, {curve[1]['iterations'] if 1 in curve else 0} iterations (PCL's own ICP is single-threaded)",
+        "phase_ms_one_run": phases,
     }
     if brute_sample:
         # cpu_A of SURVEY.md 8(d): the literal brute-force scan with the canonical arithmetic, all cores, ONE NN pass
@@ -425,11 +476,19 @@ def timed_stream(torch, dist, world, streamer, steps, warmup, aligns_per_step, c
 
     pending = 0
     table = None
+    step_seeds = []          # seeds of this rank's records of the last step, in record order
+
+    class _Sink(list):
+        pass
 
     def one_step():
-        nonlocal pending, table
-        sink = [] if comm is not None else None
+        nonlocal pending, table, step_seeds
+        sink = None
+        if comm is not None:
+            sink = _Sink(); sink.seeds = []
         res = streamer.run(aligns_per_step, sink)
+        if sink is not None:
+            step_seeds = sink.seeds
         if comm is not None:
             if pending >= 2:
                 table = comm.gather_collect(aligns_per_step * P); pending -= 1
@@ -451,7 +510,7 @@ def timed_stream(torch, dist, world, streamer, steps, warmup, aligns_per_step, c
         res = one_step()
     drain()                 # the last step's pose table is on every rank before the clock stops
     fence()
-    return time.perf_counter() - t0, res, table
+    return time.perf_counter() - t0, res, table, step_seeds
 
 
 # ------------------------------------------------------------------------------------------------ rows f-1 / f-2
@@ -727,6 +786,13 @@ def main():
                        "parallelism": f"source rows over {world} rank(s), RCCL all-reduce (C-ABI) of 29 int64 per iteration",
                        "n_src": d["res"]["n_src"], "n_tgt": d["res"]["n_tgt"]},
             "status": [d["res"]["status"]],
+            # what this mode is DESIGNED to reach: the target's preprocessing and the H2D are replicated on
+            # every rank (~0.25 ms of a 1.97 ms alignment), a launch has a ~20 us latency floor however few rows it holds, and
+            # every iteration adds one 4 KB all-reduce (~15-25 us): a latency experiment, not the scaling mode -- read a
+            # measured ratio against THIS, not against the >= 6x target of the batch mode (no data-path collective)
+            "predicted_scaling": {"vs_1_gpu": {"2": 1.5, "4": 2.0, "8": 2.2},
+                                  "model": "T(N) = 0.25 ms (H2D + preprocessing, replicated) + iterations x (max(88 us / N, 20 us) + "
+                                           "allreduce 15..25 us + head solve 2..3 us); T(1) = 1.97 ms measured"},
         }
         if "prof" in d:
             out["roofline"] = tiles_roofline(d["prof"], args.iterations, f"k_nn_tiles_acc_{size_tag}")
@@ -758,6 +824,7 @@ def main():
         specs += [(args.seed0 + k, 640, 480, args.noise_sigma) for k in range(64)]
         specs += [(args.seed0 + hi * pool_n + k, 640, 480, 0.0012) for hi in range(n_handles) for k in range(min(pool_n, 8))]
         specs += [Pool.spec(args.seed0 + hi * pool_n + k, 640, 480, args.noise_sigma, (8, 0.25)) for hi in range(n_handles) for k in range(min(pool_n, 8))]
+        specs += [Pool.spec(args.seed0 + hi * pool_n + k, 640, 480, 0.0012, (8, 0.25)) for hi in range(n_handles) for k in range(min(pool_n, 8))]
         specs += [(2000 + k, 1280, 960, args.noise_sigma) for k in range(min(args.pool, 4))]
     Pool.prefetch(synth, specs)
     pools = [Pool(torch, synth, [args.seed0 + (rank * n_handles + hi) * pool_n + k for k in range(pool_n)], args.width, args.height,
@@ -784,7 +851,7 @@ def main():
         gather = _HostGather()
     pose_exchange = ("none (1 rank)" if gather is None else "rccl: ncclAllGather behind the C-ABI (slam3d_pose_gather_*)" if comm is not None
                      else "gloo through torch.distributed (tests)" if host_comm else "torch.distributed fallback (slam3d_comm self-test failed)")
-    elapsed, res, table = timed_stream(torch, dist, world, streamer, args.steps, args.warmup, aligns, gather, P)
+    elapsed, res, table, step_seeds = timed_stream(torch, dist, world, streamer, args.steps, args.warmup, aligns, gather, P)
     elapsed = tmax(elapsed)
     total_iters = world * S * args.iterations * args.steps
     value = total_iters / elapsed
@@ -816,6 +883,19 @@ def main():
     }
     if table is not None:
         out["config"]["gathered_pose_records"] = len(table)
+        # which pair each gathered record belongs to (outside the timed region): rank blocks in rank order = pair order
+        all_seeds = [step_seeds]
+        if world > 1:
+            all_seeds = [None] * world
+            dist.all_gather_object(all_seeds, step_seeds)
+        flat = [sd for blk in all_seeds for sd in blk]
+        out["config"]["gathered_seeds"] = {"first": flat[:2], "last": flat[-2:], "ascending": bool(all(b > a for a, b in zip(flat, flat[1:])))}
+        if args.dump_table and rank == 0:
+            with open(args.dump_table, "w") as f:
+                json.dump({"seeds": flat, "world": world, "pairs_per_rank": len(step_seeds),
+                           "T": [np.asarray(r["T"], dtype=np.float64).reshape(16).tolist() for r in table],
+                           "inliers": [int(r["inliers"]) for r in table], "status": [int(r["status"]) for r in table],
+                           "norm": [float(r["norm"]) for r in table]}, f)
 
     tiles = args.nn_mode in (capi.NN_AUTO, capi.NN_TILES)
     if args.timed_only:
@@ -1042,6 +1122,18 @@ def extra_legs(args, torch, dist, capi, synth, local_rank, est, handles, pools, 
                     "note": "SURVEY.md 8(d)'s mask (8x8-pixel Bernoulli holes, p = 0.25) in the same streaming regime (H2D + distinct pairs, "
                             f"{len(handles)} in flight); nn_launch_us by HIP events one alignment at a time"})
         out["survey_mask"] = leg
+    # ---- (ii-b2) BASELINE.md section 4 / SURVEY.md 8(d)'s workload AS SPECIFIED, both parts together: sigma = 0.0012 z^2 AND the
+    # 8x8 / 0.25 mask (only ever measured separately).  Parity of this workload: tests/test_gpu_parity.py::
+    # test_full_640x480_baseline_md_workload (every iterate and index against the kd-tree oracle).
+    if not (abs(args.noise_sigma - 0.0012) < 1e-9 and (args.hole_block, args.hole_prob) == (8, 0.25)):
+        pools_b = [Pool(torch, synth, [p.seed for p in pool.pairs[:8]], args.width, args.height, 0.0012, (8, 0.25)) for pool in pools]
+        r, leg = stream_leg(handles, pools_b, 768)
+        leg.update({"noise_sigma_over_z2": 0.0012, "hole_block": 8, "hole_prob": 0.25, "n_src": r["n_src"], "n_tgt": r["n_tgt"],
+                    "inliers": r["inliers"], "status": r["status"],
+                    "note": "BASELINE.md section 4's synthetic workload exactly (sigma = 0.0012 z^2, 8x8-pixel Bernoulli holes at p = 0.25), same "
+                            f"streaming regime (H2D + distinct pairs, {len(handles)} in flight); with iid noise at this level the reference's "
+                            "0.01 m / 41-of-49 planarity rule keeps a normal on about a fifth of the targets (n_tgt)"})
+        out["baseline_md_workload"] = leg
     # ---- (ii-c) real sensor frames: the reference's Kinect depth images (tests/golden/kinect, data fixtures).  dep1 -> dep2 is a
     # wide-baseline pair (an equality test elsewhere, here only a timing on real hole / edge geometry); dep_k -> dep_k from a small
     # initial guess converges to the identity

@@ -104,6 +104,7 @@ struct slam3d_icp_handle {
     unsigned long long *d_stamps = nullptr; unsigned int *d_stamp_seq = nullptr; int stamp_rows = 0, stamp_ring = 0;
     bool ran_profiled = false;
     bool ran = false; int last_B = 0;
+    bool run_counted = false;     // k_pair_init of the run being enqueued counted it into g_runs_in_flight; cleared once its last k_solve_acc is enqueued too
     int row0 = 0, row1 = 0; int dense_it = 0;
     std::string err;
 };
@@ -651,6 +652,7 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         hipLaunchKernelGGL(k_pair_init, dim3(B), dim3(256), 0, s, ti, 0, 0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters, h->nsets,
                                stamp_ring_of(h), count_run);
     }
+    if (count_run) h->run_counted = true;
     if (nn_mode_of(h) != SLAM3D_NN_TILES) {
         HIPCHK(h, hipMemsetAsync(h->best, 0xFF, sizeof(unsigned long long) * (size_t)B * tg.nslots, s));
         hipLaunchKernelGGL(k_compact, dim3(2, B), dim3(1024), 0, s, h->d_pairs, h->src_c, h->tgt_c, h->ccounts, g, tg,
@@ -771,13 +773,18 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
         const size_t n = (size_t)(iters > 0 ? iters : 1) * h->maxB * h->tg.nslots;
         if (hipMalloc((void **)&h->corr_trace, sizeof(int) * n) != hipSuccess) { (void)hipGetLastError(); return SLAM3D_E_NOMEM; }
     }
+    h->run_counted = false;
     int rc = enqueue_preprocess(h, B, T_init, s, iters > 0 ? 1 : 0);       // (counted as in flight until the last k_solve_acc)
-    if (rc) return rc;
-    rc = enqueue_iterations(h, B, s, iters);
-    if (rc) {                   // k_pair_init counted this run in; its last k_solve_acc, which counts it out, will not run
-        if (iters > 0) { hipLaunchKernelGGL(k_run_uncount, dim3(1), dim3(1), 0, s); (void)hipGetLastError(); }
+    if (!rc) rc = enqueue_iterations(h, B, s, iters);
+    if (rc) {
+        // k_pair_init may have counted this run in (run_counted: it was launched); its last k_solve_acc, which counts it out,
+        // will not run.  Whatever failed -- a later launch of the preprocessing, the capture, the graph launch -- the stream is
+        // out of capture mode by now (enqueue_iterations always ends a capture it began), so the correction can be enqueued
+        // behind k_pair_init; a count that leaked would make every later head solve poll instead of solving locally.
+        if (h->run_counted) { hipLaunchKernelGGL(k_run_uncount, dim3(1), dim3(1), 0, s); (void)hipGetLastError(); h->run_counted = false; }
         return rc;
     }
+    h->run_counted = false;
     HIPCHK(h, hipEventRecord(h->ev[2], s));
     h->run_stream = s;
     h->ran = true;
@@ -838,6 +845,9 @@ extern "C" int slam3d_icp_set_stamping(slam3d_icp_handle *h, int32_t ring_runs)
     HIPCHK(h, hipSetDevice(h->p.device));
     HIPCHK(h, hipStreamSynchronize(h->run_stream ? h->run_stream : h->stream));
     if (ring_runs > 0 && ring_runs != h->stamp_ring) {
+        // the ring (buffer, modulus, rows per run) is baked into the captured launches as kernel arguments: a graph that
+        // outlived a re-allocation would stamp into freed memory with the old modulus
+        h->graph_B = 0;
         if (h->d_stamps) { (void)hipFree(h->d_stamps); h->d_stamps = nullptr; }
         h->stamp_rows = 2 * (h->p.iterations > 0 ? h->p.iterations : 1);
         h->stamp_ring = ring_runs;
@@ -1564,8 +1574,10 @@ extern "C" int slam3d_icp_dense_finish(slam3d_icp_handle *h, const int64_t last_
 // on the handle's own stream and nothing else between two NN launches (round 3): launch k accumulates this rank's rows into
 // accumulator set k, the all-reduce sums set k over the ranks in place (16 x 32 int64), and the head of launch k+1 solves
 // -- the same integers, hence the same pose bits, on every rank (round 2: reduce launch -> all-reduce of 29 words -> solve
-// launch).  The svd estimator and SLAM3D_HEAD_SOLVE=0 keep that three-step form.  A rank that fails locally aborts the
-// communicator (ncclCommAbort) so that its peers' collectives return instead of waiting for ever.
+// launch).  The svd estimator and SLAM3D_HEAD_SOLVE=0 keep that three-step form.  A rank that fails locally aborts ITS side of
+// the communicator (ncclCommAbort) and marks the slam3d_comm dead (every later call with it returns SLAM3D_E_COMM).  Whether the
+// peers' pending collectives then return is up to RCCL's transport -- it is not guaranteed intra-node --, so a host program
+// that must survive a rank's failure should run its ranks under a watchdog (torchrun does: a dead rank ends the job).
 // SLAM3D_DENSE_FORCE_COLLECTIVE=1 runs the collective with one rank too (developer knob: exercises RCCL on a single GPU).
 //
 // What is NOT sharded, and why: the target's preprocessing (normals, tile records: ~0.15 ms of a 2.0 ms alignment at
@@ -1576,6 +1588,7 @@ extern "C" int slam3d_icp_dense_run(slam3d_icp_handle *h, slam3d_comm *comm, con
 {
     if (!h || !out) return SLAM3D_E_INVALID;
     if (comm && comm->device != h->p.device) return SLAM3D_E_INVALID;
+    if (comm && !comm->comm) { h->err = "slam3d_icp_dense_run: the communicator was aborted by an earlier failure; create a new one"; return SLAM3D_E_COMM; }
     const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
     const bool collective = comm && (world > 1 || getenv("SLAM3D_DENSE_FORCE_COLLECTIVE"));
     int r0 = 0, r1 = h->p.height;
@@ -1615,7 +1628,7 @@ extern "C" int slam3d_icp_dense_run(slam3d_icp_handle *h, slam3d_comm *comm, con
         if (!rc) rc = slam3d_icp_dense_finish_device(h, d_sums, s, out);
     }
     if (rc < 0 && collective && world > 1 && s3d::rccl().CommAbort && comm->comm) {
-        // this rank is leaving the loop early: without the abort the other ranks would block in their next all-reduce
+        // this rank is leaving the loop early: release its side; the slam3d_comm is dead from here on (see the header comment)
         (void)s3d::rccl().CommAbort(comm->comm);
         comm->comm = nullptr;
         h->err += " (communicator aborted)";

@@ -206,6 +206,7 @@ extern "C" int slam3d_pose_gather_submit(slam3d_comm *c, const slam3d_pose_recor
 {
     if (!c || !local || n_local <= 0) return SLAM3D_E_INVALID;
     if (c->n_pending >= slam3d_comm::NSLOT) return SLAM3D_E_STATE;
+    if (!c->comm) { c->err = "communicator was aborted after a local failure (slam3d_icp_dense_run); create a new one"; return SLAM3D_E_COMM; }
     S3D_COMM_HIPCHK(c, hipSetDevice(c->device));
     const int rc = comm_reserve(c, n_local);
     if (rc) return rc;

@@ -745,3 +745,138 @@ def test_handles_of_different_geometry_side_by_side_and_slot_reuse(gpu_lib):
                 T = np.asarray(h.align(s4, t4)["T"])
                 want = T if want is None else want
                 assert np.array_equal(T, want), n
+
+
+def test_stamping_ring_can_be_resized_between_runs(gpu_lib):
+    """ADVICE r3: the stamp ring (buffer, modulus, rows per run) is baked into the captured launches as kernel arguments;
+    set_stamping(3) -> run -> set_stamping(8) -> run must re-capture instead of replaying a graph that stamps into the freed
+    ring with the old modulus.  Eleven runs through the new ring of eight: every row filled, ordered, results unchanged."""
+    pr, s4, t4 = _pair(1001, 320, 240)
+    iters = 5
+    with capi.IcpHandle(capi.default_params(pr.intr, iterations=iters)) as h:
+        want = h.align(s4, t4)
+        h.set_stamping(3)
+        h.set_clouds_host(0, s4, t4)
+        for _ in range(2):
+            h.run(1); got = h.fetch_results(1)[0]
+        assert np.array_equal(got["T_raw"], want["T_raw"])
+        h.set_stamping(8)                                            # same handle, stamping stays on, another ring
+        for _ in range(11):
+            h.run(1); got = h.fetch_results(1)[0]
+        ring = h.get_stamps().astype(np.int64)
+        assert ring.shape == (8, 2 * iters, 2)
+        nn = ring[:, :iters]
+        assert (nn[:, :, 0] > 0).all() and (nn[:, :, 1] > nn[:, :, 0]).all()          # every run of the ring has all its NN rows
+        assert (ring[1:, 0, 0] > ring[:-1, iters - 1, 1]).all()                       # oldest first
+        assert np.array_equal(got["T_raw"], want["T_raw"]) and got["inliers"] == want["inliers"]
+        h.set_stamping(2)                                            # shrink: again a fresh capture
+        for _ in range(3):
+            h.run(1); got = h.fetch_results(1)[0]
+        assert h.get_stamps().shape == (2, 2 * iters, 2) and np.array_equal(got["T_raw"], want["T_raw"])
+
+
+@pytest.mark.parametrize("seed", [1000, 1001])
+def test_full_640x480_baseline_md_workload(gpu_lib, seed):
+    """BASELINE.md section 4 / SURVEY.md 8(d)'s workload AS SPECIFIED, both parts together: depth noise sigma = 0.0012 z^2
+    AND 8x8-pixel Bernoulli holes at p = 0.25 (the two deviations had only been measured separately).  With iid
+    noise at that level the reference's own planarity rule (0.01 m, 41 of 49, src/planarFeatures.cpp:118-128) keeps a normal on
+    ~1/5 of the targets -- a different problem from the low-noise headline, not a perturbation of it.  640x480, 20
+    iterations, as depth images (projective window search) and as clouds: every iterate, every sum, the last indices and
+    d2 bit-identical to the kd-tree oracle."""
+    pr, s4, t4 = _pair(seed, 640, 480, noise_sigma=0.0012, hole_block=8, hole_prob=0.25)
+    ro = O.icp(s4, t4, O.params(pr.intr, iterations=20, nn_method=1))
+    assert ro["n_tgt"] < 0.35 * ro["n_src"]                       # the workload's signature: few targets keep a normal
+    with capi.IcpHandle(capi.default_params(pr.intr, iterations=20)) as h:
+        for depth, trace in ((True, False), (False, False), (True, True)):
+            h.set_corr_trace(trace)                               # (with the trace the loop is launched directly, without it as a graph)
+            rg = h.align_depth_batch([pr.depth_src], [pr.depth_tgt])[0] if depth else h.align(s4, t4)
+            idx, d2 = h.get_correspondences(0)
+            Tt, St = h.get_trace(0)
+            assert rg["n_src"] == ro["n_src"] and rg["n_tgt"] == ro["n_tgt"]
+            assert np.array_equal(idx, ro["idx"]), f"depth={depth}: {(idx != ro['idx']).sum()} index mismatches"
+            assert np.array_equal(d2.view(np.uint32), ro["d2"].view(np.uint32))
+            assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:20], ro["sums_trace"])
+            assert rg["inliers"] == ro["inliers"] and rg["status"] == ro["status"] == 0
+            if trace:
+                for it in (0, 1, 2, 5, 10, 19):                   # SURVEY.md 8(d): index parity per iteration
+                    want, _, _ = O.nn_once(s4, t4, O.params(pr.intr, nn_method=1), T=ro["T_trace"][it], use_normals=True)
+                    assert np.array_equal(h.get_correspondences_at(it), want), it
+    rot_gt, tr_gt = O.pose_error(pr.T_gt, rg["T"])
+    assert rot_gt < 1e-2 and tr_gt < 3e-2, (rot_gt, tr_gt)       # noise floor of THIS workload: six times the headline's sigma and only the near
+                                                                 # fifth of the target keeps a normal (oracle: 7 mrad / 2.2 cm on seed 1000, 3 mrad / 1 cm on 1001)
+
+
+def test_config5_dense_1280x960_eight_emulated_ranks(gpu_lib):
+    """BASELINE config 5's 8-GPU leg as far as ONE device allows: the 1280x960 pair of seed 2000, 20
+    iterations, source rows sharded over EIGHT ranks = eight handles on this GPU, each searching its row band against the
+    whole target; the per-iteration exchange is the integer sum of the ranks' 29-word partials (what ncclAllReduce(SUM) of
+    int64 computes; here formed on the host).  Every rank ends with the same pose, bit-identical to the UNSHARDED run on
+    the GPU and to the oracle; the ranks' index bands stitched together are the unsharded indices."""
+    from slam3d_gx_amd import shard
+    world, iters = 8, 20
+    pr, s4, t4 = _pair(2000, 1280, 960)
+    ro = O.icp(s4, t4, O.params(pr.intr, iterations=iters, nn_method=1))
+    with capi.IcpHandle(capi.default_params(pr.intr, iterations=iters)) as h1:
+        whole = h1.align(s4, t4)
+        idx_whole = h1.get_correspondences(0)[0]
+    hs = [capi.IcpHandle(capi.default_params(pr.intr, iterations=iters)) for _ in range(world)]
+    try:
+        bands = [shard.dense_row_range(pr.intr.height, world, r) for r in range(world)]
+        assert bands[0][0] == 0 and bands[-1][1] == pr.intr.height and all(a[1] == b[0] for a, b in zip(bands, bands[1:]))
+        for r, h in enumerate(hs):
+            h.set_clouds_host(0, s4, t4)
+            h.dense_set_rows(*bands[r])
+            h.dense_begin(None)
+        total = None
+        for _ in range(iters):
+            parts = [h.dense_partial() for h in hs]
+            total = np.sum(np.stack(parts), axis=0, dtype=np.int64)
+            for h in hs:
+                h.dense_update(total)
+        res = [h.dense_finish(total) for h in hs]
+        idx = [h.get_correspondences(0)[0] for h in hs]
+        n_src = [r["n_src"] for r in res]
+    finally:
+        for h in hs:
+            h.close()
+    for r in res:
+        assert np.array_equal(r["T_raw"], res[0]["T_raw"]) and r["inliers"] == res[0]["inliers"]
+    assert np.array_equal(res[0]["T_raw"], whole["T_raw"]) and res[0]["inliers"] == whole["inliers"]       # == the unsharded GPU run
+    assert np.array_equal(res[0]["T_raw"], ro["T_trace"][-1]) and res[0]["inliers"] == ro["inliers"]       # == the oracle
+    assert sum(n_src) == whole["n_src"] == ro["n_src"]
+    W = pr.intr.width
+    merged = np.full_like(idx_whole, -1)
+    for (r0, r1), ix in zip(bands, idx):
+        merged[r0 * W:r1 * W] = ix[r0 * W:r1 * W]
+        outside = np.ones(ix.size, dtype=bool); outside[r0 * W:r1 * W] = False
+        assert (ix[outside] == -1).all()                          # a rank reports nothing outside its band
+    assert np.array_equal(merged, idx_whole) and np.array_equal(merged, ro["idx"])
+
+
+def test_config4_shape_eight_ranks_of_64_pairs_on_one_device(gpu_lib, tmp_path):
+    """BASELINE config 4's shape: 512 frame pairs of 640x480 (seeds 1000..1511) sharded over EIGHT ranks,
+    64 per rank in one launch sequence, the step's 512 pose records gathered on every rank -- eight processes on this one
+    GPU over gloo (RCCL needs a GPU per rank; everything else is the code the driver's 8-GPU run executes), started the way
+    the driver starts it: a plain `python bench.py --gpus 8 ...`.  The gathered table must be in pair order (rank r holds
+    the contiguous block of seeds 1000 + 64 r ...) and sampled pairs bit-identical to the oracle."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    dump = str(tmp_path / "table.json")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1", "--pairs", "64",
+           "--pairs-per-step", "64", "--pool", "64", "--in-flight", "1", "--no-cpu-baseline", "--no-bruteforce", "--profile-aligns", "1",
+           "--overlap-aligns", "0", "--dist-backend", "gloo", "--one-device", "--dump-table", dump]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=2400, cwd=root, env=env)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["value"] > 0 and d["scaling"] == "weak" and d["survey_8d"]["gpus"] == 8
+    assert d["config"]["gathered_pose_records"] == 512 and d["config"]["pairs_per_launch"] == 64
+    assert d["config"]["gathered_seeds"] == {"first": [1000, 1001], "last": [1510, 1511], "ascending": True}
+    tab = json.load(open(dump))
+    assert tab["seeds"] == list(range(1000, 1512)) and tab["world"] == 8 and tab["pairs_per_rank"] == 64
+    assert all(s == 0 for s in tab["status"]), [i for i, s in enumerate(tab["status"]) if s][:8]
+    for k in (0, 63, 64, 200, 383, 511):                          # both ends of rank blocks and interior pairs
+        pr, s4, t4 = _pair(1000 + k, 640, 480)
+        ro = O.icp(s4, t4, O.params(pr.intr, iterations=20, nn_method=1))
+        assert np.array_equal(np.array(tab["T"][k]).reshape(4, 4), ro["T_trace"][-1]), k
+        assert tab["inliers"][k] == ro["inliers"], k
