@@ -260,7 +260,7 @@ def cpu_baseline_leg(pair, s4, t4, iterations, est, gpu_result, gpu_idx, brute_s
         t0 = time.perf_counter()
         r = O.icp(s4, t4, pth, trace=True)                                     # warm-up: thread team, page faults
         t_warm = time.perf_counter() - t0
-        if ro is None or th == 16:
+        if its == iterations and (ro is None or th == 16):
             ro = r                                                             # (the checker's copy of the result; any thread count gives the same bits)
         times = []
         hopeless = th > 1 and best_t is not None and t_warm > 4.0 * best_t      # an oversubscribed team: one run says it all
@@ -272,6 +272,8 @@ def cpu_baseline_leg(pair, s4, t4, iterations, est, gpu_result, gpu_idx, brute_s
             best_t = min(best_t or 1e30, statistics.median(times))
         curve[th] = {"value": its / statistics.median(times), "iterations": its, "runs": len(times),
                      "spread": (max(times) - min(times)) / statistics.median(times)}
+    if ro is None:
+        ro = O.icp(s4, t4, O.params(pair.intr, estimator=est, iterations=iterations, nn_method=1, threads=0), trace=True)
     best = max((c for c in counts if c > 1), key=lambda c: curve[c]["value"], default=1)
     phases = None
     if not big:      # where one run at the best thread count spends its time (the oracle prints its phase times on request)

@@ -28,8 +28,9 @@
 extern "C" {
 #endif
 
-#define SLAM3D_ICP_ABI_VERSION 4
-#define SLAM3D_ICP_NSUMS 29   /* 21 upper-tri AtA + 6 Atb + count + sum r^2 */
+#define SLAM3D_ICP_ABI_VERSION 5
+#define SLAM3D_ICP_NSUMS 29   /* the sums of the trace: 21 upper-tri AtA + 6 Atb + count + sum r^2, derived from the Gram totals */
+#define SLAM3D_ICP_NRAW  36   /* what the dense mode exchanges: the upper triangle of the 8x8 integer Gram matrix of the quantised row vectors (DESIGN.md spec S4) */
 
 /* return codes: 0 ok; >0 algorithmic (result.T == Identity); <0 usage / runtime errors */
 enum {
@@ -77,6 +78,12 @@ typedef struct slam3d_icp_params {
      *                        outlier-rejection role of solvePnPRansac's inlier subset, src/GraphicEnd.cpp:522-554.    */
     float   max_plane_residual2;
     float   min_normal_cos;
+    /* icp_coarse_iterations (3): the first coarse_iterations iterations of a run -- never its last one -- take only the sources
+     * of every fourth 8x8-pixel tile, (tile_x + 2 tile_y) mod 4 == 0 (DESIGN.md spec S4c).  The reference's per-frame call hands
+     * multiPnP no initial guess (src/GraphicEnd.cpp:168): the first iterations run on a pose that is centimetres off, where a
+     * quarter of the rows yields the same update and the searches are at their widest.  0 = every iteration uses every source. */
+    int32_t coarse_iterations;
+    int32_t _pad0;
 } slam3d_icp_params;
 
 /* a borrowed view of an organized cloud: `data` points at width*height records of
@@ -290,15 +297,15 @@ int slam3d_segment_planes_device(slam3d_icp_handle *h, int32_t B, const void *co
 int slam3d_icp_dense_set_rows(slam3d_icp_handle *h, int32_t row_begin, int32_t row_end);
 /* preprocess slot 0 (normals, compaction) and reset T to T_init */
 int slam3d_icp_dense_begin(slam3d_icp_handle *h, const double *T_init, void *stream);
-/* one NN + accumulate pass over the local rows: 29 partial sums on the host.  The sums are int64 fixed point
- * (unit 2^-32): integer addition is associative, so the all-reduced totals -- and with them the pose -- do not
- * depend on how the rows were sharded. */
-int slam3d_icp_dense_partial(slam3d_icp_handle *h, int64_t sums[SLAM3D_ICP_NSUMS], void *stream);
+/* one NN + accumulate pass over the local rows: the 36 partial Gram totals on the host.  They are exact int64 sums of
+ * products of integer row-vector components: integer addition is associative, so the all-reduced totals -- and with
+ * them the pose -- do not depend on how the rows were sharded. */
+int slam3d_icp_dense_partial(slam3d_icp_handle *h, int64_t sums[SLAM3D_ICP_NRAW], void *stream);
 /* solve with the (all-reduced, integer SUM) sums and update T on every rank identically */
-int slam3d_icp_dense_update(slam3d_icp_handle *h, const int64_t sums[SLAM3D_ICP_NSUMS], void *stream);
-int slam3d_icp_dense_finish(slam3d_icp_handle *h, const int64_t last_sums[SLAM3D_ICP_NSUMS],
+int slam3d_icp_dense_update(slam3d_icp_handle *h, const int64_t sums[SLAM3D_ICP_NRAW], void *stream);
+int slam3d_icp_dense_finish(slam3d_icp_handle *h, const int64_t last_sums[SLAM3D_ICP_NRAW],
                             slam3d_icp_result *out);
-/* the same three with the 29 sums in a caller-owned DEVICE buffer: partial writes it, the caller all-reduces it
+/* the same three with the 36 totals in a caller-owned DEVICE buffer: partial writes it, the caller all-reduces it
  * in place ON THE SAME STREAM, update reads it.  No host synchronisation until finish.  `stream` must be the stream
  * the caller's collective is enqueued on: with more than one rank pass it explicitly -- NULL means the handle's own
  * non-blocking stream, which nothing outside the library is ordered with (slam3d_icp_dense_run does all of this

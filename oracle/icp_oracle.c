@@ -39,6 +39,7 @@ void orc_default_params(orc_params *p)
     p->error_threshold = 1.0;          /* parameters.yaml:39 */
     p->nn_method = ORC_NN_KDTREE;
     p->threads = 0;
+    p->coarse_iterations = 3;
 }
 
 static int n_threads(const orc_params *p)
@@ -116,10 +117,13 @@ void orc_eig3(const double A[6], double evals[3], double V[9])
  * the adjugate.  adj(C) has the eigenvectors of C with eigenvalues l1*l2, l0*l2, l0*l1, so its DOMINANT eigenvector is C's
  * smallest one, and repeated squaring raises the dominance ratio l1/l0 to the power 2^K:
  *   M = adj(C) (cofactors, each "product - product");
- *   K = 5 times:  tr = (M00 + M11) + M22, must be a positive normal number; M *= 2^-ilogb(tr) (exact);  M = M * M;
+ *   K = 7 times (round 3: 5):  tr = (M00 + M11) + M22, must be a positive normal number; M *= 2^-ilogb(tr) (exact);  M = M * M;
+ *   dominance (round 4): ||M||_F^2 >= (1 - 2^-40) tr(M)^2, else no direction (l1 / l0 below ~1.25);
  *   column j of M with the largest diagonal entry (ties: lowest j), normalised.
  * Only +, -, *, one sqrt and three divisions, every one an individually rounded IEEE operation: bit-identical on the CPU and
- * in k_normals.  Error against the exact eigenvector: ~1e-15 + (l0/l1)^32 -- a planar patch has l1/l0 of 10 .. 1000.
+ * in k_normals.  Error against the exact eigenvector: ~1e-15 + (l0/l1)^128 <= ~1e-12 for every window that passes the
+ * dominance test -- so numpy.linalg.eigh reproduces the FLOAT normal of practically every pixel bit for bit, which is what
+ * lets the scipy-only goldens run with their own normals (tests/golden/make_independent_golden.py).
  * (Rounds 1-2 ran 8 sweeps of cyclic Jacobi here, 24 rotations with three divisions and two square roots each: 70 % of
  * k_normals' time.  orc_eig3 stays for the plane fits, which need all three eigenpairs of a handful of matrices.) */
 #define ORC_EVEC_SQUARINGS 7
@@ -554,14 +558,22 @@ static inline void xform_pt(const float Rf[9], const float tf[3], float x, float
 }
 
 /* corr[i] = compact target position or -1, d2c[i] = canonical d2 or +inf */
+/* spec S4c: does the source pixel take part in a coarse iteration?  Every fourth 8x8-pixel tile, staggered by rows. */
+static inline int coarse_active(int pix, int W)
+{
+    const int v = pix / W, u = pix - v * W;
+    return (((u >> 3) + 2 * (v >> 3)) & 3) == 0;
+}
+
 static void nn_pass(const clist *src, const clist *tgt, const kdtree *kd, const double *T,
-                    float gate2, int method, int nt, int *corr, float *d2c)
+                    float gate2, int method, int nt, int *corr, float *d2c, int coarse_W /* > 0: a coarse iteration of an image this wide */)
 {
     float Rf[9], tf[3];
     transform_f(T, Rf, tf);
     (void)nt;
 #pragma omp parallel for schedule(dynamic, 256) num_threads(nt)
     for (int i = 0; i < src->n; ++i) {
+        if (coarse_W > 0 && !coarse_active(src->orig[i], coarse_W)) { corr[i] = -1; d2c[i] = INFINITY; continue; }
         float p[3];
         xform_pt(Rf, tf, src->x[i], src->y[i], src->z[i], p);
         float best = INFINITY; int bj = -1;
@@ -618,70 +630,108 @@ static void apply_gates(const clist *src, const clist *tgt, const double *T, con
     }
 }
 
-/* ------------------------------------------------ S4 rows + tree reduction */
-static void row_sums(const clist *src, const clist *tgt, const float Rf[9], const float tf[3],
-                     int estimator, int i, int j, double *s /*29*/)
+/* ------------------------------------------------ S4 rows: quantised row vectors and their Gram matrix (round 4)
+ * Every correspondence contributes an 8-component INTEGER vector V, and the iteration's totals are the 36 upper-triangle
+ * entries of the Gram matrix G = sum V V^T -- exact int64 sums, so neither the order of the summands nor their grouping
+ * (one GPU wave per tile on the fp64 matrix cores, one atomic per block, any number of GPUs) changes a bit.
+ *   point-to-plane   a = p' x n, b = n . (q - p')   (double, every operation individually rounded, in the order written)
+ *                    V = ( rint(a 2^16) [3], rint(n 2^20) [3], rint(b 2^EB), 1 ),  EB = 20 - k with gate = m 2^k, 0.5 <= m < 1
+ *                    (|b| <= gate < 2^k, so |V6| <= 2^20; gate 0.10 m: EB = 23, 0.12 um)
+ *   svd (Kabsch)     V = ( rint(p' 2^16) [3], rint(q 2^16) [3], 0, 1 )
+ * rint = round to nearest, ties to even.  The 29 doubles of the trace / the solve are DERIVED from G (orc_derive_sums):
+ *   point-to-plane   A^T A (r, c) = G[r][c] 2^-(e_r + e_c), e = (16,16,16,20,20,20);  A^T b (r) = G[r][6] 2^-(e_r + EB);
+ *                    count = G[7][7];  sum b^2 = G[6][6] 2^-2EB
+ *   svd              sum p' = G[i][7] 2^-16, sum q = G[3+i][7] 2^-16, sum p' q^T (r, c) = G[r][3+c] 2^-32, count = G[7][7],
+ *                    sum |q - p'|^2 = (G00 + G11 + G22 + G33 + G44 + G55 - 2 (G03 + G14 + G25)) 2^-32 (integer arithmetic)
+ * each as (double)integer times a power of two.  (Rounds 1-3 rounded the 29 PRODUCTS to 2^-32 instead; the factors' form
+ * is what lets a wave's 64 rows go through sixteen v_mfma_f64_16x16x4 instead of 29 products, 29 roundings and 8 packed wave
+ * reductions.)  Ranges: |V_i V_j| <= (r 2^16)^2, r = the farthest valid point; N r^2 < 2^28 (checked where the geometry is
+ * declared) keeps every total below 2^60. */
+int orc_b_exponent(double max_corr_dist)
 {
-    for (int k = 0; k < ORC_NSUMS; ++k) s[k] = 0.0;
-    if (j < 0) return;
+    int k = 0;
+    (void)frexp(max_corr_dist, &k);            /* max_corr_dist = m 2^k, 0.5 <= m < 1 */
+    return 20 - k;
+}
+
+static inline int tri36(int i, int j) { return i * 8 - (i * (i - 1)) / 2 + (j - i); }   /* (i <= j) of the 8x8 upper triangle, row-major */
+
+static int row_vector(const clist *src, const clist *tgt, const float Rf[9], const float tf[3],
+                      int estimator, int eb, int i, int j, int64_t v[8])
+{
+    if (j < 0) return 0;
     float pf[3];
     xform_pt(Rf, tf, src->x[i], src->y[i], src->z[i], pf);
     const double px = pf[0], py = pf[1], pz = pf[2];
     const double qx = tgt->x[j], qy = tgt->y[j], qz = tgt->z[j];
-    const double dx = qx - px, dy = qy - py, dz = qz - pz;
     if (estimator == ORC_EST_POINT2PLANE) {
+        const double dx = qx - px, dy = qy - py, dz = qz - pz;
         const double nx = tgt->nx[j], ny = tgt->ny[j], nz = tgt->nz[j];
-        double a[6];
-        a[0] = py * nz - pz * ny; a[1] = pz * nx - px * nz; a[2] = px * ny - py * nx;
-        a[3] = nx; a[4] = ny; a[5] = nz;
+        const double a0 = py * nz - pz * ny, a1 = pz * nx - px * nz, a2 = px * ny - py * nx;
         const double b = (nx * dx + ny * dy) + nz * dz;
-        int k = 0;
-        for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) s[k++] = a[r] * a[c];
-        for (int r = 0; r < 6; ++r) s[21 + r] = a[r] * b;
-        s[27] = 1.0; s[28] = b * b;
+        v[0] = llrint(a0 * 65536.0); v[1] = llrint(a1 * 65536.0); v[2] = llrint(a2 * 65536.0);
+        v[3] = llrint(nx * 1048576.0); v[4] = llrint(ny * 1048576.0); v[5] = llrint(nz * 1048576.0);
+        v[6] = llrint(ldexp(b, eb));
     } else {
-        s[0] = px; s[1] = py; s[2] = pz; s[3] = qx; s[4] = qy; s[5] = qz;
-        s[6] = px * qx; s[7] = px * qy; s[8] = px * qz;
-        s[9] = py * qx; s[10] = py * qy; s[11] = py * qz;
-        s[12] = pz * qx; s[13] = pz * qy; s[14] = pz * qz;
-        s[27] = 1.0; s[28] = (dx * dx + dy * dy) + dz * dz;
+        v[0] = llrint(px * 65536.0); v[1] = llrint(py * 65536.0); v[2] = llrint(pz * 65536.0);
+        v[3] = llrint(qx * 65536.0); v[4] = llrint(qy * 65536.0); v[5] = llrint(qz * 65536.0);
+        v[6] = 0;
+    }
+    v[7] = 1;
+    return 1;
+}
+
+void orc_derive_sums(const int64_t G[ORC_NRAW], int estimator, int eb, double s[ORC_NSUMS])
+{
+    for (int k = 0; k < ORC_NSUMS; ++k) s[k] = 0.0;
+    if (estimator == ORC_EST_POINT2PLANE) {
+        int k = 0;
+        for (int r = 0; r < 6; ++r)
+            for (int c = r; c < 6; ++c) s[k++] = ldexp((double)G[tri36(r, c)], -((r < 3 ? 16 : 20) + (c < 3 ? 16 : 20)));
+        for (int r = 0; r < 6; ++r) s[21 + r] = ldexp((double)G[tri36(r, 6)], -((r < 3 ? 16 : 20) + eb));
+        s[27] = (double)G[tri36(7, 7)];
+        s[28] = ldexp((double)G[tri36(6, 6)], -2 * eb);
+    } else {
+        for (int i = 0; i < 3; ++i) { s[i] = ldexp((double)G[tri36(i, 7)], -16); s[3 + i] = ldexp((double)G[tri36(3 + i, 7)], -16); }
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) s[6 + 3 * r + c] = ldexp((double)G[tri36(r, 3 + c)], -32);
+        s[27] = (double)G[tri36(7, 7)];
+        const int64_t d2 = (G[tri36(0, 0)] + G[tri36(1, 1)] + G[tri36(2, 2)]) + (G[tri36(3, 3)] + G[tri36(4, 4)] + G[tri36(5, 5)])
+                         - 2 * (G[tri36(0, 3)] + G[tri36(1, 4)] + G[tri36(2, 5)]);
+        s[28] = ldexp((double)d2, -32);
     }
 }
 
-/* Summation (spec S4): every slot's 29 products are formed in double (row_sums), scaled by 2^32 and rounded to
- * the nearest integer (ties to even); the totals are the exact int64 sums of those integers, converted back by
- * (double)Q / 2^32.  Integer addition is associative, so the totals do not depend on the order or grouping of the
- * summands: one GPU wave per tile, one atomic per block, any number of GPUs (dense mode) -- the same bits.
- * Range: |term| <= ~100 (|p x n|^2 at 10 m), 1.2e6 slots at 1280x960 -> |Q| < 2^59. */
-#define ORC_FIX 4294967296.0
-void orc_accumulate_fixed(const double s[ORC_NSUMS], int64_t Q[ORC_NSUMS])
+/* G += V V^T (upper triangle) */
+void orc_accumulate_gram(const int64_t v[8], int64_t G[ORC_NRAW])
 {
-    for (int k = 0; k < ORC_NSUMS; ++k) Q[k] += llrint(s[k] * ORC_FIX);
+    int k = 0;
+    for (int i = 0; i < 8; ++i)
+        for (int j = i; j < 8; ++j) G[k++] += v[i] * v[j];
 }
 
-static void accumulate(const clist *src, const clist *tgt, const double *T, int estimator,
-                       const int *corr, int W, int H, int nt, double *total /*29*/)
+static void accumulate(const clist *src, const clist *tgt, const double *T, int estimator, int eb,
+                       const int *corr, int W, int H, int nt, double *total /*29*/, int64_t *raw /* 36 or NULL */)
 {
     float Rf[9], tf[3];
     transform_f(T, Rf, tf);
     (void)W; (void)H; (void)nt;
-    int64_t Q[ORC_NSUMS];
-    for (int k = 0; k < ORC_NSUMS; ++k) Q[k] = 0;
+    int64_t G[ORC_NRAW];
+    for (int k = 0; k < ORC_NRAW; ++k) G[k] = 0;
 #pragma omp parallel num_threads(nt)
     {
-        int64_t q[ORC_NSUMS];
-        double s[ORC_NSUMS];
-        for (int k = 0; k < ORC_NSUMS; ++k) q[k] = 0;
+        int64_t g[ORC_NRAW], v[8];
+        for (int k = 0; k < ORC_NRAW; ++k) g[k] = 0;
 #pragma omp for schedule(static)
         for (int i = 0; i < src->n; ++i) {
             if (corr[i] < 0) continue;
-            row_sums(src, tgt, Rf, tf, estimator, i, corr[i], s);
-            orc_accumulate_fixed(s, q);
+            if (row_vector(src, tgt, Rf, tf, estimator, eb, i, corr[i], v)) orc_accumulate_gram(v, g);
         }
 #pragma omp critical
-        for (int k = 0; k < ORC_NSUMS; ++k) Q[k] += q[k];
+        for (int k = 0; k < ORC_NRAW; ++k) G[k] += g[k];
     }
-    for (int k = 0; k < ORC_NSUMS; ++k) total[k] = (double)Q[k] / ORC_FIX;
+    orc_derive_sums(G, estimator, eb, total);
+    if (raw) memcpy(raw, G, sizeof(G));
 }
 
 /* ------------------------------------------------------------- S5 update */
@@ -793,10 +843,11 @@ int orc_icp(const float *src4, const float *tgt4, const orc_params *p, const dou
     const float g2 = gate2_of(p);
     if (T_trace) memcpy(T_trace, T, sizeof(T));
     for (int it = 0; it < p->iterations; ++it) {
-        nn_pass(&src, &tgt, &kd, T, g2, p->nn_method, nt, corr, d2c);
+        const int coarse = it < p->coarse_iterations && it < p->iterations - 1;     /* spec S4c: never the last iteration */
+        nn_pass(&src, &tgt, &kd, T, g2, p->nn_method, nt, corr, d2c, coarse ? p->width : 0);
         ORC_PHASE(3);
         apply_gates(&src, &tgt, T, p, snrm4, nt, corr, d2c);
-        accumulate(&src, &tgt, T, p->estimator, corr, p->width, p->height, nt, sums);
+        accumulate(&src, &tgt, T, p->estimator, orc_b_exponent(p->max_corr_dist), corr, p->width, p->height, nt, sums, NULL);
         ORC_PHASE(4);
         have_sums = 1;
         if (sums_trace) memcpy(sums_trace + (size_t)it * ORC_NSUMS, sums, sizeof(sums));
@@ -831,6 +882,13 @@ int orc_icp(const float *src4, const float *tgt4, const orc_params *p, const dou
 int orc_nn_once(const float *src4, const float *tgt4, const orc_params *p, const double *T,
                 int use_normals, int32_t *idx_out, float *d2_out)
 {
+    return orc_nn_once_ex(src4, tgt4, p, T, use_normals, 0, idx_out, d2_out);
+}
+
+/* the same with the source subset of a coarse iteration (spec S4c) when `coarse` is set */
+int orc_nn_once_ex(const float *src4, const float *tgt4, const orc_params *p, const double *T,
+                   int use_normals, int coarse, int32_t *idx_out, float *d2_out)
+{
     const int N = p->width * p->height;
     const float zmax = (float)p->z_filter;
     float *nrm4 = NULL;
@@ -844,7 +902,7 @@ int orc_nn_once(const float *src4, const float *tgt4, const orc_params *p, const
     float *d2c = malloc(sizeof(float) * (size_t)(src.n + 1));
     double Tid[16];
     for (int k = 0; k < 16; ++k) Tid[k] = (k % 5 == 0) ? 1.0 : 0.0;
-    nn_pass(&src, &tgt, &kd, T ? T : Tid, gate2_of(p), p->nn_method, n_threads(p), corr, d2c);
+    nn_pass(&src, &tgt, &kd, T ? T : Tid, gate2_of(p), p->nn_method, n_threads(p), corr, d2c, coarse ? p->width : 0);
     for (int i = 0; i < N; ++i) { if (idx_out) idx_out[i] = -1; if (d2_out) d2_out[i] = INFINITY; }
     for (int i = 0; i < src.n; ++i) {
         if (idx_out) idx_out[src.orig[i]] = corr[i] >= 0 ? tgt.orig[corr[i]] : -1;

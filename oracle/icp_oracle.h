@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define ORC_NSUMS 29          /* 21 upper-tri AtA + 6 Atb + count + sum r^2   */
+#define ORC_NSUMS 29          /* 21 upper-tri AtA + 6 Atb + count + sum r^2 (derived from the Gram matrix)  */
+#define ORC_NRAW  36          /* upper triangle of the 8x8 integer Gram matrix of the quantised row vectors */
 #define ORC_CHUNK 256         /* (historic) launch block of four tiles            */
 
 enum { ORC_EST_POINT2PLANE = 0, ORC_EST_SVD = 1 };
@@ -66,6 +67,11 @@ typedef struct orc_params {
      *     (the outlier-rejection role of solvePnPRansac's inlier subset, src/GraphicEnd.cpp:522-554).           */
     double max_plane_residual2;
     double min_normal_cos;
+    /* spec S4c (round 4): the first coarse_iterations iterations -- never the last one of a run -- take only the sources of
+     * every fourth 8x8-pixel tile, (tile_x + 2 tile_y) mod 4 == 0: while the pose still moves by centimetres a quarter of
+     * the rows gives the same update, and those are the iterations whose searches are widest.  0 = every iteration uses
+     * every source.  Default 3. */
+    int    coarse_iterations;
 } orc_params;
 
 typedef struct orc_result {
@@ -97,8 +103,15 @@ int orc_icp(const float *src4, const float *tgt4, const orc_params *p,
 /* one NN pass only (for index-parity tests / CPU baseline timing):
  * T (row-major 4x4 double) applied to src, search in tgt (point validity only when
  * use_normals==0, else tgt normal validity too). */
+/* spec S4 (round 4): exponent of the residual component, the Gram accumulation of one row vector, and the 29 derived sums */
+int  orc_b_exponent(double max_corr_dist);
+void orc_accumulate_gram(const int64_t v[8], int64_t G[ORC_NRAW]);
+void orc_derive_sums(const int64_t G[ORC_NRAW], int estimator, int eb, double s[ORC_NSUMS]);
+
 int orc_nn_once(const float *src4, const float *tgt4, const orc_params *p,
                 const double *T, int use_normals, int32_t *idx_out, float *d2_out);
+int orc_nn_once_ex(const float *src4, const float *tgt4, const orc_params *p, const double *T,
+                   int use_normals, int coarse, int32_t *idx_out, float *d2_out);
 
 /* per-plane fit (row a6): labels[N] in {-1,0..nplanes-1}; out planes[nplanes*4]=(a,b,c,d), d>=0
  * counts[nplanes] */

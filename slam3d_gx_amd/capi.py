@@ -13,7 +13,8 @@ import numpy as np
 
 from . import build as _build
 
-NSUMS = 29
+NSUMS = 29      # the derived sums of the trace
+NRAW = 36       # the integer Gram totals the dense mode exchanges (SLAM3D_ICP_NRAW)
 EST_POINT2PLANE, EST_SVD = 0, 1
 NN_AUTO, NN_BRUTE_VALU, NN_BRUTE_MFMA, NN_TILES = 0, 1, 2, 3
 
@@ -49,6 +50,7 @@ class Params(C.Structure):
         ("min_inliers", C.c_int32), ("error_threshold", C.c_double),
         ("max_batch", C.c_int32), ("device", C.c_int32), ("nn_mode", C.c_int32), ("extra_frames", C.c_int32),
         ("max_plane_residual2", C.c_float), ("min_normal_cos", C.c_float),
+        ("coarse_iterations", C.c_int32), ("_pad0", C.c_int32),
     ]
 
 
@@ -465,12 +467,12 @@ class IcpHandle:
         self._check(self.lib.slam3d_icp_dense_begin(self._h, _vp(Ti), C.c_void_p(stream)), False)
 
     def dense_partial(self, stream: int = 0) -> np.ndarray:
-        s = np.zeros(NSUMS, dtype=np.int64)          # fixed point, unit 2^-32: integer sums are order-free
+        s = np.zeros(NRAW, dtype=np.int64)           # exact integer Gram totals: order-free
         self._check(self.lib.slam3d_icp_dense_partial(self._h, _vp(s), C.c_void_p(stream)), False)
         return s
 
     def dense_update(self, sums: np.ndarray, stream: int = 0):
-        s = np.ascontiguousarray(sums, dtype=np.int64).reshape(NSUMS)
+        s = np.ascontiguousarray(sums, dtype=np.int64).reshape(NRAW)
         self._check(self.lib.slam3d_icp_dense_update(self._h, _vp(s), C.c_void_p(stream)), False)
 
     def dense_partial_device(self, d_sums: int, stream: int = 0):
@@ -492,7 +494,7 @@ class IcpHandle:
         return out.as_dict()
 
     def dense_finish(self, last_sums: np.ndarray) -> dict:
-        s = np.ascontiguousarray(last_sums, dtype=np.int64).reshape(NSUMS)
+        s = np.ascontiguousarray(last_sums, dtype=np.int64).reshape(NRAW)
         out = Result()
         self._check(self.lib.slam3d_icp_dense_finish(self._h, _vp(s), C.byref(out)), False)
         return out.as_dict()

@@ -151,6 +151,7 @@ extern "C" void slam3d_icp_default_params(slam3d_icp_params *p)
     p->max_batch = 1; p->device = 0; p->nn_mode = SLAM3D_NN_AUTO;
     p->extra_frames = 0;
     p->max_plane_residual2 = 0.0f; p->min_normal_cos = 0.0f;      // optional gates off
+    p->coarse_iterations = 3;                                      // spec S4c
 }
 
 extern "C" const char *slam3d_strerror(int code)
@@ -229,7 +230,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
 {
     if (!p || !out) return SLAM3D_E_INVALID;
     *out = nullptr;
-    if (p->width <= 0 || p->height <= 0 || p->max_batch <= 0 || p->iterations < 0 || p->extra_frames < 0) return SLAM3D_E_INVALID;
+    if (p->width <= 0 || p->height <= 0 || p->max_batch <= 0 || p->iterations < 0 || p->extra_frames < 0 || p->coarse_iterations < 0) return SLAM3D_E_INVALID;
     if (p->normal_window < 1 || (p->normal_window & 1) == 0 || p->normal_window / 2 > NRM_RMAX) return SLAM3D_E_INVALID;
     if (p->estimator != SLAM3D_EST_POINT2PLANE && p->estimator != SLAM3D_EST_SVD) return SLAM3D_E_INVALID;
     if (p->nn_mode < SLAM3D_NN_AUTO || p->nn_mode > SLAM3D_NN_TILES) return SLAM3D_E_INVALID;
@@ -256,6 +257,12 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     g.zmax = (float)p->z_filter;
     g.win_r = p->normal_window / 2; g.min_in = p->normal_min_inliers; g.in_dist = p->normal_inlier_dist;
     g.gate2 = (float)(p->max_corr_dist * p->max_corr_dist);
+    {   // spec S4: the residual component of a row vector is rint(b 2^eb), eb = 20 - k with max_corr_dist = m 2^k, 0.5 <= m < 1
+        int k = 0;
+        (void)frexp(p->max_corr_dist, &k);
+        g.eb = 20 - k;
+        g.b_scale = ldexp(1.0, g.eb);
+    }
     {   // projective window search: the constant of its radius bound, from the image corners' rays
         const double a0 = fabs((0.0 - p->cx) / p->fx), a1 = fabs(((double)p->width - 1.0 - p->cx) / p->fx);
         const double b0 = fabs((0.0 - p->cy) / p->fy), b1 = fabs(((double)p->height - 1.0 - p->cy) / p->fy);
@@ -275,6 +282,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     tg.ncoarse = tg.ncx * tg.ncy;
     tg.mag_ncx = (unsigned int)((0x100000000ull + tg.ncx - 1) / tg.ncx);
     tg.mag_W = (unsigned int)((0x100000000ull + p->width - 1) / p->width);
+    tg.mag_ntx = (unsigned int)((0x100000000ull + tg.ntx - 1) / tg.ntx);
     tg.nchunks = (tg.ntiles + TILES_PER_CHUNK - 1) / TILES_PER_CHUNK;
     tg.nslots = tg.nchunks * CHUNK;
     const size_t BN = (size_t)h->maxB * h->N;
@@ -328,14 +336,14 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     if (getenv("SLAM3D_HEAD_SOLVE")) h->head_solve = atoi(getenv("SLAM3D_HEAD_SOLVE"));
     if (getenv("SLAM3D_CERT")) h->cert_on = atoi(getenv("SLAM3D_CERT")) != 0;
     A(dalloc(h->slot_rec, (size_t)h->maxB * tg.nslots)); A(dalloc(h->tile_cum, (size_t)h->maxB * tg.ntiles));
-    A(dalloc(h->sums, (size_t)h->maxB * NSUMS)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
+    A(dalloc(h->sums, (size_t)h->maxB * NRAW)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
     A(dalloc(h->trace_T, (size_t)h->maxB * (iters + 1) * 16)); A(dalloc(h->trace_S, (size_t)h->maxB * iters * NSUMS));
     A(dalloc(h->d_pairs, (size_t)h->maxB));
     A(dalloc(h->d_depth, (size_t)h->N)); A(dalloc(h->d_idx, (size_t)h->N)); A(dalloc(h->d_d2, (size_t)h->N));
     A(dalloc(h->d_scratch4, (size_t)h->N));
     A(hipHostMalloc((void **)&h->pin_res, sizeof(double) * RES_REC * h->maxB, hipHostMallocMapped));
     A(hipHostGetDevicePointer((void **)&h->d_res, h->pin_res, 0));
-    A(hipHostMalloc((void **)&h->pin_out, sizeof(double) * (16 + NSUMS) * h->maxB, hipHostMallocDefault));
+    A(hipHostMalloc((void **)&h->pin_out, sizeof(double) * (16 + NRAW) * h->maxB, hipHostMallocDefault));
     A(hipHostMalloc((void **)&h->pin_int, sizeof(int) * 5 * h->maxB, hipHostMallocDefault));
     h->ev.resize(3 + 2 * (size_t)iters);
     for (auto &evx : h->ev) A(hipEventCreate(&evx));
@@ -681,6 +689,10 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
     const TileGrid &tg = h->tg;
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
     bool head = false;           // this iteration's solve runs at the head of the NEXT NN launch (icp_kernels.hpp)
+    // spec S4c: the first n_coarse iterations of a run -- never its last one -- search only the sources of every fourth tile
+    const int run_it = do_solve ? it : h->dense_it;       // (the three-step dense loop passes it = 0 and counts in dense_it)
+    const int n_coarse = std::max(0, std::min(h->p.coarse_iterations, iters - 1));
+    const int cmode = run_it < n_coarse ? 1 : ((n_coarse > 0 && run_it == n_coarse) ? 2 : 0);
     if (e0) HIPCHK(h, hipEventRecord(e0, s));
     if (nn_mode_of(h) == SLAM3D_NN_TILES) {
         // few pairs: cooperative blocks (latency bound); from 8 pairs per launch: every wave on its
@@ -694,7 +706,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         auto launch = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(gx, B), dim3(64 * NN_WAVES), 0, s, h->d_pairs, h->nn_slot, perm, write_out,
                                do_solve ? it : (first ? 0 : 1), stamp_ring_of(h, do_solve != 0), it,
-                               head ? h->head_solve : 0, (h->cert_on && do_solve) ? 1 : 0);
+                               head ? h->head_solve : 0, (h->cert_on && do_solve) ? 1 : 0, cmode);
         };
         // (+ two with the optional S4g gates compiled in: the production instances carry none of that code)
         const bool gated = h->p.estimator == SLAM3D_EST_POINT2PLANE && (h->g.resid2 > 0.0f || h->g.min_ncos > 0.0f);
@@ -705,7 +717,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         // pairs).  Cooperative build: never -- on a stream of DISTINCT pairs the interleaved default ownership is as good
         // as the measured-cost deal and the 12 us of k_balance are saved: +4 % pipelined, +11 % at 1280x960 (round 1
         // measured the deal on one pair repeated, where the previous run's map was already this pair's).
-        if (dense && do_solve && it == 1)
+        if (dense && do_solve && it == std::min(n_coarse + 1, iters - 1))       // (the costs of a launch in which every tile took part)
             hipLaunchKernelGGL(k_balance, dim3(B), dim3(1024), 0, s, h->cost, perm, tg, gx);
         if (e1) HIPCHK(h, hipEventRecord(e1, s));
     } else {
@@ -725,7 +737,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         }
         if (e1) HIPCHK(h, hipEventRecord(e1, s));
         hipLaunchKernelGGL(k_accumulate, dim3(tg.nchunks, B), dim3(CHUNK), 0, s, h->d_pairs, h->Tcur, h->best,
-                           h->corr, h->cd2, h->prevq, h->acc, h->g, tg, h->nsets);
+                           h->corr, h->cd2, h->prevq, h->acc, h->g, tg, h->nsets, cmode);
     }
     if (h->want_corr_trace && do_solve)          // this iteration's slot-order indices (index parity per iteration)
         HIPCHK(h, hipMemcpyAsync(h->corr_trace + (size_t)it * h->maxB * tg.nslots, h->corr, sizeof(int) * (size_t)B * tg.nslots,
@@ -746,12 +758,12 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         hipLaunchKernelGGL(k_solve_acc<0>, dim3(B), dim3(64), 0, s, h->acc, raw_out, h->Tcur, h->trace_T, h->trace_S, h->flags, h->d_pairs,
                            do_solve ? h->d_res : nullptr, it, iters, do_solve,
                            stamp_ring_of(h, do_solve != 0), iters + it,
-                           h->nsets, head ? it : 0, head ? 1 : 0, (counted_run && it == iters - 1) ? 1 : 0);
+                           h->nsets, head ? it : 0, head ? 1 : 0, (counted_run && it == iters - 1) ? 1 : 0, h->g.eb);
     else
         hipLaunchKernelGGL(k_solve_acc<1>, dim3(B), dim3(64), 0, s, h->acc, raw_out, h->Tcur, h->trace_T, h->trace_S, h->flags, h->d_pairs,
                            do_solve ? h->d_res : nullptr, it, iters, do_solve,
                            stamp_ring_of(h, do_solve != 0), iters + it,
-                           h->nsets, 0, 0, (counted_run && it == iters - 1) ? 1 : 0);
+                           h->nsets, 0, 0, (counted_run && it == iters - 1) ? 1 : 0, h->g.eb);
     HIPCHK(h, hipGetLastError());
     return SLAM3D_OK;
 }
@@ -1470,7 +1482,7 @@ extern "C" int slam3d_icp_dense_begin(slam3d_icp_handle *h, const double *T_init
     return SLAM3D_OK;
 }
 
-extern "C" int slam3d_icp_dense_partial(slam3d_icp_handle *h, int64_t sums[SLAM3D_ICP_NSUMS], void *stream)
+extern "C" int slam3d_icp_dense_partial(slam3d_icp_handle *h, int64_t sums[SLAM3D_ICP_NRAW], void *stream)
 {
     if (!h || !sums) return SLAM3D_E_INVALID;
     if (!h->ran) return SLAM3D_E_STATE;
@@ -1478,23 +1490,23 @@ extern "C" int slam3d_icp_dense_partial(slam3d_icp_handle *h, int64_t sums[SLAM3
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
     const int rc = enqueue_iteration(h, 1, s, nullptr, nullptr, 0, 0, h->sums, 0, h->dense_it == 0);
     if (rc) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->pin_out, h->sums, sizeof(int64_t) * NSUMS, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(h->pin_out, h->sums, sizeof(int64_t) * NRAW, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
-    memcpy(sums, h->pin_out, sizeof(int64_t) * NSUMS);
+    memcpy(sums, h->pin_out, sizeof(int64_t) * NRAW);
     return SLAM3D_OK;
 }
 
-extern "C" int slam3d_icp_dense_update(slam3d_icp_handle *h, const int64_t sums[SLAM3D_ICP_NSUMS], void *stream)
+extern "C" int slam3d_icp_dense_update(slam3d_icp_handle *h, const int64_t sums[SLAM3D_ICP_NRAW], void *stream)
 {
     if (!h || !sums) return SLAM3D_E_INVALID;
     if (!h->ran || h->dense_it >= (h->p.iterations > 0 ? h->p.iterations : 1)) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
-    memcpy(h->pin_out, sums, sizeof(int64_t) * NSUMS);          // pin_out holds (16+29)*maxB 8-byte words
-    HIPCHK(h, hipMemcpyAsync(h->sums, h->pin_out, sizeof(int64_t) * NSUMS, hipMemcpyHostToDevice, s));
+    memcpy(h->pin_out, sums, sizeof(int64_t) * NRAW);           // pin_out holds (16+36)*maxB 8-byte words
+    HIPCHK(h, hipMemcpyAsync(h->sums, h->pin_out, sizeof(int64_t) * NRAW, hipMemcpyHostToDevice, s));
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, s, h->sums, h->Tcur, h->trace_T, h->trace_S, h->flags, 1, h->dense_it,
-                       iters, h->p.estimator);
+                       iters, h->p.estimator, h->g.eb);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(s));   // pin_out is reused by the next call
     h->dense_it++;
@@ -1524,7 +1536,7 @@ extern "C" int slam3d_icp_dense_update_device(slam3d_icp_handle *h, const int64_
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, s, reinterpret_cast<const long long *>(d_sums), h->Tcur, h->trace_T, h->trace_S, h->flags, 1, h->dense_it,
-                       iters, h->p.estimator);
+                       iters, h->p.estimator, h->g.eb);
     HIPCHK(h, hipGetLastError());
     h->dense_it++;
     return SLAM3D_OK;
@@ -1539,20 +1551,20 @@ extern "C" int slam3d_icp_dense_finish_device(slam3d_icp_handle *h, const int64_
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
     double *ps = h->pin_out + 16;
     HIPCHK(h, hipMemcpyAsync(h->pin_out, h->Tcur, sizeof(double) * 16, hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipMemcpyAsync(ps, d_last_sums, sizeof(int64_t) * NSUMS, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(ps, d_last_sums, sizeof(int64_t) * NRAW, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipEventRecord(h->ev[2], s));
     HIPCHK(h, hipMemcpyAsync(h->pin_int, h->f_counts + (size_t)h->pair_src[0] * 4, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(h->pin_int + 1, h->f_counts + (size_t)h->pair_tgt[0] * 4 + 1, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(h->pin_int + 4, h->flags, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     double ls[NSUMS];
-    for (int k = 0; k < NSUMS; ++k) ls[k] = (double)reinterpret_cast<const int64_t *>(ps)[k] / FIX_SCALE;
+    for (int k = 0; k < NSUMS; ++k) ls[k] = derive_sum(h->p.estimator, h->g.eb, k, reinterpret_cast<const long long *>(ps));
     finish_result(h->p, h->pin_out, ls, h->pin_int[4], h->pin_int[0], h->pin_int[1], out);
     out->iterations = h->dense_it;
     return SLAM3D_OK;
 }
 
-extern "C" int slam3d_icp_dense_finish(slam3d_icp_handle *h, const int64_t last_sums[SLAM3D_ICP_NSUMS], slam3d_icp_result *out)
+extern "C" int slam3d_icp_dense_finish(slam3d_icp_handle *h, const int64_t last_sums[SLAM3D_ICP_NRAW], slam3d_icp_result *out)
 {
     if (!h || !out) return SLAM3D_E_INVALID;
     if (!h->ran) return SLAM3D_E_STATE;
@@ -1564,7 +1576,7 @@ extern "C" int slam3d_icp_dense_finish(slam3d_icp_handle *h, const int64_t last_
     HIPCHK(h, hipMemcpyAsync(h->pin_int + 4, h->flags, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     double ls[NSUMS];
-    for (int k = 0; k < NSUMS; ++k) ls[k] = last_sums ? (double)last_sums[k] / FIX_SCALE : 0.0;
+    for (int k = 0; k < NSUMS; ++k) ls[k] = last_sums ? derive_sum(h->p.estimator, h->g.eb, k, reinterpret_cast<const long long *>(last_sums)) : 0.0;
     finish_result(h->p, h->pin_out, ls, h->pin_int[4], h->pin_int[0], h->pin_int[1], out);
     out->iterations = h->dense_it;
     return SLAM3D_OK;
@@ -1620,7 +1632,7 @@ extern "C" int slam3d_icp_dense_run(slam3d_icp_handle *h, slam3d_comm *comm, con
             rc = slam3d_icp_dense_partial_device(h, d_sums, s);
             if (rc) break;
             if (collective) {
-                const ncclResult_t nr = s3d::rccl().AllReduce(d_sums, d_sums, NSUMS, ncclInt64, ncclSum, comm->comm, s);
+                const ncclResult_t nr = s3d::rccl().AllReduce(d_sums, d_sums, NRAW, ncclInt64, ncclSum, comm->comm, s);
                 if (nr != ncclSuccess) { h->err = std::string("ncclAllReduce failed: ") + s3d::rccl().GetErrorString(nr); rc = SLAM3D_E_COMM; break; }
             }
             rc = slam3d_icp_dense_update_device(h, d_sums, s);

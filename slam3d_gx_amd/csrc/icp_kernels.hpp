@@ -21,7 +21,8 @@
 
 namespace s3d {
 
-constexpr int NSUMS = 29;
+constexpr int NSUMS = 29;         // the derived sums of the trace / the solve (21 A^T A + 6 A^T b + count + sum b^2)
+constexpr int NRAW = 36;          // what is ACCUMULATED: the upper triangle of the 8x8 integer Gram matrix of the quantised row vectors (spec S4)
 constexpr int CHUNK = 256;
 constexpr int NN_TILE = 1024;      // targets staged in LDS per tile (brute-force kernel)
 constexpr int NN_QPT = 4;          // queries per thread (brute-force VALU kernel)
@@ -113,6 +114,8 @@ struct Geometry {
     float proj_c;                  // projective window search: pixels of radius r around a query's projection cover every target
                                    // closer than (r + 0.49) * z / proj_c  (= fmax * sqrt(1 + amax^2 + bmax^2) * 1.001), DESIGN.md 5
     int estimator;
+    int eb;                        // spec S4: the residual component of a row vector is rint(b * 2^eb), eb = 20 - k with gate = m 2^k, 0.5 <= m < 1
+    double b_scale;                // 2^eb
     double fx, fy, cx, cy, factor, zf;
 };
 
@@ -193,18 +196,19 @@ __device__ __forceinline__ void eig3_smallest(Sym3 A, double &nx, double &ny, do
     nx = nx / len; ny = ny / len; nz = nz / len;
 }
 
-// Spec S2 (round 3): unit eigenvector of the smallest eigenvalue of the window covariance by power iteration on the adjugate
-// (oracle/icp_oracle.c::orc_smallest_evec3 is the same sequence of individually rounded operations): M = adj(C); five times
-// { scale by the exact power of two that brings the trace into [1, 2); M = M * M }; the column with the largest diagonal entry,
-// normalised.  ~200 fp64 operations, one sqrt and three divisions, against ~1,700 for the eight Jacobi sweeps it replaces
+// Spec S2 (round 3; seven squarings + dominance test: round 4): unit eigenvector of the smallest eigenvalue of the window covariance by power iteration on the adjugate
+// (oracle/icp_oracle.c::orc_smallest_evec3 is the same sequence of individually rounded operations): M = adj(C); seven times
+// { scale by the exact power of two that brings the trace into [1, 2); M = M * M }; M must then be rank one to 2^-40; the column
+// with the largest diagonal entry, normalised.  ~200 fp64 operations, one sqrt and three divisions, against ~1,700 for the eight Jacobi sweeps it replaces
 // (k_normals sat on the fp64 floor: 50 us per 640x480 frame, 70 % of it here).  eig3_smallest stays for the plane fits.
+constexpr int EVEC_SQUARINGS = 7;       // (round 3: five)
 __device__ __forceinline__ bool smallest_evec3(const Sym3 &C, double &nx, double &ny, double &nz)
 {
     double m00 = C.a11 * C.a22 - C.a12 * C.a12, m01 = C.a02 * C.a12 - C.a01 * C.a22, m02 = C.a01 * C.a12 - C.a02 * C.a11;
     double m11 = C.a00 * C.a22 - C.a02 * C.a02, m12 = C.a01 * C.a02 - C.a00 * C.a12, m22 = C.a00 * C.a11 - C.a01 * C.a01;
     bool ok = true;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < EVEC_SQUARINGS; ++k) {
         const double tr = (m00 + m11) + m22;
         const int hi = __double2hiint(tr);
         const int be = (hi >> 20) & 0x7ff;
@@ -217,6 +221,12 @@ __device__ __forceinline__ bool smallest_evec3(const Sym3 &C, double &nx, double
         m11 = (a01 * a01 + a11 * a11) + a12 * a12;
         m12 = (a01 * a02 + a11 * a12) + a12 * a22;
         m22 = (a02 * a02 + a12 * a12) + a22 * a22;
+    }
+    {   // dominance (spec S2, round 4): M must be rank one to 2^-40, i.e. l1 / l0 above ~1.25 -- else the window has no
+        // well-defined direction of least variance and gets no normal (oracle/icp_oracle.c::orc_smallest_evec3)
+        const double t = (m00 + m11) + m22;
+        const double F = ((m00 * m00 + m11 * m11) + m22 * m22) + 2.0 * ((m01 * m01 + m02 * m02) + m12 * m12);
+        ok = ok && F >= (t * t) * (1.0 - 0x1p-40);
     }
     nx = m00; ny = m01; nz = m02;
     double best = m00;
@@ -309,7 +319,7 @@ __global__ __launch_bounds__(NRM_BX * NRM_BY) void k_normals(FrameTasks a, Geome
 // Both organized clouds are cut into 8x8-pixel tiles: one wavefront = one tile = 64 slots.
 // Source slot id = tile*64 + (v%8)*8 + (u%8).  Correspondences refer to targets by ORIGINAL pixel index j.
 constexpr int ACC_R = 16;                      // accumulator replicas per pair: same-address atomics serialise
-constexpr int ACC_STRIDE = 32;                 // int64 per replica (29 used)
+constexpr int ACC_STRIDE = 40;                 // int64 per replica (NRAW = 36 used)
 constexpr int TILE_PX = 8;                 // tile edge in pixels
 constexpr int TILE_SLOTS = 64;             // = one wavefront
 constexpr int TILE_REC = 72;               // target tile record: 64 slots (4 quadrants x 16) + 4 x (lo, hi) quadrant boxes
@@ -318,7 +328,14 @@ constexpr int TILES_PER_CHUNK = CHUNK / TILE_SLOTS;
 
 // nchunks = launch blocks of 4 tiles, nslots = padded slot count
 // mag_x = ceil(2^32 / x): q = umulhi(n, mag_x) is n / x exactly for n * x < 2^32 (scalar multiply, no VALU division)
-struct TileGrid { int ntx, nty, ntiles, ncx, ncy, ncoarse, nchunks, nslots; unsigned int mag_ncx, mag_W; };
+struct TileGrid { int ntx, nty, ntiles, ncx, ncy, ncoarse, nchunks, nslots; unsigned int mag_ncx, mag_W, mag_ntx; };
+// spec S4c (coarse iterations): the source tiles that take part -- every fourth 8x8-pixel tile, staggered by rows
+__device__ __forceinline__ bool coarse_tile(int tx, int ty) { return ((tx + 2 * ty) & 3) == 0; }
+__device__ __forceinline__ bool coarse_tile_id(int t, const TileGrid &tg)
+{
+    const int ty = tg.ntx == 1 ? t : (int)__umulhi((unsigned int)t, tg.mag_ntx);      // t / ntx (2^32 / 1 has no 32-bit magic)
+    return coarse_tile(t - ty * tg.ntx, ty);
+}
 
 // ---- wave64 cross-lane helpers on the VALU (DPP within a 16-lane row, v_permlane16/32_swap across
 // rows -- gfx950); no LDS round trips.  Inputs are never NaN here (+-inf marks "no value").
@@ -848,131 +865,120 @@ __global__ __launch_bounds__(64) void k_nn_mfma(const PairPtrs *__restrict__ pai
     }
 }
 
-// rows of the normal equations for a source point p' matched to target point q with normal n (spec S4)
-constexpr double FIX_SCALE = 4294967296.0;     // 2^32: unit of the fixed-point sums (spec S4)
-// A slot's 29 terms are products of a handful of values; only those eight ("basis") stay live between the gather
-// and the reduction, the products are formed group by group while they are summed (58 VGPRs of row sums made the
-// epilogue the register peak of the kernel).  point-to-plane: v = a[0..5], b, 1;  svd: v = p', q, |q - p'|^2, 1.
-// A slot without a correspondence has an all-zero basis, hence all-zero terms.  The basis carries the fixed-point
-// scale (2^16 per factor, 2^32 on single values): powers of two commute with the rounding of the products, so
-// row_term returns exactly term * 2^32 of the spec and the only thing left per term is the rint.
+// ---- spec S4 (round 4): every correspondence contributes an 8-component INTEGER row vector V, and an iteration's totals are the
+// 36 upper-triangle entries of the Gram matrix G = sum V V^T -- exact int64 sums, so neither the order inside the wave, nor which
+// block owns which tile, nor the number of GPUs changes a bit:
+//   point-to-plane   V = ( rint(a 2^16) [3], rint(n 2^20) [3], rint(b 2^eb), 1 ),  a = p' x n, b = n . (q - p')
+//   svd              V = ( rint(p' 2^16) [3], rint(q 2^16) [3], 0, 1 )
+// (oracle/icp_oracle.c::row_vector; the 29 doubles of the trace and of the solve are derived from G: derive_sum below.)
+// A wave's 64 row vectors meet on the fp64 MATRIX CORES: G is a matrix product, and with integer-valued operands below 2^22
+// every product and every partial sum of v_mfma_f64_16x16x4_f64 is exact (64 products of at most 2^44: below 2^51).  Rounds 1-3
+// rounded the 29 PRODUCTS instead -- 29 fp64 multiplications, 29 v_rndne_f64 and eight packed wave reductions of 21
+// instructions: ~300 of the 805 VALU instructions a wave spends in a settled launch, in a kernel whose stream regime is bound by
+// VALU issue (DESIGN.md section 9(0) of round 3; prototype tools/ubench_gram.hip).
 struct RowBasis { double v[8]; };
+typedef double d4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void row_basis(int estimator, float pxf, float pyf, float pzf, const float4 q4, const float4 n4, RowBasis &B)
+// b_raw: the unrounded residual n . (q - p') (the optional residual gate tests it)
+__device__ __forceinline__ void row_basis(int estimator, double b_scale, float pxf, float pyf, float pzf, const float4 q4, const float4 n4, RowBasis &B, double &b_raw)
 {
     const double px = pxf, py = pyf, pz = pzf;
     const double qx = q4.x, qy = q4.y, qz = q4.z;
-    const double dx = qx - px, dy = qy - py, dz = qz - pz;
+    b_raw = 0.0;
     if (estimator == 0) {
+        const double dx = qx - px, dy = qy - py, dz = qz - pz;
         const double nx = n4.x, ny = n4.y, nz = n4.z;
-        B.v[0] = (py * nz - pz * ny) * 65536.0; B.v[1] = (pz * nx - px * nz) * 65536.0; B.v[2] = (px * ny - py * nx) * 65536.0;
-        B.v[3] = nx * 65536.0; B.v[4] = ny * 65536.0; B.v[5] = nz * 65536.0;
-        B.v[6] = ((nx * dx + ny * dy) + nz * dz) * 65536.0;
+        B.v[0] = rint((py * nz - pz * ny) * 65536.0); B.v[1] = rint((pz * nx - px * nz) * 65536.0); B.v[2] = rint((px * ny - py * nx) * 65536.0);
+        // (n is a float: n 2^20 is exact in float, rintf of it is the same integer as rint of the double -- at the fp32 rate)
+        B.v[3] = (double)rintf(n4.x * 1048576.0f); B.v[4] = (double)rintf(n4.y * 1048576.0f); B.v[5] = (double)rintf(n4.z * 1048576.0f);
+        b_raw = (nx * dx + ny * dy) + nz * dz;
+        B.v[6] = rint(b_raw * b_scale);
     } else {
-        B.v[0] = px * FIX_SCALE; B.v[1] = py * FIX_SCALE; B.v[2] = pz * FIX_SCALE; B.v[3] = qx; B.v[4] = qy; B.v[5] = qz;
-        B.v[6] = ((dx * dx + dy * dy) + dz * dz) * FIX_SCALE;
+        B.v[0] = rint(px * 65536.0); B.v[1] = rint(py * 65536.0); B.v[2] = rint(pz * 65536.0);
+        B.v[3] = rint(qx * 65536.0); B.v[4] = rint(qy * 65536.0); B.v[5] = rint(qz * 65536.0);
+        B.v[6] = 0.0;
     }
-    B.v[7] = FIX_SCALE;
+    B.v[7] = 1.0;
 }
 
-// term K of the 29-slot record (spec S4), K a compile-time constant
-template <int EST, int K> __device__ __forceinline__ double row_term(const RowBasis &B)
+__host__ __device__ __forceinline__ int tri36(int i, int j) { return i * 8 - ((i * (i - 1)) >> 1) + (j - i); }       // (i <= j) of the 8x8 upper triangle, row-major
+
+// The 29 doubles of the trace / the solve from the integer Gram totals (oracle/icp_oracle.c::orc_derive_sums): lane k < 29 gets sum k.
+//   point-to-plane   A^T A (r, c) = G[r][c] 2^-(e_r + e_c), e = (16,16,16,20,20,20);  A^T b (r) = G[r][6] 2^-(e_r + eb);  count = G[7][7];
+//                    sum b^2 = G[6][6] 2^-2eb
+//   svd              sum p' = G[i][7] 2^-16, sum q = G[3+i][7] 2^-16, sum p' q^T (r, c) = G[r][3+c] 2^-32, count = G[7][7],
+//                    sum |q - p'|^2 = (G00 + .. + G55 - 2 (G03 + G14 + G25)) 2^-32 in integer arithmetic
+__host__ __device__ __forceinline__ double derive_sum(int estimator, int eb, int k, const long long *G)
 {
-    if constexpr (K >= NSUMS) return 0.0;
-    else if constexpr (K == 27) return B.v[7];
-    else if constexpr (EST == 0) {
-        if constexpr (K < 21) {
-            constexpr int r = K < 6 ? 0 : (K < 11 ? 1 : (K < 15 ? 2 : (K < 18 ? 3 : (K < 20 ? 4 : 5))));
-            constexpr int first = r == 0 ? 0 : (r == 1 ? 6 : (r == 2 ? 11 : (r == 3 ? 15 : (r == 4 ? 18 : 20))));
-            constexpr int c = r + (K - first);
-            return B.v[r] * B.v[c];
-        } else if constexpr (K < 27) return B.v[K - 21] * B.v[6];
-        else return B.v[6] * B.v[6];
-    } else {
-        if constexpr (K < 3) return B.v[K];
-        else if constexpr (K < 6) return B.v[K] * FIX_SCALE;
-        else if constexpr (K < 15) return B.v[(K - 6) / 3] * B.v[3 + (K - 6) % 3];
-        else if constexpr (K < 27) return 0.0;
-        else return B.v[6];
+    if (k == 27) return (double)G[35];
+    if (estimator == 0) {
+        if (k < 21) {
+            const int r = k < 6 ? 0 : (k < 11 ? 1 : (k < 15 ? 2 : (k < 18 ? 3 : (k < 20 ? 4 : 5))));
+            const int first = r == 0 ? 0 : (r == 1 ? 6 : (r == 2 ? 11 : (r == 3 ? 15 : (r == 4 ? 18 : 20))));
+            const int c = r + (k - first);
+            return ldexp((double)G[tri36(r, c)], -((r < 3 ? 16 : 20) + (c < 3 ? 16 : 20)));
+        }
+        if (k < 27) { const int r = k - 21; return ldexp((double)G[tri36(r, 6)], -((r < 3 ? 16 : 20) + eb)); }
+        return ldexp((double)G[33], -2 * eb);                          // tri36(6, 6)
     }
+    if (k < 6) return ldexp((double)G[tri36(k, 7)], -16);
+    if (k < 15) { const int r = (k - 6) / 3, c = (k - 6) - 3 * r; return ldexp((double)G[tri36(r, 3 + c)], -32); }
+    if (k < 27) return 0.0;
+    const long long d2 = (G[tri36(0, 0)] + G[tri36(1, 1)] + G[tri36(2, 2)]) + (G[tri36(3, 3)] + G[tri36(4, 4)] + G[tri36(5, 5)])
+                       - 2 * (G[tri36(0, 3)] + G[tri36(1, 4)] + G[tri36(2, 5)]);
+    return ldexp((double)d2, -32);
 }
 
-// Spec S4 summation: every slot's products are scaled by 2^32 and rounded to int64; the totals are exact integer
-// sums, so neither the order inside the wave, nor which block owns which tile, nor the number of GPUs changes a
-// bit.  The wave sums its 64 lanes with v_permlane32_swap / v_permlane16_swap / DPP row_shl (two 32-bit moves per
-// value, no LDS); FOUR components share one pass:
-//   level 32: v_permlane32_swap(a, b) puts a's lower/upper halves side by side with b's, so ONE add yields
-//             a[i]+a[i+32] in lanes 0..31 and b[i]+b[i+32] in lanes 32..63;
-//   level 16: v_permlane16_swap on two such registers -> rows 0..3 hold components (a, c, b, d);
-//   levels 8..1: DPP row_shl inside each 16-lane row, as 64-bit integer adds (below).  Result: lanes 0,16,32,48 hold the sums of a,c,b,d.
+template <int CTRL> __device__ __forceinline__ double dpp_d(double v)      // lanes the permutation does not reach read 0
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
 
-__device__ __forceinline__ double swap32_add(double a, double b)
-{
-    const auto rl = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
-    const auto rh = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
-    return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);   // (a_lo | b_lo) + (a_hi | b_hi)
-}
-__device__ __forceinline__ double swap16_add(double x, double y)
-{
-    const auto rl = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
-    const auto rh = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
-    return __hiloint2double(rh[0], rl[0]) + __hiloint2double(rh[1], rl[1]);   // rows (x0|y0|x2|y2) + (x1|y1|x3|y3)
-}
-// The wave's four sums as int64: the two cross-row levels in fp64 (one add per level and value pair), then the value -- an
-// integer below 2^46 in magnitude -- moves to two's complement (adding 1.5 * 2^52 leaves it in the low mantissa bits: three
-// instructions instead of the generic double -> int64 conversion) and the four in-row levels are 64-bit INTEGER adds with a DPP
-// operand: v_add_co_u32_dpp + v_addc_co_u32_dpp, two instructions per level where fp64 (no DPP form) needs two moves and an add.
-// Lanes a row_shl reaches past the row's end keep their value (no bound_ctrl): only lane 0 of each row is read.
-__device__ __forceinline__ long long wave_sum_x4_i64(double a, double b, double c, double d)
-{
-    const double x = swap16_add(swap32_add(a, b), swap32_add(c, d));
-    const long long q = __double_as_longlong(x + 6755399441055744.0) - 0x4338000000000000ll;
-    unsigned int lo = (unsigned int)q, hi = (unsigned int)((unsigned long long)q >> 32);
-    asm("s_nop 1\n\t"
-        "v_add_co_u32_dpp %0, vcc, %0, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_co_u32_dpp %0, vcc, %0, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_co_u32_dpp %0, vcc, %0, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_co_u32_dpp %0, vcc, %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_shl:1 row_mask:0xf bank_mask:0xf"
-        : "+v"(lo), "+v"(hi) : : "vcc");
-    return (long long)(((unsigned long long)hi << 32) | lo);      // lane 0: a, lane 16: c, lane 32: b, lane 48: d
-}
-// A slot's term in fixed-point units is an integer-valued double: row_term returns term * 2^32 exactly and rint
-// rounds it to nearest-even like the oracle's llrint.  |term| < 2^39, so the 64-lane sums stay under 2^53 and every
-// fp64 add of these integers is EXACT -- the wave may add them in any order, in the fp64 pipe, one instruction per add.
-
-// the wave's 64 slots -> the pair's accumulators (replica chosen by the block): the wave total of each component
-// is converted to int64 once (four components per pass sit in lanes 0/16/32/48) and leaves as 8 atomic
-// instructions of four addresses each; tiles without a match issue none
-template <int EST, int K0> __device__ __forceinline__ void tile_accumulate_group(const RowBasis &B, long long *__restrict__ acc, int lane, int koff)
-{
-    const long long q = wave_sum_x4_i64(rint(row_term<EST, K0>(B)), rint(row_term<EST, K0 + 1>(B)), rint(row_term<EST, K0 + 2>(B)),
-                                        rint(row_term<EST, K0 + 3>(B)));
-    if ((lane & 15) == 0 && q != 0) atomicAdd(reinterpret_cast<unsigned long long *>(acc + K0 + koff), (unsigned long long)q);
-}
-template <int EST> __device__ __forceinline__ void tile_accumulate_est(const RowBasis &B, long long *__restrict__ acc)
-{
-    const int lane = threadIdx.x & 63;
-    const int sel = lane >> 4;                       // row -> which of (a, c, b, d)
-    const int koff = sel == 0 ? 0 : (sel == 1 ? 2 : (sel == 2 ? 1 : 3));
-    tile_accumulate_group<EST, 0>(B, acc, lane, koff);  tile_accumulate_group<EST, 4>(B, acc, lane, koff);
-    tile_accumulate_group<EST, 8>(B, acc, lane, koff);  tile_accumulate_group<EST, 12>(B, acc, lane, koff);
-    if constexpr (EST == 0) {                        // svd: terms 15..26 are zero
-        tile_accumulate_group<EST, 16>(B, acc, lane, koff); tile_accumulate_group<EST, 20>(B, acc, lane, koff);
-    }
-    tile_accumulate_group<EST, 24>(B, acc, lane, koff); tile_accumulate_group<EST, 28>(B, acc, lane, koff);
-}
-__device__ __forceinline__ void tile_accumulate(int estimator, const RowBasis &B, long long *__restrict__ acc /* [ACC_STRIDE] */)
+// The wave's 64 row vectors -> the pair's accumulators (replica chosen by the caller).  `slab`: 2 KB of LDS of this wave.
+//   v_mfma_f64_16x16x4_f64: A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k (one f64 each); D[(lane >> 4) + 4 r][lane & 15] in
+//   element r of the lane's four.  G = sum V V^T needs A = B^T = the row vectors, so ONE register serves both operands; and because
+//   V has 8 components, not 16, TWO sets of four points share an instruction: rows / columns 0..7 carry component i of point
+//   8 s + k, rows / columns 8..15 component i - 8 of point 8 s + 4 + k; the diagonal 8x8 blocks of D are the two sets' Gram sums
+//   (the off-diagonal blocks mix the sets and are ignored).  Eight instructions cover the 64 points.  The transpose (lane = point
+//   -> lane = component) goes through LDS: 64 bytes per point, half the wave at a time (the slab is what is left of the stage
+//   buffers: 2 KB), read back as 512 contiguous bytes per instruction.
+__device__ __forceinline__ void tile_accumulate(const RowBasis &B, long long *__restrict__ acc /* [ACC_STRIDE] */, double *slab)
 {
     if (__ballot(B.v[7] != 0.0) == 0ull) return;
-    if (estimator == 0) tile_accumulate_est<0>(B, acc);
-    else tile_accumulate_est<1>(B, acc);
+    const int lane = threadIdx.x & 63;
+    const int rd = (4 * ((lane >> 3) & 1) + (lane >> 4)) * 8 + (lane & 7);       // (point within the group of 8) * 8 + component
+    d4 D = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                     // (whoever read the slab before is done)
+        if ((lane >> 5) == half) {
+            double2 *__restrict__ w = reinterpret_cast<double2 *>(slab + (lane & 31) * 8);
+            w[0] = make_double2(B.v[0], B.v[1]); w[1] = make_double2(B.v[2], B.v[3]);
+            w[2] = make_double2(B.v[4], B.v[5]); w[3] = make_double2(B.v[6], B.v[7]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const double x = slab[s4 * 64 + rd];
+            D = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, D, 0, 0, 0);
+        }
+    }
+    // G[i][j] = D[i][j] + D[8 + i][8 + j]: lane (q, j < 8) holds D[q][j], D[q + 4][j]; lane (q, j + 8) holds D[q + 8][j + 8], D[q + 12][j + 8]
+    const double g0 = D[0] + dpp_d<0x108>(D[2]);             // row_shl:8 -- lane l reads lane l + 8 of its 16-lane row
+    const double g1 = D[1] + dpp_d<0x108>(D[3]);
+    const int j = lane & 15, q = lane >> 4;
+    if (j < 8) {
+        // integers below 2^51: adding 1.5 * 2^52 leaves the two's complement value in the low mantissa bits
+        const long long i0 = __double_as_longlong(g0 + 6755399441055744.0) - 0x4338000000000000ll;
+        const long long i1 = __double_as_longlong(g1 + 6755399441055744.0) - 0x4338000000000000ll;
+        if (q <= j && i0 != 0) atomicAdd(reinterpret_cast<unsigned long long *>(acc + tri36(q, j)), (unsigned long long)i0);
+        if (q + 4 <= j && i1 != 0) atomicAdd(reinterpret_cast<unsigned long long *>(acc + tri36(q + 4, j)), (unsigned long long)i1);
+    }
 }
 
 // decode a packed NN key, apply the gate(s), record the correspondence and form the row products.
@@ -989,7 +995,7 @@ struct SlotGates {
 template <bool GATED>
 __device__ __forceinline__ void finish_slot(bool valid, unsigned long long key, float px, float py, float pz,
                                             const float4 *__restrict__ tcloud, const float4 *__restrict__ tnrm,
-                                            float gate2, int estimator, int *__restrict__ corr_out,
+                                            float gate2, int estimator, double b_scale, int *__restrict__ corr_out,
                                             float *__restrict__ cd2_out, float4 *__restrict__ prevq_out,
                                             RowBasis &B, bool write_out, int jprev /* match the slot already holds (-2: unknown) */,
                                             const SlotGates *sg = nullptr,
@@ -1016,13 +1022,14 @@ __device__ __forceinline__ void finish_slot(bool valid, unsigned long long key, 
         else q4 = tcloud[j];
         float4 n4 = make_float4(0, 0, 0, 0);
         if (estimator == 0) n4 = tnrm[j];
-        row_basis(estimator, px, py, pz, q4, n4, B);
+        double b_raw;
+        row_basis(estimator, b_scale, px, py, pz, q4, n4, B, b_raw);
         pq = make_float4(q4.x, q4.y, q4.z, __int_as_float(j));
         if constexpr (GATED) {
             if (estimator == 0) {
                 bool keep = true;
                 if (sg->resid2 > 0.0f) {
-                    const double e = B.v[6] * (1.0 / 65536.0);          // exact: b of the row (a power-of-two scale)
+                    const double e = b_raw;                             // b of the row, before its quantisation
                     keep = e * e <= (double)sg->resid2;
                 }
                 if (keep && sg->min_ncos > 0.0f) {
@@ -1059,7 +1066,8 @@ __global__ __launch_bounds__(CHUNK) void k_accumulate(const PairPtrs *__restrict
                                                       unsigned long long *__restrict__ best,
                                                       int *__restrict__ corr, float *__restrict__ cd2,
                                                       float4 *__restrict__ prevq,
-                                                      long long *__restrict__ acc, Geometry g, TileGrid tg, int nsets)
+                                                      long long *__restrict__ acc, Geometry g, TileGrid tg, int nsets,
+                                                      int cmode /* 1: a coarse iteration (spec S4c) -- the slots of the other tiles take no part */)
 {
     const int b = blockIdx.y, c = blockIdx.x;
     const int t = c * TILES_PER_CHUNK + (threadIdx.x >> 6);
@@ -1067,7 +1075,7 @@ __global__ __launch_bounds__(CHUNK) void k_accumulate(const PairPtrs *__restrict
     const int slot = c * CHUNK + threadIdx.x;
     const size_t gs = (size_t)b * tg.nslots + slot;
     const float4 sp = pairs[b].srcT[slot];
-    const bool valid = __float_as_int(sp.w) >= 0;
+    const bool valid = __float_as_int(sp.w) >= 0 && !(cmode == 1 && !coarse_tile_id(t, tg));
     const Rt m = load_rt(Tcur + b * 16);
     float px, py, pz;
     xform(m, sp.x, sp.y, sp.z, px, py, pz);
@@ -1078,9 +1086,10 @@ __global__ __launch_bounds__(CHUNK) void k_accumulate(const PairPtrs *__restrict
     sg.resid2 = g.resid2; sg.min_ncos = g.min_ncos; sg.snrm = pairs[b].snrm; sg.spix = max(__float_as_int(sp.w), 0);
     sg.r[0] = m.r00; sg.r[1] = m.r01; sg.r[2] = m.r02; sg.r[3] = m.r10; sg.r[4] = m.r11; sg.r[5] = m.r12;
     sg.r[6] = m.r20; sg.r[7] = m.r21; sg.r[8] = m.r22;
-    finish_slot<true>(valid, key, px, py, pz, pairs[b].tgt, pairs[b].nrm, g.gate2, g.estimator, corr + gs, cd2 + gs,
+    finish_slot<true>(valid, key, px, py, pz, pairs[b].tgt, pairs[b].nrm, g.gate2, g.estimator, g.b_scale, corr + gs, cd2 + gs,
                       prevq + gs, rb, true, -2, &sg);
-    tile_accumulate(g.estimator, rb, acc + ((size_t)b * nsets * ACC_R + (c % ACC_R)) * ACC_STRIDE);
+    __shared__ double gslab[TILES_PER_CHUNK][256];                     // the Gram transpose of tile_accumulate: 2 KB per wave
+    tile_accumulate(rb, acc + ((size_t)b * nsets * ACC_R + (c % ACC_R)) * ACC_STRIDE, gslab[threadIdx.x >> 6]);
 }
 
 // ------------------------------------------------------------------ S4, tile-pruned exact NN
@@ -1241,7 +1250,9 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                                                         int it /* iteration of the run; 0: no previous match to start from */,
                                                         StampRing sring /* launch stamps; rows null (the default): none */, int stamp_idx,
                                                         int head /* solve iteration it-1 at the head of this launch (see above) */,
-                                                        int cert /* certify from it >= 1 on (needs `it` = the run's iteration and trace_T[it - 1]) */)
+                                                        int cert /* certify from it >= 1 on (needs `it` = the run's iteration and trace_T[it - 1]) */,
+                                                        int cmode /* spec S4c: 1 = a coarse iteration (only the tiles of coarse_tile() take part), 2 = the first full iteration
+                                                                     after coarse ones (the other tiles hold no record yet), 0 = neither */)
 {
     // g / tg are used all over the kernel and stay with the compiler; the pointers and counts that only the head, the prologue
     // and the epilogue need are fetched right there through SS(): an opaque copy of the entry's address, so that the loads
@@ -1254,7 +1265,6 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         asm volatile("" : "+s"(a));
         return (nn_static_ptr)a;
     };
-    const int first = it == 0;
     const bool certify = cert && it > 0;                    // slots may carry a clearance from the previous launch (<= 0: none)
     bool trk = false;                                       // this launch tracks (best, second) and inflates its pruning radii: decided below,
     float cm = 0.0f;                                        // once this launch's pose is known (how far it moved since the last one)
@@ -1310,6 +1320,21 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             t = (j < chunk && idx < n_rem) ? full_rows * tg.ntx + idx : tg.ntiles;
         }
     }
+    // spec S4c: in a coarse iteration only every fourth tile takes part (the others' waves own nothing: they still help to drain the
+    // block's shared work); in the first full iteration after coarse ones those other tiles start like a run's first iteration
+    bool first = it == 0;
+    if (cmode != 0 && t < tg.ntiles) {
+        const bool in_pattern = coarse_tile_id(t, tg);
+        if (cmode == 1 && !in_pattern) {
+            if (write_out) {            // (only a traced run asks for a coarse iteration's correspondences: none for this tile)
+                const nn_static_ptr S0 = SS();
+                const size_t g0 = (size_t)b * tg.nslots + (size_t)t * TILE_SLOTS + (threadIdx.x & 63);
+                S0->corr[g0] = -1; S0->cd2[g0] = __int_as_float(0x7f800000);
+            }
+            t = tg.ntiles;
+        }
+        first = first || (cmode == 2 && !in_pattern);
+    }
     const bool has_tile = t < tg.ntiles;
     const long long cw0 = COOP ? 0 : clock64();         // per-tile cost: input of k_balance (throughput build only)
     float4 *__restrict__ st = stage_all[w];
@@ -1355,13 +1380,18 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                 }
                 if (!have) {
                     const long long *__restrict__ A = SH->acc + ((size_t)b * SH->nsets + (it - 1)) * ACC_R * ACC_STRIDE;
-                    if (lane < NSUMS) {
+                    long long *Gs = reinterpret_cast<long long *>(tsh + 16);            // the 36 integer Gram totals (LDS, behind tot and tsh)
+                    if (lane < NRAW) {
                         long long q = 0;
 #pragma unroll
                         for (int r = 0; r < ACC_R; ++r) q += __hip_atomic_load(A + r * ACC_STRIDE + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        tot[lane] = (double)q / FIX_SCALE;
+                        Gs[lane] = q;
                     }
                     if (lane < 16) tsh[lane] = trace_T[((size_t)b * (iters + 1) + (it - 1)) * 16 + lane];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (lane < NSUMS) tot[lane] = derive_sum(0, g.eb, lane, Gs);           // (the head solves point-to-plane only)
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1703,7 +1733,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         const nn_static_ptr SP = SS();
         float2 *__restrict__ const slot_rec = SP->slot_rec;
         float *__restrict__ const tile_cum = SP->tile_cum;
-        if (trk) cum_prev = tile_cum[(size_t)b * tg.ntiles + t];   // (wave-uniform: a scalar load, in flight with the record)
+        if (trk && !first) cum_prev = tile_cum[(size_t)b * tg.ntiles + t];   // (wave-uniform: a scalar load, in flight with the record; a tile without records starts its total over)
         if (!first) {    // (a run's first iteration: whatever an earlier run left there is ignored)
             // the slot's record is 8 bytes (match, clearance); the matched POINT is gathered again -- from the records the window
             // search and the epilogue read anyway -- instead of being kept per slot (16 B read and, where it changed, written
@@ -1718,9 +1748,19 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         }
         float4 qs = make_float4(0, 0, 0, 0);
         float ws = 1.0f;
-        if (__float_as_int(pq.w) < 0) {   // no previous match (first iteration): fall back to the target at the same pixel
-            const int ug = (t % tg.ntx) * TILE_PX + (lane & 7), vg = (t / tg.ntx) * TILE_PX + (lane >> 3);
-            if (ug < g.W && vg < g.H) {
+        int fb_pix = pix;                 // the pixel of the fallback target below
+        if (__float_as_int(pq.w) < 0) {   // no previous match (a run's first iteration; the first full one after coarse ones): fall back to the
+            // target at the pixel the query PROJECTS to under the current pose (the frame geometry's pinhole; a bound only, any valid target
+            // serves) -- with the identity that is the query's own pixel; after coarse iterations, or from a caller's initial guess, the
+            // own pixel is tens of pixels off while the projected one holds a target millimetres away
+            int ug = (t % tg.ntx) * TILE_PX + (lane & 7), vg = (t / tg.ntx) * TILE_PX + (lane >> 3);
+            if (pz > 0.05f) {
+                const float izq = __builtin_amdgcn_rcpf(pz);
+                const float uq = (float)g.fx * px * izq + (float)g.cx, vq = (float)g.fy * py * izq + (float)g.cy;
+                if (uq > -1.0e6f && uq < 1.0e6f && vq > -1.0e6f && vq < 1.0e6f) { ug = (int)rintf(uq); vg = (int)rintf(vq); }
+            }
+            fb_pix = vg * g.W + ug;
+            if (ug >= 0 && ug < g.W && vg >= 0 && vg < g.H) {
                 if (pp.tq) { const float4 r4 = pp.tq[vg * g.W + ug]; qs = make_float4(r4.y, r4.z, r4.w, 0.0f); }     // (+inf where the pixel is no target: eligibility is folded in)
                 else { qs = tcloud[vg * g.W + ug]; if (g.estimator == 0) ws = tnrm[vg * g.W + ug].w; }
             }
@@ -1732,7 +1772,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             const int jprev = __float_as_int(pq.w);
             const bool have_prev = valid && jprev >= 0;
             const bool tv = have_prev || (valid && pt_valid(qs.x, qs.y, qs.z, g.zmax) && ws > 0.5f);
-            const int jg = have_prev ? jprev : pix;
+            const int jg = have_prev ? jprev : fb_pix;
             const float4 qg = have_prev ? pq : qs;
             const float d2g = canon_d2(px, py, pz, qg.x, qg.y, qg.z);
             if (tv && d2g <= g.gate2) bkey = ((unsigned long long)(unsigned int)__float_as_int(d2g) << 32) | (unsigned int)jg;
@@ -2051,10 +2091,10 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         sg.resid2 = g.resid2; sg.min_ncos = g.min_ncos; sg.snrm = pp.snrm; sg.spix = max(pix, 0);
         sg.r[0] = m.r00; sg.r[1] = m.r01; sg.r[2] = m.r02; sg.r[3] = m.r10; sg.r[4] = m.r11; sg.r[5] = m.r12;
         sg.r[6] = m.r20; sg.r[7] = m.r21; sg.r[8] = m.r22;
-        finish_slot<true>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs_ep, cd2 + gs_ep, nullptr, rb,
+        finish_slot<true>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, g.b_scale, corr + gs_ep, cd2 + gs_ep, nullptr, rb,
                           write_out != 0, own_jprev, &sg, pp.tq, &jnn);
     } else
-        finish_slot<false>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, corr + gs_ep, cd2 + gs_ep, nullptr, rb,
+        finish_slot<false>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, g.b_scale, corr + gs_ep, cd2 + gs_ep, nullptr, rb,
                            write_out != 0, own_jprev, nullptr, pp.tq, &jnn);
     {   // the slot's record for the next iteration: the match where it changed, the clearance where this lane searched
         const bool searched = own_valid && !((cert_mask >> lane) & 1ull);
@@ -2081,7 +2121,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         else if (wr_j) slot_rec[gs_ep].x = __int_as_float(jnn);
         else if (wr_c) slot_rec[gs_ep].y = cnew;
     }
-    tile_accumulate(g.estimator, rb, SE->acc + (((size_t)b * SE->nsets + (head ? it : 0)) * ACC_R + (c % ACC_R)) * ACC_STRIDE);
+    // (the wave's stage slab is free by now: every helper left it before the block's last barrier)
+    tile_accumulate(rb, SE->acc + (((size_t)b * SE->nsets + (head ? it : 0)) * ACC_R + (c % ACC_R)) * ACC_STRIDE, reinterpret_cast<double *>(st));
     stamp_wave_end();
     if (DBG && SE->dbg && b == 0 && lane == 0) {
         long long *d = SE->dbg + (size_t)t * 20;
@@ -2480,24 +2521,28 @@ __global__ __launch_bounds__(64) void k_solve_acc(long long *__restrict__ acc, l
                                                   int it, int iters, int do_solve, StampRing sring, int stamp_idx,
                                                   int nsets, int set /* which accumulator set of the pair: 0, or `it` after head-solved launches */,
                                                   int from_trace /* T_it from trace_T[it] (head-solved launches leave Tcur at T_0) */,
-                                                  int end_run /* the last launch of a slam3d_icp_run: one run less in flight */)
+                                                  int end_run /* the last launch of a slam3d_icp_run: one run less in flight */,
+                                                  int eb /* spec S4: exponent of the residual component */)
 {
     if (end_run && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_runs_in_flight, -1);
     __shared__ double tot[32], Tsh[16];
+    __shared__ long long Gs[NRAW];
     const int b = blockIdx.x, k = threadIdx.x;
     unsigned long long *const stamp = stamp_row(sring, stamp_idx);
     if (k == 0) stamp_start(stamp, b);
     long long *__restrict__ A = acc + ((size_t)b * nsets + set) * ACC_R * ACC_STRIDE;
-    if (k < NSUMS) {
+    if (k < NRAW) {
         long long q = 0;
 #pragma unroll
         for (int r = 0; r < ACC_R; ++r) q += __hip_atomic_load(A + r * ACC_STRIDE + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
         for (int r = 0; r < ACC_R; ++r) A[r * ACC_STRIDE + k] = 0;
-        if (raw_out) raw_out[b * NSUMS + k] = q;
-        tot[k] = (double)q / FIX_SCALE;
+        if (raw_out) raw_out[b * NRAW + k] = q;
+        Gs[k] = q;
     }
     if (k < 16) Tsh[k] = from_trace ? trace_T[((size_t)b * (iters + 1) + it) * 16 + k] : Tcur[b * 16 + k];
+    __syncthreads();
+    if (k < NSUMS) tot[k] = derive_sum(EST, eb, k, Gs);
     __syncthreads();
     if constexpr (EST == 0) {                 // point-to-plane: the whole wave solves (lane-parallel LDL^T, no scratch)
         if (do_solve)
@@ -2522,12 +2567,12 @@ __global__ __launch_bounds__(64) void k_solve_acc(long long *__restrict__ acc, l
 // dense mode: solve from externally reduced sums (one thread per pair)
 __global__ void k_solve(const long long *__restrict__ sums_all, double *__restrict__ Tcur,
                         double *__restrict__ trace_T, double *__restrict__ trace_S,
-                        int *__restrict__ flags, int B, int it, int iters, int estimator)
+                        int *__restrict__ flags, int B, int it, int iters, int estimator, int eb)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     double sums[NSUMS];
-    for (int k = 0; k < NSUMS; ++k) sums[k] = (double)sums_all[b * NSUMS + k] / FIX_SCALE;     // all-reduced integer sums
+    for (int k = 0; k < NSUMS; ++k) sums[k] = derive_sum(estimator, eb, k, sums_all + (size_t)b * NRAW);     // from the all-reduced integer Gram totals
     solve_update_one(sums, Tcur + b * 16, trace_T + (size_t)b * (iters + 1) * 16, trace_S + (size_t)b * iters * NSUMS,
                      flags + b, it, estimator);
 }

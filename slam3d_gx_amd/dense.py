@@ -2,7 +2,7 @@
 
 Every rank holds the full target (tiles, boxes, normals) and the source rows
 shard.dense_row_range(height, world, rank).  Per iteration each rank runs the NN search and the
-normal-equation accumulation on its rows (slam3d_icp_dense_partial), the 29 partial sums are
+normal-equation accumulation on its rows (slam3d_icp_dense_partial), the 36 partial Gram totals are
 all-reduced (the path's single exchange step: 232 bytes), and every rank solves the same 6x6 /
 3x3 system and updates T identically (slam3d_icp_dense_update).  Correspondences are unaffected by
 the sharding (each query still sees the whole target), and because the sums are int64 fixed point
@@ -18,7 +18,7 @@ from . import shard
 
 
 def allreduce_sum_torch(device=None) -> Callable[[np.ndarray], np.ndarray]:
-    """all-reduce (SUM) of the 29 int64 fixed-point sums over torch.distributed (RCCL on the GPU box, gloo in CPU tests)."""
+    """all-reduce (SUM) of the 36 int64 Gram totals over torch.distributed (RCCL on the GPU box, gloo in CPU tests)."""
     import torch
     import torch.distributed as dist
 
@@ -39,7 +39,7 @@ def dense_align(handle, world: int, rank: int, T_init=None, allreduce: Optional[
     r0, r1 = shard.dense_row_range(handle.params.height, world, rank)
     handle.dense_set_rows(r0, r1)
     handle.dense_begin(T_init, stream)
-    total = np.zeros(29, dtype=np.int64)
+    total = np.zeros(36, dtype=np.int64)
     for _ in range(handle.params.iterations):
         part = handle.dense_partial(stream)
         total = allreduce(part) if allreduce is not None else part
@@ -51,7 +51,7 @@ def dense_align(handle, world: int, rank: int, T_init=None, allreduce: Optional[
 
 def dense_align_device(handle, world: int, rank: int, d_sums, T_init=None, stream: int = None, force_collective: bool = False) -> dict:
     """dense_align with the exchange kept on the device, through torch.distributed: `d_sums` is a torch int64 tensor
-    of 29 elements on the handle's GPU; per iteration partial -> in-place all-reduce -> update, with no host
+    of 36 elements on the handle's GPU; per iteration partial -> in-place all-reduce -> update, with no host
     synchronisation until the final fetch.
 
     Stream contract (round-1 bug: the kernels went to the handle's private non-blocking stream while ProcessGroupNCCL

@@ -115,6 +115,7 @@ void GraphicEndICP::init(const string &param_file)
         if (deg > 0.0 && deg < 90.0) _params.min_normal_cos = (float)cos(deg * M_PI / 180.0);
     }
     _params.min_inliers = _reader->GetInt("icp_min_inliers", 12);
+    _params.coarse_iterations = _reader->GetInt("icp_coarse_iterations", 3);     // spec S4c: the per-frame call has no initial guess (src/GraphicEnd.cpp:168)
     _params.error_threshold = _error_threshold;
     _max_batch = _loopclosure_frames + 2;              // random candidates + the two adjacent keyframes, one launch
     if (_max_batch < 1) _max_batch = 1;

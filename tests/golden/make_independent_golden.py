@@ -2,10 +2,11 @@
 """Writes tests/golden/independent_golden.json from the numpy / scipy restatement ALONE (no oracle, no HIP):
 a complete ICP loop -- scipy.spatial.cKDTree candidates + canonical float32 d^2 re-evaluation for the indices,
 numpy.linalg.lstsq on explicit [p x n, n] rows (or numpy.linalg.svd for Kabsch) for the update -- on seeded synthetic
-pairs.  Only the target normals are taken from the oracle's S2 (checked against numpy.linalg.eigh in
-tests/test_oracle_independent.py::test_normals_vs_numpy_eigh); everything of the iteration itself is independent.
+pairs.  Round 4: the target NORMALS too are the restatement's own (whole-frame numpy.linalg.eigh, normals_numpy_full:
+spec S2 became well defined with the dominance test, tests/test_oracle_independent.py::test_whole_frame_normals_vs_numpy_eigh),
+so nothing of oracle/ is in the chain that produces these numbers.
 tests/test_oracle_independent.py then requires oracle/icp_oracle.c to reproduce these index hashes and poses, and
-tests/test_golden.py requires the HIP path to reproduce the oracle: HIP == oracle == scipy.
+tests/test_golden.py requires the HIP path to reproduce them directly from the depth images: HIP == scipy, oracle == scipy.
 
 usage: python tests/golden/make_independent_golden.py      (CPU only, a few minutes)
 """
@@ -20,7 +21,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-import oracle_lib as O                                   # noqa: E402  (normals only)
 import test_oracle_independent as R                      # noqa: E402  (the restatement)
 from slam3d_gx_amd import synth                          # noqa: E402
 
@@ -33,18 +33,13 @@ CASES = [(1000, 160, 120, 0, 10), (1001, 160, 120, 1, 10), (1002, 320, 240, 0, 1
 
 
 def icp_numpy(s4, t4, intr, estimator, iterations, gate=0.10):
-    nrm = O.normals(t4, O.params(intr)) if estimator == 0 else None
+    nrm = R.normals_numpy_full(t4)[0] if estimator == 0 else None     # the restatement's own S2 (numpy.linalg.eigh)
     tgt_ok = R.valid_mask(t4) & ((nrm[..., 3] > 0.5) if estimator == 0 else True)
     T = np.eye(4)
     idx = None
-    for _ in range(iterations):
-        idx, ps, sv = R.nn_scipy(s4, t4, tgt_ok, T, gate)
-        if estimator == 0:
-            A, b, _, _ = R.rows_point2plane(ps, sv, idx, t4, nrm)
-            T = R.delta_point2plane(np.linalg.lstsq(A, b, rcond=None)[0]) @ T
-        else:
-            m = idx[sv] >= 0
-            T = R.kabsch(ps[m].astype(np.float64), t4.reshape(-1, 4)[idx[sv][m], :3].astype(np.float64)) @ T
+    for k in range(iterations):
+        idx, ps, sv = R.nn_scipy(s4, t4, tgt_ok, T, gate, coarse=R.is_coarse(k, iterations))       # spec S4c, default three coarse iterations
+        T = R.update_from_rows(R.row_vectors(ps, sv, idx, t4, nrm, estimator, gate), estimator, gate, T)      # spec S4: quantised row vectors
     return idx, T
 
 

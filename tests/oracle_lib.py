@@ -25,6 +25,7 @@ class OrcParams(C.Structure):
         ("min_inliers", C.c_int), ("error_threshold", C.c_double),
         ("nn_method", C.c_int), ("threads", C.c_int),
         ("max_plane_residual2", C.c_double), ("min_normal_cos", C.c_double),
+        ("coarse_iterations", C.c_int),
     ]
 
 
@@ -53,6 +54,7 @@ def lib():
         _lib = C.CDLL(build())
         _lib.orc_icp.restype = C.c_int
         _lib.orc_nn_once.restype = C.c_int
+        _lib.orc_nn_once_ex.restype = C.c_int
         _lib.orc_solve6.restype = C.c_int
     return _lib
 
@@ -106,15 +108,15 @@ def icp(src4: np.ndarray, tgt4: np.ndarray, p: OrcParams, T_init=None, trace: bo
                 T_trace=Ttr.reshape(-1, 4, 4) if trace else None, sums_trace=Str[:p.iterations] if trace else None)
 
 
-def nn_once(src4, tgt4, p: OrcParams, T=None, use_normals: bool = False):
+def nn_once(src4, tgt4, p: OrcParams, T=None, use_normals: bool = False, coarse: bool = False):
     N = p.width * p.height
     src4 = np.ascontiguousarray(src4, dtype=np.float32)
     tgt4 = np.ascontiguousarray(tgt4, dtype=np.float32)
     idx = np.empty(N, dtype=np.int32)
     d2 = np.empty(N, dtype=np.float32)
     Ti = np.ascontiguousarray(T, dtype=np.float64).reshape(16) if T is not None else None
-    ns = lib().orc_nn_once(_fp(src4, C.c_float), _fp(tgt4, C.c_float), C.byref(p), _fp(Ti, C.c_double),
-                           C.c_int(1 if use_normals else 0), _fp(idx, C.c_int32), _fp(d2, C.c_float))
+    ns = lib().orc_nn_once_ex(_fp(src4, C.c_float), _fp(tgt4, C.c_float), C.byref(p), _fp(Ti, C.c_double),
+                              C.c_int(1 if use_normals else 0), C.c_int(1 if coarse else 0), _fp(idx, C.c_int32), _fp(d2, C.c_float))
     return idx, d2, ns
 
 

@@ -135,7 +135,8 @@ def test_per_iteration_index_parity_config2(gpu_lib, estimator):
     ro = O.icp(s4, t4, p)
     assert np.array_equal(ro["T_trace"], Tt)
     for k in range(iters):
-        want, _, _ = O.nn_once(s4, t4, p, T=ro["T_trace"][k], use_normals=(estimator == 0))
+        want, _, _ = O.nn_once(s4, t4, p, T=ro["T_trace"][k], use_normals=(estimator == 0),
+                               coarse=(k < p.coarse_iterations and k < iters - 1))           # spec S4c
         assert np.array_equal(want, per_it[k]), f"iteration {k}: {(want != per_it[k]).sum()} indices differ"
 
 
@@ -213,7 +214,7 @@ def test_torch_dense_path_on_explicit_side_stream(gpu_lib):
     dev = torch.device("cuda", 0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
-        d_sums = torch.zeros(29, dtype=torch.int64, device=dev)
+        d_sums = torch.zeros(36, dtype=torch.int64, device=dev)
         with capi.IcpHandle(params) as hd:
             hd.set_clouds_host(0, s4, t4)
             got = dense.dense_align_device(hd, 1, 0, d_sums, force_collective=True)

@@ -194,10 +194,12 @@ def test_hip_path_on_real_kinect_frames(gpu_lib):
 
 @pytest.mark.gpu
 def test_hip_path_reproduces_the_scipy_only_goldens(gpu_lib):
-    """HIP == scipy with no oracle in between: tests/golden/independent_golden.json was written by the numpy / scipy restatement
-    ALONE (make_independent_golden.py: cKDTree + canonical re-evaluation, lstsq / SVD).  The full BASELINE config-2 loop --
-    640x480, 20 iterations, seeds 1000..1003 --, the reference's Kinect pair for 20 iterations and one iterate at config 5's
-    1280x960: the HIP path must produce the same index array (hash) and the same pose (lstsq vs fixed-point LDL^T: 1e-7)."""
+    """HIP == scipy with no oracle ANYWHERE in the chain: tests/golden/independent_golden.json was written by the numpy / scipy
+    restatement ALONE (make_independent_golden.py: whole-frame numpy.linalg.eigh normals -- round 4 --, cKDTree + canonical
+    re-evaluation, lstsq / SVD), and the HIP path starts from the same depth-derived clouds with its own k_normals.  The full
+    BASELINE config-2 loop -- 640x480, 20 iterations, seeds 1000..1003 --, the reference's Kinect pair for 20 iterations and
+    one iterate at config 5's 1280x960: the HIP path must produce the same index array (hash) and the same pose (lstsq vs
+    fixed-point LDL^T: 1e-7), from clouds and (the projective window search taking part) from the depth images."""
     from slam3d_gx_amd import capi
     import test_oracle_independent as R
     G = json.load(open(os.path.join(HERE, "golden", "independent_golden.json")))
@@ -207,9 +209,10 @@ def test_hip_path_reproduces_the_scipy_only_goldens(gpu_lib):
             continue
         pr, s4, t4 = R._case(c["seed"], c["width"], c["height"])
         with capi.IcpHandle(capi.default_params(pr.intr, estimator=c["estimator"], iterations=c["iterations"])) as h:
-            r = h.align(s4, t4)
-            idx, _ = h.get_correspondences(0)
-        assert hashlib.sha256(idx.astype("<i4").tobytes()).hexdigest() == c["idx_sha256"], (c["seed"], c["width"])
-        assert np.allclose(r["T_raw"], np.array(c["T_final"]), rtol=0, atol=1e-7) and r["inliers"] == c["inliers"]
+            for depth in (False, True):
+                r = h.align_depth_batch([pr.depth_src], [pr.depth_tgt])[0] if depth else h.align(s4, t4)
+                idx, _ = h.get_correspondences(0)
+                assert hashlib.sha256(idx.astype("<i4").tobytes()).hexdigest() == c["idx_sha256"], (c["seed"], c["width"], depth)
+                assert np.allclose(r["T_raw"], np.array(c["T_final"]), rtol=0, atol=1e-7) and r["inliers"] == c["inliers"]
         n += 1
     assert n >= 6

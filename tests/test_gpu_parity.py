@@ -238,7 +238,7 @@ def test_dense_mode_two_emulated_ranks(gpu_lib):
     assert np.array_equal(r1rank["T_raw"], ro["T_trace"][-1])
     # device-resident exchange buffer (what bench.py --mode dense runs over RCCL): same bits again
     import torch
-    d_sums = torch.zeros(29, dtype=torch.int64, device="cuda:0")
+    d_sums = torch.zeros(36, dtype=torch.int64, device="cuda:0")
     with capi.IcpHandle(capi.default_params(pr.intr, iterations=iters)) as h:
         h.set_clouds_host(0, s4, t4)
         rdev = dense.dense_align_device(h, 1, 0, d_sums, None, torch.cuda.current_stream().cuda_stream)
@@ -706,13 +706,16 @@ def test_depth_frames_with_and_without_the_projective_window_search(gpu_lib, siz
         rg = h.align_depth_batch([pr.depth_src], [pr.depth_tgt], None if Ti is None else [Ti])[0]
         idx, d2 = h.get_correspondences(0)
         Tt, St = h.get_trace(0)
-        mid = h.get_correspondences_at(2, 0)
+        mid, mid4 = h.get_correspondences_at(2, 0), h.get_correspondences_at(4, 0)
     assert np.array_equal(idx, ro["idx"]), int((idx != ro["idx"]).sum())
     assert np.array_equal(d2.view(np.uint32), ro["d2"].view(np.uint32))
     assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:iters], ro["sums_trace"])
     assert rg["inliers"] == ro["inliers"] and rg["status"] == ro["status"]
-    r1 = O.icp(s4, t4, O.params(pr.intr, nn_method=0, **{**kw, "iterations": 1}), T_init=ro["T_trace"][2])
-    assert np.array_equal(mid, r1["idx"])
+    # iteration 2 of a run is a coarse one (spec S4c): the sources of every fourth tile, at the trace pose
+    want, _, _ = O.nn_once(s4, t4, po, T=ro["T_trace"][2], use_normals=(estimator == 0), coarse=True)
+    assert np.array_equal(mid, want) and (mid >= 0).sum() < 0.4 * (idx >= 0).sum()
+    r1 = O.icp(s4, t4, O.params(pr.intr, nn_method=0, **{**kw, "iterations": 1}), T_init=ro["T_trace"][4])
+    assert np.array_equal(mid4, r1["idx"])
 
 
 def test_handles_of_different_geometry_side_by_side_and_slot_reuse(gpu_lib):
@@ -799,7 +802,7 @@ def test_full_640x480_baseline_md_workload(gpu_lib, seed):
             assert rg["inliers"] == ro["inliers"] and rg["status"] == ro["status"] == 0
             if trace:
                 for it in (0, 1, 2, 5, 10, 19):                   # index parity per iteration
-                    want, _, _ = O.nn_once(s4, t4, O.params(pr.intr, nn_method=1), T=ro["T_trace"][it], use_normals=True)
+                    want, _, _ = O.nn_once(s4, t4, O.params(pr.intr, nn_method=1), T=ro["T_trace"][it], use_normals=True, coarse=(it < 3))    # spec S4c
                     assert np.array_equal(h.get_correspondences_at(it), want), it
     rot_gt, tr_gt = O.pose_error(pr.T_gt, rg["T"])
     assert rot_gt < 1e-2 and tr_gt < 3e-2, (rot_gt, tr_gt)       # noise floor of THIS workload: six times the headline's sigma and only the near
@@ -809,7 +812,7 @@ def test_full_640x480_baseline_md_workload(gpu_lib, seed):
 def test_config5_dense_1280x960_eight_emulated_ranks(gpu_lib):
     """BASELINE config 5's 8-GPU leg as far as ONE device allows: the 1280x960 pair of seed 2000, 20
     iterations, source rows sharded over EIGHT ranks = eight handles on this GPU, each searching its row band against the
-    whole target; the per-iteration exchange is the integer sum of the ranks' 29-word partials (what ncclAllReduce(SUM) of
+    whole target; the per-iteration exchange is the integer sum of the ranks' 36-word partials (what ncclAllReduce(SUM) of
     int64 computes; here formed on the host).  Every rank ends with the same pose, bit-identical to the UNSHARDED run on
     the GPU and to the oracle; the ranks' index bands stitched together are the unsharded indices."""
     from slam3d_gx_amd import shard

@@ -116,16 +116,23 @@ def test_fit_planes_synthetic_room():
 
 
 def test_sums_are_fixed_point_integers_and_order_free():
-    """Spec S4 summation: every total is an exact multiple of 2^-32 (int64 fixed point), the count is an integer,
-    and a permuted / re-threaded evaluation gives the same bits (integer addition is associative)."""
+    """Spec S4 summation (round 4: integer Gram totals): every derived sum is an integer times its power of two -- A^T A
+    entries multiples of 2^-40 (the finest pair of scales: n n at 2^-20 each), A^T b of 2^-(20 + EB), sum b^2 of 2^-2EB, the
+    svd estimator's of 2^-32 --, the count is an integer, and a re-threaded evaluation gives the same bits (integer
+    addition is associative)."""
     pr = synth.make_pair(1003, 160, 120)
     s4 = synth.backproject_numpy(pr.depth_src, pr.intr)
     t4 = synth.backproject_numpy(pr.depth_tgt, pr.intr)
+    eb = 23                                                  # max_corr_dist 0.10 = 0.8 * 2^-3 -> 20 - (-3)
     for est in (0, 1):
         r1 = O.icp(s4, t4, O.params(pr.intr, estimator=est, iterations=3, threads=1))
         r5 = O.icp(s4, t4, O.params(pr.intr, estimator=est, iterations=3, threads=5))
         assert np.array_equal(r1["sums_trace"], r5["sums_trace"]) and np.array_equal(r1["T_trace"], r5["T_trace"])
-        q = r1["sums_trace"] * 4294967296.0
-        assert np.array_equal(q, np.rint(q)) and np.abs(q).max() < 2.0 ** 53          # exactly representable here
-        assert np.array_equal(r1["sums_trace"][:, 27], np.rint(r1["sums_trace"][:, 27]))
-        assert r1["inliers"] == int(r1["sums_trace"][-1, 27])
+        S = r1["sums_trace"]
+        unit = np.full(29, 2.0 ** 32)
+        if est == 0:
+            unit[:21] = 2.0 ** 40; unit[21:27] = 2.0 ** (20 + eb); unit[28] = 2.0 ** (2 * eb)
+        unit[27] = 1.0
+        q = S * unit
+        assert np.array_equal(q, np.rint(q)) and np.abs(q).max() < 2.0 ** 62
+        assert r1["inliers"] == int(S[-1, 27])

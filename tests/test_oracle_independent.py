@@ -64,11 +64,23 @@ def valid_mask(c4, zmax=7.0):
     return np.isfinite(x) & np.isfinite(y) & np.isfinite(z) & (z > 0) & (z <= np.float32(zmax))
 
 
-def nn_scipy(src4, tgt4, tgt_ok, T, gate, k=12):
+def coarse_mask(H, W):
+    """spec S4c: the source pixels that take part in a coarse iteration -- every fourth 8x8-pixel tile, staggered by rows"""
+    v, u = np.mgrid[0:H, 0:W]
+    return (((u >> 3) + 2 * (v >> 3)) & 3) == 0
+
+
+def is_coarse(k, iterations, coarse_iterations=3):
+    """spec S4c: iteration k of a run is coarse iff it is among the first coarse_iterations and not the run's last"""
+    return k < coarse_iterations and k < iterations - 1
+
+
+def nn_scipy(src4, tgt4, tgt_ok, T, gate, k=12, coarse=False):
     """exact 1-NN of spec S4 from cKDTree candidates; returns idx[N] (original target pixel index or -1)"""
     N = src4.shape[0] * src4.shape[1]
     s = src4.reshape(-1, 4)[:, :3]; t = tgt4.reshape(-1, 4)[:, :3]
-    sv = np.flatnonzero(valid_mask(src4).reshape(-1)); tv = np.flatnonzero(tgt_ok.reshape(-1))
+    src_ok = valid_mask(src4) & (coarse_mask(*src4.shape[:2]) if coarse else True)
+    sv = np.flatnonzero(src_ok.reshape(-1)); tv = np.flatnonzero(tgt_ok.reshape(-1))
     ps = transform_f32(T, s[sv])
     tree = cKDTree(t[tv].astype(np.float64))
     dist, cand = tree.query(ps.astype(np.float64), k=k)
@@ -100,6 +112,70 @@ def rows_point2plane(ps, sv, idx, tgt4, nrm4):
     A = np.concatenate([np.cross(p, n), n], axis=1)
     b = np.einsum("ij,ij->i", n, q - p)
     return A, b, p, q
+
+
+def b_exponent(gate):
+    """spec S4 (round 4): EB = 20 - k with gate = m 2^k, 0.5 <= m < 1"""
+    return 20 - int(np.frexp(float(gate))[1])
+
+
+def row_vectors(ps, sv, idx, tgt4, nrm4, estimator, gate):
+    """spec S4 (round 4): the 8-component INTEGER row vector of every correspondence, (n, 8) int64 --
+    point-to-plane (rint(a 2^16), rint(n 2^20), rint(b 2^EB), 1), a = p' x n, b = n . (q - p');  svd (rint(p' 2^16), rint(q 2^16), 0, 1)"""
+    m = idx[sv] >= 0
+    p = ps[m].astype(np.float64)
+    j = idx[sv][m]
+    q = tgt4.reshape(-1, 4)[j, :3].astype(np.float64)
+    V = np.zeros((len(p), 8), dtype=np.int64)
+    if estimator == 0:
+        n = nrm4.reshape(-1, 4)[j, :3].astype(np.float64)
+        a = np.stack([p[:, 1] * n[:, 2] - p[:, 2] * n[:, 1], p[:, 2] * n[:, 0] - p[:, 0] * n[:, 2], p[:, 0] * n[:, 1] - p[:, 1] * n[:, 0]], axis=1)
+        d = q - p
+        b = (n[:, 0] * d[:, 0] + n[:, 1] * d[:, 1]) + n[:, 2] * d[:, 2]
+        V[:, 0:3] = np.rint(a * 65536.0).astype(np.int64)
+        V[:, 3:6] = np.rint(n * 1048576.0).astype(np.int64)
+        V[:, 6] = np.rint(np.ldexp(b, b_exponent(gate))).astype(np.int64)
+    else:
+        V[:, 0:3] = np.rint(p * 65536.0).astype(np.int64)
+        V[:, 3:6] = np.rint(q * 65536.0).astype(np.int64)
+    V[:, 7] = 1
+    return V
+
+
+def gram_sums(V, estimator, gate):
+    """the 29 doubles the spec derives from the integer Gram matrix G = V^T V (exact int64 arithmetic)"""
+    G = V.T @ V                                     # int64 matmul: exact (every total is below 2^60)
+    f = lambda x, e: float(np.ldexp(np.float64(int(x)), -e))
+    s = np.zeros(29)
+    if estimator == 0:
+        e = [16, 16, 16, 20, 20, 20]
+        eb = b_exponent(gate)
+        k = 0
+        for r in range(6):
+            for c in range(r, 6):
+                s[k] = f(G[r, c], e[r] + e[c]); k += 1
+        for r in range(6):
+            s[21 + r] = f(G[r, 6], e[r] + eb)
+        s[27] = float(G[7, 7]); s[28] = f(G[6, 6], 2 * eb)
+    else:
+        for i in range(3):
+            s[i] = f(G[i, 7], 16); s[3 + i] = f(G[3 + i, 7], 16)
+        for r in range(3):
+            for c in range(3):
+                s[6 + 3 * r + c] = f(G[r, 3 + c], 32)
+        s[27] = float(G[7, 7])
+        s[28] = f(int(G[0, 0]) + int(G[1, 1]) + int(G[2, 2]) + int(G[3, 3]) + int(G[4, 4]) + int(G[5, 5]) - 2 * (int(G[0, 3]) + int(G[1, 4]) + int(G[2, 5])), 32)
+    return s
+
+
+def update_from_rows(V, estimator, gate, T):
+    """T_next from the quantised rows: numpy.linalg.lstsq on (A_q, b_q) / numpy.linalg.svd Kabsch on the quantised points"""
+    Vf = V.astype(np.float64)
+    if estimator == 0:
+        A = np.concatenate([Vf[:, 0:3] / 65536.0, Vf[:, 3:6] / 1048576.0], axis=1)
+        b = np.ldexp(Vf[:, 6], -b_exponent(gate))
+        return delta_point2plane(np.linalg.lstsq(A, b, rcond=None)[0]) @ T
+    return kabsch(Vf[:, 0:3] / 65536.0, Vf[:, 3:6] / 65536.0) @ T
 
 
 def delta_point2plane(x):
@@ -146,6 +222,53 @@ def normals_numpy(c4, pix, w=7, min_in=41, in_dist=0.01):
     return out
 
 
+def normals_numpy_full(c4, w=7, min_in=41, in_dist=0.01, band=32, zmax=7.0):
+    """spec S2 for a WHOLE frame, vectorised numpy + numpy.linalg.eigh -- no oracle code: (H, W, 4) float32 normals with the
+    planar flag in .w, and the eigenvalue ratio l1 / l0 of every window that had enough points.  Differences of algorithm
+    against oracle/icp_oracle.c: einsum moments in one go (the oracle: a sequential fma chain), eigh (the oracle: seven
+    squarings of the adjugate), the dominance rule from the eigenvalues (the oracle: ||M||_F^2 against tr(M)^2 of the
+    squared adjugate -- identical in exact arithmetic: 1 - ||M||_F^2 / tr(M)^2 = 2 (r1 + r2 + r1 r2) / (1 + r1 + r2)^2 with
+    r1 = (l0 / l1)^128, r2 = (l0 / l2)^128)."""
+    from numpy.lib.stride_tricks import sliding_window_view
+    H, W = c4.shape[:2]
+    r = w // 2
+    ok = valid_mask(c4, zmax)
+    P = np.zeros((H + 2 * r, W + 2 * r, 3), dtype=np.float64)
+    M = np.zeros((H + 2 * r, W + 2 * r), dtype=bool)
+    P[r:r + H, r:r + W] = np.where(ok[..., None], c4[..., :3].astype(np.float64), 0.0)
+    M[r:r + H, r:r + W] = ok
+    out = np.zeros((H, W, 4), dtype=np.float32)
+    ratio = np.full((H, W), np.inf)
+    for v0 in range(0, H, band):
+        v1 = min(H, v0 + band)
+        Pw = sliding_window_view(P[v0:v1 + 2 * r], (w, w), axis=(0, 1))      # (b, W, 3, w, w)
+        Mw = sliding_window_view(M[v0:v1 + 2 * r], (w, w), axis=(0, 1))      # (b, W, w, w)
+        c0 = P[v0 + r:v1 + r, r:r + W]
+        d = (Pw - c0[..., None, None]) * Mw[:, :, None]                       # relative to the centre point; invalid -> 0
+        n = Mw.sum(axis=(2, 3)).astype(np.float64)
+        cen = ok[v0:v1] & (n >= min_in)
+        nn = np.where(n > 0, n, 1.0)
+        m = d.sum(axis=(3, 4)) / nn[..., None]
+        C = np.einsum("bwixy,bwjxy->bwij", d, d) / nn[..., None, None] - m[..., :, None] * m[..., None, :]
+        evals, evecs = np.linalg.eigh(C)
+        l0, l1, l2 = np.abs(evals[..., 0]), evals[..., 1], evals[..., 2]
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore", under="ignore"):
+            r1 = np.where(l1 > 0, (l0 / l1) ** 128, np.inf)
+            r2 = np.where(l2 > 0, (l0 / l2) ** 128, np.inf)
+            defect = 2.0 * (r1 + r2 + r1 * r2) / (1.0 + r1 + r2) ** 2        # 1 - ||M||_F^2 / tr(M)^2 of the squared adjugate
+            dominant = defect <= 2.0 ** -40
+            ratio[v0:v1] = np.where(cen, l1 / np.maximum(l0, 1e-300), np.inf)
+        nv = evecs[..., 0]
+        flip = (nv * c0).sum(-1) > 0
+        nv = np.where(flip[..., None], -nv, nv)
+        e = np.einsum("bwixy,bwi->bwxy", d - m[..., None, None], nv)
+        cnt = ((np.abs(e) <= in_dist) & Mw).sum(axis=(2, 3))
+        good = cen & dominant & (cnt >= min_in)
+        out[v0:v1, :, :3] = np.where(good[..., None], nv, 0.0).astype(np.float32)
+        out[v0:v1, :, 3] = good
+    return out, ratio
+
+
 # ------------------------------------------------------------------------------------------------ the tests
 def _case(seed, w, h):
     """seed >= 0: the synthetic pair; seed -1: the reference's Kinect pair data/exp1/dep/1 -> dep/2 (tests/golden/kinect,
@@ -190,6 +313,38 @@ def test_normals_vs_numpy_eigh(seed, size):
     assert checked > 600 and planar > 200
 
 
+@pytest.mark.parametrize("seed,size,kw", [(1000, (640, 480), {}), (1001, (320, 240), {}),
+                                          (1000, (640, 480), dict(noise_sigma=0.0012, hole_block=8, hole_prob=0.25)), (-2, (640, 480), {})])
+def test_whole_frame_normals_vs_numpy_eigh(seed, size, kw):
+    """Round 4: with seven squarings and the dominance test, spec S2 is well defined -- a
+    window either has a direction of least variance to ~1e-12 or no normal at all -- so numpy.linalg.eigh must reproduce
+    the oracle's planar flags on EVERY pixel of a frame and the float normals bit for bit (a last-bit difference needs the
+    double to sit within ~1e-12 of a float rounding boundary: allowed on a handful of components, none seen on these
+    frames).  Cases: the headline workload, BASELINE.md's (sigma = 0.0012 z^2 + 8x8 holes, where 4 % of the flagged
+    windows have l1 / l0 below 2), and the reference's Kinect frame bin/dep_1.png (seed -2)."""
+    if seed == -2:
+        from PIL import Image
+        d = np.array(Image.open(os.path.join(HERE, "golden", "kinect", "bin_dep_1.png"))).astype(np.uint16)
+        intr = synth.Intrinsics()
+        t4 = synth.backproject_numpy(d, intr)
+    else:
+        pr = synth.make_pair(seed, *size, **kw)
+        intr = pr.intr
+        t4 = synth.backproject_numpy(pr.depth_tgt, intr)
+    got = O.normals(t4, O.params(intr))
+    ref, ratio = normals_numpy_full(t4)
+    fo, fn = got[..., 3] > 0.5, ref[..., 3] > 0.5
+    assert fo.sum() > 0.1 * fo.size * (0.5 if kw else 1.0)
+    assert np.array_equal(fo, fn), f"{(fo != fn).sum()} planar flags differ"
+    assert ratio[fo].min() > 1.2                                   # what carries a normal has a well-defined direction
+    # (x + 0.0 turns -0.0 into +0.0: an exactly fronto-parallel window -- constant quantised depth -- gives (+-0, +-0, -1), and the
+    # sign of a zero changes no product, sum or comparison downstream)
+    diff = ((got[..., :3] + np.float32(0)).view(np.uint32) != (ref[..., :3] + np.float32(0)).view(np.uint32)) & fo[..., None]
+    assert diff.sum() <= 3, f"{diff.sum()} float components differ"
+    dots = (got[..., :3].astype(np.float64) * ref[..., :3].astype(np.float64)).sum(-1)[fo]
+    assert dots.min() > 1 - 1e-6
+
+
 @pytest.mark.parametrize("seed,size,estimator", [(1000, (320, 240), 0), (1001, (320, 240), 1), (1003, (160, 120), 0)])
 def test_every_iteration_against_scipy_restatement(seed, size, estimator):
     """For every iterate T_k of the oracle: the scipy NN gives the SAME indices as the oracle's NN at T_k, the explicit
@@ -202,29 +357,23 @@ def test_every_iteration_against_scipy_restatement(seed, size, estimator):
     tgt_ok = valid_mask(t4) & ((nrm[..., 3] > 0.5) if estimator == 0 else True)
     for k in range(iters):
         Tk = ro["T_trace"][k]
-        idx, ps, sv = nn_scipy(s4, t4, tgt_ok, Tk, p.max_corr_dist)
-        want, _, _ = O.nn_once(s4, t4, O.params(pr.intr, estimator=estimator, nn_method=0), T=Tk, use_normals=(estimator == 0))
+        cz = is_coarse(k, iters, p.coarse_iterations)
+        idx, ps, sv = nn_scipy(s4, t4, tgt_ok, Tk, p.max_corr_dist, coarse=cz)
+        want, _, _ = O.nn_once(s4, t4, O.params(pr.intr, estimator=estimator, nn_method=0), T=Tk, use_normals=(estimator == 0), coarse=cz)
         assert np.array_equal(idx, want), f"iteration {k}: {(idx != want).sum()} indices differ between scipy and the oracle"
         S = ro["sums_trace"][k]
-        if estimator == 0:
-            A, b, _, _ = rows_point2plane(ps, sv, idx, t4, nrm)
+        V = row_vectors(ps, sv, idx, t4, nrm, estimator, p.max_corr_dist)
+        # spec S4 (round 4): the sums are DERIVED from the exact integer Gram matrix of the quantised row vectors, so the numpy
+        # restatement (np.rint, int64 matmul, ldexp) must reproduce every one of the oracle's 29 doubles EXACTLY -- no tolerance
+        assert np.array_equal(S, gram_sums(V, estimator, p.max_corr_dist)), (k, np.abs(S - gram_sums(V, estimator, p.max_corr_dist)).max())
+        if estimator == 0:      # and the quantised sums are the plain double-precision ones to the quantisation bound
+            A, bb, _, _ = rows_point2plane(ps, sv, idx, t4, nrm)
             AtA = A.T @ A
             iu = np.triu_indices(6)
-            # the oracle's sums are fixed point (spec S4): every term is rounded to a multiple of 2^-32, so a sum of n
-            # terms is within n * 2^-33 of the exact one -- a rigorous bound, not a tolerance picked to pass
-            tol = len(b) * 2.0 ** -33 * 1.01 + 1e-12
-            assert np.abs(S[:21] - AtA[iu]).max() <= tol
-            assert np.abs(S[21:27] - A.T @ b).max() <= tol
-            assert S[27] == len(b) and abs(S[28] - b @ b) <= tol
-            x = np.linalg.lstsq(A, b, rcond=None)[0]
-            T_next = delta_point2plane(x) @ Tk
-        else:
-            m = idx[sv] >= 0
-            pp = ps[m].astype(np.float64); qq = t4.reshape(-1, 4)[idx[sv][m], :3].astype(np.float64)
-            tol = len(pp) * 2.0 ** -33 * 1.01 + 1e-9
-            assert S[27] == len(pp) and np.abs(S[:3] - pp.sum(0)).max() <= tol and np.abs(S[3:6] - qq.sum(0)).max() <= tol
-            assert np.abs(S[6:15] - (pp.T @ qq).reshape(9)).max() <= tol
-            T_next = kabsch(pp, qq) @ Tk
+            amax = np.abs(A).max()
+            assert np.abs(S[:21] - AtA[iu]).max() <= len(bb) * (2.0 ** -17 * 2 * amax + 2.0 ** -34) * 1.01
+            assert S[27] == len(bb) and abs(S[28] - bb @ bb) <= len(bb) * 2.0 ** -(b_exponent(p.max_corr_dist)) * 0.11
+        T_next = update_from_rows(V, estimator, p.max_corr_dist, Tk)
         assert np.allclose(T_next, ro["T_trace"][k + 1], rtol=0, atol=1e-9), (k, np.abs(T_next - ro["T_trace"][k + 1]).max())
     # and the last iteration's correspondences the oracle reports are those of T_{iters-1}
     idx_last, _, _ = nn_scipy(s4, t4, tgt_ok, ro["T_trace"][iters - 1], p.max_corr_dist)
@@ -240,9 +389,11 @@ def test_full_size_nn_against_scipy():
     nrm = O.normals(t4, p)
     tgt_ok = valid_mask(t4) & (nrm[..., 3] > 0.5)
     for k in (0, 5):
-        idx, _, _ = nn_scipy(s4, t4, tgt_ok, ro["T_trace"][k], p.max_corr_dist)
-        want, _, _ = O.nn_once(s4, t4, p, T=ro["T_trace"][k], use_normals=True)
+        cz = is_coarse(k, 6, p.coarse_iterations)
+        idx, _, _ = nn_scipy(s4, t4, tgt_ok, ro["T_trace"][k], p.max_corr_dist, coarse=cz)
+        want, _, _ = O.nn_once(s4, t4, p, T=ro["T_trace"][k], use_normals=True, coarse=cz)
         assert np.array_equal(idx, want)
+    assert (idx >= 0).sum() > 3.5 * (nn_scipy(s4, t4, tgt_ok, ro["T_trace"][0], p.max_corr_dist, coarse=True)[0] >= 0).sum()      # a coarse iteration uses a quarter
     assert np.array_equal(idx, ro["idx"])
 
 
