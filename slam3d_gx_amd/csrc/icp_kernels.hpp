@@ -1323,9 +1323,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     // spec S4c: in a coarse iteration only every fourth tile takes part (the others' waves own nothing: they still help to drain the
     // block's shared work); in the first full iteration after coarse ones those other tiles start like a run's first iteration
     bool first = it == 0;
-    if (cmode != 0 && t < tg.ntiles) {
-        const bool in_pattern = coarse_tile_id(t, tg);
-        if (cmode == 1 && !in_pattern) {
+    if (cmode == 1) {
+        if (t < tg.ntiles && !coarse_tile_id(t, tg)) {
             if (write_out) {            // (only a traced run asks for a coarse iteration's correspondences: none for this tile)
                 const nn_static_ptr S0 = SS();
                 const size_t g0 = (size_t)b * tg.nslots + (size_t)t * TILE_SLOTS + (threadIdx.x & 63);
@@ -1333,8 +1332,19 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             }
             t = tg.ntiles;
         }
-        first = first || (cmode == 2 && !in_pattern);
-    }
+        if constexpr (COOP) {
+            // A coarse launch is a quarter of the tiles with the widest searches of a run: its length is the serial instruction
+            // stream of its heaviest owners (a 10 cm ball at 2 m meets ~50 target tiles), and what shortens that is more waves per
+            // owner.  So the participating tiles are dealt ONE per block -- active tile number c + w G of the raster enumeration
+            // below, i.e. wave 0 of block c for every frame whose grid has at least as many blocks as active tiles -- and the block's
+            // other three waves own nothing and drain its items.  (Any assignment gives the same bits.)
+            const int n_even = (tg.ntx + 3) >> 2, n_odd = (tg.ntx + 1) >> 2;        // tiles per even / odd tile row: tx = 0, 4, .. / 2, 6, ..
+            const int A = c + w * (int)gridDim.x;
+            const int pr = A / (n_even + n_odd), rem = A - pr * (n_even + n_odd);
+            const int ty = rem < n_even ? 2 * pr : 2 * pr + 1, tx = rem < n_even ? 4 * rem : 2 + 4 * (rem - n_even);
+            t = ty < tg.nty ? ty * tg.ntx + tx : tg.ntiles;
+        }
+    } else if (cmode == 2 && t < tg.ntiles) first = first || !coarse_tile_id(t, tg);
     const bool has_tile = t < tg.ntiles;
     const long long cw0 = COOP ? 0 : clock64();         // per-tile cost: input of k_balance (throughput build only)
     float4 *__restrict__ st = stage_all[w];
