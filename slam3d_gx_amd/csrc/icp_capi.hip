@@ -1505,8 +1505,10 @@ extern "C" int slam3d_icp_dense_update(slam3d_icp_handle *h, const int64_t sums[
     memcpy(h->pin_out, sums, sizeof(int64_t) * NRAW);           // pin_out holds (16+36)*maxB 8-byte words
     HIPCHK(h, hipMemcpyAsync(h->sums, h->pin_out, sizeof(int64_t) * NRAW, hipMemcpyHostToDevice, s));
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
-    hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, s, h->sums, h->Tcur, h->trace_T, h->trace_S, h->flags, 1, h->dense_it,
-                       iters, h->p.estimator, h->g.eb);
+    if (h->p.estimator == SLAM3D_EST_POINT2PLANE)
+        hipLaunchKernelGGL(k_solve<0>, dim3(1), dim3(64), 0, s, h->sums, h->Tcur, h->trace_T, h->trace_S, h->flags, h->dense_it, iters, h->g.eb);
+    else
+        hipLaunchKernelGGL(k_solve<1>, dim3(1), dim3(64), 0, s, h->sums, h->Tcur, h->trace_T, h->trace_S, h->flags, h->dense_it, iters, h->g.eb);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(s));   // pin_out is reused by the next call
     h->dense_it++;
@@ -1535,8 +1537,10 @@ extern "C" int slam3d_icp_dense_update_device(slam3d_icp_handle *h, const int64_
     if (!h->ran || h->dense_it >= iters) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
-    hipLaunchKernelGGL(k_solve, dim3(1), dim3(64), 0, s, reinterpret_cast<const long long *>(d_sums), h->Tcur, h->trace_T, h->trace_S, h->flags, 1, h->dense_it,
-                       iters, h->p.estimator, h->g.eb);
+    if (h->p.estimator == SLAM3D_EST_POINT2PLANE)
+        hipLaunchKernelGGL(k_solve<0>, dim3(1), dim3(64), 0, s, reinterpret_cast<const long long *>(d_sums), h->Tcur, h->trace_T, h->trace_S, h->flags, h->dense_it, iters, h->g.eb);
+    else
+        hipLaunchKernelGGL(k_solve<1>, dim3(1), dim3(64), 0, s, reinterpret_cast<const long long *>(d_sums), h->Tcur, h->trace_T, h->trace_S, h->flags, h->dense_it, iters, h->g.eb);
     HIPCHK(h, hipGetLastError());
     h->dense_it++;
     return SLAM3D_OK;

@@ -2497,7 +2497,7 @@ __device__ __forceinline__ double wave_solve_point2plane(const double *tot, cons
 __device__ __forceinline__ void wave_solve_update_point2plane(const double *tot, const double *sh, double *__restrict__ Tcur_b,
                                                               double *__restrict__ trace_T_b, double *__restrict__ trace_S_b,
                                                               int *__restrict__ flag_b, int it, double *__restrict__ res_rec /* nullable */,
-                                                              const PairPtrs &pp)
+                                                              const PairPtrs *pp /* read only with res_rec */)
 {
     const int lane = threadIdx.x & 63;
     if (lane < NSUMS) trace_S_b[(size_t)it * NSUMS + lane] = tot[lane];
@@ -2515,7 +2515,7 @@ __device__ __forceinline__ void wave_solve_update_point2plane(const double *tot,
     if (res_rec) {
         if (lane < 16) res_rec[lane] = Tn;
         if (lane < NSUMS) res_rec[16 + lane] = tot[lane];
-        if (lane == 0) { res_rec[45] = (double)flag; res_rec[46] = (double)pp.src_counts[0]; res_rec[47] = (double)pp.tgt_counts[1]; }
+        if (lane == 0) { res_rec[45] = (double)flag; res_rec[46] = (double)pp->src_counts[0]; res_rec[47] = (double)pp->tgt_counts[1]; }
     }
 }
 
@@ -2557,7 +2557,7 @@ __global__ __launch_bounds__(64) void k_solve_acc(long long *__restrict__ acc, l
     if constexpr (EST == 0) {                 // point-to-plane: the whole wave solves (lane-parallel LDL^T, no scratch)
         if (do_solve)
             wave_solve_update_point2plane(tot, Tsh, Tcur + b * 16, trace_T + (size_t)b * (iters + 1) * 16, trace_S + (size_t)b * iters * NSUMS,
-                                          flags + b, it, (res_host && it == iters - 1) ? res_host + (size_t)b * RES_REC : nullptr, pairs[b]);
+                                          flags + b, it, (res_host && it == iters - 1) ? res_host + (size_t)b * RES_REC : nullptr, pairs + b);
         if (k == 0) stamp_end(stamp, b);
         return;
     }
@@ -2574,17 +2574,26 @@ __global__ __launch_bounds__(64) void k_solve_acc(long long *__restrict__ acc, l
     if (k == 0) stamp_end(stamp, b);
 }
 
-// dense mode: solve from externally reduced sums (one thread per pair)
-__global__ void k_solve(const long long *__restrict__ sums_all, double *__restrict__ Tcur,
-                        double *__restrict__ trace_T, double *__restrict__ trace_S,
-                        int *__restrict__ flags, int B, int it, int iters, int estimator, int eb)
+// dense mode, three-step exchange: solve from externally reduced (all-reduced) integer Gram totals.  grid (B), block 64: the
+// point-to-plane estimator solves with the whole wave like k_solve_acc (the one-thread form took 128 VGPRs, 72 spills and 272 B
+// of scratch), the svd estimator in lane 0.
+template <int EST>
+__global__ __launch_bounds__(64) void k_solve(const long long *__restrict__ sums_all, double *__restrict__ Tcur,
+                                              double *__restrict__ trace_T, double *__restrict__ trace_S,
+                                              int *__restrict__ flags, int it, int iters, int eb)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    double sums[NSUMS];
-    for (int k = 0; k < NSUMS; ++k) sums[k] = derive_sum(estimator, eb, k, sums_all + (size_t)b * NRAW);     // from the all-reduced integer Gram totals
-    solve_update_one(sums, Tcur + b * 16, trace_T + (size_t)b * (iters + 1) * 16, trace_S + (size_t)b * iters * NSUMS,
-                     flags + b, it, estimator);
+    __shared__ double tot[32], Tsh[16];
+    const int b = blockIdx.x, k = threadIdx.x;
+    if (k < NSUMS) tot[k] = derive_sum(EST, eb, k, sums_all + (size_t)b * NRAW);
+    if (k < 16) Tsh[k] = Tcur[b * 16 + k];
+    __syncthreads();
+    if constexpr (EST == 0) {
+        wave_solve_update_point2plane(tot, Tsh, Tcur + b * 16, trace_T + (size_t)b * (iters + 1) * 16, trace_S + (size_t)b * iters * NSUMS,
+                                      flags + b, it, nullptr, nullptr);
+    } else {
+        if (k == 0)
+            solve_update_one(tot, Tcur + b * 16, trace_T + (size_t)b * (iters + 1) * 16, trace_S + (size_t)b * iters * NSUMS, flags + b, it, EST);
+    }
 }
 
 // slot-order correspondences -> original pixel order (for get_correspondences)

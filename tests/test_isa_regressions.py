@@ -1,0 +1,93 @@
+"""Build-level regression checks on the gfx950 ISA of the shipped kernels (CPU only: hipcc cross-compiles without a GPU).
+
+Two hipcc (ROCm 7.2, clang 22) miscompiles are worked around in slam3d_gx_amd/csrc/icp_kernels.hpp; a compiler upgrade can
+un-fix or re-break either silently, and the GPU parity suite would only notice as a hang or a wild load.  These tests look
+at the generated code itself.  Each names the GPU parity test that exercises the construct.
+"""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from slam3d_gx_amd import build as B  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def device_asm(tmp_path_factory):
+    out = tmp_path_factory.mktemp("isa") / "dev.s"
+    flags = [f for f in B.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
+    subprocess.check_call([B.hipcc()] + flags + ["--cuda-device-only", "-S", os.path.join(B.CSRC, "icp_capi.hip"), "-o", str(out)])
+    return out.read_text()
+
+
+def _kernel_bodies(asm):
+    """mangled name -> text between its label and its .end_amdhsa_kernel / s_endpgm block"""
+    bodies = {}
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\s*\.section\s+\.rodata", asm, re.S | re.M):
+        bodies[m.group(1)] = m.group(2)
+    return bodies
+
+
+def _meta(asm):
+    recs, cur = [], None
+    for line in asm.splitlines():
+        if re.match(r"  - \.\w+:", line):
+            cur = {}
+            recs.append(cur)
+        m = re.match(r"\s+(?:- )?\.(\w+):\s+(.*)", line)
+        if m and cur is not None:
+            cur[m.group(1)] = m.group(2).strip()
+    return {r["name"]: r for r in recs if r.get("name", "").startswith("_Z")}
+
+
+def _coop_production(names):
+    # k_nn_tiles_acc<3, 7, true (COOP), false (DBG), false (GATED)>: Itanium mangling ...ILi3ELi7ELb1ELb0ELb0EE...
+    return [n for n in names if "k_nn_tiles_acc" in n and "ILi3ELi7ELb1ELb0ELb0EE" in n]
+
+
+def test_lds_fetch_add_uniform_stays_one_exec_masked_block(device_asm):
+    """lds_fetch_add_uniform: `if (lane == 0) old = atomicAdd(p, v); old = readfirstlane(old)` inside the drain loops was
+    restructured by hipcc so that lanes != 0 spun in an inner loop with lane 0 masked off (the cooperative build hung).  The
+    fix is one opaque asm block: exec = lane 0, ds_add_rtn_u32, wait, restore.  It must reach the ISA as exactly that sequence
+    in the cooperative kernel, once per call site (cell items, tile items, the two claim counters).
+    Parity test of the construct: tests/test_gpu_parity.py::test_full_640x480_config2 (every launch drains through it)."""
+    bodies = _kernel_bodies(device_asm)
+    coop = _coop_production(bodies)
+    assert len(coop) == 1, coop
+    body = bodies[coop[0]]
+    blocks = re.findall(r"s_mov_b64 (s\[\d+:\d+\]), exec\n\s*s_mov_b64 exec, 1\n\s*ds_add_rtn_u32 v\d+, v\d+, v\d+\n\s*s_waitcnt lgkmcnt\(0\)\n\s*s_mov_b64 exec, \1", body)
+    assert len(blocks) >= 4, f"{len(blocks)} intact fetch-and-add blocks in the cooperative kernel"
+    # no other LDS returning add except the two end-of-block stamp counters (stamp_wave_end: outside any loop): the fragile
+    # source form of a drain-loop claim would show up as one more bare ds_add_rtn_u32
+    assert body.count("ds_add_rtn_u32") - len(blocks) <= 2
+
+
+def test_tile_item_mask_survives_in_front_of_the_record_address(device_asm):
+    """A tile item is (owner << 24 | tile); the tile id is masked with 0xffffff before it is scaled to the record address (a
+    64-bit multiply-add).  hipcc once dropped such a mask when the masked value also fed a 24-bit multiply (tools/attic,
+    the cross-block sharing experiment): a wild load.  The mask must be in the ISA of the cooperative kernel's phase B.
+    Parity test of the construct: tests/test_gpu_parity.py::test_randomised_configurations_stay_bit_identical."""
+    bodies = _kernel_bodies(device_asm)
+    body = bodies[_coop_production(bodies)[0]]
+    assert re.search(r"[sv]_and_b32 \w+(\[\d+\])?, (0xffffff, \w+|\w+, 0xffffff)", body), "the 24-bit tile mask is gone"
+
+
+def test_production_search_kernels_have_no_scratch_and_use_the_fp64_matrix_cores(device_asm):
+    """The production instances of k_nn_tiles_acc (cooperative and throughput build) keep their register budget -- 72 / 64
+    VGPRs at 7 / 8 waves per SIMD, no scratch --, and the epilogue's Gram accumulation is eight v_mfma_f64_16x16x4_f64 (spec
+    S4, round 4); the full-scan mode's 64 v_mfma_f32_16x16x4_f32 are there too.
+    Parity: tests/test_gpu_parity.py::test_every_nn_mode_is_bit_identical."""
+    meta = _meta(device_asm)
+    bodies = _kernel_bodies(device_asm)
+    prod = [n for n in meta if "k_nn_tiles_acc" in n and "Lb0ELb0EE" in n]         # <.., DBG = false, GATED = false>
+    assert len(prod) == 2, prod
+    for n in prod:
+        assert int(meta[n]["private_segment_fixed_size"]) == 0 and int(meta[n]["vgpr_spill_count"]) == 0, (n, meta[n])
+        assert int(meta[n]["vgpr_count"]) <= 72
+        assert bodies[n].count("v_mfma_f64_16x16x4") == 8, bodies[n].count("v_mfma_f64_16x16x4")
+    mf = [n for n in bodies if "k_nn_mfma" in n]
+    assert len(mf) == 1 and bodies[mf[0]].count("v_mfma_f32_16x16x4") >= 64
