@@ -327,7 +327,8 @@ def bruteforce_leg(capi, intr, est, s4, t4, local_rank, iterations=4):
     contraction on the f32 MFMA pipe (k_nn_mfma); the fp32-VALU scan (k_nn_valu) is timed beside it."""
     out = {}
     for mode, name in ((capi.NN_BRUTE_MFMA, "mfma"), (capi.NN_BRUTE_VALU, "valu")):
-        params = capi.default_params(intr, estimator=est, iterations=iterations, max_batch=1, device=local_rank, nn_mode=mode)
+        # (coarse_iterations = 0: every launch scans every source against every target -- the N x M contraction the flop count assumes)
+        params = capi.default_params(intr, estimator=est, iterations=iterations, max_batch=1, device=local_rank, nn_mode=mode, coarse_iterations=0)
         with capi.IcpHandle(params) as h:
             h.set_clouds_host(0, s4, t4)
             h.set_profiling(True)

@@ -723,9 +723,11 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
     } else {
         if (nn_mode_of(h) == SLAM3D_NN_BRUTE_MFMA) {
             // one wave per block; target slices so that a pair alone still gives every SIMD several waves
-            int msplit = (8 * 1024 + (h->N / MF_Q) * B - 1) / ((h->N / MF_Q) * B);
+            // (24 k waves: three resident per SIMD make eight rounds -- with 8 k the last of three rounds ran 3/4 empty: 95.6 -> 100 TFLOP/s)
+            int msplit = (24 * 1024 + (h->N / MF_Q) * B - 1) / ((h->N / MF_Q) * B);
             if (msplit < 1) msplit = 1;
-            if (msplit > 16) msplit = 16;
+            if (msplit > 32) msplit = 32;
+            if (getenv("SLAM3D_MFMA_SPLIT")) msplit = std::max(1, std::min(64, atoi(getenv("SLAM3D_MFMA_SPLIT"))));      // developer knob
             hipLaunchKernelGGL(k_nn_mfma, dim3((h->N + MF_Q - 1) / MF_Q, msplit, B), dim3(64), 0, s, h->d_pairs, h->src_c, h->tgt_c,
                                h->tgtB, h->qmax2, h->ccounts, h->prevq, h->Tcur, h->best, h->g, tg, h->npad, 0.5f * h->g.zmax,
                                msplit, first);
