@@ -310,7 +310,7 @@ def cpu_baseline_leg(pair, s4, t4, iterations, est, gpu_result, gpu_idx, brute_s
         O.nn_once(s4, t4, p_br, T=None, use_normals=(est == 0))
         t_br = time.perf_counter() - t0
         out["bruteforce_value"] = 1.0 / t_br
-        out["bruteforce_sample"] = f"cpu_A: literal brute-force NN scan (canonical fp32 arithmetic), all {cores} threads, one pass"
+        out["bruteforce_sample"] = f"cpu_A: literal brute-force NN scan (canonical fp32 arithmetic), {min(cores, 32)} threads (the oracle's default team), one pass"
     parity = None
     if gpu_result is not None:
         rot, tr = O.pose_error(ro["T_trace"][-1], gpu_result["T_raw"])

@@ -45,7 +45,12 @@ void orc_default_params(orc_params *p)
 static int n_threads(const orc_params *p)
 {
 #ifdef _OPENMP
-    return p->threads > 0 ? p->threads : omp_get_max_threads();
+    /* threads <= 0: "all that help" -- at most 32.  Measured on the 256-thread GPU host (tools/cpu_scaling.py): 198 it/s on 16
+     * threads, 184 on 32, 68 on 128 and THREE on 256 (a team as large as the machine is oversubscribed by the process's other
+     * threads, and libgomp's spinning barriers then cost ~100 ms per region); round 3's default was every hardware thread. */
+    if (p->threads > 0) return p->threads;
+    const int m = omp_get_max_threads();
+    return m > 32 ? 32 : m;
 #else
     (void)p; return 1;
 #endif
@@ -166,53 +171,59 @@ int orc_smallest_evec3(const double C[6], double n[3])
     return 1;
 }
 
-/* ------------------------------------------------------------- S2 normals */
-static void normal_at(const float *xyz4, int W, int H, int u, int v, int r,
-                      float zmax, int min_in, double in_dist, float *out)
+/* ------------------------------------------------------------- S2 normals
+ * Spec S2 (round 4b: integer window moments).  Every valid pixel's coordinates are quantised once, Xq = rintf(x * 2^16) (float
+ * arithmetic: an exact scaling, then round to nearest even -- an integer below 2^20).  For a valid pixel, over the valid pixels of
+ * its w x w window: n, S1 = sum Xq, S2 = sum Xq Xq^T -- exact integers, so any summation order gives the same values (the GPU runs
+ * them as a box filter) --; n >= normal_min_inliers; C' = n S2 - S1 S1^T (every entry an exact integer below 2^53); the direction of
+ * least variance of C' by orc_smallest_evec3, turned toward the camera against the centre's quantised coordinates; stored as float
+ * nf.  Planar iff at least normal_min_inliers valid window pixels satisfy, in float arithmetic,
+ *     |fmaf(nf.z, Zq, fmaf(nf.y, Yq, nf.x * Xq)) - dqf| <= (float)(normal_inlier_dist * 2^16),
+ * dqf = (float)((nx (S1x / n) + ny (S1y / n)) + nz (S1z / n)) with inv = 1.0 / n, S1x * inv ... in double: the LS plane through the
+ * window mean.  (Rounds 1-3: fp64 moments about the centre point accumulated in raster order with fused multiply-adds, and the
+ * inlier test in double on the unquantised coordinates.) */
+static void normal_at(const float *q4 /* quantised frame: (Xq, Yq, Zq, valid) */, int W, int H, int u, int v, int r,
+                      int min_in, double in_dist, float *out)
 {
     out[0] = out[1] = out[2] = out[3] = 0.0f;
-    const float *c0 = xyz4 + 4 * ((size_t)v * W + u);
-    if (!point_valid(c0, zmax)) return;
-    const double cx0 = c0[0], cy0 = c0[1], cz0 = c0[2];
-    int n = 0;
-    double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+    const float *c0 = q4 + 4 * ((size_t)v * W + u);
+    if (!(c0[3] > 0.5f)) return;
+    int64_t n = 0, sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
     for (int dv = -r; dv <= r; ++dv)
         for (int du = -r; du <= r; ++du) {
             const int uu = u + du, vv = v + dv;
             if (uu < 0 || uu >= W || vv < 0 || vv >= H) continue;
-            const float *q = xyz4 + 4 * ((size_t)vv * W + uu);
-            if (!point_valid(q, zmax)) continue;
-            const double dx = (double)q[0] - cx0, dy = (double)q[1] - cy0, dz = (double)q[2] - cz0;
-            ++n;
-            sx += dx; sy += dy; sz += dz;
-            /* spec S2 (round 3): the second moments accumulate with fused multiply-adds (one rounding per term) */
-            sxx = fma(dx, dx, sxx); sxy = fma(dx, dy, sxy); sxz = fma(dx, dz, sxz);
-            syy = fma(dy, dy, syy); syz = fma(dy, dz, syz); szz = fma(dz, dz, szz);
+            const float *q = q4 + 4 * ((size_t)vv * W + uu);
+            if (!(q[3] > 0.5f)) continue;
+            const int64_t x = (int64_t)q[0], y = (int64_t)q[1], z = (int64_t)q[2];
+            ++n; sx += x; sy += y; sz += z;
+            sxx += x * x; sxy += x * y; sxz += x * z; syy += y * y; syz += y * z; szz += z * z;
         }
     if (n < min_in) return;
-    const double inv = 1.0 / (double)n;
-    const double mx = sx * inv, my = sy * inv, mz = sz * inv;
     double C[6];
-    C[0] = sxx * inv - mx * mx; C[1] = sxy * inv - mx * my; C[2] = sxz * inv - mx * mz;
-    C[3] = syy * inv - my * my; C[4] = syz * inv - my * mz; C[5] = szz * inv - mz * mz;
+    C[0] = (double)(n * sxx - sx * sx); C[1] = (double)(n * sxy - sx * sy); C[2] = (double)(n * sxz - sx * sz);
+    C[3] = (double)(n * syy - sy * sy); C[4] = (double)(n * syz - sy * sz); C[5] = (double)(n * szz - sz * sz);
     double nv[3];
-    if (!orc_smallest_evec3(C, nv)) return;
+    const int have = orc_smallest_evec3(C, nv);
+    if (!have) return;
     double nx = nv[0], ny = nv[1], nz = nv[2];
-    if (nx * cx0 + ny * cy0 + nz * cz0 > 0.0) { nx = -nx; ny = -ny; nz = -nz; } /* toward camera */
-    /* the LS plane passes through the window mean c0 + m: its offset along n, in camera coordinates */
-    const double dq = ((nx * cx0 + ny * cy0) + nz * cz0) + ((nx * mx + ny * my) + nz * mz);
+    if ((nx * (double)c0[0] + ny * (double)c0[1]) + nz * (double)c0[2] > 0.0) { nx = -nx; ny = -ny; nz = -nz; } /* toward camera */
+    const double inv = 1.0 / (double)n;
+    const float dqf = (float)((nx * ((double)sx * inv) + ny * ((double)sy * inv)) + nz * ((double)sz * inv));
+    const float nxf = (float)nx, nyf = (float)ny, nzf = (float)nz;
+    const float thr = (float)(in_dist * 65536.0);
     int cnt = 0;
     for (int dv = -r; dv <= r; ++dv)
         for (int du = -r; du <= r; ++du) {
             const int uu = u + du, vv = v + dv;
             if (uu < 0 || uu >= W || vv < 0 || vv >= H) continue;
-            const float *q = xyz4 + 4 * ((size_t)vv * W + uu);
-            if (!point_valid(q, zmax)) continue;
-            const double e = fma(nz, (double)q[2], fma(ny, (double)q[1], nx * (double)q[0])) - dq;
-            if (fabs(e) <= in_dist) ++cnt;
+            const float *q = q4 + 4 * ((size_t)vv * W + uu);
+            if (!(q[3] > 0.5f)) continue;
+            const float e = fmaf(nzf, q[2], fmaf(nyf, q[1], nxf * q[0])) - dqf;
+            if (fabsf(e) <= thr) ++cnt;
         }
     if (cnt < min_in) return;
-    out[0] = (float)nx; out[1] = (float)ny; out[2] = (float)nz; out[3] = 1.0f;
+    out[0] = nxf; out[1] = nyf; out[2] = nzf; out[3] = 1.0f;
 }
 
 void orc_normals(const float *xyz4, const orc_params *p, float *nrm4)
@@ -221,11 +232,19 @@ void orc_normals(const float *xyz4, const orc_params *p, float *nrm4)
     const float zmax = (float)p->z_filter;
     const int nt = n_threads(p);
     (void)nt;
+    float *q4 = malloc(sizeof(float) * 4 * (size_t)W * H);
+#pragma omp parallel for schedule(static) num_threads(nt)
+    for (int i = 0; i < W * H; ++i) {
+        const float *c = xyz4 + 4 * (size_t)i;
+        float *q = q4 + 4 * (size_t)i;
+        if (point_valid(c, zmax)) { q[0] = rintf(c[0] * 65536.0f); q[1] = rintf(c[1] * 65536.0f); q[2] = rintf(c[2] * 65536.0f); q[3] = 1.0f; }
+        else { q[0] = q[1] = q[2] = q[3] = 0.0f; }
+    }
 #pragma omp parallel for schedule(static) num_threads(nt)
     for (int v = 0; v < H; ++v)
         for (int u = 0; u < W; ++u)
-            normal_at(xyz4, W, H, u, v, r, zmax, p->normal_min_inliers, p->normal_inlier_dist,
-                      nrm4 + 4 * ((size_t)v * W + u));
+            normal_at(q4, W, H, u, v, r, p->normal_min_inliers, p->normal_inlier_dist, nrm4 + 4 * ((size_t)v * W + u));
+    free(q4);
 }
 
 /* ------------------------------------------------------------ spec sincos
@@ -494,7 +513,7 @@ static void kd_build(kdtree *t, const clist *pts, int nt)
     if (pts->n > 0) {
         /* a small team: the tree has ~n / 4096 tasks, and libgomp's task queue is one lock per team -- with 256 threads
          * spinning on it the build took seconds (measured on the 256-thread GPU host) */
-        const int team = nt > 16 ? 16 : nt;
+        const int team = nt > 32 ? 32 : nt;       /* (the default team of every other region: no resizing of libgomp's pool between regions) */
         (void)team;
 #pragma omp parallel num_threads(team)
 #pragma omp single

@@ -270,6 +270,8 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
         g.proj_c = (float)((p->fx > p->fy ? p->fx : p->fy) * sqrt(1.0 + am * am + bm * bm) * 1.001);
         h->proj_search = !(getenv("SLAM3D_PROJ_SEARCH") && atoi(getenv("SLAM3D_PROJ_SEARCH")) == 0);
     }
+    g.cert_m = getenv("SLAM3D_CERT_M") ? (float)atof(getenv("SLAM3D_CERT_M")) : CERT_M;                       // developer knobs (exact for any value)
+    g.cert_track = getenv("SLAM3D_CERT_TRACK") ? (float)atof(getenv("SLAM3D_CERT_TRACK")) : CERT_TRACK_MOTION;
     g.resid2 = p->max_plane_residual2 > 0.0f ? p->max_plane_residual2 : 0.0f;
     g.min_ncos = p->min_normal_cos > 0.0f ? p->min_normal_cos : 0.0f;
     g.estimator = p->estimator;

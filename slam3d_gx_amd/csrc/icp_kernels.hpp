@@ -114,6 +114,7 @@ struct Geometry {
     float proj_c;                  // projective window search: pixels of radius r around a query's projection cover every target
                                    // closer than (r + 0.49) * z / proj_c  (= fmax * sqrt(1 + amax^2 + bmax^2) * 1.001), DESIGN.md 5
     int estimator;
+    float cert_m, cert_track;      // clearance certificates: margin added to every pruning radius / pose motion below which a launch tracks (CERT_M, CERT_TRACK_MOTION)
     int eb;                        // spec S4: the residual component of a row vector is rint(b * 2^eb), eb = 20 - k with gate = m 2^k, 0.5 <= m < 1
     double b_scale;                // 2^eb
     double fx, fy, cx, cy, factor, zf;
@@ -239,33 +240,63 @@ __device__ __forceinline__ bool smallest_evec3(const Sym3 &C, double &nx, double
 }
 
 // ------------------------------------------------------------------------------------ S2
-// one thread per target pixel; the (32+2r)x(8+2r) neighbourhood of a 32x8 pixel block is staged
-// in LDS once (coalesced float4 rows), then each thread walks its window twice (moments, inliers).
+// Spec S2 (round 4b: INTEGER window moments).  Every valid pixel's coordinates are quantised once, Xq = rintf(x * 2^16) (15 um; an
+// integer below 2^20, exact in float); a window's moments n, S1 = sum Xq, S2 = sum Xq Xq^T over its valid pixels are exact integers,
+// hence order-free, hence a BOX FILTER: column sums of seven rows, then row sums of seven columns -- 14 additions per moment
+// instead of 49 (rounds 1-3 accumulated fp64 moments about the centre point in raster order: 880 of the kernel's ~1,750 VALU
+// operations per pixel).  C' = n S2 - S1 S1^T (= n^2 2^32 x the covariance, every entry an exact integer below 2^53) goes through
+// smallest_evec3; the planar test runs on the quantised coordinates in fp32:
+//     |fmaf(nf.z, Zq, fmaf(nf.y, Yq, nf.x * Xq)) - dqf| <= (float)(in_dist * 2^16)
+// with nf the float normal that is stored and dqf = (float)((nx S1x/n + ny S1y/n) + nz S1z/n), n / S1 in double.
+// oracle/icp_oracle.c::normal_at is the same sequence of operations; tests/test_oracle_independent.py::normals_numpy_full the
+// numpy.linalg.eigh restatement of it.
+// One thread per target pixel, 32 x 8 pixels per block.  The (32+2r) x (8+2r) quantised neighbourhood is staged in LDS; phase V: one
+// work item per (neighbourhood column, output row) sums the 2r+1 rows below it -> LDS (64 B: n and S1 as int32, S2 as six
+// doubles); phase H: every thread adds the 2r+1 column sums of its window, solves, and walks the window once for the inliers.
 constexpr int NRM_BX = 32, NRM_BY = 8, NRM_RMAX = 4;
+struct NrmColSum { int n, sx, sy, sz; double sxx, sxy, sxz, syy, syz, szz; };      // 64 bytes
 
-// RT > 0: window radius known at compile time (the default 7x7 window: loops unrolled, LDS offsets immediate);
-// RT == 0: radius from g.win_r.  Invalid neighbours are not branched around: their coordinates are replaced by the
-// centre's, so they add exact zeros to every sum (no accumulator can be -0.0: all start at +0.0), and a lane mask
-// keeps them out of the counts -- the same bits as the skip, one LDS read per neighbour and no divergence.
 template <int RT>
 __global__ __launch_bounds__(NRM_BX * NRM_BY) void k_normals(FrameTasks a, Geometry g)
 {
     __shared__ float4 tile[(NRM_BY + 2 * NRM_RMAX) * (NRM_BX + 2 * NRM_RMAX)];
+    __shared__ NrmColSum colsum[NRM_BY * (NRM_BX + 2 * NRM_RMAX)];
     const float4 *__restrict__ cloud = a.t[blockIdx.z].cloud;
     float4 *__restrict__ nrm = a.t[blockIdx.z].nrm;
     const int r = RT > 0 ? RT : g.win_r;
-    constexpr int UN = RT > 0 ? 2 * RT + 1 : 1;       // one window row per trip of the outer loop
+    constexpr int UN = RT > 0 ? 2 * RT + 1 : 1;
     const int tw = NRM_BX + 2 * r, th = NRM_BY + 2 * r;
     const int u0 = blockIdx.x * NRM_BX - r, v0 = blockIdx.y * NRM_BY - r;
     const int tid = threadIdx.y * NRM_BX + threadIdx.x;
-    const float qnan = __int_as_float(0x7fc00000);
     for (int k = tid; k < tw * th; k += NRM_BX * NRM_BY) {
         const int ty = k / tw, tx = k - ty * tw;
         const int uu = u0 + tx, vv = v0 + ty;
-        float4 q = make_float4(qnan, qnan, qnan, 0.0f);
-        if (uu >= 0 && uu < g.W && vv >= 0 && vv < g.H) q = cloud[(size_t)vv * g.W + uu];
-        q.w = pt_valid(q.x, q.y, q.z, g.zmax) ? 1.0f : 0.0f;
+        float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);          // an invalid pixel adds zeros everywhere (w = 0: not counted)
+        if (uu >= 0 && uu < g.W && vv >= 0 && vv < g.H) {
+            const float4 c = cloud[(size_t)vv * g.W + uu];
+            if (pt_valid(c.x, c.y, c.z, g.zmax)) q = make_float4(rintf(c.x * 65536.0f), rintf(c.y * 65536.0f), rintf(c.z * 65536.0f), 1.0f);
+        }
         tile[k] = q;
+    }
+    __syncthreads();
+    // ---- phase V: (column tx of the neighbourhood, output row oy) -> sums over the rows oy .. oy + 2r
+    for (int k = tid; k < tw * NRM_BY; k += NRM_BX * NRM_BY) {
+        const int oy = k / tw, tx = k - oy * tw;
+        int n = 0;
+        double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+#pragma unroll UN
+        for (int dv = 0; dv <= 2 * r; ++dv) {
+            const float4 q = tile[(oy + dv) * tw + tx];
+            const double x = q.x, y = q.y, z = q.z;               // integers below 2^20: every product and sum below is exact
+            n += (int)q.w;
+            sx += x; sy += y; sz += z;
+            sxx = __fma_rn(x, x, sxx); sxy = __fma_rn(x, y, sxy); sxz = __fma_rn(x, z, sxz);
+            syy = __fma_rn(y, y, syy); syz = __fma_rn(y, z, syz); szz = __fma_rn(z, z, szz);
+        }
+        NrmColSum cs;
+        cs.n = n; cs.sx = (int)sx; cs.sy = (int)sy; cs.sz = (int)sz;
+        cs.sxx = sxx; cs.sxy = sxy; cs.sxz = sxz; cs.syy = syy; cs.syz = syz; cs.szz = szz;
+        colsum[k] = cs;
     }
     __syncthreads();
     const int u = blockIdx.x * NRM_BX + threadIdx.x, v = blockIdx.y * NRM_BY + threadIdx.y;
@@ -274,42 +305,37 @@ __global__ __launch_bounds__(NRM_BX * NRM_BY) void k_normals(FrameTasks a, Geome
     const float4 *__restrict__ win = tile + threadIdx.y * tw + threadIdx.x;      // top-left corner of this pixel's window
     const float4 c0 = win[r * tw + r];
     if (c0.w > 0.5f) {
-        const double cx0 = c0.x, cy0 = c0.y, cz0 = c0.z;
-        int n = 0;
-        double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
-#pragma unroll 1
-        for (int dv = 0; dv <= 2 * r; ++dv)
+        // ---- phase H: the window's moments = the 2r+1 column sums of its row
+        int n = 0, isx = 0, isy = 0, isz = 0;
+        double sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+        const NrmColSum *__restrict__ cs = colsum + threadIdx.y * tw + threadIdx.x;
 #pragma unroll UN
-            for (int du = 0; du <= 2 * r; ++du) {
-                const float4 q = win[dv * tw + du];
-                const bool ok = q.w > 0.5f;
-                const double dx = (double)(ok ? q.x : c0.x) - cx0, dy = (double)(ok ? q.y : c0.y) - cy0, dz = (double)(ok ? q.z : c0.z) - cz0;
-                n += ok ? 1 : 0;
-                sx += dx; sy += dy; sz += dz;
-                sxx = __fma_rn(dx, dx, sxx); sxy = __fma_rn(dx, dy, sxy); sxz = __fma_rn(dx, dz, sxz);       // (spec S2, round 3: fused)
-                syy = __fma_rn(dy, dy, syy); syz = __fma_rn(dy, dz, syz); szz = __fma_rn(dz, dz, szz);
-            }
+        for (int du = 0; du <= 2 * r; ++du) {
+            n += cs[du].n; isx += cs[du].sx; isy += cs[du].sy; isz += cs[du].sz;
+            sxx += cs[du].sxx; sxy += cs[du].sxy; sxz += cs[du].sxz; syy += cs[du].syy; syz += cs[du].syz; szz += cs[du].szz;
+        }
         if (n >= g.min_in) {
-            const double inv = 1.0 / (double)n;
-            const double mx = sx * inv, my = sy * inv, mz = sz * inv;
-            Sym3 C;
-            C.a00 = sxx * inv - mx * mx; C.a01 = sxy * inv - mx * my; C.a02 = sxz * inv - mx * mz;
-            C.a11 = syy * inv - my * my; C.a12 = syz * inv - my * mz; C.a22 = szz * inv - mz * mz;
+            const double dn = (double)n, sx = (double)isx, sy = (double)isy, sz = (double)isz;
+            Sym3 C;                                               // n S2 - S1 S1^T: exact integers below 2^53
+            C.a00 = dn * sxx - sx * sx; C.a01 = dn * sxy - sx * sy; C.a02 = dn * sxz - sx * sz;
+            C.a11 = dn * syy - sy * sy; C.a12 = dn * syz - sy * sz; C.a22 = dn * szz - sz * sz;
             double nx, ny, nz;
             const bool have = smallest_evec3(C, nx, ny, nz);
-            if (nx * cx0 + ny * cy0 + nz * cz0 > 0.0) { nx = -nx; ny = -ny; nz = -nz; }
-            // the LS plane passes through the window mean c0 + m: its offset along n, in camera coordinates
-            const double dq = ((nx * cx0 + ny * cy0) + nz * cz0) + ((nx * mx + ny * my) + nz * mz);
+            if ((nx * (double)c0.x + ny * (double)c0.y) + nz * (double)c0.z > 0.0) { nx = -nx; ny = -ny; nz = -nz; }      // toward the camera
+            const double inv = 1.0 / dn;
+            const float dqf = (float)((nx * (sx * inv) + ny * (sy * inv)) + nz * (sz * inv));      // the LS plane passes through the window mean
+            const float nxf = (float)nx, nyf = (float)ny, nzf = (float)nz;
+            const float thr = (float)(g.in_dist * 65536.0);
             int cnt = 0;
 #pragma unroll 1
             for (int dv = 0; dv <= 2 * r; ++dv)
 #pragma unroll UN
                 for (int du = 0; du <= 2 * r; ++du) {
                     const float4 q = win[dv * tw + du];
-                    const double e = __fma_rn(nz, (double)q.z, __fma_rn(ny, (double)q.y, nx * (double)q.x)) - dq;
-                    cnt += (q.w > 0.5f && fabs(e) <= g.in_dist) ? 1 : 0;       // NaN coordinates of an invalid point: e = NaN, not counted either way
+                    const float e = __fmaf_rn(nzf, q.z, __fmaf_rn(nyf, q.y, nxf * q.x)) - dqf;
+                    cnt += (q.w > 0.5f && fabsf(e) <= thr) ? 1 : 0;
                 }
-            if (have && cnt >= g.min_in) out = make_float4((float)nx, (float)ny, (float)nz, 1.0f);
+            if (have && cnt >= g.min_in) out = make_float4(nxf, nyf, nzf, 1.0f);
         }
     }
     nrm[(size_t)v * g.W + u] = out;
@@ -1426,8 +1452,8 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                                fabsf(uni_f(head_T[4 * r + 2]) - uni_f(prev_T[4 * r + 2])));
             mt = fmaxf(mt, fabsf(uni_f(head_T[4 * r + 3]) - uni_f(prev_T[4 * r + 3])));
         }
-        trk = mv * g.zmax + mt < CERT_TRACK_MOTION;
-        cm = trk ? CERT_M : 0.0f;
+        trk = mv * g.zmax + mt < g.cert_track;
+        cm = trk ? g.cert_m : 0.0f;
     }
 
     // ---- "current query" context: the wave's own tile in step 1, an item's owner in step 3
@@ -2120,7 +2146,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             const bool real = (unsigned int)bkey != 0xffffffffu;                    // a match (else: nothing within the gate)
             const float other = real ? (u1 == bsc ? sec : bsc) : bsc;
             const float base = __builtin_amdgcn_sqrtf(real ? u1 : g.gate2);
-            cnew = fminf(__builtin_amdgcn_sqrtf(other), base + CERT_M) * (1.0f - 1.0e-6f) - base * (1.0f + 1.0e-6f) - 1.0e-9f;
+            cnew = fminf(__builtin_amdgcn_sqrtf(other), base + cm) * (1.0f - 1.0e-6f) - base * (1.0f + 1.0e-6f) - 1.0e-9f;
             int cb = cum_bits;
             asm volatile("" : "+s"(cb));                                  // (keeps the doubling down here: hoisted, it costs a VGPR across the drain)
             cnew = cnew > 0.0f ? (cnew + 2.0f * __int_as_float(cb)) * (1.0f - 1.0e-6f) : -1.0f;      // recorded relative to the tile's motion total (rounded down)

@@ -198,9 +198,11 @@ def kabsch(p, q):
 
 
 def normals_numpy(c4, pix, w=7, min_in=41, in_dist=0.01):
-    """spec S2 for the listed pixels: (unit normal toward the camera, planar flag), by numpy eigh"""
+    """spec S2 for the listed pixels: (unit normal toward the camera, planar flag, eigenvalues), by numpy eigh on the integer
+    window moments (round 4b)"""
     H, W = c4.shape[:2]
     ok = valid_mask(c4)
+    Xq = np.rint(c4[..., :3] * np.float32(65536.0)).astype(np.float32)
     r = w // 2
     out = []
     for i in pix:
@@ -208,48 +210,53 @@ def normals_numpy(c4, pix, w=7, min_in=41, in_dist=0.01):
         if not ok[v, u]:
             out.append((None, False)); continue
         v0, v1, u0, u1 = max(0, v - r), min(H, v + r + 1), max(0, u - r), min(W, u + r + 1)
-        win = c4[v0:v1, u0:u1, :3][ok[v0:v1, u0:u1]].astype(np.float64)
-        if len(win) < min_in:
+        win = Xq[v0:v1, u0:u1][ok[v0:v1, u0:u1]].astype(np.int64)
+        n = len(win)
+        if n < min_in:
             out.append((None, False)); continue
-        d = win - c4[v, u, :3].astype(np.float64)
-        C = np.cov(d.T, bias=True)
+        S1 = win.sum(0); S2 = win.T @ win
+        C = (n * S2 - np.outer(S1, S1)).astype(np.float64)
         evals, evecs = np.linalg.eigh(C)
-        n = evecs[:, 0]
-        if n @ c4[v, u, :3].astype(np.float64) > 0:
-            n = -n
-        e = (d - d.mean(0)) @ n
-        out.append((n, bool((np.abs(e) <= in_dist).sum() >= min_in), evals))
+        nvec = evecs[:, 0]
+        if nvec @ Xq[v, u].astype(np.float64) > 0:
+            nvec = -nvec
+        nf = nvec.astype(np.float32)
+        dqf = np.float32((nvec[0] * (S1[0] * (1.0 / n)) + nvec[1] * (S1[1] * (1.0 / n))) + nvec[2] * (S1[2] * (1.0 / n)))
+        wf = win.astype(np.float32)
+        e = fma32(np.full(n, nf[2]), wf[:, 2], fma32(np.full(n, nf[1]), wf[:, 1], nf[0] * wf[:, 0])) - dqf
+        out.append((nvec, bool((np.abs(e) <= np.float32(in_dist * 65536.0)).sum() >= min_in), evals))
     return out
 
 
 def normals_numpy_full(c4, w=7, min_in=41, in_dist=0.01, band=32, zmax=7.0):
-    """spec S2 for a WHOLE frame, vectorised numpy + numpy.linalg.eigh -- no oracle code: (H, W, 4) float32 normals with the
-    planar flag in .w, and the eigenvalue ratio l1 / l0 of every window that had enough points.  Differences of algorithm
-    against oracle/icp_oracle.c: einsum moments in one go (the oracle: a sequential fma chain), eigh (the oracle: seven
-    squarings of the adjugate), the dominance rule from the eigenvalues (the oracle: ||M||_F^2 against tr(M)^2 of the
-    squared adjugate -- identical in exact arithmetic: 1 - ||M||_F^2 / tr(M)^2 = 2 (r1 + r2 + r1 r2) / (1 + r1 + r2)^2 with
-    r1 = (l0 / l1)^128, r2 = (l0 / l2)^128)."""
+    """spec S2 (round 4b: integer window moments) for a WHOLE frame, vectorised numpy + numpy.linalg.eigh -- no oracle code:
+    (H, W, 4) float32 normals with the planar flag in .w, and the eigenvalue ratio l1 / l0 of every window that had enough
+    points.  Differences of algorithm against oracle/icp_oracle.c: int64 einsum moments in one go (the oracle: a loop), eigh of
+    C' = n S2 - S1 S1^T (the oracle: seven squarings of the adjugate), the dominance rule from the eigenvalues (the oracle:
+    ||M||_F^2 against tr(M)^2 of the squared adjugate -- identical in exact arithmetic: 1 - ||M||_F^2 / tr(M)^2 =
+    2 (r1 + r2 + r1 r2) / (1 + r1 + r2)^2 with r1 = (l0 / l1)^128, r2 = (l0 / l2)^128)."""
     from numpy.lib.stride_tricks import sliding_window_view
     H, W = c4.shape[:2]
     r = w // 2
     ok = valid_mask(c4, zmax)
-    P = np.zeros((H + 2 * r, W + 2 * r, 3), dtype=np.float64)
+    Xq = np.where(ok[..., None], np.rint(c4[..., :3] * np.float32(65536.0)), np.float32(0)).astype(np.float32)      # rintf(x * 2^16): integers below 2^20
+    P = np.zeros((H + 2 * r, W + 2 * r, 3), dtype=np.int64)
     M = np.zeros((H + 2 * r, W + 2 * r), dtype=bool)
-    P[r:r + H, r:r + W] = np.where(ok[..., None], c4[..., :3].astype(np.float64), 0.0)
+    P[r:r + H, r:r + W] = Xq.astype(np.int64)
     M[r:r + H, r:r + W] = ok
     out = np.zeros((H, W, 4), dtype=np.float32)
     ratio = np.full((H, W), np.inf)
+    thr = np.float32(in_dist * 65536.0)
     for v0 in range(0, H, band):
         v1 = min(H, v0 + band)
-        Pw = sliding_window_view(P[v0:v1 + 2 * r], (w, w), axis=(0, 1))      # (b, W, 3, w, w)
+        Pw = sliding_window_view(P[v0:v1 + 2 * r], (w, w), axis=(0, 1))      # (b, W, 3, w, w) int64, zeros where invalid
         Mw = sliding_window_view(M[v0:v1 + 2 * r], (w, w), axis=(0, 1))      # (b, W, w, w)
-        c0 = P[v0 + r:v1 + r, r:r + W]
-        d = (Pw - c0[..., None, None]) * Mw[:, :, None]                       # relative to the centre point; invalid -> 0
-        n = Mw.sum(axis=(2, 3)).astype(np.float64)
+        c0 = P[v0 + r:v1 + r, r:r + W].astype(np.float64)
+        n = Mw.sum(axis=(2, 3)).astype(np.int64)
         cen = ok[v0:v1] & (n >= min_in)
-        nn = np.where(n > 0, n, 1.0)
-        m = d.sum(axis=(3, 4)) / nn[..., None]
-        C = np.einsum("bwixy,bwjxy->bwij", d, d) / nn[..., None, None] - m[..., :, None] * m[..., None, :]
+        S1 = Pw.sum(axis=(3, 4))                                               # exact integers
+        S2 = np.einsum("bwixy,bwjxy->bwij", Pw, Pw)
+        C = (n[..., None, None] * S2 - S1[..., :, None] * S1[..., None, :]).astype(np.float64)      # exact: every entry below 2^53
         evals, evecs = np.linalg.eigh(C)
         l0, l1, l2 = np.abs(evals[..., 0]), evals[..., 1], evals[..., 2]
         with np.errstate(divide="ignore", invalid="ignore", over="ignore", under="ignore"):
@@ -261,10 +268,16 @@ def normals_numpy_full(c4, w=7, min_in=41, in_dist=0.01, band=32, zmax=7.0):
         nv = evecs[..., 0]
         flip = (nv * c0).sum(-1) > 0
         nv = np.where(flip[..., None], -nv, nv)
-        e = np.einsum("bwixy,bwi->bwxy", d - m[..., None, None], nv)
-        cnt = ((np.abs(e) <= in_dist) & Mw).sum(axis=(2, 3))
+        nn = np.where(n > 0, n, 1).astype(np.float64)
+        mean = S1.astype(np.float64) * (1.0 / nn)[..., None]
+        dqf = ((nv[..., 0] * mean[..., 0] + nv[..., 1] * mean[..., 1]) + nv[..., 2] * mean[..., 2]).astype(np.float32)
+        nf = nv.astype(np.float32)
+        Pf = Pw.astype(np.float32)                                              # the quantised coordinates as floats (exact)
+        bc = lambda a: np.broadcast_to(a[..., None, None], Pf[:, :, 0].shape)
+        e = fma32(bc(nf[..., 2]), Pf[:, :, 2], fma32(bc(nf[..., 1]), Pf[:, :, 1], bc(nf[..., 0]) * Pf[:, :, 0])) - bc(dqf)
+        cnt = ((np.abs(e) <= thr) & Mw).sum(axis=(2, 3))
         good = cen & dominant & (cnt >= min_in)
-        out[v0:v1, :, :3] = np.where(good[..., None], nv, 0.0).astype(np.float32)
+        out[v0:v1, :, :3] = np.where(good[..., None], nf, np.float32(0))
         out[v0:v1, :, 3] = good
     return out, ratio
 
