@@ -704,6 +704,9 @@ def dense_leg(args, torch, dist, capi, synth, world, rank, local_rank, comm, wid
 
 def main():
     args = parse_args()
+    # the CPU baseline's OpenMP team must not keep spinning on the host's cores after its leg (libgomp's idle threads busy-wait
+    # by default, and the legs that follow are driven from this process's Python threads): read when libgomp is first loaded
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")
     import torch
     import torch.distributed as dist
     from slam3d_gx_amd import capi, synth
