@@ -3,7 +3,11 @@
 copy of the measured file, not a transcription.  usage: tools/fill_design.py profiles/r04_bench.json [n_gpu_tests] [normals_us]"""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+txt = open(sys.argv[1]).read()
+try:
+    d = json.loads(txt)
+except Exception:
+    d = json.loads([l for l in txt.splitlines() if l.startswith("{")][-1])
 k = lambda v: f"{v / 1e3:.1f} k"
 per = d["nn_ms_per_iteration"]
 rp = d.get("real_pair", {})
