@@ -243,6 +243,10 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
         const double ty = (p->fy > 0.0) ? fmax(p->cy, p->height - 1 - p->cy) / p->fy : 1.0;
         const double r2 = p->z_filter * p->z_filter * (1.0 + tx * tx + ty * ty);
         if (!((double)p->width * p->height * r2 < 268435456.0)) return SLAM3D_E_INVALID;
+        // spec S4 (round 4): a wave's 64-row Gram sums run on the fp64 matrix cores and are converted with a 2^51 magic number:
+        // 64 (r 2^16)^2 < 2^51  <=>  r^2 < 2^13 (r < 90 m); the global totals of the n.n and a.n entries need N < 2^22 and N r < 2^26
+        if (!(r2 < 8192.0) || !((double)p->width * p->height < 4194304.0) || !((double)p->width * p->height * sqrt(r2) < 67108864.0))
+            return SLAM3D_E_INVALID;
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device < 0 || p->device >= ndev) return SLAM3D_E_NODEVICE;

@@ -89,6 +89,18 @@ def test_create_fails_loudly_without_device_or_with_bad_params():
     with pytest.raises(capi.Slam3dError) as e:
         capi.IcpHandle(p)
     assert e.value.code == -1
+    # spec S4 (round 4): a wave's Gram sums must stay below 2^51 -- the farthest valid point below 90 m whatever the image size
+    from slam3d_gx_amd import synth
+    p = capi.default_params(synth.Intrinsics.scaled(64, 48))
+    p.z_filter = 80.0                       # 64 x 48 x (80 m x 1.25)^2 < 2^28 passes the total-range test; r = 100 m does not pass the wave test
+    with pytest.raises(capi.Slam3dError) as e:
+        capi.IcpHandle(p)
+    assert e.value.code == -1
+    p = capi.default_params()
+    p.coarse_iterations = -1
+    with pytest.raises(capi.Slam3dError) as e:
+        capi.IcpHandle(p)
+    assert e.value.code == -1
 
 
 def test_match_planes_is_exact_nearest_neighbour_without_gpu():
