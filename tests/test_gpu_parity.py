@@ -883,3 +883,28 @@ def test_config4_shape_eight_ranks_of_64_pairs_on_one_device(gpu_lib, tmp_path):
         ro = O.icp(s4, t4, O.params(pr.intr, iterations=20, nn_method=1))
         assert np.array_equal(np.array(tab["T"][k]).reshape(4, 4), ro["T_trace"][-1]), k
         assert tab["inliers"][k] == ro["inliers"], k
+
+
+@pytest.mark.parametrize("coarse,iters", [(0, 6), (1, 6), (5, 6), (3, 1), (3, 2), (9, 4)])
+@pytest.mark.parametrize("batch", [1, 9])
+def test_coarse_iteration_counts_and_short_runs(gpu_lib, coarse, iters, batch):
+    """Spec S4c for other settings than the default three: no coarse iteration at all, more coarse iterations than the run
+    has (every iteration but the last is coarse then), runs of one and two iterations -- on the cooperative build (one pair
+    per launch) and the throughput build (nine), with depth inputs (window search) and an initial guess for one pair: every
+    iterate, the sums and the last indices equal the oracle's."""
+    prs = [synth.make_pair(4100 + i, 200, 150, holes=True) for i in range(batch)]
+    intr = prs[0].intr
+    Ti = np.stack([synth.pose_from_seed(9 + i, 1.5, 0.03) if i % 2 else np.eye(4) for i in range(batch)])
+    kw = dict(iterations=iters, coarse_iterations=coarse)
+    with capi.IcpHandle(capi.default_params(intr, max_batch=batch, **kw)) as h:
+        res = h.align_depth_batch([p.depth_src for p in prs], [p.depth_tgt for p in prs], Ti)
+        got = [(h.get_trace(b), h.get_correspondences(b)[0]) for b in range(batch)]
+    for b in (0, batch - 1):
+        po = O.params(intr, nn_method=0, **kw)
+        s4, t4 = O.backproject(prs[b].depth_src, po), O.backproject(prs[b].depth_tgt, po)
+        ro = O.icp(s4, t4, po, T_init=Ti[b])
+        (Tt, St), idx = got[b]
+        assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:iters], ro["sums_trace"]), (coarse, iters, b)
+        assert np.array_equal(idx, ro["idx"]) and res[b]["inliers"] == ro["inliers"] and res[b]["status"] == ro["status"]
+    if iters >= 2 and coarse >= 1:      # the first iteration really was a coarse one: about a quarter of the rows
+        assert St[0][27] < 0.45 * St[-1][27]
