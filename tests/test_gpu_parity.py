@@ -908,3 +908,24 @@ def test_coarse_iteration_counts_and_short_runs(gpu_lib, coarse, iters, batch):
         assert np.array_equal(idx, ro["idx"]) and res[b]["inliers"] == ro["inliers"] and res[b]["status"] == ro["status"]
     if iters >= 2 and coarse >= 1:      # the first iteration really was a coarse one: about a quarter of the rows
         assert St[0][27] < 0.45 * St[-1][27]
+
+
+@pytest.mark.parametrize("window,min_in", [(3, 7), (5, 20), (9, 60)])
+def test_other_normal_windows_than_7x7(gpu_lib, window, min_in):
+    """Spec S2 with the window radius taken at run time (k_normals<0>: the 7x7 default has its own unrolled instance): 3x3, 5x5
+    and 9x9 windows (9 = the largest the staging supports), frames with holes and an odd size -- normals and planar flags
+    bit-identical to the oracle, and a short alignment on top of them too."""
+    pr, s4, t4 = _pair(5200 + window, 200, 150, holes=True)
+    kw = dict(normal_window=window, normal_min_inliers=min_in, iterations=5)
+    po = O.params(pr.intr, nn_method=0, **kw)
+    n_or = O.normals(t4, po)
+    ro = O.icp(s4, t4, po)
+    with capi.IcpHandle(capi.default_params(pr.intr, **kw)) as h:
+        r = h.align(s4, t4)
+        _, _, n_gpu = h.get_clouds(0, normals=True)
+        idx, _ = h.get_correspondences(0)
+        Tt, St = h.get_trace(0)
+    assert (n_or[..., 3] > 0.5).sum() > 2000
+    assert np.array_equal(n_gpu.view(np.uint32), n_or.view(np.uint32))
+    assert np.array_equal(idx, ro["idx"]) and np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:5], ro["sums_trace"])
+    assert r["inliers"] == ro["inliers"]
