@@ -122,8 +122,10 @@ typedef struct slam3d_icp_handle slam3d_icp_handle;
 
 /* ---- lifecycle --------------------------------------------------------------------------- */
 void        slam3d_icp_default_params(slam3d_icp_params *p);
-/* SLAM3D_E_INVALID also when width*height*(z_filter*sqrt(1+tan^2))^2 >= 2^28: the normal-equation sums and plane moments
- * are int64 fixed point and such a configuration could overflow them (640x480 at z_filter 7 m is 11 times below).
+/* SLAM3D_E_INVALID also when width*height*(z_filter*sqrt(1+tan^2))^2 >= 2^28: the normal-equation totals (the integer Gram
+ * matrix of DESIGN.md spec S4) and the plane moments are int64 and such a configuration could overflow them (640x480 at
+ * z_filter 7 m is 11 times below); likewise when the farthest valid point is 90 m or more away, or the image has 2^22 pixels
+ * or more (a wavefront's Gram sums must stay exact on the fp64 matrix cores).
  * A process may hold 256 handles at a time (each owns an entry of the search kernel's constant table); SLAM3D_E_NOMEM beyond. */
 int         slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle **out);
 void        slam3d_icp_destroy(slam3d_icp_handle *h);
@@ -335,9 +337,10 @@ const char *slam3d_comm_last_error(const slam3d_comm *c);
 void slam3d_shard_range(int32_t n, int32_t world, int32_t rank, int32_t *begin, int32_t *end);
 
 /* BASELINE config 5: ONE pair whose source rows are sharded over the ranks of `comm` (NULL = one rank).  Slot 0 of
- * every rank's handle holds the same pair.  Per iteration: NN + accumulate on the local rows -> ncclAllReduce(SUM)
- * of the 29 int64 fixed-point sums on the handle's stream -> the same solve on every rank; no host
- * synchronisation until the result.  Integer sums are order-free: the pose is bit-identical for any world size. */
+ * every rank's handle holds the same pair.  Per iteration: NN + accumulate on the local rows -> ONE in-place
+ * ncclAllReduce(SUM) of the iteration's int64 accumulator set (the 36 Gram totals in 16 replicas) on the handle's stream -> the
+ * same solve on every rank at the head of the next launch; no host synchronisation until the result.  Integer sums are
+ * order-free: the pose is bit-identical for any world size. */
 int slam3d_icp_dense_run(slam3d_icp_handle *h, slam3d_comm *comm, const double *T_init, slam3d_icp_result *out);
 
 /* BASELINE configs 3/4: pairs are independent, the only exchange is the gather of the SE(3) pose records. */
