@@ -1175,6 +1175,23 @@ def extra_legs(args, torch, dist, capi, synth, local_rank, est, handles, pools, 
         finally:
             for hh in khandles:
                 hh.close()
+    # ---- (ii-d) the same stream with TWO pairs per launch sequence (still four sequences in flight): what the per-launch fixed
+    # costs are worth -- a settled launch costs 22 us before any lane searches and a second pair shares it.
+    # Not the headline: config 2 is one pair per sequence.
+    p2 = capi.default_params(intr, estimator=est, iterations=args.iterations, max_batch=2, device=local_rank)
+    h2 = [capi.IcpHandle(p2) for _ in handles]
+    st2 = Streamer(h2, pools, 2)
+    st2.run(16)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k2 = 384
+    st2.run(k2)
+    torch.cuda.synchronize()
+    v2 = 2 * k2 * args.iterations / (time.perf_counter() - t0)
+    out["two_pairs_per_launch"] = {"value": v2, "ratio_to_headline": v2 / out["value"], "alignments": k2, "pairs_per_launch": 2,
+                                   "note": f"same streaming regime, two pairs per launch sequence, {len(h2)} sequences in flight"}
+    for hh in h2:
+        hh.close()
     # ---- (iii) BASELINE config 3: 64 pairs per launch sequence
     P3 = 64
     pool3 = Pool(torch, synth, [args.seed0 + k for k in range(P3)], args.width, args.height, args.noise_sigma)
