@@ -29,7 +29,9 @@ from slam3d_gx_amd import synth                          # noqa: E402
 # for 20 iterations, and one iterate at config 5's 1280x960, all by the scipy restatement alone.
 CASES = [(1000, 160, 120, 0, 10), (1001, 160, 120, 1, 10), (1002, 320, 240, 0, 10), (1003, 320, 240, 1, 8),
          (1000, 640, 480, 0, 20), (1001, 640, 480, 0, 20), (1002, 640, 480, 0, 20), (1003, 640, 480, 0, 20),
-         (-1, 640, 480, 0, 20), (2000, 1280, 960, 0, 1)]
+         (-1, 640, 480, 0, 20), (2000, 1280, 960, 0, 1),
+         # round 4: BASELINE.md section 4's own workload (sigma = 0.0012 z^2, 8x8-pixel holes at p = 0.25) and the svd estimator at full size
+         (1000, 640, 480, 0, 20, "baseline_md"), (1001, 640, 480, 1, 20)]
 
 
 def icp_numpy(s4, t4, intr, estimator, iterations, gate=0.10):
@@ -45,11 +47,13 @@ def icp_numpy(s4, t4, intr, estimator, iterations, gate=0.10):
 
 def main():
     out = {"_comment": "written by tests/golden/make_independent_golden.py from the numpy/scipy restatement alone", "cases": []}
-    for seed, w, h, est, iters in CASES:
-        pr, s4, t4 = R._case(seed, w, h)
+    for case in CASES:
+        seed, w, h, est, iters = case[:5]
+        workload = case[5] if len(case) > 5 else None
+        pr, s4, t4 = R._case(seed, w, h, workload)
         idx, T = icp_numpy(s4, t4, pr.intr, est, iters)
         rot = np.arccos(np.clip((np.trace(np.linalg.inv(pr.T_gt)[:3, :3] @ T[:3, :3]) - 1) / 2, -1, 1)) if seed >= 0 else None
-        out["cases"].append(dict(seed=seed, width=w, height=h, estimator=est, iterations=iters,
+        out["cases"].append(dict(seed=seed, width=w, height=h, estimator=est, iterations=iters, **({"workload": workload} if workload else {}),
                                  idx_sha256=hashlib.sha256(idx.astype("<i4").tobytes()).hexdigest(), inliers=int((idx >= 0).sum()),
                                  T_final=T.tolist(), rot_err_vs_gt=None if rot is None else float(rot)))
         print(seed, w, h, est, int((idx >= 0).sum()), rot)

@@ -207,7 +207,7 @@ def test_hip_path_reproduces_the_scipy_only_goldens(gpu_lib):
     for c in G["cases"]:
         if c["width"] < 640:
             continue
-        pr, s4, t4 = R._case(c["seed"], c["width"], c["height"])
+        pr, s4, t4 = R._case(c["seed"], c["width"], c["height"], c.get("workload"))
         with capi.IcpHandle(capi.default_params(pr.intr, estimator=c["estimator"], iterations=c["iterations"])) as h:
             for depth in (False, True):
                 r = h.align_depth_batch([pr.depth_src], [pr.depth_tgt])[0] if depth else h.align(s4, t4)
@@ -215,4 +215,4 @@ def test_hip_path_reproduces_the_scipy_only_goldens(gpu_lib):
                 assert hashlib.sha256(idx.astype("<i4").tobytes()).hexdigest() == c["idx_sha256"], (c["seed"], c["width"], depth)
                 assert np.allclose(r["T_raw"], np.array(c["T_final"]), rtol=0, atol=1e-7) and r["inliers"] == c["inliers"]
         n += 1
-    assert n >= 6
+    assert n >= 8

@@ -283,9 +283,13 @@ def normals_numpy_full(c4, w=7, min_in=41, in_dist=0.01, band=32, zmax=7.0):
 
 
 # ------------------------------------------------------------------------------------------------ the tests
-def _case(seed, w, h):
-    """seed >= 0: the synthetic pair; seed -1: the reference's Kinect pair data/exp1/dep/1 -> dep/2 (tests/golden/kinect,
-    intrinsics of src/convert2PCD.cpp:19-23 = synth.Intrinsics' defaults)"""
+BASELINE_MD = dict(noise_sigma=0.0012, hole_block=8, hole_prob=0.25)      # BASELINE.md section 4's synthetic workload
+
+
+def _case(seed, w, h, workload=None):
+    """seed >= 0: the synthetic pair (workload "baseline_md": BASELINE.md section 4's noise and hole mask instead of the
+    defaults); seed -1: the reference's Kinect pair data/exp1/dep/1 -> dep/2 (tests/golden/kinect, intrinsics of
+    src/convert2PCD.cpp:19-23 = synth.Intrinsics' defaults)"""
     if seed < 0:
         from PIL import Image
         kin = os.path.join(HERE, "golden", "kinect")
@@ -293,7 +297,7 @@ def _case(seed, w, h):
         d2 = np.array(Image.open(os.path.join(kin, "exp1_dep_2.png"))).astype(np.uint16)
         pr = synth.FramePair(-1, synth.Intrinsics(), d1, d2, np.eye(4))
     else:
-        pr = synth.make_pair(seed, w, h)
+        pr = synth.make_pair(seed, w, h, **(BASELINE_MD if workload == "baseline_md" else {}))
     return pr, synth.backproject_numpy(pr.depth_src, pr.intr), synth.backproject_numpy(pr.depth_tgt, pr.intr)
 
 
@@ -416,7 +420,7 @@ def test_independent_golden_hashes_are_reproduced_by_the_oracle():
     import hashlib
     G = json.load(open(os.path.join(HERE, "golden", "independent_golden.json")))
     for c in G["cases"]:
-        pr, s4, t4 = _case(c["seed"], c["width"], c["height"])
+        pr, s4, t4 = _case(c["seed"], c["width"], c["height"], c.get("workload"))
         for nn in (0, 1) if c["width"] <= 160 else (1,):
             ro = O.icp(s4, t4, O.params(pr.intr, estimator=c["estimator"], iterations=c["iterations"], nn_method=nn))
             assert hashlib.sha256(ro["idx"].astype("<i4").tobytes()).hexdigest() == c["idx_sha256"], c
