@@ -306,7 +306,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     A(dalloc(h->f_tbox, F * tg.ntiles * 2)); A(dalloc(h->f_cbox, F * tg.ncoarse * 2));
     A(dalloc(h->f_scount, F * 2 * tg.ntiles)); A(dalloc(h->f_counts, F * 4));
     if (brute) { A(dalloc(h->src_c, BN)); A(dalloc(h->tgt_c, BN)); A(dalloc(h->best, BS)); }
-    h->npad = ((h->N + MF_TCH - 1) / MF_TCH + 1) * MF_TCH;
+    h->npad = ((h->N + MF_TCH - 1) / MF_TCH + 2) * MF_TCH;      // two chunks of far-away padding: the fragment stream of k_nn_mfma runs up to 17 groups past the end
     if (nn_mode_of(h) == SLAM3D_NN_BRUTE_MFMA) {
         A(dalloc(h->tgtB, (size_t)h->maxB * 4 * h->npad)); A(dalloc(h->qmax2, (size_t)h->maxB));
     }
@@ -740,8 +740,8 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         } else {
             const int nsplit = pick_nsplit(h, B);
             const int qblocks = (h->N + NN_BLOCK * NN_QPT - 1) / (NN_BLOCK * NN_QPT);
-            hipLaunchKernelGGL(k_nn_valu, dim3(qblocks, nsplit, B), dim3(NN_BLOCK), 0, s, h->src_c, h->tgt_c, h->ccounts, h->Tcur,
-                               h->best, h->N, tg.nslots, nsplit);
+            hipLaunchKernelGGL(k_nn_valu, dim3(qblocks, nsplit, B), dim3(NN_BLOCK), 0, s, h->d_pairs, h->src_c, h->tgt_c, h->ccounts,
+                               h->prevq, h->Tcur, h->best, h->g, tg, nsplit, first);
         }
         if (e1) HIPCHK(h, hipEventRecord(e1, s));
         hipLaunchKernelGGL(k_accumulate, dim3(tg.nchunks, B), dim3(CHUNK), 0, s, h->d_pairs, h->Tcur, h->best,

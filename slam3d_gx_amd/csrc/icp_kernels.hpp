@@ -642,25 +642,60 @@ __device__ __forceinline__ float canon_d2(float px, float py, float pz, float qx
 
 __device__ __forceinline__ unsigned long long key_min(unsigned long long a, unsigned long long b);
 
-// exact brute force on the VALU.  grid = (query blocks, target splits, pairs).  Each thread owns
-// NN_QPT queries (registers) taken from the raster-compacted source list; target tiles of NN_TILE
-// points are staged in LDS and read with broadcast ds_read_b128.  Splits merge through a 64-bit
-// atomicMin on (d2 bits << 32 | j): the float bits of a non-negative d2 order like unsigned ints,
-// so the minimum is the smallest d2 and, among equal d2, the smallest target pixel index j -- the
-// spec's tie-break, independent of scheduling.  best[] is indexed by source SLOT.
-__global__ __launch_bounds__(NN_BLOCK) void k_nn_valu(const float4 *__restrict__ src_c,
+// ---- the two full-scan kernels start every query from the same upper bound ---------------------------------------
+// U = d2 to a target that EXISTS: the previous iteration's match (prevq), else the target at the query's own pixel,
+// else the gate.  The bound is a candidate like any other -- its key (d2 bits << 32 | pixel) is what the scan has to
+// beat or tie --, so starting from it changes no result; what it buys is that the scan need not keep an argmin per
+// candidate: almost nothing it meets is within the bound.
+__device__ __forceinline__ unsigned long long brute_bound(bool valid, int slot, float px, float py, float pz,
+                                                          const float4 *__restrict__ prevq_b, int first,
+                                                          const float4 *__restrict__ tcloud, const float4 *__restrict__ tnrm,
+                                                          const Geometry &g, const TileGrid &tg)
+{
+    unsigned long long bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
+    if (valid) {
+        float4 pq = prevq_b[slot];
+        if (first) pq.w = __int_as_float(-1);                  // a run's first iteration has no previous match
+        const int jprev = __float_as_int(pq.w);
+        float4 qg = pq;
+        int jg = jprev;
+        bool tv = jprev >= 0;
+        if (!tv) {                                             // same-pixel target as the first guess
+            const int tile = slot >> 6, ln = slot & 63;
+            const int u = (tile % tg.ntx) * TILE_PX + (ln & 7), v = (tile / tg.ntx) * TILE_PX + (ln >> 3);
+            jg = v * g.W + u;
+            qg = tcloud[jg];
+            tv = pt_valid(qg.x, qg.y, qg.z, g.zmax) && (g.estimator != 0 || tnrm[jg].w > 0.5f);
+        }
+        const float d2g = canon_d2(px, py, pz, qg.x, qg.y, qg.z);
+        if (tv && d2g <= g.gate2) bkey = ((unsigned long long)(unsigned int)__float_as_int(d2g) << 32) | (unsigned int)jg;
+    }
+    return bkey;
+}
+
+// exact brute force on the VALU.  grid = (query blocks, target splits, pairs).  Each thread owns NN_QPT queries
+// (registers) taken from the raster-compacted source list; target tiles of NN_TILE points are staged in LDS as
+// (pixel, x, y, z) and read with broadcast ds_read_b128.  EVERY source x target distance is evaluated, canonically
+// (3 sub, mul, 2 fma).  Round 4, second form: a candidate costs 6.5 VALU operations instead of 7.75 + a half-rate
+// v_min_f64 -- per chunk of NV_CH candidates each query keeps only the chunk's smallest d2 (one v_min3_f32 per two
+// candidates), and a chunk is rescanned with the packed keys (d2 bits << 32 | pixel, v_min_f64: smallest d2, ties to
+// the smallest pixel -- the spec's tie-break, independent of scheduling) only if some query of the wave met a distance
+// within its bound (brute_bound above; the bound tightens with every rescan).  With a bound that is the distance to a
+// real neighbour a few chunks per query qualify out of ~14,000.  Splits merge through a 64-bit atomicMin on the key;
+// best[] is indexed by source SLOT.
+constexpr int NV_CH = 16;
+__global__ __launch_bounds__(NN_BLOCK) void k_nn_valu(const PairPtrs *__restrict__ pairs,
+                                                      const float4 *__restrict__ src_c,
                                                       const float4 *__restrict__ tgt_c,
                                                       const int *__restrict__ ccounts,
+                                                      const float4 *__restrict__ prevq,
                                                       const double *__restrict__ Tcur,
-                                                      unsigned long long *__restrict__ best, int N, int nslots,
-                                                      int nsplit)
+                                                      unsigned long long *__restrict__ best, Geometry g, TileGrid tg,
+                                                      int nsplit, int first)
 {
-    // Round 4: the running best is the packed key (d2 bits << 32 | pixel) itself and every candidate costs SEVEN VALU operations --
-    // 3 sub, mul, 2 fma and one v_min_f64 (key_min: a non-negative float's bits above a pixel index are a non-negative double that
-    // orders like the pair) -- instead of nine (compare + two selects): the LDS copy of a target is (pixel, x, y, z), so the key forms
-    // in the registers the record was loaded into.  44 -> 5x TFLOP/s; the ceiling of this mix is 8 flop per 7 issue slots.
     __shared__ float4 tile[NN_TILE];
     const int b = blockIdx.z;
+    const int N = g.N, nslots = tg.nslots;
     const int ns = ccounts[b * 4 + 0], nt = ccounts[b * 4 + 1];
     const int q0 = blockIdx.x * (NN_BLOCK * NN_QPT);
     if (q0 >= ns) return;
@@ -682,25 +717,45 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_valu(const float4 *__restrict__
         if (i < ns) s = S[i];
         slot[k] = __float_as_int(s.w);
         xform(m, s.x, s.y, s.z, px[k], py[k], pz[k]);
-        bk[k] = 0x7f800000ffffffffull;                  // (+inf, no pixel)
+        bk[k] = brute_bound(slot[k] >= 0, slot[k], px[k], py[k], pz[k], prevq + (size_t)b * nslots, first, pairs[b].tgt, pairs[b].nrm, g, tg);
     }
     for (int t = tile_begin; t < tile_end; ++t) {
         const int j0 = t * NN_TILE;
         __syncthreads();
         for (int k = threadIdx.x; k < NN_TILE; k += NN_BLOCK) {
             const int j = j0 + k;
-            float4 q = make_float4(__int_as_float(-1), inf, inf, inf);        // padding: d2 = +inf never wins
+            float4 q = make_float4(__int_as_float(-1), inf, inf, inf);        // padding: d2 = +inf is within no bound
             if (j < nt) { const float4 c = Q[j]; q = make_float4(c.w, c.x, c.y, c.z); }       // (pixel, x, y, z)
             tile[k] = q;
         }
         __syncthreads();
-#pragma unroll 4
-        for (int jj = 0; jj < NN_TILE; ++jj) {
-            const float4 c = tile[jj];
+#pragma unroll 1
+        for (int c0 = 0; c0 < NN_TILE; c0 += NV_CH) {
+            float mn[NN_QPT];
 #pragma unroll
-            for (int k = 0; k < NN_QPT; ++k) {
-                const float d2 = canon_d2(px[k], py[k], pz[k], c.y, c.z, c.w);
-                bk[k] = key_min(bk[k], ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(c.x));
+            for (int jj = 0; jj < NV_CH; jj += 2) {
+                const float4 ca = tile[c0 + jj], cb = tile[c0 + jj + 1];
+#pragma unroll
+                for (int k = 0; k < NN_QPT; ++k) {
+                    const float da = canon_d2(px[k], py[k], pz[k], ca.y, ca.z, ca.w);
+                    const float db = canon_d2(px[k], py[k], pz[k], cb.y, cb.z, cb.w);
+                    if (jj == 0) asm("v_min_f32 %0, %1, %2" : "=v"(mn[k]) : "v"(da), "v"(db));
+                    else asm("v_min3_f32 %0, %0, %1, %2" : "+v"(mn[k]) : "v"(da), "v"(db));       // (never NaN: no canonicalisation wanted)
+                }
+            }
+            bool hit = false;
+#pragma unroll
+            for (int k = 0; k < NN_QPT; ++k) hit = hit || mn[k] <= __int_as_float((int)(unsigned int)(bk[k] >> 32));
+            if (__ballot(hit) != 0ull) {
+#pragma unroll 2
+                for (int jj = 0; jj < NV_CH; ++jj) {
+                    const float4 c = tile[c0 + jj];
+#pragma unroll
+                    for (int k = 0; k < NN_QPT; ++k) {
+                        const float d2 = canon_d2(px[k], py[k], pz[k], c.y, c.z, c.w);
+                        bk[k] = key_min(bk[k], ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(c.x));
+                    }
+                }
             }
         }
     }
@@ -787,24 +842,7 @@ __global__ __launch_bounds__(64) void k_nn_mfma(const PairPtrs *__restrict__ pai
         my_slot[h] = slot;
         float px, py, pz;
         xform(m, s4.x, s4.y, s4.z, px, py, pz);
-        unsigned long long bkey = ((unsigned long long)(unsigned int)__float_as_int(g.gate2) << 32) | 0xffffffffull;
-        if (valid) {
-            float4 pq = prevq[(size_t)b * tg.nslots + slot];
-            if (first) pq.w = __int_as_float(-1);                  // a run's first iteration has no previous match
-            const int jprev = __float_as_int(pq.w);
-            float4 qg = pq;
-            int jg = jprev;
-            bool tv = jprev >= 0;
-            if (!tv) {                                             // same-pixel target as the first guess
-                const int tile = slot >> 6, ln = slot & 63;
-                const int u = (tile % tg.ntx) * TILE_PX + (ln & 7), v = (tile / tg.ntx) * TILE_PX + (ln >> 3);
-                jg = v * g.W + u;
-                qg = tcloud[jg];
-                tv = pt_valid(qg.x, qg.y, qg.z, g.zmax) && (g.estimator != 0 || tnrm[jg].w > 0.5f);
-            }
-            const float d2g = canon_d2(px, py, pz, qg.x, qg.y, qg.z);
-            if (tv && d2g <= g.gate2) bkey = ((unsigned long long)(unsigned int)__float_as_int(d2g) << 32) | (unsigned int)jg;
-        }
+        const unsigned long long bkey = brute_bound(valid, slot, px, py, pz, prevq + (size_t)b * tg.nslots, first, tcloud, tnrm, g, tg);
         const float U = __int_as_float((int)(unsigned int)(bkey >> 32));
         const float rx = px, ry = py, rz = pz - cz;
         const float n2p = __fmaf_rn(rz, rz, __fmaf_rn(ry, ry, rx * rx));
@@ -833,13 +871,9 @@ __global__ __launch_bounds__(64) void k_nn_mfma(const PairPtrs *__restrict__ pai
     const int g_begin = (int)(((long long)blockIdx.y * ngroups) / nsplit);
     const int g_end = (int)(((long long)(blockIdx.y + 1) * ngroups) / nsplit);
     const float *__restrict__ Bl = Bb + (size_t)kq * npad + jq;             // this lane's stream: Bl[16 * group]
-    auto fold = [&](const f32x4 *D, int grp) __attribute__((always_inline)) {
-        int mn = 0x7fffffff;                                               // "some value <= 0" <=> "min of the bits as int <= 0"
-#pragma unroll
-        for (int rb = 0; rb < MF_RB; ++rb)
-            mn = min(mn, min(min(__float_as_int(D[rb][0]), __float_as_int(D[rb][1])),
-                             min(__float_as_int(D[rb][2]), __float_as_int(D[rb][3]))));
-        if (__ballot(mn <= 0) != 0ull) {
+    // exact re-evaluation of a group in which some pair was flagged
+    auto flagged = [&](const f32x4 *D, int grp) __attribute__((always_inline)) {
+        {
             // exact re-evaluation of the flagged pairs (rare): canonical distance, 64-bit key, LDS atomic min
             const int j = grp * 16 + jq;
             float4 c4 = make_float4(0, 0, 0, __int_as_float(-1));
@@ -860,6 +894,19 @@ __global__ __launch_bounds__(64) void k_nn_mfma(const PairPtrs *__restrict__ pai
                 }
         }
     };
+    auto fold = [&](const f32x4 *D, int grp) __attribute__((always_inline)) {
+        int mn = 0x7fffffff;                                               // "some value <= 0" <=> "min of the bits as int <= 0"
+#pragma unroll
+        for (int rb = 0; rb < MF_RB; ++rb)
+            mn = min(mn, min(min(__float_as_int(D[rb][0]), __float_as_int(D[rb][1])),
+                             min(__float_as_int(D[rb][2]), __float_as_int(D[rb][3]))));
+        if (__ballot(mn <= 0) != 0ull) flagged(D, grp);
+    };
+    (void)fold;
+#ifndef MFMA_SCHED
+#define MFMA_SCHED 1      // 0: the round-3 loop; 1: rotating pipeline (default); 2, 3: the same with that many fold operations PLACED behind every MFMA
+#endif
+#if MFMA_SCHED == 0
     float bf[MF_AHEAD], bn[MF_AHEAD];
 #pragma unroll
     for (int u = 0; u < MF_AHEAD; ++u) bf[u] = Bl[(size_t)16 * min(g_begin + u, ngroups)];     // npad leaves room past the end
@@ -881,6 +928,48 @@ __global__ __launch_bounds__(64) void k_nn_mfma(const PairPtrs *__restrict__ pai
 #pragma unroll
         for (int u = 0; u < MF_AHEAD; ++u) bf[u] = bn[u];
     }
+#else
+    // One rotating pipeline: while the VALU folds group G, the matrix core runs group G + 1 and the fragment register
+    // that G + 1 just consumed is reloaded with group G + 9 -- one pointer and immediate offsets (the 2 x 256 floats
+    // of padding behind every row of tgtB hold far-away points, so nothing is clamped), no second set of fragment
+    // registers, sixteen v_min3_i32 per group: 97.4 -> 101.2 TFLOP/s.  Measured and NOT used: placing the fold's VALU
+    // operations between the MFMAs with sched_group_barrier (MFMA_SCHED 2 / 3: 92.5 / 95.8 TFLOP/s) -- an issue slot
+    // between two back-to-back MFMAs costs the matrix pipe more than the three resident waves' overlap gives back.
+    float bf[MF_AHEAD];
+    const float *__restrict__ pB = Bl + (size_t)16 * g_begin;
+#pragma unroll
+    for (int u = 0; u < MF_AHEAD; ++u) bf[u] = pB[16 * u];
+    f32x4 D[2][MF_RB];
+#pragma unroll
+    for (int rb = 0; rb < MF_RB; ++rb) D[0][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rb], bf[0], Cc[rb], 0, 0, 0);
+    bf[0] = pB[16 * MF_AHEAD];
+    for (int g0 = g_begin; g0 < g_end; g0 += MF_AHEAD, pB += 16 * MF_AHEAD) {
+#pragma unroll
+        for (int u = 0; u < MF_AHEAD; ++u) {
+            const int un = (u + 1) % MF_AHEAD;
+#pragma unroll
+            for (int rb = 0; rb < MF_RB; ++rb)
+                D[(u + 1) & 1][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[rb], bf[un], Cc[rb], 0, 0, 0);
+            bf[un] = pB[16 * (u + 1 + MF_AHEAD)];                       // the group eight after the one just consumed
+            int mn = 0x7fffffff;                                               // "some value <= 0" <=> "min of the bits as int <= 0"
+#pragma unroll
+            for (int rb = 0; rb < MF_RB; ++rb) {                                // sixteen v_min3_i32
+                mn = min(min(mn, __float_as_int(D[u & 1][rb][0])), __float_as_int(D[u & 1][rb][1]));
+                mn = min(min(mn, __float_as_int(D[u & 1][rb][2])), __float_as_int(D[u & 1][rb][3]));
+            }
+#if MFMA_SCHED >= 2
+#pragma unroll
+            for (int rb = 0; rb < MF_RB; ++rb) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // one MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, MFMA_SCHED, 0);    // MFMA_SCHED VALU operations of the fold
+            }
+#endif
+            // (the groups a last trip runs past g_end belong to the next slice or to the padding: scanning them again
+            //  changes nothing -- the merge is a minimum -- and the padding is never flagged)
+            if (__ballot(mn <= 0) != 0ull) flagged(D[u & 1], g0 + u);
+        }
+    }
+#endif
 #pragma unroll
     for (int h = 0; h < MF_Q / 64; ++h) {
         if (my_slot[h] >= 0) {
