@@ -6,10 +6,10 @@
 // integer colour sums, so the atomics below give the same bits whatever order they land in.
 //
 //   k_voxel_insert   one thread per point: 64-bit voxel key (iz,iy,ix) -> open-addressing hash table in HBM
-//                    (64-byte slots: key, sums, colour sums and count of a voxel share ONE cache line, so the nine
-//                    atomics of an update touch one line instead of nine), atomicCAS on the key.  The lane that claims a
-//                    slot also lists it -- per block, through an LDS counter -- and bumps the histogram of the
-//                    (iz, iy) rows: no pass over the table is ever needed.
+//                    (two-line slots, see VoxSlot: atomicCAS on the key; the block that claims a slot stores its sums
+//                    with plain writes, blocks that find it claimed add theirs atomically into the key's own line).
+//                    The lane that claims a slot also lists it -- per block, through an LDS counter -- and bumps the
+//                    histogram of the (iz, iy) rows: no pass over the table is ever needed.
 //   k_voxel_scan1/2 / k_voxel_scatter   counting sort of the listed slots by row (iz, iy are the most significant fields)
 //   k_voxel_rank     output order = ascending key, like PCL's sorted linear voxel index: rank = start of the
 //                    rows a block touches + number of smaller keys among them (LDS-tiled compares), centroid
@@ -21,6 +21,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stddef.h>
 
 namespace s3d {
 
@@ -28,14 +29,27 @@ constexpr unsigned long long VOX_EMPTY = ~0ull;
 constexpr int VOX_BLOCK = 256;
 constexpr int VOX_TILE = 2048;        // keys staged in LDS per step of the ranking kernel
 
-struct __attribute__((aligned(64))) VoxSlot {      // one cache line per voxel
-    unsigned long long key;
+// A voxel slot is TWO cache lines (round 4).  Line 0 is the atomic line: the key every lane CASes on, and the sums of
+// the blocks that found the voxel already claimed ("late" sums; zero between calls).  Line 1 belongs to the ONE block whose
+// CAS claimed the slot: it writes its sums there with plain 16-byte stores -- no atomics, never cleared (a claim always
+// overwrites all of it before anything reads it).  Most voxels of an organized cloud lie inside one image tile, so most
+// updates are one returning atomic + one line store instead of one returning atomic + six atomic adds; the sums are
+// integers, so first + late is the same total whatever the order.
+struct __attribute__((aligned(64))) VoxSums {
     long long sx, sy, sz;                          // fixed-point coordinate sums (2^-20 m)
     unsigned long long c01, c23;                   // colour channel sums, two per word (c0 | c1 << 32), (c2 | c3 << 32): each < 2^27
     unsigned int n;                                // point count
-    unsigned int pad[3];
+    unsigned int pad[5];
 };
-static_assert(sizeof(VoxSlot) == 64, "a voxel slot is one 64-byte line");
+struct __attribute__((aligned(128))) VoxSlot {
+    unsigned long long key;                        // line 0: key + late sums
+    long long sx, sy, sz;
+    unsigned long long c01, c23;
+    unsigned int n;
+    unsigned int pad[3];
+    VoxSums first;                                 // line 1: the claiming block's sums
+};
+static_assert(sizeof(VoxSums) == 64 && sizeof(VoxSlot) == 128 && offsetof(VoxSlot, first) == 64, "a voxel slot is two 64-byte lines");
 struct VoxTable { VoxSlot *slot; int cap; };       // `cap` slots (power of two)
 
 __device__ __forceinline__ unsigned long long vox_key(float x, float y, float z, float inv_leaf)
@@ -60,7 +74,7 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_clear(VoxTable t)
 {
     const int s = blockIdx.x * VOX_BLOCK + threadIdx.x;
     if (s >= t.cap) return;
-    uint4 *q = reinterpret_cast<uint4 *>(t.slot + s);
+    uint4 *q = reinterpret_cast<uint4 *>(t.slot + s);                      // (line 0 only: line 1 needs no initial state)
     q[0] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
     q[1] = make_uint4(0u, 0u, 0u, 0u); q[2] = make_uint4(0u, 0u, 0u, 0u); q[3] = make_uint4(0u, 0u, 0u, 0u);
 }
@@ -123,9 +137,11 @@ __device__ __forceinline__ int vox_bin(unsigned long long key)
 // ~6x6 pixels at 2.5 m, so a tile holds about a dozen voxels) or per 256 consecutive records otherwise.
 //   1. runs of equal keys inside a wave are summed with a segmented scan (integers: same bits);
 //   2. the run tails add into a block-local hash table in LDS (512 entries; LDS atomics);
-//   3. every occupied LDS entry becomes ONE update of the global table: atomicCAS on the key + six atomic adds into
-//      the voxel's cache line.  Returning global atomics are the scarce resource here (~1-2 per ns scattered): the
-//      two aggregation levels cut them from one per point run (77 k per 640x480 frame) to one per (tile, voxel) (~15 k).
+//   3. every occupied LDS entry becomes ONE update of the global table: atomicCAS on the key, then either three plain
+//      16-byte stores (the slot was empty: this block's sums are the voxel's first) or six atomic adds (it was not).
+//      Device-scope atomics are the scarce resource here (~1-2 returning ones per ns scattered; 29 of the insert's 36 us
+//      when every update made seven): the two aggregation levels cut the updates from one per point run (77 k per
+//      640x480 frame) to one per (tile, voxel) (~15 k), the first-writer line cuts the atomics per update.
 // The lane whose CAS claims an empty global slot lists it at lkey / lslot[block * VOX_BLOCK + k] (k from an LDS
 // counter; bcount[block] = entries listed) and bumps the row histogram.
 constexpr int VOX_LH = 512;            // LDS hash entries per block (256 points: load <= 0.5)
@@ -205,12 +221,21 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(const float4 *__rest
             s = (s + 1) & (unsigned int)(t.cap - 1);
         }
         VoxSlot *q = t.slot + s;
-        atomicAdd(reinterpret_cast<unsigned long long *>(&q->sx), (unsigned long long)hsx[k]);
-        atomicAdd(reinterpret_cast<unsigned long long *>(&q->sy), (unsigned long long)hsy[k]);
-        atomicAdd(reinterpret_cast<unsigned long long *>(&q->sz), (unsigned long long)hsz[k]);
-        atomicAdd(&q->c01, hc01[k]);
-        atomicAdd(&q->c23, hc23[k]);
-        atomicAdd(&q->n, hn[k]);
+        if (claimed) {                                               // this block owns line 1: three plain 16-byte stores
+            const unsigned long long sx = (unsigned long long)hsx[k], sy = (unsigned long long)hsy[k], sz = (unsigned long long)hsz[k];
+            const unsigned long long c01 = hc01[k], c23 = hc23[k];
+            uint4 *f = reinterpret_cast<uint4 *>(&q->first);
+            f[0] = make_uint4((unsigned int)sx, (unsigned int)(sx >> 32), (unsigned int)sy, (unsigned int)(sy >> 32));
+            f[1] = make_uint4((unsigned int)sz, (unsigned int)(sz >> 32), (unsigned int)c01, (unsigned int)(c01 >> 32));
+            f[2] = make_uint4((unsigned int)c23, (unsigned int)(c23 >> 32), hn[k], 0u);
+        } else {                                                     // the voxel straddles image tiles: late sums, line 0
+            atomicAdd(reinterpret_cast<unsigned long long *>(&q->sx), (unsigned long long)hsx[k]);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&q->sy), (unsigned long long)hsy[k]);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&q->sz), (unsigned long long)hsz[k]);
+            atomicAdd(&q->c01, hc01[k]);
+            atomicAdd(&q->c23, hc23[k]);
+            atomicAdd(&q->n, hn[k]);
+        }
         if (claimed) {
             const int c = atomicAdd(&bcnt, 1);                       // LDS: at most VOX_BLOCK claims per block
             lkey[(size_t)blockIdx.x * VOX_BLOCK + c] = gk;
@@ -358,18 +383,20 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_rank(VoxTable t, const unsi
     if (!live) return;
     VoxSlot *q = t.slot + gslot[e];
     const uint4 a0 = reinterpret_cast<const uint4 *>(q)[0], a1 = reinterpret_cast<const uint4 *>(q)[1],
-                a2 = reinterpret_cast<const uint4 *>(q)[2];
-    const long long sx = (long long)(((unsigned long long)a0.w << 32) | a0.z);
-    const long long sy = (long long)(((unsigned long long)a1.y << 32) | a1.x);
-    const long long sz = (long long)(((unsigned long long)a1.w << 32) | a1.z);
-    const uint4 a3 = reinterpret_cast<const uint4 *>(q)[3];
-    const unsigned int ni = a3.x;
+                a2 = reinterpret_cast<const uint4 *>(q)[2], a3 = reinterpret_cast<const uint4 *>(q)[3];        // key + late sums
+    const uint4 f0 = reinterpret_cast<const uint4 *>(&q->first)[0], f1 = reinterpret_cast<const uint4 *>(&q->first)[1],
+                f2 = reinterpret_cast<const uint4 *>(&q->first)[2];                                             // the claiming block's sums
+    const long long sx = (long long)((((unsigned long long)a0.w << 32) | a0.z) + (((unsigned long long)f0.y << 32) | f0.x));
+    const long long sy = (long long)((((unsigned long long)a1.y << 32) | a1.x) + (((unsigned long long)f0.w << 32) | f0.z));
+    const long long sz = (long long)((((unsigned long long)a1.w << 32) | a1.z) + (((unsigned long long)f1.y << 32) | f1.x));
+    const unsigned int c0 = a2.x + f1.z, c1 = a2.y + f1.w, c2 = a2.z + f2.x, c3 = a2.w + f2.y;
+    const unsigned int ni = a3.x + f2.z;
     const double cnt = (double)ni;
     float4 o;
     o.x = (float)(((double)sx / cnt) / 1048576.0);
     o.y = (float)(((double)sy / cnt) / 1048576.0);
     o.z = (float)(((double)sz / cnt) / 1048576.0);
-    const unsigned int rgba = (a2.x / ni) | ((a2.y / ni) << 8) | ((a2.z / ni) << 16) | ((a2.w / ni) << 24);     // c0, c1 | c2, c3
+    const unsigned int rgba = (c0 / ni) | ((c1 / ni) << 8) | ((c2 / ni) << 16) | ((c3 / ni) << 24);
     o.w = __int_as_float((int)rgba);
     out[rank] = o;
     uint4 *w = reinterpret_cast<uint4 *>(q);                              // leave the slot empty for the next call
