@@ -24,7 +24,7 @@ Prints ONE JSON line on rank 0.  Beside metric/value/...:
   roofline            dominant kernel k_nn_tiles_acc accounted against HBM: algorithmic bytes per launch (SURVEY.md
                       8(d): 12 B xyz + 4 B idx per valid source point, 12 B xyz + 12 B normal per valid target) / mean
                       launch duration, measured with HIP events on the launch stream over `--profile-aligns` alignments.
-  roofline_bruteforce the north-star algorithm (full brute-force scan) on the f32 MFMA pipe and on the VALU.
+  roofline_bruteforce the north-star algorithm (full brute-force scan) on the matrix cores (bf16-split and f32 forms) and on the VALU.
   cpu_baseline        the CPU oracle timed on the host on a bounded sample of the same workload.
   config3 / config5   BASELINE configs 3 (64 pairs per launch) and 5 (1280x960 dense) measured in the same run, each
                       with its own roofline and cpu_baseline (N = 1 only; skip with --no-extra-configs).
@@ -322,32 +322,53 @@ def cpu_baseline_leg(pair, s4, t4, iterations, est, gpu_result, gpu_idx, brute_s
     return out, parity
 
 
+BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak of one MI355X (MI355X_MICROARCH.md; 2:1-sparsity figures are never used)
+
+
 def bruteforce_leg(capi, intr, est, s4, t4, local_rank, iterations=4):
-    """The north-star algorithm on one pair of the pool: every source x every target, distance step as a dense
-    contraction on the f32 MFMA pipe (k_nn_mfma); the fp32-VALU scan (k_nn_valu) is timed beside it."""
+    """The north-star algorithm on one pair of the pool: every source x every target, the distance step as a dense
+    contraction on the matrix cores.  Three kernels, same bits: k_nn_mfma16 (each float split into three bf16 terms, one
+    v_mfma_f32_16x16x32_bf16 per 16 x 16 tile -- the default of NN_BRUTE_MFMA), k_nn_mfma (v_mfma_f32_16x16x4_f32;
+    SLAM3D_MFMA_BF16=0) and the fp32-VALU scan k_nn_valu."""
     out = {}
-    for mode, name in ((capi.NN_BRUTE_MFMA, "mfma"), (capi.NN_BRUTE_VALU, "valu")):
+    for mode, name, env in ((capi.NN_BRUTE_MFMA, "mfma16", None), (capi.NN_BRUTE_MFMA, "mfma", ("SLAM3D_MFMA_BF16", "0")), (capi.NN_BRUTE_VALU, "valu", None)):
         # (coarse_iterations = 0: every launch scans every source against every target -- the N x M contraction the flop count assumes)
         params = capi.default_params(intr, estimator=est, iterations=iterations, max_batch=1, device=local_rank, nn_mode=mode, coarse_iterations=0)
-        with capi.IcpHandle(params) as h:
-            h.set_clouds_host(0, s4, t4)
-            h.set_profiling(True)
-            h.run(1)
-            h.fetch_results(1)                       # warm-up
-            h.set_clouds_host(0, s4, t4)
-            h.run(1)
-            r = h.fetch_results(1)[0]
-            ms = float(np.mean(h.get_iteration_timings()[1:]))    # iteration 0 has no previous match to bound the filter
-        out[name] = (ms, 8.0 * r["n_src"] * r["n_tgt"])
-    ms, flops = out["mfma"]
-    ach = flops / (ms * 1e-3) / 1e12
+        if env:
+            os.environ[env[0]] = env[1]
+        try:
+            with capi.IcpHandle(params) as h:
+                h.set_clouds_host(0, s4, t4)
+                h.set_profiling(True)
+                h.run(1)
+                h.fetch_results(1)                       # warm-up
+                h.set_clouds_host(0, s4, t4)
+                h.run(1)
+                r = h.fetch_results(1)[0]
+                ms = float(np.mean(h.get_iteration_timings()[1:]))    # iteration 0 has no previous match to bound the filter
+        finally:
+            if env:
+                del os.environ[env[0]]
+        out[name] = (ms, float(r["n_src"]) * float(r["n_tgt"]))
+    ms16, pairs = out["mfma16"]
+    ms, _ = out["mfma"]
     vms, _ = out["valu"]
-    return {"kernel": "k_nn_mfma (full brute-force scan: v_mfma_f32_16x16x4_f32 distance contraction as a conservative "
-                      "filter + exact fp32 re-evaluation of flagged pairs; bit-identical results)",
-            "bound": "mfma", "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP32_PEAK_TFLOPS,
-            "traffic": None, "launch_ms": ms, "flops_per_launch": flops, "iterations_per_s_if_used": 1e3 / ms,
-            "valu_kernel": {"kernel": "k_nn_valu (same scan on the fp32 VALU)", "launch_ms": vms,
-                            "achieved": flops / (vms * 1e-3) / 1e12, "frac": flops / (vms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}}
+    # executed flops: the bf16 instruction multiplies K = 32 slots per (source, target) pair (64 flop; 22 slots carry terms),
+    # the f32 one K = 4 (8 flop), the VALU scan evaluates the canonical distance (8 flop)
+    ach16 = 64.0 * pairs / (ms16 * 1e-3) / 1e12
+    ach = 8.0 * pairs / (ms * 1e-3) / 1e12
+    return {"kernel": "k_nn_mfma16 (full brute-force scan: |q|^2 - 2 p.q - thr as ONE v_mfma_f32_16x16x32_bf16 per 16x16 tile, every float split "
+                      "exactly into three bf16 terms; conservative filter + exact fp32 re-evaluation of flagged pairs; bit-identical results)",
+            "bound": "mfma", "achieved": ach16, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach16 / BF16_PEAK_TFLOPS,
+            "traffic": None, "launch_ms": ms16, "flops_per_launch": 64.0 * pairs, "iterations_per_s_if_used": 1e3 / ms16,
+            "equivalent_f32_contraction_tflops": 8.0 * pairs / (ms16 * 1e-3) / 1e12,
+            "equivalent_frac_of_f32_peak": 8.0 * pairs / (ms16 * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+            "note": "achieved counts the flops the bf16 instruction executes (64 per pair) against the dense bf16 peak; the same scan as an f32 "
+                    "K = 4 contraction is 8 flop per pair: equivalent_f32_contraction_tflops, above the 157.3 TF f32 matrix peak",
+            "f32_mfma_kernel": {"kernel": "k_nn_mfma (v_mfma_f32_16x16x4_f32, SLAM3D_MFMA_BF16=0)", "launch_ms": ms, "achieved": ach,
+                                "peak": FP32_PEAK_TFLOPS, "frac": ach / FP32_PEAK_TFLOPS},
+            "valu_kernel": {"kernel": "k_nn_valu (same scan on the fp32 VALU, canonical distances)", "launch_ms": vms,
+                            "achieved": 8.0 * pairs / (vms * 1e-3) / 1e12, "frac": 8.0 * pairs / (vms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}}
 
 
 def profiled_pass(handle, pool, P, n_align, est):
@@ -962,7 +983,8 @@ def main():
         out["survey_8d"] = {
             "gpus": world, "pairs": world * S * args.steps, "iters": args.iterations, "wall_s": elapsed,
             "icp_iters_per_s": value, "kernel_only_icp_iters_per_s": out["kernel_only_value"],
-            "nn_tflops": rb.get("achieved"), "nn_frac_fp32_peak": rb.get("frac"),
+            "nn_tflops": rb.get("equivalent_f32_contraction_tflops"), "nn_frac_fp32_peak": rb.get("equivalent_frac_of_f32_peak"),
+            "nn_bf16_tflops_executed": rb.get("achieved"), "nn_frac_bf16_peak": rb.get("frac"),
             "hbm_GBps": rf.get("achieved") if rf.get("unit") == "GB/s" else None,
             "hbm_frac_peak": rf.get("frac") if rf.get("unit") == "GB/s" else None,
             "cpu_A_iters_per_s": cb_.get("bruteforce_value"), "cpu_B_iters_per_s": cb_.get("value"),

@@ -85,7 +85,8 @@ struct slam3d_icp_handle {
     int *perm_d = nullptr;                  // its cost-balanced tile->(block,wave) assignment
     bool proj_search = true;                // SLAM3D_PROJ_SEARCH=0: developer knob, the hierarchical search alone
     int nn_gx = 0, nn_gx_d = 0;             // k_nn_tiles_acc grid widths (multiples of 8): cooperative / throughput build
-    float *tgtB = nullptr;        // BRUTE_MFMA: B-layout targets [B][4][npad]
+    float *tgtB = nullptr;        // BRUTE_MFMA: B-layout targets, f32 form [B][4][npad] floats / bf16 form [B][npad / 16][64] x 8 bytes
+    bool mfma_bf16 = true;        // BRUTE_MFMA runs the bf16-split contraction (k_nn_mfma16); SLAM3D_MFMA_BF16=0: the f32 one (k_nn_mfma)
     unsigned int *qmax2 = nullptr; int npad = 0;
     // host
     double *pin_res = nullptr, *d_res = nullptr;   // host-mapped result records (RES_REC doubles per pair) and their device address
@@ -308,7 +309,8 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     if (brute) { A(dalloc(h->src_c, BN)); A(dalloc(h->tgt_c, BN)); A(dalloc(h->best, BS)); }
     h->npad = ((h->N + MF_TCH - 1) / MF_TCH + 2) * MF_TCH;      // two chunks of far-away padding: the fragment stream of k_nn_mfma runs up to 17 groups past the end
     if (nn_mode_of(h) == SLAM3D_NN_BRUTE_MFMA) {
-        A(dalloc(h->tgtB, (size_t)h->maxB * 4 * h->npad)); A(dalloc(h->qmax2, (size_t)h->maxB));
+        if (getenv("SLAM3D_MFMA_BF16")) h->mfma_bf16 = atoi(getenv("SLAM3D_MFMA_BF16")) != 0;            // developer knob
+        A(dalloc(h->tgtB, (size_t)h->maxB * (h->mfma_bf16 ? 8 : 4) * h->npad)); A(dalloc(h->qmax2, (size_t)h->maxB));
     }
     A(dalloc(h->ccounts, (size_t)h->maxB * 4)); A(dalloc(h->ticket, (size_t)h->maxB));
     A(dalloc(h->corr, BS)); A(dalloc(h->flags, (size_t)h->maxB)); A(dalloc(h->cd2, BS));
@@ -673,8 +675,12 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
                            use_normals, h->row0, h->row1);
         if (nn_mode_of(h) == SLAM3D_NN_BRUTE_MFMA) {
             HIPCHK(h, hipMemsetAsync(h->qmax2, 0, sizeof(unsigned int) * (size_t)B, s));
-            hipLaunchKernelGGL(k_make_bfrag, dim3(h->npad / 256, B), dim3(256), 0, s, h->tgt_c, h->ccounts, h->tgtB, h->qmax2,
-                               h->N, h->npad, 0.5f * g.zmax);
+            if (h->mfma_bf16)
+                hipLaunchKernelGGL(k_make_bfrag16, dim3(h->npad / 256, B), dim3(256), 0, s, h->tgt_c, h->ccounts, reinterpret_cast<uint2 *>(h->tgtB),
+                                   h->qmax2, h->N, h->npad, 0.5f * g.zmax);
+            else
+                hipLaunchKernelGGL(k_make_bfrag, dim3(h->npad / 256, B), dim3(256), 0, s, h->tgt_c, h->ccounts, h->tgtB, h->qmax2,
+                                   h->N, h->npad, 0.5f * g.zmax);
         }
     }
     HIPCHK(h, hipGetLastError());
@@ -730,13 +736,19 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         if (nn_mode_of(h) == SLAM3D_NN_BRUTE_MFMA) {
             // one wave per block; target slices so that a pair alone still gives every SIMD several waves
             // (24 k waves: three resident per SIMD make eight rounds -- with 8 k the last of three rounds ran 3/4 empty: 95.6 -> 100 TFLOP/s)
-            int msplit = (24 * 1024 + (h->N / MF_Q) * B - 1) / ((h->N / MF_Q) * B);
+            // (the bf16 form's waves are half as long: 48 k of them -- 175 -> 183 TFLOP/s-equivalent)
+            int msplit = ((h->mfma_bf16 ? 48 : 24) * 1024 + (h->N / MF_Q) * B - 1) / ((h->N / MF_Q) * B);
             if (msplit < 1) msplit = 1;
             if (msplit > 32) msplit = 32;
             if (getenv("SLAM3D_MFMA_SPLIT")) msplit = std::max(1, std::min(64, atoi(getenv("SLAM3D_MFMA_SPLIT"))));      // developer knob
-            hipLaunchKernelGGL(k_nn_mfma, dim3((h->N + MF_Q - 1) / MF_Q, msplit, B), dim3(64), 0, s, h->d_pairs, h->src_c, h->tgt_c,
-                               h->tgtB, h->qmax2, h->ccounts, h->prevq, h->Tcur, h->best, h->g, tg, h->npad, 0.5f * h->g.zmax,
-                               msplit, first);
+            if (h->mfma_bf16)
+                hipLaunchKernelGGL(k_nn_mfma16, dim3((h->N + MF_Q - 1) / MF_Q, msplit, B), dim3(64), 0, s, h->d_pairs, h->src_c, h->tgt_c,
+                                   reinterpret_cast<const uint2 *>(h->tgtB), h->qmax2, h->ccounts, h->prevq, h->Tcur, h->best, h->g, tg, h->npad,
+                                   0.5f * h->g.zmax, msplit, first);
+            else
+                hipLaunchKernelGGL(k_nn_mfma, dim3((h->N + MF_Q - 1) / MF_Q, msplit, B), dim3(64), 0, s, h->d_pairs, h->src_c, h->tgt_c,
+                                   h->tgtB, h->qmax2, h->ccounts, h->prevq, h->Tcur, h->best, h->g, tg, h->npad, 0.5f * h->g.zmax,
+                                   msplit, first);
         } else {
             const int nsplit = pick_nsplit(h, B);
             const int qblocks = (h->N + NN_BLOCK * NN_QPT - 1) / (NN_BLOCK * NN_QPT);

@@ -804,11 +804,17 @@ __global__ __launch_bounds__(256) void k_make_bfrag(const float4 *__restrict__ t
 // contiguous slice of the targets.  No LDS staging and no barriers: the B fragments (4 bytes per lane and
 // group) stream straight from L2 into registers, eight groups ahead; exact candidates are fetched only
 // for flagged pairs.  Slices merge with a 64-bit atomicMin on best[] (same key as the VALU kernel).
-constexpr int MF_AHEAD = 8;
+#ifndef MF_AHEAD_N
+#define MF_AHEAD_N 8
+#endif
+constexpr int MF_AHEAD = MF_AHEAD_N;
 constexpr int MF_RB = 8;                 // row blocks (of 16 queries) per wave
 constexpr int MF_Q = 16 * MF_RB;         // queries per wave
 
-__global__ __launch_bounds__(64) void k_nn_mfma(const PairPtrs *__restrict__ pairs,
+#ifndef MF_WPE
+#define MF_WPE 3
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF_WPE, MF_WPE))) void k_nn_mfma(const PairPtrs *__restrict__ pairs,
                                                 const float4 *__restrict__ src_c, const float4 *__restrict__ tgt_c,
                                                 const float *__restrict__ tgtB, const unsigned int *__restrict__ qmax2_bits,
                                                 const int *__restrict__ ccounts, const float4 *__restrict__ prevq,
@@ -970,6 +976,210 @@ __global__ __launch_bounds__(64) void k_nn_mfma(const PairPtrs *__restrict__ pai
         }
     }
 #endif
+#pragma unroll
+    for (int h = 0; h < MF_Q / 64; ++h) {
+        if (my_slot[h] >= 0) {
+            const unsigned long long key = qkey[h * 64 + lane];
+            if ((unsigned int)(key & 0xffffffffull) != 0xffffffffu) atomicMin(best + (size_t)b * tg.nslots + my_slot[h], key);
+        }
+    }
+}
+
+// ------------------------------------------------- full brute force on the bf16 matrix cores (round 4)
+// gfx950 runs bf16 MFMAs at sixteen times its f32 rate, and a float is EXACTLY the sum of three bf16 numbers
+// (h = bf16(v), m = bf16(v - h), l = bf16(v - h - m): 8 + 8 + 8 significand bits).  So the same contraction
+//     D[i][j] = |q_j|^2 - 2 p_i . q_j - thr_i           (thr_i = U_i - |p_i|^2 + eps_i;  D <= 0 flags the pair)
+// fits ONE v_mfma_f32_16x16x32_bf16 per 16 x 16 tile -- 16 cycles where the f32 form takes 32.  Its K = 32 slots,
+// eight per 16-lane group kb:
+//     kb = 0, 1, 2 (coordinate c; a = -2 p_c, b = q_c):   A = (a_h, a_h | a_h, a_l | a_m, a_m | 0, 0)
+//                                                         B = (b_h, b_m | b_l, b_h | b_h, b_m | 0, 0)
+//         -> a_h b_h + a_h b_m + a_h b_l + a_l b_h + a_m b_h + a_m b_m (|m| <= 2^-8 |v|, |l| <= 2^-16 |v|: what is left out,
+//            a_m b_l + a_l b_m + a_l b_l, is below 2^-23 |a b|)
+//     kb = 3:   A = (1, 1 | 1, t_h | t_m, t_l | 0, 0),  t = -thr;   B = (n_h, n_m | n_l, 1 | 1, 1 | 0, 0),  n = |q|^2
+// bf16 x bf16 products are exact in f32; C is the inline constant 0 (no threshold registers).  In memory a target keeps
+// 8 bytes per group kb -- (h | m << 16, l | h << 16), resp. (n_h | n_m << 16, n_l | 1.0 << 16) -- and the third register
+// of the operand is a copy of the first (kb = 3: the constant (1, 1)): one v_cndmask per fragment, 512 B per group of
+// 16 targets.  As in the f32 form the matrix result is only a FILTER: flagged pairs are re-evaluated canonically, so the
+// output is bit-identical to the VALU scan as long as eps covers every error of the chain.  Beyond the f32 form's eps
+// (roundings of |q|^2, |p|^2, the centring): the dropped cross terms, < 2^-23 |a||b| summed over the coordinates (the
+// three-way split itself is exact: tests/test_oracle_math.py), and the matrix core's accumulation -- at most 23
+// additions, each bounded by a TRUNCATION (2^-23) of the running magnitude S <= 2 |p||q| + |q|^2 + |thr|, whatever order
+// or width the hardware uses: together 24 x 2^-23 S = 2.9e-6 S.
+// eps16 = 4e-6 (2 sqrt(|p|^2 max|q|^2) + max|q|^2 + |p|^2 + U) on top.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned int bf16_rne(float v)              // the bf16 nearest to a finite v, as its 16 bits
+{
+    const unsigned int u = (unsigned int)__float_as_int(v);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void bf16_split3(float v, unsigned int &h, unsigned int &m, unsigned int &l)
+{
+    h = bf16_rne(v);
+    const float r1 = v - __int_as_float((int)(h << 16));               // exact: the low bits of v
+    m = bf16_rne(r1);
+    const float r2 = r1 - __int_as_float((int)(m << 16));              // exact
+    l = bf16_rne(r2);
+}
+constexpr unsigned int BF16_ONE = 0x3f80u;
+
+// B-layout targets of the bf16 scan: tgtB16[b][group][lane = kb * 16 + (j & 15)] = the 8 bytes of target j for group kb
+__global__ __launch_bounds__(256) void k_make_bfrag16(const float4 *__restrict__ tgt_c, const int *__restrict__ ccounts,
+                                                      uint2 *__restrict__ tgtB16, unsigned int *__restrict__ qmax2_bits,
+                                                      int N, int npad, float cz)
+{
+    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= npad) return;
+    const int nt = ccounts[b * 4 + 1];
+    float r[3] = { 1e4f, 1e4f, 1e4f };                                 // padding: far away, never flagged
+    float n2 = 3e8f;
+    if (j < nt) {
+        const float4 q = tgt_c[(size_t)b * N + j];
+        r[0] = q.x; r[1] = q.y; r[2] = q.z - cz;
+        n2 = __fmaf_rn(r[2], r[2], __fmaf_rn(r[1], r[1], r[0] * r[0]));
+        atomicMax(qmax2_bits + b, (unsigned int)__float_as_int(n2));   // non-negative floats order like uints
+    }
+    uint2 *__restrict__ out = tgtB16 + ((size_t)b * (npad >> 4) + (j >> 4)) * 64 + (j & 15);
+    unsigned int h, m, l;
+#pragma unroll
+    for (int kb = 0; kb < 3; ++kb) {
+        bf16_split3(r[kb], h, m, l);
+        out[kb * 16] = make_uint2(h | (m << 16), l | (h << 16));
+    }
+    bf16_split3(n2, h, m, l);
+    out[3 * 16] = make_uint2(h | (m << 16), l | (BF16_ONE << 16));
+}
+
+#ifndef MF16_WPE
+#define MF16_WPE 3
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF16_WPE, MF16_WPE))) void k_nn_mfma16(const PairPtrs *__restrict__ pairs,
+                                                const float4 *__restrict__ src_c, const float4 *__restrict__ tgt_c,
+                                                const uint2 *__restrict__ tgtB16, const unsigned int *__restrict__ qmax2_bits,
+                                                const int *__restrict__ ccounts, const float4 *__restrict__ prevq,
+                                                const double *__restrict__ Tcur, unsigned long long *__restrict__ best,
+                                                Geometry g, TileGrid tg, int npad, float cz, int nsplit, int first)
+{
+    __shared__ float4 qpos[MF_Q];
+    __shared__ float4 qrel[MF_Q];                   // (-2 rx, -2 ry, -2 rz, -thr)
+    __shared__ unsigned long long qkey[MF_Q];
+    const int b = blockIdx.z, lane = threadIdx.x;
+    const int N = g.N;
+    const int ns = ccounts[b * 4 + 0], nt = ccounts[b * 4 + 1];
+    const int i0 = blockIdx.x * MF_Q;
+    if (i0 >= ns) return;
+    const float4 *__restrict__ Q = tgt_c + (size_t)b * N;
+    const float4 *__restrict__ tcloud = pairs[b].tgt;
+    const float4 *__restrict__ tnrm = pairs[b].nrm;
+    const Rt m = load_rt(Tcur + b * 16);
+    const float qmax2 = __int_as_float((int)qmax2_bits[b]);
+    int my_slot[MF_Q / 64];
+#pragma unroll
+    for (int h = 0; h < MF_Q / 64; ++h) {
+        const int ql = h * 64 + lane, i = i0 + ql;
+        float4 s4 = make_float4(0, 0, 0, __int_as_float(-1));
+        if (i < ns) s4 = src_c[(size_t)b * N + i];
+        const int slot = __float_as_int(s4.w);
+        const bool valid = slot >= 0;
+        my_slot[h] = slot;
+        float px, py, pz;
+        xform(m, s4.x, s4.y, s4.z, px, py, pz);
+        const unsigned long long bkey = brute_bound(valid, slot, px, py, pz, prevq + (size_t)b * tg.nslots, first, tcloud, tnrm, g, tg);
+        const float U = __int_as_float((int)(unsigned int)(bkey >> 32));
+        const float rx = px, ry = py, rz = pz - cz;
+        const float n2p = __fmaf_rn(rz, rz, __fmaf_rn(ry, ry, rx * rx));
+        const float eps = 1.0e-6f * (n2p + qmax2) + 4.0e-6f * sqrtf(U) + 1.0e-6f
+                        + 4.0e-6f * (2.0f * sqrtf(n2p * qmax2) + qmax2 + n2p + U);
+        const float thr = valid ? (U - n2p) + eps : -1e30f;           // invalid rows can never be flagged
+        qpos[ql] = make_float4(px, py, pz, 0.0f);
+        qrel[ql] = make_float4(-2.0f * rx, -2.0f * ry, -2.0f * rz, -thr);
+        qkey[ql] = bkey;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // ---- A operands: lane (kb = lane >> 4, row = lane & 15) of row block rb holds the eight slots of group kb for query rb * 16 + row
+    const int kq = lane >> 4, jq = lane & 15;
+    const bool is3 = kq == 3;
+    uint4 A[MF_RB];
+#pragma unroll
+    for (int rb = 0; rb < MF_RB; ++rb) {
+        const float4 a4 = qrel[rb * 16 + jq];
+        const float v = kq == 0 ? a4.x : (kq == 1 ? a4.y : (kq == 2 ? a4.z : a4.w));
+        unsigned int h, mm, l;
+        bf16_split3(v, h, mm, l);
+        A[rb] = is3 ? make_uint4(BF16_ONE | (BF16_ONE << 16), BF16_ONE | (h << 16), mm | (l << 16), 0u)
+                    : make_uint4(h | (h << 16), h | (l << 16), mm | (mm << 16), 0u);
+    }
+    const int ngroups = (nt + 15) / 16;
+    const int g_begin = (int)(((long long)blockIdx.y * ngroups) / nsplit);
+    const int g_end = (int)(((long long)(blockIdx.y + 1) * ngroups) / nsplit);
+    auto flagged = [&](const f32x4 *D, int grp) __attribute__((always_inline)) {
+        const int j = grp * 16 + jq;
+        float4 c4 = make_float4(0, 0, 0, __int_as_float(-1));
+        if (j < nt) c4 = Q[j];
+#pragma unroll
+        for (int rb = 0; rb < MF_RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool f = D[rb][r] <= 0.0f && j < nt;
+                if (__ballot(f) != 0ull && f) {
+                    const int qi = rb * 16 + 4 * kq + r;
+                    const float4 p4 = qpos[qi];
+                    const float d2 = canon_d2(p4.x, p4.y, p4.z, c4.x, c4.y, c4.z);
+                    const unsigned long long key =
+                        ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(c4.w);
+                    atomicMin(&qkey[qi], key);
+                }
+            }
+    };
+    union Frag { uint4 u; bf16x8 v; };
+    auto bfrag = [&](const uint2 ld) __attribute__((always_inline)) {
+        Frag f;
+        f.u = make_uint4(ld.x, ld.y, is3 ? (BF16_ONE | (BF16_ONE << 16)) : ld.x, 0u);
+        return f.v;
+    };
+    const f32x4 zero = { 0.0f, 0.0f, 0.0f, 0.0f };
+    // the rotating pipeline of k_nn_mfma: fold group G while the matrix core runs G + 1; the fragment registers G + 1 just
+    // consumed are reloaded with group G + 1 + MF_AHEAD (the padding behind the targets covers the overrun)
+    const uint2 *__restrict__ pB = tgtB16 + ((size_t)b * (npad >> 4) + g_begin) * 64 + lane;
+    uint2 bf[MF_AHEAD];
+    // (the loads are pinned in program order: the loop's s_waitcnt is static, and with the first fragments fetched in any
+    //  other order hipcc settles for vmcnt(0) at the loop head -- every trip would drain all eight prefetches)
+#pragma unroll
+    for (int u = 0; u < MF_AHEAD; ++u) { bf[u] = pB[64 * u]; asm volatile("" ::: "memory"); }
+    f32x4 D[2][MF_RB];
+    {
+        const bf16x8 b0 = bfrag(bf[0]);
+#pragma unroll
+        for (int rb = 0; rb < MF_RB; ++rb) { Frag a; a.u = A[rb]; D[0][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b0, zero, 0, 0, 0); }
+    }
+    asm volatile("" ::: "memory");
+    bf[0] = pB[64 * MF_AHEAD];
+    asm volatile("" ::: "memory");
+    for (int g0 = g_begin; g0 < g_end; g0 += MF_AHEAD, pB += 64 * MF_AHEAD) {
+#pragma unroll
+        for (int u = 0; u < MF_AHEAD; ++u) {
+            const int un = (u + 1) % MF_AHEAD;
+            const bf16x8 bn = bfrag(bf[un]);
+#pragma unroll
+            for (int rb = 0; rb < MF_RB; ++rb) { Frag a; a.u = A[rb]; D[(u + 1) & 1][rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, bn, zero, 0, 0, 0); }
+            bf[un] = pB[64 * (u + 1 + MF_AHEAD)];
+            int mn = 0x7fffffff;                                               // "some value <= 0" <=> "min of the bits as int <= 0"
+#pragma unroll
+            for (int rb = 0; rb < MF_RB; ++rb) {
+                mn = min(min(mn, __float_as_int(D[u & 1][rb][0])), __float_as_int(D[u & 1][rb][1]));
+                mn = min(min(mn, __float_as_int(D[u & 1][rb][2])), __float_as_int(D[u & 1][rb][3]));
+            }
+#if defined(MF16_SCHED) && MF16_SCHED > 0
+#pragma unroll
+            for (int rb = 0; rb < MF_RB; ++rb) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, MF16_SCHED, 0);
+            }
+#endif
+            if (__ballot(mn <= 0) != 0ull) flagged(D[u & 1], g0 + u);
+        }
+    }
 #pragma unroll
     for (int h = 0; h < MF_Q / 64; ++h) {
         if (my_slot[h] >= 0) {

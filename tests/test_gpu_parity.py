@@ -185,6 +185,28 @@ def test_every_nn_mode_is_bit_identical(gpu_lib, nn_mode, estimator):
         assert np.array_equal(St, ro["sums_trace"]) and np.array_equal(Tt, ro["T_trace"])
 
 
+@pytest.mark.parametrize("bf16", ["1", "0"])
+def test_matrix_core_scans_bf16_split_and_f32(gpu_lib, bf16, monkeypatch):
+    """NN_BRUTE_MFMA has two forms: k_nn_mfma16 (default: every float split exactly into three bf16 terms, one
+    v_mfma_f32_16x16x32_bf16 per 16 x 16 tile) and k_nn_mfma (f32 MFMA, SLAM3D_MFMA_BF16=0).  Both are conservative filters
+    in front of the canonical fp32 distance, so both must reproduce the brute-force oracle bit for bit: at 640x480 (where
+    |p|, |q| reach the far end of the depth range and the filter's error bound is largest), with a tight gate, from a poor
+    initial guess, and in a later iteration where the bounds are millimetres."""
+    monkeypatch.setenv("SLAM3D_MFMA_BF16", bf16)
+    pr, s4, t4 = _pair(1001, 640, 480)
+    for max_corr, T0, iters in ((0.10, None, 3), (0.02, synth.pose_from_seed(5, 1.0, 0.02), 2)):
+        po = O.params(pr.intr, iterations=iters, nn_method=1, max_corr_dist=max_corr)
+        ro = O.icp(s4, t4, po, T_init=T0)
+        pg = capi.default_params(pr.intr, iterations=iters, nn_mode=capi.NN_BRUTE_MFMA, max_corr_dist=max_corr)
+        with capi.IcpHandle(pg) as h:
+            h.align(s4, t4, T_init=T0)
+            idx, d2 = h.get_correspondences(0)
+            Tt, St = h.get_trace(0)
+        assert np.array_equal(idx, ro["idx"]), f"bf16={bf16} gate {max_corr}: {(idx != ro['idx']).sum()} mismatches"
+        assert np.array_equal(d2, ro["d2"])
+        assert np.array_equal(St, ro["sums_trace"]) and np.array_equal(Tt, ro["T_trace"])
+
+
 def test_odd_image_size_not_multiple_of_tile(gpu_lib):
     """Ragged tiles: width/height not multiples of 8 (tile) or 64 (coarse box)."""
     pr, s4, t4 = _pair(1001, 200, 150)

@@ -79,7 +79,7 @@ def test_tile_item_mask_survives_in_front_of_the_record_address(device_asm):
 def test_production_search_kernels_have_no_scratch_and_use_the_fp64_matrix_cores(device_asm):
     """The production instances of k_nn_tiles_acc (cooperative and throughput build) keep their register budget -- 72 / 64
     VGPRs at 7 / 8 waves per SIMD, no scratch --, and the epilogue's Gram accumulation is eight v_mfma_f64_16x16x4_f64 (spec
-    S4, round 4); the full-scan mode's 64 v_mfma_f32_16x16x4_f32 are there too.
+    S4, round 4); the full-scan mode's 64 v_mfma_f32_16x16x4_f32 and 64 v_mfma_f32_16x16x32_bf16 are there too.
     Parity: tests/test_gpu_parity.py::test_every_nn_mode_is_bit_identical."""
     meta = _meta(device_asm)
     bodies = _kernel_bodies(device_asm)
@@ -89,5 +89,14 @@ def test_production_search_kernels_have_no_scratch_and_use_the_fp64_matrix_cores
         assert int(meta[n]["private_segment_fixed_size"]) == 0 and int(meta[n]["vgpr_spill_count"]) == 0, (n, meta[n])
         assert int(meta[n]["vgpr_count"]) <= 72
         assert bodies[n].count("v_mfma_f64_16x16x4") == 8, bodies[n].count("v_mfma_f64_16x16x4")
-    mf = [n for n in bodies if "k_nn_mfma" in n]
+    mf = [n for n in bodies if "k_nn_mfmaE" in n]                                  # (Itanium names: 9k_nn_mfmaE... / 11k_nn_mfma16E...)
     assert len(mf) == 1 and bodies[mf[0]].count("v_mfma_f32_16x16x4") >= 64
+    # the bf16-split form (round 4): 64+ v_mfma_f32_16x16x32_bf16 with the inline constant 0 as C, no scratch, and a loop head that
+    # waits for ONE fragment (vmcnt(7)), not for all eight (tests/test_gpu_parity.py::test_matrix_core_scans_bf16_split_and_f32)
+    mf16 = [n for n in bodies if "k_nn_mfma16E" in n]
+    assert len(mf16) == 1 and bodies[mf16[0]].count("v_mfma_f32_16x16x32_bf16") >= 64
+    assert int(meta[mf16[0]]["private_segment_fixed_size"]) == 0 and int(meta[mf16[0]]["vgpr_spill_count"]) == 0
+    import re
+    loop = bodies[mf16[0]].split("Inner Loop Header", 1)[1]
+    first_wait = re.search(r"s_waitcnt vmcnt\((\d+)\)", loop)
+    assert first_wait and int(first_wait.group(1)) >= 4, first_wait

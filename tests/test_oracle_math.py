@@ -131,3 +131,33 @@ def test_pose_error_metric():
     assert abs(r - a) < 1e-12 and t == 0.0
     r, t = O.pose_error(T, T)
     assert r < 1e-7 and t == 0.0
+
+
+def _bf16_rne(v):
+    """the bf16 nearest to each float32 (round to nearest even), returned as float32 -- csrc/icp_kernels.hpp::bf16_rne"""
+    u = np.asarray(v, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7fff + ((u >> 16) & 1)) >> 16) << 16
+    return r.astype(np.uint32).view(np.float32)
+
+
+def test_bf16_three_way_split_is_exact_and_its_cross_terms_are_bounded():
+    """What the bf16 matrix-core scan (k_nn_mfma16) rests on: a float is EXACTLY h + m + l with h = bf16(v), m = bf16(v - h),
+    l = bf16(v - h - m) (bf16: 8 significand bits, so |m| <= 2^-8 |v|, |l| <= 2^-16 |v|); and the six products the kernel keeps
+    of (a_h + a_m + a_l)(b_h + b_m + b_l) miss a b by less than 2^-23 |a b| (a_m b_l + a_l b_m + a_l b_l: the bound its eps uses).  Checked in exact (float64) arithmetic on magnitudes the clouds have."""
+    rng = np.random.default_rng(7)
+    v = np.concatenate([rng.uniform(-8, 8, 200000), rng.normal(0, 1e-3, 50000), rng.uniform(0, 70, 50000)]).astype(np.float32)
+    h = _bf16_rne(v)
+    r1 = (v - h).astype(np.float32)
+    assert np.array_equal(r1.astype(np.float64), v.astype(np.float64) - h.astype(np.float64))          # v - h is exact in float
+    m = _bf16_rne(r1)
+    r2 = (r1 - m).astype(np.float32)
+    assert np.array_equal(r2.astype(np.float64), r1.astype(np.float64) - m.astype(np.float64))
+    l = _bf16_rne(r2)
+    assert np.array_equal(h.astype(np.float64) + m.astype(np.float64) + l.astype(np.float64), v.astype(np.float64))   # three terms: exact
+    a, b = v[:150000].astype(np.float64), v[150000:300000].astype(np.float64)
+    ah, am, al = (x[:150000].astype(np.float64) for x in (h, m, l))
+    bh, bm, bl = (x[150000:300000].astype(np.float64) for x in (h, m, l))
+    kept = ah * bh + ah * bm + ah * bl + al * bh + am * bh + am * bm
+    err = np.abs(a * b - kept)
+    assert np.all(err <= 2.0 ** -23 * np.abs(a * b) + 1e-300)
+    assert np.all(np.abs(m) <= 2.0 ** -8 * np.abs(v)) and np.all(np.abs(l) <= 2.0 ** -16 * np.abs(v))
