@@ -839,7 +839,7 @@ def main():
     P = args.pairs
     S = max(P, (args.pairs_per_step // P) * P)
     aligns = S // P
-    n_handles = 1 if args.no_pipeline else max(1, min(8, args.in_flight))
+    n_handles = 1 if args.no_pipeline else max(1, min(16, args.in_flight))
     pool_n = max(args.pool, P)
     # every in-flight handle streams its own distinct pairs: seeds seed0 + (rank * n_handles + hi) * pool_n + k
     want_extra = (rank == 0 and world == 1 and not args.no_extra_configs and args.nn_mode in (capi.NN_AUTO, capi.NN_TILES)

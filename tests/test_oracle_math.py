@@ -161,3 +161,24 @@ def test_bf16_three_way_split_is_exact_and_its_cross_terms_are_bounded():
     err = np.abs(a * b - kept)
     assert np.all(err <= 2.0 ** -23 * np.abs(a * b) + 1e-300)
     assert np.all(np.abs(m) <= 2.0 ** -8 * np.abs(v)) and np.all(np.abs(l) <= 2.0 ** -16 * np.abs(v))
+
+
+def test_pose_error_matches_the_reference_tool():
+    """Row a14, pinned by the reference itself: orc_pose_error (the metric every parity test and bench leg reports) against the
+    numbers the reference's tools/evaluate_rpe.py functions (ominus, compute_angle, compute_distance) returned for 96 seeded
+    pose pairs -- tests/golden/pose_error_golden.json, made by tests/golden/make_pose_error_golden.py, which executes those
+    functions where they lie under /root/reference.  The two differ only in how the relative pose is formed (numpy.linalg.inv
+    there, the analytic inverse here): 1e-9 on the angle away from 0, 5e-8 where acos meets a trace rounded next to 3."""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pose_error_golden.json")))
+    assert len(g["cases"]) >= 90
+    worst_a = worst_d = 0.0
+    for c in g["cases"]:
+        rot, tr = O.pose_error(np.array(c["A"]).reshape(4, 4), np.array(c["B"]).reshape(4, 4))
+        tol = 1e-9 if c["angle"] > 1e-3 else 5e-8
+        assert abs(rot - c["angle"]) <= tol, (rot, c["angle"])
+        assert abs(tr - c["distance"]) <= 1e-12 * max(1.0, c["distance"]), (tr, c["distance"])
+        if c["angle"] > 1e-3:
+            worst_a = max(worst_a, abs(rot - c["angle"]))
+        worst_d = max(worst_d, abs(tr - c["distance"]))
+    assert worst_a <= 1e-9 and worst_d <= 1e-12
