@@ -1005,7 +1005,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF_WPE, MF_W
 // three-way split itself is exact: tests/test_oracle_math.py), and the matrix core's accumulation -- at most 23
 // additions, each bounded by a TRUNCATION (2^-23) of the running magnitude S <= 2 |p||q| + |q|^2 + |thr|, whatever order
 // or width the hardware uses: together 24 x 2^-23 S = 2.9e-6 S.
-// eps16 = 4e-6 (2 sqrt(|p|^2 max|q|^2) + max|q|^2 + |p|^2 + U) on top.
+// eps16 = 4e-6 (2 sqrt(|p|^2 max|q|^2) + max|q|^2 + |p|^2 + U) on top.  (Measured, tools/ubench_bf16acc.hip: the matrix core's
+// own error on this slot pattern is 2.5 x 2^-24 S at worst -- the model bound has a factor 19 in hand; a GPU test holds it.)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned int bf16_rne(float v)              // the bf16 nearest to a finite v, as its 16 bits
 {

@@ -4,6 +4,8 @@ Bar (BASELINE.json north_star): correspondence indices bit-exact; pose within 1e
 The implementation is designed to be bit-identical in T as well; the tests
 assert the contractual tolerance and additionally report/guard the stronger property.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -205,6 +207,23 @@ def test_matrix_core_scans_bf16_split_and_f32(gpu_lib, bf16, monkeypatch):
         assert np.array_equal(idx, ro["idx"]), f"bf16={bf16} gate {max_corr}: {(idx != ro['idx']).sum()} mismatches"
         assert np.array_equal(d2, ro["d2"])
         assert np.array_equal(St, ro["sums_trace"]) and np.array_equal(Tt, ro["T_trace"])
+
+
+def test_bf16_matrix_core_accumulation_error_is_inside_the_filter_bound(gpu_lib, tmp_path):
+    """k_nn_mfma16's eps assumes that v_mfma_f32_16x16x32_bf16 returns the exact sum of its (exact) bf16 x bf16 products up to
+    24 x 2^-23 of sum |terms| -- a model bound (23 truncating additions), not a measurement.  tools/ubench_bf16acc.hip measures
+    what the hardware really does on operands with the kernel's slot pattern and magnitudes (large terms that cancel): the
+    worst error must stay inside the bound (it exits non-zero otherwise) and, as a tripwire for a changed matrix core, below
+    8 x 2^-24 (measured on gfx950: 2.5)."""
+    import re, shutil, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "ubench_bf16acc")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-w", os.path.join(root, "tools", "ubench_bf16acc.hip"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    worst = float(re.search(r"= ([0-9.]+) x 2\^-24", r.stdout).group(1))
+    assert worst < 8.0, r.stdout
 
 
 def test_odd_image_size_not_multiple_of_tile(gpu_lib):
