@@ -331,7 +331,8 @@ def bruteforce_leg(capi, intr, est, s4, t4, local_rank, iterations=4):
     v_mfma_f32_16x16x32_bf16 per 16 x 16 tile -- the default of NN_BRUTE_MFMA), k_nn_mfma (v_mfma_f32_16x16x4_f32;
     SLAM3D_MFMA_BF16=0) and the fp32-VALU scan k_nn_valu."""
     out = {}
-    for mode, name, env in ((capi.NN_BRUTE_MFMA, "mfma16", None), (capi.NN_BRUTE_MFMA, "mfma", ("SLAM3D_MFMA_BF16", "0")), (capi.NN_BRUTE_VALU, "valu", None)):
+    for mode, name, env in ((capi.NN_BRUTE_MFMA, "mfma16", None), (capi.NN_BRUTE_MFMA, "mfma", ("SLAM3D_MFMA_BF16", "0")), (capi.NN_BRUTE_VALU, "valu", None),
+                            (capi.NN_BRUTE_VALU, "valu_filter", ("SLAM3D_VALU_FILTER", "1"))):
         # (coarse_iterations = 0: every launch scans every source against every target -- the N x M contraction the flop count assumes)
         params = capi.default_params(intr, estimator=est, iterations=iterations, max_batch=1, device=local_rank, nn_mode=mode, coarse_iterations=0)
         if env:
@@ -353,6 +354,7 @@ def bruteforce_leg(capi, intr, est, s4, t4, local_rank, iterations=4):
     ms16, pairs = out["mfma16"]
     ms, _ = out["mfma"]
     vms, _ = out["valu"]
+    vfms, _ = out["valu_filter"]
     # executed flops: the bf16 instruction multiplies K = 32 slots per (source, target) pair (64 flop; 22 slots carry terms),
     # the f32 one K = 4 (8 flop), the VALU scan evaluates the canonical distance (8 flop)
     ach16 = 64.0 * pairs / (ms16 * 1e-3) / 1e12
@@ -368,7 +370,11 @@ def bruteforce_leg(capi, intr, est, s4, t4, local_rank, iterations=4):
             "f32_mfma_kernel": {"kernel": "k_nn_mfma (v_mfma_f32_16x16x4_f32, SLAM3D_MFMA_BF16=0)", "launch_ms": ms, "achieved": ach,
                                 "peak": FP32_PEAK_TFLOPS, "frac": ach / FP32_PEAK_TFLOPS},
             "valu_kernel": {"kernel": "k_nn_valu (same scan on the fp32 VALU, canonical distances)", "launch_ms": vms,
-                            "achieved": 8.0 * pairs / (vms * 1e-3) / 1e12, "frac": 8.0 * pairs / (vms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS}}
+                            "achieved": 8.0 * pairs / (vms * 1e-3) / 1e12, "frac": 8.0 * pairs / (vms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS},
+            "valu_filter_kernel": {"kernel": "k_nn_valu<filter> (SLAM3D_VALU_FILTER=1: the expanded form |q|^2 - 2 p.q as a filter on the VALU, 6 flop per pair executed; "
+                                             "flagged chunks re-evaluated canonically)", "launch_ms": vfms,
+                                   "achieved": 6.0 * pairs / (vfms * 1e-3) / 1e12, "frac": 6.0 * pairs / (vfms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                                   "equivalent_f32_contraction_tflops": 8.0 * pairs / (vfms * 1e-3) / 1e12}}
 
 
 def profiled_pass(handle, pool, P, n_align, est):

@@ -49,7 +49,9 @@ enum {
 enum { SLAM3D_EST_POINT2PLANE = 0, SLAM3D_EST_SVD = 1 };
 /* NN search variants: all return bit-identical correspondences.
  *   BRUTE_VALU  every source x every target, LDS-tiled, fp32 VALU
- *   BRUTE_MFMA  same scan, distance contraction on the f32 MFMA pipe as a conservative filter
+ *   BRUTE_MFMA  same scan, the distance step as a dense contraction on the matrix cores used as a conservative
+ *               filter (bf16 MFMA on exact three-way bf16 splits of every float; the f32 MFMA form with the
+ *               environment variable SLAM3D_MFMA_BF16=0), flagged pairs re-evaluated in canonical fp32
  *   TILES       exact search restricted to the 8x8-pixel target tiles whose bounding box can hold
  *               a winner (AABB culling against a per-query upper bound); AUTO selects this */
 enum { SLAM3D_NN_AUTO = 0, SLAM3D_NN_BRUTE_VALU = 1, SLAM3D_NN_BRUTE_MFMA = 2, SLAM3D_NN_TILES = 3 };

@@ -683,7 +683,27 @@ __device__ __forceinline__ unsigned long long brute_bound(bool valid, int slot, 
 // within its bound (brute_bound above; the bound tightens with every rescan).  With a bound that is the distance to a
 // real neighbour a few chunks per query qualify out of ~14,000.  Splits merge through a 64-bit atomicMin on the key;
 // best[] is indexed by source SLOT.
+// max |q - centre|^2 over a pair's compacted targets (the eps of the expanded-form filters needs it)
+__global__ __launch_bounds__(256) void k_qmax2(const float4 *__restrict__ tgt_c, const int *__restrict__ ccounts,
+                                               unsigned int *__restrict__ qmax2_bits, int N, float cz)
+{
+    const int b = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    float n2 = 0.0f;
+    if (j < ccounts[b * 4 + 1]) {
+        const float4 q = tgt_c[(size_t)b * N + j];
+        const float rz = q.z - cz;
+        n2 = __fmaf_rn(rz, rz, __fmaf_rn(q.y, q.y, q.x * q.x));
+    }
+    for (int o = 32; o >= 1; o >>= 1) n2 = fmaxf(n2, __shfl_xor(n2, o));
+    if ((threadIdx.x & 63) == 0 && n2 > 0.0f) atomicMax(qmax2_bits + b, (unsigned int)__float_as_int(n2));   // non-negative floats order like uints
+}
+
+// FILT (SLAM3D_VALU_FILTER=1; not the default -- the default evaluates every canonical distance): the chunk minimum is
+// taken over the EXPANDED form |q|^2 - 2 p.q (three fmas on centred coordinates, the contraction the matrix-core kernels
+// run) and compared with thr = U - |p|^2 + eps -- the same conservative filter as k_nn_mfma, eps included, on the VALU:
+// 3.5 operations per candidate.  Flagged chunks are rescanned canonically as before, so the result is the same.
 constexpr int NV_CH = 16;
+template <bool FILT, int QPT>
 __global__ __launch_bounds__(NN_BLOCK) void k_nn_valu(const PairPtrs *__restrict__ pairs,
                                                       const float4 *__restrict__ src_c,
                                                       const float4 *__restrict__ tgt_c,
@@ -691,13 +711,14 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_valu(const PairPtrs *__restrict
                                                       const float4 *__restrict__ prevq,
                                                       const double *__restrict__ Tcur,
                                                       unsigned long long *__restrict__ best, Geometry g, TileGrid tg,
-                                                      int nsplit, int first)
+                                                      int nsplit, int first, const unsigned int *__restrict__ qmax2_bits, float cz)
 {
     __shared__ float4 tile[NN_TILE];
+    __shared__ float4 tileR[FILT ? NN_TILE : 1];               // FILT: (rx, ry, rz, |r|^2) of the same candidates
     const int b = blockIdx.z;
     const int N = g.N, nslots = tg.nslots;
     const int ns = ccounts[b * 4 + 0], nt = ccounts[b * 4 + 1];
-    const int q0 = blockIdx.x * (NN_BLOCK * NN_QPT);
+    const int q0 = blockIdx.x * (NN_BLOCK * QPT);
     if (q0 >= ns) return;
     const int ntiles = (nt + NN_TILE - 1) / NN_TILE;
     const int tile_begin = (int)(((long long)blockIdx.y * ntiles) / nsplit);
@@ -706,12 +727,12 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_valu(const PairPtrs *__restrict
     const float4 *__restrict__ S = src_c + (size_t)b * N;
     const float4 *__restrict__ Q = tgt_c + (size_t)b * N;
     const Rt m = load_rt(Tcur + b * 16);
-    float px[NN_QPT], py[NN_QPT], pz[NN_QPT];
-    unsigned long long bk[NN_QPT];
-    int slot[NN_QPT];
+    float px[QPT], py[QPT], pz[QPT];
+    unsigned long long bk[QPT];
+    int slot[QPT];
     const float inf = __int_as_float(0x7f800000);
 #pragma unroll
-    for (int k = 0; k < NN_QPT; ++k) {
+    for (int k = 0; k < QPT; ++k) {
         const int i = q0 + k * NN_BLOCK + threadIdx.x;
         float4 s = make_float4(0, 0, 0, __int_as_float(-1));
         if (i < ns) s = S[i];
@@ -719,48 +740,94 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_valu(const PairPtrs *__restrict
         xform(m, s.x, s.y, s.z, px[k], py[k], pz[k]);
         bk[k] = brute_bound(slot[k] >= 0, slot[k], px[k], py[k], pz[k], prevq + (size_t)b * nslots, first, pairs[b].tgt, pairs[b].nrm, g, tg);
     }
+    // FILT: a = -2 (p - centre), and what the threshold needs: |p - centre|^2 and the U-independent part of eps (k_nn_mfma's)
+    float ax[QPT], ay[QPT], az[QPT], n2p[QPT], epsb[QPT], thr[QPT];
+    auto set_thr = [&](int k) __attribute__((always_inline)) {
+        const float U = __int_as_float((int)(unsigned int)(bk[k] >> 32));
+        thr[k] = slot[k] >= 0 ? (U - n2p[k]) + (epsb[k] + 4.0e-6f * sqrtf(U)) : -1e30f;
+    };
+    if constexpr (FILT) {
+        const float qmax2 = __int_as_float((int)qmax2_bits[b]);
+#pragma unroll
+        for (int k = 0; k < QPT; ++k) {
+            const float rx = px[k], ry = py[k], rz = pz[k] - cz;
+            n2p[k] = __fmaf_rn(rz, rz, __fmaf_rn(ry, ry, rx * rx));
+            epsb[k] = 1.0e-6f * (n2p[k] + qmax2) + 1.0e-6f;
+            ax[k] = -2.0f * rx; ay[k] = -2.0f * ry; az[k] = -2.0f * rz;
+            set_thr(k);
+        }
+    }
     for (int t = tile_begin; t < tile_end; ++t) {
         const int j0 = t * NN_TILE;
         __syncthreads();
         for (int k = threadIdx.x; k < NN_TILE; k += NN_BLOCK) {
             const int j = j0 + k;
             float4 q = make_float4(__int_as_float(-1), inf, inf, inf);        // padding: d2 = +inf is within no bound
-            if (j < nt) { const float4 c = Q[j]; q = make_float4(c.w, c.x, c.y, c.z); }       // (pixel, x, y, z)
+            float4 qr = make_float4(1e4f, 1e4f, 1e4f, 3e8f);                  // FILT padding: far away, never flagged
+            if (j < nt) {
+                const float4 c = Q[j];
+                q = make_float4(c.w, c.x, c.y, c.z);                          // (pixel, x, y, z)
+                if constexpr (FILT) {
+                    const float rz = c.z - cz;
+                    qr = make_float4(c.x, c.y, rz, __fmaf_rn(rz, rz, __fmaf_rn(c.y, c.y, c.x * c.x)));
+                }
+            }
             tile[k] = q;
+            if constexpr (FILT) tileR[k] = qr;
         }
         __syncthreads();
 #pragma unroll 1
         for (int c0 = 0; c0 < NN_TILE; c0 += NV_CH) {
-            float mn[NN_QPT];
-#pragma unroll
-            for (int jj = 0; jj < NV_CH; jj += 2) {
-                const float4 ca = tile[c0 + jj], cb = tile[c0 + jj + 1];
-#pragma unroll
-                for (int k = 0; k < NN_QPT; ++k) {
-                    const float da = canon_d2(px[k], py[k], pz[k], ca.y, ca.z, ca.w);
-                    const float db = canon_d2(px[k], py[k], pz[k], cb.y, cb.z, cb.w);
-                    if (jj == 0) asm("v_min_f32 %0, %1, %2" : "=v"(mn[k]) : "v"(da), "v"(db));
-                    else asm("v_min3_f32 %0, %0, %1, %2" : "+v"(mn[k]) : "v"(da), "v"(db));       // (never NaN: no canonicalisation wanted)
-                }
-            }
+            float mn[QPT];
             bool hit = false;
+            if constexpr (FILT) {
 #pragma unroll
-            for (int k = 0; k < NN_QPT; ++k) hit = hit || mn[k] <= __int_as_float((int)(unsigned int)(bk[k] >> 32));
+                for (int jj = 0; jj < NV_CH; jj += 2) {
+                    const float4 ca = tileR[c0 + jj], cb = tileR[c0 + jj + 1];
+#pragma unroll
+                    for (int k = 0; k < QPT; ++k) {
+                        const float ea = __fmaf_rn(az[k], ca.z, __fmaf_rn(ay[k], ca.y, __fmaf_rn(ax[k], ca.x, ca.w)));
+                        const float eb = __fmaf_rn(az[k], cb.z, __fmaf_rn(ay[k], cb.y, __fmaf_rn(ax[k], cb.x, cb.w)));
+                        if (jj == 0) asm("v_min_f32 %0, %1, %2" : "=v"(mn[k]) : "v"(ea), "v"(eb));
+                        else asm("v_min3_f32 %0, %0, %1, %2" : "+v"(mn[k]) : "v"(ea), "v"(eb));
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < QPT; ++k) hit = hit || mn[k] <= thr[k];
+            } else {
+#pragma unroll
+                for (int jj = 0; jj < NV_CH; jj += 2) {
+                    const float4 ca = tile[c0 + jj], cb = tile[c0 + jj + 1];
+#pragma unroll
+                    for (int k = 0; k < QPT; ++k) {
+                        const float da = canon_d2(px[k], py[k], pz[k], ca.y, ca.z, ca.w);
+                        const float db = canon_d2(px[k], py[k], pz[k], cb.y, cb.z, cb.w);
+                        if (jj == 0) asm("v_min_f32 %0, %1, %2" : "=v"(mn[k]) : "v"(da), "v"(db));
+                        else asm("v_min3_f32 %0, %0, %1, %2" : "+v"(mn[k]) : "v"(da), "v"(db));       // (never NaN: no canonicalisation wanted)
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < QPT; ++k) hit = hit || mn[k] <= __int_as_float((int)(unsigned int)(bk[k] >> 32));
+            }
             if (__ballot(hit) != 0ull) {
 #pragma unroll 2
                 for (int jj = 0; jj < NV_CH; ++jj) {
                     const float4 c = tile[c0 + jj];
 #pragma unroll
-                    for (int k = 0; k < NN_QPT; ++k) {
+                    for (int k = 0; k < QPT; ++k) {
                         const float d2 = canon_d2(px[k], py[k], pz[k], c.y, c.z, c.w);
                         bk[k] = key_min(bk[k], ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(c.x));
                     }
+                }
+                if constexpr (FILT) {
+#pragma unroll
+                    for (int k = 0; k < QPT; ++k) set_thr(k);          // the bound may have tightened
                 }
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < NN_QPT; ++k)
+    for (int k = 0; k < QPT; ++k)
         if (slot[k] >= 0 && (unsigned int)bk[k] != 0xffffffffu) atomicMin(best + (size_t)b * nslots + slot[k], bk[k]);
 }
 

@@ -209,6 +209,22 @@ def test_matrix_core_scans_bf16_split_and_f32(gpu_lib, bf16, monkeypatch):
         assert np.array_equal(St, ro["sums_trace"]) and np.array_equal(Tt, ro["T_trace"])
 
 
+def test_valu_scan_with_the_expanded_form_filter(gpu_lib, monkeypatch):
+    """SLAM3D_VALU_FILTER=1: k_nn_valu takes its chunk minima over the expanded form |q|^2 - 2 p.q (the matrix-core kernels'
+    contraction and eps, on the VALU) instead of the canonical distances; flagged chunks are rescanned canonically, so the
+    result must be the brute-force oracle's, bit for bit -- 640x480, wide and tight gates."""
+    monkeypatch.setenv("SLAM3D_VALU_FILTER", "1")
+    pr, s4, t4 = _pair(1003, 640, 480)
+    for max_corr, T0, iters in ((0.10, None, 3), (0.02, synth.pose_from_seed(6, 1.0, 0.02), 2)):
+        ro = O.icp(s4, t4, O.params(pr.intr, iterations=iters, nn_method=1, max_corr_dist=max_corr), T_init=T0)
+        with capi.IcpHandle(capi.default_params(pr.intr, iterations=iters, nn_mode=capi.NN_BRUTE_VALU, max_corr_dist=max_corr)) as h:
+            h.align(s4, t4, T_init=T0)
+            idx, d2 = h.get_correspondences(0)
+            Tt, St = h.get_trace(0)
+        assert np.array_equal(idx, ro["idx"]) and np.array_equal(d2, ro["d2"])
+        assert np.array_equal(St, ro["sums_trace"]) and np.array_equal(Tt, ro["T_trace"])
+
+
 def test_bf16_matrix_core_accumulation_error_is_inside_the_filter_bound(gpu_lib, tmp_path):
     """k_nn_mfma16's eps assumes that v_mfma_f32_16x16x32_bf16 returns the exact sum of its (exact) bf16 x bf16 products up to
     24 x 2^-23 of sum |terms| -- a model bound (23 truncating additions), not a measurement.  tools/ubench_bf16acc.hip measures
