@@ -1,33 +1,44 @@
 #!/usr/bin/env python3
-"""Fills the @@PLACEHOLDERS@@ of DESIGN.md section 7 / 9 from a bench line (profiles/rNN_bench.json) so that the table is a
-copy of the measured file, not a transcription.  usage: tools/fill_design.py profiles/r04_bench.json [n_gpu_tests] [normals_us]"""
+"""Rewrites the round-4 column of DESIGN.md section 7 from the committed bench lines (profiles/r04_bench.json,
+profiles/r04_voxel_bench.json), so that the table is a copy of the measured files, not a transcription.
+usage: tools/fill_design.py [n_gpu_tests]"""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-txt = open(sys.argv[1]).read()
-try:
-    d = json.loads(txt)
-except Exception:
-    d = json.loads([l for l in txt.splitlines() if l.startswith("{")][-1])
-k = lambda v: f"{v / 1e3:.1f} k"
-per = d["nn_ms_per_iteration"]
-rp = d.get("real_pair", {})
-rep = {
-    "HEADLINE": f"{d['value']:,.0f} ({1e3 * 20 / d['value']:.3f} ms per pair)",
-    "LAT": f"{d['single_step_latency_ms']:.3f}",
-    "PERIT": " / ".join(f"{1e3 * x:.0f}" for x in per[:4]) + f", {1e3 * min(per[4:8]):.0f}–{1e3 * max(per[4:8]):.0f}, {1e3 * min(per[8:]):.0f}–{1e3 * max(per[8:]):.0f}",
-    "BMD": f"{d['baseline_md_workload']['value']:,.0f} ({d['baseline_md_workload']['ratio_to_headline']:.2f}×; n_tgt {d['baseline_md_workload']['n_tgt']:,})" if "baseline_md_workload" in d else "n/a",
-    "REAL": " / ".join(k(rp[n]["value"]) for n in ("dep1_to_dep2_wide_baseline", "dep1_to_dep1_perturbed", "dep2_to_dep2_perturbed") if n in rp),
-    "C3": f"{d['config3']['value']:,.0f}" if "config3" in d else "n/a",
-    "C5": f"{d['config5']['value']:,.0f}" if "config5" in d else "n/a",
-    "NTESTS": sys.argv[2] if len(sys.argv) > 2 else "?",
-    "NRM": (sys.argv[3] + " µs (71 VGPRs)") if len(sys.argv) > 3 else "?",
-}
+d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+v = json.load(open(os.path.join(ROOT, "profiles", "r04_voxel_bench.json")))
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
-for key, v in rep.items():
-    s = s.replace("@@" + key + "@@", v)
+
+
+def row(prefix, newcell):
+    global s
+    m = re.search(r"^(\| " + re.escape(prefix) + r"[^|]*\| )([^|]*)(\| [^|]*\|)$", s, re.M)
+    assert m, prefix
+    s = s[:m.start()] + m.group(1) + newcell + " " + m.group(3) + s[m.end():]
+
+
+k = lambda x: f"{x / 1e3:.1f} k"
+per = d["nn_ms_per_iteration"]
+rb = d["roofline_bruteforce"]
+rp = d["real_pair"]
+row("**headline**", f"**{d['value']:,.0f} ({1e3 * 20 / d['value']:.3f} ms per pair)**")
+row("one alignment at a time", f"**{d['single_step_latency_ms']:.3f} ms**")
+row("NN launch per iteration", " / ".join(f"{1e3 * x:.0f}" for x in per[:4]) + f", {1e3 * min(per[4:8]):.0f}–{1e3 * max(per[4:8]):.0f}, {1e3 * min(per[8:]):.0f}–{1e3 * max(per[8:]):.0f}")
+b = d["baseline_md_workload"]
+row("BASELINE.md §4's workload", f"{b['value']:,.0f} ({b['ratio_to_headline']:.2f}×; n_tgt {b['n_tgt']:,})")
+row("the reference's Kinect frames", " / ".join(k(rp[n]["value"]) for n in ("dep1_to_dep2_wide_baseline", "dep1_to_dep1_perturbed", "dep2_to_dep2_perturbed")))
+row("config 3: 64 pairs per launch", f"**{d['config3']['value']:,.0f}**")
+t = d["two_pairs_per_launch"]
+row("the same stream with two pairs", f"{t['value']:,.0f} ({t['ratio_to_headline']:.2f}×)")
+row("config 5 on 1 GPU", f"{d['config5']['value']:,.0f}")
+vf = rb.get("valu_filter_kernel", {})
+row("full scan, 640×480 (ms per launch)", f"**{rb['launch_ms']:.2f}** / {rb['f32_mfma_kernel']['launch_ms']:.2f} / {rb['valu_kernel']['launch_ms']:.2f}" + (f" ({vf['launch_ms']:.2f} with the VALU filter)" if vf else ""))
+row("the same as contraction rates", f"{rb['achieved']:,.0f} ({100 * rb['frac']:.0f} %) / **{rb['equivalent_f32_contraction_tflops']:.0f} ({100 * rb['equivalent_frac_of_f32_peak']:.0f} %)** / "
+    f"{rb['f32_mfma_kernel']['achieved']:.0f} ({100 * rb['f32_mfma_kernel']['frac']:.0f} %) / {rb['valu_kernel']['achieved']:.0f} ({100 * rb['valu_kernel']['frac']:.0f} %)")
+row("f-1 voxel grid per 640×480 frame", f"{1e3 * v['ms_per_step']:.1f} µs (26.7)")
+c = d["cpu_baseline"]
+row("CPU oracle, kd-tree", f"{c['value']:.0f} ({c['cores']} thr) / {c['single_thread_value']:.0f} it/s")
+if len(sys.argv) > 1:
+    row("GPU test suite", sys.argv[1])
 open(p, "w").write(s)
-print({key: v for key, v in rep.items()})
-left = re.findall(r"@@\w+@@", s)
-if left:
-    print("unfilled:", left)
+print("DESIGN.md section 7 rewritten from profiles/r04_bench.json: headline", d["value"])
