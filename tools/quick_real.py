@@ -18,7 +18,7 @@ for cfg in (sys.argv[1:] or [""]):
     for kv in filter(None, cfg.split(",")):
         k, v = kv.split("="); os.environ[k] = v; keys.append(k)
     for name, s, t, T0 in cases:
-        with capi.IcpHandle(capi.default_params(synth.Intrinsics(), iterations=20)) as h:
+        with capi.IcpHandle(capi.default_params(synth.Intrinsics(), iterations=20, max_corr_dist=float(os.environ.get("QR_GATE", "0.10")))) as h:
             kw = {} if T0 is None else {"T_init": T0.reshape(1, 16)}
             for _ in range(2):
                 h.align_depth_batch([s], [t], **kw)
