@@ -590,11 +590,11 @@ def seg_mode(args, torch, dist, capi, synth, world, rank, local_rank, dev):
         "config": {"workload": f"row f-2: {F} frame(s) per GPU, <= {sp.max_planes} planes, {sp.hypotheses} hypotheses per round, "
                                f"threshold {sp.distance_threshold:.2f} m, plane_percent {sp.plane_percent:.1f}",
                    "frames_per_gpu": F, "planes_found": rounds[:8]},
-        "roofline": {"kernel": "whole launch sequence (k_seg_init + rounds x {hyp, count, moments, refine, label})",
+        "roofline": {"kernel": "whole launch sequence (k_seg_init + rounds x {hyp+count, moments, refine+label})",
                      "bound": "hbm", "achieved": alg_bytes / (elapsed / args.steps) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBPS, "traffic": None,
                      "algorithmic_bytes_per_step": alg_bytes,
-                     "note": "17 dependent small launches per call; launch latency, not bandwidth, bounds one frame"},
+                     "note": "a frame alone: 11 dependent small launches per call (init + 3 per round + final), launch latency bounds it; batches: 5 per round"},
     }
     if rank == 0:
         if not args.no_cpu_baseline:

@@ -1449,13 +1449,22 @@ extern "C" int slam3d_segment_planes_device(slam3d_icp_handle *h, int32_t B, con
     HIPCHK(h, hipMemsetAsync(h->seg_state, 0, sizeof(SegState) * B, s));
     hipLaunchKernelGGL(k_seg_init, pg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, h->g.zmax);
     for (int r = 0; r < P.max_planes; ++r) {
-        hipLaunchKernelGGL(k_seg_hyp, dim3(B), dim3(64), 0, s, h->seg_ptrs, lab, h->seg_state, N, P, r);
-        hipLaunchKernelGGL(k_seg_count, dim3(pg.x, pg.y, (P.hypotheses + SEG_HGROUP - 1) / SEG_HGROUP), dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, P.hypotheses);
-        hipLaunchKernelGGL(k_seg_moments, pg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, P.hypotheses);
-        hipLaunchKernelGGL(k_seg_refine, dim3(B), dim3(64), 0, s, h->seg_state, P.hypotheses, r);
-        hipLaunchKernelGGL(k_seg_label, pg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, P.thr, r);
+        const dim3 cg(pg.x, pg.y, (P.hypotheses + SEG_HGROUP - 1) / SEG_HGROUP);
+        if (B <= 2) {
+            // a frame alone is bound by launch latency: three launches per round -- bookkeeping + hypotheses + consensus | moments | refinement + labels
+            hipLaunchKernelGGL(k_seg_count<true>, cg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, P, r);
+            hipLaunchKernelGGL(k_seg_moments, pg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, P.hypotheses, r);
+            hipLaunchKernelGGL(k_seg_label<true>, pg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, P.hypotheses, P.thr, r);
+        } else {
+            // a batch is bound by throughput: the heads run once per frame (five launches per round)
+            hipLaunchKernelGGL(k_seg_hyp, dim3(B), dim3(64), 0, s, h->seg_ptrs, lab, h->seg_state, N, P, r);
+            hipLaunchKernelGGL(k_seg_count<false>, cg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, P, r);
+            hipLaunchKernelGGL(k_seg_moments, pg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, P.hypotheses, r);
+            hipLaunchKernelGGL(k_seg_refine, dim3(B), dim3(64), 0, s, h->seg_state, P.hypotheses, r);
+            hipLaunchKernelGGL(k_seg_label<false>, pg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, P.hypotheses, P.thr, r);
+        }
     }
-    hipLaunchKernelGGL(k_seg_final, dim3(B), dim3(1), 0, s, h->seg_state, P.max_planes);
+    hipLaunchKernelGGL(k_seg_final, dim3(B), dim3(1), 0, s, h->seg_state, P.max_planes, P.percent);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(h->pin_seg, h->seg_state, sizeof(SegState) * B, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));

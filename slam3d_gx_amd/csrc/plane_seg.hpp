@@ -30,11 +30,22 @@ struct SegHyp { float nx, ny, nz, dd, thr2nn; int ok; float p0x, p0y, p0z; };
 
 struct SegPlane { float a, b, c, d, cx, cy, cz; int count; };
 
+// Round 4: a frame ALONE takes THREE launches per round instead of five (k_seg_hyp goes into the head of k_seg_count,
+// k_seg_refine into the head of k_seg_label; 158 -> 142 us): every block redoes the few hundred scalar operations of the bookkeeping / hypotheses / eigen solve from
+// inputs that no block of the same launch writes, so all blocks agree and block 0 alone records the result.  What one
+// launch accumulates while another generation is still being read lives in two copies, indexed by the round's parity:
+//   rs[r & 1]          bookkeeping as round r finds it (remaining, nplanes, done); round r's count launch writes rs[(r+1) & 1]
+//   lab_count[r & 1]   points labelled in round r          (zeroed by round r's count launch, added by its label launch)
+//   mom[r & 1]         moments of round r                  (zeroed by round r's count launch, added by its moments launch)
+//   counts[r & 1]      consensus counts of round r         (zeroed by round r-1's moments launch; rounds 0 / 1: the initial memset)
+// Frames in batches keep the five launches (the redundant heads cost a batch of 64 frames 29 % of its rate), on the same state.
+struct SegRound { int remaining, nplanes, done, pad; };
 struct SegState {                  // one per frame, zeroed before k_seg_init
-    int n_valid, remaining, nplanes, done;
-    int best, lab_count, pad0, pad1;
-    int counts[SEG_CR][SEG_H];
-    long long mom[10];
+    int n_valid, best, nplanes, pad0;          // nplanes: the final count (k_seg_final)
+    SegRound rs[2];
+    int lab_count[2], pad1[2];
+    int counts[2][SEG_CR][SEG_H];
+    long long mom[2][10];
     SegHyp hyp[SEG_H];
     SegPlane planes[SEG_MAXP];
 };
@@ -84,41 +95,27 @@ __global__ __launch_bounds__(SEG_BLOCK) void k_seg_init(const float4 *const *__r
     if (threadIdx.x == 0 && nv) atomicAdd(&st[b].n_valid, nv);     // one same-address atomic per block, not per wave
 }
 
-// bookkeeping of the round that just ended (P4 tail): accept plane r-1 if it kept any point
-__device__ __forceinline__ void seg_close_round(SegState &s, int r)
+// bookkeeping of the round that just ended (P4 tail) + the loop condition of round r (P2 head): values only -- every
+// block of a launch evaluates this from the same inputs.  `got`: points the previous round labelled.
+__device__ __forceinline__ SegRound seg_open_round(const SegState &s, int r, float percent, int &plane_closed, int &plane_count)
 {
-    if (r == 0) { s.remaining = s.n_valid; return; }
-    if (s.done) return;
-    const int got = s.lab_count;
-    if (got == 0) { s.done = 1; return; }
-    s.planes[r - 1].count = got;
-    s.nplanes = r;
-    s.remaining -= got;
+    SegRound c = s.rs[r & 1];
+    plane_closed = -1; plane_count = 0;
+    if (r == 0) c.remaining = s.n_valid;
+    else if (!c.done) {
+        const int got = s.lab_count[(r - 1) & 1];
+        if (got == 0) c.done = 1;
+        else { plane_closed = r - 1; plane_count = got; c.nplanes = r; c.remaining -= got; }
+    }
+    return c;
 }
 
-// P2: loop condition + the H hypotheses of round r.  grid (B), block 64
-__global__ __launch_bounds__(64) void k_seg_hyp(const float4 *const *__restrict__ clouds, const int *__restrict__ labels,
-                                                SegState *__restrict__ st, int N, SegParams sp, int r)
+// hypothesis h of round r (P2): three distinct unassigned points drawn with a counter-based generator
+__device__ __forceinline__ SegHyp seg_make_hyp(const float4 *__restrict__ cloud, const int *__restrict__ lab, int N, const SegParams &sp, int r, int h)
 {
-    const int b = blockIdx.x, h = threadIdx.x;
-    SegState &s = st[b];
-    __shared__ int done;
-    if (h == 0) {
-        seg_close_round(s, r);
-        if (!s.done && (s.n_valid < 3 || !((double)s.remaining > (double)sp.percent * (double)s.n_valid))) s.done = 1;
-        done = s.done;
-        s.lab_count = 0;
-    }
-    __syncthreads();
-    if (done) return;
-    if (h < 10) s.mom[h] = 0;
-#pragma unroll
-    for (int c = 0; c < SEG_CR; ++c) s.counts[c][h] = 0;
     SegHyp hy;
     hy.nx = hy.ny = hy.nz = hy.dd = hy.thr2nn = 0.0f; hy.ok = 0; hy.p0x = hy.p0y = hy.p0z = 0.0f;
     if (h < sp.hypotheses) {
-        const float4 *__restrict__ cloud = clouds[b];
-        const int *__restrict__ lab = labels + (size_t)b * N;
         unsigned long long x = sp.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(1 + r * 4096 + h);
         int pick0 = -1, pick1 = -1, pick2 = -1, np = 0;
         for (int t = 0; t < SEG_DRAWS && np < 3; ++t) {
@@ -147,30 +144,80 @@ __global__ __launch_bounds__(64) void k_seg_hyp(const float4 *const *__restrict_
             }
         }
     }
-    s.hyp[h] = hy;
+    return hy;
 }
 
 // consensus count of hypothesis h: the replicas' sum
-__device__ __forceinline__ int seg_count_of(const SegState &s, int h)
+__device__ __forceinline__ int seg_count_of(const SegState &s, int r, int h)
 {
     int c = 0;
 #pragma unroll
-    for (int k = 0; k < SEG_CR; ++k) c += s.counts[k][h];
+    for (int k = 0; k < SEG_CR; ++k) c += s.counts[r & 1][k][h];
     return c;
 }
 
-// P2: consensus counts.  grid (ceil(N/1024), B), block 256.  Each thread keeps SEG_PTS points in registers;
-// lane h holds hypothesis h and the wave-uniform loop broadcasts it with v_readlane; a ballot + popcount gives
-// the wave's count for hypothesis h, which lane h keeps; the four waves meet in LDS and the block ends with
-// one 64-lane atomic (same-address global atomics serialise, so there is one per block, not per wave).
+// P2: bookkeeping + loop condition + the block's SEG_HGROUP hypotheses, then their consensus counts.
+// grid (ceil(N/1024), B, H / SEG_HGROUP), block 256.  Each thread keeps SEG_PTS points in registers; lane h of wave 0
+// builds hypothesis h0 + h and the block shares them through LDS; the wave-uniform loop broadcasts hypothesis h with
+// v_readlane; a ballot + popcount gives the wave's count, which lane h keeps; the four waves meet in LDS and the block ends
+// with one 64-lane atomic (same-address global atomics serialise, so there is one per block, not per wave).
+// Block (0, b, z) records: the bookkeeping (z = 0), its hypotheses, and the zeroes of the round's other accumulators.
+// the round's head on its own (frames in BATCHES: one block per frame does it once instead of every count block): grid (B), block 64
+__global__ __launch_bounds__(64) void k_seg_hyp(const float4 *const *__restrict__ clouds, const int *__restrict__ labels,
+                                                SegState *__restrict__ st, int N, SegParams sp, int r)
+{
+    const int b = blockIdx.x, h = threadIdx.x;
+    SegState &s = st[b];
+    int plane_closed, plane_count;
+    SegRound c = seg_open_round(s, r, sp.percent, plane_closed, plane_count);
+    if (!c.done && (s.n_valid < 3 || !((double)c.remaining > (double)sp.percent * (double)s.n_valid))) c.done = 1;
+    if (h == 0) {
+        s.rs[(r + 1) & 1] = c;
+        if (plane_closed >= 0) s.planes[plane_closed].count = plane_count;
+        s.lab_count[r & 1] = 0;
+#pragma unroll
+        for (int k = 0; k < 10; ++k) s.mom[r & 1][k] = 0;
+    }
+    if (c.done) return;
+    s.hyp[h] = seg_make_hyp(clouds[b], labels + (size_t)b * N, N, sp, r, h);
+}
+
+template <bool FUSED>
 __global__ __launch_bounds__(SEG_BLOCK) void k_seg_count(const float4 *const *__restrict__ clouds, const int *__restrict__ labels,
-                                                         SegState *__restrict__ st, int N, int H)
+                                                         SegState *__restrict__ st, int N, SegParams sp, int r)
 {
     const int b = blockIdx.y;
     SegState &s = st[b];
-    if (s.done) return;
     const float4 *__restrict__ cloud = clouds[b];
     const int *__restrict__ lab = labels + (size_t)b * N;
+    const int H = sp.hypotheses;
+    const int lane = threadIdx.x & 63;
+    const int h0 = blockIdx.z * SEG_HGROUP, h1 = min(H, h0 + SEG_HGROUP);
+    __shared__ SegHyp hy_sh[SEG_HGROUP];
+    __shared__ int bc[SEG_H];
+    if constexpr (FUSED) {
+        int plane_closed, plane_count;
+        SegRound c = seg_open_round(s, r, sp.percent, plane_closed, plane_count);
+        if (!c.done && (s.n_valid < 3 || !((double)c.remaining > (double)sp.percent * (double)s.n_valid))) c.done = 1;
+        const bool recorder = blockIdx.x == 0 && threadIdx.x == 0;
+        if (recorder && blockIdx.z == 0) {
+            s.rs[(r + 1) & 1] = c;
+            if (plane_closed >= 0) s.planes[plane_closed].count = plane_count;
+            s.lab_count[r & 1] = 0;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) s.mom[r & 1][k] = 0;
+        }
+        if (c.done) return;
+        if (threadIdx.x < SEG_HGROUP) {
+            const SegHyp hy = seg_make_hyp(cloud, lab, N, sp, r, h0 + (int)threadIdx.x);
+            hy_sh[threadIdx.x] = hy;
+            if (blockIdx.x == 0 && h0 + (int)threadIdx.x < SEG_H) s.hyp[h0 + threadIdx.x] = hy;
+        }
+    } else {
+        if (s.rs[(r + 1) & 1].done) return;                  // (k_seg_hyp ran before this launch)
+        if (threadIdx.x < SEG_HGROUP) hy_sh[threadIdx.x] = s.hyp[h0 + threadIdx.x];
+    }
+    if (threadIdx.x < SEG_H) bc[threadIdx.x] = 0;
     float4 q[SEG_PTS];
     bool live[SEG_PTS];
 #pragma unroll
@@ -179,44 +226,45 @@ __global__ __launch_bounds__(SEG_BLOCK) void k_seg_count(const float4 *const *__
         live[k] = i < N && lab[i] == -1;
         q[k] = live[k] ? cloud[i] : make_float4(0, 0, 0, 0);
     }
-    const int lane = threadIdx.x & 63;
-    __shared__ int bc[SEG_H];
-    if (threadIdx.x < SEG_H) bc[threadIdx.x] = 0;
     __syncthreads();
-    // lane h holds hypothesis h; the loop broadcasts it with v_readlane (no dependent scalar loads)
-    const SegHyp mh = s.hyp[lane];
+    // lane l < SEG_HGROUP holds hypothesis h0 + l; the loop broadcasts it with v_readlane (no dependent scalar loads)
+    SegHyp mh = hy_sh[lane < SEG_HGROUP ? lane : 0];
+    if (lane >= SEG_HGROUP) mh.ok = 0;
     const unsigned long long okm = __ballot(mh.ok != 0);
     int mine = 0;
-    // blockIdx.z picks a quarter of the hypotheses: four times the waves for the same number of atomics
-    const int h0 = blockIdx.z * SEG_HGROUP, h1 = min(H, h0 + SEG_HGROUP);
     for (int h = h0; h < h1; ++h) {
-        if (!((okm >> h) & 1ull)) continue;
-        const float nx = rdlane(mh.nx, h), ny = rdlane(mh.ny, h), nz = rdlane(mh.nz, h), dd = rdlane(mh.dd, h),
-                    t2 = rdlane(mh.thr2nn, h);
-        int c = 0;
+        const int l = h - h0;
+        if (!((okm >> l) & 1ull)) continue;
+        const float nx = rdlane(mh.nx, l), ny = rdlane(mh.ny, l), nz = rdlane(mh.nz, l), dd = rdlane(mh.dd, l),
+                    t2 = rdlane(mh.thr2nn, l);
+        int cc = 0;
 #pragma unroll
-        for (int k = 0; k < SEG_PTS; ++k) c += __popcll(__ballot(live[k] && seg_inlier(nx, ny, nz, dd, t2, q[k])));
-        if (lane == h) mine = c;
+        for (int k = 0; k < SEG_PTS; ++k) cc += __popcll(__ballot(live[k] && seg_inlier(nx, ny, nz, dd, t2, q[k])));
+        if (lane == l) mine = cc;
     }
-    if (mine) atomicAdd(&bc[lane], mine);
+    if (mine) atomicAdd(&bc[h0 + lane], mine);            // (mine != 0 only in lanes < SEG_HGROUP)
     __syncthreads();
-    if (threadIdx.x < SEG_H && bc[threadIdx.x]) atomicAdd(&s.counts[blockIdx.x % SEG_CR][threadIdx.x], bc[threadIdx.x]);
+    if (threadIdx.x < SEG_H && bc[threadIdx.x]) atomicAdd(&s.counts[r & 1][blockIdx.x % SEG_CR][threadIdx.x], bc[threadIdx.x]);
 }
 
 // P2 tail + P3: every block finds the best hypothesis (max count, smallest h on ties), block 0 records it, then
 // the block adds its points' fixed-point moments about the hypothesis' first sample.  grid (ceil(N/1024), B)
 __global__ __launch_bounds__(SEG_BLOCK) void k_seg_moments(const float4 *const *__restrict__ clouds, const int *__restrict__ labels,
-                                                           SegState *__restrict__ st, int N, int H)
+                                                           SegState *__restrict__ st, int N, int H, int r)
 {
     const int b = blockIdx.y;
     SegState &s = st[b];
-    if (s.done) return;
+    if (s.rs[(r + 1) & 1].done) return;
     const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x < SEG_H) {          // the counts of the NEXT round start from zero (nobody reads or adds to them now)
+#pragma unroll
+        for (int k = 0; k < SEG_CR; ++k) s.counts[(r + 1) & 1][k][threadIdx.x] = 0;
+    }
     // argmax over (count desc, h asc): key = count * 64 + (63 - h)
-    int key = lane < H ? seg_count_of(s, lane) * 64 + (63 - lane) : -1;
+    int key = lane < H ? seg_count_of(s, r, lane) * 64 + (63 - lane) : -1;
     for (int o = 32; o >= 1; o >>= 1) key = max(key, __shfl_xor(key, o));
     const int best = 63 - (key & 63), bc = key >> 6;
-    if (bc < 3) return;                       // k_seg_refine raises done
+    if (bc < 3) return;                       // the label launch raises done
     if (blockIdx.x == 0 && threadIdx.x == 0) s.best = best;
     const SegHyp &hy = s.hyp[best];
     const float nx = hy.nx, ny = hy.ny, nz = hy.nz, dd = hy.dd, t2 = hy.thr2nn;
@@ -255,45 +303,73 @@ __global__ __launch_bounds__(SEG_BLOCK) void k_seg_moments(const float4 *const *
         if (lane < 10) atomicAdd(&bm[lane], (unsigned long long)mine);
     }
     __syncthreads();
-    if (threadIdx.x < 10 && bm[threadIdx.x]) atomicAdd(reinterpret_cast<unsigned long long *>(&s.mom[threadIdx.x]), bm[threadIdx.x]);
+    if (threadIdx.x < 10 && bm[threadIdx.x]) atomicAdd(reinterpret_cast<unsigned long long *>(&s.mom[r & 1][threadIdx.x]), bm[threadIdx.x]);
 }
 
-// P3 tail: covariance -> eigenvector of the smallest eigenvalue -> (n, d), sign rule.  grid (B), block 64
-__global__ __launch_bounds__(64) void k_seg_refine(SegState *__restrict__ st, int H, int r)
+// P3 tail + P4: covariance -> eigenvector of the smallest eigenvalue -> (n, d), sign rule (thread 0 of every block: same
+// inputs, same bits; block 0 records the plane), then the plane's points = unassigned points within thr of it.
+// grid (ceil(N/1024), B)
+// the refined plane of round r from its moments (P3 tail): values only
+__device__ __forceinline__ SegPlane seg_refined_plane(const SegState &s, int r)
 {
-    SegState &s = st[blockIdx.x];
-    if (s.done) return;
-    const int lane = threadIdx.x;
-    int key = lane < H ? seg_count_of(s, lane) * 64 + (63 - lane) : -1;
-    for (int o = 32; o >= 1; o >>= 1) key = max(key, __shfl_xor(key, o));
-    if (lane != 0) return;
-    if ((key >> 6) < 3) { s.done = 1; return; }
     const SegHyp &hy = s.hyp[s.best];
+    const long long *__restrict__ mom = s.mom[r & 1];
     const double ox = hy.p0x, oy = hy.p0y, oz = hy.p0z;
-    const double inv = 1.0 / (double)s.mom[0];
-    const double mx = (double)s.mom[1] * inv, my = (double)s.mom[2] * inv, mz = (double)s.mom[3] * inv;
+    const double inv = 1.0 / (double)mom[0];
+    const double mx = (double)mom[1] * inv, my = (double)mom[2] * inv, mz = (double)mom[3] * inv;
     Sym3 C;
-    C.a00 = (double)s.mom[4] * inv - mx * mx; C.a01 = (double)s.mom[5] * inv - mx * my; C.a02 = (double)s.mom[6] * inv - mx * mz;
-    C.a11 = (double)s.mom[7] * inv - my * my; C.a12 = (double)s.mom[8] * inv - my * mz; C.a22 = (double)s.mom[9] * inv - mz * mz;
+    C.a00 = (double)mom[4] * inv - mx * mx; C.a01 = (double)mom[5] * inv - mx * my; C.a02 = (double)mom[6] * inv - mx * mz;
+    C.a11 = (double)mom[7] * inv - my * my; C.a12 = (double)mom[8] * inv - my * mz; C.a22 = (double)mom[9] * inv - mz * mz;
     double nx, ny, nz;
     eig3_smallest(C, nx, ny, nz);
     const double cx = ox + mx / 65536.0, cy = oy + my / 65536.0, cz = oz + mz / 65536.0;
     double d = -((nx * cx + ny * cy) + nz * cz);
     if (d < 0.0) { nx = -nx; ny = -ny; nz = -nz; d = -d; }      // src/GraphicEnd.cpp:383-387
-    SegPlane &P = s.planes[r];
+    SegPlane P;
     P.a = (float)nx; P.b = (float)ny; P.c = (float)nz; P.d = (float)d;
     P.cx = (float)cx; P.cy = (float)cy; P.cz = (float)cz; P.count = 0;
+    return P;
 }
 
-// P4: the plane's points = unassigned points within thr of the refined plane.  grid (ceil(N/1024), B)
+// the refinement on its own (frames in batches).  grid (B), block 64
+__global__ __launch_bounds__(64) void k_seg_refine(SegState *__restrict__ st, int H, int r)
+{
+    SegState &s = st[blockIdx.x];
+    if (s.rs[(r + 1) & 1].done) return;
+    const int lane = threadIdx.x;
+    int key = lane < H ? seg_count_of(s, r, lane) * 64 + (63 - lane) : -1;
+    for (int o = 32; o >= 1; o >>= 1) key = max(key, __shfl_xor(key, o));
+    if (lane != 0) return;
+    if ((key >> 6) < 3) { s.rs[(r + 1) & 1].done = 1; return; }
+    s.planes[r] = seg_refined_plane(s, r);
+}
+
+template <bool FUSED>
 __global__ __launch_bounds__(SEG_BLOCK) void k_seg_label(const float4 *const *__restrict__ clouds, int *__restrict__ labels,
-                                                         SegState *__restrict__ st, int N, float thr, int r)
+                                                         SegState *__restrict__ st, int N, int H, float thr, int r)
 {
     const int b = blockIdx.y;
     SegState &s = st[b];
-    if (s.done) return;
-    const SegPlane &P = s.planes[r];
-    const float a = P.a, bb = P.b, c = P.c, d = P.d;
+    if (s.rs[(r + 1) & 1].done) return;
+    __shared__ float pl[4];
+    if constexpr (FUSED) {
+        const int lane = threadIdx.x & 63;
+        int key = lane < H ? seg_count_of(s, r, lane) * 64 + (63 - lane) : -1;
+        for (int o = 32; o >= 1; o >>= 1) key = max(key, __shfl_xor(key, o));
+        if ((key >> 6) < 3) {                                    // no consensus: the loop ends (every block sees the same counts)
+            if (blockIdx.x == 0 && threadIdx.x == 0) s.rs[(r + 1) & 1].done = 1;
+            return;
+        }
+        if (threadIdx.x == 0) {
+            const SegPlane P = seg_refined_plane(s, r);
+            pl[0] = P.a; pl[1] = P.b; pl[2] = P.c; pl[3] = P.d;
+            if (blockIdx.x == 0) s.planes[r] = P;
+        }
+    } else {
+        if (threadIdx.x == 0) { const SegPlane &P = s.planes[r]; pl[0] = P.a; pl[1] = P.b; pl[2] = P.c; pl[3] = P.d; }     // (k_seg_refine ran before this launch)
+    }
+    __syncthreads();
+    const float a = pl[0], bb = pl[1], c = pl[2], d = pl[3];
     const float4 *__restrict__ cloud = clouds[b];
     int *__restrict__ lab = labels + (size_t)b * N;
     int got = 0;
@@ -307,13 +383,17 @@ __global__ __launch_bounds__(SEG_BLOCK) void k_seg_label(const float4 *const *__
         }
     }
     got = block_sum_int(got);
-    if (threadIdx.x == 0 && got) atomicAdd(&s.lab_count, got);
+    if (threadIdx.x == 0 && got) atomicAdd(&s.lab_count[r & 1], got);
 }
 
 // bookkeeping of the last round.  grid (B), block 1
-__global__ void k_seg_final(SegState *__restrict__ st, int rounds)
+__global__ void k_seg_final(SegState *__restrict__ st, int rounds, float percent)
 {
-    seg_close_round(st[blockIdx.x], rounds);
+    SegState &s = st[blockIdx.x];
+    int plane_closed, plane_count;
+    const SegRound c = seg_open_round(s, rounds, percent, plane_closed, plane_count);
+    if (plane_closed >= 0) s.planes[plane_closed].count = plane_count;
+    s.nplanes = c.nplanes;
 }
 
 // ------------------------------------------------------------------------------------ a6: planes from labels
