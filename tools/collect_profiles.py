@@ -36,7 +36,7 @@ def db_of(sub):
 
 bench = last_json(os.path.join(src, "bench.json"))
 json.dump(bench, open(os.path.join(dst, f"{tag}_bench.json"), "w"), indent=1)
-for name in ("voxel_bench", "seg64_bench"):
+for name in ("voxel_bench", "seg64_bench", "seg1_bench"):
     p = os.path.join(src, name + ".json")
     if os.path.exists(p):
         try:

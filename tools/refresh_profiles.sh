@@ -22,6 +22,7 @@ done
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/vox -o vox -- python $R/bench.py --mode voxel --steps 50 --warmup 5 --no-cpu-baseline > $OUT/voxel_bench.json 2> /dev/null
 timeout 300 python $R/bench.py --mode voxel --steps 200 --warmup 20 > $OUT/voxel_bench.json 2> /dev/null
 timeout 300 python $R/bench.py --mode seg --pairs 64 --steps 20 --warmup 3 > $OUT/seg64_bench.json 2> /dev/null
+timeout 300 python $R/bench.py --mode seg --pairs 1 --steps 100 --warmup 10 --no-cpu-baseline > $OUT/seg1_bench.json 2> /dev/null
 # summarise on the box (the databases exceed what gpurun copies back), keep only the small files
 python $R/tools/collect_profiles.py $TAG $R/gpurun_out/profiles_$TAG
 cp $OUT/*.json $OUT/bench.err $R/gpurun_out/profiles_$TAG/ 2>/dev/null
