@@ -209,6 +209,27 @@ def test_matrix_core_scans_bf16_split_and_f32(gpu_lib, bf16, monkeypatch):
         assert np.array_equal(St, ro["sums_trace"]) and np.array_equal(Tt, ro["T_trace"])
 
 
+@pytest.mark.parametrize("variant", ["mfma_bf16", "mfma_f32", "valu", "valu_filter"])
+def test_full_scan_kernels_on_a_batch_of_pairs(gpu_lib, variant, monkeypatch):
+    """The full-scan kernels index their fragment arrays, bounds and thresholds by pair: a batch of three different pairs in one
+    launch sequence must give every pair the result it gets alone in the default (tile-pruned) mode -- indices, d2 and pose bits."""
+    env = {"mfma_f32": ("SLAM3D_MFMA_BF16", "0"), "valu_filter": ("SLAM3D_VALU_FILTER", "1")}.get(variant)
+    if env:
+        monkeypatch.setenv(*env)
+    mode = capi.NN_BRUTE_MFMA if variant.startswith("mfma") else capi.NN_BRUTE_VALU
+    prs = [_pair(s, 256, 192) for s in (1100, 1101, 1102)]
+    intr = prs[0][0].intr
+    with capi.IcpHandle(capi.default_params(intr, iterations=4, max_batch=3, nn_mode=mode)) as h:
+        rb = h.align_batch([p[1] for p in prs], [p[2] for p in prs])
+        got = [h.get_correspondences(b) for b in range(3)]
+    for b, (pr, s4, t4) in enumerate(prs):
+        with capi.IcpHandle(capi.default_params(intr, iterations=4)) as h1:
+            r1 = h1.align(s4, t4)
+            idx1, d21 = h1.get_correspondences(0)
+        assert np.array_equal(got[b][0], idx1) and np.array_equal(got[b][1], d21), (variant, b)
+        assert np.array_equal(rb[b]["T_raw"], r1["T_raw"]) and rb[b]["inliers"] == r1["inliers"]
+
+
 def test_valu_scan_with_the_expanded_form_filter(gpu_lib, monkeypatch):
     """SLAM3D_VALU_FILTER=1: k_nn_valu takes its chunk minima over the expanded form |q|^2 - 2 p.q (the matrix-core kernels'
     contraction and eps, on the VALU) instead of the canonical distances; flagged chunks are rescanned canonically, so the
