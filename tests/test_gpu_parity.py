@@ -230,6 +230,20 @@ def test_full_scan_kernels_on_a_batch_of_pairs(gpu_lib, variant, monkeypatch):
         assert np.array_equal(rb[b]["T_raw"], r1["T_raw"]) and rb[b]["inliers"] == r1["inliers"]
 
 
+def test_bf16_scan_at_1280x960_equals_the_tile_search(gpu_lib):
+    """BASELINE config 5's size through the bf16 matrix-core scan (1.2 M points: the fragment arrays, the slice count and the
+    padding behind the last group at their largest): same correspondences, d2 and pose bits as the tile-pruned search."""
+    pr, s4, t4 = _pair(1200, 1280, 960)
+    out = []
+    for mode in (capi.NN_BRUTE_MFMA, capi.NN_TILES):
+        with capi.IcpHandle(capi.default_params(pr.intr, iterations=2, nn_mode=mode)) as h:
+            r = h.align(s4, t4)
+            idx, d2 = h.get_correspondences(0)
+        out.append((idx, d2, r["T_raw"], r["inliers"]))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2]) and out[0][3] == out[1][3]
+
+
 def test_valu_scan_with_the_expanded_form_filter(gpu_lib, monkeypatch):
     """SLAM3D_VALU_FILTER=1: k_nn_valu takes its chunk minima over the expanded form |q|^2 - 2 p.q (the matrix-core kernels'
     contraction and eps, on the VALU) instead of the canonical distances; flagged chunks are rescanned canonically, so the
