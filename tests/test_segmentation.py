@@ -126,3 +126,33 @@ def test_hip_segmentation_reproduces_golden(gpu_lib, c):
     with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1)) as h:
         planes, labels = h.segment_planes(s4, h.seg_params(seed=c["seed"]))
     _check(c, planes, labels)
+
+
+@pytest.mark.gpu
+def test_hip_segmentation_batched_path_equals_the_single_frame_path(gpu_lib):
+    """A frame alone takes the fused three-launch rounds, a batch the five-launch ones (csrc/plane_seg.hpp, round 4): both run on
+    the same double-buffered round state and must give every frame the same planes and labels -- five different frames in one
+    call against each of them alone (which the golden tests pin to the oracle)."""
+    import torch
+    from slam3d_gx_amd import capi, synth
+    frames = []
+    for seed in (3001, 3002, 3003, 3004, 3005):
+        pr = synth.make_pair(seed, 320, 240)
+        frames.append(synth.backproject_numpy(pr.depth_src, pr.intr))
+    intr = synth.make_pair(3001, 320, 240).intr
+    N = 320 * 240
+    with capi.IcpHandle(capi.default_params(intr, max_batch=8)) as h:
+        sp = h.seg_params(seed=11)
+        alone = [h.segment_planes(f, sp) for f in frames]
+        d = torch.from_numpy(np.stack([f.reshape(N, 4) for f in frames])).to("cuda:0")
+        d_lab = torch.zeros((len(frames), N), dtype=torch.int32, device="cuda:0")
+        ptrs = [d[i].data_ptr() for i in range(len(frames))]
+        batch = h.segment_planes_device(ptrs, sp, d_lab.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        lab = d_lab.cpu().numpy()
+    assert len(batch) == len(frames)
+    for i, (planes1, labels1) in enumerate(alone):
+        assert len(batch[i]) == len(planes1) and len(planes1) >= 1
+        for a, b in zip(batch[i], planes1):
+            assert np.array_equal(a["coeff"], b["coeff"]) and a["count"] == b["count"] and np.array_equal(a["centroid"], b["centroid"])
+        assert np.array_equal(lab[i], np.asarray(labels1).reshape(-1))
