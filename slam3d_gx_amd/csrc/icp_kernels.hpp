@@ -752,7 +752,7 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_valu(const PairPtrs *__restrict
         for (int k = 0; k < QPT; ++k) {
             const float rx = px[k], ry = py[k], rz = pz[k] - cz;
             n2p[k] = __fmaf_rn(rz, rz, __fmaf_rn(ry, ry, rx * rx));
-            epsb[k] = 1.0e-6f * (n2p[k] + qmax2) + 1.0e-6f;
+            epsb[k] = 2.0e-6f * (n2p[k] + qmax2) + 1.0e-6f;          // (twice k_nn_mfma's factor: here the threshold is not part of the fma chain)
             ax[k] = -2.0f * rx; ay[k] = -2.0f * ry; az[k] = -2.0f * rz;
             set_thr(k);
         }
@@ -841,9 +841,9 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_valu(const PairPtrs *__restrict
 // re-evaluated with the canonical fp32 distance and merged with ds_min_u64 on (d2 bits << 32 | pixel),
 // so the output is bit-identical to the VALU scan.  eps_i bounds every rounding in the chain
 // (DESIGN.md section 5): the k-ordered fma chain of the MFMA, |q|^2, |p|^2, the centring.
-// 64 queries per wave (4 row blocks) share each B fragment: 4 MFMAs per ds_read_b32; the VALU only
-// folds the 16 results with v_min3 and tests the sign.  Targets stream through LDS in chunks of 256,
-// global loads of chunk n+1 are issued before chunk n is computed.
+// 128 queries per wave (8 row blocks) share each B fragment (4 bytes per lane and group of 16 targets, streamed
+// straight from L2 eight groups ahead); the VALU only folds the 32 results per lane with v_min3 and tests the sign.
+// This is the f32 form (SLAM3D_MFMA_BF16=0); the default is k_nn_mfma16 further down.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int MF_TCH = 256;
 
