@@ -706,7 +706,7 @@ def test_bench_single_gpu_line_has_the_contract_fields(gpu_lib):
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--width", "320", "--height", "240",
-           "--iterations", "6", "--pairs-per-step", "6", "--pool", "4", "--profile-aligns", "4", "--force-collective"]
+           "--iterations", "6", "--pairs-per-step", "6", "--pool", "4", "--profile-aligns", "4", "--force-collective", "--in-flight", "4"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
