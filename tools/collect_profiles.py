@@ -160,10 +160,10 @@ def trace_summary(db, title, bench_json, note):
 
 text = ""
 if db_of("pipe"):
-    text += trace_summary(db_of("pipe"), f"{tag}: kernel trace of the pipelined regime (bench.py's default: 4 alignments in flight)",
+    text += trace_summary(db_of("pipe"), f"{tag}: kernel trace of the pipelined regime (bench.py's default: 8 alignments in flight)",
                           os.path.join(src, "pipe_bench.json"),
                           "`rocprofv3 --kernel-trace -- python bench.py --steps 3 --warmup 1 --no-extra-configs --no-cpu-baseline --no-bruteforce --timed-only`: "
-                          "four handles, one HIP stream each, every alignment uploads both depth images and rebuilds normals + tiles.")
+                          "eight handles, one HIP stream each, every alignment uploads both depth images and rebuilds normals + tiles.")
 if db_of("solo"):
     text += "\n\n" + trace_summary(db_of("solo"), f"{tag}: the same stream, one alignment at a time (--no-pipeline)",
                                    os.path.join(src, "solo_bench.json"),
