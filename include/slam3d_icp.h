@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SLAM3D_ICP_ABI_VERSION 5
+#define SLAM3D_ICP_ABI_VERSION 6
 #define SLAM3D_ICP_NSUMS 29   /* the sums of the trace: 21 upper-tri AtA + 6 Atb + count + sum r^2, derived from the Gram totals */
 #define SLAM3D_ICP_NRAW  36   /* what the dense mode exchanges: the upper triangle of the 8x8 integer Gram matrix of the quantised row vectors (DESIGN.md spec S4) */
 
@@ -46,7 +46,24 @@ enum {
     SLAM3D_E_COMM = -6              /* RCCL error / librccl not loadable (see slam3d_comm_last_error) */
 };
 
-enum { SLAM3D_EST_POINT2PLANE = 0, SLAM3D_EST_SVD = 1 };
+/* Estimators.  POINT2PLANE: target normals from the 7x7 organized window (src/planarFeatures.cpp:88-136); SVD: point-to-point
+ * (Kabsch).  PLANE (ABI 6, DESIGN.md spec S2p / S4p): plane-ICP proper -- the target frame's PLANES give the normals.  The frame is
+ * segmented on the device exactly as slam3d_segment_planes does (the pcl::SACSegmentation loop of src/GraphicEnd.cpp:353-430, with
+ * the parameters of slam3d_icp_set_seg_params), every pixel labelled with plane r takes the plane's least-squares normal
+ * (a, b, c) (the fit of src/GraphicEnd.cpp:360-375, d >= 0 :383-387: toward the camera) -- SURVEY.md App. C2 "points take their
+ * plane's normal" --, a pixel on no plane keeps its 7x7-window normal (or is no target at all with SLAM3D_PLANE_ONLY); rows,
+ * search, solve and result are those of POINT2PLANE.  Role in the reference: planes are extracted per frame and the pose is
+ * derived from plane-wise correspondences, src/GraphicEnd.cpp:158,168,557-659. */
+enum { SLAM3D_EST_POINT2PLANE = 0, SLAM3D_EST_SVD = 1, SLAM3D_EST_PLANE = 2 };
+/* slam3d_icp_params.plane_flags (SLAM3D_EST_PLANE only):
+ *   PAIR_GATE   SURVEY.md 8(a) row a9, src/GraphicEnd.cpp:459-484,:572 (PnP only inside matched plane pairs): the source frame is
+ *               segmented too, its planes are carried into the target frame by the run's initial pose (Identity without T_init)
+ *               and associated with the target's planes as GraphicEnd::match does (nearest (a, b, c, d), exact); a correspondence
+ *               is kept iff the target pixel's plane is the one associated with the source pixel's plane (pixels on no plane:
+ *               clutter only matches clutter).  A rejected source has no correspondence in that iteration.
+ *   ONLY        pixels on no plane are not targets (the literal per-plane variant of App. C2).  Off by default: two or three planes
+ *               rarely constrain all six degrees of freedom (two of them are often parallel), the clutter between them does. */
+enum { SLAM3D_PLANE_PAIR_GATE = 1, SLAM3D_PLANE_ONLY = 2 };
 /* NN search variants: all return bit-identical correspondences.
  *   BRUTE_VALU  every source x every target, LDS-tiled, fp32 VALU
  *   BRUTE_MFMA  same scan, the distance step as a dense contraction on the matrix cores used as a conservative
@@ -85,7 +102,7 @@ typedef struct slam3d_icp_params {
      * multiPnP no initial guess (src/GraphicEnd.cpp:168): the first iterations run on a pose that is centimetres off, where a
      * quarter of the rows yields the same update and the searches are at their widest.  0 = every iteration uses every source. */
     int32_t coarse_iterations;
-    int32_t _pad0;
+    int32_t plane_flags;            /* SLAM3D_PLANE_* (ABI 6; the padding word of ABI 5: 0 = neither)                    */
 } slam3d_icp_params;
 
 /* a borrowed view of an organized cloud: `data` points at width*height records of
@@ -295,6 +312,18 @@ int slam3d_segment_planes(slam3d_icp_handle *h, const slam3d_cloud_view *cloud, 
 int slam3d_segment_planes_device(slam3d_icp_handle *h, int32_t B, const void *const *d_clouds,
                                  const slam3d_seg_params *sp, slam3d_plane *planes, int32_t *nplanes,
                                  int32_t *d_labels, void *stream);
+
+/* ---- SLAM3D_EST_PLANE: the segmentation behind the normals ------------------------------------------------
+ * Parameters of the per-frame segmentation (defaults = slam3d_seg_default_params: parameters.yaml distance_threshold 0.08,
+ * plane_percent 0.2, max_planes 3; 64 hypotheses, seed 1).  Frames already built are rebuilt at the next run.
+ * SLAM3D_E_STATE unless the handle's estimator is SLAM3D_EST_PLANE. */
+int slam3d_icp_set_seg_params(slam3d_icp_handle *h, const slam3d_seg_params *sp);
+/* the planes the library extracted for a resident frame at its last build (extraction order; planes[8]); *nplanes = 0 when the
+ * frame was never built under SLAM3D_EST_PLANE.  Waits for the handle's streams.  GraphicEnd keeps them as _currKF.planes /
+ * _present.planes (src/GraphicEnd.cpp:158,168): the front end reads them here instead of segmenting the frame a second time. */
+int slam3d_icp_get_frame_planes(slam3d_icp_handle *h, int32_t frame, slam3d_plane *planes /* 8 */, int32_t *nplanes);
+/* the association the pair gate of the LAST run used for pair `slot`: assoc[i] = target plane of source plane i, or -1; 8 entries */
+int slam3d_icp_get_plane_assoc(slam3d_icp_handle *h, int32_t slot, int32_t *assoc /* 8 */);
 
 /* ---- dense (single pair sharded over ranks) building blocks, one exchange per iteration -- */
 /* restrict the source rows this handle works on to [row_begin,row_end) of slot 0 */

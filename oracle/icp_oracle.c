@@ -40,7 +40,17 @@ void orc_default_params(orc_params *p)
     p->nn_method = ORC_NN_KDTREE;
     p->threads = 0;
     p->coarse_iterations = 3;
+    p->seg_distance_threshold = 0.08f;   /* parameters.yaml distance_threshold */
+    p->seg_plane_percent = 0.2f;         /* parameters.yaml plane_percent */
+    p->seg_max_planes = 3;               /* parameters.yaml max_planes */
+    p->seg_hypotheses = 64;
+    p->seg_seed = 1;
+    p->plane_pair_gate = 0;
+    p->plane_only = 0;
 }
+
+/* rows / solve of the estimator: ORC_EST_PLANE differs from ORC_EST_POINT2PLANE only in where the target normals come from */
+static inline int row_form(int estimator) { return estimator == ORC_EST_SVD ? ORC_EST_SVD : ORC_EST_POINT2PLANE; }
 
 static int n_threads(const orc_params *p)
 {
@@ -392,17 +402,19 @@ typedef struct {
     float *x, *y, *z;      /* SoA coordinates of the compacted list */
     float *nx, *ny, *nz;   /* normals (targets only)                */
     int32_t *orig;         /* original linear index                 */
+    int32_t *lab;          /* plane label of the point (normal.w - 1; -1 none): the plane-pair gate */
 } clist;
 
 static void clist_free(clist *c)
 {
-    free(c->x); free(c->y); free(c->z); free(c->nx); free(c->ny); free(c->nz); free(c->orig);
+    free(c->x); free(c->y); free(c->z); free(c->nx); free(c->ny); free(c->nz); free(c->orig); free(c->lab);
     memset(c, 0, sizeof(*c));
 }
 
-static void clist_build(clist *c, const float *xyz4, const float *nrm4, int N, float zmax)
+static void clist_build_ex(clist *c, const float *xyz4, const float *nrm4, const float *lab4, int N, float zmax)
 {
     memset(c, 0, sizeof(*c));
+    if (lab4) c->lab = malloc(sizeof(int32_t) * (size_t)(N + 8));
     c->x = malloc(sizeof(float) * (size_t)(N + 8)); c->y = malloc(sizeof(float) * (size_t)(N + 8));
     c->z = malloc(sizeof(float) * (size_t)(N + 8)); c->orig = malloc(sizeof(int32_t) * (size_t)(N + 8));
     if (nrm4) {
@@ -416,9 +428,15 @@ static void clist_build(clist *c, const float *xyz4, const float *nrm4, int N, f
         if (nrm4 && !(nrm4[4 * (size_t)i + 3] > 0.5f)) continue;
         c->x[n] = q[0]; c->y[n] = q[1]; c->z[n] = q[2]; c->orig[n] = i;
         if (nrm4) { c->nx[n] = nrm4[4 * (size_t)i]; c->ny[n] = nrm4[4 * (size_t)i + 1]; c->nz[n] = nrm4[4 * (size_t)i + 2]; }
+        if (lab4) c->lab[n] = (int32_t)lab4[4 * (size_t)i + 3] - 1;      /* normal.w = 1 + plane (0: no plane) */
         ++n;
     }
     c->n = n;
+}
+
+static void clist_build(clist *c, const float *xyz4, const float *nrm4, int N, float zmax)
+{
+    clist_build_ex(c, xyz4, nrm4, NULL, N, zmax);
 }
 
 /* ------------------------------------------------------------- kd-tree NN
@@ -616,10 +634,11 @@ static void nn_pass(const clist *src, const clist *tgt, const kdtree *kd, const 
  * float rotation of xform_pt with the same fma chain, c = fma(rz,tz, fma(ry,ty, rx*tx)) in float, kept iff the source
  * normal is valid and c >= (float)min_normal_cos (stands in for src/GraphicEnd.cpp:542's RANSAC inlier subset). */
 static void apply_gates(const clist *src, const clist *tgt, const double *T, const orc_params *p,
-                        const float *snrm4, int nt, int *corr, float *d2c)
+                        const float *snrm4, const int32_t *assoc /* plane-pair gate: target plane of every source plane, or NULL */,
+                        int nt, int *corr, float *d2c)
 {
     const float r2f = (float)p->max_plane_residual2, cminf = (float)p->min_normal_cos;
-    if (p->estimator != ORC_EST_POINT2PLANE || (!(r2f > 0.0f) && !(cminf > 0.0f))) return;
+    if (p->estimator == ORC_EST_SVD || (!(r2f > 0.0f) && !(cminf > 0.0f) && !assoc)) return;
     float Rf[9], tf[3];
     transform_f(T, Rf, tf);
     (void)nt;
@@ -644,6 +663,10 @@ static void apply_gates(const clist *src, const clist *tgt, const double *T, con
             const float rz = fmaf(Rf[8], ns[2], fmaf(Rf[7], ns[1], Rf[6] * ns[0]));
             const float c = fmaf(rz, tgt->nz[j], fmaf(ry, tgt->ny[j], rx * tgt->nx[j]));
             keep = ns[3] > 0.5f && c >= cminf;
+        }
+        if (keep && assoc) {     /* spec S4p: plane to its associated plane, clutter (label -1) to clutter */
+            const int ls = src->lab[i];
+            keep = (ls >= 0 ? assoc[ls] : -1) == tgt->lab[j];
         }
         if (!keep) { corr[i] = -1; d2c[i] = INFINITY; }
     }
@@ -683,7 +706,7 @@ static int row_vector(const clist *src, const clist *tgt, const float Rf[9], con
     xform_pt(Rf, tf, src->x[i], src->y[i], src->z[i], pf);
     const double px = pf[0], py = pf[1], pz = pf[2];
     const double qx = tgt->x[j], qy = tgt->y[j], qz = tgt->z[j];
-    if (estimator == ORC_EST_POINT2PLANE) {
+    if (estimator != ORC_EST_SVD) {
         const double dx = qx - px, dy = qy - py, dz = qz - pz;
         const double nx = tgt->nx[j], ny = tgt->ny[j], nz = tgt->nz[j];
         const double a0 = py * nz - pz * ny, a1 = pz * nx - px * nz, a2 = px * ny - py * nx;
@@ -703,7 +726,7 @@ static int row_vector(const clist *src, const clist *tgt, const float Rf[9], con
 void orc_derive_sums(const int64_t G[ORC_NRAW], int estimator, int eb, double s[ORC_NSUMS])
 {
     for (int k = 0; k < ORC_NSUMS; ++k) s[k] = 0.0;
-    if (estimator == ORC_EST_POINT2PLANE) {
+    if (estimator != ORC_EST_SVD) {
         int k = 0;
         for (int r = 0; r < 6; ++r)
             for (int c = r; c < 6; ++c) s[k++] = ldexp((double)G[tri36(r, c)], -((r < 3 ? 16 : 20) + (c < 3 ? 16 : 20)));
@@ -770,7 +793,7 @@ static void compose(const double dR[9], const double dt[3], double *T)
 static int solve_update(const double *sums, int estimator, double *T)
 {
     double dR[9], dt[3];
-    if (estimator == ORC_EST_POINT2PLANE) {
+    if (estimator != ORC_EST_SVD) {
         if (sums[27] < 6.0) return 0;
         double x[6];
         const int rc = orc_solve6(sums, sums + 21, x);
@@ -835,6 +858,7 @@ int orc_icp(const float *src4, const float *tgt4, const orc_params *p, const dou
     double tp = omp_get_wtime();
 #define ORC_PHASE(k) do { if (timing) { const double now__ = omp_get_wtime(); tph[k] += now__ - tp; tp = now__; } } while (0)
     float *nrm4 = NULL, *snrm4 = NULL;
+    int32_t assoc_buf[16], *assoc = NULL;
     if (p->estimator == ORC_EST_POINT2PLANE) {
         nrm4 = malloc(sizeof(float) * 4 * (size_t)N);
         orc_normals(tgt4, p, nrm4);
@@ -842,11 +866,21 @@ int orc_icp(const float *src4, const float *tgt4, const orc_params *p, const dou
             snrm4 = malloc(sizeof(float) * 4 * (size_t)N);
             orc_normals(src4, p, snrm4);
         }
+    } else if (p->estimator == ORC_EST_PLANE) {         /* spec S2p: the target's planes give the normals */
+        float tpl[16 * 8], spl[16 * 8];
+        if (p->seg_max_planes < 1 || p->seg_max_planes > 16) return -1;
+        nrm4 = malloc(sizeof(float) * 4 * (size_t)N);
+        const int nt_pl = orc_plane_normals(tgt4, p, nrm4, tpl, NULL);
+        if ((float)p->min_normal_cos > 0.0f || p->plane_pair_gate) {
+            snrm4 = malloc(sizeof(float) * 4 * (size_t)N);
+            const int ns_pl = orc_plane_normals(src4, p, snrm4, spl, NULL);
+            if (p->plane_pair_gate) { orc_plane_assoc(spl, ns_pl, tpl, nt_pl, T_init, assoc_buf); assoc = assoc_buf; }
+        }
     }
     ORC_PHASE(0);
     clist src, tgt;
-    clist_build(&src, src4, NULL, N, zmax);
-    clist_build(&tgt, tgt4, nrm4, N, zmax);
+    clist_build_ex(&src, src4, NULL, assoc ? snrm4 : NULL, N, zmax);
+    clist_build_ex(&tgt, tgt4, nrm4, assoc ? nrm4 : NULL, N, zmax);
     ORC_PHASE(1);
     kdtree kd; memset(&kd, 0, sizeof(kd));
     if (p->nn_method == ORC_NN_KDTREE) kd_build(&kd, &tgt, n_threads(p));
@@ -865,12 +899,12 @@ int orc_icp(const float *src4, const float *tgt4, const orc_params *p, const dou
         const int coarse = it < p->coarse_iterations && it < p->iterations - 1;     /* spec S4c: never the last iteration */
         nn_pass(&src, &tgt, &kd, T, g2, p->nn_method, nt, corr, d2c, coarse ? p->width : 0);
         ORC_PHASE(3);
-        apply_gates(&src, &tgt, T, p, snrm4, nt, corr, d2c);
-        accumulate(&src, &tgt, T, p->estimator, orc_b_exponent(p->max_corr_dist), corr, p->width, p->height, nt, sums, NULL);
+        apply_gates(&src, &tgt, T, p, snrm4, assoc, nt, corr, d2c);
+        accumulate(&src, &tgt, T, row_form(p->estimator), orc_b_exponent(p->max_corr_dist), corr, p->width, p->height, nt, sums, NULL);
         ORC_PHASE(4);
         have_sums = 1;
         if (sums_trace) memcpy(sums_trace + (size_t)it * ORC_NSUMS, sums, sizeof(sums));
-        const int rc = solve_update(sums, p->estimator, T);
+        const int rc = solve_update(sums, row_form(p->estimator), T);
         if (rc == 2 || rc == 0) degenerate = 1;   /* damped, or no update at all in this iteration: never a silent OK */
         if (T_trace) memcpy(T_trace + (size_t)(it + 1) * 16, T, sizeof(T));
     }
@@ -911,7 +945,11 @@ int orc_nn_once_ex(const float *src4, const float *tgt4, const orc_params *p, co
     const int N = p->width * p->height;
     const float zmax = (float)p->z_filter;
     float *nrm4 = NULL;
-    if (use_normals) { nrm4 = malloc(sizeof(float) * 4 * (size_t)N); orc_normals(tgt4, p, nrm4); }
+    if (use_normals) {      /* 1: the 7x7-window normals (S2); 2: the per-plane normals (S2p) */
+        nrm4 = malloc(sizeof(float) * 4 * (size_t)N);
+        if (use_normals == 2) orc_plane_normals(tgt4, p, nrm4, NULL, NULL);
+        else orc_normals(tgt4, p, nrm4);
+    }
     clist src, tgt;
     clist_build(&src, src4, NULL, N, zmax);
     clist_build(&tgt, tgt4, nrm4, N, zmax);
@@ -972,6 +1010,65 @@ void orc_fit_planes(const float *xyz4, const int32_t *labels, int n, int nplanes
         double d = -((nx * cx + ny * cy) + nz * cz);
         if (d < 0.0) { nx = -nx; ny = -ny; nz = -nz; d = -d; }            /* src/GraphicEnd.cpp:383-387 */
         planes[4 * pl] = (float)nx; planes[4 * pl + 1] = (float)ny; planes[4 * pl + 2] = (float)nz; planes[4 * pl + 3] = (float)d;
+    }
+}
+
+/* --------------------------------------------------- S2p: per-plane normals (ORC_EST_PLANE)
+ * SURVEY.md App. C2, per-plane variant: "labels -> per-plane {sum p, sum pp^T, n} -> eigensolve -> (n, d), sign so d >= 0
+ * (src/GraphicEnd.cpp:383-387); points take their plane's normal".  The labels and the fits are the segmentation's (P1-P5,
+ * seg_oracle.c: the planes the reference extracts per frame, src/GraphicEnd.cpp:353-430).  d >= 0 means n . x = -d <= 0 for the
+ * plane's points: the normal looks toward the camera, the orientation S2 gives its window normals.  w carries 1 + plane. */
+int orc_plane_normals(const float *xyz4, const orc_params *p, float *nrm4, float *planes8, int32_t *labels)
+{
+    const int N = p->width * p->height;
+    orc_seg_params sp;
+    sp.distance_threshold = p->seg_distance_threshold; sp.plane_percent = p->seg_plane_percent;
+    sp.max_planes = p->seg_max_planes; sp.hypotheses = p->seg_hypotheses; sp.seed = p->seg_seed;
+    float *pl = planes8 ? planes8 : malloc(sizeof(float) * 8 * (size_t)sp.max_planes);
+    int32_t *lab = labels ? labels : malloc(sizeof(int32_t) * (size_t)N);
+    const int np = orc_segment_planes(xyz4, N, (float)p->z_filter, &sp, pl, lab);
+    /* a pixel on no plane keeps its 7x7-window normal (S2) with w = 0.75 -- "a normal, no plane" -- unless plane_only is set:
+     * three planes rarely constrain all six degrees of freedom (two of them are often parallel; measured: the synthetic room's
+     * target frame yields three z-facing planes and the pose runs away), the clutter between them does */
+    float *win = NULL;
+    if (!p->plane_only) { win = malloc(sizeof(float) * 4 * (size_t)N); orc_normals(xyz4, p, win); }
+    for (int i = 0; i < N; ++i) {
+        float *o = nrm4 + 4 * (size_t)i;
+        const int r = lab[i];
+        if (r >= 0 && r < np) { o[0] = pl[8 * r]; o[1] = pl[8 * r + 1]; o[2] = pl[8 * r + 2]; o[3] = (float)(1 + r); }
+        else if (win && win[4 * (size_t)i + 3] > 0.5f) { o[0] = win[4 * (size_t)i]; o[1] = win[4 * (size_t)i + 1]; o[2] = win[4 * (size_t)i + 2]; o[3] = 0.75f; }
+        else { o[0] = o[1] = o[2] = o[3] = 0.0f; }
+    }
+    free(win);
+    if (!planes8) free(pl);
+    if (!labels) free(lab);
+    return np;
+}
+
+/* spec S4p, association: plane (n, d) of frame 1 carried by X_2 = R X_1 + t: n' = R n, d' = d - n'.t in double (operations in
+ * the order written), sign rule d' >= 0, rounded to float; nearest plane of frame 2 by the squared L2 distance on (a, b, c, d)
+ * accumulated as d2 = fmaf(e_k, e_k, d2), k = 0..3, in float; ties -> lowest index (what slam3d_plane_gate / slam3d_match_planes
+ * compute; FlannBasedMatcher::match of src/GraphicEnd.cpp:459-484 computed exactly). */
+void orc_plane_assoc(const float *planes1, int n1, const float *planes2, int n2, const double *T, int32_t *assoc)
+{
+    double Tid[16];
+    for (int k = 0; k < 16; ++k) Tid[k] = (k % 5 == 0) ? 1.0 : 0.0;
+    if (!T) T = Tid;
+    for (int i = 0; i < n1; ++i) {
+        const double a = planes1[8 * i], b = planes1[8 * i + 1], c = planes1[8 * i + 2], d = planes1[8 * i + 3];
+        double n[3];
+        for (int r = 0; r < 3; ++r) n[r] = (T[r * 4] * a + T[r * 4 + 1] * b) + T[r * 4 + 2] * c;
+        double dd = d - ((n[0] * T[3] + n[1] * T[7]) + n[2] * T[11]);
+        if (dd < 0.0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; dd = -dd; }
+        const float m[4] = { (float)n[0], (float)n[1], (float)n[2], (float)dd };
+        int best = -1;
+        float bd = INFINITY;
+        for (int j = 0; j < n2; ++j) {
+            float d2 = 0.0f;
+            for (int k = 0; k < 4; ++k) { const float e = m[k] - planes2[8 * j + k]; d2 = fmaf(e, e, d2); }
+            if (d2 < bd) { bd = d2; best = j; }
+        }
+        assoc[i] = best;
     }
 }
 

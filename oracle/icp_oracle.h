@@ -41,7 +41,11 @@ extern "C" {
 #define ORC_NRAW  36          /* upper triangle of the 8x8 integer Gram matrix of the quantised row vectors */
 #define ORC_CHUNK 256         /* (historic) launch block of four tiles            */
 
-enum { ORC_EST_POINT2PLANE = 0, ORC_EST_SVD = 1 };
+/* ORC_EST_PLANE (round 5, spec S2p): the point-to-plane rows of ORC_EST_POINT2PLANE with the target normals taken from the
+ * frame's PLANES instead of its 7x7 windows: the target frame is segmented (seg_oracle.c, P1-P5), every labelled pixel takes
+ * its plane's (a, b, c), unlabelled pixels are no targets (SURVEY.md App. C2 "points take their plane's normal";
+ * src/GraphicEnd.cpp:353-430 extracts the planes per frame, :557-659 derives the pose from plane-wise correspondences). */
+enum { ORC_EST_POINT2PLANE = 0, ORC_EST_SVD = 1, ORC_EST_PLANE = 2 };
 enum { ORC_NN_BRUTE = 0, ORC_NN_KDTREE = 1 };
 enum { ORC_OK = 0, ORC_TOO_FEW_INLIERS = 1, ORC_NORM_EXCEEDED = 2, ORC_DEGENERATE = 3 };
 
@@ -72,6 +76,19 @@ typedef struct orc_params {
      * the rows gives the same update, and those are the iterations whose searches are widest.  0 = every iteration uses
      * every source.  Default 3. */
     int    coarse_iterations;
+    /* ---- ORC_EST_PLANE (spec S2p): the segmentation that yields the planes (defaults = parameters.yaml: 0.08 / 0.2 / 3; 64
+     * hypotheses, seed 1), and the optional plane-PAIR gate (src/GraphicEnd.cpp:459-484,:572: PnP only
+     * inside matched plane pairs): the source frame is segmented too, its planes are carried into the target frame by the
+     * run's initial pose and associated with the target's planes exactly as GraphicEnd::match does (nearest (a, b, c, d));
+     * a correspondence is kept iff the target pixel's plane is the one associated with the source pixel's plane (a pixel on no
+     * plane: label -1, associated with -1 -- clutter only matches clutter).
+     * plane_only: pixels on no plane are NOT targets (the literal per-plane variant of App. C2); default 0: they keep their 7x7
+     * window normal, because two or three planes rarely constrain all six degrees of freedom. */
+    float  seg_distance_threshold, seg_plane_percent;
+    int    seg_max_planes, seg_hypotheses;
+    uint64_t seg_seed;
+    int    plane_pair_gate;
+    int    plane_only;
 } orc_params;
 
 typedef struct orc_result {
@@ -91,6 +108,14 @@ void orc_backproject(const uint16_t *depth, const orc_params *p, float *xyz4);
 
 /* S2: per-pixel normals of an organized cloud; out {nx,ny,nz,1} or {0,0,0,0} */
 void orc_normals(const float *xyz4, const orc_params *p, float *nrm4);
+
+/* S2p: per-plane normals of an organized cloud: out {a,b,c, 1 + plane} for a pixel labelled with plane r; a pixel on no plane
+ * keeps its S2 window normal as {nx,ny,nz, 0.75} (plane_only: {0,0,0,0}); {0,0,0,0} where there is neither;
+ * planes8 (seg_max_planes * 8: a b c d cx cy cz count) and labels (N) nullable; returns the number of planes */
+int orc_plane_normals(const float *xyz4, const orc_params *p, float *nrm4, float *planes8, int32_t *labels);
+/* plane association of the pair gate: planes of frame 1 (n1 x 8 floats, a b c d first) carried by T (row-major 4x4, nullable =
+ * Identity) and matched to the planes of frame 2; assoc[i] = index in frame 2 or -1 */
+void orc_plane_assoc(const float *planes1, int n1, const float *planes2, int n2, const double *T, int32_t *assoc);
 
 /* S3..S6: full ICP.  src4/tgt4 organized float4 clouds (w ignored).
  * idx_out[N] (original linear indices, -1 none) / d2_out[N] of the LAST iteration,

@@ -15,7 +15,8 @@ from . import build as _build
 
 NSUMS = 29      # the derived sums of the trace
 NRAW = 36       # the integer Gram totals the dense mode exchanges (SLAM3D_ICP_NRAW)
-EST_POINT2PLANE, EST_SVD = 0, 1
+EST_POINT2PLANE, EST_SVD, EST_PLANE = 0, 1, 2
+PLANE_PAIR_GATE, PLANE_ONLY = 1, 2        # slam3d_icp_params.plane_flags
 NN_AUTO, NN_BRUTE_VALU, NN_BRUTE_MFMA, NN_TILES = 0, 1, 2, 3
 
 EXPORTED_SYMBOLS = [
@@ -36,6 +37,7 @@ EXPORTED_SYMBOLS = [
     "slam3d_comm_last_error", "slam3d_shard_range", "slam3d_icp_dense_run", "slam3d_pose_gather_submit",
     "slam3d_pose_gather_collect", "slam3d_pose_gather", "slam3d_pose_record_from_result",
     "slam3d_plane_gate", "slam3d_device_count",
+    "slam3d_icp_set_seg_params", "slam3d_icp_get_frame_planes", "slam3d_icp_get_plane_assoc",
 ]
 COMM_ID_BYTES = 128
 
@@ -50,7 +52,7 @@ class Params(C.Structure):
         ("min_inliers", C.c_int32), ("error_threshold", C.c_double),
         ("max_batch", C.c_int32), ("device", C.c_int32), ("nn_mode", C.c_int32), ("extra_frames", C.c_int32),
         ("max_plane_residual2", C.c_float), ("min_normal_cos", C.c_float),
-        ("coarse_iterations", C.c_int32), ("_pad0", C.c_int32),
+        ("coarse_iterations", C.c_int32), ("plane_flags", C.c_int32),
     ]
 
 
@@ -457,6 +459,21 @@ class IcpHandle:
         self._check(self.lib.slam3d_segment_planes_device(self._h, C.c_int32(B), ptrs, C.byref(sp), planes, npl,
                                                           C.c_void_p(d_labels), C.c_void_p(stream)), False)
         return self._planes_out(planes, npl, B, sp.max_planes)
+
+    # ---- SLAM3D_EST_PLANE ----------------------------------------------------------------
+    def set_seg_params(self, sp: SegParams):
+        self._check(self.lib.slam3d_icp_set_seg_params(self._h, C.byref(sp)), False)
+
+    def get_frame_planes(self, frame: int) -> list:
+        planes = (Plane * 8)()
+        n = C.c_int32(0)
+        self._check(self.lib.slam3d_icp_get_frame_planes(self._h, C.c_int32(frame), planes, C.byref(n)), False)
+        return [dict(coeff=np.array(planes[r].coeff), count=planes[r].count, centroid=np.array(planes[r].centroid)) for r in range(n.value)]
+
+    def get_plane_assoc(self, slot: int = 0) -> np.ndarray:
+        a = np.zeros(8, dtype=np.int32)
+        self._check(self.lib.slam3d_icp_get_plane_assoc(self._h, C.c_int32(slot), _vp(a)), False)
+        return a
 
     # ---- dense mode --------------------------------------------------------------------
     def dense_set_rows(self, r0: int, r1: int):

@@ -64,6 +64,12 @@ struct slam3d_icp_handle {
     int *seg_labels = nullptr;
     const float4 **seg_ptrs = nullptr;
     FitState *fit_state = nullptr, *pin_fit = nullptr;   // slam3d_fit_planes
+    // SLAM3D_EST_PLANE (spec S2p): the library's own segmentation scratch (one slot per frame a preprocessing pass may rebuild), the
+    // planes it found per frame, the pair gate's association per pair
+    SegState *pl_state = nullptr; int *pl_labels = nullptr; const float4 **pl_ptrs = nullptr;
+    FramePlanes *f_planes = nullptr;      // [maxF]
+    int *assoc = nullptr;                 // [maxB][8]
+    slam3d_seg_params seg_sp;             // slam3d_icp_set_seg_params
     // voxel grid (f-1): allocated on first use
     unsigned char *vox_mem = nullptr;
     VoxTable vox;
@@ -134,6 +140,11 @@ static inline int nn_mode_of(const slam3d_icp_handle *h)
     return h->p.nn_mode == SLAM3D_NN_AUTO ? SLAM3D_NN_TILES : h->p.nn_mode;
 }
 
+// rows / solve of the estimator: SLAM3D_EST_PLANE differs from POINT2PLANE only in where the target normals come from (spec S2p)
+static inline bool is_p2p(const slam3d_icp_handle *h) { return h->p.estimator != SLAM3D_EST_SVD; }
+static inline bool is_plane(const slam3d_icp_handle *h) { return h->p.estimator == SLAM3D_EST_PLANE; }
+static inline int row_estimator(const slam3d_icp_handle *h) { return h->p.estimator == SLAM3D_EST_SVD ? 1 : 0; }
+
 static inline void identity16(double *T) { for (int k = 0; k < 16; ++k) T[k] = (k % 5 == 0) ? 1.0 : 0.0; }
 
 extern "C" int slam3d_icp_abi_version(void) { return SLAM3D_ICP_ABI_VERSION; }
@@ -154,6 +165,7 @@ extern "C" void slam3d_icp_default_params(slam3d_icp_params *p)
     p->extra_frames = 0;
     p->max_plane_residual2 = 0.0f; p->min_normal_cos = 0.0f;      // optional gates off
     p->coarse_iterations = 3;                                      // spec S4c
+    p->plane_flags = 0;
 }
 
 extern "C" const char *slam3d_strerror(int code)
@@ -208,6 +220,7 @@ static void free_all(slam3d_icp_handle *h)
     if (h->pin_seg) (void)hipHostFree(h->pin_seg);
     if (h->pin_fit) (void)hipHostFree(h->pin_fit);
     F(h->fit_state);
+    F(h->pl_state); F(h->pl_labels); F(h->pl_ptrs); F(h->f_planes); F(h->assoc);
     F(h->seg_state); F(h->seg_labels); F(h->seg_ptrs);
     F(h->vox_mem); F(h->vox_lkey); F(h->vox_lslot); F(h->vox_m); F(h->vox_out); F(h->vox_gkey); F(h->vox_gslot); F(h->vox_hist);
     if (h->pin_vox_m) (void)hipHostFree(h->pin_vox_m);
@@ -234,7 +247,9 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     *out = nullptr;
     if (p->width <= 0 || p->height <= 0 || p->max_batch <= 0 || p->iterations < 0 || p->extra_frames < 0 || p->coarse_iterations < 0) return SLAM3D_E_INVALID;
     if (p->normal_window < 1 || (p->normal_window & 1) == 0 || p->normal_window / 2 > NRM_RMAX) return SLAM3D_E_INVALID;
-    if (p->estimator != SLAM3D_EST_POINT2PLANE && p->estimator != SLAM3D_EST_SVD) return SLAM3D_E_INVALID;
+    if (p->estimator != SLAM3D_EST_POINT2PLANE && p->estimator != SLAM3D_EST_SVD && p->estimator != SLAM3D_EST_PLANE) return SLAM3D_E_INVALID;
+    if (p->plane_flags & ~(SLAM3D_PLANE_PAIR_GATE | SLAM3D_PLANE_ONLY)) return SLAM3D_E_INVALID;
+    if (p->plane_flags != 0 && p->estimator != SLAM3D_EST_PLANE) return SLAM3D_E_INVALID;
     if (p->nn_mode < SLAM3D_NN_AUTO || p->nn_mode > SLAM3D_NN_TILES) return SLAM3D_E_INVALID;
     if (!(p->max_corr_dist > 0.0) || !(p->z_filter > 0.0)) return SLAM3D_E_INVALID;
     {   // range of the int64 fixed-point sums (unit 2^-32): a term is at most |p|^2, all N slots may carry one.  With the
@@ -280,7 +295,9 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     g.cert_track = getenv("SLAM3D_CERT_TRACK") ? (float)atof(getenv("SLAM3D_CERT_TRACK")) : CERT_TRACK_MOTION;
     g.resid2 = p->max_plane_residual2 > 0.0f ? p->max_plane_residual2 : 0.0f;
     g.min_ncos = p->min_normal_cos > 0.0f ? p->min_normal_cos : 0.0f;
-    g.estimator = p->estimator;
+    g.estimator = p->estimator == SLAM3D_EST_SVD ? 1 : 0;          // the kernels know two row forms; PLANE is POINT2PLANE with other normals
+    g.pair_gate = (p->estimator == SLAM3D_EST_PLANE && (p->plane_flags & SLAM3D_PLANE_PAIR_GATE)) ? 1 : 0;
+    slam3d_seg_default_params(&h->seg_sp);
     g.fx = p->fx; g.fy = p->fy; g.cx = p->cx; g.cy = p->cy; g.factor = p->depth_factor; g.zf = p->z_filter;
     h->row0 = 0; h->row1 = p->height;
     TileGrid &tg = h->tg;
@@ -352,6 +369,10 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     A(dalloc(h->sums, (size_t)h->maxB * NRAW)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
     A(dalloc(h->trace_T, (size_t)h->maxB * (iters + 1) * 16)); A(dalloc(h->trace_S, (size_t)h->maxB * iters * NSUMS));
     A(dalloc(h->d_pairs, (size_t)h->maxB));
+    if (p->estimator == SLAM3D_EST_PLANE) {
+        A(dalloc(h->pl_state, F)); A(dalloc(h->pl_labels, F * h->N)); A(dalloc(h->pl_ptrs, F));
+        A(dalloc(h->f_planes, F)); A(dalloc(h->assoc, (size_t)h->maxB * 8));
+    }
     A(dalloc(h->d_depth, (size_t)h->N)); A(dalloc(h->d_idx, (size_t)h->N)); A(dalloc(h->d_d2, (size_t)h->N));
     A(dalloc(h->d_scratch4, (size_t)h->N));
     A(hipHostMalloc((void **)&h->pin_res, sizeof(double) * RES_REC * h->maxB, hipHostMallocMapped));
@@ -389,6 +410,10 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     h->pair_src.assign(h->maxB, -1); h->pair_tgt.assign(h->maxB, -1);
     h->h_pairs.assign(h->maxB, PairPtrs{}); h->up_pairs.assign(h->maxB, PairPtrs{});
     (void)hipMemsetAsync(h->f_counts, 0, sizeof(int) * 4 * F, h->stream);
+    if (h->f_planes) {
+        (void)hipMemsetAsync(h->f_planes, 0, sizeof(FramePlanes) * F, h->stream);
+        (void)hipMemsetAsync(h->assoc, 0xFF, sizeof(int) * 8 * (size_t)h->maxB, h->stream);
+    }
     (void)hipMemsetAsync(h->perm_d, 0xFF, sizeof(int) * (size_t)h->maxB * h->nn_gx_d * NN_WAVES, h->stream);
     (void)hipMemsetAsync(h->acc, 0, sizeof(long long) * (size_t)h->maxB * h->nsets * ACC_R * ACC_STRIDE, h->stream);   // k_pair_init re-zeroes at every run
     *out = h;
@@ -550,6 +575,42 @@ extern "C" int slam3d_icp_set_depth_device(slam3d_icp_handle *h, int32_t slot, c
     return slam3d_icp_set_pair(h, slot, 2 * slot, 2 * slot + 1);
 }
 
+// the launches of one segmentation pass over B frames (spec P1-P5): nothing returns to the host.  ptrs_dev[b] = cloud of frame b,
+// lab + b * N its labels, st[b] its state (zeroed here).  Shared by slam3d_segment_planes* and the preprocessing of SLAM3D_EST_PLANE.
+static int enqueue_segmentation(slam3d_icp_handle *h, int B, const float4 **ptrs_dev, int *lab, SegState *st, const slam3d_seg_params *sp, hipStream_t s)
+{
+    const int N = h->N;
+    const SegParams P = { sp->distance_threshold, sp->plane_percent, sp->max_planes, sp->hypotheses, sp->seed };
+    const dim3 pg((N + SEG_BLOCK * SEG_PTS - 1) / (SEG_BLOCK * SEG_PTS), B);
+    HIPCHK(h, hipMemsetAsync(st, 0, sizeof(SegState) * B, s));
+    hipLaunchKernelGGL(k_seg_init, pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, h->g.zmax);
+    for (int r = 0; r < P.max_planes; ++r) {
+        const dim3 cg(pg.x, pg.y, (P.hypotheses + SEG_HGROUP - 1) / SEG_HGROUP);
+        if (B <= 2) {
+            // a frame alone is bound by launch latency: three launches per round -- bookkeeping + hypotheses + consensus | moments | refinement + labels
+            hipLaunchKernelGGL(k_seg_count<true>, cg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P, r);
+            hipLaunchKernelGGL(k_seg_moments, pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P.hypotheses, r);
+            hipLaunchKernelGGL(k_seg_label<true>, pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P.hypotheses, P.thr, r);
+        } else {
+            // a batch is bound by throughput: the heads run once per frame (five launches per round)
+            hipLaunchKernelGGL(k_seg_hyp, dim3(B), dim3(64), 0, s, ptrs_dev, lab, st, N, P, r);
+            hipLaunchKernelGGL(k_seg_count<false>, cg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P, r);
+            hipLaunchKernelGGL(k_seg_moments, pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P.hypotheses, r);
+            hipLaunchKernelGGL(k_seg_refine, dim3(B), dim3(64), 0, s, st, P.hypotheses, r);
+            hipLaunchKernelGGL(k_seg_label<false>, pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P.hypotheses, P.thr, r);
+        }
+    }
+    hipLaunchKernelGGL(k_seg_final, dim3(B), dim3(1), 0, s, st, P.max_planes, P.percent);
+    HIPCHK(h, hipGetLastError());
+    return SLAM3D_OK;
+}
+
+static bool seg_params_ok(const slam3d_seg_params *sp)
+{
+    return sp && sp->max_planes >= 1 && sp->max_planes <= SEG_MAXP && sp->hypotheses >= 1 && sp->hypotheses <= SEG_H &&
+           sp->distance_threshold > 0.0f && sp->plane_percent >= 0.0f;
+}
+
 // ------------------------------------------------------------------------------ run
 static int pick_nsplit(const slam3d_icp_handle *h, int B)
 {
@@ -568,8 +629,8 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
 {
     const Geometry &g = h->g;
     const TileGrid &tg = h->tg;
-    const int use_normals = h->p.estimator == SLAM3D_EST_POINT2PLANE ? 1 : 0;
-    const bool src_normals = use_normals && g.min_ncos > 0.0f;       // the normal-angle gate reads the source frame's normals
+    const int use_normals = is_p2p(h) ? 1 : 0;
+    const bool src_normals = use_normals && (g.min_ncos > 0.0f || g.pair_gate);       // the normal-angle gate / the plane-pair gate read the source frame's normals
     std::vector<FrameTask> tasks, ntasks;
     auto task_of = [&](int f, int role) {
         FrameTask t;
@@ -631,14 +692,41 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         pp.cbox = h->f_cbox + (size_t)ft * tg.ncoarse * 2;
         pp.src_counts = h->f_counts + (size_t)fs * 4;
         pp.tgt_counts = h->f_counts + (size_t)ft * 4;
+        pp.spl = h->f_planes ? h->f_planes + fs : nullptr;
+        pp.tpl = h->f_planes ? h->f_planes + ft : nullptr;
+        pp.assoc = h->assoc ? h->assoc + (size_t)b * 8 : nullptr;
     }
-    for (size_t k0 = 0; k0 < ntasks.size(); k0 += FRAME_ARGS) {
+    const bool plane_only = is_plane(h) && (h->p.plane_flags & SLAM3D_PLANE_ONLY);
+    for (size_t k0 = 0; k0 < ntasks.size() && !plane_only; k0 += FRAME_ARGS) {
         FrameTasks a;
         const int n = (int)std::min<size_t>(FRAME_ARGS, ntasks.size() - k0);
         for (int k = 0; k < n; ++k) a.t[k] = ntasks[k0 + k];
         dim3 grid((g.W + NRM_BX - 1) / NRM_BX, (g.H + NRM_BY - 1) / NRM_BY, n);
         if (g.win_r == 3) hipLaunchKernelGGL(k_normals<3>, grid, dim3(NRM_BX, NRM_BY), 0, s, a, g);
         else hipLaunchKernelGGL(k_normals<0>, grid, dim3(NRM_BX, NRM_BY), 0, s, a, g);
+    }
+    if (is_plane(h) && !ntasks.empty()) {
+        // spec S2p: the frames that need normals are segmented together (scratch slot k = task k), then every labelled pixel takes
+        // its plane's normal and the frame's plane table is recorded
+        const int nt = (int)ntasks.size();          // <= maxF: one task per frame at most
+        for (int k0 = 0; k0 < nt; k0 += PTR_ARGS) {
+            PtrArgs a;
+            const int n = std::min(PTR_ARGS, nt - k0);
+            for (int k = 0; k < n; ++k) a.p[k] = ntasks[k0 + k].cloud;
+            hipLaunchKernelGGL(k_set_ptrs, dim3(1), dim3(64), 0, s, h->pl_ptrs + k0, a, n);
+        }
+        const int src = enqueue_segmentation(h, nt, h->pl_ptrs, h->pl_labels, h->pl_state, &h->seg_sp, s);
+        if (src) return src;
+        for (int k0 = 0; k0 < nt; k0 += PLANE_ARGS) {
+            PlaneTasks a;
+            const int n = std::min(PLANE_ARGS, nt - k0);
+            for (int k = 0; k < n; ++k) {
+                const size_t f = (size_t)(ntasks[k0 + k].nrm - h->f_nrm) / (size_t)h->N;
+                a.t[k].lab = h->pl_labels + (size_t)(k0 + k) * h->N; a.t[k].st = h->pl_state + (k0 + k);
+                a.t[k].nrm = ntasks[k0 + k].nrm; a.t[k].out = h->f_planes + f;
+            }
+            hipLaunchKernelGGL(k_plane_normals, dim3((h->N + 255) / 256, n), dim3(256), 0, s, a, h->N, plane_only ? 1 : 0);
+        }
     }
     for (size_t k0 = 0; k0 < tasks.size(); k0 += FRAME_ARGS) {
         FrameTasks a;
@@ -674,6 +762,7 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
                                stamp_ring_of(h), count_run);
     }
     if (count_run) h->run_counted = true;
+    if (g.pair_gate) hipLaunchKernelGGL(k_plane_assoc, dim3(B), dim3(64), 0, s, h->d_pairs, h->Tcur);      // (behind k_set_pairs and k_pair_init)
     if (nn_mode_of(h) != SLAM3D_NN_TILES) {
         HIPCHK(h, hipMemsetAsync(h->best, 0xFF, sizeof(unsigned long long) * (size_t)B * tg.nslots, s));
         hipLaunchKernelGGL(k_compact, dim3(2, B), dim3(1024), 0, s, h->d_pairs, h->src_c, h->tgt_c, h->ccounts, g, tg,
@@ -719,7 +808,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         // few pairs: cooperative blocks (latency bound); from 8 pairs per launch: every wave on its
         // own, 8 waves per SIMD (throughput bound); three staged tile records per wave in both
         const bool dense = B >= h->dense_batch;
-        head = h->head_solve != 0 && !dense && do_solve && h->p.estimator == SLAM3D_EST_POINT2PLANE;
+        head = h->head_solve != 0 && !dense && do_solve && is_p2p(h);
         const int write_out = (!do_solve || it == iters - 1 || h->want_corr_trace) ? 1 : 0;      // corr / cd2: only the last iteration's are read
         int *perm = dense ? h->perm_d : nullptr;            // the cooperative build owns tiles by the interleaved default
         const int gx = dense ? h->nn_gx_d : h->nn_gx;
@@ -730,7 +819,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
                                head ? h->head_solve : 0, (h->cert_on && do_solve) ? 1 : 0, cmode);
         };
         // (+ two with the optional S4g gates compiled in: the production instances carry none of that code)
-        const bool gated = h->p.estimator == SLAM3D_EST_POINT2PLANE && (h->g.resid2 > 0.0f || h->g.min_ncos > 0.0f);
+        const bool gated = is_p2p(h) && (h->g.resid2 > 0.0f || h->g.min_ncos > 0.0f || h->g.pair_gate);
         if (gated) { if (dense) launch(k_nn_tiles_acc<3, 8, false, false, true>); else launch(k_nn_tiles_acc<3, S3D_COOP_WPE, true, false, true>); }
         else if (dense) { if (h->dbg) launch(k_nn_tiles_acc<3, 8, false, true>); else launch(k_nn_tiles_acc<3, 8, false, false>); }
         else       { if (h->dbg) launch(k_nn_tiles_acc<3, S3D_COOP_WPE, true, true>);  else launch(k_nn_tiles_acc<3, S3D_COOP_WPE, true, false>); }
@@ -787,7 +876,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
     }
     if (head && it < iters - 1) {
         // solved at the head of the next NN launch; only the run's last iteration keeps its k_solve_acc (result record)
-    } else if (h->p.estimator == SLAM3D_EST_POINT2PLANE)
+    } else if (is_p2p(h))
         hipLaunchKernelGGL(k_solve_acc<0>, dim3(B), dim3(64), 0, s, h->acc, raw_out, h->Tcur, h->trace_T, h->trace_S, h->flags, h->d_pairs,
                            do_solve ? h->d_res : nullptr, it, iters, do_solve,
                            stamp_ring_of(h, do_solve != 0), iters + it,
@@ -1105,7 +1194,7 @@ extern "C" int slam3d_icp_get_clouds(slam3d_icp_handle *h, int32_t slot, float *
     if (src_xyz4) HIPCHK(h, hipMemcpyAsync(src_xyz4, S.cloud, bytes, hipMemcpyDeviceToHost, s));
     if (tgt_xyz4) HIPCHK(h, hipMemcpyAsync(tgt_xyz4, T.cloud, bytes, hipMemcpyDeviceToHost, s));
     if (tgt_nrm4) {
-        if (!h->ran || h->p.estimator != SLAM3D_EST_POINT2PLANE) return SLAM3D_E_STATE;
+        if (!h->ran || !is_p2p(h)) return SLAM3D_E_STATE;
         HIPCHK(h, hipMemcpyAsync(tgt_nrm4, h->f_nrm + (size_t)h->pair_tgt[slot] * h->N, bytes, hipMemcpyDeviceToHost, s));
     }
     HIPCHK(h, hipStreamSynchronize(s));
@@ -1426,14 +1515,11 @@ extern "C" int slam3d_segment_planes_device(slam3d_icp_handle *h, int32_t B, con
                                             int32_t *d_labels, void *stream)
 {
     if (!h || !d_clouds || !sp || !planes || !nplanes || B <= 0 || B > h->maxB) return SLAM3D_E_INVALID;
-    if (sp->max_planes < 1 || sp->max_planes > SEG_MAXP || sp->hypotheses < 1 || sp->hypotheses > SEG_H ||
-        !(sp->distance_threshold > 0.0f) || !(sp->plane_percent >= 0.0f))
-        return SLAM3D_E_INVALID;
+    if (!seg_params_ok(sp)) return SLAM3D_E_INVALID;
     HIPCHK(h, hipSetDevice(h->p.device));
     int rc = seg_alloc(h);
     if (rc) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    const int N = h->N;
     for (int b0 = 0; b0 < B; b0 += PTR_ARGS) {
         PtrArgs a;
         const int n = B - b0 < PTR_ARGS ? B - b0 : PTR_ARGS;
@@ -1444,28 +1530,8 @@ extern "C" int slam3d_segment_planes_device(slam3d_icp_handle *h, int32_t B, con
         hipLaunchKernelGGL(k_set_ptrs, dim3(1), dim3(64), 0, s, h->seg_ptrs + b0, a, n);
     }
     int *lab = d_labels ? d_labels : h->seg_labels;
-    const SegParams P = { sp->distance_threshold, sp->plane_percent, sp->max_planes, sp->hypotheses, sp->seed };
-    const dim3 pg((N + SEG_BLOCK * SEG_PTS - 1) / (SEG_BLOCK * SEG_PTS), B);
-    HIPCHK(h, hipMemsetAsync(h->seg_state, 0, sizeof(SegState) * B, s));
-    hipLaunchKernelGGL(k_seg_init, pg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, h->g.zmax);
-    for (int r = 0; r < P.max_planes; ++r) {
-        const dim3 cg(pg.x, pg.y, (P.hypotheses + SEG_HGROUP - 1) / SEG_HGROUP);
-        if (B <= 2) {
-            // a frame alone is bound by launch latency: three launches per round -- bookkeeping + hypotheses + consensus | moments | refinement + labels
-            hipLaunchKernelGGL(k_seg_count<true>, cg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, P, r);
-            hipLaunchKernelGGL(k_seg_moments, pg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, P.hypotheses, r);
-            hipLaunchKernelGGL(k_seg_label<true>, pg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, P.hypotheses, P.thr, r);
-        } else {
-            // a batch is bound by throughput: the heads run once per frame (five launches per round)
-            hipLaunchKernelGGL(k_seg_hyp, dim3(B), dim3(64), 0, s, h->seg_ptrs, lab, h->seg_state, N, P, r);
-            hipLaunchKernelGGL(k_seg_count<false>, cg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, P, r);
-            hipLaunchKernelGGL(k_seg_moments, pg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, P.hypotheses, r);
-            hipLaunchKernelGGL(k_seg_refine, dim3(B), dim3(64), 0, s, h->seg_state, P.hypotheses, r);
-            hipLaunchKernelGGL(k_seg_label<false>, pg, dim3(SEG_BLOCK), 0, s, h->seg_ptrs, lab, h->seg_state, N, P.hypotheses, P.thr, r);
-        }
-    }
-    hipLaunchKernelGGL(k_seg_final, dim3(B), dim3(1), 0, s, h->seg_state, P.max_planes, P.percent);
-    HIPCHK(h, hipGetLastError());
+    rc = enqueue_segmentation(h, B, h->seg_ptrs, lab, h->seg_state, sp, s);
+    if (rc) return rc;
     HIPCHK(h, hipMemcpyAsync(h->pin_seg, h->seg_state, sizeof(SegState) * B, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     for (int b = 0; b < B; ++b) {
@@ -1495,6 +1561,47 @@ extern "C" int slam3d_segment_planes(slam3d_icp_handle *h, const slam3d_cloud_vi
     rc = slam3d_segment_planes_device(h, 1, &ptr, sp, planes, nplanes, nullptr, h->stream);
     if (rc) return rc;
     if (labels) HIPCHK(h, hipMemcpy(labels, h->seg_labels, sizeof(int) * (size_t)h->N, hipMemcpyDeviceToHost));
+    return SLAM3D_OK;
+}
+
+// ------------------------------------------------------------------------------ SLAM3D_EST_PLANE: parameters / introspection
+extern "C" int slam3d_icp_set_seg_params(slam3d_icp_handle *h, const slam3d_seg_params *sp)
+{
+    if (!h || !seg_params_ok(sp)) return SLAM3D_E_INVALID;
+    if (!is_plane(h)) return SLAM3D_E_STATE;
+    h->seg_sp = *sp;
+    for (auto &fr : h->frames) { fr.nrm_epoch = 0; fr.tgt_epoch = 0; }      // normals and target tiles of every frame are stale
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_get_frame_planes(slam3d_icp_handle *h, int32_t frame, slam3d_plane *planes, int32_t *nplanes)
+{
+    if (!frame_ok(h, frame) || !planes || !nplanes) return SLAM3D_E_INVALID;
+    *nplanes = 0;
+    memset(planes, 0, sizeof(slam3d_plane) * 8);
+    if (!h->f_planes) return SLAM3D_E_STATE;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    if (h->ran && h->run_stream) HIPCHK(h, hipStreamSynchronize(h->run_stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    FramePlanes fp;
+    HIPCHK(h, hipMemcpy(&fp, h->f_planes + frame, sizeof fp, hipMemcpyDeviceToHost));
+    if (h->frames[frame].nrm_epoch != h->frames[frame].epoch || h->frames[frame].epoch == 0) return SLAM3D_OK;      // not built (for this content)
+    *nplanes = fp.n;
+    for (int r = 0; r < fp.n && r < 8; ++r) {
+        planes[r].coeff[0] = fp.pl[r].a; planes[r].coeff[1] = fp.pl[r].b; planes[r].coeff[2] = fp.pl[r].c; planes[r].coeff[3] = fp.pl[r].d;
+        planes[r].count = fp.pl[r].count;
+        planes[r].centroid[0] = fp.pl[r].cx; planes[r].centroid[1] = fp.pl[r].cy; planes[r].centroid[2] = fp.pl[r].cz;
+    }
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_icp_get_plane_assoc(slam3d_icp_handle *h, int32_t slot, int32_t *assoc)
+{
+    if (!slot_ok(h, slot) || !assoc) return SLAM3D_E_INVALID;
+    if (!h->assoc || !h->g.pair_gate || !h->ran || slot >= h->last_B) return SLAM3D_E_STATE;
+    HIPCHK(h, hipSetDevice(h->p.device));
+    HIPCHK(h, hipStreamSynchronize(h->run_stream));
+    HIPCHK(h, hipMemcpy(assoc, h->assoc + (size_t)slot * 8, sizeof(int) * 8, hipMemcpyDeviceToHost));
     return SLAM3D_OK;
 }
 
@@ -1547,7 +1654,7 @@ extern "C" int slam3d_icp_dense_update(slam3d_icp_handle *h, const int64_t sums[
     memcpy(h->pin_out, sums, sizeof(int64_t) * NRAW);           // pin_out holds (16+36)*maxB 8-byte words
     HIPCHK(h, hipMemcpyAsync(h->sums, h->pin_out, sizeof(int64_t) * NRAW, hipMemcpyHostToDevice, s));
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
-    if (h->p.estimator == SLAM3D_EST_POINT2PLANE)
+    if (is_p2p(h))
         hipLaunchKernelGGL(k_solve<0>, dim3(1), dim3(64), 0, s, h->sums, h->Tcur, h->trace_T, h->trace_S, h->flags, h->dense_it, iters, h->g.eb);
     else
         hipLaunchKernelGGL(k_solve<1>, dim3(1), dim3(64), 0, s, h->sums, h->Tcur, h->trace_T, h->trace_S, h->flags, h->dense_it, iters, h->g.eb);
@@ -1579,7 +1686,7 @@ extern "C" int slam3d_icp_dense_update_device(slam3d_icp_handle *h, const int64_
     if (!h->ran || h->dense_it >= iters) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     hipStream_t s = stream ? (hipStream_t)stream : h->run_stream;
-    if (h->p.estimator == SLAM3D_EST_POINT2PLANE)
+    if (is_p2p(h))
         hipLaunchKernelGGL(k_solve<0>, dim3(1), dim3(64), 0, s, reinterpret_cast<const long long *>(d_sums), h->Tcur, h->trace_T, h->trace_S, h->flags, h->dense_it, iters, h->g.eb);
     else
         hipLaunchKernelGGL(k_solve<1>, dim3(1), dim3(64), 0, s, reinterpret_cast<const long long *>(d_sums), h->Tcur, h->trace_T, h->trace_S, h->flags, h->dense_it, iters, h->g.eb);
@@ -1604,7 +1711,7 @@ extern "C" int slam3d_icp_dense_finish_device(slam3d_icp_handle *h, const int64_
     HIPCHK(h, hipMemcpyAsync(h->pin_int + 4, h->flags, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     double ls[NSUMS];
-    for (int k = 0; k < NSUMS; ++k) ls[k] = derive_sum(h->p.estimator, h->g.eb, k, reinterpret_cast<const long long *>(ps));
+    for (int k = 0; k < NSUMS; ++k) ls[k] = derive_sum(row_estimator(h), h->g.eb, k, reinterpret_cast<const long long *>(ps));
     finish_result(h->p, h->pin_out, ls, h->pin_int[4], h->pin_int[0], h->pin_int[1], out);
     out->iterations = h->dense_it;
     return SLAM3D_OK;
@@ -1622,7 +1729,7 @@ extern "C" int slam3d_icp_dense_finish(slam3d_icp_handle *h, const int64_t last_
     HIPCHK(h, hipMemcpyAsync(h->pin_int + 4, h->flags, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     double ls[NSUMS];
-    for (int k = 0; k < NSUMS; ++k) ls[k] = last_sums ? derive_sum(h->p.estimator, h->g.eb, k, reinterpret_cast<const long long *>(last_sums)) : 0.0;
+    for (int k = 0; k < NSUMS; ++k) ls[k] = last_sums ? derive_sum(row_estimator(h), h->g.eb, k, reinterpret_cast<const long long *>(last_sums)) : 0.0;
     finish_result(h->p, h->pin_out, ls, h->pin_int[4], h->pin_int[0], h->pin_int[1], out);
     out->iterations = h->dense_it;
     return SLAM3D_OK;
@@ -1656,7 +1763,7 @@ extern "C" int slam3d_icp_dense_run(slam3d_icp_handle *h, slam3d_comm *comm, con
     hipStream_t s = h->stream;
     rc = slam3d_icp_dense_begin(h, T_init, s);
     const int iters = h->p.iterations;
-    const bool head_flow = h->head_solve != 0 && h->p.estimator == SLAM3D_EST_POINT2PLANE && nn_mode_of(h) == SLAM3D_NN_TILES && 1 < h->dense_batch && iters > 0;
+    const bool head_flow = h->head_solve != 0 && is_p2p(h) && nn_mode_of(h) == SLAM3D_NN_TILES && 1 < h->dense_batch && iters > 0;
     int64_t *d_sums = reinterpret_cast<int64_t *>(h->sums);
     if (head_flow) {
         for (int it = 0; it < iters && !rc; ++it) {

@@ -33,6 +33,9 @@ constexpr int NN_BLOCK = 256;
 // once per pair: the 32 loop-closure candidates of src/GraphicEnd.cpp:685-762 share one target frame, and the
 // keyframe of GraphicEnd::run (src/GraphicEnd.cpp:168) stays the source of many consecutive pairs.
 // A PAIR is two frame references plus its own iteration state (T, accumulators, slot records / prevq, ownership map).
+// SLAM3D_EST_PLANE (spec S2p): the planes of a frame as its last build found them (plane_seg.hpp fills it)
+struct FramePlane { float a, b, c, d, cx, cy, cz; int count; };
+struct FramePlanes { FramePlane pl[8]; int n, pad[3]; };
 struct PairPtrs {                  // per frame-pair device pointers: the resident products of its two frames
     const float4 *src;             // organized source cloud (only the brute-force compaction reads it)
     const float4 *tgt;             // organized target cloud
@@ -46,6 +49,8 @@ struct PairPtrs {                  // per frame-pair device pointers: the reside
     const float4 *cbox;            // target coarse boxes [ncoarse * 2]
     const int *src_counts;         // [0] = valid source points of the source frame (inside its row shard)
     const int *tgt_counts;         // [1] = valid target points of the target frame
+    const FramePlanes *spl, *tpl;  // planes of the source / target frame (SLAM3D_EST_PLANE; null otherwise)
+    int *assoc;                    // [8] plane-pair gate: target plane of every source plane (-1 none), written by k_plane_assoc at the start of a run
 };
 constexpr int RES_REC = 48;        // doubles per pair in the host-mapped result record
 constexpr unsigned long long HEAD_EMPTY = 0x7ff8dead0badc0deull;     // a pose entry "not published yet" (head solve): a quiet NaN with a payload no arithmetic produces
@@ -111,6 +116,7 @@ struct Geometry {
     double in_dist;
     float gate2;
     float resid2, min_ncos;        // optional gates of the point-to-plane estimator (spec S4g), 0 = off
+    int pair_gate;                 // spec S4p: the plane-pair gate of SLAM3D_EST_PLANE (normal.w carries 1 + plane)
     float proj_c;                  // projective window search: pixels of radius r around a query's projection cover every target
                                    // closer than (r + 0.49) * z / proj_c  (= fmax * sqrt(1 + amax^2 + bmax^2) * 1.001), DESIGN.md 5
     int estimator;
@@ -1380,6 +1386,7 @@ __device__ __forceinline__ void tile_accumulate(const RowBasis &B, long long *__
 // correspondence, but its nearest neighbour still serves as the next iteration's upper bound (prevq of the brute-force modes, slot_rec of the tile search).
 struct SlotGates {
     float resid2, min_ncos;
+    const int *assoc;              // plane-pair gate (spec S4p): target plane of every source plane; null = off
     const float4 *snrm;            // source normals, indexed by source pixel
     int spix;                      // this slot's source pixel
     float r[9];                    // the float rotation of the current pose (xform's)
@@ -1432,6 +1439,14 @@ __device__ __forceinline__ void finish_slot(bool valid, unsigned long long key, 
                     const float c = __fmaf_rn(rz, n4.z, __fmaf_rn(ry, n4.y, rx * n4.x));
                     keep = ns.w > 0.5f && c >= sg->min_ncos;
                 }
+                if (keep && sg->assoc) {
+                    // spec S4p: normal.w = 1 + plane (0.75: a window normal on no plane, 0: none => label -1); a plane matches its
+                    // associated plane only, clutter only clutter
+                    const int ls = (int)sg->snrm[sg->spix].w - 1, lt = (int)n4.w - 1;
+                    int want = -1;
+                    if (ls >= 0) want = sg->assoc[ls & 7];
+                    keep = want == lt;
+                }
                 if (!keep) {
                     ok = false;
 #pragma unroll
@@ -1476,6 +1491,7 @@ __global__ __launch_bounds__(CHUNK) void k_accumulate(const PairPtrs *__restrict
     RowBasis rb;
     SlotGates sg;
     sg.resid2 = g.resid2; sg.min_ncos = g.min_ncos; sg.snrm = pairs[b].snrm; sg.spix = max(__float_as_int(sp.w), 0);
+    sg.assoc = g.pair_gate ? pairs[b].assoc : nullptr;
     sg.r[0] = m.r00; sg.r[1] = m.r01; sg.r[2] = m.r02; sg.r[3] = m.r10; sg.r[4] = m.r11; sg.r[5] = m.r12;
     sg.r[6] = m.r20; sg.r[7] = m.r21; sg.r[8] = m.r22;
     finish_slot<true>(valid, key, px, py, pz, pairs[b].tgt, pairs[b].nrm, g.gate2, g.estimator, g.b_scale, corr + gs, cd2 + gs,
@@ -2491,6 +2507,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
         SlotGates sg;
         const Rt m = load_rt_lds(head_T);
         sg.resid2 = g.resid2; sg.min_ncos = g.min_ncos; sg.snrm = pp.snrm; sg.spix = max(pix, 0);
+        sg.assoc = g.pair_gate ? pp.assoc : nullptr;
         sg.r[0] = m.r00; sg.r[1] = m.r01; sg.r[2] = m.r02; sg.r[3] = m.r10; sg.r[4] = m.r11; sg.r[5] = m.r12;
         sg.r[6] = m.r20; sg.r[7] = m.r21; sg.r[8] = m.r22;
         finish_slot<true>(own_valid, bkey, opx, opy, opz, tcloud, tnrm, g.gate2, g.estimator, g.b_scale, corr + gs_ep, cd2 + gs_ep, nullptr, rb,

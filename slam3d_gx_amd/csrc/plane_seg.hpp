@@ -484,6 +484,75 @@ __global__ __launch_bounds__(64) void k_fit_refine(FitState *__restrict__ st, in
     P.cx = (float)cx; P.cy = (float)cy; P.cz = (float)cz;
 }
 
+// ------------------------------------------------------------------------------------ S2p: per-plane normals (SLAM3D_EST_PLANE)
+// SURVEY.md App. C2, per-plane variant: "points take their plane's normal".  One task = one frame that was just segmented
+// (labels + SegState of scratch slot k): the pixel labelled with plane r gets (a, b, c, 1 + r) -- the fit's normal, d >= 0, i.e.
+// toward the camera like the window normals --, a pixel on no plane keeps the 7x7-window normal k_normals left there with
+// w = 0.75 ("a normal, no plane"; plane_only: nothing), and the frame's plane table is recorded for the pair gate / the caller.
+// oracle/icp_oracle.c::orc_plane_normals.  grid (ceil(N / 256), tasks), block 256
+struct PlaneTask { const int *lab; const SegState *st; float4 *nrm; FramePlanes *out; };
+constexpr int PLANE_ARGS = 32;
+struct PlaneTasks { PlaneTask t[PLANE_ARGS]; };
+__global__ __launch_bounds__(256) void k_plane_normals(PlaneTasks a, int N, int plane_only)
+{
+    const PlaneTask &t = a.t[blockIdx.y];
+    const SegState &s = *t.st;
+    const int np = s.nplanes;
+    if (blockIdx.x == 0 && threadIdx.x <= SEG_MAXP) {
+        if (threadIdx.x == SEG_MAXP) t.out->n = np;
+        else {
+            const SegPlane &q = s.planes[threadIdx.x];
+            FramePlane o = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0 };
+            if ((int)threadIdx.x < np) { o.a = q.a; o.b = q.b; o.c = q.c; o.d = q.d; o.cx = q.cx; o.cy = q.cy; o.cz = q.cz; o.count = q.count; }
+            t.out->pl[threadIdx.x] = o;
+        }
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int r = t.lab[i];
+    float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (r >= 0 && r < np) {
+        const SegPlane &q = s.planes[r];
+        o = make_float4(q.a, q.b, q.c, (float)(1 + r));
+    } else if (!plane_only) {
+        const float4 w = t.nrm[i];
+        if (w.w > 0.5f) o = make_float4(w.x, w.y, w.z, 0.75f);
+    }
+    t.nrm[i] = o;
+}
+
+// spec S4p, association (oracle/icp_oracle.c::orc_plane_assoc; slam3d_plane_gate's arithmetic): the planes of the source frame
+// carried by the run's initial pose (Tcur right after k_pair_init), matched to the target frame's planes by the squared L2
+// distance on (a, b, c, d) -- GraphicEnd::match, src/GraphicEnd.cpp:459-484, exact.  grid (B), block 64: lane i = source plane i
+__global__ __launch_bounds__(64) void k_plane_assoc(const PairPtrs *__restrict__ pairs, const double *__restrict__ Tcur)
+{
+    const int b = blockIdx.x, i = threadIdx.x;
+    if (i >= 8) return;
+    const PairPtrs &pp = pairs[b];
+    int best = -1;
+    if (pp.spl && pp.tpl && i < pp.spl->n) {
+        const double *__restrict__ T = Tcur + b * 16;
+        const FramePlane &P = pp.spl->pl[i];
+        const double pa = P.a, pb = P.b, pc = P.c, pd = P.d;
+        double n0 = (T[0] * pa + T[1] * pb) + T[2] * pc, n1 = (T[4] * pa + T[5] * pb) + T[6] * pc, n2 = (T[8] * pa + T[9] * pb) + T[10] * pc;
+        double dd = pd - ((n0 * T[3] + n1 * T[7]) + n2 * T[11]);
+        if (dd < 0.0) { n0 = -n0; n1 = -n1; n2 = -n2; dd = -dd; }        // src/GraphicEnd.cpp:383-387
+        const float m0 = (float)n0, m1 = (float)n1, m2 = (float)n2, m3 = (float)dd;
+        float bd = __int_as_float(0x7f800000);
+        const int n2p = pp.tpl->n;
+        for (int j = 0; j < n2p; ++j) {
+            const FramePlane &Q = pp.tpl->pl[j];
+            float d2 = 0.0f, e;
+            e = m0 - Q.a; d2 = __fmaf_rn(e, e, d2);
+            e = m1 - Q.b; d2 = __fmaf_rn(e, e, d2);
+            e = m2 - Q.c; d2 = __fmaf_rn(e, e, d2);
+            e = m3 - Q.d; d2 = __fmaf_rn(e, e, d2);
+            if (d2 < bd) { bd = d2; best = j; }
+        }
+    }
+    if (pp.assoc) pp.assoc[i] = best;
+}
+
 constexpr int PTR_ARGS = 32;
 struct PtrArgs { const float4 *p[PTR_ARGS]; };
 __global__ void k_set_ptrs(const float4 **__restrict__ dst, PtrArgs a, int n)

@@ -26,6 +26,9 @@ class OrcParams(C.Structure):
         ("nn_method", C.c_int), ("threads", C.c_int),
         ("max_plane_residual2", C.c_double), ("min_normal_cos", C.c_double),
         ("coarse_iterations", C.c_int),
+        ("seg_distance_threshold", C.c_float), ("seg_plane_percent", C.c_float),
+        ("seg_max_planes", C.c_int), ("seg_hypotheses", C.c_int), ("seg_seed", C.c_uint64),
+        ("plane_pair_gate", C.c_int), ("plane_only", C.c_int),
     ]
 
 
@@ -90,6 +93,29 @@ def normals(xyz4: np.ndarray, p: OrcParams) -> np.ndarray:
     return out
 
 
+def plane_normals(xyz4: np.ndarray, p: OrcParams):
+    """spec S2p: -> (nrm4 [H,W,4] with w = 1 + plane, planes [n,8] = a b c d cx cy cz count, labels [N])"""
+    xyz4 = np.ascontiguousarray(xyz4, dtype=np.float32)
+    out = np.empty((p.height, p.width, 4), dtype=np.float32)
+    planes = np.zeros((p.seg_max_planes, 8), dtype=np.float32)
+    labels = np.zeros(p.width * p.height, dtype=np.int32)
+    f = lib().orc_plane_normals
+    f.restype = C.c_int
+    k = f(_fp(xyz4, C.c_float), C.byref(p), _fp(out, C.c_float), _fp(planes, C.c_float), _fp(labels, C.c_int32))
+    return out, planes[:k].copy(), labels
+
+
+def plane_assoc(planes1, planes2, T=None) -> np.ndarray:
+    a = np.ascontiguousarray(planes1, dtype=np.float32).reshape(-1, 8)
+    b = np.ascontiguousarray(planes2, dtype=np.float32).reshape(-1, 8)
+    out = np.full(max(1, a.shape[0]), -1, dtype=np.int32)
+    Tm = np.ascontiguousarray(T, dtype=np.float64).reshape(16) if T is not None else None
+    f = lib().orc_plane_assoc
+    f.restype = None
+    f(_fp(a, C.c_float), C.c_int(a.shape[0]), _fp(b, C.c_float), C.c_int(b.shape[0]), _fp(Tm, C.c_double), _fp(out, C.c_int32))
+    return out[: a.shape[0]]
+
+
 def icp(src4: np.ndarray, tgt4: np.ndarray, p: OrcParams, T_init=None, trace: bool = True):
     """Returns dict(T, norm, rmse, inliers, status, n_src, n_tgt, idx, d2, T_trace, sums_trace)."""
     N = p.width * p.height
@@ -108,7 +134,8 @@ def icp(src4: np.ndarray, tgt4: np.ndarray, p: OrcParams, T_init=None, trace: bo
                 T_trace=Ttr.reshape(-1, 4, 4) if trace else None, sums_trace=Str[:p.iterations] if trace else None)
 
 
-def nn_once(src4, tgt4, p: OrcParams, T=None, use_normals: bool = False, coarse: bool = False):
+def nn_once(src4, tgt4, p: OrcParams, T=None, use_normals=False, coarse: bool = False):
+    """use_normals: False / True (7x7-window normals) / 2 (per-plane normals, spec S2p)"""
     N = p.width * p.height
     src4 = np.ascontiguousarray(src4, dtype=np.float32)
     tgt4 = np.ascontiguousarray(tgt4, dtype=np.float32)
@@ -116,7 +143,7 @@ def nn_once(src4, tgt4, p: OrcParams, T=None, use_normals: bool = False, coarse:
     d2 = np.empty(N, dtype=np.float32)
     Ti = np.ascontiguousarray(T, dtype=np.float64).reshape(16) if T is not None else None
     ns = lib().orc_nn_once_ex(_fp(src4, C.c_float), _fp(tgt4, C.c_float), C.byref(p), _fp(Ti, C.c_double),
-                              C.c_int(1 if use_normals else 0), C.c_int(1 if coarse else 0), _fp(idx, C.c_int32), _fp(d2, C.c_float))
+                              C.c_int(int(use_normals)), C.c_int(1 if coarse else 0), _fp(idx, C.c_int32), _fp(d2, C.c_float))
     return idx, d2, ns
 
 
