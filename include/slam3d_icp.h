@@ -139,6 +139,13 @@ typedef struct slam3d_plane {
 
 typedef struct slam3d_icp_handle slam3d_icp_handle;
 
+/* ---- threading contract ---------------------------------------------------------------------
+ * A handle is used by ONE thread at a time (it is not internally locked).  DIFFERENT handles may be used from different threads
+ * concurrently, on different devices or on the same one (GraphicEndICP::multiPnPBatch runs one thread per handle; the reference
+ * itself is single-threaded and not re-entrant: process globals g_pParaReader / camera_*, src/ParameterReader.cpp:8-9).  Handles
+ * hold no process-global mutable state; the handles of one DEVICE share exactly one word of library-owned device memory -- the
+ * count of slam3d_icp_run runs in flight on that GPU, updated by device-side atomics only --, which shapes scheduling inside the
+ * search kernel (poll another block's pose or solve locally) and never a result: any interleaving gives the same bits. */
 /* ---- lifecycle --------------------------------------------------------------------------- */
 void        slam3d_icp_default_params(slam3d_icp_params *p);
 /* SLAM3D_E_INVALID also when width*height*(z_filter*sqrt(1+tan^2))^2 >= 2^28: the normal-equation totals (the integer Gram

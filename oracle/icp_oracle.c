@@ -677,7 +677,7 @@ static void apply_gates(const clist *src, const clist *tgt, const double *T, con
  * entries of the Gram matrix G = sum V V^T -- exact int64 sums, so neither the order of the summands nor their grouping
  * (one GPU wave per tile on the fp64 matrix cores, one atomic per block, any number of GPUs) changes a bit.
  *   point-to-plane   a = p' x n, b = n . (q - p')   (double, every operation individually rounded, in the order written)
- *                    V = ( rint(a 2^16) [3], rint(n 2^20) [3], rint(b 2^EB), 1 ),  EB = 20 - k with gate = m 2^k, 0.5 <= m < 1
+ *                    V = ( rint(a 2^16) [3], rint(n 2^20) [3], rint(b 2^EB), 1 ),  EB = 20 - min(k, 8) with gate = m 2^k, 0.5 <= m < 1
  *                    (|b| <= gate < 2^k, so |V6| <= 2^20; gate 0.10 m: EB = 23, 0.12 um)
  *   svd (Kabsch)     V = ( rint(p' 2^16) [3], rint(q 2^16) [3], 0, 1 )
  * rint = round to nearest, ties to even.  The 29 doubles of the trace / the solve are DERIVED from G (orc_derive_sums):
@@ -693,7 +693,9 @@ int orc_b_exponent(double max_corr_dist)
 {
     int k = 0;
     (void)frexp(max_corr_dist, &k);            /* max_corr_dist = m 2^k, 0.5 <= m < 1 */
-    return 20 - k;
+    /* |b| <= |q - p'| < 2^8 for any gate (every valid point lies within 90.5 m of the sensor): k is clamped at 8, so that a gate
+     * of kilometres (PCL's default is sqrt(DBL_MAX)) does not quantise the residual to metres */
+    return 20 - (k < 8 ? k : 8);
 }
 
 static inline int tri36(int i, int j) { return i * 8 - (i * (i - 1)) / 2 + (j - i); }   /* (i <= j) of the 8x8 upper triangle, row-major */

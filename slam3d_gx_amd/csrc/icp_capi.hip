@@ -83,6 +83,7 @@ struct slam3d_icp_handle {
     TileGrid tg;
     float4 *prevq = nullptr;
     int nn_slot = -1;             // this handle's entry of c_nn_static (icp_kernels.hpp)
+    int *dev_runs = nullptr;      // the device's run counter (device_state_take)
     float *tile_cum = nullptr;    // [maxB][ntiles] motion totals of the certificates (icp_kernels.hpp)
     float2 *slot_rec = nullptr;   // every slot's result after the last iteration of the tile search: (match, clearance) (icp_kernels.hpp); [maxB][nslots]
     bool cert_on = true;          // SLAM3D_CERT=0: developer knob, every iteration searches
@@ -93,6 +94,7 @@ struct slam3d_icp_handle {
     int nn_gx = 0, nn_gx_d = 0;             // k_nn_tiles_acc grid widths (multiples of 8): cooperative / throughput build
     float *tgtB = nullptr;        // BRUTE_MFMA: B-layout targets, f32 form [B][4][npad] floats / bf16 form [B][npad / 16][64] x 8 bytes
     bool valu_filter = false;     // BRUTE_VALU with the expanded-form filter in front of the canonical distances (SLAM3D_VALU_FILTER=1)
+    int mfma_split = 0;           // SLAM3D_MFMA_SPLIT (developer knob): target slices of the matrix-core scans, 0 = automatic
     bool mfma_bf16 = true;        // BRUTE_MFMA runs the bf16-split contraction (k_nn_mfma16); SLAM3D_MFMA_BF16=0: the f32 one (k_nn_mfma)
     unsigned int *qmax2 = nullptr; int npad = 0;
     // host
@@ -112,7 +114,7 @@ struct slam3d_icp_handle {
     unsigned long long *d_stamps = nullptr; unsigned int *d_stamp_seq = nullptr; int stamp_rows = 0, stamp_ring = 0;
     bool ran_profiled = false;
     bool ran = false; int last_B = 0;
-    bool run_counted = false;     // k_pair_init of the run being enqueued counted it into g_runs_in_flight; cleared once its last k_solve_acc is enqueued too
+    bool run_counted = false;     // k_pair_init of the run being enqueued counted it into the device's run counter; cleared once its last k_solve_acc is enqueued too
     int row0 = 0, row1 = 0; int dense_it = 0;
     std::string err;
 };
@@ -187,6 +189,37 @@ extern "C" const char *slam3d_strerror(int code)
 
 extern "C" const char *slam3d_last_error(const slam3d_icp_handle *h) { return h ? h->err.c_str() : ""; }
 
+// Per-DEVICE state owned by the library: the count of slam3d_icp_run runs in flight on the device, which the
+// head solve of the search kernel reads to decide between polling block 0's pose and solving locally (icp_kernels.hpp).  One word
+// of device memory per GPU, allocated with the first handle created on that GPU and freed with the last.  Multi-thread contract
+// (documented in include/slam3d_icp.h): a handle is used by one thread at a time; DIFFERENT handles -- on the same device or not
+// -- may be used from different threads concurrently (GraphicEndICP::multiPnPBatch runs one thread per handle).  The word is
+// shared by the handles of a device, is touched only by device-side atomics, and shapes speed, never a result.
+struct DeviceState { int *runs = nullptr; int refs = 0; };
+static std::mutex g_dev_mu;
+static std::unordered_map<int, DeviceState> g_dev;
+static int *device_state_take(int device)      // the caller has made `device` current
+{
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    DeviceState &d = g_dev[device];
+    if (!d.runs) {
+        if (hipMalloc((void **)&d.runs, sizeof(int)) != hipSuccess || hipMemset(d.runs, 0, sizeof(int)) != hipSuccess) {
+            (void)hipGetLastError();
+            if (d.runs) { (void)hipFree(d.runs); d.runs = nullptr; }
+            return nullptr;
+        }
+    }
+    d.refs += 1;
+    return d.runs;
+}
+static void device_state_give(int device)
+{
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    auto it = g_dev.find(device);
+    if (it == g_dev.end()) return;
+    if (--it->second.refs <= 0) { if (it->second.runs) (void)hipFree(it->second.runs); g_dev.erase(it); }
+}
+
 // entries of c_nn_static (the per-handle constants of the NN kernel): a process-wide free list
 static std::mutex g_nn_slot_mu;
 static bool g_nn_slot_used[NN_STATIC_SLOTS];
@@ -214,6 +247,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->d_stamps); F(h->d_stamp_seq);
     if (h->vox_done) (void)hipEventDestroy(h->vox_done);
     nn_slot_give(h->nn_slot); h->nn_slot = -1;
+    if (h->dev_runs) { device_state_give(h->p.device); h->dev_runs = nullptr; }
     F(h->dbg); F(h->prevq); F(h->slot_rec); F(h->tile_cum); F(h->perm_d); F(h->cost); F(h->tgtB); F(h->qmax2);
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->pin_res) (void)hipHostFree(h->pin_res);
@@ -264,6 +298,12 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
         // 64 (r 2^16)^2 < 2^51  <=>  r^2 < 2^13 (r < 90 m); the global totals of the n.n and a.n entries need N < 2^22 and N r < 2^26
         if (!(r2 < 8192.0) || !((double)p->width * p->height < 4194304.0) || !((double)p->width * p->height * sqrt(r2) < 67108864.0))
             return SLAM3D_E_INVALID;
+        // spec S2: the window moments C' = n S2 - S1 S1^T must be exact integers below 2^53: n^2 (r 2^16)^2 < 2^53 with n = window^2
+        // (7x7 at z_filter 7 m: 11 times below; a 9x9 window beyond ~17 m is refused, not computed inexactly -- ADVICE r4)
+        if (p->estimator != SLAM3D_EST_SVD) {
+            const double nw = (double)p->normal_window * p->normal_window;
+            if (!(nw * nw * r2 * 4294967296.0 < 9007199254740992.0)) return SLAM3D_E_INVALID;
+        }
     }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device < 0 || p->device >= ndev) return SLAM3D_E_NODEVICE;
@@ -278,10 +318,13 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     g.zmax = (float)p->z_filter;
     g.win_r = p->normal_window / 2; g.min_in = p->normal_min_inliers; g.in_dist = p->normal_inlier_dist;
     g.gate2 = (float)(p->max_corr_dist * p->max_corr_dist);
-    {   // spec S4: the residual component of a row vector is rint(b 2^eb), eb = 20 - k with max_corr_dist = m 2^k, 0.5 <= m < 1
+    {   // spec S4: the residual component of a row vector is rint(b 2^eb), eb = 20 - min(k, 8) with max_corr_dist = m 2^k, 0.5 <= m < 1.
+        // |b| <= |q - p'| < 2^8 whatever the gate (the range check above keeps every point within 90.5 m of the sensor), so a gate
+        // beyond 256 m must not coarsen the residual any further (with eb = 20 - k a gate of 1e6 m quantised b to metres,
+        // A^T b became 0, the pose never moved and the run still said OK; PCL's default gate is sqrt(DBL_MAX))
         int k = 0;
         (void)frexp(p->max_corr_dist, &k);
-        g.eb = 20 - k;
+        g.eb = 20 - (k < 8 ? k : 8);
         g.b_scale = ldexp(1.0, g.eb);
     }
     {   // projective window search: the constant of its radius bound, from the image corners' rays
@@ -332,6 +375,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     }
     if (nn_mode_of(h) == SLAM3D_NN_BRUTE_MFMA) {
         if (getenv("SLAM3D_MFMA_BF16")) h->mfma_bf16 = atoi(getenv("SLAM3D_MFMA_BF16")) != 0;            // developer knob
+        if (getenv("SLAM3D_MFMA_SPLIT")) h->mfma_split = std::max(1, std::min(64, atoi(getenv("SLAM3D_MFMA_SPLIT"))));
         A(dalloc(h->tgtB, (size_t)h->maxB * (h->mfma_bf16 ? 8 : 4) * h->npad)); A(dalloc(h->qmax2, (size_t)h->maxB));
     }
     A(dalloc(h->ccounts, (size_t)h->maxB * 4)); A(dalloc(h->ticket, (size_t)h->maxB));
@@ -392,12 +436,14 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
         st.Tcur = h->Tcur; st.corr = h->corr; st.cd2 = h->cd2; st.cost = h->cost; st.acc = h->acc; st.dbg = h->dbg;
         st.trace_T = h->trace_T; st.trace_S = h->trace_S; st.flags = h->flags; st.slot_rec = h->slot_rec; st.tile_cum = h->tile_cum;
         st.g = h->g; st.tg = tg; st.iters = iters; st.nsets = h->nsets;
+        h->dev_runs = device_state_take(p->device);
+        st.runs = h->dev_runs;
         h->nn_slot = nn_slot_take();
         // (through the handle's own stream: with hipMemcpyToSymbol -- a default-stream operation between the creation of one handle's
         // stream and the next -- four handles in flight reached 50 k it/s instead of 73 k, 1.7 launches resident instead of 3.0:
         // presumably two of their streams then shared one of the runtime's four hardware queues)
         NnStatic *sym = nullptr;
-        if (h->nn_slot < 0 || hipGetSymbolAddress((void **)&sym, HIP_SYMBOL(c_nn_static)) != hipSuccess ||
+        if (h->nn_slot < 0 || !h->dev_runs || hipGetSymbolAddress((void **)&sym, HIP_SYMBOL(c_nn_static)) != hipSuccess ||
             hipMemcpyAsync(sym + h->nn_slot, &st, sizeof st, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
             hipStreamSynchronize(h->stream) != hipSuccess) {
             free_all(h);
@@ -753,13 +799,13 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
             const int n = B - b0 < TINIT_ARGS ? B - b0 : TINIT_ARGS;
             memcpy(ti.T, T_init + (size_t)b0 * 16, sizeof(double) * 16 * n);
             hipLaunchKernelGGL(k_pair_init, dim3(n), dim3(256), 0, s, ti, 1, b0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters, h->nsets,
-                               stamp_ring_of(h, b0 == 0), (count_run && b0 == 0) ? 1 : 0);
+                               stamp_ring_of(h, b0 == 0), (count_run && b0 == 0) ? h->dev_runs : nullptr);
         }
     } else {
         TinitArgs ti;
         memset(&ti, 0, sizeof ti);
         hipLaunchKernelGGL(k_pair_init, dim3(B), dim3(256), 0, s, ti, 0, 0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters, h->nsets,
-                               stamp_ring_of(h), count_run);
+                               stamp_ring_of(h), count_run ? h->dev_runs : nullptr);
     }
     if (count_run) h->run_counted = true;
     if (g.pair_gate) hipLaunchKernelGGL(k_plane_assoc, dim3(B), dim3(64), 0, s, h->d_pairs, h->Tcur);      // (behind k_set_pairs and k_pair_init)
@@ -827,7 +873,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         // pairs).  Cooperative build: never -- on a stream of DISTINCT pairs the interleaved default ownership is as good
         // as the measured-cost deal and the 12 us of k_balance are saved: +4 % pipelined, +11 % at 1280x960 (round 1
         // measured the deal on one pair repeated, where the previous run's map was already this pair's).
-        if (dense && do_solve && it == std::min(n_coarse + 1, iters - 1))       // (the costs of a launch in which every tile took part)
+        if (dense && do_solve && iters > 1 && it == std::min(n_coarse + 1, iters - 1))       // (the costs of a launch in which every tile took part; a single-iteration run has no later launch to balance)
             hipLaunchKernelGGL(k_balance, dim3(B), dim3(1024), 0, s, h->cost, perm, tg, gx);
         if (e1) HIPCHK(h, hipEventRecord(e1, s));
     } else {
@@ -838,7 +884,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
             int msplit = ((h->mfma_bf16 ? 48 : 24) * 1024 + (h->N / MF_Q) * B - 1) / ((h->N / MF_Q) * B);
             if (msplit < 1) msplit = 1;
             if (msplit > 32) msplit = 32;
-            if (getenv("SLAM3D_MFMA_SPLIT")) msplit = std::max(1, std::min(64, atoi(getenv("SLAM3D_MFMA_SPLIT"))));      // developer knob
+            if (h->mfma_split > 0) msplit = h->mfma_split;                                                               // developer knob SLAM3D_MFMA_SPLIT (read at create)
             if (h->mfma_bf16)
                 hipLaunchKernelGGL(k_nn_mfma16, dim3((h->N + MF_Q - 1) / MF_Q, msplit, B), dim3(64), 0, s, h->d_pairs, h->src_c, h->tgt_c,
                                    reinterpret_cast<const uint2 *>(h->tgtB), h->qmax2, h->ccounts, h->prevq, h->Tcur, h->best, h->g, tg, h->npad,
@@ -880,12 +926,12 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         hipLaunchKernelGGL(k_solve_acc<0>, dim3(B), dim3(64), 0, s, h->acc, raw_out, h->Tcur, h->trace_T, h->trace_S, h->flags, h->d_pairs,
                            do_solve ? h->d_res : nullptr, it, iters, do_solve,
                            stamp_ring_of(h, do_solve != 0), iters + it,
-                           h->nsets, head ? it : 0, head ? 1 : 0, (counted_run && it == iters - 1) ? 1 : 0, h->g.eb);
+                           h->nsets, head ? it : 0, head ? 1 : 0, (counted_run && it == iters - 1) ? h->dev_runs : nullptr, h->g.eb);
     else
         hipLaunchKernelGGL(k_solve_acc<1>, dim3(B), dim3(64), 0, s, h->acc, raw_out, h->Tcur, h->trace_T, h->trace_S, h->flags, h->d_pairs,
                            do_solve ? h->d_res : nullptr, it, iters, do_solve,
                            stamp_ring_of(h, do_solve != 0), iters + it,
-                           h->nsets, 0, 0, (counted_run && it == iters - 1) ? 1 : 0, h->g.eb);
+                           h->nsets, 0, 0, (counted_run && it == iters - 1) ? h->dev_runs : nullptr, h->g.eb);
     HIPCHK(h, hipGetLastError());
     return SLAM3D_OK;
 }
@@ -915,7 +961,7 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
         // will not run.  Whatever failed -- a later launch of the preprocessing, the capture, the graph launch -- the stream is
         // out of capture mode by now (enqueue_iterations always ends a capture it began), so the correction can be enqueued
         // behind k_pair_init; a count that leaked would make every later head solve poll instead of solving locally.
-        if (h->run_counted) { hipLaunchKernelGGL(k_run_uncount, dim3(1), dim3(1), 0, s); (void)hipGetLastError(); h->run_counted = false; }
+        if (h->run_counted) { hipLaunchKernelGGL(k_run_uncount, dim3(1), dim3(1), 0, s, h->dev_runs); (void)hipGetLastError(); h->run_counted = false; }
         return rc;
     }
     h->run_counted = false;
@@ -1737,7 +1783,7 @@ extern "C" int slam3d_icp_dense_finish(slam3d_icp_handle *h, const int64_t last_
 
 // BASELINE config 5 inside the library: source rows sharded over the ranks of `comm`, ONE ncclAllReduce(SUM) per iteration
 // on the handle's own stream and nothing else between two NN launches (round 3): launch k accumulates this rank's rows into
-// accumulator set k, the all-reduce sums set k over the ranks in place (16 x 32 int64), and the head of launch k+1 solves
+// accumulator set k, the all-reduce sums set k over the ranks in place (16 x 40 int64), and the head of launch k+1 solves
 // -- the same integers, hence the same pose bits, on every rank (round 2: reduce launch -> all-reduce of 29 words -> solve
 // launch).  The svd estimator and SLAM3D_HEAD_SOLVE=0 keep that three-step form.  A rank that fails locally aborts ITS side of
 // the communicator (ncclCommAbort) and marks the slam3d_comm dead (every later call with it returns SLAM3D_E_COMM).  Whether the

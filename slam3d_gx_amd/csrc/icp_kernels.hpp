@@ -68,7 +68,10 @@ constexpr unsigned long long HEAD_EMPTY = 0x7ff8dead0badc0deull;     // a pose e
 // launch are VALU work the other alignments want (63 k it/s against 68 k polling).  So the blocks poll only while other
 // runs are in flight on the device: k_pair_init / the run's last k_solve_acc keep the count (slam3d_icp_run's launches
 // only).  A stale count (a run that died between the two) costs speed, never correctness.
-__device__ int g_runs_in_flight = 0;
+// Round 5: the count is NOT a module global any more but a word of per-DEVICE state that the library owns
+// (icp_capi.hip: device_state(): allocated with the first handle of a device, freed with the last, handed to every handle of that
+// device): `runs` below.  Contract: handles are used by one thread each; handles of one device may run on different threads --
+// the word is only ever touched by device-side atomics, it shapes scheduling (poll or solve), never a result.
 
 constexpr int STAMP_R = 16, STAMP_ROW = 2 * STAMP_R;
 struct StampRing { unsigned long long *rows; unsigned int *seq; int ring, rows_per_run; };
@@ -121,7 +124,7 @@ struct Geometry {
                                    // closer than (r + 0.49) * z / proj_c  (= fmax * sqrt(1 + amax^2 + bmax^2) * 1.001), DESIGN.md 5
     int estimator;
     float cert_m, cert_track;      // clearance certificates: margin added to every pruning radius / pose motion below which a launch tracks (CERT_M, CERT_TRACK_MOTION)
-    int eb;                        // spec S4: the residual component of a row vector is rint(b * 2^eb), eb = 20 - k with gate = m 2^k, 0.5 <= m < 1
+    int eb;                        // spec S4: the residual component of a row vector is rint(b * 2^eb), eb = 20 - min(k, 8) with gate = m 2^k, 0.5 <= m < 1
     double b_scale;                // 2^eb
     double fx, fy, cx, cy, factor, zf;
 };
@@ -534,10 +537,10 @@ struct TinitArgs { double T[TINIT_ARGS][16]; };
 __global__ __launch_bounds__(256) void k_pair_init(TinitArgs ti, int has_T, int b0, double *__restrict__ Tcur,
                                                   double *__restrict__ trace_T, int *__restrict__ flags,
                                                   long long *__restrict__ acc, unsigned int *__restrict__ ticket, int iters, int nsets,
-                                                  StampRing sr /* rows null: no stamps */, int count_run /* slam3d_icp_run: one more run in flight */)
+                                                  StampRing sr /* rows null: no stamps */, int *__restrict__ runs /* the device's run counter; non-null (slam3d_icp_run): one more run in flight */)
 {
     const int k = blockIdx.x, b = b0 + k, lane = threadIdx.x;
-    if (count_run && k == 0 && lane == 0) atomicAdd(&g_runs_in_flight, 1);
+    if (runs && k == 0 && lane == 0) atomicAdd(runs, 1);
     if (sr.rows && k == 0 && lane < 64) {       // launch stamps (opt-in, first wave): this run takes the next slot of the ring; start = min -> ~0, end = max -> 0
         const unsigned int run = (*sr.seq + 1u) % (unsigned int)sr.ring;
         unsigned long long *__restrict__ rows = sr.rows + (size_t)run * sr.rows_per_run * STAMP_ROW;
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(256) void k_pair_init(TinitArgs ti, int has_T, int 
 }
 
 // a run that was counted by k_pair_init but whose launches could not all be enqueued: take it out of the count again
-__global__ void k_run_uncount() { if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&g_runs_in_flight, -1); }
+__global__ void k_run_uncount(int *__restrict__ runs) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(runs, -1); }
 
 // stable raster-order stream compaction, one 1024-thread block per (pair, src|tgt).  Only the full
 // brute-force modes use these lists.  src w = SLOT id of the pixel, tgt w = pixel index.
@@ -1644,7 +1647,7 @@ constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (
 // instructions per wave for nothing.  Loads from constant memory are scalar, invariant and re-issued where needed instead.
 struct NnStatic {
     const double *Tcur; int *corr; float *cd2; int *cost; long long *acc; long long *dbg;
-    double *trace_T, *trace_S; int *flags; float2 *slot_rec; float *tile_cum;
+    double *trace_T, *trace_S; int *flags; float2 *slot_rec; float *tile_cum; int *runs;
     Geometry g; TileGrid tg; int iters, nsets;
 };
 constexpr int NN_STATIC_SLOTS = 256;
@@ -1783,7 +1786,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                 double *tsh = tot + 32;
                 bool have = false;
                 // head: 1 poll while other runs are in flight on the device, else solve locally; developer knobs: 2 never poll, 3 always
-                if (c != 0 && (head == 3 || (head == 1 && __hip_atomic_load(&g_runs_in_flight, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 1))) {
+                if (c != 0 && (head == 3 || (head == 1 && __hip_atomic_load(SH->runs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 1))) {
                     // lane l < 16 watches entry l of the row: every entry is ONE 8-byte agent-scope store of the publisher and was
                     // reset to HEAD_EMPTY (a NaN pattern no arithmetic produces) by k_pair_init, so each entry validates itself --
                     // no ordering between the stores is needed, hence no release / acquire fence (on gfx950 those write back and
@@ -2506,7 +2509,12 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
     if constexpr (GATED) {             // the optional S4g gates: their own instances, the production ones carry none of this
         SlotGates sg;
         const Rt m = load_rt_lds(head_T);
-        sg.resid2 = g.resid2; sg.min_ncos = g.min_ncos; sg.snrm = pp.snrm; sg.spix = max(pix, 0);
+        // (the slot's source pixel is read again here: kept live from step 1 across the drain it cost the gated cooperative instance two
+        // VGPR spills -- 12 B of scratch per lane; one 4-byte load per lane of an instance that gathers normals anyway)
+        int t_g = t, lane_g = lane;
+        asm volatile("" : "+s"(t_g), "+v"(lane_g));               // (opaque copies: the address must be formed HERE, not hoisted above the drain and spilled)
+        const int spix = has_tile ? __float_as_int(pp.srcT[(size_t)t_g * TILE_SLOTS + lane_g].w) : -1;
+        sg.resid2 = g.resid2; sg.min_ncos = g.min_ncos; sg.snrm = pp.snrm; sg.spix = max(spix, 0);
         sg.assoc = g.pair_gate ? pp.assoc : nullptr;
         sg.r[0] = m.r00; sg.r[1] = m.r01; sg.r[2] = m.r02; sg.r[3] = m.r10; sg.r[4] = m.r11; sg.r[5] = m.r12;
         sg.r[6] = m.r20; sg.r[7] = m.r21; sg.r[8] = m.r22;
@@ -2940,10 +2948,10 @@ __global__ __launch_bounds__(64) void k_solve_acc(long long *__restrict__ acc, l
                                                   int it, int iters, int do_solve, StampRing sring, int stamp_idx,
                                                   int nsets, int set /* which accumulator set of the pair: 0, or `it` after head-solved launches */,
                                                   int from_trace /* T_it from trace_T[it] (head-solved launches leave Tcur at T_0) */,
-                                                  int end_run /* the last launch of a slam3d_icp_run: one run less in flight */,
+                                                  int *__restrict__ end_run /* the device's run counter when this is the last launch of a slam3d_icp_run (one run less in flight), else null */,
                                                   int eb /* spec S4: exponent of the residual component */)
 {
-    if (end_run && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_runs_in_flight, -1);
+    if (end_run && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(end_run, -1);
     __shared__ double tot[32], Tsh[16];
     __shared__ long long Gs[NRAW];
     const int b = blockIdx.x, k = threadIdx.x;

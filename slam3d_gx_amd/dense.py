@@ -3,9 +3,9 @@
 Every rank holds the full target (tiles, boxes, normals) and the source rows
 shard.dense_row_range(height, world, rank).  Per iteration each rank runs the NN search and the
 normal-equation accumulation on its rows (slam3d_icp_dense_partial), the 36 partial Gram totals are
-all-reduced (the path's single exchange step: 232 bytes), and every rank solves the same 6x6 /
+all-reduced (the path's single exchange step: 36 int64 = 288 bytes; slam3d_icp_dense_run exchanges the 16 x 40 int64 accumulator set in place), and every rank solves the same 6x6 /
 3x3 system and updates T identically (slam3d_icp_dense_update).  Correspondences are unaffected by
-the sharding (each query still sees the whole target), and because the sums are int64 fixed point
+the sharding (each query still sees the whole target), and because the sums are exact int64 Gram totals
 (integer addition is associative) the pose is bit-identical to the 1-rank run for any sharding.
 """
 from __future__ import annotations

@@ -101,8 +101,16 @@ void GraphicEndICP::init(const string &param_file)
     // new keys, defaults when absent
     _params.iterations = _reader->GetInt("icp_iterations", 20);
     _params.max_corr_dist = _reader->GetDouble("icp_max_corr_dist", 0.10);
-    _params.estimator = (_reader->Has("icp_estimator") && _reader->GetPara("icp_estimator") == "svd") ? SLAM3D_EST_SVD
-                                                                                                       : SLAM3D_EST_POINT2PLANE;
+    // icp_estimator: point2plane (7x7-window normals) | svd | plane -- plane-ICP proper: the frames' planes give the normals, as the
+    // reference derives the pose from the planes it extracts per frame (src/GraphicEnd.cpp:158,168,557-659); with
+    // icp_plane_pair_gate: yes correspondences are kept only inside associated plane pairs (src/GraphicEnd.cpp:459-484,:572),
+    // icp_plane_only: yes drops the pixels on no plane from the targets
+    const string est_name = _reader->Has("icp_estimator") ? _reader->GetPara("icp_estimator") : string("point2plane");
+    _params.estimator = est_name == "svd" ? SLAM3D_EST_SVD : (est_name == "plane" ? SLAM3D_EST_PLANE : SLAM3D_EST_POINT2PLANE);
+    if (_params.estimator == SLAM3D_EST_PLANE) {
+        if (_reader->Has("icp_plane_pair_gate") && _reader->GetPara("icp_plane_pair_gate") == "yes") _params.plane_flags |= SLAM3D_PLANE_PAIR_GATE;
+        if (_reader->Has("icp_plane_only") && _reader->GetPara("icp_plane_only") == "yes") _params.plane_flags |= SLAM3D_PLANE_ONLY;
+    }
     _params.normal_window = _reader->GetInt("icp_normal_window", 7);
     // optional correspondence gates, off unless asked for:
     //   icp_plane_residual_gate: yes -> e^2 <= min_error_plane, the reference's own key and test (src/GraphicEnd.cpp~:484-489,
@@ -147,6 +155,11 @@ void GraphicEndICP::init(const string &param_file)
             cerr << "slam3d_icp_create (device " << d.device << ") failed: " << slam3d_strerror(rc) << endl;
             if (k == 0) exit(1);                                   // the reference exits on fatal config errors (:113)
             break;                                                 // fewer GPUs than asked for: go on with what there is
+        }
+        if (_params.estimator == SLAM3D_EST_PLANE) {     // the library segments with the reference's plane parameters (fixed seed: a frame's planes do not depend on who aligns it)
+            slam3d_seg_params sp = _seg;
+            sp.seed = 1;
+            (void)slam3d_icp_set_seg_params(d.icp, &sp);
         }
         d.first_frame = 2 * _max_batch;
         d.key.assign(_params.extra_frames, -1);

@@ -14,6 +14,8 @@ tests/test_oracle_math.py::test_pose_error_matches_the_reference_tool checks ora
 every parity test) against them.  Run in the build container only (the GPU box has no /root/reference):
     python tests/golden/make_pose_error_golden.py
 """
+import ast
+import hashlib
 import json
 import os
 import re
@@ -25,14 +27,44 @@ REF = "/root/reference/tools/evaluate_rpe.py"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+# The reference is untrusted input: before any of its text is executed, every extracted definition must parse to NOTHING but
+# arithmetic on its arguments and calls of a fixed set of numpy functions (exec() of extracted text runs with the
+# developer's privileges).  No imports, no attribute access outside numpy / numpy.linalg, no names beyond the whitelist, no
+# builtins at run time.  The SHA-256 of what was executed is recorded in the JSON.
+_ALLOWED_NODES = (ast.Module, ast.FunctionDef, ast.arguments, ast.arg, ast.Return, ast.Expr, ast.Constant, ast.Name, ast.Load, ast.Store,
+                  ast.Call, ast.Attribute, ast.BinOp, ast.UnaryOp, ast.Add, ast.Sub, ast.Mult, ast.Div, ast.USub, ast.Subscript, ast.Slice,
+                  ast.Tuple, ast.Assign, ast.keyword)
+_ALLOWED_NUMPY = {"dot", "trace", "arccos", "min", "max", "linalg", "inv", "norm"}
+_ALLOWED_NAMES = {"numpy", "min", "max"}
+
+
+def _vet(name, text):
+    tree = ast.parse(text)
+    if len(tree.body) != 1 or not isinstance(tree.body[0], ast.FunctionDef) or tree.body[0].name != name or tree.body[0].decorator_list:
+        raise SystemExit(f"{name}: expected exactly one plain function definition")
+    args = {a.arg for a in tree.body[0].args.args}
+    for node in ast.walk(tree):
+        if not isinstance(node, _ALLOWED_NODES):
+            raise SystemExit(f"{name}: {type(node).__name__} is not allowed in a reference function that gets executed")
+        if isinstance(node, ast.Attribute) and node.attr not in _ALLOWED_NUMPY:
+            raise SystemExit(f"{name}: attribute .{node.attr} is not on the whitelist")
+        if isinstance(node, ast.Name) and node.id not in _ALLOWED_NAMES | args:
+            raise SystemExit(f"{name}: name {node.id} is not on the whitelist")
+    return tree
+
+
 def reference_functions():
     src = open(REF).read()
-    ns = {"numpy": numpy}
+    ns = {"numpy": numpy, "__builtins__": {"min": min, "max": max}}
+    digest = hashlib.sha256()
     for name in ("ominus", "compute_distance", "compute_angle"):
         m = re.search(r"^def %s\(.*?(?=^def |\Z)" % name, src, re.S | re.M)
         if not m:
             raise SystemExit(f"{name} not found in {REF}")
-        exec(compile(m.group(0), REF, "exec"), ns)
+        # (doc strings are expressions of constants: allowed; a trailing comment block belongs to no statement)
+        exec(compile(_vet(name, m.group(0)), REF, "exec"), ns)
+        digest.update(m.group(0).encode())
+    ns["_sha256"] = digest.hexdigest()
     return ns
 
 
@@ -60,6 +92,7 @@ def main():
         cases.append({"A": A.reshape(16).tolist(), "B": B.reshape(16).tolist(),
                       "angle": float(E["compute_angle"](rel)), "distance": float(E["compute_distance"](rel))})
     json.dump({"source": "tools/evaluate_rpe.py: ominus, compute_angle, compute_distance (executed from /root/reference, not copied)",
+               "executed_source_sha256": E["_sha256"],
                "cases": cases}, open(os.path.join(HERE, "pose_error_golden.json"), "w"), indent=0)
     print(len(cases), "cases; angle range", min(c["angle"] for c in cases), max(c["angle"] for c in cases))
 

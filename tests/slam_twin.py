@@ -42,7 +42,11 @@ class Twin:
         self.h = capi.IcpHandle(capi.default_params(intr, iterations=self.c["icp_iterations"], min_inliers=self.c["icp_min_inliers"],
                                                     error_threshold=self.c["error_threshold"], max_batch=1,
                                                     max_plane_residual2=self.c.get("max_plane_residual2", 0.0),
-                                                    min_normal_cos=self.c.get("min_normal_cos", 0.0)))
+                                                    min_normal_cos=self.c.get("min_normal_cos", 0.0),
+                                                    estimator=self.c.get("estimator", 0), plane_flags=self.c.get("plane_flags", 0)))
+        if self.c.get("estimator", 0) == capi.EST_PLANE:      # GraphicEndICP hands the library parameters.yaml's plane keys, seed 1
+            self.h.set_seg_params(self.h.seg_params(distance_threshold=self.c.get("distance_threshold", 0.08), plane_percent=self.c.get("plane_percent", 0.2),
+                                                    max_planes=self.c.get("max_planes", 3), hypotheses=self.c.get("ransac_hypotheses", 64), seed=1))
         self.index = self.c["start_index"]
         self.lost = 0
         self.lc_state = self.c["loopclosure_seed"]

@@ -169,3 +169,48 @@ def test_gated_batch_and_resident_frames_in_both_roles(gpu_lib):
         assert np.array_equal(got[b], ro["idx"]), b
         assert np.array_equal(traces[b].reshape(-1, 4, 4), ro["T_trace"]), b
         assert res[b]["inliers"] == ro["inliers"]
+
+
+# ------------------------------------------------------------------------------------------------ the distance gate's range
+def test_b_exponent_is_clamped_for_large_gates():
+    """EB = 20 - k quantised the residual to metres for a gate of kilometres (PCL's default gate is
+    sqrt(DBL_MAX)), A^T b became 0 and the pose never moved while the run said OK.  |b| < 2^8 for any gate, so k is clamped at 8."""
+    import test_oracle_independent as R
+    L = O.lib()
+    L.orc_b_exponent.restype = int
+    import ctypes as C
+    for gate, want in ((0.10, 23), (0.5, 20), (1.0, 19), (100.0, 13), (255.0, 12), (256.0, 12), (1e6, 12), (1e300, 12), (1e-3, 29)):
+        assert L.orc_b_exponent(C.c_double(gate)) == want == R.b_exponent(gate), gate
+
+
+def test_a_huge_gate_still_moves_the_pose():
+    pr, s4, t4 = _pair(1000, 160, 120)
+    r = O.icp(s4, t4, O.params(pr.intr, iterations=10, nn_method=1, max_corr_dist=1e6))
+    rot, tr = O.pose_error(pr.T_gt, r["T"])
+    assert r["status"] == 0 and rot < 5e-3 and tr < 2e-2, (rot, tr)
+    assert O.pose_error(np.eye(4), r["T"])[0] > 1e-3          # it moved away from the identity it started at
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gate", [300.0, 1e6])
+def test_hip_with_a_huge_gate_equals_the_oracle(gpu_lib, gate):
+    from slam3d_gx_amd import capi
+    pr, s4, t4 = _pair(1000, 160, 120)
+    ro = O.icp(s4, t4, O.params(pr.intr, iterations=8, nn_method=1, max_corr_dist=gate))
+    with capi.IcpHandle(capi.default_params(pr.intr, iterations=8, max_corr_dist=gate)) as h:
+        rg = h.align(s4, t4)
+        Tt, St = h.get_trace(0)
+    assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:8], ro["sums_trace"])
+    assert rg["status"] == ro["status"] == 0 and rg["inliers"] == ro["inliers"]
+    assert O.pose_error(pr.T_gt, rg["T"])[1] < 2e-2
+
+
+@pytest.mark.gpu
+def test_create_refuses_window_moments_that_would_not_be_exact(gpu_lib):
+    """C' = n S2 - S1 S1^T is only an exact integer below 2^53 while n^2 (r 2^16)^2 < 2^53: a 9x9 window at 40 m is refused"""
+    from slam3d_gx_amd import capi
+    intr = synth.Intrinsics.scaled(160, 120)
+    with pytest.raises(capi.Slam3dError):
+        capi.IcpHandle(capi.default_params(intr, normal_window=9, normal_min_inliers=60, z_filter=40.0))
+    capi.IcpHandle(capi.default_params(intr, normal_window=9, normal_min_inliers=60, z_filter=7.0)).close()
+    capi.IcpHandle(capi.default_params(intr, normal_window=9, normal_min_inliers=60, z_filter=40.0, estimator=capi.EST_SVD)).close()

@@ -208,11 +208,11 @@ def test_hip_path_reproduces_the_scipy_only_goldens(gpu_lib):
         if c["width"] < 640:
             continue
         pr, s4, t4 = R._case(c["seed"], c["width"], c["height"], c.get("workload"))
-        with capi.IcpHandle(capi.default_params(pr.intr, estimator=c["estimator"], iterations=c["iterations"])) as h:
+        with capi.IcpHandle(capi.default_params(pr.intr, estimator=c["estimator"], iterations=c["iterations"], plane_flags=c.get("plane_flags", 0))) as h:
             for depth in (False, True):
                 r = h.align_depth_batch([pr.depth_src], [pr.depth_tgt])[0] if depth else h.align(s4, t4)
                 idx, _ = h.get_correspondences(0)
                 assert hashlib.sha256(idx.astype("<i4").tobytes()).hexdigest() == c["idx_sha256"], (c["seed"], c["width"], depth)
                 assert np.allclose(r["T_raw"], np.array(c["T_final"]), rtol=0, atol=1e-7) and r["inliers"] == c["inliers"]
         n += 1
-    assert n >= 8
+    assert n >= 12 and sum(1 for c in G["cases"] if c["estimator"] == 2 and c["width"] >= 640) >= 4      # round 5: + SLAM3D_EST_PLANE

@@ -716,6 +716,11 @@ def test_bench_single_gpu_line_has_the_contract_fields(gpu_lib):
     assert d["parity_vs_oracle"]["idx_mismatches"] == 0 and d["parity_vs_oracle"]["T_bit_identical"]
     assert d["config"]["gathered_pose_records"] == 6 and "workload" in d["config"]
     assert d["rccl_ranks"] == 1 and d["pose_exchange"].startswith("rccl")
+    assert d["config"]["coarse_iterations"] == 3 and d["config"]["noise_sigma_over_z2"] == 0.0012 and d["config"]["hole_block_px"] == 8
+    assert len(d["per_rank"]) == 1 and d["per_rank"][0]["h2d_GBps"] > 1 and d["per_rank"][0]["gather_us_per_step"] > 0
+    # the roofline's algorithmic bytes count the three coarse launches of the six at a quarter of the sources
+    r0 = d["config"]["n_src"][0], d["config"]["n_tgt"][0]
+    assert d["roofline"]["algorithmic_bytes_per_launch"] < 16 * 0.7 * 76800 + 24 * 76800
     ov = d["overlap"]
     assert ov["mean_resident_nn_kernels"] > 0 and ov["nn_launch_us_overlapped"]["mean"] > 0 and ov["in_flight"] == 4
     assert abs(ov["sum_nn_us_per_alignment"] / ov["mean_resident_nn_kernels"] - ov["per_alignment_wall_us_device_clock"]) < 1e-6 * ov["per_alignment_wall_us_device_clock"]
@@ -966,12 +971,14 @@ def test_config4_shape_eight_ranks_of_64_pairs_on_one_device(gpu_lib, tmp_path):
     d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 8 and d["value"] > 0 and d["scaling"] == "weak" and d["survey_8d"]["gpus"] == 8
     assert d["config"]["gathered_pose_records"] == 512 and d["config"]["pairs_per_launch"] == 64
+    assert d["config"]["coarse_iterations"] == 3 and d["config"]["synthetic_workload"].startswith("BASELINE.md section 4")
+    assert [r["rank"] for r in d["per_rank"]] == list(range(8)) and all(r["h2d_GBps"] > 0 and r["enqueue_us_per_alignment"] > 0 and r["gather_us_per_step"] > 0 for r in d["per_rank"])
     assert d["config"]["gathered_seeds"] == {"first": [1000, 1001], "last": [1510, 1511], "ascending": True}
     tab = json.load(open(dump))
     assert tab["seeds"] == list(range(1000, 1512)) and tab["world"] == 8 and tab["pairs_per_rank"] == 64
     assert all(s == 0 for s in tab["status"]), [i for i, s in enumerate(tab["status"]) if s][:8]
     for k in (0, 63, 64, 200, 383, 511):                          # both ends of rank blocks and interior pairs
-        pr, s4, t4 = _pair(1000 + k, 640, 480)
+        pr, s4, t4 = _pair(1000 + k, 640, 480, noise_sigma=0.0012, hole_block=8, hole_prob=0.25)      # bench.py's default workload: BASELINE.md section 4's
         ro = O.icp(s4, t4, O.params(pr.intr, iterations=20, nn_method=1))
         assert np.array_equal(np.array(tab["T"][k]).reshape(4, 4), ro["T_trace"][-1]), k
         assert tab["inliers"][k] == ro["inliers"], k

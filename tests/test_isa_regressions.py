@@ -89,6 +89,13 @@ def test_production_search_kernels_have_no_scratch_and_use_the_fp64_matrix_cores
         assert int(meta[n]["private_segment_fixed_size"]) == 0 and int(meta[n]["vgpr_spill_count"]) == 0, (n, meta[n])
         assert int(meta[n]["vgpr_count"]) <= 72
         assert bodies[n].count("v_mfma_f64_16x16x4") == 8, bodies[n].count("v_mfma_f64_16x16x4")
+    # round 5: EVERY instance of the search kernel -- the gated ones (spec S4g / S4p: what max_plane_residual2,
+    # min_normal_cos and the plane-pair gate run) and the instrumented ones too -- is free of scratch; the gated cooperative
+    # instance carried 12 B per lane until the source pixel was re-read in the epilogue instead of kept live across the drain
+    every = [n for n in meta if "k_nn_tiles_acc" in n]
+    assert len(every) == 6, every
+    for n in every:
+        assert int(meta[n]["private_segment_fixed_size"]) == 0 and int(meta[n]["vgpr_spill_count"]) == 0, (n, meta[n])
     mf = [n for n in bodies if "k_nn_mfmaE" in n]                                  # (Itanium names: 9k_nn_mfmaE... / 11k_nn_mfma16E...)
     assert len(mf) == 1 and bodies[mf[0]].count("v_mfma_f32_16x16x4") >= 64
     # the bf16-split form (round 4): 64+ v_mfma_f32_16x16x32_bf16 with the inline constant 0 as C, no scratch, and a loop head that

@@ -136,3 +136,52 @@ def test_sums_are_fixed_point_integers_and_order_free():
         q = S * unit
         assert np.array_equal(q, np.rint(q)) and np.abs(q).max() < 2.0 ** 62
         assert r1["inliers"] == int(S[-1, 27])
+
+
+BASELINE_MD = dict(noise_sigma=0.0012, hole_block=8, hole_prob=0.25)
+
+
+def _kinect_depth(name):
+    import os
+    from PIL import Image
+    return np.array(Image.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kinect", name))).astype(np.uint16)
+
+
+@pytest.mark.parametrize("workload", ["low_noise", "baseline_md"])
+def test_coarse_iterations_do_not_move_the_final_pose(workload):
+    """Spec S4c deviates from SURVEY.md App. C3 ("for each valid source i"): iterations 0-2 take a quarter of the sources.  The
+    deviation is BOUNDED here: after 20 iterations the pose of coarse_iterations = 3 and the pose of
+    coarse_iterations = 0 differ by at most 1e-4 rad / 1e-4 m -- the metric's own bar -- on seeds 1000..1003 under both synthetic
+    workloads (measured: <= 3.5e-6 rad / 4.7e-6 m)."""
+    kw = BASELINE_MD if workload == "baseline_md" else {}
+    worst = (0.0, 0.0)
+    for seed in (1000, 1001, 1002, 1003):
+        pr = synth.make_pair(seed, **kw)
+        s4 = synth.backproject_numpy(pr.depth_src, pr.intr); t4 = synth.backproject_numpy(pr.depth_tgt, pr.intr)
+        T = {c: O.icp(s4, t4, O.params(pr.intr, iterations=20, nn_method=1, coarse_iterations=c))["T_trace"][-1] for c in (0, 3)}
+        rot, tr = O.pose_error(T[0], T[3])
+        assert rot <= 1e-4 and tr <= 1e-4, (seed, rot, tr)
+        worst = (max(worst[0], rot), max(worst[1], tr))
+    assert worst[0] < 2e-5 and worst[1] < 2e-5, worst
+
+
+def test_coarse_iterations_on_the_reference_kinect_frames():
+    """The same bound on real frames: the perturbed self-alignments (which converge) end within 1e-4 rad / 1e-4 m whatever
+    coarse_iterations is; the wide-baseline pair dep1 -> dep2 does NOT converge in 20 iterations (no unique
+    answer from the identity) -- its two poses differ by less than the distance the pose still moves in its last iteration, which
+    is all that can be asked of a run that has no fixed point yet.  Both estimators."""
+    d1, d2 = _kinect_depth("exp1_dep_1.png"), _kinect_depth("exp1_dep_2.png")
+    intr = synth.Intrinsics()
+    Ti = synth.pose_from_seed(77, 2.0, 0.03)
+    for est in (0, 2):
+        for a, b, T0 in ((d1, d1, Ti), (d2, d2, Ti), (d1, d2, None)):
+            r = {}
+            for c in (0, 3):
+                p = O.params(intr, iterations=20, nn_method=1, coarse_iterations=c, estimator=est, plane_pair_gate=1 if est == 2 else 0)
+                r[c] = O.icp(O.backproject(a, p), O.backproject(b, p), p, T_init=T0)["T_trace"]
+            rot, tr = O.pose_error(r[0][-1], r[3][-1])
+            if T0 is not None:
+                assert rot <= 1e-4 and tr <= 1e-4, (est, rot, tr)
+            else:
+                srot, str_ = O.pose_error(r[3][-2], r[3][-1])
+                assert rot <= max(1e-4, 1.5 * srot) and tr <= max(1e-4, 3.0 * str_), (est, rot, tr, srot, str_)

@@ -115,8 +115,8 @@ def rows_point2plane(ps, sv, idx, tgt4, nrm4):
 
 
 def b_exponent(gate):
-    """spec S4 (round 4): EB = 20 - k with gate = m 2^k, 0.5 <= m < 1"""
-    return 20 - int(np.frexp(float(gate))[1])
+    """spec S4 (round 4; clamp: round 5): EB = 20 - min(k, 8) with gate = m 2^k, 0.5 <= m < 1"""
+    return 20 - min(int(np.frexp(float(gate))[1]), 8)
 
 
 def row_vectors(ps, sv, idx, tgt4, nrm4, estimator, gate):
@@ -282,6 +282,146 @@ def normals_numpy_full(c4, w=7, min_in=41, in_dist=0.01, band=32, zmax=7.0):
     return out, ratio
 
 
+# ------------------------------------------------------------------------------------------------ spec P1-P5 / S2p / S4p in numpy
+_GOLD = 0x9E3779B97F4A7C15
+_M64 = (1 << 64) - 1
+
+
+def _mix64(z):
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def segment_planes_numpy(c4, zmax=7.0, thr=0.08, percent=0.2, max_planes=3, hypotheses=64, seed=1, draws=32):
+    """Spec P1-P5 (DESIGN.md section 10; the pcl::SACSegmentation loop of src/GraphicEnd.cpp:353-430) written against the SPEC
+    with numpy: python integers for the counter-based draws, vectorised float32 consensus tests, int64 moments,
+    numpy.linalg.eigh for the refinement (the oracle: cyclic Jacobi).  -> (planes [n, 8] float32: a b c d cx cy cz count, labels [N])"""
+    P = c4.reshape(-1, 4)[:, :3].astype(np.float32)
+    n = P.shape[0]
+    ok = valid_mask(c4.reshape(-1, 4), zmax)
+    lab = np.where(ok, -1, -2).astype(np.int32)
+    n_valid = int(ok.sum())
+    remaining = n_valid
+    thr = np.float32(thr); percent = np.float32(percent)
+    planes = []
+    x, y, z = P[:, 0], P[:, 1], P[:, 2]
+    for r in range(max_planes):
+        if n_valid < 3 or not (float(remaining) > float(percent) * float(n_valid)):
+            break
+        H = []
+        for h in range(hypotheses):
+            st = (seed + _GOLD * (1 + r * 4096 + h)) & _M64
+            pick = []
+            for _ in range(draws):
+                if len(pick) == 3:
+                    break
+                st = (st + _GOLD) & _M64
+                pix = ((_mix64(st) >> 32) * n) >> 32
+                if lab[pix] != -1 or pix in pick[:2]:
+                    continue
+                pick.append(pix)
+            if len(pick) < 3:
+                H.append(None); continue
+            p0, p1, p2 = P[pick[0]], P[pick[1]], P[pick[2]]
+            a = p1 - p0; b = p2 - p0
+            one = lambda v: np.array([v], dtype=np.float32)
+            nx = fma32(one(a[1]), one(b[2]), -one(a[2] * b[1]))[0]
+            ny = fma32(one(a[2]), one(b[0]), -one(a[0] * b[2]))[0]
+            nz = fma32(one(a[0]), one(b[1]), -one(a[1] * b[0]))[0]
+            nn = fma32(one(nz), one(nz), fma32(one(ny), one(ny), one(nx * nx)))[0]
+            if not nn > np.float32(1e-16):
+                H.append(None); continue
+            dd = -fma32(one(nx), one(p0[0]), fma32(one(ny), one(p0[1]), one(nz * p0[2])))[0]
+            H.append((nx, ny, nz, dd, np.float32(thr * thr) * nn, p0))
+        un = lab == -1
+        xs, ys, zs = x[un], y[un], z[un]
+        def inl(hy, xs=xs, ys=ys, zs=zs):
+            nx, ny, nz, dd, t2, _ = hy
+            e = fma32(np.full_like(xs, nx), xs, fma32(np.full_like(xs, ny), ys, nz * zs)) + dd
+            return e * e <= t2
+        cnt = [int(inl(hy).sum()) if hy is not None else 0 for hy in H]
+        best = int(np.argmax(cnt))                      # first maximum: ties -> lowest h
+        if cnt[best] < 3:
+            break
+        hy = H[best]
+        m = inl(hy)
+        o = hy[5].astype(np.float64)
+        q = np.stack([np.rint((xs[m].astype(np.float64) - o[0]) * 65536.0), np.rint((ys[m].astype(np.float64) - o[1]) * 65536.0),
+                      np.rint((zs[m].astype(np.float64) - o[2]) * 65536.0)], axis=1).astype(np.int64)
+        S0 = len(q); S1 = q.sum(0); S2 = q.T @ q
+        inv = 1.0 / S0
+        mean = S1.astype(np.float64) * inv
+        C = S2.astype(np.float64) * inv - np.outer(mean, mean)
+        evals, evecs = np.linalg.eigh(C)
+        nv = evecs[:, 0] / np.linalg.norm(evecs[:, 0])
+        c = o + mean / 65536.0
+        d = -((nv[0] * c[0] + nv[1] * c[1]) + nv[2] * c[2])
+        if d < 0:
+            nv, d = -nv, -d
+        af, bf, cf, df = np.float32(nv[0]), np.float32(nv[1]), np.float32(nv[2]), np.float32(d)
+        e = fma32(np.full_like(xs, af), xs, fma32(np.full_like(xs, bf), ys, cf * zs)) + df
+        on = np.abs(e) <= thr
+        got = int(on.sum())
+        if got == 0:
+            break
+        idx_un = np.flatnonzero(un)
+        lab[idx_un[on]] = r
+        planes.append([af, bf, cf, df, np.float32(c[0]), np.float32(c[1]), np.float32(c[2]), np.float32(got)])
+        remaining -= got
+    return np.array(planes, dtype=np.float32).reshape(-1, 8), lab
+
+
+def plane_normals_numpy(c4, plane_only=False, seg=None, **kw):
+    """Spec S2p: a pixel labelled with plane r takes (a, b, c) of the plane, w = 1 + r; a pixel on no plane keeps its S2 window
+    normal with w = 0.75 (plane_only: nothing).  No oracle code: segment_planes_numpy + normals_numpy_full."""
+    planes, lab = segment_planes_numpy(c4, **(seg or {}))
+    H, W = c4.shape[:2]
+    out = np.zeros((H * W, 4), dtype=np.float32)
+    if not plane_only:
+        win = normals_numpy_full(c4, **kw)[0].reshape(-1, 4)
+        m = win[:, 3] > 0.5
+        out[m, :3] = win[m, :3]; out[m, 3] = 0.75
+    for r in range(len(planes)):
+        m = lab == r
+        out[m, :3] = planes[r, :3]; out[m, 3] = 1 + r
+    return out.reshape(H, W, 4), planes, lab
+
+
+def plane_assoc_numpy(P1, P2, T=None):
+    """Spec S4p: planes of frame 1 carried by T (n' = R n, d' = d - n'.t, sign d' >= 0), nearest plane of frame 2 on (a, b, c, d)"""
+    T = np.eye(4) if T is None else np.asarray(T, dtype=np.float64)
+    out = np.full(len(P1), -1, dtype=np.int32)
+    for i in range(len(P1)):
+        a, b, c, d = [float(v) for v in P1[i, :4]]
+        n = [(T[r, 0] * a + T[r, 1] * b) + T[r, 2] * c for r in range(3)]
+        dd = d - ((n[0] * T[0, 3] + n[1] * T[1, 3]) + n[2] * T[2, 3])
+        if dd < 0:
+            n, dd = [-v for v in n], -dd
+        m = np.array([*n, dd]).astype(np.float32)
+        best, bd = -1, np.float32(np.inf)
+        for j in range(len(P2)):
+            d2 = np.zeros(1, dtype=np.float32)
+            for k in range(4):
+                e = np.array([m[k] - P2[j, k]], dtype=np.float32)
+                d2 = fma32(e, e, d2)
+            if d2[0] < bd:
+                bd, best = d2[0], j
+        out[i] = best
+    return out
+
+
+def pair_gate_numpy(idx, snrm, tnrm, assoc):
+    """Spec S4p: a correspondence is kept iff the target pixel's plane is the one associated with the source pixel's plane
+    (label = int(normal.w) - 1; a pixel on no plane: -1, associated with -1)"""
+    ls = snrm.reshape(-1, 4)[:, 3].astype(np.int32) - 1
+    lt = tnrm.reshape(-1, 4)[:, 3].astype(np.int32) - 1
+    has = idx >= 0
+    want = np.where(ls >= 0, np.concatenate([assoc, [-1]])[np.where(ls >= 0, np.minimum(ls, len(assoc)), len(assoc))] if len(assoc) else -1, -1)
+    keep = has & (want == lt[np.where(has, idx, 0)])
+    return np.where(keep, idx, -1).astype(np.int32)
+
+
 # ------------------------------------------------------------------------------------------------ the tests
 BASELINE_MD = dict(noise_sigma=0.0012, hole_block=8, hole_prob=0.25)      # BASELINE.md section 4's synthetic workload
 
@@ -422,9 +562,69 @@ def test_independent_golden_hashes_are_reproduced_by_the_oracle():
     for c in G["cases"]:
         pr, s4, t4 = _case(c["seed"], c["width"], c["height"], c.get("workload"))
         for nn in (0, 1) if c["width"] <= 160 else (1,):
-            ro = O.icp(s4, t4, O.params(pr.intr, estimator=c["estimator"], iterations=c["iterations"], nn_method=nn))
+            fl = c.get("plane_flags", 0)
+            ro = O.icp(s4, t4, O.params(pr.intr, estimator=c["estimator"], iterations=c["iterations"], nn_method=nn, plane_pair_gate=fl & 1, plane_only=(fl >> 1) & 1))
             assert hashlib.sha256(ro["idx"].astype("<i4").tobytes()).hexdigest() == c["idx_sha256"], c
             # 20 chained lstsq solves against 20 chained LDL^T solves of the fixed-point sums: the pose agrees far below the
             # 1e-4 bar of the metric (1e-8 after <= 10 iterations; the real pair's long chain is looser)
             assert np.allclose(ro["T_trace"][-1], np.array(c["T_final"]), rtol=0, atol=1e-8 if c["iterations"] <= 10 else 1e-7), c
             assert ro["inliers"] == c["inliers"]
+
+
+@pytest.mark.parametrize("case", [(1000, (320, 240), {}), (1002, (640, 480), BASELINE_MD), (-2, (640, 480), {}), (-1, (640, 480), {})])
+def test_plane_normals_against_the_numpy_restatement(case):
+    """Spec S2p with no oracle code in the chain (python-integer draws, vectorised float32 consensus, int64 moments,
+    numpy.linalg.eigh refinement, whole-frame eigh window normals): the oracle's planes, labels and per-pixel normals must be
+    reproduced exactly -- the headline geometry, BASELINE.md's workload, and the reference's Kinect frames."""
+    seed, size, kw = case
+    if seed < 0:
+        from PIL import Image
+        name = "bin_dep_1.png" if seed == -2 else "exp1_dep_2.png"
+        intr = synth.Intrinsics()
+        t4 = synth.backproject_numpy(np.array(Image.open(os.path.join(HERE, "golden", "kinect", name))).astype(np.uint16), intr)
+    else:
+        pr = synth.make_pair(seed, *size, **kw)
+        intr = pr.intr
+        t4 = synth.backproject_numpy(pr.depth_tgt, intr)
+    p = O.params(intr, estimator=2)
+    got, planes, labels = O.plane_normals(t4, p)
+    want, planes_np, labels_np = plane_normals_numpy(t4)
+    assert len(planes) == len(planes_np) >= 1
+    assert np.array_equal(labels, labels_np), f"{(labels != labels_np).sum()} labels differ"
+    assert np.array_equal(planes[:, 7], planes_np[:, 7])
+    assert np.abs(planes[:, :7].astype(np.float64) - planes_np[:, :7]).max() < 1e-6
+    assert (planes[:, :4].view(np.uint32) != planes_np[:, :4].view(np.uint32)).sum() <= 1      # a last-bit difference needs a double within ~1e-15 of a float rounding boundary
+    assert np.array_equal(got[..., 3], want[..., 3])
+    assert ((got[..., :3] + np.float32(0)).view(np.uint32) != (want[..., :3] + np.float32(0)).view(np.uint32)).sum() <= 3 * (labels >= 0).sum() * ((planes[:, :3] != planes_np[:, :3]).any()) + 3
+
+
+@pytest.mark.parametrize("seed,size,gate", [(1000, (320, 240), 1), (1003, (160, 120), 0)])
+def test_every_iteration_of_the_plane_estimator_against_the_restatement(seed, size, gate):
+    """SLAM3D_EST_PLANE (spec S2p / S4p) at every iterate of the oracle: scipy NN over the targets that carry a (plane or window)
+    normal gives the oracle's indices, the plane-pair gate in numpy keeps the same correspondences, the integer Gram sums are
+    equal exactly and lstsq reproduces the next pose."""
+    pr, s4, t4 = _case(seed, *size)
+    iters = 6
+    p = O.params(pr.intr, estimator=2, iterations=iters, nn_method=1, plane_pair_gate=gate)
+    ro = O.icp(s4, t4, p)
+    tn, tpl, _ = plane_normals_numpy(t4)
+    sn, spl, _ = plane_normals_numpy(s4)
+    assoc = plane_assoc_numpy(spl, tpl)
+    assert np.array_equal(assoc, O.plane_assoc(np.asarray(spl), np.asarray(tpl)))
+    tgt_ok = valid_mask(t4) & (tn[..., 3] > 0.5)
+    for k in range(iters):
+        Tk = ro["T_trace"][k]
+        cz = is_coarse(k, iters, p.coarse_iterations)
+        idx, ps, sv = nn_scipy(s4, t4, tgt_ok, Tk, p.max_corr_dist, coarse=cz)
+        want, _, _ = O.nn_once(s4, t4, O.params(pr.intr, estimator=2, nn_method=0), T=Tk, use_normals=2, coarse=cz)
+        assert np.array_equal(idx, want), k
+        if gate:
+            idx = pair_gate_numpy(idx, sn, tn, assoc)
+        V = row_vectors(ps, sv, idx, t4, tn, 0, p.max_corr_dist)
+        assert np.array_equal(ro["sums_trace"][k], gram_sums(V, 0, p.max_corr_dist)), k
+        T_next = update_from_rows(V, 0, p.max_corr_dist, Tk)
+        assert np.allclose(T_next, ro["T_trace"][k + 1], rtol=0, atol=1e-9), k
+    idx_last = nn_scipy(s4, t4, tgt_ok, ro["T_trace"][iters - 1], p.max_corr_dist)[0]
+    if gate:
+        idx_last = pair_gate_numpy(idx_last, sn, tn, assoc)
+    assert np.array_equal(idx_last, ro["idx"])
