@@ -1647,7 +1647,7 @@ constexpr int NN_WAVES = 4;          // waves (= owned source tiles) per block (
 // instructions per wave for nothing.  Loads from constant memory are scalar, invariant and re-issued where needed instead.
 struct NnStatic {
     const double *Tcur; int *corr; float *cd2; int *cost; long long *acc; long long *dbg;
-    double *trace_T, *trace_S; int *flags; float2 *slot_rec; float *tile_cum; int *runs;
+    double *trace_T, *trace_S; int *flags; float2 *slot_rec; float *tile_cum;
     Geometry g; TileGrid tg; int iters, nsets;
 };
 constexpr int NN_STATIC_SLOTS = 256;
@@ -1663,7 +1663,9 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                                                         int head /* solve iteration it-1 at the head of this launch (see above) */,
                                                         int cert /* certify from it >= 1 on (needs `it` = the run's iteration and trace_T[it - 1]) */,
                                                         int cmode /* spec S4c: 1 = a coarse iteration (only the tiles of coarse_tile() take part), 2 = the first full iteration
-                                                                     after coarse ones (the other tiles hold no record yet), 0 = neither */)
+                                                                     after coarse ones (the other tiles hold no record yet), 0 = neither */,
+                                                        const int *__restrict__ dev_runs /* the device's count of runs in flight (a kernel argument: it arrives with the others, no
+                                                                     dependent load in front of the head's poll-or-solve decision) */)
 {
     // g / tg are used all over the kernel and stay with the compiler; the pointers and counts that only the head, the prologue
     // and the epilogue need are fetched right there through SS(): an opaque copy of the entry's address, so that the loads
@@ -1786,7 +1788,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                 double *tsh = tot + 32;
                 bool have = false;
                 // head: 1 poll while other runs are in flight on the device, else solve locally; developer knobs: 2 never poll, 3 always
-                if (c != 0 && (head == 3 || (head == 1 && __hip_atomic_load(SH->runs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 1))) {
+                if (c != 0 && (head == 3 || (head == 1 && __hip_atomic_load(dev_runs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 1))) {
                     // lane l < 16 watches entry l of the row: every entry is ONE 8-byte agent-scope store of the publisher and was
                     // reset to HEAD_EMPTY (a NaN pattern no arithmetic produces) by k_pair_init, so each entry validates itself --
                     // no ordering between the stores is needed, hence no release / acquire fence (on gfx950 those write back and
