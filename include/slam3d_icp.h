@@ -105,6 +105,12 @@ typedef struct slam3d_icp_params {
     int32_t plane_flags;            /* SLAM3D_PLANE_* (ABI 6; the padding word of ABI 5: 0 = neither)                    */
 } slam3d_icp_params;
 
+/* UNORGANIZED clouds (round 5): a handle created with height == 1 aligns point lists of up to `width` points -- the cloud readimage
+ * produces (PCD -> PassThrough -> VoxelGrid: 16,034 / 14,758 points for the reference's data/exp1 frames, src/GraphicEnd.cpp:283-295)
+ * and hands to the plane extraction (:158).  Views may then carry any width <= params.width (height 1); records beyond a view are
+ * invalid.  No camera model is assumed (fx .. cy unused; |x|, |y| <= z for the range check), there are no image windows or tiles:
+ * the estimator is SLAM3D_EST_SVD or SLAM3D_EST_PLANE with SLAM3D_PLANE_ONLY (SLAM3D_E_INVALID otherwise) and SLAM3D_NN_AUTO selects
+ * the full scan on the matrix cores.  Spec S4c's coarse iterations take the points whose index i satisfies (i / 8) mod 4 == 0. */
 /* a borrowed view of an organized cloud: `data` points at width*height records of
  * `stride_bytes` each whose first 12 bytes are float x,y,z (pcl::PointXYZRGBA is 32 B,
  * src/GraphicEnd.h:71-72; a packed float4 cloud is 16 B).  Invalid = NaN or z <= 0. */
@@ -291,6 +297,12 @@ int slam3d_device_count(void);
 int slam3d_voxel_grid(slam3d_icp_handle *h, const void *points16, int32_t n, float leaf, void *out16, int32_t *n_out);
 int slam3d_voxel_grid_device(slam3d_icp_handle *h, const void *d_points16, int32_t n, float leaf, void *d_out16,
                              int32_t *n_out, void *stream);
+/* The same filters on B clouds in ONE launch sequence (grid.y = cloud): the keyframes saveOutput merges (src/saveOutput.cpp:58-96), the
+ * loop-closure candidates of src/GraphicEnd.cpp:685-762.  d_points16 / d_out16: host arrays of B device pointers, n[b] <= width*height
+ * records in cloud b, room for n[b] records in d_out16[b]; n_out[b] = voxels of cloud b.  Stream semantics as slam3d_voxel_grid_device.
+ * The handle's voxel tables grow to B clouds at the first call that needs them (about 76 MB per 640x480 cloud). */
+int slam3d_voxel_grid_batch_device(slam3d_icp_handle *h, int32_t B, const void *const *d_points16, const int32_t *n, float leaf,
+                                   void *const *d_out16, int32_t *n_out, void *stream);
 /* ---- keyframe cloud merge of saveOutput (src/saveOutput.cpp:47-103): per keyframe VoxelGrid alone (:80-83), then
  * PassThrough z in [0, pass_z] and pcl::transformPointCloud by the keyframe's pose (:84-92); the merged cloud goes
  * through VoxelGrid alone once more (:97-100).  Same 16-byte records.  pass_transform writes NaN for dropped
@@ -380,6 +392,17 @@ void slam3d_shard_range(int32_t n, int32_t world, int32_t rank, int32_t *begin, 
  * same solve on every rank at the head of the next launch; no host synchronisation until the result.  Integer sums are
  * order-free: the pose is bit-identical for any world size. */
 int slam3d_icp_dense_run(slam3d_icp_handle *h, slam3d_comm *comm, const double *T_init, slam3d_icp_result *out);
+
+/* The same loop over a CALLER's transport (MPI, gloo, a test harness): `allreduce` must SUM `count` int64 at d_buf over the ranks,
+ * in place, ordered on hip_stream (or complete when it returns), and return 0.  rank / world shard the source rows.
+ * Failure protocol (both forms): a rank whose iteration k cannot be enqueued still takes part in the remaining exchanges, with
+ * zero totals and a failure word set, and returns its own error; every other rank completes its run and returns SLAM3D_E_COMM
+ * (T = Identity) -- nobody is left waiting in a collective for a rank that is gone.  Only when even those exchanges cannot be
+ * enqueued is the RCCL communicator aborted (the slam3d_comm is dead from then on).
+ * SLAM3D_DENSE_FAIL_AT=k in the environment makes this process fail in iteration k (failure injection for tests). */
+typedef int (*slam3d_allreduce_fn)(void *ctx, void *d_int64_buf, int64_t count, void *hip_stream);
+int slam3d_icp_dense_run_with(slam3d_icp_handle *h, int32_t rank, int32_t world, slam3d_allreduce_fn allreduce, void *ctx,
+                              const double *T_init, slam3d_icp_result *out);
 
 /* BASELINE configs 3/4: pairs are independent, the only exchange is the gather of the SE(3) pose records. */
 typedef struct slam3d_pose_record {      /* 160 bytes */

@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "slam3d_comm_last_error", "slam3d_shard_range", "slam3d_icp_dense_run", "slam3d_pose_gather_submit",
     "slam3d_pose_gather_collect", "slam3d_pose_gather", "slam3d_pose_record_from_result",
     "slam3d_plane_gate", "slam3d_device_count",
-    "slam3d_icp_set_seg_params", "slam3d_icp_get_frame_planes", "slam3d_icp_get_plane_assoc",
+    "slam3d_icp_set_seg_params", "slam3d_icp_get_frame_planes", "slam3d_icp_get_plane_assoc", "slam3d_voxel_grid_batch_device", "slam3d_icp_dense_run_with",
 ]
 COMM_ID_BYTES = 128
 
@@ -188,8 +188,8 @@ def _vp(a: Optional[np.ndarray]):
 
 def _cloud_view(a: np.ndarray, w: int, h: int) -> CloudView:
     """a: (H, W, k) float32 array with k*4-byte records (k >= 3), C-contiguous."""
-    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and a.shape[0] == h and a.shape[1] == w
-    return CloudView(a.ctypes.data, a.shape[2] * 4, w, h)
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and a.shape[0] == h and (a.shape[1] == w or (h == 1 and a.shape[1] <= w))
+    return CloudView(a.ctypes.data, a.shape[2] * 4, a.shape[1], h)       # (an unorganized handle, h == 1, takes clouds of any width <= w)
 
 
 class IcpHandle:
@@ -424,6 +424,16 @@ class IcpHandle:
                                                       C.byref(m), C.c_void_p(stream)), False)
         return m.value
 
+    def voxel_grid_batch_device(self, d_pts: Sequence[int], n: Sequence[int], d_out: Sequence[int], leaf: float = 0.03, stream: int = 0) -> list:
+        """B clouds resident on the device (pointers), one launch sequence; -> voxel count per cloud"""
+        B = len(d_pts)
+        pin = (C.c_void_p * B)(*[C.c_void_p(p) for p in d_pts])
+        pout = (C.c_void_p * B)(*[C.c_void_p(p) for p in d_out])
+        nn = (C.c_int32 * B)(*[int(x) for x in n])
+        m = (C.c_int32 * B)()
+        self._check(self.lib.slam3d_voxel_grid_batch_device(self._h, C.c_int32(B), pin, nn, C.c_float(leaf), pout, m, C.c_void_p(stream)), False)
+        return list(m)
+
     # ---- plane segmentation (f-2) ---------------------------------------------------------
     @staticmethod
     def seg_params(**kw) -> SegParams:
@@ -508,6 +518,22 @@ class IcpHandle:
         Ti = None if T_init is None else np.ascontiguousarray(T_init, dtype=np.float64).reshape(16)
         out = Result()
         self._check(self.lib.slam3d_icp_dense_run(self._h, comm._c if comm is not None else None, _vp(Ti), C.byref(out)))
+        return out.as_dict()
+
+    def dense_run_with(self, rank: int, world: int, allreduce, T_init=None) -> dict:
+        """slam3d_icp_dense_run over a caller's transport: allreduce(d_buf: int, count: int, stream: int) -> 0 must SUM `count`
+        int64 at device address d_buf over the ranks, in place (dense.host_staged_allreduce: through torch.distributed / gloo)"""
+        CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+        def thunk(ctx, d_buf, count, stream):
+            try:
+                return int(allreduce(int(d_buf or 0), int(count), int(stream or 0)))
+            except Exception:       # noqa: BLE001 -- an exception must not unwind through the C frames
+                return 1
+        cb = CB(thunk) if allreduce is not None else C.cast(None, CB)
+        Ti = None if T_init is None else np.ascontiguousarray(T_init, dtype=np.float64).reshape(16)
+        out = Result()
+        self._check(self.lib.slam3d_icp_dense_run_with(self._h, C.c_int32(rank), C.c_int32(world), cb, None, _vp(Ti), C.byref(out)))
         return out.as_dict()
 
     def dense_finish(self, last_sums: np.ndarray) -> dict:

@@ -76,7 +76,9 @@ struct slam3d_icp_handle {
     unsigned long long *vox_lkey = nullptr, *vox_gkey = nullptr;
     int *vox_lslot = nullptr, *vox_gslot = nullptr, *vox_m = nullptr, *vox_hist = nullptr;   // hist | start | cursor
     float4 *vox_out = nullptr;
-    int *pin_vox_m = nullptr, *pin_vox_m_dev = nullptr;     // host-mapped: k_voxel_scan writes the voxel count there
+    int *pin_vox_m = nullptr, *pin_vox_m_dev = nullptr;     // host-mapped: k_voxel_scan writes the voxel counts there (one per frame of a batch)
+    VoxFrame *vox_frames = nullptr;                         // a batch's (records, output, count) table
+    int vox_B = 0, vox_nblk = 0;                            // frames the tables are allocated for; insert blocks per frame
     bool vox_dirty = true;        // table / histogram need a full clear before the next voxel call
     hipEvent_t vox_done = nullptr; bool vox_done_valid = false;   // end of the last voxel call's launches: the next call (any stream) waits for it
     // 8x8-pixel tiles (slot order of the sums; target tiles + boxes for the pruned NN)
@@ -139,7 +141,10 @@ static inline StampRing stamp_ring_of(const slam3d_icp_handle *h, bool on = true
 
 static inline int nn_mode_of(const slam3d_icp_handle *h)
 {
-    return h->p.nn_mode == SLAM3D_NN_AUTO ? SLAM3D_NN_TILES : h->p.nn_mode;
+    // an UNORGANIZED cloud (height == 1: the voxel-grid output of readimage, src/GraphicEnd.cpp:283-295) has no image tiles to prune
+    // with: its search is the full scan on the matrix cores (16 k x 15 k points: a few microseconds)
+    if (h->p.nn_mode == SLAM3D_NN_AUTO) return h->p.height == 1 ? SLAM3D_NN_BRUTE_MFMA : SLAM3D_NN_TILES;
+    return h->p.nn_mode;
 }
 
 // rows / solve of the estimator: SLAM3D_EST_PLANE differs from POINT2PLANE only in where the target normals come from (spec S2p)
@@ -260,7 +265,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->fit_state);
     F(h->pl_state); F(h->pl_labels); F(h->pl_ptrs); F(h->f_planes); F(h->assoc);
     F(h->seg_state); F(h->seg_labels); F(h->seg_ptrs);
-    F(h->vox_mem); F(h->vox_lkey); F(h->vox_lslot); F(h->vox_m); F(h->vox_out); F(h->vox_gkey); F(h->vox_gslot); F(h->vox_hist);
+    F(h->vox_mem); F(h->vox_lkey); F(h->vox_lslot); F(h->vox_m); F(h->vox_out); F(h->vox_gkey); F(h->vox_gslot); F(h->vox_hist); F(h->vox_frames);
     if (h->pin_vox_m) (void)hipHostFree(h->pin_vox_m);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->pin_int) (void)hipHostFree(h->pin_int);
@@ -288,14 +293,19 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     if (p->estimator != SLAM3D_EST_POINT2PLANE && p->estimator != SLAM3D_EST_SVD && p->estimator != SLAM3D_EST_PLANE) return SLAM3D_E_INVALID;
     if (p->plane_flags & ~(SLAM3D_PLANE_PAIR_GATE | SLAM3D_PLANE_ONLY)) return SLAM3D_E_INVALID;
     if (p->plane_flags != 0 && p->estimator != SLAM3D_EST_PLANE) return SLAM3D_E_INVALID;
+    // unorganized clouds (height == 1) have no 7x7 image windows: svd, or the planes alone
+    if (p->height == 1 && p->width > 1 && (p->estimator == SLAM3D_EST_POINT2PLANE || (p->estimator == SLAM3D_EST_PLANE && !(p->plane_flags & SLAM3D_PLANE_ONLY))))
+        return SLAM3D_E_INVALID;
     if (p->nn_mode < SLAM3D_NN_AUTO || p->nn_mode > SLAM3D_NN_TILES) return SLAM3D_E_INVALID;
     if (!(p->max_corr_dist > 0.0) || !(p->z_filter > 0.0)) return SLAM3D_E_INVALID;
     {   // range of the int64 fixed-point sums (unit 2^-32): a term is at most |p|^2, all N slots may carry one.  With the
         // declared camera the farthest valid point is z_filter * sqrt(1 + tx^2 + ty^2); N * |p|^2 must stay below 2^28
         // (2^60 in fixed point; the plane moments about a sample point need the factor 4 of (2|p|)^2).  640x480 @ 7 m
         // is 11 times below, 1280x960 @ 7 m 2.8 times; a configuration beyond it is refused, not wrapped.
-        const double tx = (p->fx > 0.0) ? fmax(p->cx, p->width - 1 - p->cx) / p->fx : 1.0;
-        const double ty = (p->fy > 0.0) ? fmax(p->cy, p->height - 1 - p->cy) / p->fy : 1.0;
+        // (an unorganized cloud, height == 1, has no camera model: |x|, |y| <= z is assumed -- a 90 degree field of view)
+        const bool unorganized = p->height == 1;
+        const double tx = (p->fx > 0.0 && !unorganized) ? fmax(p->cx, p->width - 1 - p->cx) / p->fx : 1.0;
+        const double ty = (p->fy > 0.0 && !unorganized) ? fmax(p->cy, p->height - 1 - p->cy) / p->fy : 1.0;
         const double r2 = p->z_filter * p->z_filter * (1.0 + tx * tx + ty * ty);
         if (!((double)p->width * p->height * r2 < 268435456.0)) return SLAM3D_E_INVALID;
         // spec S4 (round 4): a wave's 64-row Gram sums run on the fp64 matrix cores and are converted with a 2^51 magic number:
@@ -414,7 +424,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     if (getenv("SLAM3D_HEAD_SOLVE")) h->head_solve = atoi(getenv("SLAM3D_HEAD_SOLVE"));
     if (getenv("SLAM3D_CERT")) h->cert_on = atoi(getenv("SLAM3D_CERT")) != 0;
     A(dalloc(h->slot_rec, (size_t)h->maxB * tg.nslots)); A(dalloc(h->tile_cum, (size_t)h->maxB * tg.ntiles));
-    A(dalloc(h->sums, (size_t)h->maxB * NRAW)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
+    A(dalloc(h->sums, (size_t)h->maxB * NRAW + 8)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
     A(dalloc(h->trace_T, (size_t)h->maxB * (iters + 1) * 16)); A(dalloc(h->trace_S, (size_t)h->maxB * iters * NSUMS));
     A(dalloc(h->d_pairs, (size_t)h->maxB));
     if (p->estimator == SLAM3D_EST_PLANE) {
@@ -490,10 +500,26 @@ static void frame_touch(slam3d_icp_handle *h, int f, const float4 *cloud, bool f
     fr.epoch += 1;                 // both roles are stale now
 }
 
+__global__ __launch_bounds__(256) void k_fill_invalid(float4 *__restrict__ dst, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float qnan = __int_as_float(0x7fc00000);
+    if (i < n) dst[i] = make_float4(qnan, qnan, qnan, 0.0f);
+}
+
 static int upload_cloud(slam3d_icp_handle *h, const slam3d_cloud_view *v, float4 *dst)
 {
-    if (!v || !v->data || v->width != h->p.width || v->height != h->p.height || v->stride_bytes < 12) return SLAM3D_E_INVALID;
-    const size_t N = h->N;
+    if (!v || v->stride_bytes < 12) return SLAM3D_E_INVALID;
+    // an unorganized handle (height == 1) takes clouds of ANY size up to its width: the records beyond the view are invalid
+    const bool ragged = h->p.height == 1 && v->height == 1 && v->width >= 0 && v->width <= h->p.width;
+    if (!ragged && (v->width != h->p.width || v->height != h->p.height)) return SLAM3D_E_INVALID;
+    if (!v->data && v->width > 0) return SLAM3D_E_INVALID;
+    const size_t N = ragged ? (size_t)v->width : (size_t)h->N;
+    if (ragged && N < (size_t)h->N) {
+        hipLaunchKernelGGL(k_fill_invalid, dim3((unsigned)((h->N - N + 255) / 256)), dim3(256), 0, h->stream, dst + N, (int)(h->N - N));
+        HIPCHK(h, hipGetLastError());
+        if (N == 0) return SLAM3D_OK;
+    }
     if (v->stride_bytes == 16) {
         HIPCHK(h, hipMemcpyAsync(dst, v->data, N * 16, hipMemcpyHostToDevice, h->stream));
         return SLAM3D_OK;
@@ -622,6 +648,27 @@ extern "C" int slam3d_icp_set_depth_device(slam3d_icp_handle *h, int32_t slot, c
     rc = slam3d_icp_frame_set_depth_device(h, 2 * slot + 1, d_tgt_depth);
     if (rc) return rc;
     return slam3d_icp_set_pair(h, slot, 2 * slot, 2 * slot + 1);
+}
+
+// dense mode's exchange step, transport-agnostic: SUM over the ranks of `count` int64 at d_buf, in place, ordered on `stream` (or
+// complete when the call returns); 0 = ok.  slam3d_icp_dense_run passes RCCL's ncclAllReduce, slam3d_icp_dense_run_with the caller's.
+struct DenseExchange { slam3d_allreduce_fn fn; void *ctx; };
+static int rccl_allreduce_thunk(void *ctx, void *d_buf, int64_t count, void *stream)
+{
+    slam3d_comm *c = static_cast<slam3d_comm *>(ctx);
+    if (!c || !c->comm) return 1;
+    const ncclResult_t nr = s3d::rccl().AllReduce(d_buf, d_buf, (size_t)count, ncclInt64, ncclSum, c->comm, (hipStream_t)stream);
+    if (nr != ncclSuccess) { c->err = std::string("ncclAllReduce failed: ") + s3d::rccl().GetErrorString(nr); return 1; }
+    return 0;
+}
+// word DENSE_POISON of an exchanged set (the Gram totals use words 0..35 of the 40): the number of ranks that FAILED locally in this
+// iteration or earlier.  A rank whose iteration k cannot be enqueued keeps taking part in the remaining exchanges with zero totals
+// and this word set, so no peer is left waiting in a collective; every rank then sees a non-zero word and returns SLAM3D_E_COMM.
+constexpr int DENSE_POISON = 36;
+__global__ void k_dense_poison(long long *__restrict__ set, int n)
+{
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k < n) set[k] = k == DENSE_POISON ? 1 : 0;
 }
 
 // the launches of one segmentation pass over B frames (spec P1-P5): nothing returns to the host.  ptrs_dev[b] = cloud of frame b,
@@ -842,7 +889,7 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
 #endif
 static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int it, int do_solve,
                              long long *raw_out = nullptr, int balance = 0, int first = 0, int counted_run = 0,
-                             slam3d_comm *exchange = nullptr /* dense mode: all-reduce this iteration's accumulator set in place */,
+                             const DenseExchange *exchange = nullptr /* dense mode: all-reduce this iteration's accumulator set in place */,
                              bool *used_head = nullptr)
 {
     const TileGrid &tg = h->tg;
@@ -920,8 +967,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         // integers, whose replica sum is the global total: the head of the next launch (or the final k_solve_acc) then solves
         // the identical system on every rank.  ONE exchange per iteration, no reduction or solve launch beside it.
         long long *set = h->acc + (size_t)it * ACC_R * ACC_STRIDE;
-        const ncclResult_t nr = s3d::rccl().AllReduce(set, set, (size_t)ACC_R * ACC_STRIDE, ncclInt64, ncclSum, exchange->comm, s);
-        if (nr != ncclSuccess) { h->err = std::string("ncclAllReduce failed: ") + s3d::rccl().GetErrorString(nr); return SLAM3D_E_COMM; }
+        if (exchange->fn(exchange->ctx, set, (int64_t)ACC_R * ACC_STRIDE, (void *)s) != 0) { h->err = "dense mode: the all-reduce of an iteration's totals failed"; return SLAM3D_E_COMM; }
     }
     if (head && it < iters - 1) {
         // solved at the head of the next NN launch; only the run's last iteration keeps its k_solve_acc (result record)
@@ -1389,97 +1435,168 @@ extern "C" int slam3d_device_count(void)
 }
 
 // ------------------------------------------------------------------------------ frame ingestion filters (f-1)
-static int vox_alloc(slam3d_icp_handle *h)
+static void vox_free(slam3d_icp_handle *h)
 {
-    if (h->vox_mem) return SLAM3D_OK;
+    auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    F(h->vox_mem); F(h->vox_lkey); F(h->vox_lslot); F(h->vox_m); F(h->vox_out); F(h->vox_gkey); F(h->vox_gslot); F(h->vox_hist); F(h->vox_frames);
+    if (h->pin_vox_m) { (void)hipHostFree(h->pin_vox_m); h->pin_vox_m = nullptr; }
+    h->vox_B = 0;
+}
+
+// tables for B frames per launch sequence (a later, larger batch re-allocates: nothing of a call survives it -- the tables are
+// self-cleaning).  Per frame at 640x480: 64 MB of slots (every point its own voxel still fits), 12 MB of lists and rows.
+static int vox_alloc(slam3d_icp_handle *h, int B = 1)
+{
+    if (h->vox_mem && B <= h->vox_B) return SLAM3D_OK;
+    if (h->vox_mem) {
+        if (h->vox_done_valid) { (void)hipEventSynchronize(h->vox_done); h->vox_done_valid = false; }
+        vox_free(h);
+    }
     int cap = 1024;
     while (cap < h->N) cap <<= 1;                         // every point its own voxel still fits; typical load ~ 0.1
     // insert blocks: runs of 256 records, or 16x16 tiles of the organized image (ragged edges need a few more)
     const int nblk = std::max((h->N + VOX_BLOCK - 1) / VOX_BLOCK, ((h->p.width + VOX_TW - 1) / VOX_TW) * ((h->p.height + VOX_TW - 1) / VOX_TW));
-    if (hipMalloc((void **)&h->vox_mem, (size_t)cap * sizeof(VoxSlot)) != hipSuccess ||
-        hipMalloc((void **)&h->vox_lkey, sizeof(unsigned long long) * (size_t)nblk * VOX_BLOCK) != hipSuccess ||
-        hipMalloc((void **)&h->vox_lslot, sizeof(int) * (size_t)nblk * VOX_BLOCK) != hipSuccess ||
-        hipMalloc((void **)&h->vox_m, sizeof(int) * (size_t)(nblk + 1)) != hipSuccess ||            // [0] kept-count of pass_transform, [1..] claims per insert block
-        hipMalloc((void **)&h->vox_gkey, sizeof(unsigned long long) * h->N) != hipSuccess ||
-        hipMalloc((void **)&h->vox_gslot, sizeof(int) * h->N) != hipSuccess ||
-        hipMalloc((void **)&h->vox_hist, sizeof(int) * (3 * VOX_BINS + 16 + 2 * VOX_SCAN_BLOCKS)) != hipSuccess ||
+    const size_t Bz = (size_t)B;
+    if (hipMalloc((void **)&h->vox_mem, Bz * cap * sizeof(VoxSlot)) != hipSuccess ||
+        hipMalloc((void **)&h->vox_lkey, sizeof(unsigned long long) * Bz * nblk * VOX_BLOCK) != hipSuccess ||
+        hipMalloc((void **)&h->vox_lslot, sizeof(int) * Bz * nblk * VOX_BLOCK) != hipSuccess ||
+        hipMalloc((void **)&h->vox_m, sizeof(int) * Bz * (nblk + 1)) != hipSuccess ||            // per frame: [0] kept-count of pass_transform, [1..] claims per insert block
+        hipMalloc((void **)&h->vox_gkey, sizeof(unsigned long long) * Bz * h->N) != hipSuccess ||
+        hipMalloc((void **)&h->vox_gslot, sizeof(int) * Bz * h->N) != hipSuccess ||
+        hipMalloc((void **)&h->vox_hist, sizeof(int) * Bz * VOX_HIST_INTS) != hipSuccess ||
         hipMalloc((void **)&h->vox_out, sizeof(float4) * h->N) != hipSuccess ||
-        hipHostMalloc((void **)&h->pin_vox_m, sizeof(int), hipHostMallocMapped) != hipSuccess ||
+        hipMalloc((void **)&h->vox_frames, sizeof(VoxFrame) * Bz) != hipSuccess ||
+        hipHostMalloc((void **)&h->pin_vox_m, sizeof(int) * Bz, hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer((void **)&h->pin_vox_m_dev, h->pin_vox_m, 0) != hipSuccess) {
         (void)hipGetLastError();
+        vox_free(h);
         return SLAM3D_E_NOMEM;
     }
     h->vox.slot = reinterpret_cast<VoxSlot *>(h->vox_mem);
     h->vox.cap = cap;
+    h->vox_B = B;
+    h->vox_nblk = nblk;
     h->vox_dirty = true;                                  // first use: slots and histogram are cleared once
     return SLAM3D_OK;
 }
 
-static int voxel_grid_impl(slam3d_icp_handle *h, const void *d_points16, int32_t n, float leaf, float zmin, float zmax, void *d_out16,
-                           int32_t *n_out, void *stream)
+static VoxLayout vox_layout(const slam3d_icp_handle *h)
 {
-    if (!h || !d_points16 || !d_out16 || !n_out || n < 0 || n > h->N || !(leaf > 0.0f)) return SLAM3D_E_INVALID;
+    VoxLayout L;
+    L.t = h->vox;
+    L.lkey = h->vox_lkey; L.lslot = h->vox_lslot; L.bcount = h->vox_m; L.blk_stride = h->vox_nblk;
+    L.hist = h->vox_hist; L.hist_stride = VOX_HIST_INTS;
+    L.gkey = h->vox_gkey; L.gslot = h->vox_gslot; L.g_stride = h->N;
+    L.m_host = h->pin_vox_m_dev;
+    return L;
+}
+
+constexpr int VOXF_ARGS = 128;
+struct VoxFrameArgs { VoxFrame f[VOXF_ARGS]; };
+__global__ void k_set_voxframes(VoxFrame *__restrict__ dst, VoxFrameArgs a, int n)
+{
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = a.f[threadIdx.x];
+}
+
+// PassThrough z in [zmin, zmax] + VoxelGrid(leaf) of B frames in ONE launch sequence (grid.y = frame).  frames[b] = (records, output,
+// count); B == 1: the record travels as a kernel argument.  n_out[b] on the host when the call returns; the records follow in
+// stream order (stream != NULL) or are complete (stream == NULL: the handle's stream, drained).
+static int voxel_grid_impl(slam3d_icp_handle *h, int B, const VoxFrame *frames, float leaf, float zmin, float zmax, int32_t *n_out, void *stream)
+{
+    if (!h || !frames || !n_out || B < 1 || B > 4096 || !(leaf > 0.0f)) return SLAM3D_E_INVALID;
+    int nmax = 0;
+    bool all_full = true;
+    for (int b = 0; b < B; ++b) {
+        if (frames[b].n < 0 || frames[b].n > h->N || (frames[b].n > 0 && (!frames[b].pts || !frames[b].out))) return SLAM3D_E_INVALID;
+        nmax = std::max(nmax, frames[b].n);
+        all_full = all_full && frames[b].n == h->N;
+        n_out[b] = 0;
+    }
     HIPCHK(h, hipSetDevice(h->p.device));
-    int rc = vox_alloc(h);
+    int rc = vox_alloc(h, B);
     if (rc) return rc;
-    *n_out = 0;
-    if (n == 0) return SLAM3D_OK;
+    if (nmax == 0) return SLAM3D_OK;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    const VoxTable &t = h->vox;
     // The handle's tables (hash slots, histogram, claim lists) serve one call at a time.  With a caller's stream a call returns
     // as soon as the count is known, its scatter and rank launches still queued: whatever stream the NEXT call runs on first
     // waits for the end of those launches (two streams raced on the tables).
     if (!h->vox_done) HIPCHK(h, hipEventCreateWithFlags(&h->vox_done, hipEventDisableTiming));
     if (h->vox_done_valid) HIPCHK(h, hipStreamWaitEvent(s, h->vox_done, 0));
     if (h->vox_dirty) {      // allocation, or an earlier call failed half way: from then on every call cleans up after itself
-        hipLaunchKernelGGL(k_voxel_clear, dim3((t.cap + VOX_BLOCK - 1) / VOX_BLOCK), dim3(VOX_BLOCK), 0, s, t);
-        HIPCHK(h, hipMemsetAsync(h->vox_hist, 0, sizeof(int) * (3 * VOX_BINS + 16 + 2 * VOX_SCAN_BLOCKS), s));     // histogram AND the scan ticket
+        hipLaunchKernelGGL(k_voxel_clear, dim3((h->vox.cap + VOX_BLOCK - 1) / VOX_BLOCK, h->vox_B), dim3(VOX_BLOCK), 0, s, h->vox);
+        HIPCHK(h, hipMemsetAsync(h->vox_hist, 0, sizeof(int) * (size_t)h->vox_B * VOX_HIST_INTS, s));     // histograms AND the scan tickets
     }
     h->vox_dirty = true;     // until this call has run to its end
-    int *start = h->vox_hist + VOX_BINS, *cursor = start + VOX_BINS + 8, *btot = cursor + VOX_BINS, *boff = btot + VOX_SCAN_BLOCKS,
-        *ticket = boff + VOX_SCAN_BLOCKS, *bcount = h->vox_m + 1;
+    const VoxLayout L = vox_layout(h);
+    const VoxFrame *d_frames = nullptr;
+    if (B > 1) {
+        for (int b0 = 0; b0 < B; b0 += VOXF_ARGS) {
+            VoxFrameArgs a;
+            const int n = std::min(VOXF_ARGS, B - b0);
+            memcpy(a.f, frames + b0, sizeof(VoxFrame) * n);
+            hipLaunchKernelGGL(k_set_voxframes, dim3(1), dim3(VOXF_ARGS), 0, s, h->vox_frames + b0, a, n);
+        }
+        d_frames = h->vox_frames;
+    }
     // an organized cloud (all width x height records present) is cut into 16x16-pixel tiles, anything else into runs of 256
-    const bool org = n == h->N;
-    const int nblk = org ? ((h->p.width + VOX_TW - 1) / VOX_TW) * ((h->p.height + VOX_TW - 1) / VOX_TW) : (n + VOX_BLOCK - 1) / VOX_BLOCK;
-    if (org) hipLaunchKernelGGL(k_voxel_insert<true>, dim3(nblk), dim3(VOX_BLOCK), 0, s, static_cast<const float4 *>(d_points16), n, h->p.width,
-                                h->p.height, 1.0f / leaf, zmin, zmax, t, h->vox_lkey, h->vox_lslot, bcount, h->vox_hist);
-    else hipLaunchKernelGGL(k_voxel_insert<false>, dim3(nblk), dim3(VOX_BLOCK), 0, s, static_cast<const float4 *>(d_points16), n, h->p.width,
-                            h->p.height, 1.0f / leaf, zmin, zmax, t, h->vox_lkey, h->vox_lslot, bcount, h->vox_hist);
-    *(volatile int *)h->pin_vox_m = -1;
-    hipLaunchKernelGGL(k_voxel_scan, dim3(VOX_SCAN_BLOCKS), dim3(1024), 0, s, h->vox_hist, start, cursor, btot, boff, ticket, h->pin_vox_m_dev);
-    hipLaunchKernelGGL(k_voxel_scatter, dim3(nblk), dim3(VOX_BLOCK), 0, s, h->vox_lkey, h->vox_lslot, bcount, start, boff, cursor, h->vox_gkey,
-                       h->vox_gslot);
-    hipLaunchKernelGGL(k_voxel_rank, dim3(nblk), dim3(VOX_BLOCK), 0, s, t, h->vox_gkey, h->vox_gslot, start, boff, static_cast<float4 *>(d_out16));
+    const bool org = all_full;
+    const int nblk = org ? ((h->p.width + VOX_TW - 1) / VOX_TW) * ((h->p.height + VOX_TW - 1) / VOX_TW) : (nmax + VOX_BLOCK - 1) / VOX_BLOCK;
+    if (org) hipLaunchKernelGGL(k_voxel_insert<true>, dim3(nblk, B), dim3(VOX_BLOCK), 0, s, frames[0], d_frames, h->p.width, h->p.height, 1.0f / leaf, zmin, zmax, L);
+    else hipLaunchKernelGGL(k_voxel_insert<false>, dim3(nblk, B), dim3(VOX_BLOCK), 0, s, frames[0], d_frames, h->p.width, h->p.height, 1.0f / leaf, zmin, zmax, L);
+    for (int b = 0; b < B; ++b) ((volatile int *)h->pin_vox_m)[b] = -1;
+    hipLaunchKernelGGL(k_voxel_scan, dim3(VOX_SCAN_BLOCKS, B), dim3(1024), 0, s, L);
+    hipLaunchKernelGGL(k_voxel_scatter, dim3(nblk, B), dim3(VOX_BLOCK), 0, s, L);
+    hipLaunchKernelGGL(k_voxel_rank, dim3(nblk, B), dim3(VOX_BLOCK), 0, s, frames[0], d_frames, L);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->vox_done, s));
     h->vox_done_valid = true;
     if (stream) {
-        // A caller's stream: the records are ready IN STREAM ORDER, and the call returns as soon as the count is known --
-        // k_voxel_scan writes it into host-mapped memory while the scatter and rank launches are still queued behind it.
-        int m = -1;
-        for (unsigned spins = 1; (m = *(volatile int *)h->pin_vox_m) < 0; ++spins) {
-            if ((spins & 0x3ff) != 0) continue;
-            const hipError_t q = hipStreamQuery(s);                 // a failed launch must not leave us spinning
-            if (q == hipErrorNotReady) continue;
-            HIPCHK(h, q);
-            m = *(volatile int *)h->pin_vox_m;
-            if (m < 0) { h->err = "voxel grid: the stream drained without a count"; return SLAM3D_E_HIP; }
-            break;
+        // A caller's stream: the records are ready IN STREAM ORDER, and the call returns as soon as the counts are known --
+        // k_voxel_scan writes them into host-mapped memory while the scatter and rank launches are still queued behind it.
+        for (int b = 0; b < B; ++b) {
+            int m = -1;
+            for (unsigned spins = 1; (m = ((volatile int *)h->pin_vox_m)[b]) < 0; ++spins) {
+                if ((spins & 0x3ff) != 0) continue;
+                const hipError_t q = hipStreamQuery(s);                 // a failed launch must not leave us spinning
+                if (q == hipErrorNotReady) continue;
+                HIPCHK(h, q);
+                m = ((volatile int *)h->pin_vox_m)[b];
+                if (m < 0) { h->err = "voxel grid: the stream drained without a count"; return SLAM3D_E_HIP; }
+                break;
+            }
+            n_out[b] = m;
         }
-        *n_out = m;
     } else {
-        HIPCHK(h, hipStreamSynchronize(s));      // the voxel count is in host-mapped memory by now (written by k_voxel_scan)
-        *n_out = *(volatile int *)h->pin_vox_m;
+        HIPCHK(h, hipStreamSynchronize(s));      // the voxel counts are in host-mapped memory by now (written by k_voxel_scan)
+        for (int b = 0; b < B; ++b) n_out[b] = ((volatile int *)h->pin_vox_m)[b];
     }
     h->vox_dirty = false;
     return SLAM3D_OK;
+}
+
+static int voxel_grid_one(slam3d_icp_handle *h, const void *d_points16, int32_t n, float leaf, float zmin, float zmax, void *d_out16,
+                          int32_t *n_out, void *stream)
+{
+    if (!h || !d_points16 || !d_out16 || !n_out || n < 0 || n > h->N) return SLAM3D_E_INVALID;
+    VoxFrame f = { static_cast<const float4 *>(d_points16), static_cast<float4 *>(d_out16), n, 0 };
+    return voxel_grid_impl(h, 1, &f, leaf, zmin, zmax, n_out, stream);
 }
 
 extern "C" int slam3d_voxel_grid_device(slam3d_icp_handle *h, const void *d_points16, int32_t n, float leaf, void *d_out16,
                                         int32_t *n_out, void *stream)
 {
     if (!h) return SLAM3D_E_INVALID;
-    return voxel_grid_impl(h, d_points16, n, leaf, 0.0f, h->g.zmax, d_out16, n_out, stream);      // PassThrough z in [0, z_filter]
+    return voxel_grid_one(h, d_points16, n, leaf, 0.0f, h->g.zmax, d_out16, n_out, stream);      // PassThrough z in [0, z_filter]
+}
+
+// B frames in one launch sequence: the keyframes saveOutput merges (src/saveOutput.cpp:58-96), the 30 loop-closure candidates
+extern "C" int slam3d_voxel_grid_batch_device(slam3d_icp_handle *h, int32_t B, const void *const *d_points16, const int32_t *n, float leaf,
+                                              void *const *d_out16, int32_t *n_out, void *stream)
+{
+    if (!h || !d_points16 || !n || !d_out16 || !n_out || B < 1 || B > 4096) return SLAM3D_E_INVALID;
+    std::vector<VoxFrame> fr((size_t)B);
+    for (int b = 0; b < B; ++b) fr[b] = VoxFrame{ static_cast<const float4 *>(d_points16[b]), static_cast<float4 *>(d_out16[b]), n[b], 0 };
+    return voxel_grid_impl(h, B, fr.data(), leaf, 0.0f, h->g.zmax, n_out, stream);
 }
 
 static int voxel_host(slam3d_icp_handle *h, const void *points16, int32_t n, float leaf, float zmin, float zmax, void *out16, int32_t *n_out)
@@ -1489,7 +1606,7 @@ static int voxel_host(slam3d_icp_handle *h, const void *points16, int32_t n, flo
     int rc = vox_alloc(h);
     if (rc) return rc;
     if (n > 0) HIPCHK(h, hipMemcpyAsync(h->d_scratch4, points16, (size_t)n * 16, hipMemcpyHostToDevice, h->stream));
-    rc = voxel_grid_impl(h, h->d_scratch4, n, leaf, zmin, zmax, h->vox_out, n_out, h->stream);
+    rc = voxel_grid_one(h, h->d_scratch4, n, leaf, zmin, zmax, h->vox_out, n_out, h->stream);
     if (rc) return rc;
     if (*n_out > 0) HIPCHK(h, hipMemcpyAsync(out16, h->vox_out, (size_t)*n_out * 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1798,13 +1915,9 @@ extern "C" int slam3d_icp_dense_finish(slam3d_icp_handle *h, const int64_t last_
 // 1280x960).  Its products are 62 MB (19.7 MB normals, 22 MB tile records, 19.7 MB image-order records, boxes) from 2.4 MB of
 // depth image: all-gathering them over xGMI costs several times what every rank needs to recompute them from the image it
 // already holds.  The same holds for the H2D of the pair (each rank uploads both images over its own PCIe link).
-extern "C" int slam3d_icp_dense_run(slam3d_icp_handle *h, slam3d_comm *comm, const double *T_init, slam3d_icp_result *out)
+static int dense_run_impl(slam3d_icp_handle *h, int rank, int world, const DenseExchange *ex, const double *T_init, slam3d_icp_result *out)
 {
-    if (!h || !out) return SLAM3D_E_INVALID;
-    if (comm && comm->device != h->p.device) return SLAM3D_E_INVALID;
-    if (comm && !comm->comm) { h->err = "slam3d_icp_dense_run: the communicator was aborted by an earlier failure; create a new one"; return SLAM3D_E_COMM; }
-    const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
-    const bool collective = comm && (world > 1 || getenv("SLAM3D_DENSE_FORCE_COLLECTIVE"));
+    const bool collective = ex != nullptr;
     int r0 = 0, r1 = h->p.height;
     slam3d_shard_range(h->p.height, world, rank, &r0, &r1);
     int rc = slam3d_icp_dense_set_rows(h, r0, r1);
@@ -1814,39 +1927,95 @@ extern "C" int slam3d_icp_dense_run(slam3d_icp_handle *h, slam3d_comm *comm, con
     const int iters = h->p.iterations;
     const bool head_flow = h->head_solve != 0 && is_p2p(h) && nn_mode_of(h) == SLAM3D_NN_TILES && 1 < h->dense_batch && iters > 0;
     int64_t *d_sums = reinterpret_cast<int64_t *>(h->sums);
-    if (head_flow) {
-        for (int it = 0; it < iters && !rc; ++it) {
+    const int fail_at = getenv("SLAM3D_DENSE_FAIL_AT") ? atoi(getenv("SLAM3D_DENSE_FAIL_AT")) : -1;      // failure injection (tests): this process's iteration fail_at cannot be enqueued
+    int failed_it = -1;
+    if (!head_flow && collective && !rc) HIPCHK(h, hipMemsetAsync(d_sums + NRAW, 0, sizeof(int64_t) * 8, s));      // the three-step exchange carries the poison word behind the 36 totals
+    for (int it = 0; it < iters && !rc; ++it) {
+        if (it == fail_at) { h->err = "dense mode: injected failure (SLAM3D_DENSE_FAIL_AT)"; rc = SLAM3D_E_HIP; }
+        else if (head_flow) {
             const bool ev = h->ran_profiled;
             bool used = false;
-            rc = enqueue_iteration(h, 1, s, ev ? h->ev[3 + 2 * it] : nullptr, ev ? h->ev[4 + 2 * it] : nullptr, it, 1, nullptr, 0, it == 0, 0,
-                                   collective ? comm : nullptr, &used);
+            rc = enqueue_iteration(h, 1, s, ev ? h->ev[3 + 2 * it] : nullptr, ev ? h->ev[4 + 2 * it] : nullptr, it, 1, nullptr, 0, it == 0, 0, ex, &used);
             if (!rc && !used) rc = SLAM3D_E_STATE;
+        } else {
+            rc = slam3d_icp_dense_partial_device(h, d_sums, s);
+            if (!rc && collective && ex->fn(ex->ctx, d_sums, NRAW + 1, (void *)s) != 0) { h->err = "dense mode: the all-reduce of an iteration's totals failed"; rc = SLAM3D_E_COMM; }
+            if (!rc) rc = slam3d_icp_dense_update_device(h, d_sums, s);
         }
-        if (!rc) {
+        if (rc) failed_it = it;
+    }
+    if (rc < 0 && rc != SLAM3D_E_COMM && collective && failed_it >= 0) {
+        // This rank leaves the loop early.  Its peers have every remaining exchange queued already (nothing synchronises with the
+        // host before the result): take part in all of them with zero totals and the poison word set, so that nobody waits for a
+        // rank that is gone and everybody learns of the failure.  If even that cannot be enqueued the transport is aborted below.
+        bool drained = true;
+        for (int it = failed_it; it < iters && drained; ++it) {
+            long long *set = head_flow ? h->acc + (size_t)it * ACC_R * ACC_STRIDE : reinterpret_cast<long long *>(d_sums);
+            const int n = head_flow ? ACC_R * ACC_STRIDE : NRAW + 1;
+            hipLaunchKernelGGL(k_dense_poison, dim3((n + 63) / 64), dim3(64), 0, s, set, n);
+            drained = hipGetLastError() == hipSuccess && ex->fn(ex->ctx, set, n, (void *)s) == 0;
+        }
+        if (drained) { (void)hipStreamSynchronize(s); h->err += " (the remaining exchanges were completed with the failure flag set: peers return SLAM3D_E_COMM)"; }
+        else rc = rc == SLAM3D_E_COMM ? rc : SLAM3D_E_COMM - 100;      // marks "could not drain" for the caller below
+    }
+    if (!rc) {
+        if (head_flow) {
             h->dense_it = iters;
             if (hipEventRecord(h->ev[2], s) != hipSuccess) rc = SLAM3D_E_HIP;
             h->res_mapped = true;
             if (!rc) rc = slam3d_icp_fetch_results(h, 1, out);
             if (!rc) out->iterations = iters;
-        }
-    } else {
-        for (int it = 0; it < iters && !rc; ++it) {
-            rc = slam3d_icp_dense_partial_device(h, d_sums, s);
-            if (rc) break;
-            if (collective) {
-                const ncclResult_t nr = s3d::rccl().AllReduce(d_sums, d_sums, NRAW, ncclInt64, ncclSum, comm->comm, s);
-                if (nr != ncclSuccess) { h->err = std::string("ncclAllReduce failed: ") + s3d::rccl().GetErrorString(nr); rc = SLAM3D_E_COMM; break; }
-            }
-            rc = slam3d_icp_dense_update_device(h, d_sums, s);
-        }
-        if (!rc) rc = slam3d_icp_dense_finish_device(h, d_sums, s, out);
+        } else rc = slam3d_icp_dense_finish_device(h, d_sums, s, out);
     }
-    if (rc < 0 && collective && world > 1 && s3d::rccl().CommAbort && comm->comm) {
-        // this rank is leaving the loop early: release its side; the slam3d_comm is dead from here on (see the header comment)
-        (void)s3d::rccl().CommAbort(comm->comm);
-        comm->comm = nullptr;
-        h->err += " (communicator aborted)";
+    if (rc >= 0 && collective && iters > 0) {
+        // did a peer fail?  (the poison words of every exchanged set; the stream is drained by now)
+        std::vector<long long> w((size_t)iters, 0);
+        hipError_t ce;
+        if (head_flow) ce = hipMemcpy2D(w.data(), sizeof(long long), h->acc + DENSE_POISON, sizeof(long long) * ACC_R * ACC_STRIDE, sizeof(long long), (size_t)iters, hipMemcpyDeviceToHost);
+        else ce = hipMemcpy(w.data(), d_sums + DENSE_POISON, sizeof(long long), hipMemcpyDeviceToHost);
+        if (ce != hipSuccess) { (void)hipGetLastError(); rc = SLAM3D_E_HIP; }
+        else {
+            for (int it = 0; it < iters; ++it)
+                if (w[it] != 0) {
+                    h->err = "dense mode: " + std::to_string((long long)w[it]) + " peer rank(s) failed in or before iteration " + std::to_string(head_flow ? it : iters - 1) + "; the pose is not valid";
+                    identity16(out->T); out->status = SLAM3D_DEGENERATE;
+                    rc = SLAM3D_E_COMM;
+                    break;
+                }
+        }
     }
     (void)slam3d_icp_dense_set_rows(h, 0, h->p.height);
+    return rc;
+}
+
+extern "C" int slam3d_icp_dense_run_with(slam3d_icp_handle *h, int32_t rank, int32_t world, slam3d_allreduce_fn allreduce, void *ctx,
+                                         const double *T_init, slam3d_icp_result *out)
+{
+    if (!h || !out || world < 1 || rank < 0 || rank >= world || (world > 1 && !allreduce)) return SLAM3D_E_INVALID;
+    DenseExchange ex = { allreduce, ctx };
+    int rc = dense_run_impl(h, rank, world, allreduce ? &ex : nullptr, T_init, out);
+    if (rc == SLAM3D_E_COMM - 100) rc = SLAM3D_E_COMM;
+    return rc;
+}
+
+extern "C" int slam3d_icp_dense_run(slam3d_icp_handle *h, slam3d_comm *comm, const double *T_init, slam3d_icp_result *out)
+{
+    if (!h || !out) return SLAM3D_E_INVALID;
+    if (comm && comm->device != h->p.device) return SLAM3D_E_INVALID;
+    if (comm && !comm->comm) { h->err = "slam3d_icp_dense_run: the communicator was aborted by an earlier failure; create a new one"; return SLAM3D_E_COMM; }
+    const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
+    const bool collective = comm && (world > 1 || getenv("SLAM3D_DENSE_FORCE_COLLECTIVE"));
+    DenseExchange ex = { rccl_allreduce_thunk, comm };
+    int rc = dense_run_impl(h, rank, world, collective ? &ex : nullptr, T_init, out);
+    if (rc == SLAM3D_E_COMM - 100 || (rc == SLAM3D_E_COMM && comm && !comm->err.empty() && h->err.find("peer rank") == std::string::npos)) {
+        // the exchanges themselves failed (or could not be completed after a local failure): release this rank's side; the
+        // slam3d_comm is dead from here on.  Whether the peers' pending collectives then return is up to RCCL's transport.
+        if (collective && world > 1 && s3d::rccl().CommAbort && comm->comm) {
+            (void)s3d::rccl().CommAbort(comm->comm);
+            comm->comm = nullptr;
+            h->err += " (communicator aborted)";
+        }
+        rc = SLAM3D_E_COMM;
+    }
     return rc;
 }

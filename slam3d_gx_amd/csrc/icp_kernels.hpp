@@ -2167,6 +2167,11 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
             if (jp >= 0 && jp < g.W * g.H) {
                 if (pp.tq) { const float4 r4 = pp.tq[jp]; pq = make_float4(r4.y, r4.z, r4.w, rec.x); }
                 else { const float4 c4 = tcloud[jp]; pq = make_float4(c4.x, c4.y, c4.z, rec.x); }
+#ifdef S3D_PREFETCH_NRM
+                // the epilogue will gather the NORMAL of the match, and once the pose has settled the match is this one: touch its cache
+                // line now, in the same round trip as the match point (one dword, consumed by an empty asm: no register kept, no result used)
+                if (g.estimator == 0) { const float tn = tnrm[jp].x; asm volatile("" :: "v"(tn)); }
+#endif
             }
         }
         float4 qs = make_float4(0, 0, 0, 0);

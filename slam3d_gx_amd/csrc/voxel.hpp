@@ -50,7 +50,19 @@ struct __attribute__((aligned(128))) VoxSlot {
     VoxSums first;                                 // line 1: the claiming block's sums
 };
 static_assert(sizeof(VoxSums) == 64 && sizeof(VoxSlot) == 128 && offsetof(VoxSlot, first) == 64, "a voxel slot is two 64-byte lines");
-struct VoxTable { VoxSlot *slot; int cap; };       // `cap` slots (power of two)
+struct VoxTable { VoxSlot *slot; int cap; };       // `cap` slots (power of two) PER FRAME: frame f of a batch owns slot[f * cap, (f + 1) * cap)
+// Round 5: one launch sequence serves a BATCH of frames (blockIdx.y = frame; saveOutput merges every keyframe, src/saveOutput.cpp:58-96,
+// and loop closure touches 30 at a time): every table below exists once per frame, `*_stride` apart.  A single frame is the batch of
+// one whose record travels as a kernel argument (no pointer table to upload first).
+struct VoxFrame { const float4 *pts; float4 *out; int n, pad; };
+struct VoxLayout {
+    VoxTable t;
+    unsigned long long *lkey; int *lslot; int *bcount; int blk_stride;      // claim lists: blk_stride insert blocks per frame (bcount: blk_stride + 1 ints)
+    int *hist; int hist_stride;                                            // hist | start | cursor | btot | boff | ticket, VOX_HIST_INTS per frame
+    unsigned long long *gkey; int *gslot; int g_stride;                    // sorted lists: g_stride entries per frame
+    int *m_host;                                                           // host-mapped voxel counts, one per frame
+};
+__device__ __forceinline__ VoxFrame vox_frame(const VoxFrame *__restrict__ frames, const VoxFrame &f0) { return frames ? frames[blockIdx.y] : f0; }
 
 __device__ __forceinline__ unsigned long long vox_key(float x, float y, float z, float inv_leaf)
 {
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_clear(VoxTable t)
 {
     const int s = blockIdx.x * VOX_BLOCK + threadIdx.x;
     if (s >= t.cap) return;
-    uint4 *q = reinterpret_cast<uint4 *>(t.slot + s);                      // (line 0 only: line 1 needs no initial state)
+    uint4 *q = reinterpret_cast<uint4 *>(t.slot + (size_t)blockIdx.y * t.cap + s);                      // (line 0 only: line 1 needs no initial state)
     q[0] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
     q[1] = make_uint4(0u, 0u, 0u, 0u); q[2] = make_uint4(0u, 0u, 0u, 0u); q[3] = make_uint4(0u, 0u, 0u, 0u);
 }
@@ -118,6 +130,8 @@ template <typename T> __device__ __forceinline__ T run_scan(T v, int seg)
 constexpr int VOX_BZ = 512, VOX_BY = 256;   // ordering bins: (iz, iy) rows, both clamped (the order stays monotone)
 constexpr int zbias = 128;                   // iz in [-128, 383] has its own slab (-3.8 m .. 11.5 m at a 3 cm leaf)
 constexpr int VOX_BINS = VOX_BZ * VOX_BY;
+constexpr int VOX_SCAN_BLOCKS = VOX_BINS / 1024;
+constexpr int VOX_HIST_INTS = 3 * VOX_BINS + 16 + 2 * VOX_SCAN_BLOCKS;      // per frame: hist | start (+8) | cursor | btot | boff | ticket (+8)
 
 // bin = the (iz, iy) row of the voxel: a monotone function of the key (clamping only merges rows at the ends), so
 // bins are ordered like keys and a row holds at most one voxel per ix -- a few hundred entries even for a wall
@@ -148,10 +162,17 @@ constexpr int VOX_LH = 512;            // LDS hash entries per block (256 points
 constexpr int VOX_TW = 16;             // tile edge in pixels (ORG)
 
 template <bool ORG>
-__global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(const float4 *__restrict__ pts, int n, int W, int H, float inv_leaf, float zmin,
-                                                            float zmax, VoxTable t, unsigned long long *__restrict__ lkey,
-                                                            int *__restrict__ lslot, int *__restrict__ bcount, int *__restrict__ hist)
+__global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const VoxFrame *__restrict__ frames, int W, int H, float inv_leaf, float zmin,
+                                                            float zmax, VoxLayout L)
 {
+    const VoxFrame fr = vox_frame(frames, f0);
+    const float4 *__restrict__ pts = fr.pts;
+    const int n = fr.n, fb = blockIdx.y;
+    VoxTable t = L.t; t.slot += (size_t)fb * t.cap;
+    unsigned long long *__restrict__ lkey = L.lkey + (size_t)fb * L.blk_stride * VOX_BLOCK;
+    int *__restrict__ lslot = L.lslot + (size_t)fb * L.blk_stride * VOX_BLOCK;
+    int *__restrict__ bcount = L.bcount + (size_t)fb * (L.blk_stride + 1) + 1;
+    int *__restrict__ hist = L.hist + (size_t)fb * L.hist_stride;
     __shared__ unsigned long long hk[VOX_LH], hc01[VOX_LH], hc23[VOX_LH];
     __shared__ long long hsx[VOX_LH], hsy[VOX_LH], hsz[VOX_LH];
     __shared__ unsigned int hn[VOX_LH];
@@ -252,11 +273,20 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(const float4 *__rest
 // block) and leaves its total; the block that arrives last at the ticket (no spinning: it is simply the last one) turns
 // the 128 totals into the blocks' exclusive offsets boff[] and the voxel count M = start[VOX_BINS], which it also writes
 // straight into host-mapped memory (no copy launch behind the pipeline).  Consumers read vox_start(): start[b] + boff[b / 1024].
-constexpr int VOX_SCAN_BLOCKS = VOX_BINS / 1024;
-__global__ __launch_bounds__(1024) void k_voxel_scan(int *__restrict__ hist, int *__restrict__ start, int *__restrict__ cursor,
-                                                     int *__restrict__ btot, int *__restrict__ boff, int *__restrict__ ticket,
-                                                     int *__restrict__ m_host)
+struct VoxHist { int *hist, *start, *cursor, *btot, *boff, *ticket; };
+__device__ __forceinline__ VoxHist vox_hist_of(const VoxLayout &L, int fb)
 {
+    VoxHist h;
+    h.hist = L.hist + (size_t)fb * L.hist_stride; h.start = h.hist + VOX_BINS; h.cursor = h.start + VOX_BINS + 8; h.btot = h.cursor + VOX_BINS;
+    h.boff = h.btot + VOX_SCAN_BLOCKS; h.ticket = h.boff + VOX_SCAN_BLOCKS;
+    return h;
+}
+// grid (VOX_SCAN_BLOCKS, frames)
+__global__ __launch_bounds__(1024) void k_voxel_scan(VoxLayout L)
+{
+    const VoxHist vh = vox_hist_of(L, blockIdx.y);
+    int *__restrict__ hist = vh.hist, *__restrict__ start = vh.start, *__restrict__ cursor = vh.cursor, *__restrict__ btot = vh.btot,
+        *__restrict__ boff = vh.boff, *__restrict__ ticket = vh.ticket, *__restrict__ m_host = L.m_host + blockIdx.y;
     __shared__ int wtot[16];
     __shared__ int last_sh;
     const int i = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -311,11 +341,17 @@ __device__ __forceinline__ int vox_start(const int *__restrict__ start, const in
 // group the listed slots by row (order inside a row is arbitrary; k_voxel_rank fixes it).  Thread e looks at entry
 // e % VOX_BLOCK of insert block e / VOX_BLOCK.  The claims of one insert block come from one image tile, i.e. from a
 // handful of rows: lanes with the same row share ONE returning atomic on its cursor.
-__global__ __launch_bounds__(VOX_BLOCK) void k_voxel_scatter(const unsigned long long *__restrict__ lkey, const int *__restrict__ lslot,
-                                                             const int *__restrict__ bcount, const int *__restrict__ start,
-                                                             const int *__restrict__ boff, int *__restrict__ cursor,
-                                                             unsigned long long *__restrict__ gkey, int *__restrict__ gslot)
+__global__ __launch_bounds__(VOX_BLOCK) void k_voxel_scatter(VoxLayout L)
 {
+    const int fb = blockIdx.y;
+    const VoxHist vh = vox_hist_of(L, fb);
+    const unsigned long long *__restrict__ lkey = L.lkey + (size_t)fb * L.blk_stride * VOX_BLOCK;
+    const int *__restrict__ lslot = L.lslot + (size_t)fb * L.blk_stride * VOX_BLOCK;
+    const int *__restrict__ bcount = L.bcount + (size_t)fb * (L.blk_stride + 1) + 1;
+    const int *__restrict__ start = vh.start, *__restrict__ boff = vh.boff;
+    int *__restrict__ cursor = vh.cursor;
+    unsigned long long *__restrict__ gkey = L.gkey + (size_t)fb * L.g_stride;
+    int *__restrict__ gslot = L.gslot + (size_t)fb * L.g_stride;
     const int nb = bcount[blockIdx.x];
     if ((int)(threadIdx.x & ~63u) >= nb) return;                       // whole wave beyond the list
     const bool live = (int)threadIdx.x < nb;
@@ -347,10 +383,15 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_scatter(const unsigned long
 // are ordered, so an entry's rank = start of the first row its block touches + the keys of the block's rows below
 // its own: the block stages the union of its entries' rows through LDS.  grid covers the worst case (n entries);
 // blocks beyond the voxel count leave at once.  Every slot is reset as it is read (self-cleaning table).
-__global__ __launch_bounds__(VOX_BLOCK) void k_voxel_rank(VoxTable t, const unsigned long long *__restrict__ gkey,
-                                                          const int *__restrict__ gslot, const int *__restrict__ start,
-                                                          const int *__restrict__ boff, float4 *__restrict__ out)
+__global__ __launch_bounds__(VOX_BLOCK) void k_voxel_rank(VoxFrame fr0, const VoxFrame *__restrict__ frames, VoxLayout L)
 {
+    const int fb = blockIdx.y;
+    const VoxHist vh = vox_hist_of(L, fb);
+    VoxTable t = L.t; t.slot += (size_t)fb * t.cap;
+    const unsigned long long *__restrict__ gkey = L.gkey + (size_t)fb * L.g_stride;
+    const int *__restrict__ gslot = L.gslot + (size_t)fb * L.g_stride;
+    const int *__restrict__ start = vh.start, *__restrict__ boff = vh.boff;
+    float4 *__restrict__ out = vox_frame(frames, fr0).out;
     __shared__ unsigned long long tile[VOX_TILE];
     __shared__ int lo_sh, hi_sh;
     const int M = start[VOX_BINS];

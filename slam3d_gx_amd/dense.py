@@ -92,3 +92,27 @@ def dense_align_device(handle, world: int, rank: int, d_sums, T_init=None, strea
         res = handle.dense_finish_device(ptr, stream)
     handle.dense_set_rows(0, handle.params.height)
     return res
+
+
+def host_staged_allreduce():
+    """An all-reduce for IcpHandle.dense_run_with that needs no RCCL: drain the stream, stage the int64 buffer through host memory,
+    SUM it with torch.distributed (gloo works with several ranks on ONE GPU -- RCCL needs a GPU per rank), write it back.  The
+    exchange is then synchronous; it exists to run the library's dense loop and its failure protocol with two ranks in tests."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    hip = C.CDLL("libamdhip64.so")
+
+    def f(d_buf: int, count: int, stream: int) -> int:
+        if hip.hipStreamSynchronize(C.c_void_p(stream)) != 0:
+            return 1
+        host = np.empty(count, dtype=np.int64)
+        if hip.hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(d_buf), C.c_size_t(count * 8), C.c_int(2)) != 0:      # hipMemcpyDeviceToHost
+            return 1
+        t = torch.from_numpy(host)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if hip.hipMemcpy(C.c_void_p(d_buf), C.c_void_p(host.ctypes.data), C.c_size_t(count * 8), C.c_int(1)) != 0:      # hipMemcpyHostToDevice
+            return 1
+        return 0
+
+    return f

@@ -276,3 +276,40 @@ def test_failed_solve_is_never_reported_ok(gpu_lib):
     ro = O.icp(s4, s4, O.params(intr, iterations=3, nn_method=0), T_init=Ti)
     assert r["status"] == ro["status"] and r["status"] == 3           # DEGENERATE (damped or unsolved), T = Identity
     assert np.array_equal(r["T"], np.eye(4)) and np.array_equal(r["T_raw"], ro["T_trace"][-1])
+
+
+@pytest.mark.parametrize("estimator", [0, 1])
+def test_dense_failure_injection_two_ranks(gpu_lib, tmp_path, estimator):
+    """the dense loop's failure protocol with TWO ranks (two processes on this GPU, exchange over gloo through
+    slam3d_icp_dense_run_with -- the same library loop as slam3d_icp_dense_run, RCCL needs a GPU per rank).  Healthy: both ranks end
+    with the oracle's pose bits.  Rank 1 fails in iteration 3 (SLAM3D_DENSE_FAIL_AT): it returns its own error (SLAM3D_E_HIP) after
+    completing the remaining exchanges with the failure word set; rank 0 returns SLAM3D_E_COMM -- within the timeout, not a hang.
+    estimator 0: the head-solve flow (the accumulator set is exchanged in place); 1: the three-step flow (36 totals + the word)."""
+    import json, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pr, s4, t4 = _pair(1000, 320, 240)
+    ro = O.icp(s4, t4, O.params(pr.intr, iterations=8, nn_method=1, estimator=estimator))
+    for fail_at in (-1, 3):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+        outs = [str(tmp_path / f"r{r}_{fail_at}.json") for r in range(2)]
+        procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "_dense_fail_worker.py"), str(r), "2", port, str(estimator), str(fail_at), outs[r]],
+                                  cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+        logs = []
+        for p_ in procs:
+            try:
+                logs.append(p_.communicate(timeout=240)[0])
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                pytest.fail(f"a rank hung (fail_at={fail_at})")
+        assert all(p_.returncode == 0 for p_ in procs), logs
+        res = [json.load(open(o)) for o in outs]
+        if fail_at < 0:
+            for r in res:
+                assert r["code"] == 0 and r["status"] == ro["status"] and r["inliers"] == ro["inliers"]
+                assert np.array_equal(np.array(r["T"]).reshape(4, 4), ro["T_trace"][-1])
+        else:
+            assert res[1]["code"] == -2 and "injected failure" in res[1]["message"], res[1]
+            assert res[0]["code"] == -6 and "peer rank" in res[0]["message"], res[0]

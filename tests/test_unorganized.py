@@ -1,0 +1,95 @@
+"""ICP at the reference's ACTUAL operating point (VERDICT r4 'Missing 2'): readimage turns a frame into an
+UNORGANIZED cloud of ~15 k points (PCD -> PassThrough z <= 7 -> VoxelGrid 0.03: 16,034 / 14,758 points for data/exp1/pcd/{1,2}.pcd,
+src/GraphicEnd.cpp:283-295) and hands THAT cloud on (:158).  A handle with height == 1 aligns such point lists: full scan on the
+matrix cores, svd estimator or the planes alone.  The voxel clouds here are made from the reference's depth images (tests/golden/
+kinect: the PCDs hold exactly their back-projection, tests/test_golden.py) by the oracle's voxel grid."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from slam3d_gx_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def kinect_voxel_clouds():
+    from PIL import Image
+    out = []
+    for name in ("exp1_dep_1.png", "exp1_dep_2.png"):
+        d = np.array(Image.open(os.path.join(HERE, "golden", "kinect", name))).astype(np.uint16)
+        c = synth.backproject_numpy(d, synth.Intrinsics(), z_filter=1e9).reshape(-1, 4)
+        c = c[np.isfinite(c[:, 2])].copy()                      # convert2PCD drops d == 0 (src/convert2PCD.cpp:60-61)
+        c[:, 3] = np.float32(0)
+        out.append(O.voxel_grid(c, 0.03, 7.0))
+    return out
+
+
+def pad(c, n):
+    out = np.full((1, n, 4), np.nan, dtype=np.float32)
+    out[0, : len(c), :3] = c[:, :3]
+    out[0, : len(c), 3] = 1.0
+    return out
+
+
+def test_reference_operating_point_cloud_sizes():
+    v1, v2 = kinect_voxel_clouds()
+    assert (len(v1), len(v2)) == (16034, 14758)
+
+
+def test_oracle_on_unorganized_clouds_converges_on_a_perturbed_copy():
+    v1, _ = kinect_voxel_clouds()
+    n = len(v1)
+    intr = synth.Intrinsics(width=n, height=1)
+    Ti = synth.pose_from_seed(77, 2.0, 0.03)
+    r = O.icp(pad(v1, n), pad(v1, n), O.params(intr, estimator=1, iterations=20, nn_method=1), T_init=Ti)
+    rot, tr = O.pose_error(np.eye(4), r["T"])
+    assert r["status"] == 0 and r["n_src"] == r["n_tgt"] == n and rot < 2e-3 and tr < 5e-3, (rot, tr)
+    rb = O.icp(pad(v1, n), pad(v1, n), O.params(intr, estimator=1, iterations=3, nn_method=0), T_init=Ti)
+    rk = O.icp(pad(v1, n), pad(v1, n), O.params(intr, estimator=1, iterations=3, nn_method=1), T_init=Ti)
+    assert np.array_equal(rb["idx"], rk["idx"]) and np.array_equal(rb["T_trace"], rk["T_trace"])     # brute == kd-tree here too
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["1->2", "1->1", "2->2 plane_only"])
+def test_hip_unorganized_icp_equals_the_oracle(gpu_lib, case):
+    """16,034 x 14,758 points (ragged views of a 16,034-wide handle), 20 iterations: every iterate, sum, index and d2 bit-identical
+    to the oracle; SLAM3D_NN_AUTO runs the bf16 matrix-core scan, the tile search and the VALU scan give the same bits."""
+    from slam3d_gx_amd import capi
+    v1, v2 = kinect_voxel_clouds()
+    W = max(len(v1), len(v2))
+    intr = synth.Intrinsics(width=W, height=1)
+    a, b = (v1, v2) if case.startswith("1->2") else ((v1, v1) if case.startswith("1->1") else (v2, v2))
+    Ti = None if case.startswith("1->2") else synth.pose_from_seed(77, 2.0, 0.03)
+    plane = case.endswith("plane_only")
+    okw = dict(estimator=2, plane_only=1) if plane else dict(estimator=1)
+    gkw = dict(estimator=capi.EST_PLANE, plane_flags=capi.PLANE_ONLY) if plane else dict(estimator=capi.EST_SVD)
+    ro = O.icp(pad(a, W), pad(b, W), O.params(intr, iterations=20, nn_method=1, **okw), T_init=Ti)
+    sa = np.ascontiguousarray(pad(a, len(a))); sb = np.ascontiguousarray(pad(b, len(b)))          # ragged: the views carry their own widths
+    for mode in (capi.NN_AUTO, capi.NN_TILES, capi.NN_BRUTE_VALU):
+        with capi.IcpHandle(capi.default_params(intr, iterations=20, nn_mode=mode, **gkw)) as h:
+            rg = h.align(sa, sb, Ti)
+            idx, d2 = h.get_correspondences(0)
+            Tt, St = h.get_trace(0)
+        assert rg["n_src"] == ro["n_src"] == len(a) and rg["n_tgt"] == ro["n_tgt"], (mode, rg["n_tgt"], ro["n_tgt"])
+        assert np.array_equal(idx, ro["idx"]) and np.array_equal(d2.view(np.uint32), ro["d2"].view(np.uint32)), mode
+        assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:20], ro["sums_trace"]), mode
+        assert rg["status"] == ro["status"] and rg["inliers"] == ro["inliers"]
+    if Ti is not None and not plane:
+        rot, tr = O.pose_error(np.eye(4), rg["T_raw"])
+        assert rot < 2e-3 and tr < 5e-3
+
+
+@pytest.mark.gpu
+def test_unorganized_handles_refuse_window_estimators(gpu_lib):
+    from slam3d_gx_amd import capi
+    intr = synth.Intrinsics(width=5000, height=1)
+    for bad in (dict(estimator=capi.EST_POINT2PLANE), dict(estimator=capi.EST_PLANE, plane_flags=0), dict(estimator=capi.EST_PLANE, plane_flags=capi.PLANE_PAIR_GATE)):
+        with pytest.raises(capi.Slam3dError):
+            capi.IcpHandle(capi.default_params(intr, **bad))
+    with capi.IcpHandle(capi.default_params(intr, estimator=capi.EST_SVD)) as h:
+        with pytest.raises(AssertionError):
+            h.align(np.zeros((1, 5001, 4), np.float32), np.zeros((1, 10, 4), np.float32))
+        r = h.align(np.full((1, 0, 4), np.nan, np.float32), np.full((1, 7, 4), np.nan, np.float32))      # empty clouds: no inliers, Identity
+        assert r["status"] == 1 and np.array_equal(r["T"], np.eye(4))
