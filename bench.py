@@ -777,13 +777,25 @@ def dense_leg(args, torch, dist, capi, synth, world, rank, local_rank, comm, wid
     # launch when profiling is on); algorithmic bytes of THIS rank's share (its source rows, the whole target)
     h.set_profiling(True)
     nn, alg, flops = [], [], []
+    pre = []
     for _ in range(min(6, max(2, steps))):
         r = step()
         nn.append(float(np.sum(h.get_iteration_timings())))
+        pre.append(float(h.get_timings()["preprocess_ms"]))
         alg.append(alg_bytes_per_launch(r["n_src"], r["n_tgt"], est, args.iterations))
         flops.append(8.0 * r["n_src"] * r["n_tgt"])
     h.set_profiling(False)
     out["prof"] = dict(nn_ms=statistics.mean(nn), alg_bytes=statistics.mean(alg), flops=statistics.mean(flops))
+    # SURVEY.md 8(e) / VERDICT r4 item 7c: the target's preprocessing is REPLICATED on every rank.  What it costs (measured here, HIP
+    # events) against what sharding it would cost: the products a rank would have to receive from its peers -- normals 16 B, tile records
+    # 18 B, image-order records 16 B, boxes: ~51 B per pixel -- over xGMI (ring all-gather, (N-1)/N of the bytes per rank at ~150 GB/s per
+    # link pair) plus two collective latencies
+    n_px = width * height
+    prod_bytes = 51.0 * n_px
+    out["target_preprocessing"] = {
+        "replicated_ms_measured": statistics.mean(pre), "products_bytes": prod_bytes,
+        "predicted_sharded_ms": {str(n): round(statistics.mean(pre) / n + prod_bytes * (n - 1) / n / 150e9 * 1e3 + 0.03, 4) for n in (2, 4, 8)},
+        "note": "preprocessing (back-projection, normals, tiles of BOTH frames) stays replicated: recomputing costs less than gathering its products"}
     if world == 1:
         if want_cpu:
             j = out["last_j"]
@@ -897,6 +909,7 @@ def main():
         }
         if "prof" in d:
             out["roofline"] = tiles_roofline(d["prof"], args.iterations, f"k_nn_tiles_acc_{size_tag}")
+            out["target_preprocessing"] = d.get("target_preprocessing")
         if "cpu" in d:
             out["cpu_baseline"], out["parity_vs_oracle"] = d["cpu"], d["parity"]
         if rank == 0:
@@ -1490,7 +1503,7 @@ def extra_legs(args, torch, dist, capi, synth, local_rank, est, handles, pools, 
                       "images inside every step, 24 steps timed",
           "value": 24 * args.iterations / d["elapsed"], "unit": "ICP iterations/s", "ms_per_step": 1e3 * d["elapsed"] / 24,
           "roofline": tiles_roofline(d["prof"], args.iterations, "k_nn_tiles_acc_1280x960"),
-          "n_src": d["res"]["n_src"], "n_tgt": d["res"]["n_tgt"]}
+          "n_src": d["res"]["n_src"], "n_tgt": d["res"]["n_tgt"], "target_preprocessing": d.get("target_preprocessing")}
     if "cpu" in d:
         c5["cpu_baseline"], c5["parity_vs_oracle"] = d["cpu"], d["parity"]
     out["config5"] = c5
