@@ -933,7 +933,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
             // (the bf16 form's waves are half as long: 48 k of them -- 175 -> 183 TFLOP/s-equivalent)
             int msplit = ((h->mfma_bf16 ? 48 : 24) * 1024 + (h->N / MF_Q) * B - 1) / ((h->N / MF_Q) * B);
             if (msplit < 1) msplit = 1;
-            if (msplit > 32) msplit = 32;
+            if (msplit > 64) msplit = 64;      // (round 5: 64, not 32 -- the 16 k x 15 k scans of unorganized clouds have 128 query blocks: 53 -> 38 us per launch)
             if (h->mfma_split > 0) msplit = h->mfma_split;                                                               // developer knob SLAM3D_MFMA_SPLIT (read at create)
             if (h->mfma_bf16)
                 hipLaunchKernelGGL(k_nn_mfma16, dim3((h->N + MF_Q - 1) / MF_Q, msplit, B), dim3(64), 0, s, h->d_pairs, h->src_c, h->tgt_c,

@@ -738,6 +738,7 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_valu(const PairPtrs *__restrict
     const Rt m = load_rt(Tcur + b * 16);
     float px[QPT], py[QPT], pz[QPT];
     unsigned long long bk[QPT];
+    unsigned int jb0[QPT];
     int slot[QPT];
     const float inf = __int_as_float(0x7f800000);
 #pragma unroll
@@ -748,6 +749,7 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_valu(const PairPtrs *__restrict
         slot[k] = __float_as_int(s.w);
         xform(m, s.x, s.y, s.z, px[k], py[k], pz[k]);
         bk[k] = brute_bound(slot[k] >= 0, slot[k], px[k], py[k], pz[k], prevq + (size_t)b * nslots, first, pairs[b].tgt, pairs[b].nrm, g, tg);
+        jb0[k] = (unsigned int)bk[k];                // the bound's own target: a slice that did not improve on it has nothing to merge
     }
     // FILT: a = -2 (p - centre), and what the threshold needs: |p - centre|^2 and the U-independent part of eps (k_nn_mfma's)
     float ax[QPT], ay[QPT], az[QPT], n2p[QPT], epsb[QPT], thr[QPT];
@@ -837,7 +839,10 @@ __global__ __launch_bounds__(NN_BLOCK) void k_nn_valu(const PairPtrs *__restrict
     }
 #pragma unroll
     for (int k = 0; k < QPT; ++k)
-        if (slot[k] >= 0 && (unsigned int)bk[k] != 0xffffffffu) atomicMin(best + (size_t)b * nslots + slot[k], bk[k]);
+        // (round 5: the bound is a candidate every slice starts from -- only the first non-empty slice merges it, the others only what beat it: an
+        //  improvement is a DIFFERENT target.  A settled iteration made nsplit same-address atomics per query of which one mattered:
+        //  524 k of them were ~50 us of the 16 k x 15 k scan)
+        if (slot[k] >= 0 && (unsigned int)bk[k] != 0xffffffffu && ((unsigned int)bk[k] != jb0[k] || tile_begin == 0)) atomicMin(best + (size_t)b * nslots + slot[k], bk[k]);
 }
 
 // ------------------------------------------------------------- full brute force on the matrix cores
@@ -914,6 +919,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF_WPE, MF_W
     const Rt m = load_rt(Tcur + b * 16);
     const float qmax2 = __int_as_float((int)qmax2_bits[b]);
     int my_slot[MF_Q / 64];
+    unsigned int my_j0[MF_Q / 64];             // the target of each query's starting bound (see k_nn_valu: only improvements are merged)
 #pragma unroll
     for (int h = 0; h < MF_Q / 64; ++h) {
         const int ql = h * 64 + lane, i = i0 + ql;
@@ -933,6 +939,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF_WPE, MF_W
         qrel[ql] = make_float4(-2.0f * rx, -2.0f * ry, -2.0f * rz, 1.0f);
         qthr[ql] = valid ? (U - n2p) + eps : -1e30f;           // invalid rows can never be flagged
         qkey[ql] = bkey;
+        my_j0[h] = (unsigned int)bkey;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1056,7 +1063,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF_WPE, MF_W
     for (int h = 0; h < MF_Q / 64; ++h) {
         if (my_slot[h] >= 0) {
             const unsigned long long key = qkey[h * 64 + lane];
-            if ((unsigned int)(key & 0xffffffffull) != 0xffffffffu) atomicMin(best + (size_t)b * tg.nslots + my_slot[h], key);
+            if ((unsigned int)(key & 0xffffffffull) != 0xffffffffu && ((unsigned int)key != my_j0[h] || g_begin == 0))
+                atomicMin(best + (size_t)b * tg.nslots + my_slot[h], key);
         }
     }
 }
@@ -1150,6 +1158,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF16_WPE, MF
     const Rt m = load_rt(Tcur + b * 16);
     const float qmax2 = __int_as_float((int)qmax2_bits[b]);
     int my_slot[MF_Q / 64];
+    unsigned int my_j0[MF_Q / 64];             // the target of each query's starting bound (see k_nn_valu: only improvements are merged)
 #pragma unroll
     for (int h = 0; h < MF_Q / 64; ++h) {
         const int ql = h * 64 + lane, i = i0 + ql;
@@ -1170,6 +1179,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF16_WPE, MF
         qpos[ql] = make_float4(px, py, pz, 0.0f);
         qrel[ql] = make_float4(-2.0f * rx, -2.0f * ry, -2.0f * rz, -thr);
         qkey[ql] = bkey;
+        my_j0[h] = (unsigned int)bkey;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1261,7 +1271,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF16_WPE, MF
     for (int h = 0; h < MF_Q / 64; ++h) {
         if (my_slot[h] >= 0) {
             const unsigned long long key = qkey[h * 64 + lane];
-            if ((unsigned int)(key & 0xffffffffull) != 0xffffffffu) atomicMin(best + (size_t)b * tg.nslots + my_slot[h], key);
+            if ((unsigned int)(key & 0xffffffffull) != 0xffffffffu && ((unsigned int)key != my_j0[h] || g_begin == 0))
+                atomicMin(best + (size_t)b * tg.nslots + my_slot[h], key);
         }
     }
 }

@@ -15,7 +15,7 @@ for cfg in (sys.argv[1:] or [""]):
     keys = []
     for kv in filter(None, cfg.split(",")):
         k, v = kv.split("="); os.environ[k] = v; keys.append(k)
-    for mode in (capi.NN_AUTO, capi.NN_TILES, capi.NN_BRUTE_VALU):
+    for mode in ((capi.NN_AUTO,) if os.environ.get("QU_AUTO_ONLY") else (capi.NN_AUTO, capi.NN_TILES, capi.NN_BRUTE_VALU)):
         with capi.IcpHandle(capi.default_params(intr, iterations=20, estimator=capi.EST_SVD, nn_mode=mode)) as h:
             for _ in range(3):
                 h.align(a, b)
