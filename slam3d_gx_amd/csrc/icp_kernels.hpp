@@ -967,20 +967,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF_WPE, MF_W
             const int j = grp * 16 + jq;
             float4 c4 = make_float4(0, 0, 0, __int_as_float(-1));
             if (j < nt) c4 = Q[j];
+            // (round 5) every lane first collects WHICH of its 32 accumulators flagged a pair, then the wave loops until no lane has
+            // one left: as many trips as the busiest lane has flags (one or two) instead of 32 ballots and branches per flagged group
+            // -- on voxel clouds, whose neighbour spacing is of the order of the filter's margin, nearly every group near a query is
+            // flagged and this path was the scan's critical one
+            unsigned int fm = 0u;
 #pragma unroll
             for (int rb = 0; rb < MF_RB; ++rb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool f = D[rb][r] <= 0.0f && j < nt;
-                    if (__ballot(f) != 0ull && f) {
-                        const int qi = rb * 16 + 4 * kq + r;
-                        const float4 p4 = qpos[qi];
-                        const float d2 = canon_d2(p4.x, p4.y, p4.z, c4.x, c4.y, c4.z);
-                        const unsigned long long key =
-                            ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(c4.w);
-                        atomicMin(&qkey[qi], key);
-                    }
+                for (int r = 0; r < 4; ++r) fm |= (D[rb][r] <= 0.0f ? 1u : 0u) << (rb * 4 + r);
+            if (!(j < nt)) fm = 0u;
+            while (__ballot(fm != 0u) != 0ull) {
+                if (fm != 0u) {
+                    const int bit = __builtin_ctz(fm);
+                    fm &= fm - 1u;
+                    const int qi = (bit >> 2) * 16 + 4 * kq + (bit & 3);
+                    const float4 p4 = qpos[qi];
+                    const float d2 = canon_d2(p4.x, p4.y, p4.z, c4.x, c4.y, c4.z);
+                    const unsigned long long key =
+                        ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(c4.w);
+                    atomicMin(&qkey[qi], key);
                 }
+            }
         }
     };
     auto fold = [&](const f32x4 *D, int grp) __attribute__((always_inline)) {
@@ -1147,6 +1155,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF16_WPE, MF
     __shared__ float4 qpos[MF_Q];
     __shared__ float4 qrel[MF_Q];                   // (-2 rx, -2 ry, -2 rz, -thr)
     __shared__ unsigned long long qkey[MF_Q];
+    __shared__ int qslot[MF_Q];                     // each query's slot and the target of its starting bound: only needed again after the scan --
+    __shared__ unsigned int qj0[MF_Q];              // in LDS, not in registers across the loop (the kernel sits at its 168-VGPR budget)
     const int b = blockIdx.z, lane = threadIdx.x;
     const int N = g.N;
     const int ns = ccounts[b * 4 + 0], nt = ccounts[b * 4 + 1];
@@ -1157,8 +1167,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF16_WPE, MF
     const float4 *__restrict__ tnrm = pairs[b].nrm;
     const Rt m = load_rt(Tcur + b * 16);
     const float qmax2 = __int_as_float((int)qmax2_bits[b]);
-    int my_slot[MF_Q / 64];
-    unsigned int my_j0[MF_Q / 64];             // the target of each query's starting bound (see k_nn_valu: only improvements are merged)
 #pragma unroll
     for (int h = 0; h < MF_Q / 64; ++h) {
         const int ql = h * 64 + lane, i = i0 + ql;
@@ -1166,7 +1174,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF16_WPE, MF
         if (i < ns) s4 = src_c[(size_t)b * N + i];
         const int slot = __float_as_int(s4.w);
         const bool valid = slot >= 0;
-        my_slot[h] = slot;
+        qslot[ql] = slot;
         float px, py, pz;
         xform(m, s4.x, s4.y, s4.z, px, py, pz);
         const unsigned long long bkey = brute_bound(valid, slot, px, py, pz, prevq + (size_t)b * tg.nslots, first, tcloud, tnrm, g, tg);
@@ -1179,7 +1187,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF16_WPE, MF
         qpos[ql] = make_float4(px, py, pz, 0.0f);
         qrel[ql] = make_float4(-2.0f * rx, -2.0f * ry, -2.0f * rz, -thr);
         qkey[ql] = bkey;
-        my_j0[h] = (unsigned int)bkey;
+        qj0[ql] = (unsigned int)bkey;              // (see k_nn_valu: only improvements on the bound are merged)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1204,20 +1212,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF16_WPE, MF
         const int j = grp * 16 + jq;
         float4 c4 = make_float4(0, 0, 0, __int_as_float(-1));
         if (j < nt) c4 = Q[j];
+        unsigned int fm = 0u;                   // (which of this lane's 32 accumulators flagged a pair: see k_nn_mfma)
 #pragma unroll
         for (int rb = 0; rb < MF_RB; ++rb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool f = D[rb][r] <= 0.0f && j < nt;
-                if (__ballot(f) != 0ull && f) {
-                    const int qi = rb * 16 + 4 * kq + r;
-                    const float4 p4 = qpos[qi];
-                    const float d2 = canon_d2(p4.x, p4.y, p4.z, c4.x, c4.y, c4.z);
-                    const unsigned long long key =
-                        ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(c4.w);
-                    atomicMin(&qkey[qi], key);
-                }
+            for (int r = 0; r < 4; ++r) fm |= (D[rb][r] <= 0.0f ? 1u : 0u) << (rb * 4 + r);
+        if (!(j < nt)) fm = 0u;
+        while (__ballot(fm != 0u) != 0ull) {
+            if (fm != 0u) {
+                const int bit = __builtin_ctz(fm);
+                fm &= fm - 1u;
+                const int qi = (bit >> 2) * 16 + 4 * kq + (bit & 3);
+                const float4 p4 = qpos[qi];
+                const float d2 = canon_d2(p4.x, p4.y, p4.z, c4.x, c4.y, c4.z);
+                const unsigned long long key =
+                    ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(c4.w);
+                atomicMin(&qkey[qi], key);
             }
+        }
     };
     union Frag { uint4 u; bf16x8 v; };
     auto bfrag = [&](const uint2 ld) __attribute__((always_inline)) {
@@ -1269,10 +1281,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF16_WPE, MF
     }
 #pragma unroll
     for (int h = 0; h < MF_Q / 64; ++h) {
-        if (my_slot[h] >= 0) {
-            const unsigned long long key = qkey[h * 64 + lane];
-            if ((unsigned int)(key & 0xffffffffull) != 0xffffffffu && ((unsigned int)key != my_j0[h] || g_begin == 0))
-                atomicMin(best + (size_t)b * tg.nslots + my_slot[h], key);
+        int le = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // the lane id again (one wave per block), and
+        asm volatile("" : "+v"(le));               // opaque: the LDS addresses are formed HERE -- hoisted above the loop they (and the lane id) were spilled to scratch
+        const int slot = qslot[h * 64 + le];
+        if (slot >= 0) {
+            const unsigned long long key = qkey[h * 64 + le];
+            if ((unsigned int)(key & 0xffffffffull) != 0xffffffffu && ((unsigned int)key != qj0[h * 64 + le] || g_begin == 0))
+                atomicMin(best + (size_t)b * tg.nslots + slot, key);
         }
     }
 }
