@@ -1212,17 +1212,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF16_WPE, MF
         const int j = grp * 16 + jq;
         float4 c4 = make_float4(0, 0, 0, __int_as_float(-1));
         if (j < nt) c4 = Q[j];
-        unsigned int fm = 0u;                   // (which of this lane's 32 accumulators flagged a pair: see k_nn_mfma)
+        // which of this lane's 32 accumulators flagged a pair (see k_nn_mfma), collected with ONE funnel shift each: v_alignbit(fm, D, 31) =
+        // fm << 1 | sign(D).  The sign bit alone decides here: a pair within the bound has D_exact <= -eps, and eps exceeds the proven error
+        // of the chain by 1.1e-6 S + 1e-6 (4e-6 S against 24 x 2^-23 S, see above), so its computed D is strictly negative -- a D of
+        // exactly +0 that sent the wave here belongs to no such pair.  Accumulator k = rb * 4 + r ends up at bit 31 - k.
+        unsigned int fm = 0u;
 #pragma unroll
         for (int rb = 0; rb < MF_RB; ++rb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) fm |= (D[rb][r] <= 0.0f ? 1u : 0u) << (rb * 4 + r);
+            for (int r = 0; r < 4; ++r) fm = __builtin_amdgcn_alignbit(fm, (unsigned int)__float_as_int(D[rb][r]), 31);
         if (!(j < nt)) fm = 0u;
         while (__ballot(fm != 0u) != 0ull) {
             if (fm != 0u) {
-                const int bit = __builtin_ctz(fm);
-                fm &= fm - 1u;
-                const int qi = (bit >> 2) * 16 + 4 * kq + (bit & 3);
+                const int bit = 31 - __builtin_clz(fm);
+                fm &= ~(1u << bit);
+                const int k = 31 - bit;
+                const int qi = (k >> 2) * 16 + 4 * kq + (k & 3);
                 const float4 p4 = qpos[qi];
                 const float d2 = canon_d2(p4.x, p4.y, p4.z, c4.x, c4.y, c4.z);
                 const unsigned long long key =

@@ -22,7 +22,7 @@ for db in sorted(glob.glob("$OUT/p_*/**/*.db", recursive=True)):
             dur[name.split("(")[0]] = (d / 1e3, n)
     except Exception as e:
         print("<!--", db, e, "-->")
-print("# r04: PMC passes over the full-scan kernels (640x480 pair, tools/pmc_brute.sh; one rocprofv3 --pmc run per counter set, per dispatch, summed over XCDs / SEs)\n")
+print("# r05: PMC passes over the full-scan kernels (640x480 pair, tools/pmc_brute.sh; one rocprofv3 --pmc run per counter set, per dispatch, summed over XCDs / SEs)\n")
 print("| kernel | counter | per dispatch | dispatches |\n|---|---|---|---|")
 for (k, cn), (v, n) in sorted(rows.items()):
     print(f"| \`{k}\` | {cn} | {v:,.0f} | {n} |")
