@@ -1208,33 +1208,66 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF16_WPE, MF
     const int ngroups = (nt + 15) / 16;
     const int g_begin = (int)(((long long)blockIdx.y * ngroups) / nsplit);
     const int g_end = (int)(((long long)(blockIdx.y + 1) * ngroups) / nsplit);
+    // ---- flagged groups are QUEUED, not re-evaluated on the spot (round 5).  The exact re-evaluation needs the group's canonical
+    // targets Q[j] from memory; inside the scan loop that load is the YOUNGEST in flight, so waiting for it (s_waitcnt vmcnt(0))
+    // drained all eight fragment prefetches -- one L2 round trip per flagged group, ~9 % of the groups of a 640x480 scan.  A flagged
+    // group now only leaves its per-lane flag mask (one v_alignbit per accumulator: fm = fm << 1 | sign(D); accumulator
+    // k = rb * 4 + r ends at bit 31 - k) and its number in an LDS queue; the queue is drained when it is full and after the loop, the
+    // Q[j] of all its entries loaded together.  The thresholds sit in the A operands, fixed for the launch, so WHEN a flagged pair is
+    // re-evaluated changes nothing.  (The sign bit alone decides: a pair within the bound has D_exact <= -eps, and eps exceeds the
+    // proven error of the chain by 1.1e-6 S + 1e-6 -- 4e-6 S against 24 x 2^-23 S, see above --, so its computed D is strictly
+    // negative; a D of exactly +0 that sent the wave here belongs to no such pair.)
+    constexpr int FQ_CAP = 16;
+    __shared__ unsigned int fq_mask[FQ_CAP][64];
+    __shared__ int fq_grp[FQ_CAP];
+    int fq_n = 0;                                   // wave-uniform
+    auto drain = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+        for (int e0 = 0; e0 < fq_n; e0 += 4) {
+            float4 c4[4];
+            unsigned int fm[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {           // four entries' targets in flight together
+                const int e = e0 + u;
+                const int j = e < fq_n ? fq_grp[e] * 16 + jq : nt;
+                c4[u] = make_float4(0, 0, 0, __int_as_float(-1));
+                fm[u] = 0u;
+                if (j < nt) { c4[u] = Q[j]; fm[u] = fq_mask[e & (FQ_CAP - 1)][lane]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                unsigned int m = fm[u];
+                while (__ballot(m != 0u) != 0ull) {
+                    if (m != 0u) {
+                        const int bit = 31 - __builtin_clz(m);
+                        m &= ~(1u << bit);
+                        const int k = 31 - bit;
+                        const int qi = (k >> 2) * 16 + 4 * kq + (k & 3);
+                        const float4 p4 = qpos[qi];
+                        const float d2 = canon_d2(p4.x, p4.y, p4.z, c4[u].x, c4[u].y, c4[u].z);
+                        const unsigned long long key =
+                            ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(c4[u].w);
+                        atomicMin(&qkey[qi], key);
+                    }
+                }
+            }
+        }
+        fq_n = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
     auto flagged = [&](const f32x4 *D, int grp) __attribute__((always_inline)) {
-        const int j = grp * 16 + jq;
-        float4 c4 = make_float4(0, 0, 0, __int_as_float(-1));
-        if (j < nt) c4 = Q[j];
-        // which of this lane's 32 accumulators flagged a pair (see k_nn_mfma), collected with ONE funnel shift each: v_alignbit(fm, D, 31) =
-        // fm << 1 | sign(D).  The sign bit alone decides here: a pair within the bound has D_exact <= -eps, and eps exceeds the proven error
-        // of the chain by 1.1e-6 S + 1e-6 (4e-6 S against 24 x 2^-23 S, see above), so its computed D is strictly negative -- a D of
-        // exactly +0 that sent the wave here belongs to no such pair.  Accumulator k = rb * 4 + r ends up at bit 31 - k.
         unsigned int fm = 0u;
 #pragma unroll
         for (int rb = 0; rb < MF_RB; ++rb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) fm = __builtin_amdgcn_alignbit(fm, (unsigned int)__float_as_int(D[rb][r]), 31);
-        if (!(j < nt)) fm = 0u;
-        while (__ballot(fm != 0u) != 0ull) {
-            if (fm != 0u) {
-                const int bit = 31 - __builtin_clz(fm);
-                fm &= ~(1u << bit);
-                const int k = 31 - bit;
-                const int qi = (k >> 2) * 16 + 4 * kq + (k & 3);
-                const float4 p4 = qpos[qi];
-                const float d2 = canon_d2(p4.x, p4.y, p4.z, c4.x, c4.y, c4.z);
-                const unsigned long long key =
-                    ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(c4.w);
-                atomicMin(&qkey[qi], key);
-            }
-        }
+        fq_mask[fq_n][lane] = fm;
+        if (lane == 0) fq_grp[fq_n] = grp;
+        fq_n += 1;
+        if (fq_n == FQ_CAP) drain();
     };
     union Frag { uint4 u; bf16x8 v; };
     auto bfrag = [&](const uint2 ld) __attribute__((always_inline)) {
@@ -1284,6 +1317,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MF16_WPE, MF
             if (__ballot(mn <= 0) != 0ull) flagged(D[u & 1], g0 + u);
         }
     }
+    drain();
 #pragma unroll
     for (int h = 0; h < MF_Q / 64; ++h) {
         int le = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // the lane id again (one wave per block), and
