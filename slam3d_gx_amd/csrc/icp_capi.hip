@@ -29,6 +29,7 @@ struct FrameHost {
     uint64_t src_epoch = 0; int src_row0 = -1, src_row1 = -1;    // source role: built for this epoch and row shard
     uint64_t tgt_epoch = 0; int tgt_normals = -1;                // target role: built for this epoch with/without normals
     uint64_t nrm_epoch = 0;                                      // the frame's normals were computed for this epoch
+    bool nrm_full = false;             // ... with the normal VECTORS of every pixel (SLAM3D_EST_PLANE builds labels only for a frame that is a source of the pair gate)
     bool from_depth = false;           // the cloud is OUR back-projection of a depth image with the handle's intrinsics
 };
 
@@ -70,6 +71,7 @@ struct slam3d_icp_handle {
     FramePlanes *f_planes = nullptr;      // [maxF]
     int *assoc = nullptr;                 // [maxB][8]
     slam3d_seg_params seg_sp;             // slam3d_icp_set_seg_params
+    std::vector<const float4 *> pl_ptrs_up;   // what pl_ptrs holds on the device
     // voxel grid (f-1): allocated on first use
     unsigned char *vox_mem = nullptr;
     VoxTable vox;
@@ -673,7 +675,8 @@ __global__ void k_dense_poison(long long *__restrict__ set, int n)
 
 // the launches of one segmentation pass over B frames (spec P1-P5): nothing returns to the host.  ptrs_dev[b] = cloud of frame b,
 // lab + b * N its labels, st[b] its state (zeroed here).  Shared by slam3d_segment_planes* and the preprocessing of SLAM3D_EST_PLANE.
-static int enqueue_segmentation(slam3d_icp_handle *h, int B, const float4 **ptrs_dev, int *lab, SegState *st, const slam3d_seg_params *sp, hipStream_t s)
+static int enqueue_segmentation(slam3d_icp_handle *h, int B, const float4 **ptrs_dev, int *lab, SegState *st, const slam3d_seg_params *sp, hipStream_t s,
+                                bool final_launch = true /* false: the caller's next kernel closes the last round itself (k_plane_normals) */)
 {
     const int N = h->N;
     const SegParams P = { sp->distance_threshold, sp->plane_percent, sp->max_planes, sp->hypotheses, sp->seed };
@@ -696,7 +699,7 @@ static int enqueue_segmentation(slam3d_icp_handle *h, int B, const float4 **ptrs
             hipLaunchKernelGGL(k_seg_label<false>, pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P.hypotheses, P.thr, r);
         }
     }
-    hipLaunchKernelGGL(k_seg_final, dim3(B), dim3(1), 0, s, st, P.max_planes, P.percent);
+    if (final_launch) hipLaunchKernelGGL(k_seg_final, dim3(B), dim3(1), 0, s, st, P.max_planes, P.percent);
     HIPCHK(h, hipGetLastError());
     return SLAM3D_OK;
 }
@@ -728,6 +731,11 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
     const int use_normals = is_p2p(h) ? 1 : 0;
     const bool src_normals = use_normals && (g.min_ncos > 0.0f || g.pair_gate);       // the normal-angle gate / the plane-pair gate read the source frame's normals
     std::vector<FrameTask> tasks, ntasks;
+    std::vector<char> nfull;                       // per normals task: vectors wanted (1) or plane labels only (0)
+    std::unordered_map<int, size_t> ntask_of;      // frame -> its normals task of this pass
+    // SLAM3D_EST_PLANE: a SOURCE frame's normals are read by the pair gate for their plane labels alone (unless the normal-angle gate
+    // is on too), so its 7x7-window pass is skipped: k_plane_normals writes (plane normal, 1 + r) or nothing
+    const bool src_labels_only = is_plane(h) && !(g.min_ncos > 0.0f);
     auto task_of = [&](int f, int role) {
         FrameTask t;
         t.cloud = h->frames[f].cloud;
@@ -758,6 +766,15 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         if (it == plan.end()) it = plan.emplace(f, h->frames[f]).first;
         return it->second;
     };
+    auto want_normals = [&](int f, bool full) {
+        FrameHost &F = planned(f);
+        if (F.nrm_epoch == F.epoch && (F.nrm_full || !full)) return;
+        auto it = ntask_of.find(f);
+        if (it != ntask_of.end()) { if (full) { nfull[it->second] = 1; F.nrm_full = true; } return; }      // (already planned in this pass: upgrade it)
+        ntask_of[f] = ntasks.size();
+        ntasks.push_back(task_of(f, 1)); nfull.push_back(full ? 1 : 0);
+        F.nrm_epoch = F.epoch; F.nrm_full = full;
+    };
     for (int b = 0; b < B; ++b) {
         const int fs = h->pair_src[b], ft = h->pair_tgt[b];
         {
@@ -766,12 +783,12 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
                 tasks.push_back(task_of(fs, 0));
                 S.src_epoch = S.epoch; S.src_row0 = h->row0; S.src_row1 = h->row1;
             }
-            if (src_normals && S.nrm_epoch != S.epoch) { ntasks.push_back(task_of(fs, 1)); S.nrm_epoch = S.epoch; }
+            if (src_normals) want_normals(fs, !src_labels_only);
         }
         {
             FrameHost &T = planned(ft);
             if (T.tgt_epoch != T.epoch || T.tgt_normals != use_normals) {
-                if (use_normals && T.nrm_epoch != T.epoch) { ntasks.push_back(task_of(ft, 1)); T.nrm_epoch = T.epoch; }
+                if (use_normals) want_normals(ft, true);
                 tasks.push_back(task_of(ft, 1));
                 T.tgt_epoch = T.epoch; T.tgt_normals = use_normals;
             }
@@ -793,10 +810,12 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         pp.assoc = h->assoc ? h->assoc + (size_t)b * 8 : nullptr;
     }
     const bool plane_only = is_plane(h) && (h->p.plane_flags & SLAM3D_PLANE_ONLY);
-    for (size_t k0 = 0; k0 < ntasks.size() && !plane_only; k0 += FRAME_ARGS) {
+    std::vector<FrameTask> wtasks;                 // the normals tasks that need the 7x7-window pass
+    for (size_t k = 0; k < ntasks.size(); ++k) if (nfull[k] && !plane_only) wtasks.push_back(ntasks[k]);
+    for (size_t k0 = 0; k0 < wtasks.size(); k0 += FRAME_ARGS) {
         FrameTasks a;
-        const int n = (int)std::min<size_t>(FRAME_ARGS, ntasks.size() - k0);
-        for (int k = 0; k < n; ++k) a.t[k] = ntasks[k0 + k];
+        const int n = (int)std::min<size_t>(FRAME_ARGS, wtasks.size() - k0);
+        for (int k = 0; k < n; ++k) a.t[k] = wtasks[k0 + k];
         dim3 grid((g.W + NRM_BX - 1) / NRM_BX, (g.H + NRM_BY - 1) / NRM_BY, n);
         if (g.win_r == 3) hipLaunchKernelGGL(k_normals<3>, grid, dim3(NRM_BX, NRM_BY), 0, s, a, g);
         else hipLaunchKernelGGL(k_normals<0>, grid, dim3(NRM_BX, NRM_BY), 0, s, a, g);
@@ -805,13 +824,19 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         // spec S2p: the frames that need normals are segmented together (scratch slot k = task k), then every labelled pixel takes
         // its plane's normal and the frame's plane table is recorded
         const int nt = (int)ntasks.size();          // <= maxF: one task per frame at most
-        for (int k0 = 0; k0 < nt; k0 += PTR_ARGS) {
+        bool ptrs_same = (int)h->pl_ptrs_up.size() >= nt;     // (a stream of pairs through the same two frame slots names the same clouds every time)
+        for (int k = 0; k < nt && ptrs_same; ++k) ptrs_same = h->pl_ptrs_up[k] == ntasks[k].cloud;
+        for (int k0 = 0; k0 < nt && !ptrs_same; k0 += PTR_ARGS) {
             PtrArgs a;
             const int n = std::min(PTR_ARGS, nt - k0);
             for (int k = 0; k < n; ++k) a.p[k] = ntasks[k0 + k].cloud;
             hipLaunchKernelGGL(k_set_ptrs, dim3(1), dim3(64), 0, s, h->pl_ptrs + k0, a, n);
         }
-        const int src = enqueue_segmentation(h, nt, h->pl_ptrs, h->pl_labels, h->pl_state, &h->seg_sp, s);
+        if (!ptrs_same) {
+            if ((int)h->pl_ptrs_up.size() < nt) h->pl_ptrs_up.resize(nt);
+            for (int k = 0; k < nt; ++k) h->pl_ptrs_up[k] = ntasks[k].cloud;
+        }
+        const int src = enqueue_segmentation(h, nt, h->pl_ptrs, h->pl_labels, h->pl_state, &h->seg_sp, s, /* final launch */ false);
         if (src) return src;
         for (int k0 = 0; k0 < nt; k0 += PLANE_ARGS) {
             PlaneTasks a;
@@ -820,8 +845,9 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
                 const size_t f = (size_t)(ntasks[k0 + k].nrm - h->f_nrm) / (size_t)h->N;
                 a.t[k].lab = h->pl_labels + (size_t)(k0 + k) * h->N; a.t[k].st = h->pl_state + (k0 + k);
                 a.t[k].nrm = ntasks[k0 + k].nrm; a.t[k].out = h->f_planes + f;
+                a.t[k].window = (nfull[k0 + k] && !plane_only) ? 1 : 0;
             }
-            hipLaunchKernelGGL(k_plane_normals, dim3((h->N + 255) / 256, n), dim3(256), 0, s, a, h->N, plane_only ? 1 : 0);
+            hipLaunchKernelGGL(k_plane_normals, dim3((h->N + 255) / 256, n), dim3(256), 0, s, a, h->N, h->seg_sp.max_planes, h->seg_sp.plane_percent);
         }
     }
     for (size_t k0 = 0; k0 < tasks.size(); k0 += FRAME_ARGS) {
@@ -849,16 +875,15 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
             const int n = B - b0 < TINIT_ARGS ? B - b0 : TINIT_ARGS;
             memcpy(ti.T, T_init + (size_t)b0 * 16, sizeof(double) * 16 * n);
             hipLaunchKernelGGL(k_pair_init, dim3(n), dim3(256), 0, s, ti, 1, b0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters, h->nsets,
-                               stamp_ring_of(h, b0 == 0), (count_run && b0 == 0) ? h->dev_runs : nullptr);
+                               stamp_ring_of(h, b0 == 0), (count_run && b0 == 0) ? h->dev_runs : nullptr, g.pair_gate ? h->d_pairs : nullptr);
         }
     } else {
         TinitArgs ti;
         memset(&ti, 0, sizeof ti);
         hipLaunchKernelGGL(k_pair_init, dim3(B), dim3(256), 0, s, ti, 0, 0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters, h->nsets,
-                               stamp_ring_of(h), count_run ? h->dev_runs : nullptr);
+                               stamp_ring_of(h), count_run ? h->dev_runs : nullptr, g.pair_gate ? h->d_pairs : nullptr);
     }
     if (count_run) h->run_counted = true;
-    if (g.pair_gate) hipLaunchKernelGGL(k_plane_assoc, dim3(B), dim3(64), 0, s, h->d_pairs, h->Tcur);      // (behind k_set_pairs and k_pair_init)
     if (nn_mode_of(h) != SLAM3D_NN_TILES) {
         HIPCHK(h, hipMemsetAsync(h->best, 0xFF, sizeof(unsigned long long) * (size_t)B * tg.nslots, s));
         hipLaunchKernelGGL(k_compact, dim3(2, B), dim3(1024), 0, s, h->d_pairs, h->src_c, h->tgt_c, h->ccounts, g, tg,

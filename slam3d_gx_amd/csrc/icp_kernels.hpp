@@ -537,9 +537,41 @@ struct TinitArgs { double T[TINIT_ARGS][16]; };
 __global__ __launch_bounds__(256) void k_pair_init(TinitArgs ti, int has_T, int b0, double *__restrict__ Tcur,
                                                   double *__restrict__ trace_T, int *__restrict__ flags,
                                                   long long *__restrict__ acc, unsigned int *__restrict__ ticket, int iters, int nsets,
-                                                  StampRing sr /* rows null: no stamps */, int *__restrict__ runs /* the device's run counter; non-null (slam3d_icp_run): one more run in flight */)
+                                                  StampRing sr /* rows null: no stamps */, int *__restrict__ runs /* the device's run counter; non-null (slam3d_icp_run): one more run in flight */,
+                                                  const PairPtrs *__restrict__ gate_pairs /* SLAM3D_PLANE_PAIR_GATE: the pair table (spec S4p association); else null */)
 {
     const int k = blockIdx.x, b = b0 + k, lane = threadIdx.x;
+    if (gate_pairs && lane >= 64 && lane < 72) {
+        // spec S4p, association (oracle/icp_oracle.c::orc_plane_assoc; slam3d_plane_gate's arithmetic): source plane i carried by the run's
+        // initial pose, nearest target plane on (a, b, c, d) -- GraphicEnd::match, src/GraphicEnd.cpp:459-484, exact.  (Round 5: here
+        // instead of a launch of its own; the planes of both frames were written by launches before this one.)
+        const int i = lane - 64;
+        const PairPtrs &pp = gate_pairs[b];
+        int best = -1;
+        if (pp.spl && pp.tpl && i < pp.spl->n) {
+            double T[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) T[q] = has_T ? ti.T[k % TINIT_ARGS][q] : ((q % 5 == 0) ? 1.0 : 0.0);
+            const FramePlane &P = pp.spl->pl[i];
+            const double pa = P.a, pb = P.b, pc = P.c, pd = P.d;
+            double n0 = (T[0] * pa + T[1] * pb) + T[2] * pc, n1 = (T[4] * pa + T[5] * pb) + T[6] * pc, n2 = (T[8] * pa + T[9] * pb) + T[10] * pc;
+            double dd = pd - ((n0 * T[3] + n1 * T[7]) + n2 * T[11]);
+            if (dd < 0.0) { n0 = -n0; n1 = -n1; n2 = -n2; dd = -dd; }        // src/GraphicEnd.cpp:383-387
+            const float m0 = (float)n0, m1 = (float)n1, m2 = (float)n2, m3 = (float)dd;
+            float bd = __int_as_float(0x7f800000);
+            const int n2p = pp.tpl->n;
+            for (int j = 0; j < n2p; ++j) {
+                const FramePlane &Q = pp.tpl->pl[j];
+                float d2 = 0.0f, e;
+                e = m0 - Q.a; d2 = __fmaf_rn(e, e, d2);
+                e = m1 - Q.b; d2 = __fmaf_rn(e, e, d2);
+                e = m2 - Q.c; d2 = __fmaf_rn(e, e, d2);
+                e = m3 - Q.d; d2 = __fmaf_rn(e, e, d2);
+                if (d2 < bd) { bd = d2; best = j; }
+            }
+        }
+        if (pp.assoc) pp.assoc[i] = best;
+    }
     if (runs && k == 0 && lane == 0) atomicAdd(runs, 1);
     if (sr.rows && k == 0 && lane < 64) {       // launch stamps (opt-in, first wave): this run takes the next slot of the ring; start = min -> ~0, end = max -> 0
         const unsigned int run = (*sr.seq + 1u) % (unsigned int)sr.ring;

@@ -118,7 +118,26 @@ __device__ __forceinline__ SegHyp seg_make_hyp(const float4 *__restrict__ cloud,
     if (h < sp.hypotheses) {
         unsigned long long x = sp.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(1 + r * 4096 + h);
         int pick0 = -1, pick1 = -1, pick2 = -1, np = 0;
-        for (int t = 0; t < SEG_DRAWS && np < 3; ++t) {
+        // The draws are a counter-based sequence: the first SEG_AHEAD of them are formed at once and their labels fetched TOGETHER (one
+        // round trip instead of up to one per draw -- a count launch's head was three to five dependent trips), then walked in order with
+        // the spec's acceptance rule; the rare hypothesis that needs more draws goes on one by one.  Same picks by construction.
+        constexpr int SEG_AHEAD = 8;
+        int px_[SEG_AHEAD], lb_[SEG_AHEAD];
+#pragma unroll
+        for (int t = 0; t < SEG_AHEAD; ++t) {
+            x += 0x9E3779B97F4A7C15ull;
+            const unsigned long long o = seg_mix64(x);
+            px_[t] = (int)(((o >> 32) * (unsigned long long)N) >> 32);
+        }
+#pragma unroll
+        for (int t = 0; t < SEG_AHEAD; ++t) lb_[t] = lab[px_[t]];
+#pragma unroll
+        for (int t = 0; t < SEG_AHEAD; ++t) {
+            const int pix = px_[t];
+            const bool take = np < 3 && lb_[t] == -1 && !((np > 0 && pick0 == pix) || (np > 1 && pick1 == pix));
+            if (take) { if (np == 0) pick0 = pix; else if (np == 1) pick1 = pix; else pick2 = pix; ++np; }
+        }
+        for (int t = SEG_AHEAD; t < SEG_DRAWS && np < 3; ++t) {
             x += 0x9E3779B97F4A7C15ull;
             const unsigned long long o = seg_mix64(x);
             const int pix = (int)(((o >> 32) * (unsigned long long)N) >> 32);
@@ -195,6 +214,15 @@ __global__ __launch_bounds__(SEG_BLOCK) void k_seg_count(const float4 *const *__
     const int h0 = blockIdx.z * SEG_HGROUP, h1 = min(H, h0 + SEG_HGROUP);
     __shared__ SegHyp hy_sh[SEG_HGROUP];
     __shared__ int bc[SEG_H];
+    // this thread's points first: their loads are in flight while the head below draws the hypotheses (dependent trips of its own)
+    float4 q[SEG_PTS];
+    bool live[SEG_PTS];
+#pragma unroll
+    for (int k = 0; k < SEG_PTS; ++k) {
+        const int i = (blockIdx.x * SEG_PTS + k) * SEG_BLOCK + threadIdx.x;
+        live[k] = i < N && lab[i] == -1;
+        q[k] = i < N ? cloud[i] : make_float4(0, 0, 0, 0);
+    }
     if constexpr (FUSED) {
         int plane_closed, plane_count;
         SegRound c = seg_open_round(s, r, sp.percent, plane_closed, plane_count);
@@ -218,14 +246,6 @@ __global__ __launch_bounds__(SEG_BLOCK) void k_seg_count(const float4 *const *__
         if (threadIdx.x < SEG_HGROUP) hy_sh[threadIdx.x] = s.hyp[h0 + threadIdx.x];
     }
     if (threadIdx.x < SEG_H) bc[threadIdx.x] = 0;
-    float4 q[SEG_PTS];
-    bool live[SEG_PTS];
-#pragma unroll
-    for (int k = 0; k < SEG_PTS; ++k) {
-        const int i = (blockIdx.x * SEG_PTS + k) * SEG_BLOCK + threadIdx.x;
-        live[k] = i < N && lab[i] == -1;
-        q[k] = live[k] ? cloud[i] : make_float4(0, 0, 0, 0);
-    }
     __syncthreads();
     // lane l < SEG_HGROUP holds hypothesis h0 + l; the loop broadcasts it with v_readlane (no dependent scalar loads)
     SegHyp mh = hy_sh[lane < SEG_HGROUP ? lane : 0];
@@ -490,20 +510,26 @@ __global__ __launch_bounds__(64) void k_fit_refine(FitState *__restrict__ st, in
 // toward the camera like the window normals --, a pixel on no plane keeps the 7x7-window normal k_normals left there with
 // w = 0.75 ("a normal, no plane"; plane_only: nothing), and the frame's plane table is recorded for the pair gate / the caller.
 // oracle/icp_oracle.c::orc_plane_normals.  grid (ceil(N / 256), tasks), block 256
-struct PlaneTask { const int *lab; const SegState *st; float4 *nrm; FramePlanes *out; };
+struct PlaneTask { const int *lab; const SegState *st; float4 *nrm; FramePlanes *out; int window, pad; };      // window: pixels on no plane keep the 7x7-window normal already in nrm
 constexpr int PLANE_ARGS = 32;
 struct PlaneTasks { PlaneTask t[PLANE_ARGS]; };
-__global__ __launch_bounds__(256) void k_plane_normals(PlaneTasks a, int N, int plane_only)
+__global__ __launch_bounds__(256) void k_plane_normals(PlaneTasks a, int N, int rounds, float percent)
 {
     const PlaneTask &t = a.t[blockIdx.y];
     const SegState &s = *t.st;
-    const int np = s.nplanes;
+    // the bookkeeping of the last round (what k_seg_final does for slam3d_segment_planes*): values only, every block the same
+    int plane_closed, plane_count;
+    const SegRound fin = seg_open_round(s, rounds, percent, plane_closed, plane_count);
+    const int np = fin.nplanes;
     if (blockIdx.x == 0 && threadIdx.x <= SEG_MAXP) {
         if (threadIdx.x == SEG_MAXP) t.out->n = np;
         else {
             const SegPlane &q = s.planes[threadIdx.x];
             FramePlane o = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0 };
-            if ((int)threadIdx.x < np) { o.a = q.a; o.b = q.b; o.c = q.c; o.d = q.d; o.cx = q.cx; o.cy = q.cy; o.cz = q.cz; o.count = q.count; }
+            if ((int)threadIdx.x < np) {
+                o.a = q.a; o.b = q.b; o.c = q.c; o.d = q.d; o.cx = q.cx; o.cy = q.cy; o.cz = q.cz;
+                o.count = (int)threadIdx.x == plane_closed ? plane_count : q.count;
+            }
             t.out->pl[threadIdx.x] = o;
         }
     }
@@ -514,44 +540,14 @@ __global__ __launch_bounds__(256) void k_plane_normals(PlaneTasks a, int N, int 
     if (r >= 0 && r < np) {
         const SegPlane &q = s.planes[r];
         o = make_float4(q.a, q.b, q.c, (float)(1 + r));
-    } else if (!plane_only) {
+    } else if (t.window) {
         const float4 w = t.nrm[i];
         if (w.w > 0.5f) o = make_float4(w.x, w.y, w.z, 0.75f);
     }
     t.nrm[i] = o;
 }
 
-// spec S4p, association (oracle/icp_oracle.c::orc_plane_assoc; slam3d_plane_gate's arithmetic): the planes of the source frame
-// carried by the run's initial pose (Tcur right after k_pair_init), matched to the target frame's planes by the squared L2
-// distance on (a, b, c, d) -- GraphicEnd::match, src/GraphicEnd.cpp:459-484, exact.  grid (B), block 64: lane i = source plane i
-__global__ __launch_bounds__(64) void k_plane_assoc(const PairPtrs *__restrict__ pairs, const double *__restrict__ Tcur)
-{
-    const int b = blockIdx.x, i = threadIdx.x;
-    if (i >= 8) return;
-    const PairPtrs &pp = pairs[b];
-    int best = -1;
-    if (pp.spl && pp.tpl && i < pp.spl->n) {
-        const double *__restrict__ T = Tcur + b * 16;
-        const FramePlane &P = pp.spl->pl[i];
-        const double pa = P.a, pb = P.b, pc = P.c, pd = P.d;
-        double n0 = (T[0] * pa + T[1] * pb) + T[2] * pc, n1 = (T[4] * pa + T[5] * pb) + T[6] * pc, n2 = (T[8] * pa + T[9] * pb) + T[10] * pc;
-        double dd = pd - ((n0 * T[3] + n1 * T[7]) + n2 * T[11]);
-        if (dd < 0.0) { n0 = -n0; n1 = -n1; n2 = -n2; dd = -dd; }        // src/GraphicEnd.cpp:383-387
-        const float m0 = (float)n0, m1 = (float)n1, m2 = (float)n2, m3 = (float)dd;
-        float bd = __int_as_float(0x7f800000);
-        const int n2p = pp.tpl->n;
-        for (int j = 0; j < n2p; ++j) {
-            const FramePlane &Q = pp.tpl->pl[j];
-            float d2 = 0.0f, e;
-            e = m0 - Q.a; d2 = __fmaf_rn(e, e, d2);
-            e = m1 - Q.b; d2 = __fmaf_rn(e, e, d2);
-            e = m2 - Q.c; d2 = __fmaf_rn(e, e, d2);
-            e = m3 - Q.d; d2 = __fmaf_rn(e, e, d2);
-            if (d2 < bd) { bd = d2; best = j; }
-        }
-    }
-    if (pp.assoc) pp.assoc[i] = best;
-}
+// (spec S4p's association of the pair gate runs inside k_pair_init, icp_kernels.hpp.)
 
 constexpr int PTR_ARGS = 32;
 struct PtrArgs { const float4 *p[PTR_ARGS]; };
