@@ -82,6 +82,36 @@ def test_hip_unorganized_icp_equals_the_oracle(gpu_lib, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["auto", "valu"])
+def test_hip_unorganized_icp_does_not_depend_on_the_order_of_the_points(gpu_lib, mode):
+    """A size-independent property with no oracle in the chain: a point list has no order, so shuffling the source records (and
+    scattering invalid records among them), or the target records, changes no bit of the pose, the sums or any iterate -- every
+    correspondence is found per point by an exact search, and the totals are integer sums (spec S4).  Only the indices move with
+    the targets' positions.  (coarse_iterations = 0: S4c's leading iterations take every fourth TILE of 64 consecutive source
+    records, which is a function of the order by definition.)"""
+    from slam3d_gx_amd import capi
+    v1, v2 = kinect_voxel_clouds()
+    rng = np.random.default_rng(5)
+    W = len(v1) + 500
+    intr = synth.Intrinsics(width=W, height=1)
+    a, b = np.ascontiguousarray(pad(v1, len(v1))), np.ascontiguousarray(pad(v2, len(v2)))
+    ps, pt = rng.permutation(len(v1)), rng.permutation(len(v2))
+    holes = np.full((1, W, 4), np.nan, np.float32)                     # the source again, shuffled, with 500 invalid records in between
+    holes[0, np.sort(rng.choice(W, len(v1), replace=False))] = a[0, ps]
+    nn = capi.NN_AUTO if mode == "auto" else capi.NN_BRUTE_VALU
+    with capi.IcpHandle(capi.default_params(intr, iterations=20, nn_mode=nn, estimator=capi.EST_SVD, coarse_iterations=0)) as h:
+        r0 = h.align(a, b); T0, S0 = h.get_trace(0); i0, d0 = h.get_correspondences(0)
+        r1 = h.align(np.ascontiguousarray(a[:, ps]), b); T1, S1 = h.get_trace(0)
+        r2 = h.align(holes, b); T2, S2 = h.get_trace(0)
+        r3 = h.align(a, np.ascontiguousarray(b[:, pt])); T3, S3 = h.get_trace(0); i3, d3 = h.get_correspondences(0)
+    assert r0["status"] == 0 and r0["n_src"] == len(v1) and r2["n_src"] == len(v1)
+    for r, T, S in ((r1, T1, S1), (r2, T2, S2), (r3, T3, S3)):
+        assert np.array_equal(T, T0) and np.array_equal(S, S0)
+        assert np.array_equal(r["T"], r0["T"]) and r["inliers"] == r0["inliers"] and r["norm"] == r0["norm"]
+    assert np.array_equal(d3.view(np.uint32), d0.view(np.uint32)) and np.array_equal(pt[i3[i3 >= 0]], i0[i0 >= 0])
+
+
+@pytest.mark.gpu
 def test_unorganized_handles_refuse_window_estimators(gpu_lib):
     from slam3d_gx_amd import capi
     intr = synth.Intrinsics(width=5000, height=1)

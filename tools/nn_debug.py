@@ -19,7 +19,7 @@ else:
     pr = synth.make_pair(seed, **(dict(noise_sigma=0.0012, hole_block=8, hole_prob=0.25) if os.environ.get("NNDBG_BMD") else {}))
 s4 = synth.backproject_numpy(pr.depth_src, pr.intr); t4 = synth.backproject_numpy(pr.depth_tgt, pr.intr)
 for it in (1, iters):
-    with capi.IcpHandle(capi.default_params(pr.intr, iterations=it)) as h:
+    with capi.IcpHandle(capi.default_params(pr.intr, iterations=it, estimator=int(os.environ.get("NNDBG_EST", "0")), plane_flags=int(os.environ.get("NNDBG_FLAGS", "0")))) as h:
         h.align_depth_batch([pr.depth_src], [pr.depth_tgt])      # depth inputs: the projective window search takes part
         d = h.get_nn_debug()
     act = d[:, 4] > 0
