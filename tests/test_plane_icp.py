@@ -212,6 +212,50 @@ def test_plane_icp_batch_frames_seg_params_and_every_nn_mode(gpu_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("min_cos", [0.0, 0.5])
+def test_plane_icp_resident_frames_change_roles(gpu_lib, min_cos):
+    """Resident frames under the pair gate: a frame that is only a SOURCE is segmented but gets no window normals (labels are all the
+    gate needs -- unless min_normal_cos compares source normals); the same frame as a TARGET later must then be completed, a former
+    target serves as a source as it is, two pairs of one launch share frames in both roles, and a frame whose contents are replaced
+    is rebuilt.  Every run equals the oracle's run on the two clouds, whatever the frames were used for before."""
+    from slam3d_gx_amd import capi
+    (pr, a, b), (_, c, d) = _pair(1000, 320, 240), _pair(1001, 320, 240)
+    clouds = {0: a, 1: b, 2: c}
+    po = O.params(pr.intr, estimator=2, iterations=5, nn_method=1, plane_pair_gate=1, min_normal_cos=min_cos)
+    want = {}
+    def oracle(i, j):
+        if (i, j) not in want:
+            want[(i, j)] = O.icp(clouds[i], clouds[j], po)
+        return want[(i, j)]
+    with capi.IcpHandle(capi.default_params(pr.intr, estimator=capi.EST_PLANE, iterations=5, max_batch=2, extra_frames=3, plane_flags=capi.PLANE_PAIR_GATE,
+                                            min_normal_cos=min_cos)) as h:
+        f0 = h.first_free_frame()
+        for k, cl in clouds.items():
+            h.frame_set_cloud_host(f0 + k, cl)
+        def run(pairs):
+            for slot, (i, j) in enumerate(pairs):
+                h.set_pair(slot, f0 + i, f0 + j)
+            h.run(len(pairs)); rs = h.fetch_results(len(pairs))
+            for slot, (i, j) in enumerate(pairs):
+                ro = oracle(i, j)
+                Tt, St = h.get_trace(slot)
+                assert np.array_equal(Tt, ro["T_trace"]) and np.array_equal(St, ro["sums_trace"]), (pairs, slot)
+                assert rs[slot]["status"] == ro["status"] and rs[slot]["inliers"] == ro["inliers"]
+        run([(0, 1)])                   # 0: source only, 1: target
+        run([(1, 2)])                   # the former target as a source
+        run([(2, 0)])                   # the labels-only source as a target: its normals are completed now
+        run([(0, 1), (1, 0)])           # both roles in one launch
+        _, planes, _ = O.plane_normals(clouds[0], O.params(pr.intr, estimator=2))
+        got = h.get_frame_planes(f0)
+        assert len(got) == len(planes) and all(np.array_equal(g["coeff"], q[:4]) for g, q in zip(got, planes))
+        clouds[0] = d                   # new contents for frame 0: everything of it is rebuilt
+        want.clear()
+        h.frame_set_cloud_host(f0, d)
+        run([(0, 2)])
+        run([(1, 0)])
+
+
+@pytest.mark.gpu
 def test_plane_flags_are_validated(gpu_lib):
     from slam3d_gx_amd import capi
     intr = synth.Intrinsics.scaled(160, 120)

@@ -6,7 +6,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slam3d_gx_amd import capi, synth
 
-pr = synth.make_pair(1000, 640, 480)
+pr = synth.make_pair(1000, 640, 480, **(dict(noise_sigma=0.0012, hole_block=8, hole_prob=0.25) if os.environ.get("QB_BMD") else {}))
 s4 = synth.backproject_numpy(pr.depth_src, pr.intr); t4 = synth.backproject_numpy(pr.depth_tgt, pr.intr)
 for cfg in (sys.argv[1:] or [""]):
     keys = []
