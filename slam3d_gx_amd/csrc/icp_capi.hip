@@ -680,23 +680,25 @@ static int enqueue_segmentation(slam3d_icp_handle *h, int B, const float4 **ptrs
 {
     const int N = h->N;
     const SegParams P = { sp->distance_threshold, sp->plane_percent, sp->max_planes, sp->hypotheses, sp->seed };
-    const dim3 pg((N + SEG_BLOCK * SEG_PTS - 1) / (SEG_BLOCK * SEG_PTS), B);
+    const int pts = B <= 2 ? SEG_PTS : SEG_PTS_BATCH;
+    const dim3 pg((N + SEG_BLOCK * pts - 1) / (SEG_BLOCK * pts), B);
     HIPCHK(h, hipMemsetAsync(st, 0, sizeof(SegState) * B, s));
-    hipLaunchKernelGGL(k_seg_init, pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, h->g.zmax);
+    if (B <= 2) hipLaunchKernelGGL(k_seg_init<SEG_PTS>, pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, h->g.zmax);
+    else hipLaunchKernelGGL(k_seg_init<SEG_PTS_BATCH>, pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, h->g.zmax);
     for (int r = 0; r < P.max_planes; ++r) {
         const dim3 cg(pg.x, pg.y, (P.hypotheses + SEG_HGROUP - 1) / SEG_HGROUP);
         if (B <= 2) {
             // a frame alone is bound by launch latency: three launches per round -- bookkeeping + hypotheses + consensus | moments | refinement + labels
-            hipLaunchKernelGGL(k_seg_count<true>, cg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P, r);
-            hipLaunchKernelGGL(k_seg_moments, pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P.hypotheses, r);
-            hipLaunchKernelGGL(k_seg_label<true>, pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P.hypotheses, P.thr, r);
+            hipLaunchKernelGGL((k_seg_count<true, SEG_PTS>), cg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P, r);
+            hipLaunchKernelGGL(k_seg_moments<SEG_PTS>, pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P.hypotheses, r);
+            hipLaunchKernelGGL((k_seg_label<true, SEG_PTS>), pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P.hypotheses, P.thr, r);
         } else {
             // a batch is bound by throughput: the heads run once per frame (five launches per round)
             hipLaunchKernelGGL(k_seg_hyp, dim3(B), dim3(64), 0, s, ptrs_dev, lab, st, N, P, r);
-            hipLaunchKernelGGL(k_seg_count<false>, cg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P, r);
-            hipLaunchKernelGGL(k_seg_moments, pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P.hypotheses, r);
+            hipLaunchKernelGGL((k_seg_count<false, SEG_PTS_BATCH>), cg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P, r);
+            hipLaunchKernelGGL(k_seg_moments<SEG_PTS_BATCH>, pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P.hypotheses, r);
             hipLaunchKernelGGL(k_seg_refine, dim3(B), dim3(64), 0, s, st, P.hypotheses, r);
-            hipLaunchKernelGGL(k_seg_label<false>, pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P.hypotheses, P.thr, r);
+            hipLaunchKernelGGL((k_seg_label<false, SEG_PTS_BATCH>), pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, P.hypotheses, P.thr, r);
         }
     }
     if (final_launch) hipLaunchKernelGGL(k_seg_final, dim3(B), dim3(1), 0, s, st, P.max_planes, P.percent);
