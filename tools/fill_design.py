@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Rewrites the round-4 column of DESIGN.md section 7 from the committed bench lines (profiles/r04_bench.json,
-profiles/r04_voxel_bench.json), so that the table is a copy of the measured files, not a transcription.
+"""Rewrites the round-5 column of DESIGN.md section 7 from the committed bench lines (profiles/r05_bench.json,
+profiles/r05_voxel_bench.json), so that the table is a copy of the measured files, not a transcription.
 usage: tools/fill_design.py [n_gpu_tests]"""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
-v = json.load(open(os.path.join(ROOT, "profiles", "r04_voxel_bench.json")))
+d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+v = json.load(open(os.path.join(ROOT, "profiles", "r05_voxel_bench.json")))
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
 
@@ -21,24 +21,44 @@ k = lambda x: f"{x / 1e3:.1f} k"
 per = d["nn_ms_per_iteration"]
 rb = d["roofline_bruteforce"]
 rp = d["real_pair"]
+pn = d["plane_normals"]
+legs = ("dep1_to_dep2_wide_baseline", "dep1_to_dep1_perturbed", "dep2_to_dep2_perturbed")
 row("**headline**", f"**{d['value']:,.0f} ({1e3 * 20 / d['value']:.3f} ms per pair)**")
+b = d["low_noise_surrogate"]
+row("the low-noise surrogate", f"{b['value']:,.0f} ({b['ratio_to_headline']:.2f}×; n_tgt {b['n_tgt']:,})")
+a = d["all_sources_every_iteration"]
+row("every iteration on every source", f"{a['value']:,.0f} ({a['ratio_to_headline']:.2f}×)")
 row("one alignment at a time", f"**{d['single_step_latency_ms']:.3f} ms**")
 row("NN launch per iteration", " / ".join(f"{1e3 * x:.0f}" for x in per[:4]) + f", {1e3 * min(per[4:8]):.0f}–{1e3 * max(per[4:8]):.0f}, {1e3 * min(per[8:]):.0f}–{1e3 * max(per[8:]):.0f}")
-b = d["baseline_md_workload"]
-row("BASELINE.md §4's workload", f"{b['value']:,.0f} ({b['ratio_to_headline']:.2f}×; n_tgt {b['n_tgt']:,})")
-row("the reference's Kinect frames", " / ".join(k(rp[n]["value"]) for n in ("dep1_to_dep2_wide_baseline", "dep1_to_dep1_perturbed", "dep2_to_dep2_perturbed")))
+row("**`SLAM3D_EST_PLANE` + pair gate**", f"{pn['value']:,.0f} ({pn['ratio_to_headline']:.2f}×; n_tgt {pn['n_tgt']:,}; NN launch {pn['nn_launch_us']:.0f} µs; preprocessing {pn['preprocess_us']:.0f} µs)")
+row("the reference's Kinect frames, window normals", " / ".join(k(rp[n]["value"]) for n in legs))
+
+
+def resid(x):
+    if "residual_rot_rad" in x:
+        return f" ({1e3 * x['residual_rot_rad']:.1f} mrad / {1e3 * x['residual_trans_m']:.1f} mm)"
+    return f" (status {x['status']})"
+
+
+row("the same under `SLAM3D_EST_PLANE` + gate", " / ".join(k(pn["real_pair"][n]["value"]) + resid(pn["real_pair"][n]) for n in legs)
+    + f"; preprocessing {pn['real_pair'][legs[1]]['preprocess_us']:.0f} µs")
 row("config 3: 64 pairs per launch", f"**{d['config3']['value']:,.0f}**")
 t = d["two_pairs_per_launch"]
 row("the same stream with two pairs", f"{t['value']:,.0f} ({t['ratio_to_headline']:.2f}×)")
 row("config 5 on 1 GPU", f"{d['config5']['value']:,.0f}")
 vf = rb.get("valu_filter_kernel", {})
-row("full scan, 640×480 (ms per launch)", f"**{rb['launch_ms']:.2f}** / {rb['f32_mfma_kernel']['launch_ms']:.2f} / {rb['valu_kernel']['launch_ms']:.2f}" + (f" ({vf['launch_ms']:.2f} with the VALU filter)" if vf else ""))
-row("the same as contraction rates", f"{rb['achieved']:,.0f} ({100 * rb['frac']:.0f} %) / **{rb['equivalent_f32_contraction_tflops']:.0f} ({100 * rb['equivalent_frac_of_f32_peak']:.0f} %)** / "
-    f"{rb['f32_mfma_kernel']['achieved']:.0f} ({100 * rb['f32_mfma_kernel']['frac']:.0f} %) / {rb['valu_kernel']['achieved']:.0f} ({100 * rb['valu_kernel']['frac']:.0f} %)")
-row("f-1 voxel grid per 640×480 frame", f"{1e3 * v['ms_per_step']:.1f} µs (26.7)")
+row("full scan, 640×480 (ms per launch)", f"**{rb['launch_ms']:.2f}** / {rb['f32_mfma_kernel']['launch_ms']:.2f} / {rb['valu_kernel']['launch_ms']:.2f}"
+    + (f" ({vf['launch_ms']:.2f} with the VALU filter)" if vf else "") + f" — {d['config']['n_src'][0] / 1e3:.0f} k × {d['config']['n_tgt'][0] / 1e3:.1f} k pairs")
+row("the same as contraction rates", f"{rb['achieved']:,.0f} ({100 * rb['frac']:.0f} %) / **{rb['equivalent_f32_contraction_tflops']:.0f} ({100 * rb['equivalent_frac_of_f32_peak']:.0f} %)**")
+vi = d["voxel_icp"]
+u = vi["dep1_to_dep2"]
+row("unorganized clouds, 16,034 × 14,758 points", f"{k(u['value'])} / {k(u['icp_only_value'])} it/s (CPU kd-tree, {u['cpu_baseline']['cores']} threads: {k(u['cpu_baseline']['value'])})")
+vb = vi["voxel_grid_batch"]
+row("voxel grid, 64 clouds per launch sequence", f"{vb['us_per_frame']:.1f} µs per cloud ({vb['roofline']['achieved']:.0f} GB/s, {100 * vb['roofline']['frac']:.1f} % of HBM)")
+row("f-1 voxel grid per 640×480 frame, one call", f"{1e3 * v['ms_per_step']:.1f} µs")
 c = d["cpu_baseline"]
 row("CPU oracle, kd-tree", f"{c['value']:.0f} ({c['cores']} thr) / {c['single_thread_value']:.0f} it/s")
 if len(sys.argv) > 1:
     row("GPU test suite", sys.argv[1])
 open(p, "w").write(s)
-print("DESIGN.md section 7 rewritten from profiles/r04_bench.json: headline", d["value"])
+print("DESIGN.md section 7 rewritten from profiles/r05_bench.json: headline", d["value"])
