@@ -50,6 +50,7 @@ struct slam3d_icp_handle {
     PairPtrs *d_pairs = nullptr;
     float4 *src_c = nullptr, *tgt_c = nullptr;           // brute-force modes: raster-compacted lists per pair
     int *ccounts = nullptr, *corr = nullptr, *flags = nullptr;
+    int *chunk_cnt = nullptr;     // [maxB][2][ceil(N / 1024)] kept records per chunk (k_compact_count -> k_compact_scatter; brute-force modes)
     unsigned int *ticket = nullptr;
     unsigned long long *best = nullptr;
     float *cd2 = nullptr;
@@ -252,7 +253,7 @@ static void free_all(slam3d_icp_handle *h)
 {
     auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(h->f_cloud); F(h->f_nrm); F(h->f_srcT); F(h->f_tgtT); F(h->f_tbox); F(h->f_cbox); F(h->f_tq); F(h->f_scount); F(h->f_counts);
-    F(h->src_c); F(h->tgt_c); F(h->ccounts); F(h->corr); F(h->ticket);
+    F(h->src_c); F(h->tgt_c); F(h->ccounts); F(h->chunk_cnt); F(h->corr); F(h->ticket);
     F(h->flags); F(h->best); F(h->cd2); F(h->acc); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
     F(h->d_pairs); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4); F(h->corr_trace);
     F(h->d_stamps); F(h->d_stamp_seq);
@@ -396,6 +397,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     }
     A(dalloc(h->ccounts, (size_t)h->maxB * 4)); A(dalloc(h->ticket, (size_t)h->maxB));
     A(dalloc(h->corr, BS)); A(dalloc(h->flags, (size_t)h->maxB)); A(dalloc(h->cd2, BS));
+    if (brute) A(dalloc(h->chunk_cnt, (size_t)h->maxB * 2 * ((h->N + 1023) / 1024)));
     if (brute) A(dalloc(h->prevq, BS));      // (the tile search keeps 8-byte slot records instead: slot_rec)
     h->nsets = p->iterations > 0 ? p->iterations : 1;
     A(dalloc(h->acc, (size_t)h->maxB * h->nsets * ACC_R * ACC_STRIDE));
@@ -888,7 +890,9 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
     if (count_run) h->run_counted = true;
     if (nn_mode_of(h) != SLAM3D_NN_TILES) {
         HIPCHK(h, hipMemsetAsync(h->best, 0xFF, sizeof(unsigned long long) * (size_t)B * tg.nslots, s));
-        hipLaunchKernelGGL(k_compact, dim3(2, B), dim3(1024), 0, s, h->d_pairs, h->src_c, h->tgt_c, h->ccounts, g, tg,
+        const dim3 cgrid((h->N + 1023) / 1024, 2, B);
+        hipLaunchKernelGGL(k_compact_count, cgrid, dim3(1024), 0, s, h->d_pairs, h->chunk_cnt, g, use_normals, h->row0, h->row1);
+        hipLaunchKernelGGL(k_compact_scatter, cgrid, dim3(1024), 0, s, h->d_pairs, h->chunk_cnt, h->src_c, h->tgt_c, h->ccounts, g, tg,
                            use_normals, h->row0, h->row1);
         if (h->valu_filter) {
             HIPCHK(h, hipMemsetAsync(h->qmax2, 0, sizeof(unsigned int) * (size_t)B, s));
@@ -1659,6 +1663,9 @@ extern "C" int slam3d_pass_transform(slam3d_icp_handle *h, const void *points16,
     hipStream_t s = h->stream;
     Pose34 P;
     for (int k = 0; k < 12; ++k) P.m[k] = T[k];
+    // (vox_m doubles as the claim counts of the voxel grid: a device-resident call on a caller's stream may still have its scatter
+    //  launch queued -- wait for it like the next voxel call would)
+    if (h->vox_done_valid) HIPCHK(h, hipStreamWaitEvent(s, h->vox_done, 0));
     HIPCHK(h, hipMemsetAsync(h->vox_m, 0, sizeof(int), s));
     if (n > 0) {
         HIPCHK(h, hipMemcpyAsync(h->d_scratch4, points16, (size_t)n * 16, hipMemcpyHostToDevice, s));

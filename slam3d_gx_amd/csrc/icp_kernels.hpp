@@ -4,7 +4,7 @@
 //   S1 k_backproject      u16 depth -> organized float4 cloud      src/convert2PCD.cpp:54-72
 //   S2 k_normals          7x7 window covariance -> normal          src/planarFeatures.cpp:88-136 (a7)
 //   S3 k_frame_tiles      8x8-pixel tiles (one wavefront each) of a frame as source / as target + target AABBs
-//      k_compact          raster-ordered dense lists (only the full brute-force modes need them)
+//      k_compact_*        raster-ordered dense lists (only the full brute-force modes need them)
 //   S4 k_nn_tiles_acc     exact tile-pruned 1-NN fused with the normal-equation accumulation
 //      k_nn_valu          exact full brute-force 1-NN (replaces FLANN matching, src/GraphicEnd.cpp:486-520)
 //      k_accumulate       point-to-plane / Kabsch normal equations, deterministic 256-slot chunk tree
@@ -598,50 +598,86 @@ __global__ __launch_bounds__(256) void k_pair_init(TinitArgs ti, int has_T, int 
 // a run that was counted by k_pair_init but whose launches could not all be enqueued: take it out of the count again
 __global__ void k_run_uncount(int *__restrict__ runs) { if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(runs, -1); }
 
-// stable raster-order stream compaction, one 1024-thread block per (pair, src|tgt).  Only the full
-// brute-force modes use these lists.  src w = SLOT id of the pixel, tgt w = pixel index.
-__global__ __launch_bounds__(1024) void k_compact(const PairPtrs *__restrict__ pairs,
-                                                  float4 *__restrict__ src_c, float4 *__restrict__ tgt_c,
-                                                  int *__restrict__ ccounts, Geometry g, TileGrid tg,
-                                                  int use_normals, int row0, int row1)
+// stable raster-order stream compaction of the valid sources / the eligible targets of each pair.  Only the full brute-force
+// modes use these lists.  src w = SLOT id of the pixel, tgt w = pixel index.  Two launches, one 1024-thread block per chunk of 1024
+// records (round 5; one block per (pair, role) walked its 300 chunks one dependent load after the other: 327 us per 640x480 pair):
+//   k_compact_count     the chunk's number of kept records -> chunk_cnt[(b * 2 + role) * nchunks + chunk]
+//   k_compact_scatter   base = the counts of the chunks in front (<= a few hundred integers, summed by the block), then the chunk's
+//                       records at base + rank; the last chunk of a role records the total in ccounts[b * 4 + role]
+__device__ __forceinline__ bool compact_keep(const float4 *__restrict__ cloud, const float4 *__restrict__ nrm, int i, int i_end, int which,
+                                             int use_normals, float zmax, float4 &q)
+{
+    q = make_float4(0, 0, 0, 0);
+    bool ok = false;
+    if (i < i_end) {
+        q = cloud[i];
+        ok = pt_valid(q.x, q.y, q.z, zmax);
+        if (ok && which == 1 && use_normals) ok = nrm[i].w > 0.5f;
+    }
+    return ok;
+}
+// the block's kept records: rank of this thread's record among them, and their number
+__device__ __forceinline__ int compact_rank(bool ok, int &total)
 {
     __shared__ int wave_tot[16];
-    const int which = blockIdx.x, b = blockIdx.y;
-    const float4 *__restrict__ cloud = which == 0 ? pairs[b].src : pairs[b].tgt;
-    const float4 *__restrict__ nrm = pairs[b].nrm;
-    float4 *__restrict__ outp = (which == 0 ? src_c : tgt_c) + (size_t)b * g.N;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int i_begin = which == 0 ? row0 * g.W : 0;
-    const int i_end = which == 0 ? row1 * g.W : g.N;
-    int base = 0;
-    for (int t0 = i_begin; t0 < i_end; t0 += 1024) {
-        const int i = t0 + tid;
-        float4 q = make_float4(0, 0, 0, 0);
-        bool ok = false;
-        if (i < i_end) {
-            q = cloud[i];
-            ok = pt_valid(q.x, q.y, q.z, g.zmax);
-            if (ok && which == 1 && use_normals) ok = nrm[i].w > 0.5f;
-        }
-        const unsigned long long m = __ballot(ok);
-        const int prefix = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_tot[w] = __popcll(m);
-        __syncthreads();
-        int woff = 0, total = 0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(ok);
+    if (lane == 0) wave_tot[w] = __popcll(m);
+    __syncthreads();
+    int woff = 0;
+    total = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { const int c = wave_tot[k]; if (k < w) woff += c; total += c; }
-        if (ok) {
-            int tag = i;
-            if (which == 0) {
-                const int v = i / g.W, u = i - v * g.W;
-                tag = ((v / TILE_PX) * tg.ntx + u / TILE_PX) * TILE_SLOTS + (v % TILE_PX) * TILE_PX + (u % TILE_PX);
-            }
-            outp[base + woff + prefix] = make_float4(q.x, q.y, q.z, __int_as_float(tag));
-        }
-        base += total;
-        __syncthreads();
+    for (int k = 0; k < 16; ++k) { const int c = wave_tot[k]; if (k < w) woff += c; total += c; }
+    return woff + __popcll(m & ((1ull << lane) - 1ull));
+}
+// grid (nchunks, 2, B)
+__global__ __launch_bounds__(1024) void k_compact_count(const PairPtrs *__restrict__ pairs, int *__restrict__ chunk_cnt, Geometry g,
+                                                        int use_normals, int row0, int row1)
+{
+    const int chunk = blockIdx.x, which = blockIdx.y, b = blockIdx.z;
+    const int i_begin = which == 0 ? row0 * g.W : 0, i_end = which == 0 ? row1 * g.W : g.N;
+    if (i_begin + chunk * 1024 >= i_end) return;
+    float4 q;
+    int total;
+    compact_rank(compact_keep(which == 0 ? pairs[b].src : pairs[b].tgt, pairs[b].nrm, i_begin + chunk * 1024 + (int)threadIdx.x, i_end, which,
+                              use_normals, g.zmax, q), total);
+    if (threadIdx.x == 0) chunk_cnt[((size_t)b * 2 + which) * gridDim.x + chunk] = total;
+}
+__global__ __launch_bounds__(1024) void k_compact_scatter(const PairPtrs *__restrict__ pairs, const int *__restrict__ chunk_cnt,
+                                                          float4 *__restrict__ src_c, float4 *__restrict__ tgt_c,
+                                                          int *__restrict__ ccounts, Geometry g, TileGrid tg,
+                                                          int use_normals, int row0, int row1)
+{
+    __shared__ int front[16];
+    const int chunk = blockIdx.x, which = blockIdx.y, b = blockIdx.z;
+    const int i_begin = which == 0 ? row0 * g.W : 0, i_end = which == 0 ? row1 * g.W : g.N;
+    const int nch = i_end > i_begin ? (i_end - i_begin + 1023) / 1024 : 0;
+    if (chunk >= nch) {
+        if (nch == 0 && chunk == 0 && threadIdx.x == 0) ccounts[b * 4 + which] = 0;       // an empty row shard
+        return;
     }
-    if (tid == 0) ccounts[b * 4 + which] = base;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = i_begin + chunk * 1024 + tid;
+    float4 q;
+    const bool ok = compact_keep(which == 0 ? pairs[b].src : pairs[b].tgt, pairs[b].nrm, i, i_end, which, use_normals, g.zmax, q);
+    int pre = 0;
+    for (int c = tid; c < chunk; c += 1024) pre += chunk_cnt[((size_t)b * 2 + which) * gridDim.x + c];
+    for (int o = 32; o >= 1; o >>= 1) pre += __shfl_xor(pre, o);
+    if (lane == 0) front[w] = pre;
+    int total;
+    const int rank = compact_rank(ok, total);            // (its barrier also publishes front[])
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) base += front[k];
+    if (ok) {
+        int tag = i;
+        if (which == 0) {
+            const int v = i / g.W, u = i - v * g.W;
+            tag = ((v / TILE_PX) * tg.ntx + u / TILE_PX) * TILE_SLOTS + (v % TILE_PX) * TILE_PX + (u % TILE_PX);
+        }
+        ((which == 0 ? src_c : tgt_c) + (size_t)b * g.N)[base + rank] = make_float4(q.x, q.y, q.z, __int_as_float(tag));
+    }
+    if (chunk == nch - 1 && tid == 0) ccounts[b * 4 + which] = base + total;
 }
 
 // ------------------------------------------------------------------------------------ S4
