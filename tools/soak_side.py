@@ -26,7 +26,7 @@ for case in range(n_cases):
     T = synth.pose_from_seed(seed, max_angle_deg=40.0, max_trans=3.0)
     to, _ = O.pass_transform(c, T, 5.0)
     v2 = O.voxel_grid_only(to, leaf)
-    with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1)) as h:
+    with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1, estimator=capi.EST_SVD)) as h:      # (no ICP here; the svd estimator has no window-moment range limit: 64 x 240 frames have a 150 degree camera)
         pg, lg = h.segment_planes(c.reshape(H, W, 4), h.seg_params(distance_threshold=thr, plane_percent=pct, max_planes=mp, hypotheses=hyp, seed=seed))
         vg = h.voxel_grid(c, leaf)
         tg, _ = h.pass_transform(c, T, 5.0)
