@@ -994,7 +994,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
     if (used_head) *used_head = head;
     if (exchange && head) {
         // Dense mode, several ranks: each rank accumulated the rows of ITS source shard into this iteration's set; summing the
-        // sets element-wise over the ranks (16 replicas x 32 int64, in place, on this stream) gives every rank the same
+        // sets element-wise over the ranks (16 replicas x 40 int64 -- 36 Gram totals, the poison word, padding --, in place, on this stream) gives every rank the same
         // integers, whose replica sum is the global total: the head of the next launch (or the final k_solve_acc) then solves
         // the identical system on every rank.  ONE exchange per iteration, no reduction or solve launch beside it.
         long long *set = h->acc + (size_t)it * ACC_R * ACC_STRIDE;
