@@ -112,6 +112,31 @@ def test_hip_unorganized_icp_does_not_depend_on_the_order_of_the_points(gpu_lib,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ns,nt", [(1, 1), (2, 5), (3, 3), (15, 17), (64, 63), (129, 16), (1000, 7), (257, 4099)])
+def test_hip_unorganized_icp_on_tiny_and_ragged_point_lists(gpu_lib, ns, nt):
+    """Edge sizes of the point-list path (fewer points than a matrix-core tile, than a wave, one more than a block; fewer than the
+    three correspondences a pose needs): status, iterates, sums and indices are the oracle's in both scan modes -- a run that cannot
+    solve says so (status != 0, identity), it does not crash or report a pose."""
+    from slam3d_gx_amd import capi
+    v1, v2 = kinect_voxel_clouds()
+    rng = np.random.default_rng(ns * 7919 + nt)
+    a, b = v1[rng.choice(len(v1), ns, replace=False)], v1[rng.choice(len(v1), nt, replace=False)]
+    W = 4200
+    intr = synth.Intrinsics(width=W, height=1)
+    Ti = synth.pose_from_seed(3, 1.0, 0.01)
+    ro = O.icp(pad(a, W), pad(b, W), O.params(intr, estimator=1, iterations=5, nn_method=0, max_corr_dist=0.5), T_init=Ti)
+    for mode in (capi.NN_AUTO, capi.NN_BRUTE_VALU):
+        with capi.IcpHandle(capi.default_params(intr, iterations=5, nn_mode=mode, estimator=capi.EST_SVD, max_corr_dist=0.5)) as h:
+            rg = h.align(np.ascontiguousarray(pad(a, ns)), np.ascontiguousarray(pad(b, nt)), Ti)
+            idx, d2 = h.get_correspondences(0)
+            Tt, St = h.get_trace(0)
+        assert rg["status"] == ro["status"] and rg["inliers"] == ro["inliers"] and rg["n_src"] == ns and rg["n_tgt"] == nt, (mode, rg["status"], ro["status"])
+        assert np.array_equal(idx, ro["idx"]) and np.array_equal(d2.view(np.uint32), ro["d2"].view(np.uint32)), mode
+        assert np.array_equal(Tt, ro["T_trace"]) and np.array_equal(St, ro["sums_trace"]), mode
+        assert np.array_equal(rg["T"], ro["T"])
+
+
+@pytest.mark.gpu
 def test_unorganized_handles_refuse_window_estimators(gpu_lib):
     from slam3d_gx_amd import capi
     intr = synth.Intrinsics(width=5000, height=1)
