@@ -256,6 +256,45 @@ def test_plane_icp_resident_frames_change_roles(gpu_lib, min_cos):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("gate", [0, 1])
+def test_plane_icp_in_dense_mode_over_row_shards(gpu_lib, gate):
+    """SLAM3D_EST_PLANE in the dense mode (one pair, the SOURCE rows sharded over ranks; both frames are segmented whole on every
+    rank: the planes are global, only the rows a rank accumulates are its own): two emulated ranks exchanging integer totals on the
+    host, and the single-call run over a host all-reduce, equal the unsharded oracle bit for bit."""
+    from slam3d_gx_amd import capi, dense, shard
+    pr, s4, t4 = _pair(1002, 320, 240)
+    iters = 6
+    ro = O.icp(s4, t4, O.params(pr.intr, estimator=2, iterations=iters, nn_method=1, plane_pair_gate=gate))
+    kw = dict(estimator=capi.EST_PLANE, plane_flags=gate, iterations=iters)
+    hs = [capi.IcpHandle(capi.default_params(pr.intr, **kw)) for _ in range(2)]
+    try:
+        for r, h in enumerate(hs):
+            h.set_clouds_host(0, s4, t4)
+            h.dense_set_rows(*shard.dense_row_range(pr.intr.height, 2, r))
+            h.dense_begin(None)
+        total = None
+        for _ in range(iters):
+            parts = [h.dense_partial() for h in hs]
+            total = parts[0] + parts[1]
+            for h in hs:
+                h.dense_update(total)
+        res = [h.dense_finish(total) for h in hs]
+    finally:
+        for h in hs:
+            h.close()
+    assert np.array_equal(res[0]["T_raw"], res[1]["T_raw"]) and np.array_equal(res[0]["T_raw"], ro["T_trace"][-1])
+    assert res[0]["inliers"] == ro["inliers"] and res[0]["status"] == ro["status"]
+    with capi.IcpHandle(capi.default_params(pr.intr, **kw)) as h:
+        h.set_clouds_host(0, s4, t4)
+        calls = []
+        def allreduce(d_buf, count, stream):          # one rank: the sum over the ranks is the buffer itself
+            calls.append(count)
+            return 0
+        r1 = h.dense_run_with(0, 1, allreduce)
+    assert np.array_equal(r1["T_raw"], ro["T_trace"][-1]) and r1["inliers"] == ro["inliers"]
+
+
+@pytest.mark.gpu
 def test_plane_flags_are_validated(gpu_lib):
     from slam3d_gx_amd import capi
     intr = synth.Intrinsics.scaled(160, 120)
