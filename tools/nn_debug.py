@@ -16,7 +16,7 @@ if seed < 0:      # the reference's Kinect pair (tests/golden/kinect): dep1 -> d
     pr = synth.FramePair(-1, synth.Intrinsics(), np.array(Image.open(os.path.join(kin, "exp1_dep_1.png"))).astype(np.uint16),
                          np.array(Image.open(os.path.join(kin, "exp1_dep_2.png" if seed == -1 else "exp1_dep_1.png"))).astype(np.uint16), np.eye(4))
 else:
-    pr = synth.make_pair(seed, **(dict(noise_sigma=0.0012, hole_block=8, hole_prob=0.25) if os.environ.get("NNDBG_BMD") else {}))
+    pr = synth.make_pair(seed, int(os.environ.get("NNDBG_W", "640")), int(os.environ.get("NNDBG_H", "480")), **(dict(noise_sigma=0.0012, hole_block=8, hole_prob=0.25) if os.environ.get("NNDBG_BMD") else {}))
 s4 = synth.backproject_numpy(pr.depth_src, pr.intr); t4 = synth.backproject_numpy(pr.depth_tgt, pr.intr)
 for it in (1, iters):
     with capi.IcpHandle(capi.default_params(pr.intr, iterations=it, estimator=int(os.environ.get("NNDBG_EST", "0")), plane_flags=int(os.environ.get("NNDBG_FLAGS", "0")))) as h:
