@@ -295,6 +295,43 @@ def test_plane_icp_in_dense_mode_over_row_shards(gpu_lib, gate):
 
 
 @pytest.mark.gpu
+def test_handles_give_back_every_device_byte(gpu_lib):
+    """Create / use / destroy, many times, with everything round 5 added in use (plane estimator + gate, batched voxel grid,
+    segmentation, full-scan modes, unorganized handles, stamping): the device's free memory returns to where it was -- no buffer
+    of a handle outlives slam3d_icp_destroy."""
+    import torch
+    from slam3d_gx_amd import capi
+    pr, s4, t4 = _pair(1000, 160, 120)
+    pts = np.ascontiguousarray(s4.reshape(-1, 4))
+    lst = np.full((1, 3000, 4), np.nan, np.float32); lst[0, :2500, :3] = pts[np.isfinite(pts[:, 2])][:2500, :3]; lst[0, :2500, 3] = 1.0
+
+    def cycle():
+        with capi.IcpHandle(capi.default_params(pr.intr, estimator=capi.EST_PLANE, plane_flags=capi.PLANE_PAIR_GATE, iterations=4, max_batch=2,
+                                                extra_frames=2)) as h:
+            h.set_stamping(8)
+            h.align_batch([s4, t4], [t4, s4])
+            h.get_frame_planes(0); h.get_plane_assoc(0)
+            h.segment_planes(s4)
+            h.voxel_grid(pts)
+            d = torch.from_numpy(pts).to("cuda:0"); o = [torch.empty_like(d) for _ in range(3)]
+            h.voxel_grid_batch_device([d.data_ptr()] * 3, [pts.shape[0]] * 3, [x.data_ptr() for x in o])
+            del d, o
+        for mode in (capi.NN_BRUTE_MFMA, capi.NN_BRUTE_VALU):
+            with capi.IcpHandle(capi.default_params(pr.intr, iterations=2, nn_mode=mode)) as h:
+                h.align(s4, t4)
+        with capi.IcpHandle(capi.default_params(synth.Intrinsics(width=3000, height=1), estimator=capi.EST_SVD, iterations=2)) as h:
+            h.align(lst, lst)
+        torch.cuda.synchronize(); torch.cuda.empty_cache()
+
+    cycle(); cycle()                                   # (first uses: module load, constant tables, the runtime's own pools)
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(12):
+        cycle()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < (8 << 20), (free0, free1)   # twelve cycles of ~100 MB of handles each: nothing accumulates
+
+
+@pytest.mark.gpu
 def test_plane_flags_are_validated(gpu_lib):
     from slam3d_gx_amd import capi
     intr = synth.Intrinsics.scaled(160, 120)
