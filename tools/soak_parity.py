@@ -18,10 +18,14 @@ t0 = time.time()
 for case in range(n_cases):
     W = int(rng.choice([64, 96, 104, 128, 160, 200, 256, 320]))
     H = int(rng.choice([48, 56, 72, 96, 120, 150, 200, 240]))
+    if os.environ.get("SOAK_FULL"):      # full frames (BASELINE's size): long runs only, against the kd-tree oracle
+        W, H = 640, 480
     seed = int(rng.integers(0, 1 << 30))
     est = int(rng.integers(0, 3))      # 2: SLAM3D_EST_PLANE (round 5), with and without the pair gate / planes only
     # short runs against the brute-force oracle; long ones (clearance certificates work from the seventh iteration on) against its kd-tree
     iters = int(rng.integers(1, 7)) if rng.random() < 0.4 else int(rng.integers(8, 36))
+    if os.environ.get("SOAK_FULL"):
+        iters = int(rng.integers(8, 28))
     gate = float(rng.choice([0.01, 0.03, 0.1, 0.3, 1.0]))
     bmd = rng.random() < 0.3           # BASELINE.md section 4's noise and holes (round 5's headline workload), scaled to the frame
     pr = (synth.make_pair(seed, W, H, noise_sigma=0.0012, hole_block=8, hole_prob=0.25) if bmd
