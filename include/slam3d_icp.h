@@ -399,10 +399,15 @@ int slam3d_icp_dense_run(slam3d_icp_handle *h, slam3d_comm *comm, const double *
  * zero totals and a failure word set, and returns its own error; every other rank completes its run and returns SLAM3D_E_COMM
  * (T = Identity) -- nobody is left waiting in a collective for a rank that is gone.  Only when even those exchanges cannot be
  * enqueued is the RCCL communicator aborted (the slam3d_comm is dead from then on).
- * SLAM3D_DENSE_FAIL_AT=k in the environment makes this process fail in iteration k (failure injection for tests). */
+ * A rank that fails before its first iteration (preprocessing) is drained the same way. */
 typedef int (*slam3d_allreduce_fn)(void *ctx, void *d_int64_buf, int64_t count, void *hip_stream);
 int slam3d_icp_dense_run_with(slam3d_icp_handle *h, int32_t rank, int32_t world, slam3d_allreduce_fn allreduce, void *ctx,
                               const double *T_init, slam3d_icp_result *out);
+/* Test hook of the failure protocol above: iteration `dense_fail_at` of THIS handle's dense runs behaves as if it could not be
+ * enqueued (SLAM3D_E_HIP on this rank, SLAM3D_E_COMM on its peers); -2: the failure happens before the first iteration; 1000 + k: behind
+ * iteration k's exchange (the peers' iteration k is then complete); -1 (the default) = off.  An explicit call on a handle, not an
+ * environment variable: nothing a production process inherits can switch it on. */
+int slam3d_icp_set_fault_injection(slam3d_icp_handle *h, int32_t dense_fail_at);
 
 /* BASELINE configs 3/4: pairs are independent, the only exchange is the gather of the SE(3) pose records. */
 typedef struct slam3d_pose_record {      /* 160 bytes */

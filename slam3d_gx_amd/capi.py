@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "slam3d_comm_last_error", "slam3d_shard_range", "slam3d_icp_dense_run", "slam3d_pose_gather_submit",
     "slam3d_pose_gather_collect", "slam3d_pose_gather", "slam3d_pose_record_from_result",
     "slam3d_plane_gate", "slam3d_device_count",
-    "slam3d_icp_set_seg_params", "slam3d_icp_get_frame_planes", "slam3d_icp_get_plane_assoc", "slam3d_voxel_grid_batch_device", "slam3d_icp_dense_run_with",
+    "slam3d_icp_set_seg_params", "slam3d_icp_get_frame_planes", "slam3d_icp_get_plane_assoc", "slam3d_voxel_grid_batch_device", "slam3d_icp_dense_run_with", "slam3d_icp_set_fault_injection",
 ]
 COMM_ID_BYTES = 128
 
@@ -519,6 +519,10 @@ class IcpHandle:
         out = Result()
         self._check(self.lib.slam3d_icp_dense_run(self._h, comm._c if comm is not None else None, _vp(Ti), C.byref(out)))
         return out.as_dict()
+
+    def set_fault_injection(self, dense_fail_at: int = -1) -> None:
+        """test hook: this handle's dense runs fail in iteration `dense_fail_at` (-1: off)"""
+        self._check(self.lib.slam3d_icp_set_fault_injection(self._h, C.c_int32(dense_fail_at)))
 
     def dense_run_with(self, rank: int, world: int, allreduce, T_init=None) -> dict:
         """slam3d_icp_dense_run over a caller's transport: allreduce(d_buf: int, count: int, stream: int) -> 0 must SUM `count`

@@ -109,6 +109,7 @@ struct slam3d_icp_handle {
     int *pin_int = nullptr;       // maxB*5
     std::vector<hipEvent_t> ev;   // 0 start, 1 after preprocess, 2 end, then (nn0,nn1) per iteration
     int dense_batch = 8;          // pairs per launch from which the throughput build of the NN kernel is used
+    int dense_fail_at = -1;       // slam3d_icp_set_fault_injection (tests): the dense loop's iteration that "cannot be enqueued" on this handle
     hipGraphExec_t graph_exec = nullptr;   // the captured iteration loop (slam3d_icp_run without profiling)
     int graph_B = 0;
     bool use_graph = true;
@@ -921,7 +922,7 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
 static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEvent_t e0, hipEvent_t e1, int it, int do_solve,
                              long long *raw_out = nullptr, int balance = 0, int first = 0, int counted_run = 0,
                              const DenseExchange *exchange = nullptr /* dense mode: all-reduce this iteration's accumulator set in place */,
-                             bool *used_head = nullptr)
+                             bool *used_head = nullptr, bool *exchanged = nullptr /* out: this iteration's exchange was enqueued */)
 {
     const TileGrid &tg = h->tg;
     const int iters = h->p.iterations > 0 ? h->p.iterations : 1;
@@ -962,7 +963,8 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
             // one wave per block; target slices so that a pair alone still gives every SIMD several waves
             // (24 k waves: three resident per SIMD make eight rounds -- with 8 k the last of three rounds ran 3/4 empty: 95.6 -> 100 TFLOP/s)
             // (the bf16 form's waves are half as long: 48 k of them -- 175 -> 183 TFLOP/s-equivalent)
-            int msplit = ((h->mfma_bf16 ? 48 : 24) * 1024 + (h->N / MF_Q) * B - 1) / ((h->N / MF_Q) * B);
+            const int qblocks = (h->N + MF_Q - 1) / MF_Q * B;      // = grid.x * grid.z, never 0 (N / MF_Q was 0 for lists shorter than 128 points)
+            int msplit = ((h->mfma_bf16 ? 48 : 24) * 1024 + qblocks - 1) / qblocks;
             if (msplit < 1) msplit = 1;
             if (msplit > 64) msplit = 64;      // (round 5: 64, not 32 -- the 16 k x 15 k scans of unorganized clouds have 128 query blocks: 53 -> 38 us per launch)
             if (h->mfma_split > 0) msplit = h->mfma_split;                                                               // developer knob SLAM3D_MFMA_SPLIT (read at create)
@@ -999,6 +1001,7 @@ static int enqueue_iteration(slam3d_icp_handle *h, int B, hipStream_t s, hipEven
         // the identical system on every rank.  ONE exchange per iteration, no reduction or solve launch beside it.
         long long *set = h->acc + (size_t)it * ACC_R * ACC_STRIDE;
         if (exchange->fn(exchange->ctx, set, (int64_t)ACC_R * ACC_STRIDE, (void *)s) != 0) { h->err = "dense mode: the all-reduce of an iteration's totals failed"; return SLAM3D_E_COMM; }
+        if (exchanged) *exchanged = true;
     }
     if (head && it < iters - 1) {
         // solved at the head of the next NN launch; only the run's last iteration keeps its k_solve_acc (result record)
@@ -1961,19 +1964,34 @@ static int dense_run_impl(slam3d_icp_handle *h, int rank, int world, const Dense
     const int iters = h->p.iterations;
     const bool head_flow = h->head_solve != 0 && is_p2p(h) && nn_mode_of(h) == SLAM3D_NN_TILES && 1 < h->dense_batch && iters > 0;
     int64_t *d_sums = reinterpret_cast<int64_t *>(h->sums);
-    const int fail_at = getenv("SLAM3D_DENSE_FAIL_AT") ? atoi(getenv("SLAM3D_DENSE_FAIL_AT")) : -1;      // failure injection (tests): this process's iteration fail_at cannot be enqueued
+    const int fail_at = h->dense_fail_at;      // failure injection (tests; slam3d_icp_set_fault_injection): this handle's iteration fail_at cannot be enqueued
     int failed_it = -1;
-    if (!head_flow && collective && !rc) HIPCHK(h, hipMemsetAsync(d_sums + NRAW, 0, sizeof(int64_t) * 8, s));      // the three-step exchange carries the poison word behind the 36 totals
+    bool exchanged = false;                    // iteration failed_it's exchange was already enqueued when the failure happened
+    // a rank that fails BEFORE the loop (dense_begin, the memset below) has no exchange enqueued yet, while its peers queue all of
+    // theirs: it is a failure of iteration 0 and is drained like any other (it used to skip the drain and leave the peers
+    // in their first all-reduce)
+    if (!rc && fail_at == -2) { h->err = "dense mode: injected failure before the first iteration (slam3d_icp_set_fault_injection)"; rc = SLAM3D_E_HIP; }
+    if (rc) failed_it = 0;
+    const bool three_step_exchange = !head_flow && collective;
     for (int it = 0; it < iters && !rc; ++it) {
-        if (it == fail_at) { h->err = "dense mode: injected failure (SLAM3D_DENSE_FAIL_AT)"; rc = SLAM3D_E_HIP; }
+        exchanged = false;
+        if (it == fail_at) { h->err = "dense mode: injected failure (slam3d_icp_set_fault_injection)"; rc = SLAM3D_E_HIP; }
         else if (head_flow) {
             const bool ev = h->ran_profiled;
             bool used = false;
-            rc = enqueue_iteration(h, 1, s, ev ? h->ev[3 + 2 * it] : nullptr, ev ? h->ev[4 + 2 * it] : nullptr, it, 1, nullptr, 0, it == 0, 0, ex, &used);
+            rc = enqueue_iteration(h, 1, s, ev ? h->ev[3 + 2 * it] : nullptr, ev ? h->ev[4 + 2 * it] : nullptr, it, 1, nullptr, 0, it == 0, 0, ex, &used, &exchanged);
             if (!rc && !used) rc = SLAM3D_E_STATE;
+            if (!rc && fail_at == 1000 + it) { h->err = "dense mode: injected failure behind the exchange (slam3d_icp_set_fault_injection)"; rc = SLAM3D_E_HIP; }
         } else {
-            rc = slam3d_icp_dense_partial_device(h, d_sums, s);
-            if (!rc && collective && ex->fn(ex->ctx, d_sums, NRAW + 1, (void *)s) != 0) { h->err = "dense mode: the all-reduce of an iteration's totals failed"; rc = SLAM3D_E_COMM; }
+            // the three-step exchange carries the poison word behind the 36 totals; cleared before every partial, so that what the
+            // all-reduce leaves there is the number of ranks that failed in THIS exchange (not a running re-sum of earlier ones)
+            if (three_step_exchange && hipMemsetAsync(d_sums + NRAW, 0, sizeof(int64_t) * 8, s) != hipSuccess) { (void)hipGetLastError(); h->err = "dense mode: hipMemsetAsync failed"; rc = SLAM3D_E_HIP; }
+            if (!rc) rc = slam3d_icp_dense_partial_device(h, d_sums, s);
+            if (!rc && collective) {
+                if (ex->fn(ex->ctx, d_sums, NRAW + 1, (void *)s) != 0) { h->err = "dense mode: the all-reduce of an iteration's totals failed"; rc = SLAM3D_E_COMM; }
+                else exchanged = true;
+            }
+            if (!rc && fail_at == 1000 + it) { h->err = "dense mode: injected failure behind the exchange (slam3d_icp_set_fault_injection)"; rc = SLAM3D_E_HIP; }
             if (!rc) rc = slam3d_icp_dense_update_device(h, d_sums, s);
         }
         if (rc) failed_it = it;
@@ -1982,8 +2000,10 @@ static int dense_run_impl(slam3d_icp_handle *h, int rank, int world, const Dense
         // This rank leaves the loop early.  Its peers have every remaining exchange queued already (nothing synchronises with the
         // host before the result): take part in all of them with zero totals and the poison word set, so that nobody waits for a
         // rank that is gone and everybody learns of the failure.  If even that cannot be enqueued the transport is aborted below.
+        // The drain starts BEHIND an exchange this rank already enqueued for the failing iteration (a failure of the update or of
+        // the final solve after the all-reduce): one exchange too many would block this rank in a collective nobody joins.
         bool drained = true;
-        for (int it = failed_it; it < iters && drained; ++it) {
+        for (int it = failed_it + (exchanged ? 1 : 0); it < iters && drained; ++it) {
             long long *set = head_flow ? h->acc + (size_t)it * ACC_R * ACC_STRIDE : reinterpret_cast<long long *>(d_sums);
             const int n = head_flow ? ACC_R * ACC_STRIDE : NRAW + 1;
             hipLaunchKernelGGL(k_dense_poison, dim3((n + 63) / 64), dim3(64), 0, s, set, n);
@@ -2020,6 +2040,13 @@ static int dense_run_impl(slam3d_icp_handle *h, int rank, int world, const Dense
     }
     (void)slam3d_icp_dense_set_rows(h, 0, h->p.height);
     return rc;
+}
+
+extern "C" int slam3d_icp_set_fault_injection(slam3d_icp_handle *h, int32_t dense_fail_at)
+{
+    if (!h) return SLAM3D_E_INVALID;
+    h->dense_fail_at = dense_fail_at;
+    return SLAM3D_OK;
 }
 
 extern "C" int slam3d_icp_dense_run_with(slam3d_icp_handle *h, int32_t rank, int32_t world, slam3d_allreduce_fn allreduce, void *ctx,

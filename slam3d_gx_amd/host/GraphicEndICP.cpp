@@ -159,7 +159,11 @@ void GraphicEndICP::init(const string &param_file)
         if (_params.estimator == SLAM3D_EST_PLANE) {     // the library segments with the reference's plane parameters (fixed seed: a frame's planes do not depend on who aligns it)
             slam3d_seg_params sp = _seg;
             sp.seed = 1;
-            (void)slam3d_icp_set_seg_params(d.icp, &sp);
+            const int src = slam3d_icp_set_seg_params(d.icp, &sp);
+            if (src != SLAM3D_OK) {      // e.g. max_planes / ransac_hypotheses above the library's limits: the library would segment with ITS defaults
+                cerr << "slam3d_icp_set_seg_params failed: " << slam3d_strerror(src) << " (" << slam3d_last_error(d.icp) << "); plane parameters of parameters.yaml are out of the library's range" << endl;
+                exit(1);                 // while extractPlanes used _seg -- a fatal config error like the reference's (:113)
+            }
         }
         d.first_frame = 2 * _max_batch;
         d.key.assign(_params.extra_frames, -1);

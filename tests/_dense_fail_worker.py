@@ -10,8 +10,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 rank, world, port, est, fail_at, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
-if fail_at >= 0 and rank == 1:
-    os.environ["SLAM3D_DENSE_FAIL_AT"] = str(fail_at)           # only THIS process fails
 os.environ["MASTER_ADDR"] = "127.0.0.1"
 os.environ["MASTER_PORT"] = port
 import torch.distributed as dist
@@ -23,6 +21,8 @@ s4 = synth.backproject_numpy(pr.depth_src, pr.intr); t4 = synth.backproject_nump
 res = {"rank": rank}
 with capi.IcpHandle(capi.default_params(pr.intr, iterations=8, estimator=est)) as h:
     h.set_clouds_host(0, s4, t4)
+    if fail_at != -1 and rank == 1:
+        h.set_fault_injection(fail_at)                          # only THIS rank's handle fails
     try:
         r = h.dense_run_with(rank, world, dense.host_staged_allreduce())
         res.update(code=0, status=r["status"], T=np.asarray(r["T_raw"]).reshape(16).tolist(), inliers=r["inliers"])

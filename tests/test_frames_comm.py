@@ -282,14 +282,17 @@ def test_failed_solve_is_never_reported_ok(gpu_lib):
 def test_dense_failure_injection_two_ranks(gpu_lib, tmp_path, estimator):
     """the dense loop's failure protocol with TWO ranks (two processes on this GPU, exchange over gloo through
     slam3d_icp_dense_run_with -- the same library loop as slam3d_icp_dense_run, RCCL needs a GPU per rank).  Healthy: both ranks end
-    with the oracle's pose bits.  Rank 1 fails in iteration 3 (SLAM3D_DENSE_FAIL_AT): it returns its own error (SLAM3D_E_HIP) after
+    with the oracle's pose bits.  Rank 1 fails in iteration 3 (slam3d_icp_set_fault_injection): it returns its own error (SLAM3D_E_HIP) after
     completing the remaining exchanges with the failure word set; rank 0 returns SLAM3D_E_COMM -- within the timeout, not a hang.
     estimator 0: the head-solve flow (the accumulator set is exchanged in place); 1: the three-step flow (36 totals + the word)."""
     import json, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pr, s4, t4 = _pair(1000, 320, 240)
     ro = O.icp(s4, t4, O.params(pr.intr, iterations=8, nn_method=1, estimator=estimator))
-    for fail_at in (-1, 3):
+    # -1 healthy; 3: iteration 3 cannot be enqueued; -2: the rank fails before its first iteration (ADVICE r5: used to leave the peer in its
+    # first all-reduce); 1003: behind iteration 3's exchange (the drain must not repeat that exchange); 1007: behind the LAST exchange --
+    # every exchange is complete, the healthy rank's pose is valid and it returns it
+    for fail_at in (-1, 3, -2, 1003, 1007):
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = str(sk.getsockname()[1])
@@ -306,7 +309,11 @@ def test_dense_failure_injection_two_ranks(gpu_lib, tmp_path, estimator):
                 pytest.fail(f"a rank hung (fail_at={fail_at})")
         assert all(p_.returncode == 0 for p_ in procs), logs
         res = [json.load(open(o)) for o in outs]
-        if fail_at < 0:
+        if fail_at == 1007:
+            assert res[1]["code"] == -2 and "injected failure" in res[1]["message"], res[1]
+            r = res[0]
+            assert r["code"] == 0 and r["status"] == ro["status"] and np.array_equal(np.array(r["T"]).reshape(4, 4), ro["T_trace"][-1]), r
+        elif fail_at == -1:
             for r in res:
                 assert r["code"] == 0 and r["status"] == ro["status"] and r["inliers"] == ro["inliers"]
                 assert np.array_equal(np.array(r["T"]).reshape(4, 4), ro["T_trace"][-1])

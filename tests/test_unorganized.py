@@ -148,3 +148,24 @@ def test_unorganized_handles_refuse_window_estimators(gpu_lib):
             h.align(np.zeros((1, 5001, 4), np.float32), np.zeros((1, 10, 4), np.float32))
         r = h.align(np.full((1, 0, 4), np.nan, np.float32), np.full((1, 7, 4), np.nan, np.float32))      # empty clouds: no inliers, Identity
         assert r["status"] == 1 and np.array_equal(r["T"], np.eye(4))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 7, 64, 100, 127, 128, 129, 300])
+def test_hip_short_point_lists(gpu_lib, n):
+    """point lists SHORTER than one query block of the matrix-core scan (128 points; the slice count divided by
+    N / 128 = 0 on the host) -- every mode, bit-identical to the oracle, incl. a single point (too few rows: no update)."""
+    from slam3d_gx_amd import capi
+    v1, _ = kinect_voxel_clouds()
+    a = v1[:: max(1, len(v1) // n)][:n].copy()
+    intr = synth.Intrinsics(width=n, height=1)
+    Ti = synth.pose_from_seed(5, 1.0, 0.02)
+    ro = O.icp(pad(a, n), pad(a, n), O.params(intr, estimator=1, iterations=5, nn_method=0, max_corr_dist=0.5), T_init=Ti)
+    for mode in (capi.NN_AUTO, capi.NN_BRUTE_MFMA, capi.NN_BRUTE_VALU, capi.NN_TILES):
+        with capi.IcpHandle(capi.default_params(intr, iterations=5, nn_mode=mode, estimator=capi.EST_SVD, max_corr_dist=0.5)) as h:
+            rg = h.align(pad(a, n), pad(a, n), Ti)
+            idx, d2 = h.get_correspondences(0)
+            Tt, St = h.get_trace(0)
+        assert np.array_equal(idx, ro["idx"]) and np.array_equal(d2.view(np.uint32), ro["d2"].view(np.uint32)), (n, mode)
+        assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:5], ro["sums_trace"]), (n, mode)
+        assert rg["status"] == ro["status"] and rg["inliers"] == ro["inliers"], (n, mode)

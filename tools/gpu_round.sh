@@ -11,4 +11,4 @@ timeout 1500 python -m pytest tests -m gpu -q --maxfail=10 -p no:cacheprovider "
 echo "pytest rc=$?" | tee -a $OUT/pytest.log
 tail -n 30 $OUT/pytest.log
 timeout 300 python tools/nn_debug.py 20 > $OUT/nn_debug.log 2>&1; tail -n 30 $OUT/nn_debug.log
-timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 1500 $OUT/bench.err; head -c 3000 $OUT/bench.json
+timeout 900 python bench.py --legs-file $OUT/bench.json > $OUT/bench_stdout.txt 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 1500 $OUT/bench.err; tail -n 1 $OUT/bench_stdout.txt | wc -c; tail -n 1 $OUT/bench_stdout.txt

@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/refresh_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 Q="--no-extra-configs --no-cpu-baseline --no-bruteforce"
-timeout 1200 python $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout 1200 python $R/bench.py --legs-file $OUT/bench.json > $OUT/bench_stdout.txt 2> $OUT/bench.err
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $R/bench.py --steps 2 --warmup 1 --no-extra-configs --no-cpu-baseline > /dev/null 2>&1
 timeout 600 rocprofv3 --kernel-trace -d $OUT/pipe -o pipe -- python $R/bench.py --steps 3 --warmup 1 $Q --timed-only > $OUT/pipe_bench.json 2> /dev/null
 timeout 600 rocprofv3 --kernel-trace -d $OUT/solo -o solo -- python $R/bench.py --steps 1 --warmup 1 --pairs-per-step 96 --no-pipeline $Q --timed-only > $OUT/solo_bench.json 2> /dev/null
@@ -25,6 +25,6 @@ timeout 300 python $R/bench.py --mode seg --pairs 64 --steps 20 --warmup 3 > $OU
 timeout 300 python $R/bench.py --mode seg --pairs 1 --steps 100 --warmup 10 --no-cpu-baseline > $OUT/seg1_bench.json 2> /dev/null
 # summarise on the box (the databases exceed what gpurun copies back), keep only the small files
 python $R/tools/collect_profiles.py $TAG $R/gpurun_out/profiles_$TAG
-cp $OUT/*.json $OUT/bench.err $R/gpurun_out/profiles_$TAG/ 2>/dev/null
+cp $OUT/*.json $OUT/bench.err $OUT/bench_stdout.txt $R/gpurun_out/profiles_$TAG/ 2>/dev/null
 rm -rf $OUT
 ls -la $R/gpurun_out/profiles_$TAG
