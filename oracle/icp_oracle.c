@@ -345,20 +345,25 @@ int orc_solve6(const double U[21], const double Atb[6], double x[6])
 }
 
 /* ----------------------------------------------------- 3x3 SVD -> rotation
- * one-sided (Hestenes) Jacobi on the columns of H, 12 fixed sweeps; R = V U^T
+ * one-sided (Hestenes) Jacobi on the columns of H, at most 12 sweeps; R = V U^T.
+ * Round 6: a rotation is skipped when its two columns are orthogonal to 2^-50 (ga^2 <= 2^-100 al be; ga == 0 is the special case of
+ * rounds 1-5) and the sweeps stop after one that rotated nothing -- Jacobi converges quadratically, 4-6 sweeps do what 12 did, and
+ * the serial chain of divisions and square roots is what an iteration of the svd estimator waits for on the GPU.
  * with the smallest-singular-value pair replaced by cross products (det = +1). */
 void orc_svd3_rotation(const double H[9], double R[9])
 {
     double g[3][3], v[3][3] = { { 1, 0, 0 }, { 0, 1, 0 }, { 0, 0, 1 } }; /* [row][col] */
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) g[r][c] = H[r * 3 + c];
     static const int PP[3] = { 0, 0, 1 }, QQ[3] = { 1, 2, 2 };
-    for (int sweep = 0; sweep < 12; ++sweep)
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        int rotated = 0;
         for (int k = 0; k < 3; ++k) {
             const int p = PP[k], q = QQ[k];
             const double al = (g[0][p] * g[0][p] + g[1][p] * g[1][p]) + g[2][p] * g[2][p];
             const double be = (g[0][q] * g[0][q] + g[1][q] * g[1][q]) + g[2][q] * g[2][q];
             const double ga = (g[0][p] * g[0][q] + g[1][p] * g[1][q]) + g[2][p] * g[2][q];
-            if (ga == 0.0) continue;
+            if (ga * ga <= 0x1p-100 * (al * be)) continue;
+            rotated = 1;
             const double zeta = (be - al) / (2.0 * ga);
             double t = 1.0 / (fabs(zeta) + sqrt(zeta * zeta + 1.0));
             if (zeta < 0.0) t = -t;
@@ -373,6 +378,8 @@ void orc_svd3_rotation(const double H[9], double R[9])
                 v[m][q] = s * vp + c * vq;
             }
         }
+        if (!rotated) break;
+    }
     double sg[3];
     for (int k = 0; k < 3; ++k)
         sg[k] = sqrt((g[0][k] * g[0][k] + g[1][k] * g[1][k]) + g[2][k] * g[2][k]);

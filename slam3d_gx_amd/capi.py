@@ -374,6 +374,15 @@ class IcpHandle:
         self._check(self.lib.slam3d_icp_get_stamps(self._h, _vp(out), C.c_int32(max_runs), C.byref(n)), False)
         return out[: n.value]
 
+    def get_list_debug(self) -> np.ndarray:
+        """SLAM3D_LIST_DEBUG=1, point-list handles (one pair per launch): thread 0 of every block's phase times of the last run,
+        [iterations][256 blocks][12] in 10 ns ticks: bounds, listing, scans, rows, Gram, arrive, barrier wait, totals, derive, solve;
+        [10] tiles wave 0 scanned, [11] iteration start (blocks beyond the grid read 0)"""
+        it = max(self.params.iterations, 1)
+        out = np.zeros(it * 256 * 12, dtype=np.int64)
+        self._check(self.lib.slam3d_icp_get_nn_debug(self._h, _vp(out), C.c_int32(out.size)), False)
+        return out.reshape(it, 256, 12)
+
     def get_nn_debug(self) -> np.ndarray:
         nt = ((self.params.width + 7) // 8) * ((self.params.height + 7) // 8)
         out = np.zeros(nt * 20, dtype=np.int64)

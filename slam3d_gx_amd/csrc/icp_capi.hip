@@ -5,6 +5,7 @@
 // every entry point that computes runs HIP kernels on a gfx950 device or returns an error.
 #include "../../include/slam3d_icp.h"
 #include "icp_kernels.hpp"
+#include "list_icp.hpp"
 #include "plane_seg.hpp"
 #include "voxel.hpp"
 #include "rccl_comm.hpp"
@@ -31,6 +32,8 @@ struct FrameHost {
     uint64_t nrm_epoch = 0;                                      // the frame's normals were computed for this epoch
     bool nrm_full = false;             // ... with the normal VECTORS of every pixel (SLAM3D_EST_PLANE builds labels only for a frame that is a source of the pair gate)
     bool from_depth = false;           // the cloud is OUR back-projection of a depth image with the handle's intrinsics
+    uint64_t ls_epoch[2] = { 0, 0 };   // point-list handles (list_icp.hpp): the sorted list of role 0 / 1 was built for this epoch ...
+    int ls_normals = -1;               // ... the target list with / without the normal filter
 };
 
 struct slam3d_icp_handle {
@@ -109,6 +112,17 @@ struct slam3d_icp_handle {
     int *pin_int = nullptr;       // maxB*5
     std::vector<hipEvent_t> ev;   // 0 start, 1 after preprocess, 2 end, then (nn0,nn1) per iteration
     int dense_batch = 8;          // pairs per launch from which the throughput build of the NN kernel is used
+    // point lists (height == 1, SLAM3D_NN_AUTO; list_icp.hpp): sorted lists + tile boxes per frame and role, per-pair previous matches,
+    // the counting sort's scratch (LS_TASKS lists per launch sequence)
+    bool list_on = false;
+    bool ran_list = false;        // the last run went through the persistent list launch (its correspondences are scattered without tile slots)
+    int ls_npad = 0, ls_ntile = 0;
+    float4 *ls_pts = nullptr, *ls_box = nullptr;   // [maxF][2][ls_npad], [maxF][2][ls_ntile * 2]
+    int2 *ls_tile = nullptr;                        // [maxF][2][ls_ntile] (start, count)
+    int *ls_n = nullptr;                            // [maxF][2][2]: points, tiles
+    int *ls_cnt = nullptr, *ls_cstart = nullptr, *ls_grp = nullptr; int2 *ls_cr = nullptr, *ls_super = nullptr;
+    float4 *ls_match = nullptr;                     // [maxB][ls_npad]: previous match (point, index) by sorted source position
+    long long *ls_dbg = nullptr;                    // SLAM3D_LIST_DEBUG=1: block 0's per-iteration stamps (slam3d_icp_get_nn_debug)
     int dense_fail_at = -1;       // slam3d_icp_set_fault_injection (tests): the dense loop's iteration that "cannot be enqueued" on this handle
     hipGraphExec_t graph_exec = nullptr;   // the captured iteration loop (slam3d_icp_run without profiling)
     int graph_B = 0;
@@ -254,6 +268,7 @@ static void free_all(slam3d_icp_handle *h)
 {
     auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(h->f_cloud); F(h->f_nrm); F(h->f_srcT); F(h->f_tgtT); F(h->f_tbox); F(h->f_cbox); F(h->f_tq); F(h->f_scount); F(h->f_counts);
+    F(h->ls_dbg); F(h->ls_pts); F(h->ls_box); F(h->ls_tile); F(h->ls_super); F(h->ls_n); F(h->ls_cnt); F(h->ls_cstart); F(h->ls_grp); F(h->ls_cr); F(h->ls_match);
     F(h->src_c); F(h->tgt_c); F(h->ccounts); F(h->chunk_cnt); F(h->corr); F(h->ticket);
     F(h->flags); F(h->best); F(h->cd2); F(h->acc); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
     F(h->d_pairs); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4); F(h->corr_trace);
@@ -396,6 +411,17 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
         if (getenv("SLAM3D_MFMA_SPLIT")) h->mfma_split = std::max(1, std::min(64, atoi(getenv("SLAM3D_MFMA_SPLIT"))));
         A(dalloc(h->tgtB, (size_t)h->maxB * (h->mfma_bf16 ? 8 : 4) * h->npad)); A(dalloc(h->qmax2, (size_t)h->maxB));
     }
+    // point lists: one persistent launch per run (list_icp.hpp); SLAM3D_LIST_ICP=0 (developer knob) keeps round 5's three launches per iteration
+    h->list_on = p->height == 1 && p->width > 1 && p->nn_mode == SLAM3D_NN_AUTO && !(getenv("SLAM3D_LIST_ICP") && atoi(getenv("SLAM3D_LIST_ICP")) == 0);
+    if (h->list_on) {
+        h->ls_ntile = h->N / 64 + 1 + std::min(h->N, LS_NSUPER);       // tiles never leave a super-cell: at most one partial tile per non-empty super-cell
+        h->ls_npad = (h->N + 63) / 64 * 64 + 64;                       // + the padding behind the list
+        A(dalloc(h->ls_pts, F * 2 * h->ls_npad)); A(dalloc(h->ls_box, F * 2 * h->ls_ntile * 2)); A(dalloc(h->ls_tile, F * 2 * h->ls_ntile));
+        A(dalloc(h->ls_n, F * 4)); A(dalloc(h->ls_super, (size_t)LS_TASKS * LS_NSUPER));
+        if (getenv("SLAM3D_LIST_DEBUG")) A(dalloc(h->ls_dbg, (size_t)iters * LS_MAX_BLOCKS * 12));
+        A(dalloc(h->ls_cnt, (size_t)LS_TASKS * LS_NCELL)); A(dalloc(h->ls_cstart, (size_t)LS_TASKS * LS_NCELL)); A(dalloc(h->ls_grp, (size_t)LS_TASKS * LS_NGROUP));
+        A(dalloc(h->ls_cr, (size_t)LS_TASKS * h->N)); A(dalloc(h->ls_match, (size_t)h->maxB * h->ls_npad));
+    }
     A(dalloc(h->ccounts, (size_t)h->maxB * 4)); A(dalloc(h->ticket, (size_t)h->maxB));
     A(dalloc(h->corr, BS)); A(dalloc(h->flags, (size_t)h->maxB)); A(dalloc(h->cd2, BS));
     if (brute) A(dalloc(h->chunk_cnt, (size_t)h->maxB * 2 * ((h->N + 1023) / 1024)));
@@ -470,6 +496,11 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
         }
     }
     (void)hipMemsetAsync(h->ticket, 0, sizeof(unsigned int) * (size_t)h->maxB, h->stream);
+    if (h->list_on) {      // the counting sort's counters clean up after themselves from here on
+        (void)hipMemsetAsync(h->ls_cnt, 0, sizeof(int) * (size_t)LS_TASKS * LS_NCELL, h->stream);
+        (void)hipMemsetAsync(h->ls_grp, 0, sizeof(int) * (size_t)LS_TASKS * LS_NGROUP, h->stream);
+        (void)hipMemsetAsync(h->ls_n, 0, sizeof(int) * 4 * F, h->stream);
+    }
     h->frames.assign(h->maxF, FrameHost());
     h->pair_src.assign(h->maxB, -1); h->pair_tgt.assign(h->maxB, -1);
     h->h_pairs.assign(h->maxB, PairPtrs{}); h->up_pairs.assign(h->maxB, PairPtrs{});
@@ -719,7 +750,7 @@ static bool seg_params_ok(const slam3d_seg_params *sp)
 static int pick_nsplit(const slam3d_icp_handle *h, int B)
 {
     // enough workgroups for 256 CUs: aim at >= ~2048 blocks (query blocks are sized for ~75 % valid)
-    const int qblocks = ((h->N * 3) / 4 + NN_BLOCK * NN_QPT - 1) / (NN_BLOCK * NN_QPT);
+    const int qblocks = std::max(1, ((h->N * 3) / 4 + NN_BLOCK * NN_QPT - 1) / (NN_BLOCK * NN_QPT));      // (never 0: a one-point list gave 0 and a division by zero)
     int ns = (2048 + qblocks * B - 1) / (qblocks * B);
     if (ns < 1) ns = 1;
     if (ns > 16) ns = 16;
@@ -729,7 +760,8 @@ static int pick_nsplit(const slam3d_icp_handle *h, int B)
 // Preprocessing of a run: every (frame, role) the pairs [0,B) use and that is stale is rebuilt ONCE (normals, tile
 // records, boxes / source slots), the pair table is refreshed when it changed (kernel arguments: nothing in flight
 // reads host memory), and the pairs' iteration state is reset (T_init by kernel argument too).
-static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init, hipStream_t s, int count_run = 0)
+static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init, hipStream_t s, int count_run = 0,
+                              bool list = false /* a point-list run (list_icp.hpp): sorted lists instead of tile records and compacted lists */)
 {
     const Geometry &g = h->g;
     const TileGrid &tg = h->tg;
@@ -752,6 +784,16 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         t.scount = h->f_scount + ((size_t)f * 2 + role) * tg.ntiles;
         t.counts = h->f_counts + (size_t)f * 4;
         t.role = role; t.row0 = h->row0; t.row1 = h->row1; t.use_normals = use_normals;
+        return t;
+    };
+    std::vector<ListTask> ltasks;
+    auto list_task_of = [&](int f, int role) {
+        ListTask t;
+        t.cloud = h->frames[f].cloud; t.nrm = h->f_nrm + (size_t)f * h->N;
+        t.pts = h->ls_pts + ((size_t)f * 2 + role) * h->ls_npad; t.box = h->ls_box + ((size_t)f * 2 + role) * h->ls_ntile * 2;
+        t.tile = h->ls_tile + ((size_t)f * 2 + role) * h->ls_ntile;
+        t.n = h->ls_n + ((size_t)f * 2 + role) * 2;
+        t.which = role; t.use_normals = use_normals; t.i_begin = role == 0 ? h->row0 * g.W : 0; t.i_end = role == 0 ? h->row1 * g.W : h->N;
         return t;
     };
     // every pair is validated before anything is planned, and the per-frame "built for this epoch" marks are kept in a
@@ -782,15 +824,23 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
     };
     for (int b = 0; b < B; ++b) {
         const int fs = h->pair_src[b], ft = h->pair_tgt[b];
-        {
+        if (list) {
+            FrameHost &S = planned(fs);
+            if (S.ls_epoch[0] != S.epoch) { ltasks.push_back(list_task_of(fs, 0)); S.ls_epoch[0] = S.epoch; }
+            if (src_normals) want_normals(fs, !src_labels_only);
+            FrameHost &T = planned(ft);
+            if (T.ls_epoch[1] != T.epoch || T.ls_normals != use_normals) {
+                if (use_normals) want_normals(ft, true);
+                ltasks.push_back(list_task_of(ft, 1));
+                T.ls_epoch[1] = T.epoch; T.ls_normals = use_normals;
+            }
+        } else {
             FrameHost &S = planned(fs);
             if (S.src_epoch != S.epoch || S.src_row0 != h->row0 || S.src_row1 != h->row1) {
                 tasks.push_back(task_of(fs, 0));
                 S.src_epoch = S.epoch; S.src_row0 = h->row0; S.src_row1 = h->row1;
             }
             if (src_normals) want_normals(fs, !src_labels_only);
-        }
-        {
             FrameHost &T = planned(ft);
             if (T.tgt_epoch != T.epoch || T.tgt_normals != use_normals) {
                 if (use_normals) want_normals(ft, true);
@@ -813,6 +863,13 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         pp.spl = h->f_planes ? h->f_planes + fs : nullptr;
         pp.tpl = h->f_planes ? h->f_planes + ft : nullptr;
         pp.assoc = h->assoc ? h->assoc + (size_t)b * 8 : nullptr;
+        pp.ls_src = pp.ls_tgt = pp.ls_tbox = nullptr; pp.ls_ns = pp.ls_nt = nullptr; pp.ls_stile = pp.ls_ttile = nullptr;
+        if (h->list_on) {
+            pp.ls_src = h->ls_pts + ((size_t)fs * 2 + 0) * h->ls_npad; pp.ls_tgt = h->ls_pts + ((size_t)ft * 2 + 1) * h->ls_npad;
+            pp.ls_tbox = h->ls_box + ((size_t)ft * 2 + 1) * h->ls_ntile * 2;
+            pp.ls_stile = h->ls_tile + ((size_t)fs * 2 + 0) * h->ls_ntile; pp.ls_ttile = h->ls_tile + ((size_t)ft * 2 + 1) * h->ls_ntile;
+            pp.ls_ns = h->ls_n + ((size_t)fs * 2 + 0) * 2; pp.ls_nt = h->ls_n + ((size_t)ft * 2 + 1) * 2;
+        }
     }
     const bool plane_only = is_plane(h) && (h->p.plane_flags & SLAM3D_PLANE_ONLY);
     std::vector<FrameTask> wtasks;                 // the normals tasks that need the 7x7-window pass
@@ -862,6 +919,16 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
         hipLaunchKernelGGL(k_frame_tiles, dim3(tg.ntiles, n), dim3(64), 0, s, a, g, tg);
         hipLaunchKernelGGL(k_coarse_boxes, dim3(tg.ncoarse, n), dim3(64), 0, s, a, tg);
     }
+    for (size_t k0 = 0; k0 < ltasks.size(); k0 += LS_TASKS) {      // the counting sort of every stale list (list_icp.hpp), LS_TASKS lists at a time
+        ListTasks a;
+        const int n = (int)std::min<size_t>(LS_TASKS, ltasks.size() - k0);
+        for (int k = 0; k < n; ++k) a.t[k] = ltasks[k0 + k];
+        const dim3 pg((h->N + 255) / 256, n);
+        hipLaunchKernelGGL(k_list_bin, pg, dim3(256), 0, s, a, h->ls_cnt, h->ls_grp, h->ls_cr, h->N, g.zmax);
+        hipLaunchKernelGGL(k_list_scan, dim3(LS_NGROUP, n), dim3(64), 0, s, a, h->ls_cnt, h->ls_cstart, h->ls_grp, h->ls_super);
+        hipLaunchKernelGGL(k_list_scatter, pg, dim3(256), 0, s, a, h->ls_cstart, h->ls_super, h->ls_cr, h->N);
+        hipLaunchKernelGGL(k_list_boxes, dim3(std::max((h->ls_ntile + 3) / 4, 4), n), dim3(256), 0, s, a, h->ls_grp);
+    }
     bool same = B <= h->pairs_uploaded;                 // the device copy of the pair table is still current
     for (int b = 0; b < B && same; ++b) same = memcmp(&h->up_pairs[b], &h->h_pairs[b], sizeof(PairPtrs)) == 0;
     if (!same) {
@@ -889,7 +956,7 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
                                stamp_ring_of(h), count_run ? h->dev_runs : nullptr, g.pair_gate ? h->d_pairs : nullptr);
     }
     if (count_run) h->run_counted = true;
-    if (nn_mode_of(h) != SLAM3D_NN_TILES) {
+    if (nn_mode_of(h) != SLAM3D_NN_TILES && !list) {
         HIPCHK(h, hipMemsetAsync(h->best, 0xFF, sizeof(unsigned long long) * (size_t)B * tg.nslots, s));
         const dim3 cgrid((h->N + 1023) / 1024, 2, B);
         hipLaunchKernelGGL(k_compact_count, cgrid, dim3(1024), 0, s, h->d_pairs, h->chunk_cnt, g, use_normals, h->row0, h->row1);
@@ -1037,7 +1104,7 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
         if (hipMalloc((void **)&h->corr_trace, sizeof(int) * n) != hipSuccess) { (void)hipGetLastError(); return SLAM3D_E_NOMEM; }
     }
     h->run_counted = false;
-    int rc = enqueue_preprocess(h, B, T_init, s, iters > 0 ? 1 : 0);       // (counted as in flight until the last k_solve_acc)
+    int rc = enqueue_preprocess(h, B, T_init, s, iters > 0 ? 1 : 0, h->list_on);       // (counted as in flight until the last k_solve_acc)
     if (!rc) rc = enqueue_iterations(h, B, s, iters);
     if (rc) {
         // k_pair_init may have counted this run in (run_counted: it was launched); its last k_solve_acc, which counts it out,
@@ -1053,6 +1120,7 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
     h->ran = true;
     h->ran_profiled = h->profiling;
     h->ran_corr_trace = h->want_corr_trace;
+    h->ran_list = h->list_on && iters > 0;
     h->res_mapped = iters > 0;
     h->last_B = B;
     return SLAM3D_OK;
@@ -1062,6 +1130,27 @@ extern "C" int slam3d_icp_run(slam3d_icp_handle *h, int32_t B, const double *T_i
 static int enqueue_iterations(slam3d_icp_handle *h, int B, hipStream_t s, int iters)
 {
     int rc = SLAM3D_OK;
+    if (h->list_on && iters > 0) {
+        // point lists: ALL iterations in one persistent launch (list_icp.hpp); at most LS_MAX_BLOCKS blocks, so that the launches of
+        // four streams are always co-resident
+        const int G = std::max(1, std::min(h->ls_ntile, LS_MAX_BLOCKS / B));
+        const int n_coarse = std::max(0, std::min(h->p.coarse_iterations, iters - 1));
+        const bool gated = is_p2p(h) && (h->g.resid2 > 0.0f || h->g.min_ncos > 0.0f || h->g.pair_gate);
+        if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[1], s)); HIPCHK(h, hipEventRecord(h->ev[3], s)); }
+        auto launch = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(G, B), dim3(64 * LS_WAVES), 0, s, h->d_pairs, h->g, iters, n_coarse, h->nsets, h->ls_npad, h->Tcur, h->trace_T,
+                               h->trace_S, h->flags, h->acc, h->ticket, h->ls_match, h->corr, h->cd2, h->want_corr_trace ? h->corr_trace : nullptr,
+                               h->maxB, h->tg.nslots, h->d_res, h->dev_runs, h->ls_dbg);
+        };
+        if (h->ls_dbg && !is_p2p(h)) launch(k_list_icp<1, false, true>);        // SLAM3D_LIST_DEBUG=1: the instrumented instance
+        else if (!is_p2p(h)) launch(k_list_icp<1, false>);
+        else if (gated) launch(k_list_icp<0, true>);
+        else launch(k_list_icp<0, false>);
+        HIPCHK(h, hipGetLastError());
+        if (h->profiling)        // one launch: its time is booked on iteration 0, the other iterations read 0
+            for (int it = 0; it < iters; ++it) { if (it > 0) HIPCHK(h, hipEventRecord(h->ev[3 + 2 * it], s)); HIPCHK(h, hipEventRecord(h->ev[4 + 2 * it], s)); }
+        return SLAM3D_OK;
+    }
     if (iters > 0 && !h->profiling && h->use_graph && !h->want_corr_trace) {
         // The iteration loop (iterations x {NN, solve}) has launch-invariant arguments: it is captured once per B into
         // a HIP graph and replayed with one hipGraphLaunch.  What changes from run to run -- which frames need their
@@ -1268,7 +1357,9 @@ static int corr_to_host(slam3d_icp_handle *h, int slot, const int *corr_slot, co
     hipStream_t s = h->run_stream;
     const int N = h->N;
     hipLaunchKernelGGL(k_fill_corr, dim3((N + 255) / 256), dim3(256), 0, s, h->d_idx, h->d_d2, N);
-    if (h->p.iterations > 0)
+    if (h->p.iterations > 0 && h->list_on && h->ran_list)
+        hipLaunchKernelGGL(k_scatter_corr_list, dim3((N + 255) / 256), dim3(256), 0, s, h->d_pairs, corr_slot, cd2_slot, slot, N, h->g.zmax, h->d_idx, h->d_d2);
+    else if (h->p.iterations > 0)
         hipLaunchKernelGGL(k_scatter_corr, dim3((h->tg.nslots + 255) / 256), dim3(256), 0, s, h->d_pairs, corr_slot, cd2_slot,
                            slot, h->tg, h->d_idx, h->d_d2);
     HIPCHK(h, hipGetLastError());
@@ -1351,6 +1442,14 @@ extern "C" int slam3d_icp_get_timings(slam3d_icp_handle *h, float ms[4])
 extern "C" int slam3d_icp_get_nn_debug(slam3d_icp_handle *h, int64_t *out /* ntiles*8 */, int32_t n)
 {
     if (!h || !out) return SLAM3D_E_INVALID;
+    if (h->ls_dbg && h->ran_list) {         // a list handle: block 0's stamps, iterations x 4
+        const int m = (h->p.iterations > 0 ? h->p.iterations : 1) * LS_MAX_BLOCKS * 12;
+        if (n < m) return SLAM3D_E_STATE;
+        HIPCHK(h, hipSetDevice(h->p.device));
+        HIPCHK(h, hipStreamSynchronize(h->run_stream));
+        HIPCHK(h, hipMemcpy(out, h->ls_dbg, sizeof(long long) * (size_t)m, hipMemcpyDeviceToHost));
+        return SLAM3D_OK;
+    }
     if (!h->dbg || !h->ran || n < h->tg.ntiles * 20) return SLAM3D_E_STATE;
     HIPCHK(h, hipSetDevice(h->p.device));
     HIPCHK(h, hipStreamSynchronize(h->run_stream));
@@ -1830,7 +1929,7 @@ extern "C" int slam3d_icp_dense_begin(slam3d_icp_handle *h, const double *T_init
     h->dense_it = 0;
     HIPCHK(h, hipEventRecord(h->ev[0], s));
     if (h->profiling) HIPCHK(h, hipEventRecord(h->ev[1], s));
-    h->run_stream = s; h->ran = true; h->last_B = 1; h->res_mapped = false; h->ran_profiled = h->profiling;
+    h->run_stream = s; h->ran = true; h->last_B = 1; h->res_mapped = false; h->ran_list = false; h->ran_profiled = h->profiling;
     return SLAM3D_OK;
 }
 

@@ -51,6 +51,11 @@ struct PairPtrs {                  // per frame-pair device pointers: the reside
     const int *tgt_counts;         // [1] = valid target points of the target frame
     const FramePlanes *spl, *tpl;  // planes of the source / target frame (SLAM3D_EST_PLANE; null otherwise)
     int *assoc;                    // [8] plane-pair gate: target plane of every source plane (-1 none), written by k_plane_assoc at the start of a run
+    // point lists (height == 1 handles, list_icp.hpp): both frames' points sorted into space cells, 64-point tiles and their boxes
+    const float4 *ls_src, *ls_tgt; // sorted (x, y, z, original index) of the source / target frame's role list
+    const float4 *ls_tbox;         // target tile boxes [2 t], [2 t + 1]
+    const int2 *ls_stile, *ls_ttile;   // tile tables (start, count <= 64) of the two lists
+    const int *ls_ns, *ls_nt;      // [0] points, [1] tiles of the two lists
 };
 constexpr int RES_REC = 48;        // doubles per pair in the host-mapped result record
 constexpr unsigned long long HEAD_EMPTY = 0x7ff8dead0badc0deull;     // a pose entry "not published yet" (head solve): a quiet NaN with a payload no arithmetic produces
@@ -90,7 +95,7 @@ __device__ __forceinline__ void stamp_end(unsigned long long *__restrict__ row, 
     if (row) atomicMax(row + STAMP_R + (c & (STAMP_R - 1)), (unsigned long long)wall_clock64());
 }
 
-constexpr int PAIR_ARGS = 32;
+constexpr int PAIR_ARGS = 16;       // (x 152 bytes: kernel arguments are limited to 4 KB)
 struct PairArgs { PairPtrs p[PAIR_ARGS]; };
 // the pair table travels as a kernel argument (copied at launch), not through pinned host memory
 __global__ void k_set_pairs(PairPtrs *__restrict__ dst, PairArgs a, int n)
@@ -2839,19 +2844,22 @@ __device__ inline int solve6(const double *U, const double *Atb, double *x)
     return 0;
 }
 
-// one-sided Jacobi SVD of H (12 sweeps) -> R = V U^T with det +1 (spec S5, Kabsch)
+// one-sided Jacobi SVD of H (at most 12 sweeps; round 6: rotations of columns orthogonal to 2^-50 are skipped, a sweep without a
+// rotation ends it -- oracle/icp_oracle.c::orc_svd3_rotation) -> R = V U^T with det +1 (spec S5, Kabsch)
 __device__ inline void svd3_rotation(const double *H, double *R)
 {
     double g[3][3], v[3][3];
     for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) { g[r][c] = H[r * 3 + c]; v[r][c] = r == c ? 1.0 : 0.0; }
-    for (int sweep = 0; sweep < 12; ++sweep)
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        bool rotated = false;
         for (int k = 0; k < 3; ++k) {
             const int p = k == 2 ? 1 : 0, q = k == 0 ? 1 : 2;
             const double al = (g[0][p] * g[0][p] + g[1][p] * g[1][p]) + g[2][p] * g[2][p];
             const double be = (g[0][q] * g[0][q] + g[1][q] * g[1][q]) + g[2][q] * g[2][q];
             const double ga = (g[0][p] * g[0][q] + g[1][p] * g[1][q]) + g[2][p] * g[2][q];
-            if (ga == 0.0) continue;
+            if (ga * ga <= 0x1p-100 * (al * be)) continue;
+            rotated = true;
             const double zeta = (be - al) / (2.0 * ga);
             double t = 1.0 / (fabs(zeta) + sqrt(zeta * zeta + 1.0));
             if (zeta < 0.0) t = -t;
@@ -2866,6 +2874,8 @@ __device__ inline void svd3_rotation(const double *H, double *R)
                 v[m][q] = s * vp + c * vq;
             }
         }
+        if (!rotated) break;
+    }
     double sg[3];
     for (int k = 0; k < 3; ++k) sg[k] = sqrt((g[0][k] * g[0][k] + g[1][k] * g[1][k]) + g[2][k] * g[2][k]);
     int i0 = 0, i1 = 1, i2 = 2, tmp;
@@ -2897,14 +2907,9 @@ __device__ inline void compose(const double *dR, const double *dt, double *T)
     for (int k = 0; k < 16; ++k) T[k] = Tn[k];
 }
 
-// solve + SE(3) update from the 29 sums (one thread), trace bookkeeping
-__device__ inline void solve_update_one(const double *__restrict__ sums, double *__restrict__ Tcur_b,
-                                        double *__restrict__ trace_T_b, double *__restrict__ trace_S_b,
-                                        int *__restrict__ flag, int it, int estimator)
+// one solve + SE(3) update step from the 29 sums on a local pose T (one thread): 1 solved, 2 solved after damping, 0 no update (T unchanged)
+__device__ inline int solve_step_one(const double *__restrict__ sums, double *T, int estimator)
 {
-    double T[16];
-    for (int k = 0; k < 16; ++k) T[k] = Tcur_b[k];
-    for (int k = 0; k < NSUMS; ++k) trace_S_b[(size_t)it * NSUMS + k] = sums[k];
     int rc = 0;
     double dR[9], dt[3];
     if (estimator == 0) {
@@ -2934,8 +2939,20 @@ __device__ inline void solve_update_one(const double *__restrict__ sums, double 
             rc = 1;
         }
     }
+    if (rc) compose(dR, dt, T);
+    return rc;
+}
+
+// solve + SE(3) update from the 29 sums (one thread), trace bookkeeping
+__device__ inline void solve_update_one(const double *__restrict__ sums, double *__restrict__ Tcur_b,
+                                        double *__restrict__ trace_T_b, double *__restrict__ trace_S_b,
+                                        int *__restrict__ flag, int it, int estimator)
+{
+    double T[16];
+    for (int k = 0; k < 16; ++k) T[k] = Tcur_b[k];
+    for (int k = 0; k < NSUMS; ++k) trace_S_b[(size_t)it * NSUMS + k] = sums[k];
+    const int rc = solve_step_one(sums, T, estimator);
     if (rc) {
-        compose(dR, dt, T);
         for (int k = 0; k < 16; ++k) Tcur_b[k] = T[k];
         if (rc == 2) *flag = *flag | 1;
     } else {
