@@ -422,7 +422,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
         A(dalloc(h->ls_cnt, (size_t)LS_TASKS * LS_NCELL)); A(dalloc(h->ls_cstart, (size_t)LS_TASKS * LS_NCELL)); A(dalloc(h->ls_grp, (size_t)LS_TASKS * LS_NGROUP));
         A(dalloc(h->ls_cr, (size_t)LS_TASKS * h->N)); A(dalloc(h->ls_match, (size_t)h->maxB * h->ls_npad));
     }
-    A(dalloc(h->ccounts, (size_t)h->maxB * 4)); A(dalloc(h->ticket, (size_t)h->maxB));
+    A(dalloc(h->ccounts, (size_t)h->maxB * 4)); A(dalloc(h->ticket, (size_t)h->maxB * 2));      // [maxB, 2 maxB): the list kernel's claim counters
     A(dalloc(h->corr, BS)); A(dalloc(h->flags, (size_t)h->maxB)); A(dalloc(h->cd2, BS));
     if (brute) A(dalloc(h->chunk_cnt, (size_t)h->maxB * 2 * ((h->N + 1023) / 1024)));
     if (brute) A(dalloc(h->prevq, BS));      // (the tile search keeps 8-byte slot records instead: slot_rec)
@@ -495,7 +495,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
             return SLAM3D_E_NOMEM;
         }
     }
-    (void)hipMemsetAsync(h->ticket, 0, sizeof(unsigned int) * (size_t)h->maxB, h->stream);
+    (void)hipMemsetAsync(h->ticket, 0, sizeof(unsigned int) * (size_t)h->maxB * 2, h->stream);
     if (h->list_on) {      // the counting sort's counters clean up after themselves from here on
         (void)hipMemsetAsync(h->ls_cnt, 0, sizeof(int) * (size_t)LS_TASKS * LS_NCELL, h->stream);
         (void)hipMemsetAsync(h->ls_grp, 0, sizeof(int) * (size_t)LS_TASKS * LS_NGROUP, h->stream);
@@ -946,13 +946,13 @@ static int enqueue_preprocess(slam3d_icp_handle *h, int B, const double *T_init,
             TinitArgs ti;
             const int n = B - b0 < TINIT_ARGS ? B - b0 : TINIT_ARGS;
             memcpy(ti.T, T_init + (size_t)b0 * 16, sizeof(double) * 16 * n);
-            hipLaunchKernelGGL(k_pair_init, dim3(n), dim3(256), 0, s, ti, 1, b0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters, h->nsets,
+            hipLaunchKernelGGL(k_pair_init, dim3(n), dim3(256), 0, s, ti, 1, b0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, h->maxB, iters, h->nsets,
                                stamp_ring_of(h, b0 == 0), (count_run && b0 == 0) ? h->dev_runs : nullptr, g.pair_gate ? h->d_pairs : nullptr);
         }
     } else {
         TinitArgs ti;
         memset(&ti, 0, sizeof ti);
-        hipLaunchKernelGGL(k_pair_init, dim3(B), dim3(256), 0, s, ti, 0, 0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, iters, h->nsets,
+        hipLaunchKernelGGL(k_pair_init, dim3(B), dim3(256), 0, s, ti, 0, 0, h->Tcur, h->trace_T, h->flags, h->acc, h->ticket, h->maxB, iters, h->nsets,
                                stamp_ring_of(h), count_run ? h->dev_runs : nullptr, g.pair_gate ? h->d_pairs : nullptr);
     }
     if (count_run) h->run_counted = true;
@@ -1139,7 +1139,7 @@ static int enqueue_iterations(slam3d_icp_handle *h, int B, hipStream_t s, int it
         if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[1], s)); HIPCHK(h, hipEventRecord(h->ev[3], s)); }
         auto launch = [&](auto kern) {
             hipLaunchKernelGGL(kern, dim3(G, B), dim3(64 * LS_WAVES), 0, s, h->d_pairs, h->g, iters, n_coarse, h->nsets, h->ls_npad, h->Tcur, h->trace_T,
-                               h->trace_S, h->flags, h->acc, h->ticket, h->ls_match, h->corr, h->cd2, h->want_corr_trace ? h->corr_trace : nullptr,
+                               h->trace_S, h->flags, h->acc, h->ticket, h->ticket + h->maxB, h->ls_match, h->corr, h->cd2, h->want_corr_trace ? h->corr_trace : nullptr,
                                h->maxB, h->tg.nslots, h->d_res, h->dev_runs, h->ls_dbg);
         };
         if (h->ls_dbg && !is_p2p(h)) launch(k_list_icp<1, false, true>);        // SLAM3D_LIST_DEBUG=1: the instrumented instance

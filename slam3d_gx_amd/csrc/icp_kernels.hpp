@@ -541,7 +541,7 @@ constexpr int TINIT_ARGS = 16;
 struct TinitArgs { double T[TINIT_ARGS][16]; };
 __global__ __launch_bounds__(256) void k_pair_init(TinitArgs ti, int has_T, int b0, double *__restrict__ Tcur,
                                                   double *__restrict__ trace_T, int *__restrict__ flags,
-                                                  long long *__restrict__ acc, unsigned int *__restrict__ ticket, int iters, int nsets,
+                                                  long long *__restrict__ acc, unsigned int *__restrict__ ticket, int claim_off /* ticket[claim_off + b]: the list kernel's claim counter */, int iters, int nsets,
                                                   StampRing sr /* rows null: no stamps */, int *__restrict__ runs /* the device's run counter; non-null (slam3d_icp_run): one more run in flight */,
                                                   const PairPtrs *__restrict__ gate_pairs /* SLAM3D_PLANE_PAIR_GATE: the pair table (spec S4p association); else null */)
 {
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(256) void k_pair_init(TinitArgs ti, int has_T, int 
     // the pose rows the head solves will publish: every entry "not published yet"
     for (int j = 16 + lane; j < (iters + 1) * 16; j += 256)
         reinterpret_cast<unsigned long long *>(trace_T)[(size_t)b * (iters + 1) * 16 + j] = HEAD_EMPTY;
-    if (lane == 0) { flags[b] = 0; ticket[b] = 0u; }
+    if (lane == 0) { flags[b] = 0; ticket[b] = 0u; ticket[claim_off + b] = 0u; }
 }
 
 // a run that was counted by k_pair_init but whose launches could not all be enqueued: take it out of the count again

@@ -182,26 +182,29 @@ __global__ __launch_bounds__(256) void k_list_boxes(ListTasks a, int *__restrict
 //   * a wave first collects the candidate tiles that pass its lanes' box tests (LDS only), then streams them: the points of tile k + 1 are
 //     in flight while tile k is scanned out of a 1 KB LDS stage (one coalesced load per tile instead of four dependent scalar trips);
 //   * the previous match's coordinates are stored, not gathered again.
-// The svd estimator's step (solve_step_one(sums, T, 1): the same operations in the same order, so the same bits) with every array in
-// LDS: inlined into the persistent kernel the register form (H, g, v, dR, T: ~60 doubles) pushed the loop-carried values of the
-// search out to scratch -- 33 spilled VGPRs whose reloads (one L2 trip each) cost ~10 us at the head of every iteration.
-// ws: 48 doubles of LDS; T: the pose (LDS), updated in place.  One lane.  Returns 1 (updated) or 0 (fewer than 3 correspondences).
-__device__ __noinline__ int list_solve_svd(const double *sums, double *T, double *ws)
+// The svd estimator's step (solve_step_one(sums, T, 1): the same operations in the same order per value, so the same bits) for the
+// persistent kernel.  Inlined, the register form (H, g, v, dR, T: ~60 doubles in one lane) pushed the loop-carried values of the search
+// out to scratch (33 spilled VGPRs, reloaded at the head of every iteration); one lane working out of LDS took 7.9 us per iteration.
+// Spread over a wave: lane m < 3 owns ROW m of g and of v (lanes >= 3 shadow row 2); a column dot product is three
+// products, one per row, summed in the serial code's order from v_readlane values -- (g0p g0q + g1p g1q) + g2p g2q --, so every lane
+// computes the same al, be, ga, c and s and rotates its own row.  Same operations, same order per value as solve_step_one: the same bits (tests/test_unorganized.py compares every iterate with the oracle's), a third of the arithmetic and no
+// LDS round trip inside the chain (the one-lane LDS form: 7.9 us per iteration).  All 64 lanes call it; T is read before it is written.
+__device__ __noinline__ int list_solve_svd_wave(const double *sums, double *T)
 {
+    const int lane = threadIdx.x & 63, m = lane < 2 ? lane : 2;
     const double n = sums[27];
     if (n < 3.0) return 0;
-    double *g = ws, *v = ws + 9, *R = ws + 18, *pq = ws + 27;        // g[r * 3 + c], v[r * 3 + c], R (dR), pm[3] qm[3] dt[3], Tn[12]
-    for (int k = 0; k < 3; ++k) { pq[k] = sums[k] / n; pq[3 + k] = sums[3 + k] / n; }
-    for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) { g[r * 3 + c] = sums[6 + r * 3 + c] - (n * pq[r]) * pq[3 + c]; v[r * 3 + c] = r == c ? 1.0 : 0.0; }
+    const double pm0 = sums[0] / n, pm1 = sums[1] / n, pm2 = sums[2] / n, qm0 = sums[3] / n, qm1 = sums[4] / n, qm2 = sums[5] / n;
+    const double pmm = m == 0 ? pm0 : (m == 1 ? pm1 : pm2);
+    double g0 = sums[6 + m * 3 + 0] - (n * pmm) * qm0, g1 = sums[6 + m * 3 + 1] - (n * pmm) * qm1, g2 = sums[6 + m * 3 + 2] - (n * pmm) * qm2;
+    double v0 = m == 0 ? 1.0 : 0.0, v1 = m == 1 ? 1.0 : 0.0, v2 = m == 2 ? 1.0 : 0.0;
+    auto col3 = [&](double x) __attribute__((always_inline)) { return (bcast_d(x, 0) + bcast_d(x, 1)) + bcast_d(x, 2); };
     for (int sweep = 0; sweep < 12; ++sweep) {
         bool rotated = false;
+#pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const int p = k == 2 ? 1 : 0, q = k == 0 ? 1 : 2;
-            const double g0p = g[p], g1p = g[3 + p], g2p = g[6 + p], g0q = g[q], g1q = g[3 + q], g2q = g[6 + q];
-            const double al = (g0p * g0p + g1p * g1p) + g2p * g2p;
-            const double be = (g0q * g0q + g1q * g1q) + g2q * g2q;
-            const double ga = (g0p * g0q + g1p * g1q) + g2p * g2q;
+            double &gp = k == 2 ? g1 : g0, &gq = k == 0 ? g1 : g2, &vp = k == 2 ? v1 : v0, &vq = k == 0 ? v1 : v2;
+            const double al = col3(gp * gp), be = col3(gq * gq), ga = col3(gp * gq);
             if (ga * ga <= 0x1p-100 * (al * be)) continue;
             rotated = true;
             const double zeta = (be - al) / (2.0 * ga);
@@ -209,43 +212,45 @@ __device__ __noinline__ int list_solve_svd(const double *sums, double *T, double
             if (zeta < 0.0) t = -t;
             const double c = 1.0 / sqrt(t * t + 1.0);
             const double s = c * t;
-            for (int m = 0; m < 3; ++m) {
-                const double gp = g[m * 3 + p], gq = g[m * 3 + q];
-                g[m * 3 + p] = c * gp - s * gq;
-                g[m * 3 + q] = s * gp + c * gq;
-                const double vp = v[m * 3 + p], vq = v[m * 3 + q];
-                v[m * 3 + p] = c * vp - s * vq;
-                v[m * 3 + q] = s * vp + c * vq;
-            }
+            const double a = gp, b_ = gq;
+            gp = c * a - s * b_;
+            gq = s * a + c * b_;
+            const double e = vp, f = vq;
+            vp = c * e - s * f;
+            vq = s * e + c * f;
         }
         if (!rotated) break;
     }
-    double sg[3];
-    for (int k = 0; k < 3; ++k) sg[k] = sqrt((g[k] * g[k] + g[3 + k] * g[3 + k]) + g[6 + k] * g[6 + k]);
+    const double sg0 = sqrt(col3(g0 * g0)), sg1 = sqrt(col3(g1 * g1)), sg2 = sqrt(col3(g2 * g2));
+    auto sgof = [&](int i) __attribute__((always_inline)) { return i == 0 ? sg0 : (i == 1 ? sg1 : sg2); };
     int i0 = 0, i1 = 1, i2 = 2, tmp;
-    if (sg[i1] > sg[i0]) { tmp = i0; i0 = i1; i1 = tmp; }
-    if (sg[i2] > sg[i1]) { tmp = i1; i1 = i2; i2 = tmp; }
-    if (sg[i1] > sg[i0]) { tmp = i0; i0 = i1; i1 = tmp; }
-    for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
-    if ((sg[i0] > 0.0) && (sg[i1] > 1e-14 * sg[i0])) {
-        const double s0 = sg[i0], s1 = sg[i1];
-        const double u00 = g[i0] / s0, u01 = g[3 + i0] / s0, u02 = g[6 + i0] / s0;
-        const double u10 = g[i1] / s1, u11 = g[3 + i1] / s1, u12 = g[6 + i1] / s1;
-        const double v00 = v[i0], v01 = v[3 + i0], v02 = v[6 + i0], v10 = v[i1], v11 = v[3 + i1], v12 = v[6 + i1];
+    if (sgof(i1) > sgof(i0)) { tmp = i0; i0 = i1; i1 = tmp; }
+    if (sgof(i2) > sgof(i1)) { tmp = i1; i1 = i2; i2 = tmp; }
+    if (sgof(i1) > sgof(i0)) { tmp = i0; i0 = i1; i1 = tmp; }
+    double R0 = m == 0 ? 1.0 : 0.0, R1 = m == 1 ? 1.0 : 0.0, R2 = m == 2 ? 1.0 : 0.0;       // row m of dR
+    if ((sgof(i0) > 0.0) && (sgof(i1) > 1e-14 * sgof(i0))) {
+        const double s0 = sgof(i0), s1 = sgof(i1);
+        const double u0m = (i0 == 0 ? g0 : (i0 == 1 ? g1 : g2)) / s0, u1m = (i1 == 0 ? g0 : (i1 == 1 ? g1 : g2)) / s1;      // u0[m], u1[m]
+        const double w0m = i0 == 0 ? v0 : (i0 == 1 ? v1 : v2), w1m = i1 == 0 ? v0 : (i1 == 1 ? v1 : v2);                // v0[m], v1[m]
+        const double u00 = bcast_d(u0m, 0), u01 = bcast_d(u0m, 1), u02 = bcast_d(u0m, 2), u10 = bcast_d(u1m, 0), u11 = bcast_d(u1m, 1), u12 = bcast_d(u1m, 2);
+        const double w00 = bcast_d(w0m, 0), w01 = bcast_d(w0m, 1), w02 = bcast_d(w0m, 2), w10 = bcast_d(w1m, 0), w11 = bcast_d(w1m, 1), w12 = bcast_d(w1m, 2);
         const double u20 = u01 * u12 - u02 * u11, u21 = u02 * u10 - u00 * u12, u22 = u00 * u11 - u01 * u10;
-        const double v20 = v01 * v12 - v02 * v11, v21 = v02 * v10 - v00 * v12, v22 = v00 * v11 - v01 * v10;
-        R[0] = (v00 * u00 + v10 * u10) + v20 * u20; R[1] = (v00 * u01 + v10 * u11) + v20 * u21; R[2] = (v00 * u02 + v10 * u12) + v20 * u22;
-        R[3] = (v01 * u00 + v11 * u10) + v21 * u20; R[4] = (v01 * u01 + v11 * u11) + v21 * u21; R[5] = (v01 * u02 + v11 * u12) + v21 * u22;
-        R[6] = (v02 * u00 + v12 * u10) + v22 * u20; R[7] = (v02 * u01 + v12 * u11) + v22 * u21; R[8] = (v02 * u02 + v12 * u12) + v22 * u22;
+        const double w20 = w01 * w12 - w02 * w11, w21 = w02 * w10 - w00 * w12, w22 = w00 * w11 - w01 * w10;
+        const double w2m = m == 0 ? w20 : (m == 1 ? w21 : w22);
+        R0 = (w0m * u00 + w1m * u10) + w2m * u20;
+        R1 = (w0m * u01 + w1m * u11) + w2m * u21;
+        R2 = (w0m * u02 + w1m * u12) + w2m * u22;
     }
-    for (int r = 0; r < 3; ++r) pq[6 + r] = pq[3 + r] - ((R[r * 3 + 0] * pq[0] + R[r * 3 + 1] * pq[1]) + R[r * 3 + 2] * pq[2]);
-    double *Tn = ws + 36;
-    for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) Tn[r * 4 + c] = (R[r * 3 + 0] * T[0 * 4 + c] + R[r * 3 + 1] * T[1 * 4 + c]) + R[r * 3 + 2] * T[2 * 4 + c];
-        Tn[r * 4 + 3] = ((R[r * 3 + 0] * T[3] + R[r * 3 + 1] * T[7]) + R[r * 3 + 2] * T[11]) + pq[6 + r];
-    }
-    for (int k = 0; k < 12; ++k) T[k] = Tn[k];
-    T[12] = 0.0; T[13] = 0.0; T[14] = 0.0; T[15] = 1.0;
+    const double qmm = m == 0 ? qm0 : (m == 1 ? qm1 : qm2);
+    const double dt = qmm - ((R0 * pm0 + R1 * pm1) + R2 * pm2);
+    const double t0 = (R0 * T[0] + R1 * T[4]) + R2 * T[8], t1 = (R0 * T[1] + R1 * T[5]) + R2 * T[9], t2 = (R0 * T[2] + R1 * T[6]) + R2 * T[10];
+    const double t3 = ((R0 * T[3] + R1 * T[7]) + R2 * T[11]) + dt;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                               // (every lane has read T)
+    if (lane < 3) { T[lane * 4 + 0] = t0; T[lane * 4 + 1] = t1; T[lane * 4 + 2] = t2; T[lane * 4 + 3] = t3; }
+    if (lane == 3) { T[12] = 0.0; T[13] = 0.0; T[14] = 0.0; T[15] = 1.0; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     return 1;
 }
 
@@ -272,7 +277,7 @@ template <int EST, bool GATED, bool DBG = false>
 __global__ __launch_bounds__(64 * LS_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_list_icp(
     const PairPtrs *__restrict__ pairs, Geometry g, int iters, int n_coarse, int nsets, int N,
     double *__restrict__ Tcur, double *__restrict__ trace_T, double *__restrict__ trace_S, int *__restrict__ flags,
-    long long *__restrict__ acc, unsigned int *__restrict__ ticket, float4 *__restrict__ prev /* [B][N]: previous match (x, y, z, index) by sorted source position */,
+    long long *__restrict__ acc, unsigned int *__restrict__ ticket, unsigned int *__restrict__ claim /* [B], zero at launch */, float4 *__restrict__ prev /* [B][N]: previous match (x, y, z, index) by sorted source position */,
     int *__restrict__ corr, float *__restrict__ cd2, int *__restrict__ corr_trace /* nullable: [iters][maxB][nslots] */, int maxB, int nslots,
     double *__restrict__ res_host, int *__restrict__ end_run,
     long long *__restrict__ dbg /* nullable (SLAM3D_LIST_DEBUG=1): [iters][G][12] per block, thread 0: 100 MHz ticks spent in bounds, listing, scans, rows, Gram, arrive, barrier wait, totals, derive, solve; tiles wave 0 scanned; iteration start */)
@@ -286,7 +291,8 @@ __global__ __launch_bounds__(64 * LS_WAVES) __attribute__((amdgpu_waves_per_eu(4
     __shared__ float4 s_box[2 * LS_LDS_TILES];
     __shared__ int2 s_tile[LS_LDS_TILES];
     __shared__ float4 s_stage[LS_WAVES][64];
-    __shared__ float4 s_prev[2][64];
+    __shared__ float4 s_prev[1][64];
+    __shared__ int s_claim;
     __shared__ int s_cand[LS_WAVES][LS_CAND];
     const int b = blockIdx.y, G = gridDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const PairPtrs &pp = pairs[b];
@@ -302,18 +308,16 @@ __global__ __launch_bounds__(64 * LS_WAVES) __attribute__((amdgpu_waves_per_eu(4
         for (int k = tid; k < ntt; k += 64 * LS_WAVES) { const ls_i2 v = ttileg[k]; s_tile[k] = make_int2(v.x, v.y); }
     }
     if (tid < 16) Tsh[tid] = Tcur[b * 16 + tid];
-    // the block's first TWO source tiles (a 16 k-point list has ~330 tiles for 256 blocks): resident in registers
-    float4 r_s4a = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1)), r_s4b = r_s4a;
-    int r_starta = 0, r_cnta = 0, r_startb = 0, r_cntb = 0;
+    // the block's OWN source tile (tile = block): resident in registers.  The tiles beyond the grid width (a 16 k-point list has ~330
+    // tiles for 256 blocks) are CLAIMED, one at a time, by whichever block has finished: blocks whose own tile is cheap take them, and the
+    // slowest block -- which every other block waits for at the barrier -- is the one with the dearest single tile, not the one that
+    // was dealt two dear ones (static deal: slowest block 30-37 us, median 6-9).
+    float4 r_s4a = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
+    int r_starta = 0, r_cnta = 0;
     if ((int)blockIdx.x < nst) {
         const ls_i2 sd = stile[blockIdx.x];
         r_starta = sd.x; r_cnta = sd.y;
         if (lane < r_cnta) r_s4a = ls_ld(spts, r_starta + lane);
-    }
-    if ((int)blockIdx.x + G < nst) {
-        const ls_i2 sd = stile[blockIdx.x + G];
-        r_startb = sd.x; r_cntb = sd.y;
-        if (lane < r_cntb) r_s4b = ls_ld(spts, r_startb + lane);
     }
     int flag = 0;
     const float inf = __int_as_float(0x7f800000);
@@ -336,16 +340,40 @@ __global__ __launch_bounds__(64 * LS_WAVES) __attribute__((amdgpu_waves_per_eu(4
         m.r20 = uni_f((float)Tsh[8]); m.r21 = uni_f((float)Tsh[9]); m.r22 = uni_f((float)Tsh[10]); m.t2 = uni_f((float)Tsh[11]);
         long long *__restrict__ set = acc + (((size_t)b * nsets + it) * ACC_R + (blockIdx.x & (ACC_R - 1))) * ACC_STRIDE;
         const bool last = it == iters - 1;
-        for (int tile = blockIdx.x; tile < nst; tile += G) {
-            const bool res_a = tile == (int)blockIdx.x, res_b = tile == (int)blockIdx.x + G, resident = res_a || res_b;
-            int start = res_a ? r_starta : r_startb, cnt = res_a ? r_cnta : r_cntb;
-            float4 s4 = res_a ? r_s4a : r_s4b;
+        const int extras = nst > G ? nst - G : 0;                     // tiles beyond the grid: claimed
+        // (the claim for the NEXT tile is taken when the scans of the current one are merged: its round trip flies under the rows and the
+        //  Gram sums -- asked for after them it sat between the slowest block's last row and the barrier, 2.7 us; asked for a whole tile
+        //  ahead the extra tiles went to whoever STARTED first, not to whoever finished: the static deal again, 0.84 instead of 0.72 ms)
+        unsigned int my_claim = 0u;
+        for (int rnd = 0; ; ++rnd) {
+            int tile = blockIdx.x;
+            if (rnd > 0) {
+                // every block claims until a claim fails: extras + G claims per iteration, so iteration `it` starts at it * (extras + G)
+                if (extras == 0) break;
+                if (tid == 0) s_claim = (int)(my_claim - (unsigned int)it * (unsigned int)(extras + G));
+                ls_barrier();
+                const int c = s_claim;
+                ls_barrier();
+                if (c >= extras) break;
+                tile = G + c;
+            } else if (tile >= nst) continue;
+            const bool resident = rnd == 0;
+            int start = r_starta, cnt = r_cnta;
+            float4 s4 = r_s4a;
+            float4 pv = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
             if (!resident) {
                 const ls_i2 sd = stile[tile];                 // (wave-uniform)
                 start = sd.x; cnt = sd.y;
                 s4 = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-1));
-                if (lane < cnt) s4 = ls_ld(spts, start + lane);
-            }
+                if (lane < cnt) {
+                    s4 = ls_ld(spts, start + lane);
+                    if (it > 0) {      // its previous matches were stored by another block, maybe on another XCD: device-scope loads
+                        const unsigned long long *pg = reinterpret_cast<const unsigned long long *>(gprev + start + lane);
+                        const unsigned long long lo = __hip_atomic_load(pg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), hi = __hip_atomic_load(pg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        pv = make_float4(__int_as_float((int)(unsigned int)lo), __int_as_float((int)(unsigned int)(lo >> 32)), __int_as_float((int)(unsigned int)hi), __int_as_float((int)(unsigned int)(hi >> 32)));
+                    }
+                }
+            } else pv = s_prev[0][lane];
             const int idx = start + lane;
             const bool valid = lane < cnt;
             const int i = __float_as_int(s4.w);
@@ -354,7 +382,6 @@ __global__ __launch_bounds__(64 * LS_WAVES) __attribute__((amdgpu_waves_per_eu(4
             xform(m, s4.x, s4.y, s4.z, px, py, pz);
             unsigned long long key = key_gate;
             if (active && it > 0) {
-                const float4 pv = resident ? s_prev[res_a ? 0 : 1][lane] : gprev[idx];
                 const int jprev = __float_as_int(pv.w);
                 if (jprev >= 0) {
                     const float d2 = canon_d2(px, py, pz, pv.x, pv.y, pv.z);
@@ -388,41 +415,28 @@ __global__ __launch_bounds__(64 * LS_WAVES) __attribute__((amdgpu_waves_per_eu(4
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifndef LS_SCAN_EXP
-#define LS_SCAN_EXP 0
-#endif
-#if LS_SCAN_EXP == 0
+                    // Four candidates interleaved by hand, two key accumulators: with ONE wave per SIMD nothing else fills the issue slots
+                    // behind a dependent instruction (measured: ~10 cycles per VALU instruction in the straight form, 2.5 us per 64-candidate
+                    // tile; variants timed on the 16 k-point pair, tools/variants: LDS read + float minimum only -- the same time; lane
+                    // broadcast by v_readlane instead of LDS -- the same; next reads prefetched under the arithmetic -- the same; this form -9 %).
+                    unsigned long long kb = key;
                     for (int c0 = 0; c0 < n_; c0 += 8) {
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            const float4 q = s_stage[w][c0 + c];          // (broadcast read; entries behind the tile's count are at infinity)
-                            const float d2 = canon_d2(px, py, pz, q.x, q.y, q.z);
-                            key = key_min(key, ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | (unsigned int)__float_as_int(q.w));
+                        for (int h = 0; h < 2; ++h) {
+                            const float4 q0 = s_stage[w][c0 + 4 * h], q1 = s_stage[w][c0 + 4 * h + 1], q2 = s_stage[w][c0 + 4 * h + 2], q3 = s_stage[w][c0 + 4 * h + 3];
+                            const float x0 = q0.x - px, x1 = q1.x - px, x2 = q2.x - px, x3 = q3.x - px;
+                            const float y0 = q0.y - py, y1 = q1.y - py, y2 = q2.y - py, y3 = q3.y - py;
+                            const float z0 = q0.z - pz, z1 = q1.z - pz, z2 = q2.z - pz, z3 = q3.z - pz;
+                            float a0 = x0 * x0, a1 = x1 * x1, a2 = x2 * x2, a3 = x3 * x3;                // the canonical d2: fma(dz, dz, fma(dy, dy, dx dx))
+                            a0 = __fmaf_rn(y0, y0, a0); a1 = __fmaf_rn(y1, y1, a1); a2 = __fmaf_rn(y2, y2, a2); a3 = __fmaf_rn(y3, y3, a3);
+                            a0 = __fmaf_rn(z0, z0, a0); a1 = __fmaf_rn(z1, z1, a1); a2 = __fmaf_rn(z2, z2, a2); a3 = __fmaf_rn(z3, z3, a3);
+                            key = key_min(key, ((unsigned long long)(unsigned int)__float_as_int(a0) << 32) | (unsigned int)__float_as_int(q0.w));
+                            kb = key_min(kb, ((unsigned long long)(unsigned int)__float_as_int(a1) << 32) | (unsigned int)__float_as_int(q1.w));
+                            key = key_min(key, ((unsigned long long)(unsigned int)__float_as_int(a2) << 32) | (unsigned int)__float_as_int(q2.w));
+                            kb = key_min(kb, ((unsigned long long)(unsigned int)__float_as_int(a3) << 32) | (unsigned int)__float_as_int(q3.w));
                         }
                     }
-#elif LS_SCAN_EXP == 1      // timing experiment: LDS reads + float minimum only (results wrong)
-                    float dm = __int_as_float((int)(unsigned int)(key >> 32));
-                    for (int c0 = 0; c0 < n_; c0 += 8) {
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            const float4 q = s_stage[w][c0 + c];
-                            dm = fminf(dm, canon_d2(px, py, pz, q.x, q.y, q.z));
-                        }
-                    }
-                    key = ((unsigned long long)(unsigned int)__float_as_int(dm) << 32) | (unsigned int)key;
-#elif LS_SCAN_EXP == 2      // lane broadcast from the register instead of LDS, keyed minimum
-                    for (int c0 = 0; c0 < n_; c0 += 8) {
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            const float qx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.x), c0 + c)), qy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.y), c0 + c));
-                            const float qz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r.z), c0 + c));
-                            const unsigned int qj = (unsigned int)__builtin_amdgcn_readlane(__float_as_int(r.w), c0 + c);
-                            const float d2 = canon_d2(px, py, pz, qx, qy, qz);
-                            key = key_min(key, ((unsigned long long)(unsigned int)__float_as_int(d2) << 32) | qj);
-                        }
-                    }
-#elif LS_SCAN_EXP == 3      // timing experiment: no scan at all
-#endif
+                    key = key_min(key, kb);
                     __builtin_amdgcn_wave_barrier();                   // (the stage is rewritten by the next tile)
                 };
                 auto scan_listed = [&]() __attribute__((always_inline)) {
@@ -468,6 +482,7 @@ __global__ __launch_bounds__(64 * LS_WAVES) __attribute__((amdgpu_waves_per_eu(4
                 if (key != key0) atomicMin(&skey[lane], key);
             }
             ls_barrier();
+            if (extras > 0 && tid == 0) my_claim = __hip_atomic_fetch_add(claim + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (stamp) { const long long now_ = (long long)wall_clock64(); ph[2] += now_ - ph_prev; ph_prev = now_; }
             if (w == 0) {
                 key = skey[lane];
@@ -489,8 +504,12 @@ __global__ __launch_bounds__(64 * LS_WAVES) __attribute__((amdgpu_waves_per_eu(4
                 if (corr_trace && valid) corr_trace[((size_t)it * maxB + b) * nslots + slot] = rb.v[7] != 0.0 ? (int)(unsigned int)key : -1;
                 // the next iteration's bound: this match (an inactive point of a coarse iteration keeps the one it has; none yet in iteration 0)
                 if (active || it == 0) {
-                    if (resident) s_prev[res_a ? 0 : 1][lane] = pq;
-                    else if (valid) gprev[idx] = pq;
+                    if (resident) s_prev[0][lane] = pq;
+                    else if (valid) {      // (device-scope stores: the next iteration's claimant may sit on another XCD)
+                        unsigned long long *pg = reinterpret_cast<unsigned long long *>(gprev + idx);
+                        __hip_atomic_store(pg, (unsigned long long)(unsigned int)__float_as_int(pq.x) | ((unsigned long long)(unsigned int)__float_as_int(pq.y) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(pg + 1, (unsigned long long)(unsigned int)__float_as_int(pq.z) | ((unsigned long long)(unsigned int)__float_as_int(pq.w) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 }
                 if (stamp) { const long long now_ = (long long)wall_clock64(); ph[3] += now_ - ph_prev; ph_prev = now_; }
                 tile_accumulate(rb, set, slab);
@@ -498,6 +517,7 @@ __global__ __launch_bounds__(64 * LS_WAVES) __attribute__((amdgpu_waves_per_eu(4
             }
         }
         // ---- grid barrier of the pair: every block's Gram sums are in the accumulator set
+        if (tid < NRAW) Gs[tid] = 0;
         ls_barrier();
         if (w == 0) {
             // Wave 0 issued every global write of this block that another block reads: the Gram atomics (device-scope read-modify-writes,
@@ -515,11 +535,21 @@ __global__ __launch_bounds__(64 * LS_WAVES) __attribute__((amdgpu_waves_per_eu(4
         ls_barrier();
         if (stamp) { const long long now_ = (long long)wall_clock64(); ph[6] += now_ - ph_prev; ph_prev = now_; }
         const long long *__restrict__ A = acc + ((size_t)b * nsets + it) * ACC_R * ACC_STRIDE;
-        if (tid < NRAW) {
-            long long q = 0;
+        {   // the 16 replicas x 36 totals: every thread fetches two or three words (device-scope loads, all in flight together) and adds
+            // them into the LDS totals (zeroed before the grid barrier) -- 36 threads x 16 loads each took 4.4 us
+            long long v[3];
 #pragma unroll
-            for (int r = 0; r < ACC_R; ++r) q += __hip_atomic_load(A + r * ACC_STRIDE + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            Gs[tid] = q;
+            for (int u = 0; u < 3; ++u) {
+                const int idx = tid + u * 64 * LS_WAVES;
+                v[u] = 0;
+                if (idx < ACC_R * ACC_STRIDE && idx % ACC_STRIDE < NRAW) v[u] = __hip_atomic_load(A + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int idx = tid + u * 64 * LS_WAVES;
+                if (idx < ACC_R * ACC_STRIDE && idx % ACC_STRIDE < NRAW && v[u] != 0)
+                    atomicAdd(reinterpret_cast<unsigned long long *>(&Gs[idx % ACC_STRIDE]), (unsigned long long)v[u]);
+            }
         }
         ls_barrier();
         if (stamp) { const long long now_ = (long long)wall_clock64(); ph[7] += now_ - ph_prev; ph_prev = now_; }
@@ -533,7 +563,8 @@ __global__ __launch_bounds__(64 * LS_WAVES) __attribute__((amdgpu_waves_per_eu(4
                 __builtin_amdgcn_wave_barrier();
                 if (lane < 16) Tsh[lane] = Tn;
             } else {
-                if (lane == 0) s_rc = list_solve_svd(tot, Tsh, slab);       // (the Gram slab is free between two tiles)
+                const int rcw = list_solve_svd_wave(tot, Tsh);
+                if (lane == 0) s_rc = rcw;
             }
         }
         ls_barrier();

@@ -114,3 +114,24 @@ def test_production_search_kernels_have_no_scratch_and_use_the_fp64_matrix_cores
     assert waits and int(waits[-1]) >= 3, waits
     # and no wait inside the scan loop's own blocks drains everything before an MFMA: the flagged groups are queued (LDS), their
     # targets are loaded in the drain
+
+
+def test_persistent_list_kernel_keeps_its_co_residency_budget(device_asm):
+    """k_list_icp (point lists, round 6) meets its other blocks at a grid barrier, so every block of a launch must be resident:
+    at most 256 blocks of four waves per launch, and four such launches (the runtime's four hardware queues) fit the chip only while a
+    block needs <= 128 VGPRs, no scratch and <= 40 KB of LDS (four blocks per CU).  The production instances also must not fence:
+    __threadfence() is buffer_wbl2 + buffer_inv on gfx950 -- an L2 write-back and invalidate per block and iteration.
+    Parity: tests/test_unorganized.py."""
+    meta = _meta(device_asm)
+    bodies = _kernel_bodies(device_asm)
+    inst = [n for n in meta if "k_list_icp" in n]
+    assert len(inst) == 4, inst                                  # svd, planes, planes + gates, and the instrumented svd instance
+    for n in inst:
+        assert int(meta[n]["vgpr_count"]) <= 128 and int(meta[n]["private_segment_fixed_size"]) == 0 and int(meta[n]["vgpr_spill_count"]) == 0, (n, meta[n])
+        assert int(meta[n]["group_segment_fixed_size"]) <= 40 * 1024, meta[n]["group_segment_fixed_size"]
+        # (the device functions this kernel calls out of line sit in front of it and would swallow its label in _kernel_bodies)
+        body = device_asm.split("\n" + n + ":", 1)[1].split("s_endpgm", 1)[0]
+        assert "buffer_wbl2" not in body and "buffer_inv" not in body, "a device-scope fence crept into the persistent kernel"
+        assert body.count("v_mfma_f64_16x16x4") == 8
+        # the tile loads are issued by hand and waited for with vmcnt(2): three in flight
+        assert len(re.findall(r"s_waitcnt vmcnt\(2\)", body)) >= 3
