@@ -57,7 +57,10 @@ GraphicEndICP::GraphicEndICP()
 
 GraphicEndICP::~GraphicEndICP()
 {
-    for (size_t k = 0; k < _devs.size(); ++k) if (_devs[k].icp) slam3d_icp_destroy(_devs[k].icp);
+    for (size_t k = 0; k < _devs.size(); ++k) {
+        if (_devs[k].icp_list) slam3d_icp_destroy(_devs[k].icp_list);
+        if (_devs[k].icp) slam3d_icp_destroy(_devs[k].icp);
+    }
     delete _reader;
     if (g_pParaReader == _reader) g_pParaReader = nullptr;
 }
@@ -83,6 +86,12 @@ void GraphicEndICP::init(const string &param_file)
     _read_pcd = _reader->Has("icp_read_pcd") && _reader->GetPara("icp_read_pcd") == "yes";
     _pclPath = source + "/pcd/";                                                       // src/GraphicEnd.cpp:85
     _grid_leaf = (float)_reader->GetDouble("grid_leaf", 0.03);                         // :288
+    // icp_cloud: depth (default) -- multiPnP aligns the organized depth frames;  voxel -- it aligns the cloud readimage made of the
+    // frame (PCD -> PassThrough -> VoxelGrid, ~15 k points; needs icp_read_pcd: yes), which is what the reference hands on
+    // (src/GraphicEnd.cpp:279-295 -> :158): point lists, svd estimator, one persistent launch per alignment (csrc/list_icp.hpp)
+    _cloud_voxel = _reader->Has("icp_cloud") && _reader->GetPara("icp_cloud") == "voxel";
+    _cloud_max_points = _reader->GetInt("icp_cloud_max_points", 32768);
+    if (_cloud_voxel && !_read_pcd) { cerr << "icp_cloud: voxel needs icp_read_pcd: yes (the voxel cloud is made from the frame's PCD file)" << endl; exit(1); }
     _extract_planes = _reader->Has("icp_extract_planes") && _reader->GetPara("icp_extract_planes") == "yes";
     slam3d_seg_default_params(&_seg);
     _seg.distance_threshold = (float)_reader->GetDouble("distance_threshold", 0.08);   // src/GraphicEnd.cpp:89
@@ -164,6 +173,15 @@ void GraphicEndICP::init(const string &param_file)
                 cerr << "slam3d_icp_set_seg_params failed: " << slam3d_strerror(src) << " (" << slam3d_last_error(d.icp) << "); plane parameters of parameters.yaml are out of the library's range" << endl;
                 exit(1);                 // while extractPlanes used _seg -- a fatal config error like the reference's (:113)
             }
+        }
+        if (_cloud_voxel) {
+            slam3d_icp_params lp = _params;
+            lp.width = _cloud_max_points; lp.height = 1;
+            lp.estimator = SLAM3D_EST_SVD; lp.plane_flags = 0;                 // a list has no 7x7 windows: point-to-point (Kabsch)
+            lp.max_plane_residual2 = 0.0f; lp.min_normal_cos = 0.0f;
+            lp.nn_mode = SLAM3D_NN_AUTO;
+            const int lrc = slam3d_icp_create(&lp, &d.icp_list);
+            if (lrc != SLAM3D_OK) { cerr << "slam3d_icp_create (point lists, device " << d.device << ") failed: " << slam3d_strerror(lrc) << endl; exit(1); }
         }
         d.first_frame = 2 * _max_batch;
         d.key.assign(_params.extra_frames, -1);
@@ -276,7 +294,11 @@ int GraphicEndICP::residentFrame(Device &d, const FRAME &f, unsigned long long p
     }
     const int victim = free_slot >= 0 ? free_slot : lru;
     if (victim < 0) return -1;
-    if (slam3d_icp_frame_set_depth_host(d.icp, d.first_frame + victim, f.depth.data()) != SLAM3D_OK) return -1;
+    if (_cloud_voxel) {
+        if (f.cloud.empty() || (int)f.cloud.size() > _cloud_max_points) return -1;          // no PCD for this frame, or more voxels than the handle holds
+        const slam3d_cloud_view v = { f.cloud.data(), 16, (int32_t)f.cloud.size(), 1 };    // {x, y, z, rgba} records: xyz are read
+        if (slam3d_icp_frame_set_cloud_host(d.icp_list, d.first_frame + victim, &v) != SLAM3D_OK) return -1;
+    } else if (slam3d_icp_frame_set_depth_host(d.icp, d.first_frame + victim, f.depth.data()) != SLAM3D_OK) return -1;
     d.key[victim] = f.frame_index;
     d.used[victim] = pin;
     return d.first_frame + victim;
@@ -285,19 +307,20 @@ int GraphicEndICP::residentFrame(Device &d, const FRAME &f, unsigned long long p
 void GraphicEndICP::alignOnDevice(Device &d, const vector<const FRAME *> &f1, const vector<const FRAME *> &f2, int b0, int b1,
                                   int minimum_inliers, bool loopclosure, vector<RESULT_OF_MULTIPNP> &out, const double *T_init)
 {
+    slam3d_icp_handle *icp = _cloud_voxel ? d.icp_list : d.icp;
     for (int c0 = b0; c0 < b1; c0 += _max_batch) {
         const int nb = min(_max_batch, b1 - c0);
         const unsigned long long pin = ++d.clock;
         bool ok = true;
         for (int k = 0; k < nb && ok; ++k) {
             const int fs = residentFrame(d, *f1[c0 + k], pin), ft = residentFrame(d, *f2[c0 + k], pin);
-            ok = fs >= 0 && ft >= 0 && slam3d_icp_set_pair(d.icp, k, fs, ft) == SLAM3D_OK;
+            ok = fs >= 0 && ft >= 0 && slam3d_icp_set_pair(icp, k, fs, ft) == SLAM3D_OK;
         }
         vector<slam3d_icp_result> res(nb);
-        int rc = ok ? slam3d_icp_run(d.icp, nb, T_init ? T_init + (size_t)c0 * 16 : nullptr, nullptr) : SLAM3D_E_STATE;
-        if (rc == SLAM3D_OK) rc = slam3d_icp_fetch_results(d.icp, nb, res.data());
+        int rc = ok ? slam3d_icp_run(icp, nb, T_init ? T_init + (size_t)c0 * 16 : nullptr, nullptr) : SLAM3D_E_STATE;
+        if (rc == SLAM3D_OK) rc = slam3d_icp_fetch_results(icp, nb, res.data());
         if (rc < 0) {
-            cerr << "slam3d_icp (device " << d.device << "): " << slam3d_strerror(rc) << " " << slam3d_last_error(d.icp) << endl;
+            cerr << "slam3d_icp (device " << d.device << "): " << slam3d_strerror(rc) << " " << slam3d_last_error(icp) << endl;
             continue;                                              // results stay Identity = "not matched"
         }
         const double min_ratio = loopclosure ? _loop_min_inlier_ratio : _min_inlier_ratio;

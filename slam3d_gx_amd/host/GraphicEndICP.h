@@ -91,6 +91,7 @@ class GraphicEndICP {
     // a keyframe is uploaded and preprocessed once, not once per multiPnP call
     struct Device {
         slam3d_icp_handle *icp = nullptr;
+        slam3d_icp_handle *icp_list = nullptr;       // icp_cloud: voxel -- a point-list handle (height 1) for readimage's voxel clouds
         int device = 0, first_frame = 0;
         std::vector<int> key;                        // resident slot -> frame_index (-1 free)
         std::vector<unsigned long long> used;        // LRU stamps
@@ -128,6 +129,8 @@ class GraphicEndICP {
     slam3d_seg_params _seg;
     std::ofstream _lcfile, _planefile;
     bool _read_pcd = false;
+    bool _cloud_voxel = false;        // icp_cloud: voxel -- multiPnP aligns readimage's voxel clouds (point lists), as the reference hands them on (src/GraphicEnd.cpp:158)
+    int _cloud_max_points = 32768;    // icp_cloud_max_points: capacity of the point-list handle
     std::string _pclPath;
     float _grid_leaf = 0.03f;
 };

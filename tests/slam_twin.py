@@ -32,9 +32,12 @@ def inv_rigid(T):
 
 
 class Twin:
-    def __init__(self, intr, depth_of, cfg):
-        """depth_of(frame_index) -> uint16 image; cfg: dict of the parameters.yaml values run_SLAM was given"""
+    def __init__(self, intr, depth_of, cfg, cloud_of=None):
+        """depth_of(frame_index) -> uint16 image; cfg: dict of the parameters.yaml values run_SLAM was given;
+        cloud_of(frame_index) -> [n, 4] float32 voxel cloud (icp_cloud: voxel -- multiPnP aligns readimage's point lists)"""
         self.depth_of = depth_of
+        self.cloud_of = cloud_of
+        self.hl = None
         self.c = dict(max_pos_change=0.25, error_threshold=1.0, lost_frames=10, loop_closure_error=1.5, loop_closure_inliers=30,
                       loop_closure_detection=False, loopclosure_frames=30, loopclosure_seed=1, icp_iterations=20, icp_min_inliers=12,
                       icp_min_inlier_ratio=0.3, icp_max_rmse=0.05, icp_loop_min_inlier_ratio=0.6, icp_loop_max_rmse=0.02, start_index=1)
@@ -47,6 +50,12 @@ class Twin:
         if self.c.get("estimator", 0) == capi.EST_PLANE:      # GraphicEndICP hands the library parameters.yaml's plane keys, seed 1
             self.h.set_seg_params(self.h.seg_params(distance_threshold=self.c.get("distance_threshold", 0.08), plane_percent=self.c.get("plane_percent", 0.2),
                                                     max_planes=self.c.get("max_planes", 3), hypotheses=self.c.get("ransac_hypotheses", 64), seed=1))
+        if self.c.get("icp_cloud") == "voxel":                # GraphicEndICP's second handle: lists of icp_cloud_max_points, svd
+            cap = int(self.c.get("icp_cloud_max_points", 32768))
+            self.cap = cap
+            self.hl = capi.IcpHandle(capi.default_params(type(intr)(width=cap, height=1), iterations=self.c["icp_iterations"],
+                                                         min_inliers=self.c["icp_min_inliers"], error_threshold=self.c["error_threshold"],
+                                                         max_batch=1, estimator=capi.EST_SVD))
         self.index = self.c["start_index"]
         self.lost = 0
         self.lc_state = self.c["loopclosure_seed"]
@@ -66,11 +75,22 @@ class Twin:
 
     def close(self):
         self.h.close()
+        if self.hl is not None:
+            self.hl.close()
+
+    def _list_view(self, f):
+        c = np.asarray(self.cloud_of(f), dtype=np.float32)
+        out = np.zeros((1, len(c), 4), dtype=np.float32)
+        out[0, :, :3] = c[:, :3]
+        return out
 
     # ---- multiPnP with the gates of GraphicEndICP::alignOnDevice
     def multi_pnp(self, f1, f2, loop=False, min_inliers=None, T_init=None):
         min_inliers = self.c["icp_min_inliers"] if min_inliers is None else min_inliers
-        r = self.h.align_depth_batch([self.depth_of(f1)], [self.depth_of(f2)], None if T_init is None else [T_init])[0]
+        if self.hl is not None:
+            r = self.hl.align(self._list_view(f1), self._list_view(f2), T_init)
+        else:
+            r = self.h.align_depth_batch([self.depth_of(f1)], [self.depth_of(f2)], None if T_init is None else [T_init])[0]
         ratio = self.c["icp_loop_min_inlier_ratio"] if loop else self.c["icp_min_inlier_ratio"]
         rmse = self.c["icp_loop_max_rmse"] if loop else self.c["icp_max_rmse"]
         good = r["status"] == 0 and r["inliers"] >= min_inliers

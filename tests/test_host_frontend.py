@@ -544,6 +544,64 @@ def test_correspondence_gates_reach_the_device_from_parameters_yaml(gpu_lib, tmp
 
 
 @pytest.mark.gpu
+def test_run_slam_aligns_the_voxel_clouds_readimage_makes(gpu_lib, tmp_path):
+    """the reference hands the cloud readimage produced -- PCD -> PassThrough -> VoxelGrid(0.03) -- on to its
+    alignment (src/GraphicEnd.cpp:279-295 -> :158).  `icp_cloud: voxel` makes GraphicEndICP::multiPnP align exactly those point lists
+    (a height-1 handle, svd, the persistent list launch): run_SLAM on PCD input == the Python twin that aligns the ORACLE's voxel
+    clouds through the C-ABI, and differs from the depth-image run of the same sequence."""
+    import slam_twin
+    _build_host()
+    step = synth.pose_from_seed(4242, max_angle_deg=1.0, max_trans=0.02)
+    poses = [np.eye(4)]
+    for k in range(4):
+        poses.append(step @ poses[-1])
+    intr, data = _sequence(tmp_path, poses)
+    (data / "pcd").mkdir()
+    head = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z rgba\nSIZE 4 4 4 4\nTYPE F F F U\nCOUNT 1 1 1 1\n"
+            "WIDTH {n}\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {n}\nDATA binary\n")
+    from PIL import Image
+    depth_of = lambda i: np.array(Image.open(str(data / "dep_index" / f"{i}.png"))).astype(np.uint16)
+    vox = {}
+    for k in range(len(poses)):
+        c = synth.backproject_numpy(depth_of(k + 1), intr, z_filter=1e9).reshape(-1, 4)
+        c = c[np.isfinite(c[:, 2])].copy()                      # convert2PCD drops d == 0 (src/convert2PCD.cpp:60-61)
+        c[:, 3] = np.float32(0)
+        (data / "pcd" / f"{k + 1}.pcd").write_bytes(head.format(n=c.shape[0]).encode() + c.tobytes())
+        vox[k + 1] = O.voxel_grid(c, 0.03, 7.0)
+    assert all(10000 < len(v) < 32768 for v in vox.values()), [len(v) for v in vox.values()]      # > 384 tiles: the boxes do not fit LDS, read from L2
+    cfg = dict(max_pos_change=0.005, icp_iterations=15)
+    n = len(poses) - 1
+    logs = {}
+    for mode in ("voxel", "depth"):
+        extra = "icp_cloud: voxel\n" if mode == "voxel" else ""
+        (tmp_path / "parameters.yaml").write_text(
+            PARAMS.format(src=str(data), mpc=cfg["max_pos_change"], fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=320, h=240, lc="no", planes="no",
+                          pcd="yes", extra=extra))
+        out = subprocess.run([os.path.join(HOST, "run_SLAM"), str(n)], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        logs[mode] = [float(x) for x in (tmp_path / "data" / "error_of_transform.log").read_text().split()]
+        if mode == "voxel":
+            got = [int(t.split()[2]) for t in out.stdout.splitlines() if t.startswith("multiICP::inliers")]      # "inliers = a / n_src"
+            nsrc = [int(t.split()[4].rstrip(",")) for t in out.stdout.splitlines() if t.startswith("multiICP::inliers")]
+            assert got and all(a > 1000 for a in got) and set(nsrc) <= {len(v) for v in vox.values()}, (got, nsrc)   # the sources ARE the voxel clouds
+    tw = slam_twin.Twin(intr, depth_of, dict(cfg, icp_cloud="voxel"), cloud_of=lambda i: vox[i])
+    try:
+        for _ in range(n):
+            tw.run()
+    finally:
+        tw.close()
+    want = [float(x) for x in tw.err_log]
+    assert len(logs["voxel"]) == len(want) == n
+    assert all(abs(a - b) <= 1e-5 * max(1.0, abs(b)) for a, b in zip(logs["voxel"], want)), (logs["voxel"], want)
+    assert any(abs(a - b) > 1e-7 for a, b in zip(logs["voxel"], logs["depth"]))
+    # icp_cloud: voxel without PCD input is a fatal configuration error, like the reference's (src/GraphicEnd.cpp:113)
+    (tmp_path / "parameters.yaml").write_text(
+        PARAMS.format(src=str(data), mpc=0.005, fx=intr.fx, fy=intr.fy, cx=intr.cx, cy=intr.cy, w=320, h=240, lc="no", planes="no", pcd="no", extra="icp_cloud: voxel\n"))
+    bad = subprocess.run([os.path.join(HOST, "run_SLAM"), "1"], cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "icp_read_pcd" in bad.stderr
+
+
+@pytest.mark.gpu
 def test_plane_estimator_reaches_the_device_from_parameters_yaml(gpu_lib, tmp_path):
     """`icp_estimator: plane` (+ `icp_plane_pair_gate: yes`): run_SLAM aligns with SLAM3D_EST_PLANE -- the planes the library extracts
     per frame give the normals (src/GraphicEnd.cpp:158,168: planes per frame drive the pose), correspondences only inside associated
