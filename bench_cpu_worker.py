@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""bench.py's cpu_baseline leg, the timed part: the CPU oracle on one pair at ONE thread count, in a process of its own.
+
+Why a process of its own: the team must be pinned before libgomp starts -- OMP_PROC_BIND / OMP_PLACES are read
+once, and sched_setaffinity on a live process moves only the calling thread -- and bench.py's own threads (pose fetchers, the HIP
+runtime's) must not share the team's cores.  The worker restricts itself to the first `threads` PHYSICAL cores of ONE NUMA node
+(one hardware thread per core, the node of the first allowed CPU), binds the OpenMP team to them (OMP_PROC_BIND=close,
+OMP_PLACES=cores), runs a warm-up and `runs` timed alignments and prints their wall times as JSON.
+
+usage: bench_cpu_worker.py pair.npz spec.json      (spec: width height params{...} T_init|null threads runs)
+Test infrastructure: this file and tests/oracle_lib.py are the only callers of oracle/ outside tests/."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def numa_local_cores(n):
+    """up to n CPUs: one hardware thread per physical core, all on the NUMA node of the first CPU this process may run on"""
+    allowed = sorted(os.sched_getaffinity(0))
+    first = allowed[0]
+    node_cpus = None
+    try:
+        base = "/sys/devices/system/node"
+        for d in sorted(os.listdir(base)):
+            if not d.startswith("node"):
+                continue
+            cpus = set()
+            for part in open(os.path.join(base, d, "cpulist")).read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+            if first in cpus:
+                node_cpus = cpus
+                break
+    except OSError:
+        pass
+    cand = [c for c in allowed if node_cpus is None or c in node_cpus]
+    seen, cores = set(), []
+    for c in cand:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        if sib in seen:
+            continue
+        seen.add(sib)
+        cores.append(c)
+    if len(cores) < n:                       # more threads than the node has cores: its hardware threads, then the other nodes' CPUs
+        cores += [c for c in cand if c not in cores]
+        cores += [c for c in allowed if c not in cores]
+    return cores[:n], (node_cpus is not None and len([c for c in cores[:n] if c in node_cpus]) == min(n, len(cores[:n])))
+
+
+def main():
+    npz, spec_path = sys.argv[1], sys.argv[2]
+    spec = json.load(open(spec_path))
+    th = int(spec["threads"])
+    cpus, local = numa_local_cores(th)
+    os.sched_setaffinity(0, cpus)
+    os.environ["OMP_NUM_THREADS"] = str(th)
+    os.environ["OMP_PROC_BIND"] = "close"
+    os.environ["OMP_PLACES"] = "cores"
+    os.environ.setdefault("OMP_WAIT_POLICY", "active")          # (a dedicated, pinned team: spinning is what a tuned CPU run would do)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import oracle_lib as O
+    from slam3d_gx_amd import synth
+    z = np.load(npz)
+    intr = synth.Intrinsics.scaled(spec["width"], spec["height"]) if spec["height"] > 1 else synth.Intrinsics(width=spec["width"], height=1)
+    p = O.params(intr, threads=th, **spec["params"])
+    Ti = None if spec.get("T_init") is None else np.array(spec["T_init"], dtype=np.float64).reshape(4, 4)
+    O.icp(z["s4"], z["t4"], p, T_init=Ti, trace=False)          # warm-up: thread team, page faults
+    times = []
+    for _ in range(int(spec["runs"])):
+        t0 = time.perf_counter()
+        O.icp(z["s4"], z["t4"], p, T_init=Ti, trace=False)
+        times.append(time.perf_counter() - t0)
+    print(json.dumps({"threads": th, "times_s": times, "cpus": cpus, "numa_local": bool(local)}))
+
+
+if __name__ == "__main__":
+    main()
