@@ -374,6 +374,8 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     g.estimator = p->estimator == SLAM3D_EST_SVD ? 1 : 0;          // the kernels know two row forms; PLANE is POINT2PLANE with other normals
     g.pair_gate = (p->estimator == SLAM3D_EST_PLANE && (p->plane_flags & SLAM3D_PLANE_PAIR_GATE)) ? 1 : 0;
     slam3d_seg_default_params(&h->seg_sp);
+    h->seg_sp.distance_threshold = 0.04f;      // SLAM3D_EST_PLANE's own segmentation (spec S2p; round 6: swept 0.02-0.08 on the Kinect frames and both synthetic workloads,
+                                               // DESIGN.md section 3 -- slam3d_seg_default_params keeps the reference's plane-extraction key, 0.08)
     g.fx = p->fx; g.fy = p->fy; g.cx = p->cx; g.cy = p->cy; g.factor = p->depth_factor; g.zf = p->z_filter;
     h->row0 = 0; h->row1 = p->height;
     TileGrid &tg = h->tg;

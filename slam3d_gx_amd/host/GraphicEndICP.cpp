@@ -168,6 +168,8 @@ void GraphicEndICP::init(const string &param_file)
         if (_params.estimator == SLAM3D_EST_PLANE) {     // the library segments with the reference's plane parameters (fixed seed: a frame's planes do not depend on who aligns it)
             slam3d_seg_params sp = _seg;
             sp.seed = 1;
+            // the ICP's own segmentation threshold (spec S2p) -- not the plane-extraction key distance_threshold (0.08, src/GraphicEnd.cpp:89)
+            sp.distance_threshold = (float)_reader->GetDouble("icp_seg_distance_threshold", 0.04);
             const int src = slam3d_icp_set_seg_params(d.icp, &sp);
             if (src != SLAM3D_OK) {      // e.g. max_planes / ransac_hypotheses above the library's limits: the library would segment with ITS defaults
                 cerr << "slam3d_icp_set_seg_params failed: " << slam3d_strerror(src) << " (" << slam3d_last_error(d.icp) << "); plane parameters of parameters.yaml are out of the library's range" << endl;

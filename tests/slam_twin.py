@@ -48,7 +48,7 @@ class Twin:
                                                     min_normal_cos=self.c.get("min_normal_cos", 0.0),
                                                     estimator=self.c.get("estimator", 0), plane_flags=self.c.get("plane_flags", 0)))
         if self.c.get("estimator", 0) == capi.EST_PLANE:      # GraphicEndICP hands the library parameters.yaml's plane keys, seed 1
-            self.h.set_seg_params(self.h.seg_params(distance_threshold=self.c.get("distance_threshold", 0.08), plane_percent=self.c.get("plane_percent", 0.2),
+            self.h.set_seg_params(self.h.seg_params(distance_threshold=self.c.get("icp_seg_distance_threshold", 0.04), plane_percent=self.c.get("plane_percent", 0.2),
                                                     max_planes=self.c.get("max_planes", 3), hypotheses=self.c.get("ransac_hypotheses", 64), seed=1))
         if self.c.get("icp_cloud") == "voxel":                # GraphicEndICP's second handle: lists of icp_cloud_max_points, svd
             cap = int(self.c.get("icp_cloud_max_points", 32768))

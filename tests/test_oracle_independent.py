@@ -293,7 +293,7 @@ def _mix64(z):
     return z ^ (z >> 31)
 
 
-def segment_planes_numpy(c4, zmax=7.0, thr=0.08, percent=0.2, max_planes=3, hypotheses=64, seed=1, draws=32):
+def segment_planes_numpy(c4, zmax=7.0, thr=0.04, percent=0.2, max_planes=3, hypotheses=64, seed=1, draws=32):
     """Spec P1-P5 (DESIGN.md section 10; the pcl::SACSegmentation loop of src/GraphicEnd.cpp:353-430) written against the SPEC
     with numpy: python integers for the counter-based draws, vectorised float32 consensus tests, int64 moments,
     numpy.linalg.eigh for the refinement (the oracle: cyclic Jacobi).  -> (planes [n, 8] float32: a b c d cx cy cz count, labels [N])"""

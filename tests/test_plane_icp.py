@@ -80,19 +80,35 @@ def test_plane_association_is_the_exact_nearest_plane_under_the_initial_pose():
 
 def test_plane_estimator_settles_where_the_window_estimator_keeps_moving():
     """The measured reason for the estimator: on the reference's Kinect frames the window-normal run still
-    moves by a millimetre per iteration at its end, the plane run has stopped -- so its late launches track and certify."""
-    d2 = _kinect("exp1_dep_2.png")
+    moves by a millimetre per iteration at its end, the plane run has stopped -- so its late launches track and certify.
+    Round 6: the test also looks at WHERE the run stops.  The perturbed self-alignments (2 degrees / 3 cm off)
+    of BOTH frames must come back to the identity: dep1 within 1 mrad / 2 mm; dep2 within 3 mrad / 5 mm -- point-to-plane residuals
+    do not see a slide along the frame's planes and the identity is one fixed point among several, its rotation error stays at
+    2.0-2.6 mrad for every segmentation threshold between 0.02 and 0.08 m (sweep in DESIGN.md section 3).  The default threshold
+    (0.04 m, chosen from that sweep) is what is under test: at the reference's plane-extraction key (0.08 m) dep2 ended 10.7 mm off."""
     intr = synth.Intrinsics()
     Ti = synth.pose_from_seed(77, 2.0, 0.03)
-    step = {}
-    for est in (0, 2):
-        p = O.params(intr, iterations=20, estimator=est, plane_pair_gate=1 if est == 2 else 0)
-        c = O.backproject(d2, p)
-        r = O.icp(c, c, p, T_init=Ti)
-        assert r["status"] == 0
-        step[est] = O.pose_error(r["T_trace"][15], r["T_trace"][16])
-    assert step[0][1] > 1e-3            # window normals: > 1 mm per iteration at iteration 15
-    assert step[2][1] < 1e-4 and step[2][0] < 1e-4
+    bars = {"exp1_dep_1.png": (1e-3, 2e-3), "exp1_dep_2.png": (3e-3, 5e-3)}
+    for name, (rot_bar, tr_bar) in bars.items():
+        d = _kinect(name)
+        step, end = {}, {}
+        for est in (0, 2):
+            p = O.params(intr, iterations=20, estimator=est, plane_pair_gate=1 if est == 2 else 0)
+            assert est == 0 or abs(p.seg_distance_threshold - 0.04) < 1e-7
+            c = O.backproject(d, p)
+            r = O.icp(c, c, p, T_init=Ti)
+            assert r["status"] == 0
+            step[est] = O.pose_error(r["T_trace"][15], r["T_trace"][16])
+            end[est] = O.pose_error(np.eye(4), r["T_trace"][-1])
+        assert step[2][1] < 2e-4 and step[2][0] < 1e-4, (name, step)        # (0.1 mm per iteration on dep2, 40 times less than the window run)
+        assert end[2][0] <= rot_bar and end[2][1] <= tr_bar, (name, end)
+        assert end[2][1] < end[0][1], (name, end)          # closer to the identity than the window estimator's run (4.1 mm on both frames)
+        if name == "exp1_dep_2.png":
+            assert step[0][1] > 1e-3                        # window normals: > 1 mm per iteration at iteration 15
+            p8 = O.params(intr, iterations=20, estimator=2, plane_pair_gate=1, seg_distance_threshold=0.08)
+            c = O.backproject(d, p8)
+            far = O.pose_error(np.eye(4), O.icp(c, c, p8, T_init=Ti)["T_trace"][-1])
+            assert far[1] > 2.0 * end[2][1], (far, end)     # the old default stops twice as far away
 
 
 def test_planes_only_is_degenerate_on_the_synthetic_room_and_says_so():
@@ -100,7 +116,9 @@ def test_planes_only_is_degenerate_on_the_synthetic_room_and_says_so():
     planes, the 6x6 system needs damping, and the run must never report OK."""
     pr, s4, t4 = _pair(1000)
     r = O.icp(s4, t4, O.params(pr.intr, iterations=6, estimator=2, plane_only=1))
-    assert r["status"] == 3 and np.array_equal(r["T"], np.eye(4))
+    assert r["status"] in (1, 3) and np.array_equal(r["T"], np.eye(4))      # DEGENERATE at the 0.08 m threshold of round 5, TOO_FEW_INLIERS at 0.04: never OK
+    r8 = O.icp(s4, t4, O.params(pr.intr, iterations=6, estimator=2, plane_only=1, seg_distance_threshold=0.08))
+    assert r8["status"] == 3 and np.array_equal(r8["T"], np.eye(4))
     r = O.icp(s4, t4, O.params(pr.intr, iterations=20, estimator=2))
     rot, tr = O.pose_error(pr.T_gt, r["T"])
     assert r["status"] == 0 and rot < 2e-3 and tr < 5e-3
