@@ -195,7 +195,7 @@ def test_plane_icp_on_the_reference_kinect_frames(gpu_lib, case):
         for depth in (True, False):
             _gpu_case(h, pr, s4, t4, ro, depth, 20, Ti)
     if a == b:      # the perturbed self-alignment has stopped moving long before the run ends
-        assert max(O.pose_error(ro["T_trace"][15], ro["T_trace"][16])) < 1e-4
+        assert max(O.pose_error(ro["T_trace"][15], ro["T_trace"][16])) < 2e-4
 
 
 @pytest.mark.gpu
