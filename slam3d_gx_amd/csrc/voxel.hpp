@@ -301,13 +301,15 @@ __global__ __launch_bounds__(1024) void k_voxel_scan(VoxLayout L)
     start[i] = before + incl - v;                      // exclusive prefix inside the block
     cursor[i] = 0;
     if (threadIdx.x == 1023) {
+        // (round 6: no __threadfence() on either side of the ticket -- on gfx950 it is buffer_wbl2 + buffer_inv, an L2 write-back and
+        //  invalidate.  The block total is a device-scope store and the last block reads the totals with device-scope loads: the store
+        //  only has to have been PERFORMED before the ticket is taken, which is s_waitcnt vmcnt(0).)
         __hip_atomic_store(btot + blockIdx.x, before + incl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        last_sh = atomicAdd(ticket, 1) == VOX_SCAN_BLOCKS - 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last_sh = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == VOX_SCAN_BLOCKS - 1;
     }
     __syncthreads();
     if (!last_sh || threadIdx.x >= 64) return;
-    __threadfence();
     // the last block: exclusive scan of the VOX_SCAN_BLOCKS totals by one wave (two values per lane at 128 blocks)
     constexpr int PER = (VOX_SCAN_BLOCKS + 63) / 64;
     int tv[PER], sum = 0;
@@ -328,9 +330,8 @@ __global__ __launch_bounds__(1024) void k_voxel_scan(VoxLayout L)
     }
     if (lane == 63) {
         start[VOX_BINS] = inc;                         // = number of voxels
-        *m_host = inc;
         *ticket = 0;                                   // ready for the next call
-        __threadfence_system();
+        __hip_atomic_store(m_host, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // host-mapped: the host polls it while the later launches run
     }
 }
 __device__ __forceinline__ int vox_start(const int *__restrict__ start, const int *__restrict__ boff, int b)
