@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SLAM3D_ICP_ABI_VERSION 6
+#define SLAM3D_ICP_ABI_VERSION 7
 #define SLAM3D_ICP_NSUMS 29   /* the sums of the trace: 21 upper-tri AtA + 6 Atb + count + sum r^2, derived from the Gram totals */
 #define SLAM3D_ICP_NRAW  36   /* what the dense mode exchanges: the upper triangle of the 8x8 integer Gram matrix of the quantised row vectors (DESIGN.md spec S4) */
 
