@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Rewrites the round-5 column of DESIGN.md section 7 from the committed bench lines (profiles/r05_bench.json,
-profiles/r05_voxel_bench.json), so that the table is a copy of the measured files, not a transcription.
+"""Rewrites the round-6 column of DESIGN.md section 7 from the committed bench lines (profiles/r06_bench.json,
+profiles/r06_voxel_bench.json), so that the table is a copy of the measured files, not a transcription.
 usage: tools/fill_design.py [n_gpu_tests]"""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
-v = json.load(open(os.path.join(ROOT, "profiles", "r05_voxel_bench.json")))
+d = json.load(open(os.path.join(ROOT, "profiles", "r06_bench.json")))
+v = json.load(open(os.path.join(ROOT, "profiles", "r06_voxel_bench.json")))
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
 
@@ -52,13 +52,13 @@ row("full scan, 640×480 (ms per launch)", f"**{rb['launch_ms']:.2f}** / {rb['f3
 row("the same as contraction rates", f"{rb['achieved']:,.0f} ({100 * rb['frac']:.0f} %) / **{rb['equivalent_f32_contraction_tflops']:.0f} ({100 * rb['equivalent_frac_of_f32_peak']:.0f} %)**")
 vi = d["voxel_icp"]
 u = vi["dep1_to_dep2"]
-row("unorganized clouds, 16,034 × 14,758 points", f"{k(u['value'])} / {k(u['icp_only_value'])} it/s (CPU kd-tree, {u['cpu_baseline']['cores']} threads: {k(u['cpu_baseline']['value'])})")
+row("unorganized clouds, 16,034 × 14,758 points", f"**{k(u['value'])} / {k(u['icp_only_value'])} it/s** ({u['us_per_iteration']:.0f} µs per iteration; CPU kd-tree, {u['cpu_baseline']['cores']} pinned threads: {k(u['cpu_baseline']['value'])} = {u['vs_cpu']:.1f}×); perturbed self-alignment {k(vi['dep1_to_dep1_perturbed']['icp_only_value'])} ({vi['dep1_to_dep1_perturbed']['vs_cpu']:.1f}× its CPU run)")
 vb = vi["voxel_grid_batch"]
 row("voxel grid, 64 clouds per launch sequence", f"{vb['us_per_frame']:.1f} µs per cloud ({vb['roofline']['achieved']:.0f} GB/s, {100 * vb['roofline']['frac']:.1f} % of HBM)")
 row("f-1 voxel grid per 640×480 frame, one call", f"{1e3 * v['ms_per_step']:.1f} µs")
 c = d["cpu_baseline"]
-row("CPU oracle, kd-tree", f"{c['value']:.0f} ({c['cores']} thr) / {c['single_thread_value']:.0f} it/s")
+row("CPU oracle, kd-tree", f"{c['value']:.0f} ({c['cores']} pinned thr, spread {100 * c['spread']:.0f} %) / {c['single_thread_value']:.0f} it/s")
 if len(sys.argv) > 1:
     row("GPU test suite", sys.argv[1])
 open(p, "w").write(s)
-print("DESIGN.md section 7 rewritten from profiles/r05_bench.json: headline", d["value"])
+print("DESIGN.md section 7 rewritten from profiles/r06_bench.json: headline", d["value"])
