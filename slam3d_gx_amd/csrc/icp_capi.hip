@@ -66,6 +66,8 @@ struct slam3d_icp_handle {
     int *corr_trace = nullptr; bool want_corr_trace = false, ran_corr_trace = false;   // [iters][maxB][nslots], opt-in
     // plane segmentation (f-2): allocated on first use
     SegState *seg_state = nullptr, *pin_seg = nullptr;
+    SegScratch *seg_scratch = nullptr;     // the persistent segmentation launch's accumulators (two frames)
+    bool seg_persist = false;              // SLAM3D_SEG_PERSIST=1: developer knob, one persistent launch per pass (plane_seg.hpp: bit-identical, measured SLOWER -- 263 vs 139 us per frame)
     int *seg_labels = nullptr;
     const float4 **seg_ptrs = nullptr;
     FitState *fit_state = nullptr, *pin_fit = nullptr;   // slam3d_fit_planes
@@ -268,7 +270,7 @@ static void free_all(slam3d_icp_handle *h)
 {
     auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
     F(h->f_cloud); F(h->f_nrm); F(h->f_srcT); F(h->f_tgtT); F(h->f_tbox); F(h->f_cbox); F(h->f_tq); F(h->f_scount); F(h->f_counts);
-    F(h->ls_dbg); F(h->ls_pts); F(h->ls_box); F(h->ls_tile); F(h->ls_super); F(h->ls_n); F(h->ls_cnt); F(h->ls_cstart); F(h->ls_grp); F(h->ls_cr); F(h->ls_match);
+    F(h->seg_scratch); F(h->ls_dbg); F(h->ls_pts); F(h->ls_box); F(h->ls_tile); F(h->ls_super); F(h->ls_n); F(h->ls_cnt); F(h->ls_cstart); F(h->ls_grp); F(h->ls_cr); F(h->ls_match);
     F(h->src_c); F(h->tgt_c); F(h->ccounts); F(h->chunk_cnt); F(h->corr); F(h->ticket);
     F(h->flags); F(h->best); F(h->cd2); F(h->acc); F(h->sums); F(h->Tcur); F(h->trace_T); F(h->trace_S);
     F(h->d_pairs); F(h->d_raw); F(h->d_depth); F(h->d_idx); F(h->d_d2); F(h->d_scratch4); F(h->corr_trace);
@@ -456,6 +458,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     if (getenv("SLAM3D_DENSE_BATCH")) h->dense_batch = atoi(getenv("SLAM3D_DENSE_BATCH"));
     if (getenv("SLAM3D_HEAD_SOLVE")) h->head_solve = atoi(getenv("SLAM3D_HEAD_SOLVE"));
     if (getenv("SLAM3D_CERT")) h->cert_on = atoi(getenv("SLAM3D_CERT")) != 0;
+    if (getenv("SLAM3D_SEG_PERSIST")) h->seg_persist = atoi(getenv("SLAM3D_SEG_PERSIST")) != 0;
     A(dalloc(h->slot_rec, (size_t)h->maxB * tg.nslots)); A(dalloc(h->tile_cum, (size_t)h->maxB * tg.ntiles));
     A(dalloc(h->sums, (size_t)h->maxB * NRAW + 8)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
     A(dalloc(h->trace_T, (size_t)h->maxB * (iters + 1) * 16)); A(dalloc(h->trace_S, (size_t)h->maxB * iters * NSUMS));
@@ -719,6 +722,22 @@ static int enqueue_segmentation(slam3d_icp_handle *h, int B, const float4 **ptrs
     const int pts = B <= 2 ? SEG_PTS : SEG_PTS_BATCH;
     const dim3 pg((N + SEG_BLOCK * pts - 1) / (SEG_BLOCK * pts), B);
     HIPCHK(h, hipMemsetAsync(st, 0, sizeof(SegState) * B, s));
+    if (B <= 2 && h->seg_persist) {
+        // round 6 experiment (off by default): a frame alone (or the two frames of a pair) in ONE persistent launch -- pixels resident in
+        // LDS, three grid barriers per RANSAC round instead of three launches (plane_seg.hpp); <= 256 blocks, so four handles' launches
+        // are always co-resident -- which is also why it loses: one wave per SIMD
+        const int g_max = 256 / B;
+        const int ppt = (N + SEG_BLOCK * g_max - 1) / (SEG_BLOCK * g_max);
+        if (ppt <= SEG_PPT_MAX) {
+            if (!h->seg_scratch && hipMalloc((void **)&h->seg_scratch, sizeof(SegScratch) * 2) != hipSuccess) { (void)hipGetLastError(); return SLAM3D_E_NOMEM; }
+            HIPCHK(h, hipMemsetAsync(h->seg_scratch, 0, sizeof(SegScratch) * B, s));
+            const int G = (N + SEG_BLOCK * ppt - 1) / (SEG_BLOCK * ppt);
+            hipLaunchKernelGGL(k_seg_persist, dim3(G, B), dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, h->seg_scratch, N, ppt, h->g.zmax, P);
+            if (final_launch) hipLaunchKernelGGL(k_seg_final, dim3(B), dim3(1), 0, s, st, P.max_planes, P.percent);
+            HIPCHK(h, hipGetLastError());
+            return SLAM3D_OK;
+        }
+    }
     if (B <= 2) hipLaunchKernelGGL(k_seg_init<SEG_PTS>, pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, h->g.zmax);
     else hipLaunchKernelGGL(k_seg_init<SEG_PTS_BATCH>, pg, dim3(SEG_BLOCK), 0, s, ptrs_dev, lab, st, N, h->g.zmax);
     for (int r = 0; r < P.max_planes; ++r) {

@@ -419,6 +419,328 @@ __global__ void k_seg_final(SegState *__restrict__ st, int rounds, float percent
     s.nplanes = c.nplanes;
 }
 
+// ------------------------------------------------------------------------------------ round 6: ONE persistent launch per pass (frames alone)
+// A frame alone paid 1 + 3 x 3 dependent launches (init; count | moments | label per round): 137 us per frame, 180 us for the two
+// frames of a SLAM3D_EST_PLANE alignment -- every launch re-reads the cloud and the labels, and every launch boundary is a drain.
+// Here the frame's pixels stay in REGISTERS (point + label, SEG_PPT_MAX per thread) from the first load to the last label; what the
+// blocks exchange -- the valid count, the 64 consensus counts, the ten moments, the labelled count -- are device-scope integer atomics
+// read back with device-scope loads behind a grid barrier (three per round; no fence: list_icp.hpp explains why), into accumulators of
+// their own per round (SegScratch, zeroed by one memset in front of the launch).  The bookkeeping, the hypotheses and the refinement are
+// redone by every block from the same numbers, as in the fused launches above; block 0 records what the consumers of SegState read.
+// A hypothesis draws RANDOM pixels and needs to know whether they are still unassigned: the labels of other blocks' pixels live in
+// their registers, so the draw decides it from the pixel itself -- valid, and within thr of none of the planes refined so far, tested in
+// round order -- which is exactly how the label launches assign (spec P4).  Same integers, same floats, same labels and planes as the
+// launches above (tests/test_segmentation.py, tests/test_plane_icp.py compare with the oracle and the numpy restatement).
+// Co-residency as in list_icp.hpp: G x frames <= 256 blocks of 256 threads, <= 128 VGPRs.
+// MEASURED (640x480, one frame, tools/variants -DSEG_DBG, thread 0 of block 0, sums over the three rounds): load 1.5 us, first barrier 7 |
+// hypotheses 25, consensus 87, barrier 24 | moments 11, barrier 24 | refinement 19, labels 2.5, barrier 35 = 263 us per frame against
+// 139 us for the ten launches.  The consensus phase is THROUGHPUT work (307 k pixels x 64 hypotheses): the launches run it on 4,800
+// blocks at full occupancy, the persistent grid -- capped at a quarter of the chip's wave slots so that four launches are always
+// co-resident -- runs it with ONE wave per SIMD, where a dependent VALU / ballot chain issues every 10-27 cycles; and every barrier
+// waits for the slowest block of such a phase.  A persistent launch pays where an iteration is latency (list_icp.hpp: 0.97 -> 0.66 ms),
+// not where it is arithmetic.  Kept OFF (SLAM3D_SEG_PERSIST=1 enables it; tests/test_segmentation.py runs both forms).
+constexpr int SEG_PPT_MAX = 10;
+struct SegScratch {
+    int n_valid; unsigned int ticket; int lab_count[SEG_MAXP]; int pad[6];
+    long long mom[SEG_MAXP][10];
+    int counts[SEG_MAXP][SEG_CR][SEG_H];
+};
+
+// (the pixel is unassigned at the head of round r <=> valid and in none of the planes of rounds 0 .. r-1)
+__device__ __forceinline__ bool seg_free_at(const float4 q, float zmax, const SegPlane *pl, int r, float thr)
+{
+    if (!pt_valid(q.x, q.y, q.z, zmax)) return false;
+    for (int k = 0; k < r; ++k) {
+        const float e = __fmaf_rn(pl[k].a, q.x, __fmaf_rn(pl[k].b, q.y, pl[k].c * q.z)) + pl[k].d;
+        if (fabsf(e) <= thr) return false;
+    }
+    return true;
+}
+
+// seg_make_hyp with the labels decided from the pixels (same draws, same acceptance rule, same picks)
+__device__ __forceinline__ SegHyp seg_make_hyp_free(const float4 *__restrict__ cloud, int N, const SegParams &sp, int r, int h, float zmax, const SegPlane *pl)
+{
+    SegHyp hy;
+    hy.nx = hy.ny = hy.nz = hy.dd = hy.thr2nn = 0.0f; hy.ok = 0; hy.p0x = hy.p0y = hy.p0z = 0.0f;
+    if (h < sp.hypotheses) {
+        unsigned long long x = sp.seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(1 + r * 4096 + h);
+        int pick0 = -1, pick1 = -1, pick2 = -1, np = 0;
+        float4 p0 = make_float4(0, 0, 0, 0), p1 = p0, p2 = p0;
+        constexpr int SEG_AHEAD = 8;
+        int px_[SEG_AHEAD];
+        float4 pq_[SEG_AHEAD];
+#pragma unroll
+        for (int t = 0; t < SEG_AHEAD; ++t) {
+            x += 0x9E3779B97F4A7C15ull;
+            const unsigned long long o = seg_mix64(x);
+            px_[t] = (int)(((o >> 32) * (unsigned long long)N) >> 32);
+        }
+#pragma unroll
+        for (int t = 0; t < SEG_AHEAD; ++t) pq_[t] = cloud[px_[t]];
+#pragma unroll
+        for (int t = 0; t < SEG_AHEAD; ++t) {
+            const int pix = px_[t];
+            const bool take = np < 3 && seg_free_at(pq_[t], zmax, pl, r, sp.thr) && !((np > 0 && pick0 == pix) || (np > 1 && pick1 == pix));
+            if (take) { if (np == 0) { pick0 = pix; p0 = pq_[t]; } else if (np == 1) { pick1 = pix; p1 = pq_[t]; } else { pick2 = pix; p2 = pq_[t]; } ++np; }
+        }
+        for (int t = SEG_AHEAD; t < SEG_DRAWS && np < 3; ++t) {
+            x += 0x9E3779B97F4A7C15ull;
+            const unsigned long long o = seg_mix64(x);
+            const int pix = (int)(((o >> 32) * (unsigned long long)N) >> 32);
+            const float4 qq = cloud[pix];
+            if (!seg_free_at(qq, zmax, pl, r, sp.thr)) continue;
+            if ((np > 0 && pick0 == pix) || (np > 1 && pick1 == pix)) continue;
+            if (np == 0) { pick0 = pix; p0 = qq; } else if (np == 1) { pick1 = pix; p1 = qq; } else { pick2 = pix; p2 = qq; }
+            ++np;
+        }
+        (void)pick2;
+        if (np == 3) {
+            const float ax = p1.x - p0.x, ay = p1.y - p0.y, az = p1.z - p0.z;
+            const float bx = p2.x - p0.x, by = p2.y - p0.y, bz = p2.z - p0.z;
+            const float nx = __fmaf_rn(ay, bz, -(az * by));
+            const float ny = __fmaf_rn(az, bx, -(ax * bz));
+            const float nz = __fmaf_rn(ax, by, -(ay * bx));
+            const float nn = __fmaf_rn(nz, nz, __fmaf_rn(ny, ny, nx * nx));
+            if (nn > 1e-16f) {
+                hy.nx = nx; hy.ny = ny; hy.nz = nz;
+                hy.dd = -__fmaf_rn(nx, p0.x, __fmaf_rn(ny, p0.y, nz * p0.z));
+                hy.thr2nn = (sp.thr * sp.thr) * nn;
+                hy.ok = 1;
+                hy.p0x = p0.x; hy.p0y = p0.y; hy.p0z = p0.z;
+            }
+        }
+    }
+    return hy;
+}
+
+// the refined plane of a round from its moments and the winning hypothesis' first sample (seg_refined_plane's arithmetic)
+__device__ __noinline__ SegPlane seg_refine_from(const long long *mom, double ox, double oy, double oz)      // (out of line: the eigen solve's registers must not push the resident pixels into scratch)
+{
+    const double inv = 1.0 / (double)mom[0];
+    const double mx = (double)mom[1] * inv, my = (double)mom[2] * inv, mz = (double)mom[3] * inv;
+    Sym3 C;
+    C.a00 = (double)mom[4] * inv - mx * mx; C.a01 = (double)mom[5] * inv - mx * my; C.a02 = (double)mom[6] * inv - mx * mz;
+    C.a11 = (double)mom[7] * inv - my * my; C.a12 = (double)mom[8] * inv - my * mz; C.a22 = (double)mom[9] * inv - mz * mz;
+    double nx, ny, nz;
+    eig3_smallest(C, nx, ny, nz);
+    const double cx = ox + mx / 65536.0, cy = oy + my / 65536.0, cz = oz + mz / 65536.0;
+    double d = -((nx * cx + ny * cy) + nz * cz);
+    if (d < 0.0) { nx = -nx; ny = -ny; nz = -nz; d = -d; }      // src/GraphicEnd.cpp:383-387
+    SegPlane P;
+    P.a = (float)nx; P.b = (float)ny; P.c = (float)nz; P.d = (float)d;
+    P.cx = (float)cx; P.cy = (float)cy; P.cz = (float)cz; P.count = 0;
+    return P;
+}
+
+// grid (G, frames), block 256; ppt = pixels per thread (pixel i = (blockIdx.x * ppt + k) * 256 + thread, k < ppt <= SEG_PPT_MAX).
+// The block's pixels live in LDS (x, y, z planes + a label byte: 33 KB at ten pixels per thread; kept in registers they and the
+// eigen solve / the eight look-ahead draws did not fit 128 VGPRs -- 48 spilled registers).  Every phase walks k = 0 .. ppt-1 once.
+
+#ifdef SEG_DBG
+#define SEGT(k) do { if (rec && b == 0) { const long long n_ = (long long)wall_clock64(); tph[k] += n_ - tprev; tprev = n_; } } while (0)
+#else
+#define SEGT(k) do { } while (0)
+#endif
+__global__ __launch_bounds__(SEG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_seg_persist(
+    const float4 *const *__restrict__ clouds, int *__restrict__ labels, SegState *__restrict__ st, SegScratch *__restrict__ scr, int N, int ppt, float zmax, SegParams sp)
+{
+    __shared__ float sx[SEG_PPT_MAX][SEG_BLOCK], sy[SEG_PPT_MAX][SEG_BLOCK], sz[SEG_PPT_MAX][SEG_BLOCK];
+    __shared__ signed char sl[SEG_PPT_MAX][SEG_BLOCK];           // -3 no pixel, -2 invalid, -1 unassigned, r >= 0 plane
+    __shared__ SegHyp hy_sh[SEG_H];
+    __shared__ SegPlane pl_sh[SEG_MAXP];
+    __shared__ int bc[SEG_H];
+    __shared__ unsigned long long bm[10];
+    __shared__ int part[SEG_BLOCK / 64];
+    const int b = blockIdx.y, G = gridDim.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    SegState &s = st[b];
+    SegScratch &x = scr[b];
+    const float4 *__restrict__ cloud = clouds[b];
+    const int H = sp.hypotheses;
+    const bool rec = blockIdx.x == 0 && tid == 0;
+    unsigned int epoch = 0;
+    long long tph[10] = {0,0,0,0,0,0,0,0,0,0}, tprev = (long long)wall_clock64(); (void)tph; (void)tprev;
+    auto grid_barrier = [&]() __attribute__((always_inline)) {
+        ls_barrier();
+        if (w == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (all of a block's global atomics are issued by wave 0: they have been performed)
+            if (lane == 0) {
+                epoch += 1;
+                __hip_atomic_fetch_add(&x.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (__hip_atomic_load(&x.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * (unsigned int)G) __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        ls_barrier();
+    };
+    auto block_sum = [&](int v) __attribute__((always_inline)) {      // valid in every thread
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        ls_barrier();
+        if (lane == 0) part[w] = v;
+        ls_barrier();
+        return part[0] + part[1] + part[2] + part[3];
+    };
+    // ---- P1: the block's pixels, resident from here on
+    int nv = 0;
+    for (int k = 0; k < ppt; ++k) {
+        const int i = (blockIdx.x * ppt + k) * SEG_BLOCK + tid;
+        float4 qq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        int l = -3;
+        if (i < N) {
+            qq = cloud[i];
+            const bool ok = pt_valid(qq.x, qq.y, qq.z, zmax);
+            l = ok ? -1 : -2;
+            nv += ok ? 1 : 0;
+        }
+        sx[k][tid] = qq.x; sy[k][tid] = qq.y; sz[k][tid] = qq.z; sl[k][tid] = (signed char)l;
+    }
+    nv = block_sum(nv);
+    if (tid == 0 && nv) __hip_atomic_fetch_add(&x.n_valid, nv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    SEGT(0);
+    grid_barrier();
+    SEGT(1);
+    const int n_valid = __hip_atomic_load(&x.n_valid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    SegRound c;
+    c.remaining = 0; c.nplanes = 0; c.done = 0; c.pad = 0;
+    int best = 0, last_got = 0;
+    for (int r = 0; r < sp.max_planes; ++r) {
+        // ---- bookkeeping of the round that ended + this round's loop condition (seg_open_round on the block's own copy)
+        last_got = 0;
+        if (r == 0) c.remaining = n_valid;
+        else if (!c.done) {
+            const int got = __hip_atomic_load(&x.lab_count[r - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (got == 0) c.done = 1;
+            else { c.nplanes = r; c.remaining -= got; if (rec) s.planes[r - 1].count = got; }
+        }
+        if (!c.done && (n_valid < 3 || !((double)c.remaining > (double)sp.percent * (double)n_valid))) c.done = 1;
+        if (c.done) break;
+        // ---- P2: the 64 hypotheses (every block the same), then their consensus among this block's unassigned pixels
+        if (tid < SEG_H) {
+            const SegHyp hy = seg_make_hyp_free(cloud, N, sp, r, tid, zmax, pl_sh);
+            hy_sh[tid] = hy;
+            if (blockIdx.x == 0) s.hyp[tid] = hy;
+            bc[tid] = 0;
+        }
+        ls_barrier();
+        SEGT(2);
+        {
+            const SegHyp mh = hy_sh[lane];
+            const unsigned long long okm = __ballot(mh.ok != 0 && lane < H);
+            int mine = 0;
+            // (hypothesis outer, pixels inner and in registers for this phase: one v_readlane set per hypothesis serves all the thread's
+            //  pixels, whose inlier tests are independent chains -- with ONE wave per SIMD a dependent chain issues every ~10 cycles)
+            float px_[SEG_PPT_MAX], py_[SEG_PPT_MAX], pz_[SEG_PPT_MAX];
+            bool live[SEG_PPT_MAX];
+#pragma unroll
+            for (int k = 0; k < SEG_PPT_MAX; ++k) {
+                live[k] = k < ppt && sl[k][tid] == -1;
+                px_[k] = k < ppt ? sx[k][tid] : 0.0f; py_[k] = k < ppt ? sy[k][tid] : 0.0f; pz_[k] = k < ppt ? sz[k][tid] : 0.0f;
+            }
+            for (int h = 0; h < H; ++h) {
+                if (!((okm >> h) & 1ull)) continue;
+                const float nx = rdlane(mh.nx, h), ny = rdlane(mh.ny, h), nz = rdlane(mh.nz, h), dd = rdlane(mh.dd, h), t2 = rdlane(mh.thr2nn, h);
+                int cc = 0;
+#pragma unroll
+                for (int k = 0; k < SEG_PPT_MAX; ++k) cc += __popcll(__ballot(live[k] && seg_inlier(nx, ny, nz, dd, t2, make_float4(px_[k], py_[k], pz_[k], 0.0f))));
+                if (lane == h) mine = cc;
+            }
+            if (mine) atomicAdd(&bc[lane], mine);
+        }
+        ls_barrier();
+        if (tid < SEG_H && bc[tid]) __hip_atomic_fetch_add(&x.counts[r][blockIdx.x % SEG_CR][tid], bc[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SEGT(3);
+        grid_barrier();
+        SEGT(4);
+        // ---- P2 tail: the best hypothesis (max count, smallest h on ties); P3: moments of its inliers about its first sample
+        {
+            int cnt = 0;
+            if (lane < H)
+#pragma unroll
+                for (int k = 0; k < SEG_CR; ++k) cnt += __hip_atomic_load(&x.counts[r][k][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int key = lane < H ? cnt * 64 + (63 - lane) : -1;
+            for (int o = 32; o >= 1; o >>= 1) key = max(key, __shfl_xor(key, o));
+            best = 63 - (key & 63);
+            if ((key >> 6) < 3) { c.done = 1; break; }             // no consensus: the loop ends (every block sees the same counts)
+        }
+        if (rec) s.best = best;
+        const SegHyp hb = hy_sh[best];
+        {
+            const double ox = hb.p0x, oy = hb.p0y, oz = hb.p0z;
+            long long m[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) m[k] = 0;
+            for (int k = 0; k < ppt; ++k) {
+                const float4 qq = make_float4(sx[k][tid], sy[k][tid], sz[k][tid], 0.0f);
+                if (sl[k][tid] == -1 && seg_inlier(hb.nx, hb.ny, hb.nz, hb.dd, hb.thr2nn, qq)) {
+                    const long long qx = __double2ll_rn(((double)qq.x - ox) * 65536.0), qy = __double2ll_rn(((double)qq.y - oy) * 65536.0),
+                                    qz = __double2ll_rn(((double)qq.z - oz) * 65536.0);
+                    m[0] += 1; m[1] += qx; m[2] += qy; m[3] += qz;
+                    m[4] += qx * qx; m[5] += qx * qy; m[6] += qx * qz; m[7] += qy * qy; m[8] += qy * qz; m[9] += qz * qz;
+                }
+            }
+            if (tid < 10) bm[tid] = 0;
+            ls_barrier();
+            if (__any(m[0] != 0)) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) {
+                    long long v = m[k];
+                    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+                    m[k] = v;
+                }
+                long long mine = 0;
+#pragma unroll
+                for (int k = 0; k < 10; ++k) if (lane == k) mine = m[k];
+                if (lane < 10) atomicAdd(&bm[lane], (unsigned long long)mine);
+            }
+            ls_barrier();
+            if (tid < 10 && bm[tid]) __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(&x.mom[r][tid]), bm[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        SEGT(5);
+        grid_barrier();
+        SEGT(6);
+        // ---- P3 tail + P4: the refined plane (thread 0 of every block: same moments, same bits), then the plane's pixels
+        if (tid == 0) {
+            long long mom[10];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) mom[k] = (long long)__hip_atomic_load(reinterpret_cast<unsigned long long *>(&x.mom[r][k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const SegPlane P = seg_refine_from(mom, hb.p0x, hb.p0y, hb.p0z);
+            pl_sh[r] = P;
+            if (blockIdx.x == 0) s.planes[r] = P;
+        }
+        ls_barrier();
+        SEGT(7);
+        {
+            const float a = pl_sh[r].a, bb = pl_sh[r].b, cc_ = pl_sh[r].c, d = pl_sh[r].d;
+            int got = 0;
+            for (int k = 0; k < ppt; ++k) {
+                if (sl[k][tid] == -1) {
+                    const float e = __fmaf_rn(a, sx[k][tid], __fmaf_rn(bb, sy[k][tid], cc_ * sz[k][tid])) + d;
+                    if (fabsf(e) <= sp.thr) { sl[k][tid] = (signed char)r; ++got; }
+                }
+            }
+            got = block_sum(got);
+            if (tid == 0 && got) __hip_atomic_fetch_add(&x.lab_count[r], got, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        SEGT(8);
+        grid_barrier();
+        SEGT(9);
+        last_got = r == sp.max_planes - 1 ? __hip_atomic_load(&x.lab_count[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    }
+    // ---- the labels, and the state seg_open_round(s, max_planes) -- k_seg_final / k_plane_normals -- closes the last round from
+    int *__restrict__ lab = labels + (size_t)b * N;
+    for (int k = 0; k < ppt; ++k) {
+        const int i = (blockIdx.x * ppt + k) * SEG_BLOCK + tid;
+        if (i < N) lab[i] = (int)sl[k][tid];
+    }
+#ifdef SEG_DBG
+    if (rec && b == 0) printf("seg phases us: load %.1f bar %.1f | hyp %.1f count %.1f bar %.1f | mom %.1f bar %.1f | refine %.1f label %.1f bar %.1f\n", tph[0]*.01, tph[1]*.01, tph[2]*.01, tph[3]*.01, tph[4]*.01, tph[5]*.01, tph[6]*.01, tph[7]*.01, tph[8]*.01, tph[9]*.01);
+#endif
+    if (rec) {
+        s.n_valid = n_valid;
+        s.rs[0] = c; s.rs[1] = c;
+        s.lab_count[0] = 0; s.lab_count[1] = 0;
+        if (!c.done) s.lab_count[(sp.max_planes - 1) & 1] = last_got;      // (the loop ran its last round to the end: its labelled count is still to be booked)
+    }
+}
+
 // ------------------------------------------------------------------------------------ a6: planes from labels
 // slam3d_fit_planes: per-plane least-squares fit for GIVEN labels (the refinement PCL runs inside
 // SACSegmentation::segment, src/GraphicEnd.cpp:360-375).  Same arithmetic as P3 with the sensor origin as the

@@ -119,9 +119,14 @@ def test_loop_parameters_and_determinism():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("persist", ["0", "1"])
 @pytest.mark.parametrize("c", G["cases"], ids=lambda c: f"{c['width']}x{c['height']}-{c['seed']}")
-def test_hip_segmentation_reproduces_golden(gpu_lib, c):
+def test_hip_segmentation_reproduces_golden(gpu_lib, c, persist, monkeypatch):
+    """Both forms of the single-frame pass: the launches (default) and the ONE persistent launch of round 6 (SLAM3D_SEG_PERSIST=1:
+    pixels resident in LDS, labels of drawn pixels decided from the planes, grid barriers; measured slower and kept off, plane_seg.hpp)
+    -- the same planes and labels as the golden vectors."""
     from slam3d_gx_amd import capi
+    monkeypatch.setenv("SLAM3D_SEG_PERSIST", persist)
     pr, s4 = _cloud(c)
     with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1)) as h:
         planes, labels = h.segment_planes(s4, h.seg_params(seed=c["seed"]))
