@@ -80,7 +80,7 @@ def _short(s, n):
 
 
 _ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "algorithmic_bytes_per_launch", "valu_issue_frac")
-_CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "min_value", "median_value", "spread", "single_thread_value", "bruteforce_value")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "min_value", "median_value", "spread", "numa_local", "single_thread_value", "bruteforce_value")
 
 
 def _roof(r):
@@ -418,9 +418,9 @@ class Streamer:
 
 def cpu_thread_curve(s4, t4, width, height, okw, iterations, counts, runs, T_init=None, single_iterations=None):
     """The CPU oracle timed at every thread count of `counts`, each in a process of its own (bench_cpu_worker.py): the team pinned to
-    the first `count` physical cores of ONE NUMA node before libgomp starts, a warm-up run, then `runs` timed alignments.
-    Returns {count: {value (median), min_value, max_value, spread, iterations, runs, numa_local}}, and the count to quote:
-    the fastest median among the points whose spread (max - min) / median is <= 20 % (round 5 quoted a point
+    `count` physical cores (one NUMA node first, then its neighbours) before libgomp starts, a warm-up run, then `runs` timed alignments.
+    Returns {count: {value (median), min_value, max_value, spread (IQR / median), range, iterations, runs, numa_local}}, and the count to
+    quote: the fastest median among the points whose spread is <= 20 % (round 5 quoted a point
     whose samples differed by 100 %), or -- if none is that steady -- the steadiest point."""
     import subprocess
     import tempfile
@@ -442,9 +442,11 @@ def cpu_thread_curve(s4, t4, width, height, okw, iterations, counts, runs, T_ini
             except Exception as e:      # noqa: BLE001 -- a thread count that cannot be timed is left out of the curve
                 print(f"bench.py: cpu baseline worker failed at {th} threads: {e}", file=sys.stderr)
                 continue
-            t = d["times_s"]
+            t = sorted(d["times_s"])
             med = statistics.median(t)
-            curve[th] = {"value": its / med, "min_value": its / max(t), "max_value": its / min(t), "spread": (max(t) - min(t)) / med,
+            # spread = interquartile range / median (one preempted run out of seven must not disqualify a point); range = (max - min) / median
+            q1, q3 = t[len(t) // 4], t[(3 * len(t)) // 4 if len(t) >= 4 else -1]
+            curve[th] = {"value": its / med, "min_value": its / t[-1], "max_value": its / t[0], "spread": (q3 - q1) / med, "range": (t[-1] - t[0]) / med,
                          "iterations": its, "runs": len(t), "numa_local": d["numa_local"]}
     multi = [c for c in curve if c > 1] or list(curve)
     steady = [c for c in multi if curve[c]["spread"] <= 0.20]
@@ -490,7 +492,7 @@ def cpu_baseline_leg(pair, s4, t4, iterations, est, gpu_result, gpu_idx, brute_s
     out = {
         "value": curve[best]["value"], "unit": "ICP iterations/s", "cores": best, "kind": "port", "host_hardware_threads": cores,
         "median_value": curve[best]["value"], "min_value": curve[best]["min_value"], "spread": curve[best]["spread"], "numa_local": curve[best]["numa_local"],
-        "sample": f"oracle kd-tree ICP, {best} threads pinned to physical cores of one NUMA node (own process), 1 pair seed {pair.seed} x {iterations} "
+        "sample": f"oracle kd-tree ICP, {best} threads pinned to physical cores (one NUMA node first; own process), 1 pair seed {pair.seed} x {iterations} "
                   f"iterations incl. normals + kd-tree build, median of {curve[best]['runs']} after a warm-up; fastest thread count with spread <= 20 %",
         "thread_curve": {str(k): round(v["value"], 2) for k, v in curve.items()},
         "thread_curve_spread": {str(k): round(v["spread"], 3) for k, v in curve.items()},
@@ -1364,13 +1366,13 @@ def voxel_icp_leg(args, torch, capi, synth, local_rank, vh, d1, d2, want_cpu):
                 ro = O.icp(va, vb, O.params(uintr, iterations=args.iterations, estimator=1, nn_method=1, threads=min(16, os.cpu_count() or 1)), T_init=T0)
                 # the headline's protocol: every thread count in its own process, team pinned to physical cores of one
                 # NUMA node, median of 7 after a warm-up, fastest count among the steady ones
-                curve, bc = cpu_thread_curve(va, vb, W, 1, dict(estimator=1), args.iterations, (1, 8, 16, 32), 7, T_init=T0)
+                curve, bc = cpu_thread_curve(va, vb, W, 1, dict(estimator=1), args.iterations, (1, 8, 16, 32, 64), 7, T_init=T0)
                 leg["cpu_baseline"] = {"value": curve[bc]["value"], "unit": "ICP iterations/s", "cores": bc, "kind": "port",
                                        "median_value": curve[bc]["value"], "min_value": curve[bc]["min_value"], "spread": curve[bc]["spread"],
                                        "thread_curve": {str(k): round(v["value"], 1) for k, v in curve.items()},
                                        "thread_curve_spread": {str(k): round(v["spread"], 3) for k, v in curve.items()},
-                                       "sample": "oracle kd-tree ICP (svd) on the same two voxel clouds, threads pinned to physical cores of one NUMA node "
-                                                 "(own process), median of 7 after a warm-up; fastest of 1 / 8 / 16 / 32 threads with spread <= 20 %"}
+                                       "sample": "oracle kd-tree ICP (svd) on the same two voxel clouds, threads pinned to physical cores (one NUMA node first; own "
+                                                 "process), median of 7 after a warm-up; fastest of 1 / 8 / 16 / 32 / 64 threads with IQR spread <= 20 %"}
                 leg["vs_cpu"] = leg["icp_only_value"] / curve[bc]["value"]
                 leg["parity_vs_oracle"] = {"T_bit_identical": bool(np.array_equal(ro["T_trace"][-1], r["T_raw"])), "inliers_equal": bool(ro["inliers"] == r["inliers"])}
             res[name] = leg

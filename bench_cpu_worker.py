@@ -3,8 +3,8 @@
 
 Why a process of its own: the team must be pinned before libgomp starts -- OMP_PROC_BIND / OMP_PLACES are read
 once, and sched_setaffinity on a live process moves only the calling thread -- and bench.py's own threads (pose fetchers, the HIP
-runtime's) must not share the team's cores.  The worker restricts itself to the first `threads` PHYSICAL cores of ONE NUMA node
-(one hardware thread per core, the node of the first allowed CPU), binds the OpenMP team to them (OMP_PROC_BIND=close,
+runtime's) must not share the team's cores.  The worker restricts itself to `threads` PHYSICAL cores (one hardware thread per core: the
+NUMA node of the first allowed CPU first, then the neighbouring nodes; a team that fits one node is NUMA-local), binds the OpenMP team to them (OMP_PROC_BIND=close,
 OMP_PLACES=cores), runs a warm-up and `runs` timed alignments and prints their wall times as JSON.
 
 usage: bench_cpu_worker.py pair.npz spec.json      (spec: width height params{...} T_init|null threads runs)
@@ -18,39 +18,42 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
 def numa_local_cores(n):
-    """up to n CPUs: one hardware thread per physical core, all on the NUMA node of the first CPU this process may run on"""
+    """n CPUs for a team of n threads: physical cores first (one hardware thread per core) -- those of the NUMA node of the first CPU
+    this process may run on, then the other nodes' in node order (neighbouring nodes share a socket) --, SMT siblings only when the
+    machine has fewer cores than n.  Returns (cpus, all on one node?)."""
     allowed = sorted(os.sched_getaffinity(0))
-    first = allowed[0]
-    node_cpus = None
+    nodes = []
     try:
         base = "/sys/devices/system/node"
-        for d in sorted(os.listdir(base)):
-            if not d.startswith("node"):
-                continue
+        for d in sorted((x for x in os.listdir(base) if x.startswith("node") and x[4:].isdigit()), key=lambda x: int(x[4:])):
             cpus = set()
             for part in open(os.path.join(base, d, "cpulist")).read().strip().split(","):
+                if not part:
+                    continue
                 a, _, b = part.partition("-")
                 cpus.update(range(int(a), int(b or a) + 1))
-            if first in cpus:
-                node_cpus = cpus
-                break
+            nodes.append(sorted(c for c in cpus if c in allowed))
     except OSError:
         pass
-    cand = [c for c in allowed if node_cpus is None or c in node_cpus]
-    seen, cores = set(), []
-    for c in cand:
-        try:
-            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
-        except OSError:
-            sib = str(c)
-        if sib in seen:
-            continue
-        seen.add(sib)
-        cores.append(c)
-    if len(cores) < n:                       # more threads than the node has cores: its hardware threads, then the other nodes' CPUs
-        cores += [c for c in cand if c not in cores]
-        cores += [c for c in allowed if c not in cores]
-    return cores[:n], (node_cpus is not None and len([c for c in cores[:n] if c in node_cpus]) == min(n, len(cores[:n])))
+    if not any(nodes):
+        nodes = [allowed]
+    first = next(k for k, cs in enumerate(nodes) if allowed[0] in cs) if any(allowed[0] in cs for cs in nodes) else 0
+    order = nodes[first:] + nodes[:first]
+    seen, cores, rest, node_of = set(), [], [], {}
+    for k, cs in enumerate(order):
+        for c in cs:
+            node_of[c] = k
+            try:
+                sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+            except OSError:
+                sib = str(c)
+            if sib in seen:
+                rest.append(c)
+            else:
+                seen.add(sib)
+                cores.append(c)
+    pick = (cores + rest)[:n]
+    return pick, len({node_of[c] for c in pick}) == 1
 
 
 def main():
