@@ -7,7 +7,9 @@ runtime's) must not share the team's cores.  The worker restricts itself to `thr
 NUMA node of the first allowed CPU first, then the neighbouring nodes; a team that fits one node is NUMA-local), binds the OpenMP team to them (OMP_PROC_BIND=close,
 OMP_PLACES=cores), runs a warm-up and `runs` timed alignments and prints their wall times as JSON.
 
-usage: bench_cpu_worker.py pair.npz spec.json      (spec: width height params{...} T_init|null threads runs)
+usage: bench_cpu_worker.py pair.npz spec.json      (spec: width height params{...} T_init|null threads runs placement)
+placement "close": one NUMA node first; "spread": the physical cores dealt round-robin over the nodes (a kd-tree search is bound by memory
+latency: both sockets' caches and channels can beat locality -- bench.py times both and quotes the faster steady one).
 Test infrastructure: this file and tests/oracle_lib.py are the only callers of oracle/ outside tests/."""
 import json
 import os
@@ -17,7 +19,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
-def numa_local_cores(n):
+def numa_local_cores(n, placement="close"):
     """n CPUs for a team of n threads: physical cores first (one hardware thread per core) -- those of the NUMA node of the first CPU
     this process may run on, then the other nodes' in node order (neighbouring nodes share a socket) --, SMT siblings only when the
     machine has fewer cores than n.  Returns (cpus, all on one node?)."""
@@ -52,6 +54,9 @@ def numa_local_cores(n):
             else:
                 seen.add(sib)
                 cores.append(c)
+    if placement == "spread":           # physical cores dealt round-robin over the nodes: every socket's caches and memory channels
+        per = [[c for c in cores if node_of[c] == k] for k in range(len(order))]
+        cores = [per[k][j] for j in range(max(len(x) for x in per)) for k in range(len(per)) if j < len(per[k])]
     pick = (cores + rest)[:n]
     return pick, len({node_of[c] for c in pick}) == 1
 
@@ -60,10 +65,11 @@ def main():
     npz, spec_path = sys.argv[1], sys.argv[2]
     spec = json.load(open(spec_path))
     th = int(spec["threads"])
-    cpus, local = numa_local_cores(th)
+    placement = spec.get("placement", "close")
+    cpus, local = numa_local_cores(th, placement)
     os.sched_setaffinity(0, cpus)
     os.environ["OMP_NUM_THREADS"] = str(th)
-    os.environ["OMP_PROC_BIND"] = "close"
+    os.environ["OMP_PROC_BIND"] = "close" if placement == "close" else "spread"
     os.environ["OMP_PLACES"] = "cores"
     os.environ.setdefault("OMP_WAIT_POLICY", "active")          # (a dedicated, pinned team: spinning is what a tuned CPU run would do)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -81,7 +87,7 @@ def main():
         t0 = time.perf_counter()
         O.icp(z["s4"], z["t4"], p, T_init=Ti, trace=False)
         times.append(time.perf_counter() - t0)
-    print(json.dumps({"threads": th, "times_s": times, "cpus": cpus, "numa_local": bool(local)}))
+    print(json.dumps({"threads": th, "times_s": times, "cpus": cpus, "numa_local": bool(local), "placement": placement}))
 
 
 if __name__ == "__main__":
