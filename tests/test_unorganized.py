@@ -169,3 +169,103 @@ def test_hip_short_point_lists(gpu_lib, n):
         assert np.array_equal(idx, ro["idx"]) and np.array_equal(d2.view(np.uint32), ro["d2"].view(np.uint32)), (n, mode)
         assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:5], ro["sums_trace"]), (n, mode)
         assert rg["status"] == ro["status"] and rg["inliers"] == ro["inliers"], (n, mode)
+
+
+@pytest.mark.gpu
+def test_list_kernel_batches_resident_frames_gates_and_traces(gpu_lib):
+    """The persistent list launch beyond one pair per run (round 6): (i) a batch of three pairs with initial poses in ONE launch
+    (grid.y = pair, a barrier counter per pair); (ii) resident frames -- one keyframe list as the source of several pairs, its sorted
+    list built once; (iii) the gated instance (k_list_icp<0, true>: planes only + residual gate + normal-angle gate); (iv) the
+    correspondences of EVERY iteration (slam3d_icp_set_corr_trace).  All against the oracle, bit for bit."""
+    from slam3d_gx_amd import capi
+    v1, v2 = kinect_voxel_clouds()
+    rng = np.random.default_rng(11)
+    subs = [v1[np.sort(rng.choice(len(v1), 6000, replace=False))], v2[np.sort(rng.choice(len(v2), 5000, replace=False))], v1[::3].copy()]
+    W = 6144
+    intr = synth.Intrinsics(width=W, height=1)
+    Ts = np.stack([synth.pose_from_seed(30 + k, 1.5, 0.02) for k in range(3)])
+    pairs = [(subs[0], subs[1]), (subs[2], subs[0]), (subs[1], subs[1])]
+    ros = [O.icp(pad(a, W), pad(b, W), O.params(intr, estimator=1, iterations=8, nn_method=1), T_init=Ts[k]) for k, (a, b) in enumerate(pairs)]
+    with capi.IcpHandle(capi.default_params(intr, iterations=8, estimator=capi.EST_SVD, max_batch=3, extra_frames=4)) as h:
+        res = h.align_batch([pad(a, len(a)) for a, _ in pairs], [pad(b, len(b)) for _, b in pairs], Ts)        # (i)
+        for k, ro in enumerate(ros):
+            Tt, St = h.get_trace(k)
+            assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:8], ro["sums_trace"]), k
+            assert np.array_equal(h.get_correspondences(k)[0], ro["idx"]) and res[k]["status"] == ro["status"] and res[k]["inliers"] == ro["inliers"], k
+        # (ii) frames 6.. are free (2 * max_batch = 6 pair slots' frames): keyframe = subs[0] as the source of two pairs in one run, twice
+        kf, fa, fb = 6, 7, 8
+        h.frame_set_cloud_host(kf, pad(subs[0], len(subs[0]))); h.frame_set_cloud_host(fa, pad(subs[1], len(subs[1]))); h.frame_set_cloud_host(fb, pad(subs[2], len(subs[2])))
+        want = [O.icp(pad(subs[0], W), pad(t, W), O.params(intr, estimator=1, iterations=8, nn_method=1), T_init=Ts[k]) for k, t in enumerate((subs[1], subs[2]))]
+        for rep in range(2):                                     # the second run finds every sorted list built
+            h.set_pair(0, kf, fa); h.set_pair(1, kf, fb)
+            h.run(2, Ts[:2])
+            got = h.fetch_results(2)
+            for k in range(2):
+                assert np.array_equal(got[k]["T_raw"], want[k]["T_trace"][-1]) and got[k]["inliers"] == want[k]["inliers"], (rep, k)
+                assert np.array_equal(h.get_correspondences(k)[0], want[k]["idx"]), (rep, k)
+    # (iv) every iteration's correspondences
+    a, b = subs[0], subs[1]
+    ro = O.icp(pad(a, W), pad(b, W), O.params(intr, estimator=1, iterations=5, nn_method=1), T_init=Ts[0])
+    with capi.IcpHandle(capi.default_params(intr, iterations=5, estimator=capi.EST_SVD)) as h:
+        h.set_corr_trace(True)
+        h.align(pad(a, len(a)), pad(b, len(b)), Ts[0])
+        for it in range(5):
+            Tk = ro["T_trace"][it]
+            want_it, _, _ = O.nn_once(pad(a, W), pad(b, W), O.params(intr, estimator=1, nn_method=1), T=Tk, use_normals=False, coarse=it < 3)
+            assert np.array_equal(h.get_correspondences_at(it), want_it), it
+    # (iii) planes only + both gates: the gated instance of the kernel
+    c = v2
+    Wc = len(c)
+    ic = synth.Intrinsics(width=Wc, height=1)
+    Ti = synth.pose_from_seed(77, 2.0, 0.03)
+    okw = dict(estimator=2, plane_only=1, max_plane_residual2=4e-4, min_normal_cos=float(np.cos(np.deg2rad(25.0))))
+    ro = O.icp(pad(c, Wc), pad(c, Wc), O.params(ic, iterations=10, nn_method=1, **okw), T_init=Ti)
+    with capi.IcpHandle(capi.default_params(ic, iterations=10, estimator=capi.EST_PLANE, plane_flags=capi.PLANE_ONLY, max_plane_residual2=4e-4,
+                                            min_normal_cos=float(np.cos(np.deg2rad(25.0))))) as h:
+        rg = h.align(pad(c, Wc), pad(c, Wc), Ti)
+        Tt, St = h.get_trace(0)
+        assert np.array_equal(Tt.reshape(-1, 4, 4), ro["T_trace"]) and np.array_equal(St[:10], ro["sums_trace"])
+        assert np.array_equal(h.get_correspondences(0)[0], ro["idx"]) and rg["status"] == ro["status"] and rg["inliers"] == ro["inliers"]
+    plain = O.icp(pad(c, Wc), pad(c, Wc), O.params(ic, iterations=10, nn_method=1, estimator=2, plane_only=1), T_init=Ti)
+    assert plain["inliers"] != ro["inliers"]                     # the gates bite
+
+
+@pytest.mark.gpu
+def test_four_list_runs_in_flight_on_one_device(gpu_lib):
+    """The co-residency claim of list_icp.hpp: four persistent launches -- four handles, four streams, queued from four host threads at
+    once, twelve runs each -- all finish (no launch waits for blocks that another launch keeps off the chip) with the bits of a handle
+    that runs alone."""
+    import threading
+    from slam3d_gx_amd import capi
+    v1, v2 = kinect_voxel_clouds()
+    W = max(len(v1), len(v2))
+    intr = synth.Intrinsics(width=W, height=1)
+    a, b = np.ascontiguousarray(pad(v1, len(v1))), np.ascontiguousarray(pad(v2, len(v2)))
+    with capi.IcpHandle(capi.default_params(intr, iterations=20, estimator=capi.EST_SVD)) as h0:
+        want = h0.align(a, b)["T_raw"].copy()
+    handles = [capi.IcpHandle(capi.default_params(intr, iterations=20, estimator=capi.EST_SVD)) for _ in range(4)]
+    out, errs = [None] * 4, []
+
+    def work(k):
+        try:
+            got = []
+            for _ in range(12):
+                handles[k].set_clouds_host(0, a, b)
+                handles[k].run(1)
+                got.append(handles[k].fetch_results(1)[0]["T_raw"].copy())
+            out[k] = got
+        except Exception as e:      # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    alive = [t.is_alive() for t in th]
+    for hh in handles:
+        if not any(alive):
+            hh.close()
+    assert not any(alive), "a persistent launch did not finish: co-residency broken"
+    assert not errs, errs
+    assert all(np.array_equal(T, want) for got in out for T in got)
