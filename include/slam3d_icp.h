@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SLAM3D_ICP_ABI_VERSION 7
+#define SLAM3D_ICP_ABI_VERSION 8
 #define SLAM3D_ICP_NSUMS 29   /* the sums of the trace: 21 upper-tri AtA + 6 Atb + count + sum r^2, derived from the Gram totals */
 #define SLAM3D_ICP_NRAW  36   /* what the dense mode exchanges: the upper triangle of the 8x8 integer Gram matrix of the quantised row vectors (DESIGN.md spec S4) */
 
@@ -300,9 +300,14 @@ int slam3d_voxel_grid_device(slam3d_icp_handle *h, const void *d_points16, int32
 /* The same filters on B clouds in ONE launch sequence (grid.y = cloud): the keyframes saveOutput merges (src/saveOutput.cpp:58-96), the
  * loop-closure candidates of src/GraphicEnd.cpp:685-762.  d_points16 / d_out16: host arrays of B device pointers, n[b] <= width*height
  * records in cloud b, room for n[b] records in d_out16[b]; n_out[b] = voxels of cloud b.  Stream semantics as slam3d_voxel_grid_device.
- * The handle's voxel tables grow to B clouds at the first call that needs them (about 76 MB per 640x480 cloud). */
+ * The handle's voxel tables grow to B clouds at the first call that needs them (about 93 MB per 640x480 cloud). */
 int slam3d_voxel_grid_batch_device(slam3d_icp_handle *h, int32_t B, const void *const *d_points16, const int32_t *n, float leaf,
                                    void *const *d_out16, int32_t *n_out, void *stream);
+/* Measurement aid (no reference counterpart; ABI 8): how the voxel-grid calls of this handle were ordered so far.  counts[0] = calls whose
+ * every cloud stayed inside the dense key range (three launches: insert, scan, finalize -- every cloud in a camera frame at the reference's
+ * 3 cm leaf), counts[1] = calls in which a cloud left it (|ix| > 256 cells, iy or iz outside the row table) and took the general ordering
+ * path as well.  The tables grow by 17 MB per cloud for the dense path's bitmaps. */
+int slam3d_voxel_grid_path_counts(slam3d_icp_handle *h, int64_t counts[2]);
 /* ---- keyframe cloud merge of saveOutput (src/saveOutput.cpp:47-103): per keyframe VoxelGrid alone (:80-83), then
  * PassThrough z in [0, pass_z] and pcl::transformPointCloud by the keyframe's pose (:84-92); the merged cloud goes
  * through VoxelGrid alone once more (:97-100).  Same 16-byte records.  pass_transform writes NaN for dropped

@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "slam3d_comm_last_error", "slam3d_shard_range", "slam3d_icp_dense_run", "slam3d_pose_gather_submit",
     "slam3d_pose_gather_collect", "slam3d_pose_gather", "slam3d_pose_record_from_result",
     "slam3d_plane_gate", "slam3d_device_count",
-    "slam3d_icp_set_seg_params", "slam3d_icp_get_frame_planes", "slam3d_icp_get_plane_assoc", "slam3d_voxel_grid_batch_device", "slam3d_icp_dense_run_with", "slam3d_icp_set_fault_injection",
+    "slam3d_icp_set_seg_params", "slam3d_icp_get_frame_planes", "slam3d_icp_get_plane_assoc", "slam3d_voxel_grid_batch_device", "slam3d_icp_dense_run_with", "slam3d_icp_set_fault_injection", "slam3d_voxel_grid_path_counts",
 ]
 COMM_ID_BYTES = 128
 
@@ -444,6 +444,12 @@ class IcpHandle:
         return list(m)
 
     # ---- plane segmentation (f-2) ---------------------------------------------------------
+    def voxel_grid_path_counts(self):
+        """(calls ordered by the dense path alone, calls that also took the general ordering path) of this handle so far"""
+        c = (C.c_int64 * 2)()
+        self._check(self.lib.slam3d_voxel_grid_path_counts(self._h, c), False)
+        return int(c[0]), int(c[1])
+
     @staticmethod
     def seg_params(**kw) -> SegParams:
         sp = SegParams()

@@ -83,6 +83,8 @@ struct slam3d_icp_handle {
     VoxTable vox;
     unsigned long long *vox_lkey = nullptr, *vox_gkey = nullptr;
     int *vox_lslot = nullptr, *vox_gslot = nullptr, *vox_m = nullptr, *vox_hist = nullptr;   // hist | start | cursor
+    long long vox_calls_dense = 0, vox_calls_general = 0;      // slam3d_voxel_grid_path_counts
+    unsigned long long *vox_bits = nullptr, *vox_rowbits = nullptr; int *vox_flags = nullptr;   // dense ordering path (voxel.hpp, k_voxel_finalize)
     float4 *vox_out = nullptr;
     int *pin_vox_m = nullptr, *pin_vox_m_dev = nullptr;     // host-mapped: k_voxel_scan writes the voxel counts there (one per frame of a batch)
     VoxFrame *vox_frames = nullptr;                         // a batch's (records, output, count) table
@@ -286,7 +288,7 @@ static void free_all(slam3d_icp_handle *h)
     F(h->fit_state);
     F(h->pl_state); F(h->pl_labels); F(h->pl_ptrs); F(h->f_planes); F(h->assoc);
     F(h->seg_state); F(h->seg_labels); F(h->seg_ptrs);
-    F(h->vox_mem); F(h->vox_lkey); F(h->vox_lslot); F(h->vox_m); F(h->vox_out); F(h->vox_gkey); F(h->vox_gslot); F(h->vox_hist); F(h->vox_frames);
+    F(h->vox_mem); F(h->vox_lkey); F(h->vox_lslot); F(h->vox_m); F(h->vox_out); F(h->vox_gkey); F(h->vox_gslot); F(h->vox_hist); F(h->vox_frames); F(h->vox_bits); F(h->vox_rowbits); F(h->vox_flags);
     if (h->pin_vox_m) (void)hipHostFree(h->pin_vox_m);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->pin_int) (void)hipHostFree(h->pin_int);
@@ -1592,7 +1594,7 @@ extern "C" int slam3d_device_count(void)
 static void vox_free(slam3d_icp_handle *h)
 {
     auto F = [](auto *&p) { if (p) { (void)hipFree(p); p = nullptr; } };
-    F(h->vox_mem); F(h->vox_lkey); F(h->vox_lslot); F(h->vox_m); F(h->vox_out); F(h->vox_gkey); F(h->vox_gslot); F(h->vox_hist); F(h->vox_frames);
+    F(h->vox_mem); F(h->vox_lkey); F(h->vox_lslot); F(h->vox_m); F(h->vox_out); F(h->vox_gkey); F(h->vox_gslot); F(h->vox_hist); F(h->vox_frames); F(h->vox_bits); F(h->vox_rowbits); F(h->vox_flags);
     if (h->pin_vox_m) { (void)hipHostFree(h->pin_vox_m); h->pin_vox_m = nullptr; }
     h->vox_B = 0;
 }
@@ -1618,6 +1620,9 @@ static int vox_alloc(slam3d_icp_handle *h, int B = 1)
         hipMalloc((void **)&h->vox_gkey, sizeof(unsigned long long) * Bz * h->N) != hipSuccess ||
         hipMalloc((void **)&h->vox_gslot, sizeof(int) * Bz * h->N) != hipSuccess ||
         hipMalloc((void **)&h->vox_hist, sizeof(int) * Bz * VOX_HIST_INTS) != hipSuccess ||
+        hipMalloc((void **)&h->vox_bits, sizeof(unsigned long long) * Bz * VOX_BINS * VOX_BW) != hipSuccess ||
+        hipMalloc((void **)&h->vox_rowbits, sizeof(unsigned long long) * Bz * VOX_BINS * VOX_BW) != hipSuccess ||
+        hipMalloc((void **)&h->vox_flags, sizeof(int) * Bz) != hipSuccess ||
         hipMalloc((void **)&h->vox_out, sizeof(float4) * h->N) != hipSuccess ||
         hipMalloc((void **)&h->vox_frames, sizeof(VoxFrame) * Bz) != hipSuccess ||
         hipHostMalloc((void **)&h->pin_vox_m, sizeof(int) * Bz, hipHostMallocMapped) != hipSuccess ||
@@ -1642,6 +1647,7 @@ static VoxLayout vox_layout(const slam3d_icp_handle *h)
     L.hist = h->vox_hist; L.hist_stride = VOX_HIST_INTS;
     L.gkey = h->vox_gkey; L.gslot = h->vox_gslot; L.g_stride = h->N;
     L.m_host = h->pin_vox_m_dev;
+    L.bits = h->vox_bits; L.rowbits = h->vox_rowbits; L.flags = h->vox_flags;
     return L;
 }
 
@@ -1679,6 +1685,8 @@ static int voxel_grid_impl(slam3d_icp_handle *h, int B, const VoxFrame *frames, 
     if (h->vox_dirty) {      // allocation, or an earlier call failed half way: from then on every call cleans up after itself
         hipLaunchKernelGGL(k_voxel_clear, dim3((h->vox.cap + VOX_BLOCK - 1) / VOX_BLOCK, h->vox_B), dim3(VOX_BLOCK), 0, s, h->vox);
         HIPCHK(h, hipMemsetAsync(h->vox_hist, 0, sizeof(int) * (size_t)h->vox_B * VOX_HIST_INTS, s));     // histograms AND the scan tickets
+        HIPCHK(h, hipMemsetAsync(h->vox_bits, 0, sizeof(unsigned long long) * (size_t)h->vox_B * VOX_BINS * VOX_BW, s));
+        HIPCHK(h, hipMemsetAsync(h->vox_flags, 0, sizeof(int) * (size_t)h->vox_B, s));
     }
     h->vox_dirty = true;     // until this call has run to its end
     const VoxLayout L = vox_layout(h);
@@ -1698,33 +1706,60 @@ static int voxel_grid_impl(slam3d_icp_handle *h, int B, const VoxFrame *frames, 
     if (org) hipLaunchKernelGGL(k_voxel_insert<true>, dim3(nblk, B), dim3(VOX_BLOCK), 0, s, frames[0], d_frames, h->p.width, h->p.height, 1.0f / leaf, zmin, zmax, L);
     else hipLaunchKernelGGL(k_voxel_insert<false>, dim3(nblk, B), dim3(VOX_BLOCK), 0, s, frames[0], d_frames, h->p.width, h->p.height, 1.0f / leaf, zmin, zmax, L);
     for (int b = 0; b < B; ++b) ((volatile int *)h->pin_vox_m)[b] = -1;
-    hipLaunchKernelGGL(k_voxel_scan, dim3(VOX_SCAN_BLOCKS, B), dim3(1024), 0, s, L);
-    hipLaunchKernelGGL(k_voxel_scatter, dim3(nblk, B), dim3(VOX_BLOCK), 0, s, L);
-    hipLaunchKernelGGL(k_voxel_rank, dim3(nblk, B), dim3(VOX_BLOCK), 0, s, frames[0], d_frames, L);
+    hipLaunchKernelGGL(k_voxel_scan<true>, dim3(VOX_SCAN_BLOCKS, B), dim3(1024), 0, s, L);
+    hipLaunchKernelGGL(k_voxel_finalize, dim3(nblk, B), dim3(64), 0, s, frames[0], d_frames, L);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->vox_done, s));
     h->vox_done_valid = true;
+    // the general ordering path for the frames the dense one flagged (a claimed voxel outside the bitmap's key range: clouds in a world
+    // frame, huge leaves): histogram from the claim lists, scan, scatter, rank -- the round-5 sequence, on those frames only
+    auto general_path = [&]() -> int {
+        for (int b = 0; b < B; ++b) if (((volatile int *)h->pin_vox_m)[b] == -2) ((volatile int *)h->pin_vox_m)[b] = -1;
+        hipLaunchKernelGGL(k_voxel_hist, dim3(nblk, B), dim3(VOX_BLOCK), 0, s, L);
+        hipLaunchKernelGGL(k_voxel_scan<false>, dim3(VOX_SCAN_BLOCKS, B), dim3(1024), 0, s, L);
+        hipLaunchKernelGGL(k_voxel_scatter, dim3(nblk, B), dim3(VOX_BLOCK), 0, s, L);
+        hipLaunchKernelGGL(k_voxel_rank, dim3(nblk, B), dim3(VOX_BLOCK), 0, s, frames[0], d_frames, L);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemsetAsync(h->vox_flags, 0, sizeof(int) * (size_t)B, s));
+        HIPCHK(h, hipEventRecord(h->vox_done, s));
+        return SLAM3D_OK;
+    };
+    for (int pass = 0; pass < 2; ++pass) {
+    bool flagged = false;
     if (stream) {
         // A caller's stream: the records are ready IN STREAM ORDER, and the call returns as soon as the counts are known --
         // k_voxel_scan writes them into host-mapped memory while the scatter and rank launches are still queued behind it.
         for (int b = 0; b < B; ++b) {
             int m = -1;
-            for (unsigned spins = 1; (m = ((volatile int *)h->pin_vox_m)[b]) < 0; ++spins) {
+            for (unsigned spins = 1; (m = ((volatile int *)h->pin_vox_m)[b]) == -1; ++spins) {
                 if ((spins & 0x3ff) != 0) continue;
                 const hipError_t q = hipStreamQuery(s);                 // a failed launch must not leave us spinning
                 if (q == hipErrorNotReady) continue;
                 HIPCHK(h, q);
                 m = ((volatile int *)h->pin_vox_m)[b];
-                if (m < 0) { h->err = "voxel grid: the stream drained without a count"; return SLAM3D_E_HIP; }
+                if (m == -1) { h->err = "voxel grid: the stream drained without a count"; return SLAM3D_E_HIP; }
                 break;
             }
             n_out[b] = m;
+            flagged = flagged || m == -2;
         }
     } else {
         HIPCHK(h, hipStreamSynchronize(s));      // the voxel counts are in host-mapped memory by now (written by k_voxel_scan)
-        for (int b = 0; b < B; ++b) n_out[b] = ((volatile int *)h->pin_vox_m)[b];
+        for (int b = 0; b < B; ++b) { n_out[b] = ((volatile int *)h->pin_vox_m)[b]; flagged = flagged || n_out[b] == -2; }
+    }
+    if (pass == 0) ++(flagged ? h->vox_calls_general : h->vox_calls_dense);
+    if (!flagged) break;
+    if (pass == 1) { h->err = "voxel grid: the general path left a frame flagged"; return SLAM3D_E_HIP; }
+    { const int rc2 = general_path(); if (rc2) return rc2; }
     }
     h->vox_dirty = false;
+    return SLAM3D_OK;
+}
+
+extern "C" int slam3d_voxel_grid_path_counts(slam3d_icp_handle *h, int64_t counts[2])
+{
+    if (!h || !counts) return SLAM3D_E_INVALID;
+    counts[0] = h->vox_calls_dense; counts[1] = h->vox_calls_general;
     return SLAM3D_OK;
 }
 
@@ -2200,3 +2235,7 @@ extern "C" int slam3d_icp_dense_run(slam3d_icp_handle *h, slam3d_comm *comm, con
     }
     return rc;
 }
+
+#ifdef VOX_DBG
+extern "C" int slam3d_debug_vox_phases(long long *out, int n_ll) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(s3d::g_vox_dbg), sizeof(long long) * (size_t)n_ll); }
+#endif

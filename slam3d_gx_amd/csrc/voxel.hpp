@@ -60,7 +60,9 @@ struct VoxLayout {
     unsigned long long *lkey; int *lslot; int *bcount; int blk_stride;      // claim lists: blk_stride insert blocks per frame (bcount: blk_stride + 1 ints)
     int *hist; int hist_stride;                                            // hist | start | cursor | btot | boff | ticket, VOX_HIST_INTS per frame
     unsigned long long *gkey; int *gslot; int g_stride;                    // sorted lists: g_stride entries per frame
-    int *m_host;                                                           // host-mapped voxel counts, one per frame
+    int *m_host;                                                           // host-mapped voxel counts, one per frame (-2: the frame needs the general ordering path)
+    unsigned long long *bits, *rowbits;                                    // round 6: occupancy bitmaps of the dense key range, VOX_BINS x VOX_BW words per frame (see k_voxel_finalize)
+    int *flags;                                                            // per frame: 1 = a voxel outside the dense key range was claimed
 };
 __device__ __forceinline__ VoxFrame vox_frame(const VoxFrame *__restrict__ frames, const VoxFrame &f0) { return frames ? frames[blockIdx.y] : f0; }
 
@@ -147,6 +149,23 @@ __device__ __forceinline__ int vox_bin(unsigned long long key)
     return iz * VOX_BY + by;
 }
 
+// Round 6: the ORDER without a sort.  Inside the dense key range -- iz and iy inside the row table above, ix in [-256, 255] (7.7 m either
+// side at a 3 cm leaf: every cloud in a camera frame) -- a voxel is one BIT: row (iz, iy), bit ix of the row's VOX_BW 64-bit words.  The
+// lane that claims a voxel sets its bit (ORed per block in LDS first: one memory-side atomic per (block, word), 11.8 k instead of the
+// 35 k histogram increments of a 640x480 frame); k_voxel_scan<true> turns the rows' popcounts into row starts, copies the occupied rows
+// to `rowbits` and clears the bitmap; k_voxel_finalize ranks every claimed voxel by start[row] + popcount(bits below its own) -- ascending
+// key, PCL's order -- and writes its centroid.  Three launches, no scatter, no key compares.  A claimed voxel outside the range raises the
+// frame's flag: the host then runs the general path (k_voxel_hist from the claim lists, scan, scatter, rank) for that frame.
+constexpr int VOX_BW = 8;                    // 64-bit words per row: 512 ix values
+__device__ __forceinline__ bool vox_dense(unsigned long long key, int &row, int &ixr)
+{
+    const int iz = (int)(key >> 42) - 1048576 + (int)zbias;
+    const int iy = (int)((key >> 21) & 0x1FFFFF) - 1048576 + VOX_BY / 2;
+    ixr = (int)(key & 0x1FFFFF) - 1048576 + 32 * VOX_BW;
+    row = iz * VOX_BY + iy;
+    return iz >= 0 && iz < VOX_BZ && iy >= 0 && iy < VOX_BY && ixr >= 0 && ixr < 64 * VOX_BW;
+}
+
 // One thread per point, one block per 16x16-pixel tile of an organized cloud (ORG; a voxel of the 3 cm grid covers
 // ~6x6 pixels at 2.5 m, so a tile holds about a dozen voxels) or per 256 consecutive records otherwise.
 //   1. runs of equal keys inside a wave are summed with a segmented scan (integers: same bits);
@@ -158,6 +177,12 @@ __device__ __forceinline__ int vox_bin(unsigned long long key)
 //      640x480 frame) to one per (tile, voxel) (~15 k), the first-writer line cuts the atomics per update.
 // The lane whose CAS claims an empty global slot lists it at lkey / lslot[block * VOX_BLOCK + k] (k from an LDS
 // counter; bcount[block] = entries listed) and bumps the row histogram.
+#ifdef VOX_DBG       // developer build: thread 0 of every insert block books the 100 MHz clock at its phase boundaries (tools/vox_phases.py)
+__device__ long long g_vox_dbg[4096 * 8];
+#define VOXT(k) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) g_vox_dbg[blockIdx.x * 8 + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define VOXT(k) do { } while (0)
+#endif
 constexpr int VOX_LH = 512;            // LDS hash entries per block (256 points: load <= 0.5)
 constexpr int VOX_TW = 16;             // tile edge in pixels (ORG)
 
@@ -172,12 +197,12 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
     unsigned long long *__restrict__ lkey = L.lkey + (size_t)fb * L.blk_stride * VOX_BLOCK;
     int *__restrict__ lslot = L.lslot + (size_t)fb * L.blk_stride * VOX_BLOCK;
     int *__restrict__ bcount = L.bcount + (size_t)fb * (L.blk_stride + 1) + 1;
-    int *__restrict__ hist = L.hist + (size_t)fb * L.hist_stride;
     __shared__ unsigned long long hk[VOX_LH], hc01[VOX_LH], hc23[VOX_LH];
     __shared__ long long hsx[VOX_LH], hsy[VOX_LH], hsz[VOX_LH];
     __shared__ unsigned int hn[VOX_LH];
     __shared__ int occ[VOX_LH];                                  // the occupied entries, compacted
     __shared__ int bcnt, nocc;
+    VOXT(0);
     for (int k = threadIdx.x; k < VOX_LH; k += VOX_BLOCK) { hk[k] = VOX_EMPTY; hc01[k] = 0; hc23[k] = 0; hsx[k] = 0; hsy[k] = 0; hsz[k] = 0; hn[k] = 0; }
     if (threadIdx.x == 0) { bcnt = 0; nocc = 0; }
     __syncthreads();
@@ -194,6 +219,10 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
     const int lane = threadIdx.x & 63;
     float4 p = make_float4(0.0f, 0.0f, -1.0f, 0.0f);
     if (i >= 0) p = pts[i];
+#ifdef VOX_DBG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    VOXT(1);
     const bool ok = i >= 0 && isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && p.z >= zmin && p.z <= zmax;     // PassThrough
     const unsigned long long key = ok ? vox_key(p.x, p.y, p.z, inv_leaf) : VOX_EMPTY;
     const unsigned long long prev = __shfl_up(key, 1);
@@ -208,6 +237,7 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
     const unsigned long long c01 = run_scan((unsigned long long)(rgba & 0xffu) | ((unsigned long long)((rgba >> 8) & 0xffu) << 32), seg);
     const unsigned long long c23 = run_scan((unsigned long long)((rgba >> 16) & 0xffu) | ((unsigned long long)(rgba >> 24) << 32), seg);
     const int cnt = run_scan(1, seg);
+    VOXT(2);
     if (ok && tail) {                                            // level 2: the block's LDS table
         unsigned int s = vox_hash(key) & (VOX_LH - 1);
         for (;;) {
@@ -223,15 +253,19 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
         atomicAdd(&hn[s], (unsigned int)cnt);
     }
     __syncthreads();
+    VOXT(3);
     // level 3: one global update per (block, voxel).  The few dozen occupied entries are compacted first, so that each has
     // a thread of its own and the block pays ONE round of returning-atomic latency (thread t looking at entries t and
     // t + 256 in turn paid two whenever any thread held two).
     for (int k = threadIdx.x; k < VOX_LH; k += VOX_BLOCK)
         if (hk[k] != VOX_EMPTY) occ[atomicAdd(&nocc, 1)] = k;
     __syncthreads();
-    const int n_occ = nocc;
-    for (int e = threadIdx.x; e < n_occ; e += VOX_BLOCK) {
-        const int k = occ[e];
+    const int n_occ = nocc;                                          // <= VOX_BLOCK: a block holds 256 points
+    VOXT(4);
+    int wi = -1;                                                     // the bitmap word of the voxel this thread claimed (-1: none)
+    unsigned long long wbit = 0ull;
+    if ((int)threadIdx.x < n_occ) {
+        const int k = occ[threadIdx.x];
         const unsigned long long gk = hk[k];
         unsigned int s = vox_hash(gk) & (unsigned int)(t.cap - 1);
         bool claimed = false;
@@ -242,6 +276,7 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
             s = (s + 1) & (unsigned int)(t.cap - 1);
         }
         VoxSlot *q = t.slot + s;
+        VOXT(5);
         if (claimed) {                                               // this block owns line 1: three plain 16-byte stores
             const unsigned long long sx = (unsigned long long)hsx[k], sy = (unsigned long long)hsy[k], sz = (unsigned long long)hsz[k];
             const unsigned long long c01 = hc01[k], c23 = hc23[k];
@@ -249,6 +284,12 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
             f[0] = make_uint4((unsigned int)sx, (unsigned int)(sx >> 32), (unsigned int)sy, (unsigned int)(sy >> 32));
             f[1] = make_uint4((unsigned int)sz, (unsigned int)(sz >> 32), (unsigned int)c01, (unsigned int)(c01 >> 32));
             f[2] = make_uint4((unsigned int)c23, (unsigned int)(c23 >> 32), hn[k], 0u);
+            const int c = atomicAdd(&bcnt, 1);                       // LDS: at most VOX_BLOCK claims per block
+            lkey[(size_t)blockIdx.x * VOX_BLOCK + c] = gk;
+            lslot[(size_t)blockIdx.x * VOX_BLOCK + c] = (int)s;
+            int row, ixr;
+            if (vox_dense(gk, row, ixr)) { wi = row * VOX_BW + (ixr >> 6); wbit = 1ull << (ixr & 63); }
+            else L.flags[fb] = 1;                                    // (same value from every writer)
         } else {                                                     // the voxel straddles image tiles: late sums, line 0
             atomicAdd(reinterpret_cast<unsigned long long *>(&q->sx), (unsigned long long)hsx[k]);
             atomicAdd(reinterpret_cast<unsigned long long *>(&q->sy), (unsigned long long)hsy[k]);
@@ -257,15 +298,39 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
             atomicAdd(&q->c23, hc23[k]);
             atomicAdd(&q->n, hn[k]);
         }
-        if (claimed) {
-            const int c = atomicAdd(&bcnt, 1);                       // LDS: at most VOX_BLOCK claims per block
-            lkey[(size_t)blockIdx.x * VOX_BLOCK + c] = gk;
-            lslot[(size_t)blockIdx.x * VOX_BLOCK + c] = (int)s;
-            atomicAdd(hist + vox_bin(gk), 1);                        // 131072 rows: no address is hot
+    }
+    // the claimed voxels' bits, ORed per bitmap word in LDS (the hash arrays are free by now: hk = word index, hsx = bits)
+    __syncthreads();
+    for (int k = threadIdx.x; k < VOX_LH; k += VOX_BLOCK) { hk[k] = VOX_EMPTY; hsx[k] = 0; }
+    __syncthreads();
+    if (wi >= 0) {
+        unsigned int s = vox_hash((unsigned long long)wi) & (VOX_LH - 1);
+        for (;;) {
+            const unsigned long long was = atomicCAS(&hk[s], VOX_EMPTY, (unsigned long long)wi);
+            if (was == VOX_EMPTY || was == (unsigned long long)wi) break;
+            s = (s + 1) & (VOX_LH - 1);
         }
+        atomicOr(reinterpret_cast<unsigned long long *>(&hsx[s]), wbit);
     }
     __syncthreads();
+    unsigned long long *__restrict__ bits = L.bits + (size_t)fb * VOX_BINS * VOX_BW;
+    for (int k = threadIdx.x; k < VOX_LH; k += VOX_BLOCK)
+        if (hk[k] != VOX_EMPTY) atomicOr(bits + hk[k], (unsigned long long)hsx[k]);
+    VOXT(6);
+#ifdef VOX_DBG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    VOXT(7);
     if (threadIdx.x == 0) bcount[blockIdx.x] = bcnt;
+}
+
+// general ordering path only: the row histogram of a flagged frame, from its claim lists.  grid (insert blocks, frames)
+__global__ __launch_bounds__(VOX_BLOCK) void k_voxel_hist(VoxLayout L)
+{
+    const int fb = blockIdx.y;
+    if (!L.flags[fb]) return;
+    const int nb = L.bcount[(size_t)fb * (L.blk_stride + 1) + 1 + blockIdx.x];
+    if ((int)threadIdx.x < nb) atomicAdd(L.hist + (size_t)fb * L.hist_stride + vox_bin(L.lkey[((size_t)fb * L.blk_stride + blockIdx.x) * VOX_BLOCK + threadIdx.x]), 1);
 }
 
 // exclusive prefix of the row histogram; cursor[] and the histogram itself reset for the next call.  ONE launch of
@@ -281,17 +346,35 @@ __device__ __forceinline__ VoxHist vox_hist_of(const VoxLayout &L, int fb)
     h.boff = h.btot + VOX_SCAN_BLOCKS; h.ticket = h.boff + VOX_SCAN_BLOCKS;
     return h;
 }
-// grid (VOX_SCAN_BLOCKS, frames)
+// grid (VOX_SCAN_BLOCKS, frames).  <BITS>: a row's count is the popcount of its bitmap words; occupied rows are copied to `rowbits` (what
+// k_voxel_finalize reads) and cleared in place -- the bitmap is empty again when the launch ends; a flagged frame reports -2 instead of its
+// count (the host then runs the general path, whose scan is the <false> instance, on it).  <false> only works on flagged frames.
+template <bool BITS>
 __global__ __launch_bounds__(1024) void k_voxel_scan(VoxLayout L)
 {
+    if (!BITS && !L.flags[blockIdx.y]) return;
     const VoxHist vh = vox_hist_of(L, blockIdx.y);
     int *__restrict__ hist = vh.hist, *__restrict__ start = vh.start, *__restrict__ cursor = vh.cursor, *__restrict__ btot = vh.btot,
         *__restrict__ boff = vh.boff, *__restrict__ ticket = vh.ticket, *__restrict__ m_host = L.m_host + blockIdx.y;
     __shared__ int wtot[16];
     __shared__ int last_sh;
     const int i = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int v = hist[i];
-    if (v) hist[i] = 0;
+    int v;
+    if constexpr (BITS) {
+        uint4 *__restrict__ rb = reinterpret_cast<uint4 *>(L.bits + ((size_t)blockIdx.y * VOX_BINS + i) * VOX_BW);
+        uint4 r[VOX_BW / 2];
+        v = 0;
+#pragma unroll
+        for (int k = 0; k < VOX_BW / 2; ++k) { r[k] = rb[k]; v += __popc(r[k].x) + __popc(r[k].y) + __popc(r[k].z) + __popc(r[k].w); }
+        if (v) {
+            uint4 *__restrict__ cp = reinterpret_cast<uint4 *>(L.rowbits + ((size_t)blockIdx.y * VOX_BINS + i) * VOX_BW);
+#pragma unroll
+            for (int k = 0; k < VOX_BW / 2; ++k) { cp[k] = r[k]; rb[k] = make_uint4(0u, 0u, 0u, 0u); }
+        }
+    } else {
+        v = hist[i];
+        if (v) hist[i] = 0;
+    }
     int incl = v;
     for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
     if (lane == 63) wtot[w] = incl;
@@ -299,7 +382,7 @@ __global__ __launch_bounds__(1024) void k_voxel_scan(VoxLayout L)
     int before = 0;
     for (int q = 0; q < w; ++q) before += wtot[q];
     start[i] = before + incl - v;                      // exclusive prefix inside the block
-    cursor[i] = 0;
+    if constexpr (!BITS) cursor[i] = 0;
     if (threadIdx.x == 1023) {
         // (round 6: no __threadfence() on either side of the ticket -- on gfx950 it is buffer_wbl2 + buffer_inv, an L2 write-back and
         //  invalidate.  The block total is a device-scope store and the last block reads the totals with device-scope loads: the store
@@ -331,7 +414,8 @@ __global__ __launch_bounds__(1024) void k_voxel_scan(VoxLayout L)
     if (lane == 63) {
         start[VOX_BINS] = inc;                         // = number of voxels
         *ticket = 0;                                   // ready for the next call
-        __hip_atomic_store(m_host, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // host-mapped: the host polls it while the later launches run
+        const int report = (BITS && L.flags[blockIdx.y]) ? -2 : inc;
+        __hip_atomic_store(m_host, report, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // host-mapped: the host polls it while the later launches run
     }
 }
 __device__ __forceinline__ int vox_start(const int *__restrict__ start, const int *__restrict__ boff, int b)
@@ -345,6 +429,7 @@ __device__ __forceinline__ int vox_start(const int *__restrict__ start, const in
 __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_scatter(VoxLayout L)
 {
     const int fb = blockIdx.y;
+    if (!L.flags[fb]) return;                                          // general ordering path: flagged frames only
     const VoxHist vh = vox_hist_of(L, fb);
     const unsigned long long *__restrict__ lkey = L.lkey + (size_t)fb * L.blk_stride * VOX_BLOCK;
     const int *__restrict__ lslot = L.lslot + (size_t)fb * L.blk_stride * VOX_BLOCK;
@@ -384,9 +469,68 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_scatter(VoxLayout L)
 // are ordered, so an entry's rank = start of the first row its block touches + the keys of the block's rows below
 // its own: the block stages the union of its entries' rows through LDS.  grid covers the worst case (n entries);
 // blocks beyond the voxel count leave at once.  Every slot is reset as it is read (self-cleaning table).
+// centroid of slot q (first + late sums) -> out[rank]; the slot is left empty for the next call
+__device__ __forceinline__ void vox_emit(VoxSlot *q, float4 *__restrict__ out, int rank)
+{
+    const uint4 a0 = reinterpret_cast<const uint4 *>(q)[0], a1 = reinterpret_cast<const uint4 *>(q)[1],
+                a2 = reinterpret_cast<const uint4 *>(q)[2], a3 = reinterpret_cast<const uint4 *>(q)[3];        // key + late sums
+    const uint4 f0 = reinterpret_cast<const uint4 *>(&q->first)[0], f1 = reinterpret_cast<const uint4 *>(&q->first)[1],
+                f2 = reinterpret_cast<const uint4 *>(&q->first)[2];                                             // the claiming block's sums
+    const long long sx = (long long)((((unsigned long long)a0.w << 32) | a0.z) + (((unsigned long long)f0.y << 32) | f0.x));
+    const long long sy = (long long)((((unsigned long long)a1.y << 32) | a1.x) + (((unsigned long long)f0.w << 32) | f0.z));
+    const long long sz = (long long)((((unsigned long long)a1.w << 32) | a1.z) + (((unsigned long long)f1.y << 32) | f1.x));
+    const unsigned int c0 = a2.x + f1.z, c1 = a2.y + f1.w, c2 = a2.z + f2.x, c3 = a2.w + f2.y;
+    const unsigned int ni = a3.x + f2.z;
+    const double cnt = (double)ni;
+    float4 o;
+    o.x = (float)(((double)sx / cnt) / 1048576.0);
+    o.y = (float)(((double)sy / cnt) / 1048576.0);
+    o.z = (float)(((double)sz / cnt) / 1048576.0);
+    const unsigned int rgba = (c0 / ni) | ((c1 / ni) << 8) | ((c2 / ni) << 16) | ((c3 / ni) << 24);
+    o.w = __int_as_float((int)rgba);
+    out[rank] = o;
+    uint4 *w = reinterpret_cast<uint4 *>(q);                              // leave the slot empty for the next call
+    w[0] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
+    w[1] = make_uint4(0u, 0u, 0u, 0u); w[2] = make_uint4(0u, 0u, 0u, 0u); w[3] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// The dense path's last launch: one wave per insert block walks that block's claim list.  rank = start of the voxel's row + occupied bits
+// below its own in the row's copy of the bitmap.  grid (insert blocks, frames), block 64.
+__global__ __launch_bounds__(64) void k_voxel_finalize(VoxFrame fr0, const VoxFrame *__restrict__ frames, VoxLayout L)
+{
+    const int fb = blockIdx.y;
+    if (L.flags[fb]) return;                                           // the general path will order this frame
+    const int nb = L.bcount[(size_t)fb * (L.blk_stride + 1) + 1 + blockIdx.x];
+    if (nb == 0) return;
+    const VoxHist vh = vox_hist_of(L, fb);
+    const int *__restrict__ start = vh.start, *__restrict__ boff = vh.boff;
+    VoxSlot *const slots = L.t.slot + (size_t)fb * L.t.cap;
+    const unsigned long long *__restrict__ lkey = L.lkey + ((size_t)fb * L.blk_stride + blockIdx.x) * VOX_BLOCK;
+    const int *__restrict__ lslot = L.lslot + ((size_t)fb * L.blk_stride + blockIdx.x) * VOX_BLOCK;
+    float4 *__restrict__ out = vox_frame(frames, fr0).out;
+    for (int e = threadIdx.x; e < nb; e += 64) {
+        const unsigned long long key = lkey[e];
+        VoxSlot *q = slots + lslot[e];
+        int row, ixr;
+        (void)vox_dense(key, row, ixr);
+        const ulonglong2 *__restrict__ rb = reinterpret_cast<const ulonglong2 *>(L.rowbits + ((size_t)fb * VOX_BINS + row) * VOX_BW);
+        int rank = start[row] + boff[row >> 10];
+        const int wi = ixr >> 6;
+        const unsigned long long below = (1ull << (ixr & 63)) - 1ull;
+#pragma unroll
+        for (int k = 0; k < VOX_BW / 2; ++k) {
+            const ulonglong2 w2 = rb[k];
+            rank += 2 * k < wi ? __popcll(w2.x) : (2 * k == wi ? __popcll(w2.x & below) : 0);
+            rank += 2 * k + 1 < wi ? __popcll(w2.y) : (2 * k + 1 == wi ? __popcll(w2.y & below) : 0);
+        }
+        vox_emit(q, out, rank);
+    }
+}
+
 __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_rank(VoxFrame fr0, const VoxFrame *__restrict__ frames, VoxLayout L)
 {
     const int fb = blockIdx.y;
+    if (!L.flags[fb]) return;                                          // general ordering path: flagged frames only
     const VoxHist vh = vox_hist_of(L, fb);
     VoxTable t = L.t; t.slot += (size_t)fb * t.cap;
     const unsigned long long *__restrict__ gkey = L.gkey + (size_t)fb * L.g_stride;
@@ -423,27 +567,7 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_rank(VoxFrame fr0, const Vo
         }
     }
     if (!live) return;
-    VoxSlot *q = t.slot + gslot[e];
-    const uint4 a0 = reinterpret_cast<const uint4 *>(q)[0], a1 = reinterpret_cast<const uint4 *>(q)[1],
-                a2 = reinterpret_cast<const uint4 *>(q)[2], a3 = reinterpret_cast<const uint4 *>(q)[3];        // key + late sums
-    const uint4 f0 = reinterpret_cast<const uint4 *>(&q->first)[0], f1 = reinterpret_cast<const uint4 *>(&q->first)[1],
-                f2 = reinterpret_cast<const uint4 *>(&q->first)[2];                                             // the claiming block's sums
-    const long long sx = (long long)((((unsigned long long)a0.w << 32) | a0.z) + (((unsigned long long)f0.y << 32) | f0.x));
-    const long long sy = (long long)((((unsigned long long)a1.y << 32) | a1.x) + (((unsigned long long)f0.w << 32) | f0.z));
-    const long long sz = (long long)((((unsigned long long)a1.w << 32) | a1.z) + (((unsigned long long)f1.y << 32) | f1.x));
-    const unsigned int c0 = a2.x + f1.z, c1 = a2.y + f1.w, c2 = a2.z + f2.x, c3 = a2.w + f2.y;
-    const unsigned int ni = a3.x + f2.z;
-    const double cnt = (double)ni;
-    float4 o;
-    o.x = (float)(((double)sx / cnt) / 1048576.0);
-    o.y = (float)(((double)sy / cnt) / 1048576.0);
-    o.z = (float)(((double)sz / cnt) / 1048576.0);
-    const unsigned int rgba = (c0 / ni) | ((c1 / ni) << 8) | ((c2 / ni) << 16) | ((c3 / ni) << 24);
-    o.w = __int_as_float((int)rgba);
-    out[rank] = o;
-    uint4 *w = reinterpret_cast<uint4 *>(q);                              // leave the slot empty for the next call
-    w[0] = make_uint4(0xffffffffu, 0xffffffffu, 0u, 0u);
-    w[1] = make_uint4(0u, 0u, 0u, 0u); w[2] = make_uint4(0u, 0u, 0u, 0u); w[3] = make_uint4(0u, 0u, 0u, 0u);
+    vox_emit(t.slot + gslot[e], out, rank);
 }
 
 // src/saveOutput.cpp:84-92: PassThrough z in [0, z_max] on a (down-sampled) keyframe cloud, then

@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 def test_abi_version_and_strerror_without_gpu():
     lib = capi.load_library()
-    assert lib.slam3d_icp_abi_version() == 7
+    assert lib.slam3d_icp_abi_version() == 8
     assert b"no gfx950" in lib.slam3d_strerror(-4)
     assert lib.slam3d_strerror(0) == b"ok"
 

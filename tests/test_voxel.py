@@ -186,6 +186,57 @@ def test_hip_voxel_grid_batch_equals_the_single_calls(gpu_lib, organized):
 
 
 @pytest.mark.gpu
+def test_hip_voxel_grid_dense_and_general_ordering_paths(gpu_lib):
+    """Round 6: inside the dense key range (iz, iy in the row table, ix in [-256, 255]) the order comes from occupancy bitmaps (scan +
+    k_voxel_finalize: three launches); a frame that claims a voxel outside it is flagged on the device and ordered by the general path
+    (histogram from the claim lists, scan, scatter, rank).  Both give the oracle's bits: the range's edge cells, a tiny leaf, clouds
+    shifted out of the range, flagged and unflagged frames in ONE batch, and dense calls after general ones on the same tables."""
+    import torch
+    from slam3d_gx_amd import capi
+    pr, c = _cloud(31, 320, 240)
+    leaf = 0.03
+    rec = lambda x, y, z, rgba=0: [x, y, z, np.array([rgba], dtype=np.uint32).view(np.float32)[0]]
+    edge_in = np.array([rec((-256 + 0.5) * leaf, 0.0, 1.0, 1), rec((255 + 0.5) * leaf, 0.0, 1.0, 2), rec(0.0, (-128 + 0.5) * leaf, 1.0, 3),
+                        rec(0.0, (127 + 0.5) * leaf, 1.0, 4), rec(0.1, 0.1, 0.01, 5), rec(0.1, 0.1, 7.0, 6)], dtype=np.float32)
+    edge_out = [np.array([rec((-257 + 0.5) * leaf, 0.0, 1.0, 1), rec(0.0, 0.0, 1.0, 2)], dtype=np.float32),
+                np.array([rec((256 + 0.5) * leaf, 0.0, 1.0, 1), rec(0.0, 0.0, 1.0, 2)], dtype=np.float32),
+                np.array([rec(0.0, (128 + 0.5) * leaf, 1.0, 1), rec(0.0, 0.0, 1.0, 2)], dtype=np.float32),
+                np.array([rec(0.0, (-129 + 0.5) * leaf, 1.0, 1), rec(0.0, 0.0, 1.0, 2)], dtype=np.float32)]
+    shifted = c.copy(); shifted[:, 0] += 20.0
+    same = lambda a, b: a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1)) as h:
+        assert same(h.voxel_grid(edge_in), O.voxel_grid(edge_in))
+        assert h.voxel_grid_path_counts() == (1, 0)
+        for e in edge_out:
+            assert same(h.voxel_grid(e), O.voxel_grid(e))
+            assert same(h.voxel_grid(edge_in), O.voxel_grid(edge_in))        # a dense call right after a general one
+        assert h.voxel_grid_path_counts() == (5, 4)
+        for lf in (0.005, 0.03, 0.008, 0.03, 2.0):                            # general, dense, general, dense, dense (one voxel per metre)
+            assert same(h.voxel_grid(c, leaf=lf), O.voxel_grid(c, lf)), lf
+        assert h.voxel_grid_path_counts() == (8, 6)
+        assert same(h.voxel_grid(shifted), O.voxel_grid(shifted))
+        assert same(h.voxel_grid(c), O.voxel_grid(c))
+        assert h.voxel_grid_path_counts() == (9, 7)
+        # one batch, flagged and unflagged frames side by side; then an all-dense and an all-general batch on the same tables
+        clouds = [c, shifted, _cloud(32, 320, 240)[1], shifted[::-1].copy(), _cloud(33, 320, 240)[1]]
+        ds = [torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0") for x in clouds]
+        outs = [torch.zeros_like(d) for d in ds]
+        wants = [O.voxel_grid(x) for x in clouds]
+        st = torch.cuda.Stream()
+        for sel, stream in (([0, 1, 2, 3, 4], st.cuda_stream), ([0, 2, 4], st.cuda_stream), ([1, 3], st.cuda_stream), ([3, 0], torch.cuda.current_stream().cuda_stream)):
+            torch.cuda.synchronize()
+            for o in outs:
+                o.zero_()
+            torch.cuda.synchronize()
+            ms = h.voxel_grid_batch_device([ds[k].data_ptr() for k in sel], [len(clouds[k]) for k in sel], [outs[k].data_ptr() for k in sel], leaf, stream)
+            torch.cuda.synchronize()
+            for k, m in zip(sel, ms):
+                assert m == wants[k].shape[0], (sel, k)
+                assert np.array_equal(outs[k][:m].cpu().numpy().view(np.uint32), wants[k].view(np.uint32)), (sel, k)
+        assert h.voxel_grid_path_counts() == (10, 10)
+
+
+@pytest.mark.gpu
 def test_hip_voxel_grid_device_on_a_caller_stream_is_stream_ordered(gpu_lib):
     """With a caller's stream the call returns as soon as the count is known (host-mapped, written by the scan kernel);
     the records are ready in stream order.  Back-to-back calls reuse the table (self-cleaning) while the previous

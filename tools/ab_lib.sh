@@ -11,7 +11,7 @@ Q="--no-extra-configs --no-cpu-baseline --no-bruteforce --steps 10 --warmup 3"
 i=0
 for m in $NAMES; do
     i=$((i+1))
-    SLAM3D_LIB=$R/tools/variants/$m.so timeout 600 python bench.py $Q "$@" > $OUT/$m.$i.json 2> $OUT/$m.$i.err
+    SLAM3D_LIB=$R/tools/variants/$m.so timeout 600 python bench.py $Q --legs-file $OUT/$m.$i.json "$@" > $OUT/$m.$i.out 2> $OUT/$m.$i.err
     python - <<PY
 import json
 d=json.load(open("$OUT/$m.$i.json"))
