@@ -185,143 +185,175 @@ __device__ long long g_vox_dbg[4096 * 8];
 #endif
 constexpr int VOX_LH = 512;            // LDS hash entries per block (256 points: load <= 0.5)
 constexpr int VOX_TW = 16;             // tile edge in pixels (ORG)
+constexpr int VOX_MAX_PASSES = 16;     // runs of 256 records a list block may take (the claim lists are allocated in multiples of it)
 
+// Point LISTS (round 6): a block takes `passes` runs of 256 consecutive records into ONE LDS table before it touches the global one.  The
+// reference's PCD frames are raster-ordered lists without the invalid pixels: 256 records are half an image row, a 3 cm voxel at 2 m spans six
+// rows, so every voxel was claimed once and then updated by five other blocks with six atomics each (302 k memory-side atomics per frame; an
+// organized frame cut into 16x16 tiles needs 66 k).  4096 records are nine rows: 58 k.  The table (1024 entries) is flushed early whenever the
+// next pass could fill it, so any input is handled; the block's claim list is its `passes` segments of 256, filled in order.
 template <bool ORG>
 __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const VoxFrame *__restrict__ frames, int W, int H, float inv_leaf, float zmin,
-                                                            float zmax, VoxLayout L)
+                                                            float zmax, VoxLayout L, int passes /* runs of 256 records per block (lists; 1 for tiles) */)
 {
+    constexpr int LH = ORG ? VOX_LH : 2 * VOX_LH;
     const VoxFrame fr = vox_frame(frames, f0);
     const float4 *__restrict__ pts = fr.pts;
     const int n = fr.n, fb = blockIdx.y;
     VoxTable t = L.t; t.slot += (size_t)fb * t.cap;
-    unsigned long long *__restrict__ lkey = L.lkey + (size_t)fb * L.blk_stride * VOX_BLOCK;
-    int *__restrict__ lslot = L.lslot + (size_t)fb * L.blk_stride * VOX_BLOCK;
-    int *__restrict__ bcount = L.bcount + (size_t)fb * (L.blk_stride + 1) + 1;
-    __shared__ unsigned long long hk[VOX_LH], hc01[VOX_LH], hc23[VOX_LH];
-    __shared__ long long hsx[VOX_LH], hsy[VOX_LH], hsz[VOX_LH];
-    __shared__ unsigned int hn[VOX_LH];
-    __shared__ int occ[VOX_LH];                                  // the occupied entries, compacted
-    __shared__ int bcnt, nocc;
-    VOXT(0);
-    for (int k = threadIdx.x; k < VOX_LH; k += VOX_BLOCK) { hk[k] = VOX_EMPTY; hc01[k] = 0; hc23[k] = 0; hsx[k] = 0; hsy[k] = 0; hsz[k] = 0; hn[k] = 0; }
-    if (threadIdx.x == 0) { bcnt = 0; nocc = 0; }
-    __syncthreads();
-    int i = -1;
-    if constexpr (ORG) {
-        const int tiles_x = (W + VOX_TW - 1) / VOX_TW;
-        const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-        const int u = tx * VOX_TW + (threadIdx.x & (VOX_TW - 1)), v = ty * VOX_TW + (threadIdx.x / VOX_TW);
-        if (u < W && v < H) i = v * W + u;
-    } else {
-        i = blockIdx.x * VOX_BLOCK + threadIdx.x;
-        if (i >= n) i = -1;
-    }
-    const int lane = threadIdx.x & 63;
-    float4 p = make_float4(0.0f, 0.0f, -1.0f, 0.0f);
-    if (i >= 0) p = pts[i];
-#ifdef VOX_DBG
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-    VOXT(1);
-    const bool ok = i >= 0 && isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && p.z >= zmin && p.z <= zmax;     // PassThrough
-    const unsigned long long key = ok ? vox_key(p.x, p.y, p.z, inv_leaf) : VOX_EMPTY;
-    const unsigned long long prev = __shfl_up(key, 1);
-    const bool head = lane == 0 || prev != key;
-    const unsigned long long heads = __ballot(head);
-    const int seg = __popcll(heads & ((2ull << lane) - 1ull));                  // run number of this lane
-    const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
-    const unsigned int rgba = (unsigned int)__float_as_int(p.w);
-    const long long qx = run_scan(ok ? __double2ll_rn((double)p.x * 1048576.0) : 0ll, seg);
-    const long long qy = run_scan(ok ? __double2ll_rn((double)p.y * 1048576.0) : 0ll, seg);
-    const long long qz = run_scan(ok ? __double2ll_rn((double)p.z * 1048576.0) : 0ll, seg);
-    const unsigned long long c01 = run_scan((unsigned long long)(rgba & 0xffu) | ((unsigned long long)((rgba >> 8) & 0xffu) << 32), seg);
-    const unsigned long long c23 = run_scan((unsigned long long)((rgba >> 16) & 0xffu) | ((unsigned long long)(rgba >> 24) << 32), seg);
-    const int cnt = run_scan(1, seg);
-    VOXT(2);
-    if (ok && tail) {                                            // level 2: the block's LDS table
-        unsigned int s = vox_hash(key) & (VOX_LH - 1);
-        for (;;) {
-            const unsigned long long was = atomicCAS(&hk[s], VOX_EMPTY, key);
-            if (was == VOX_EMPTY || was == key) break;
-            s = (s + 1) & (VOX_LH - 1);
-        }
-        atomicAdd(reinterpret_cast<unsigned long long *>(&hsx[s]), (unsigned long long)qx);
-        atomicAdd(reinterpret_cast<unsigned long long *>(&hsy[s]), (unsigned long long)qy);
-        atomicAdd(reinterpret_cast<unsigned long long *>(&hsz[s]), (unsigned long long)qz);
-        atomicAdd(&hc01[s], c01);
-        atomicAdd(&hc23[s], c23);
-        atomicAdd(&hn[s], (unsigned int)cnt);
-    }
-    __syncthreads();
-    VOXT(3);
-    // level 3: one global update per (block, voxel).  The few dozen occupied entries are compacted first, so that each has
-    // a thread of its own and the block pays ONE round of returning-atomic latency (thread t looking at entries t and
-    // t + 256 in turn paid two whenever any thread held two).
-    for (int k = threadIdx.x; k < VOX_LH; k += VOX_BLOCK)
-        if (hk[k] != VOX_EMPTY) occ[atomicAdd(&nocc, 1)] = k;
-    __syncthreads();
-    const int n_occ = nocc;                                          // <= VOX_BLOCK: a block holds 256 points
-    VOXT(4);
-    int wi = -1;                                                     // the bitmap word of the voxel this thread claimed (-1: none)
-    unsigned long long wbit = 0ull;
-    if ((int)threadIdx.x < n_occ) {
-        const int k = occ[threadIdx.x];
-        const unsigned long long gk = hk[k];
-        unsigned int s = vox_hash(gk) & (unsigned int)(t.cap - 1);
-        bool claimed = false;
-        for (;;) {
-            const unsigned long long was = atomicCAS(&t.slot[s].key, VOX_EMPTY, gk);
-            if (was == VOX_EMPTY) { claimed = true; break; }
-            if (was == gk) break;
-            s = (s + 1) & (unsigned int)(t.cap - 1);
-        }
-        VoxSlot *q = t.slot + s;
-        VOXT(5);
-        if (claimed) {                                               // this block owns line 1: three plain 16-byte stores
-            const unsigned long long sx = (unsigned long long)hsx[k], sy = (unsigned long long)hsy[k], sz = (unsigned long long)hsz[k];
-            const unsigned long long c01 = hc01[k], c23 = hc23[k];
-            uint4 *f = reinterpret_cast<uint4 *>(&q->first);
-            f[0] = make_uint4((unsigned int)sx, (unsigned int)(sx >> 32), (unsigned int)sy, (unsigned int)(sy >> 32));
-            f[1] = make_uint4((unsigned int)sz, (unsigned int)(sz >> 32), (unsigned int)c01, (unsigned int)(c01 >> 32));
-            f[2] = make_uint4((unsigned int)c23, (unsigned int)(c23 >> 32), hn[k], 0u);
-            const int c = atomicAdd(&bcnt, 1);                       // LDS: at most VOX_BLOCK claims per block
-            lkey[(size_t)blockIdx.x * VOX_BLOCK + c] = gk;
-            lslot[(size_t)blockIdx.x * VOX_BLOCK + c] = (int)s;
-            int row, ixr;
-            if (vox_dense(gk, row, ixr)) { wi = row * VOX_BW + (ixr >> 6); wbit = 1ull << (ixr & 63); }
-            else L.flags[fb] = 1;                                    // (same value from every writer)
-        } else {                                                     // the voxel straddles image tiles: late sums, line 0
-            atomicAdd(reinterpret_cast<unsigned long long *>(&q->sx), (unsigned long long)hsx[k]);
-            atomicAdd(reinterpret_cast<unsigned long long *>(&q->sy), (unsigned long long)hsy[k]);
-            atomicAdd(reinterpret_cast<unsigned long long *>(&q->sz), (unsigned long long)hsz[k]);
-            atomicAdd(&q->c01, hc01[k]);
-            atomicAdd(&q->c23, hc23[k]);
-            atomicAdd(&q->n, hn[k]);
-        }
-    }
-    // the claimed voxels' bits, ORed per bitmap word in LDS (the hash arrays are free by now: hk = word index, hsx = bits)
-    __syncthreads();
-    for (int k = threadIdx.x; k < VOX_LH; k += VOX_BLOCK) { hk[k] = VOX_EMPTY; hsx[k] = 0; }
-    __syncthreads();
-    if (wi >= 0) {
-        unsigned int s = vox_hash((unsigned long long)wi) & (VOX_LH - 1);
-        for (;;) {
-            const unsigned long long was = atomicCAS(&hk[s], VOX_EMPTY, (unsigned long long)wi);
-            if (was == VOX_EMPTY || was == (unsigned long long)wi) break;
-            s = (s + 1) & (VOX_LH - 1);
-        }
-        atomicOr(reinterpret_cast<unsigned long long *>(&hsx[s]), wbit);
-    }
-    __syncthreads();
+    unsigned long long *__restrict__ lkey = L.lkey + ((size_t)fb * L.blk_stride + (size_t)blockIdx.x * passes) * VOX_BLOCK;
+    int *__restrict__ lslot = L.lslot + ((size_t)fb * L.blk_stride + (size_t)blockIdx.x * passes) * VOX_BLOCK;
+    int *__restrict__ bcount = L.bcount + (size_t)fb * (L.blk_stride + 1) + 1 + (size_t)blockIdx.x * passes;
     unsigned long long *__restrict__ bits = L.bits + (size_t)fb * VOX_BINS * VOX_BW;
-    for (int k = threadIdx.x; k < VOX_LH; k += VOX_BLOCK)
-        if (hk[k] != VOX_EMPTY) atomicOr(bits + hk[k], (unsigned long long)hsx[k]);
+    __shared__ unsigned long long hk[LH], hc01[LH], hc23[LH];
+    __shared__ long long hsx[LH], hsy[LH], hsz[LH];
+    __shared__ unsigned int hn[LH];
+    __shared__ int occ[LH];                                      // the occupied entries, compacted; then the bitmap word of each claimed one
+    __shared__ unsigned char obit[LH];                           // ... and its bit
+    __shared__ int bcnt, nocc, nkeys;
+    VOXT(0);
+    for (int k = threadIdx.x; k < LH; k += VOX_BLOCK) { hk[k] = VOX_EMPTY; hc01[k] = 0; hc23[k] = 0; hsx[k] = 0; hsy[k] = 0; hsz[k] = 0; hn[k] = 0; }
+    if (threadIdx.x == 0) { bcnt = 0; nocc = 0; nkeys = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    auto record_of = [&](int pass) __attribute__((always_inline)) {
+        int i = -1;
+        if constexpr (ORG) {
+            const int tiles_x = (W + VOX_TW - 1) / VOX_TW;
+            const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+            const int u = tx * VOX_TW + (threadIdx.x & (VOX_TW - 1)), v = ty * VOX_TW + (threadIdx.x / VOX_TW);
+            if (u < W && v < H) i = v * W + u;
+        } else {
+            i = (blockIdx.x * passes + pass) * VOX_BLOCK + threadIdx.x;
+            if (i >= n) i = -1;
+        }
+        return i;
+    };
+    // level 3: one global update per (block, voxel) in the table, then the table is empty again.  The occupied entries are compacted first, so
+    // that each has a thread of its own and the block pays one round of returning-atomic latency per 256 of them.
+    auto flush = [&]() __attribute__((always_inline)) {
+        for (int k = threadIdx.x; k < LH; k += VOX_BLOCK)
+            if (hk[k] != VOX_EMPTY) occ[atomicAdd(&nocc, 1)] = k;
+        __syncthreads();
+        const int n_occ = nocc;
+        VOXT(4);
+        for (int e = threadIdx.x; e < n_occ; e += VOX_BLOCK) {
+            const int k = occ[e];
+            const unsigned long long gk = hk[k];
+            unsigned int s = vox_hash(gk) & (unsigned int)(t.cap - 1);
+            bool claimed = false;
+            for (;;) {
+                const unsigned long long was = atomicCAS(&t.slot[s].key, VOX_EMPTY, gk);
+                if (was == VOX_EMPTY) { claimed = true; break; }
+                if (was == gk) break;
+                s = (s + 1) & (unsigned int)(t.cap - 1);
+            }
+            VoxSlot *q = t.slot + s;
+            VOXT(5);
+            int wi = -1, wb = 0;                                     // the bitmap word / bit of the voxel this entry claimed (-1: none)
+            if (claimed) {                                               // this block owns line 1: three plain 16-byte stores
+                const unsigned long long sx = (unsigned long long)hsx[k], sy = (unsigned long long)hsy[k], sz = (unsigned long long)hsz[k];
+                const unsigned long long c01 = hc01[k], c23 = hc23[k];
+                uint4 *f = reinterpret_cast<uint4 *>(&q->first);
+                f[0] = make_uint4((unsigned int)sx, (unsigned int)(sx >> 32), (unsigned int)sy, (unsigned int)(sy >> 32));
+                f[1] = make_uint4((unsigned int)sz, (unsigned int)(sz >> 32), (unsigned int)c01, (unsigned int)(c01 >> 32));
+                f[2] = make_uint4((unsigned int)c23, (unsigned int)(c23 >> 32), hn[k], 0u);
+                const int c = atomicAdd(&bcnt, 1);                       // LDS: at most one claim per record of the block
+                lkey[c] = gk;
+                lslot[c] = (int)s;
+                int row, ixr;
+                if (vox_dense(gk, row, ixr)) { wi = row * VOX_BW + (ixr >> 6); wb = ixr & 63; }
+                else L.flags[fb] = 1;                                    // (same value from every writer)
+            } else {                                                     // another block claimed the voxel: late sums, line 0
+                atomicAdd(reinterpret_cast<unsigned long long *>(&q->sx), (unsigned long long)hsx[k]);
+                atomicAdd(reinterpret_cast<unsigned long long *>(&q->sy), (unsigned long long)hsy[k]);
+                atomicAdd(reinterpret_cast<unsigned long long *>(&q->sz), (unsigned long long)hsz[k]);
+                atomicAdd(&q->c01, hc01[k]);
+                atomicAdd(&q->c23, hc23[k]);
+                atomicAdd(&q->n, hn[k]);
+            }
+            occ[e] = wi; obit[e] = (unsigned char)wb;                    // (entry e is this thread's alone)
+        }
+        // the claimed voxels' bits, ORed per bitmap word in LDS (the hash arrays are free by now: hk = word index, hsx = bits)
+        __syncthreads();
+        for (int k = threadIdx.x; k < LH; k += VOX_BLOCK) { hk[k] = VOX_EMPTY; hsx[k] = 0; }
+        __syncthreads();
+        for (int e = threadIdx.x; e < n_occ; e += VOX_BLOCK) {
+            const int wi = occ[e];
+            if (wi < 0) continue;
+            unsigned int s = vox_hash((unsigned long long)wi) & (LH - 1);
+            for (;;) {
+                const unsigned long long was = atomicCAS(&hk[s], VOX_EMPTY, (unsigned long long)wi);
+                if (was == VOX_EMPTY || was == (unsigned long long)wi) break;
+                s = (s + 1) & (LH - 1);
+            }
+            atomicOr(reinterpret_cast<unsigned long long *>(&hsx[s]), 1ull << obit[e]);
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < LH; k += VOX_BLOCK) {
+            if (hk[k] != VOX_EMPTY) atomicOr(bits + hk[k], (unsigned long long)hsx[k]);
+            hk[k] = VOX_EMPTY; hc01[k] = 0; hc23[k] = 0; hsx[k] = 0; hsy[k] = 0; hsz[k] = 0; hn[k] = 0;      // an empty table for the passes that follow
+        }
+        if (threadIdx.x == 0) { nocc = 0; nkeys = 0; }
+        __syncthreads();
+    };
+    int i = record_of(0);
+    float4 pn = make_float4(0.0f, 0.0f, -1.0f, 0.0f);
+    if (i >= 0) pn = pts[i];
+    for (int pass = 0; pass < passes; ++pass) {
+        const float4 p = pn;
+        const bool have = i >= 0;
+        if (pass + 1 < passes) {                                     // the next run's record is in flight while this one is summed
+            i = record_of(pass + 1);
+            pn = make_float4(0.0f, 0.0f, -1.0f, 0.0f);
+            if (i >= 0) pn = pts[i];
+        }
+#ifdef VOX_DBG
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        VOXT(1);
+        const bool ok = have && isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && p.z >= zmin && p.z <= zmax;     // PassThrough
+        const unsigned long long key = ok ? vox_key(p.x, p.y, p.z, inv_leaf) : VOX_EMPTY;
+        const unsigned long long prev = __shfl_up(key, 1);
+        const bool head = lane == 0 || prev != key;
+        const unsigned long long heads = __ballot(head);
+        const int seg = __popcll(heads & ((2ull << lane) - 1ull));                  // run number of this lane
+        const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+        const unsigned int rgba = (unsigned int)__float_as_int(p.w);
+        const long long qx = run_scan(ok ? __double2ll_rn((double)p.x * 1048576.0) : 0ll, seg);
+        const long long qy = run_scan(ok ? __double2ll_rn((double)p.y * 1048576.0) : 0ll, seg);
+        const long long qz = run_scan(ok ? __double2ll_rn((double)p.z * 1048576.0) : 0ll, seg);
+        const unsigned long long c01 = run_scan((unsigned long long)(rgba & 0xffu) | ((unsigned long long)((rgba >> 8) & 0xffu) << 32), seg);
+        const unsigned long long c23 = run_scan((unsigned long long)((rgba >> 16) & 0xffu) | ((unsigned long long)(rgba >> 24) << 32), seg);
+        const int cnt = run_scan(1, seg);
+        VOXT(2);
+        if (ok && tail) {                                            // level 2: the block's LDS table
+            unsigned int s = vox_hash(key) & (LH - 1);
+            for (;;) {
+                const unsigned long long was = atomicCAS(&hk[s], VOX_EMPTY, key);
+                if (was == VOX_EMPTY) { if constexpr (!ORG) atomicAdd(&nkeys, 1); break; }
+                if (was == key) break;
+                s = (s + 1) & (LH - 1);
+            }
+            atomicAdd(reinterpret_cast<unsigned long long *>(&hsx[s]), (unsigned long long)qx);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&hsy[s]), (unsigned long long)qy);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&hsz[s]), (unsigned long long)qz);
+            atomicAdd(&hc01[s], c01);
+            atomicAdd(&hc23[s], c23);
+            atomicAdd(&hn[s], (unsigned int)cnt);
+        }
+        __syncthreads();
+        VOXT(3);
+        // the next run may bring 256 new keys: the table must not fill up (load <= 3/4), so it is emptied early when more than half is taken
+        if (!ORG && pass + 1 < passes && nkeys > LH / 2) flush();
+    }
+    flush();
     VOXT(6);
 #ifdef VOX_DBG
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     VOXT(7);
-    if (threadIdx.x == 0) bcount[blockIdx.x] = bcnt;
+    if ((int)threadIdx.x < passes) bcount[threadIdx.x] = min(VOX_BLOCK, max(0, bcnt - (int)threadIdx.x * VOX_BLOCK));      // the block's segments, filled in order
 }
 
 // general ordering path only: the row histogram of a flagged frame, from its claim lists.  grid (insert blocks, frames)
@@ -383,6 +415,10 @@ __global__ __launch_bounds__(1024) void k_voxel_scan(VoxLayout L)
     for (int q = 0; q < w; ++q) before += wtot[q];
     start[i] = before + incl - v;                      // exclusive prefix inside the block
     if constexpr (!BITS) cursor[i] = 0;
+    if constexpr (BITS) {       // the dense path stops here: k_voxel_finalize sums the block totals itself (no ticket, no last-block pass on the critical path)
+        if (threadIdx.x == 1023) btot[blockIdx.x] = before + incl;
+        return;
+    }
     if (threadIdx.x == 1023) {
         // (round 6: no __threadfence() on either side of the ticket -- on gfx950 it is buffer_wbl2 + buffer_inv, an L2 write-back and
         //  invalidate.  The block total is a device-scope store and the last block reads the totals with device-scope loads: the store
@@ -414,8 +450,7 @@ __global__ __launch_bounds__(1024) void k_voxel_scan(VoxLayout L)
     if (lane == 63) {
         start[VOX_BINS] = inc;                         // = number of voxels
         *ticket = 0;                                   // ready for the next call
-        const int report = (BITS && L.flags[blockIdx.y]) ? -2 : inc;
-        __hip_atomic_store(m_host, report, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // host-mapped: the host polls it while the later launches run
+        __hip_atomic_store(m_host, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);     // host-mapped: the host polls it while the later launches run
     }
 }
 __device__ __forceinline__ int vox_start(const int *__restrict__ start, const int *__restrict__ boff, int b)
@@ -495,26 +530,52 @@ __device__ __forceinline__ void vox_emit(VoxSlot *q, float4 *__restrict__ out, i
 }
 
 // The dense path's last launch: one wave per insert block walks that block's claim list.  rank = start of the voxel's row + occupied bits
-// below its own in the row's copy of the bitmap.  grid (insert blocks, frames), block 64.
-__global__ __launch_bounds__(64) void k_voxel_finalize(VoxFrame fr0, const VoxFrame *__restrict__ frames, VoxLayout L)
+// below its own in the row's copy of the bitmap.  grid (list segments, frames), block 256: one thread per entry of the segment (a tile's
+// segment holds ~30 claims: waves 1-3 leave at once; a list block's first segments are full).
+// Workgroups go to the XCDs round robin, and a list block fills its first segments only: taken in list order, the busy segments of blocks
+// with 16 segments each would all sit on XCDs 0 and 1 (measured: 3x the launch time).  So workgroup g takes segment g / nins of insert block
+// g % nins: every block's first segment, then every block's second, ...
+__global__ __launch_bounds__(VOX_BLOCK) void k_voxel_finalize(VoxFrame fr0, const VoxFrame *__restrict__ frames, VoxLayout L, int nins, int passes)
 {
     const int fb = blockIdx.y;
-    if (L.flags[fb]) return;                                           // the general path will order this frame
-    const int nb = L.bcount[(size_t)fb * (L.blk_stride + 1) + 1 + blockIdx.x];
-    if (nb == 0) return;
+    const int seg = ((int)blockIdx.x % nins) * passes + (int)blockIdx.x / nins;
+    const unsigned long long *__restrict__ lkey = L.lkey + ((size_t)fb * L.blk_stride + seg) * VOX_BLOCK;
+    const int *__restrict__ lslot = L.lslot + ((size_t)fb * L.blk_stride + seg) * VOX_BLOCK;
+    // the first 64 list entries are fetched together with the flag and the count (entries beyond the count are stale, never used):
+    // one round trip less in front of the gathers below
+    unsigned long long key0 = 0ull;
+    int slot0 = 0;
+    if (threadIdx.x < 64) { key0 = lkey[threadIdx.x]; slot0 = lslot[threadIdx.x]; }
+    // every wave turns the scan blocks' totals into their exclusive offsets by itself: lane l holds blocks 2l and 2l + 1
+    static_assert(VOX_SCAN_BLOCKS == 128, "two scan blocks per lane");
     const VoxHist vh = vox_hist_of(L, fb);
-    const int *__restrict__ start = vh.start, *__restrict__ boff = vh.boff;
+    const int lane = threadIdx.x & 63;
+    const int t0 = vh.btot[2 * lane], t1 = vh.btot[2 * lane + 1];
+    const int flagged = L.flags[fb];
+    const int nb = L.bcount[(size_t)fb * (L.blk_stride + 1) + 1 + seg];
+    int inc = t0 + t1;
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o); if (lane >= o) inc += u; }
+    const int excl = inc - (t0 + t1);
+    if (blockIdx.x == 0 && threadIdx.x == 63)      // the frame's voxel count, straight into host-mapped memory (-2: the general path will order this frame)
+        __hip_atomic_store(L.m_host + fb, flagged ? -2 : inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (flagged) return;
+    if ((int)(threadIdx.x & ~63u) >= nb) return;
+    const int *__restrict__ start = vh.start;
     VoxSlot *const slots = L.t.slot + (size_t)fb * L.t.cap;
-    const unsigned long long *__restrict__ lkey = L.lkey + ((size_t)fb * L.blk_stride + blockIdx.x) * VOX_BLOCK;
-    const int *__restrict__ lslot = L.lslot + ((size_t)fb * L.blk_stride + blockIdx.x) * VOX_BLOCK;
     float4 *__restrict__ out = vox_frame(frames, fr0).out;
-    for (int e = threadIdx.x; e < nb; e += 64) {
-        const unsigned long long key = lkey[e];
-        VoxSlot *q = slots + lslot[e];
-        int row, ixr;
-        (void)vox_dense(key, row, ixr);
+    const int e = threadIdx.x;
+    const bool live = e < nb;
+    const unsigned long long key = e < 64 ? key0 : (live ? lkey[e] : 0ull);
+    int row, ixr;
+    (void)vox_dense(key, row, ixr);
+    if (!live) { row = 0; ixr = 0; }                                   // (stale list entries: any valid row)
+    const int sb = row >> 10;                                          // the row's scan block; the shuffles run with the whole wave active
+    const int off_even = __shfl(excl, sb >> 1), first_of_pair = __shfl(t0, sb >> 1);      // (both unconditional: a lane masked off would hand 0 to its readers)
+    const int row_off = off_even + ((sb & 1) ? first_of_pair : 0);
+    if (live) {
+        VoxSlot *q = slots + (e < 64 ? slot0 : lslot[e]);
         const ulonglong2 *__restrict__ rb = reinterpret_cast<const ulonglong2 *>(L.rowbits + ((size_t)fb * VOX_BINS + row) * VOX_BW);
-        int rank = start[row] + boff[row >> 10];
+        int rank = start[row] + row_off;
         const int wi = ixr >> 6;
         const unsigned long long below = (1ull << (ixr & 63)) - 1ull;
 #pragma unroll
