@@ -205,14 +205,16 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
     int *__restrict__ lslot = L.lslot + ((size_t)fb * L.blk_stride + (size_t)blockIdx.x * passes) * VOX_BLOCK;
     int *__restrict__ bcount = L.bcount + (size_t)fb * (L.blk_stride + 1) + 1 + (size_t)blockIdx.x * passes;
     unsigned long long *__restrict__ bits = L.bits + (size_t)fb * VOX_BINS * VOX_BW;
-    __shared__ unsigned long long hk[LH], hc01[LH], hc23[LH];
+    // colour sums: a tile block holds 256 points, so its four channel sums fit 16-bit fields of ONE word (hc01; 255 * 256 < 2^16); a list block
+    // sums up to 4,096 points per voxel: two words of two 32-bit fields, as in the global table
+    __shared__ unsigned long long hk[LH], hc01[LH], hc23[ORG ? 1 : LH];
     __shared__ long long hsx[LH], hsy[LH], hsz[LH];
     __shared__ unsigned int hn[LH];
     __shared__ int occ[LH];                                      // the occupied entries, compacted; then the bitmap word of each claimed one
     __shared__ unsigned char obit[LH];                           // ... and its bit
     __shared__ int bcnt, nocc, nkeys;
     VOXT(0);
-    for (int k = threadIdx.x; k < LH; k += VOX_BLOCK) { hk[k] = VOX_EMPTY; hc01[k] = 0; hc23[k] = 0; hsx[k] = 0; hsy[k] = 0; hsz[k] = 0; hn[k] = 0; }
+    for (int k = threadIdx.x; k < LH; k += VOX_BLOCK) { hk[k] = VOX_EMPTY; hc01[k] = 0; if constexpr (!ORG) hc23[k] = 0; hsx[k] = 0; hsy[k] = 0; hsz[k] = 0; hn[k] = 0; }
     if (threadIdx.x == 0) { bcnt = 0; nocc = 0; nkeys = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -251,9 +253,11 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
             VoxSlot *q = t.slot + s;
             VOXT(5);
             int wi = -1, wb = 0;                                     // the bitmap word / bit of the voxel this entry claimed (-1: none)
+            unsigned long long c01, c23;                             // the global table's form: (c0 | c1 << 32), (c2 | c3 << 32)
+            if constexpr (ORG) { const unsigned long long c = hc01[k]; c01 = (c & 0xffffull) | (((c >> 16) & 0xffffull) << 32); c23 = ((c >> 32) & 0xffffull) | ((c >> 48) << 32); }
+            else { c01 = hc01[k]; c23 = hc23[k]; }
             if (claimed) {                                               // this block owns line 1: three plain 16-byte stores
                 const unsigned long long sx = (unsigned long long)hsx[k], sy = (unsigned long long)hsy[k], sz = (unsigned long long)hsz[k];
-                const unsigned long long c01 = hc01[k], c23 = hc23[k];
                 uint4 *f = reinterpret_cast<uint4 *>(&q->first);
                 f[0] = make_uint4((unsigned int)sx, (unsigned int)(sx >> 32), (unsigned int)sy, (unsigned int)(sy >> 32));
                 f[1] = make_uint4((unsigned int)sz, (unsigned int)(sz >> 32), (unsigned int)c01, (unsigned int)(c01 >> 32));
@@ -268,8 +272,8 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
                 atomicAdd(reinterpret_cast<unsigned long long *>(&q->sx), (unsigned long long)hsx[k]);
                 atomicAdd(reinterpret_cast<unsigned long long *>(&q->sy), (unsigned long long)hsy[k]);
                 atomicAdd(reinterpret_cast<unsigned long long *>(&q->sz), (unsigned long long)hsz[k]);
-                atomicAdd(&q->c01, hc01[k]);
-                atomicAdd(&q->c23, hc23[k]);
+                atomicAdd(&q->c01, c01);
+                atomicAdd(&q->c23, c23);
                 atomicAdd(&q->n, hn[k]);
             }
             occ[e] = wi; obit[e] = (unsigned char)wb;                    // (entry e is this thread's alone)
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
         __syncthreads();
         for (int k = threadIdx.x; k < LH; k += VOX_BLOCK) {
             if (hk[k] != VOX_EMPTY) atomicOr(bits + hk[k], (unsigned long long)hsx[k]);
-            hk[k] = VOX_EMPTY; hc01[k] = 0; hc23[k] = 0; hsx[k] = 0; hsy[k] = 0; hsz[k] = 0; hn[k] = 0;      // an empty table for the passes that follow
+            hk[k] = VOX_EMPTY; hc01[k] = 0; if constexpr (!ORG) hc23[k] = 0; hsx[k] = 0; hsy[k] = 0; hsz[k] = 0; hn[k] = 0;      // an empty table for the passes that follow
         }
         if (threadIdx.x == 0) { nocc = 0; nkeys = 0; }
         __syncthreads();
@@ -323,9 +327,11 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
         const long long qx = run_scan(ok ? __double2ll_rn((double)p.x * 1048576.0) : 0ll, seg);
         const long long qy = run_scan(ok ? __double2ll_rn((double)p.y * 1048576.0) : 0ll, seg);
         const long long qz = run_scan(ok ? __double2ll_rn((double)p.z * 1048576.0) : 0ll, seg);
-        const unsigned long long c01 = run_scan((unsigned long long)(rgba & 0xffu) | ((unsigned long long)((rgba >> 8) & 0xffu) << 32), seg);
-        const unsigned long long c23 = run_scan((unsigned long long)((rgba >> 16) & 0xffu) | ((unsigned long long)(rgba >> 24) << 32), seg);
-        const int cnt = run_scan(1, seg);
+        // the four colour channels in 16-bit fields of one word (a run is at most 64 lanes: 64 * 255 < 2^16): one scan instead of two; the run's
+        // length needs none -- its lanes are consecutive, the tail knows where its head is
+        const unsigned long long c4 = run_scan((unsigned long long)(rgba & 0xffu) | ((unsigned long long)((rgba >> 8) & 0xffu) << 16) |
+                                               ((unsigned long long)((rgba >> 16) & 0xffu) << 32) | ((unsigned long long)(rgba >> 24) << 48), seg);
+        const int cnt = lane - (63 - __builtin_clzll(heads & ((2ull << lane) - 1ull))) + 1;
         VOXT(2);
         if (ok && tail) {                                            // level 2: the block's LDS table
             unsigned int s = vox_hash(key) & (LH - 1);
@@ -338,8 +344,11 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
             atomicAdd(reinterpret_cast<unsigned long long *>(&hsx[s]), (unsigned long long)qx);
             atomicAdd(reinterpret_cast<unsigned long long *>(&hsy[s]), (unsigned long long)qy);
             atomicAdd(reinterpret_cast<unsigned long long *>(&hsz[s]), (unsigned long long)qz);
-            atomicAdd(&hc01[s], c01);
-            atomicAdd(&hc23[s], c23);
+            if constexpr (ORG) atomicAdd(&hc01[s], c4);
+            else {
+                atomicAdd(&hc01[s], (c4 & 0xffffull) | (((c4 >> 16) & 0xffffull) << 32));
+                atomicAdd(&hc23[s], ((c4 >> 32) & 0xffffull) | ((c4 >> 48) << 32));
+            }
             atomicAdd(&hn[s], (unsigned int)cnt);
         }
         __syncthreads();
