@@ -1612,7 +1612,7 @@ static int vox_alloc(slam3d_icp_handle *h, int B = 1)
     while (cap < h->N) cap <<= 1;                         // every point its own voxel still fits; typical load ~ 0.1
     // insert blocks: runs of 256 records, or 16x16 tiles of the organized image (ragged edges need a few more)
     int nblk = std::max((h->N + VOX_BLOCK - 1) / VOX_BLOCK, ((h->p.width + VOX_TW - 1) / VOX_TW) * ((h->p.height + VOX_TW - 1) / VOX_TW));
-    nblk = (nblk + VOX_MAX_PASSES - 1) / VOX_MAX_PASSES * VOX_MAX_PASSES;      // list blocks own `passes` whole segments of the claim lists
+    nblk = (nblk + VOX_SEG_ALIGN - 1) / VOX_SEG_ALIGN * VOX_SEG_ALIGN;      // list blocks own whole segments of the claim lists
     const size_t Bz = (size_t)B;
     if (hipMalloc((void **)&h->vox_mem, Bz * cap * sizeof(VoxSlot)) != hipSuccess ||
         hipMalloc((void **)&h->vox_lkey, sizeof(unsigned long long) * Bz * nblk * VOX_BLOCK) != hipSuccess ||
@@ -1703,17 +1703,18 @@ static int voxel_grid_impl(slam3d_icp_handle *h, int B, const VoxFrame *frames, 
     }
     // an organized cloud (all width x height records present) is cut into 16x16-pixel tiles, anything else into runs of 256
     const bool org = all_full;
-    // a list block sums `passes` runs of 256 records before it touches the global table (voxel.hpp): 16 when the batch fills the chip anyway,
-    // 4 for a single list (217 blocks of four runs each: the call's latency is the longest block), 8 in between
-    int passes = org ? 1 : (B >= 8 ? VOX_MAX_PASSES : (B >= 2 ? 8 : 4));      // (measured on the reference's 221 k-record frames: tools/quick_voxel.py)
+    // a list block sums `passes` runs of 1,024 records before it touches the global table (voxel.hpp): 4 when the batch fills the chip anyway
+    // (55 blocks per 221 k-record frame), 2 for one or two lists (109 blocks each: the call's latency is the longest block)
+    int passes = org ? 1 : (B >= 4 ? VOX_MAX_PASSES : 2);      // (measured on the reference's 221 k-record frames: tools/quick_voxel.py)
     if (!org) { if (const char *e = getenv("SLAM3D_VOX_PASSES")) passes = std::min(VOX_MAX_PASSES, std::max(1, atoi(e))); }      // developer knob
-    const int nins = org ? ((h->p.width + VOX_TW - 1) / VOX_TW) * ((h->p.height + VOX_TW - 1) / VOX_TW) : (nmax + passes * VOX_BLOCK - 1) / (passes * VOX_BLOCK);
-    const int nblk = nins * passes;                       // segments of the claim lists = blocks of the launches that walk them
+    const int run = org ? VOX_BLOCK : VOX_LIST_BLOCK, segs = run / VOX_BLOCK;
+    const int nins = org ? ((h->p.width + VOX_TW - 1) / VOX_TW) * ((h->p.height + VOX_TW - 1) / VOX_TW) : (nmax + passes * run - 1) / (passes * run);
+    const int nblk = nins * passes * segs;                // segments of the claim lists = blocks of the launches that walk them
     if (org) hipLaunchKernelGGL(k_voxel_insert<true>, dim3(nins, B), dim3(VOX_BLOCK), 0, s, frames[0], d_frames, h->p.width, h->p.height, 1.0f / leaf, zmin, zmax, L, passes);
-    else hipLaunchKernelGGL(k_voxel_insert<false>, dim3(nins, B), dim3(VOX_BLOCK), 0, s, frames[0], d_frames, h->p.width, h->p.height, 1.0f / leaf, zmin, zmax, L, passes);
+    else hipLaunchKernelGGL(k_voxel_insert<false>, dim3(nins, B), dim3(VOX_LIST_BLOCK), 0, s, frames[0], d_frames, h->p.width, h->p.height, 1.0f / leaf, zmin, zmax, L, passes);
     for (int b = 0; b < B; ++b) ((volatile int *)h->pin_vox_m)[b] = -1;
     hipLaunchKernelGGL(k_voxel_scan<true>, dim3(VOX_SCAN_BLOCKS, B), dim3(1024), 0, s, L);
-    hipLaunchKernelGGL(k_voxel_finalize, dim3(nblk, B), dim3(VOX_BLOCK), 0, s, frames[0], d_frames, L, nins, passes);
+    hipLaunchKernelGGL(k_voxel_finalize, dim3(nblk, B), dim3(VOX_BLOCK), 0, s, frames[0], d_frames, L, nins, passes * segs);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->vox_done, s));
     h->vox_done_valid = true;

@@ -185,25 +185,30 @@ __device__ long long g_vox_dbg[4096 * 8];
 #endif
 constexpr int VOX_LH = 512;            // LDS hash entries per block (256 points: load <= 0.5)
 constexpr int VOX_TW = 16;             // tile edge in pixels (ORG)
-constexpr int VOX_MAX_PASSES = 16;     // runs of 256 records a list block may take (the claim lists are allocated in multiples of it)
+constexpr int VOX_LIST_BLOCK = 1024;   // threads of a LIST insert block: a run is 1,024 consecutive records, summed in one pass
+constexpr int VOX_MAX_PASSES = 4;      // runs a list block may take
+constexpr int VOX_SEG_ALIGN = VOX_MAX_PASSES * VOX_LIST_BLOCK / 256;      // the claim lists are allocated in multiples of a list block's segments
 
-// Point LISTS (round 6): a block takes `passes` runs of 256 consecutive records into ONE LDS table before it touches the global one.  The
-// reference's PCD frames are raster-ordered lists without the invalid pixels: 256 records are half an image row, a 3 cm voxel at 2 m spans six
-// rows, so every voxel was claimed once and then updated by five other blocks with six atomics each (302 k memory-side atomics per frame; an
-// organized frame cut into 16x16 tiles needs 66 k).  4096 records are nine rows: 58 k.  The table (1024 entries) is flushed early whenever the
-// next pass could fill it, so any input is handled; the block's claim list is its `passes` segments of 256, filled in order.
+// Point LISTS (round 6): a block of 1,024 threads takes `passes` runs of 1,024 consecutive records into ONE LDS table before it touches the
+// global one.  The reference's PCD frames are raster-ordered lists without the invalid pixels: 256 records (round 5's block) are half an image
+// row, a 3 cm voxel at 2 m spans six rows, so every voxel was claimed once and then updated by five other blocks with six atomics each (302 k
+// memory-side atomics per frame; an organized frame cut into 16x16 tiles needs 66 k).  4,096 records are nine rows: 58 k.  The table (2,048
+// entries: a run cannot fill more than half) is flushed early whenever the next run could fill it, so any input is handled; the block's
+// claim list is its passes x 4 segments of 256 entries, filled in order.
 template <bool ORG>
-__global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const VoxFrame *__restrict__ frames, int W, int H, float inv_leaf, float zmin,
+__global__ __launch_bounds__(ORG ? VOX_BLOCK : VOX_LIST_BLOCK) void k_voxel_insert(VoxFrame f0, const VoxFrame *__restrict__ frames, int W, int H, float inv_leaf, float zmin,
                                                             float zmax, VoxLayout L, int passes /* runs of 256 records per block (lists; 1 for tiles) */)
 {
-    constexpr int LH = ORG ? VOX_LH : 2 * VOX_LH;
+    constexpr int BS = ORG ? VOX_BLOCK : VOX_LIST_BLOCK;       // threads = records per run
+    constexpr int LH = 2 * BS;                                 // LDS hash entries: a run cannot fill more than half
+    constexpr int SEGS = BS / VOX_BLOCK;                       // claim-list segments (of VOX_BLOCK entries) a run may fill
     const VoxFrame fr = vox_frame(frames, f0);
     const float4 *__restrict__ pts = fr.pts;
     const int n = fr.n, fb = blockIdx.y;
     VoxTable t = L.t; t.slot += (size_t)fb * t.cap;
-    unsigned long long *__restrict__ lkey = L.lkey + ((size_t)fb * L.blk_stride + (size_t)blockIdx.x * passes) * VOX_BLOCK;
-    int *__restrict__ lslot = L.lslot + ((size_t)fb * L.blk_stride + (size_t)blockIdx.x * passes) * VOX_BLOCK;
-    int *__restrict__ bcount = L.bcount + (size_t)fb * (L.blk_stride + 1) + 1 + (size_t)blockIdx.x * passes;
+    unsigned long long *__restrict__ lkey = L.lkey + ((size_t)fb * L.blk_stride + (size_t)blockIdx.x * passes * SEGS) * VOX_BLOCK;
+    int *__restrict__ lslot = L.lslot + ((size_t)fb * L.blk_stride + (size_t)blockIdx.x * passes * SEGS) * VOX_BLOCK;
+    int *__restrict__ bcount = L.bcount + (size_t)fb * (L.blk_stride + 1) + 1 + (size_t)blockIdx.x * passes * SEGS;
     unsigned long long *__restrict__ bits = L.bits + (size_t)fb * VOX_BINS * VOX_BW;
     // colour sums: a tile block holds 256 points, so its four channel sums fit 16-bit fields of ONE word (hc01; 255 * 256 < 2^16); a list block
     // sums up to 4,096 points per voxel: two words of two 32-bit fields, as in the global table
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
     __shared__ unsigned char obit[LH];                           // ... and its bit
     __shared__ int bcnt, nocc, nkeys;
     VOXT(0);
-    for (int k = threadIdx.x; k < LH; k += VOX_BLOCK) { hk[k] = VOX_EMPTY; hc01[k] = 0; if constexpr (!ORG) hc23[k] = 0; hsx[k] = 0; hsy[k] = 0; hsz[k] = 0; hn[k] = 0; }
+    for (int k = threadIdx.x; k < LH; k += BS) { hk[k] = VOX_EMPTY; hc01[k] = 0; if constexpr (!ORG) hc23[k] = 0; hsx[k] = 0; hsy[k] = 0; hsz[k] = 0; hn[k] = 0; }
     if (threadIdx.x == 0) { bcnt = 0; nocc = 0; nkeys = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
             const int u = tx * VOX_TW + (threadIdx.x & (VOX_TW - 1)), v = ty * VOX_TW + (threadIdx.x / VOX_TW);
             if (u < W && v < H) i = v * W + u;
         } else {
-            i = (blockIdx.x * passes + pass) * VOX_BLOCK + threadIdx.x;
+            i = (blockIdx.x * passes + pass) * BS + threadIdx.x;
             if (i >= n) i = -1;
         }
         return i;
@@ -234,12 +239,12 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
     // level 3: one global update per (block, voxel) in the table, then the table is empty again.  The occupied entries are compacted first, so
     // that each has a thread of its own and the block pays one round of returning-atomic latency per 256 of them.
     auto flush = [&]() __attribute__((always_inline)) {
-        for (int k = threadIdx.x; k < LH; k += VOX_BLOCK)
+        for (int k = threadIdx.x; k < LH; k += BS)
             if (hk[k] != VOX_EMPTY) occ[atomicAdd(&nocc, 1)] = k;
         __syncthreads();
         const int n_occ = nocc;
         VOXT(4);
-        for (int e = threadIdx.x; e < n_occ; e += VOX_BLOCK) {
+        for (int e = threadIdx.x; e < n_occ; e += BS) {
             const int k = occ[e];
             const unsigned long long gk = hk[k];
             unsigned int s = vox_hash(gk) & (unsigned int)(t.cap - 1);
@@ -280,9 +285,9 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
         }
         // the claimed voxels' bits, ORed per bitmap word in LDS (the hash arrays are free by now: hk = word index, hsx = bits)
         __syncthreads();
-        for (int k = threadIdx.x; k < LH; k += VOX_BLOCK) { hk[k] = VOX_EMPTY; hsx[k] = 0; }
+        for (int k = threadIdx.x; k < LH; k += BS) { hk[k] = VOX_EMPTY; hsx[k] = 0; }
         __syncthreads();
-        for (int e = threadIdx.x; e < n_occ; e += VOX_BLOCK) {
+        for (int e = threadIdx.x; e < n_occ; e += BS) {
             const int wi = occ[e];
             if (wi < 0) continue;
             unsigned int s = vox_hash((unsigned long long)wi) & (LH - 1);
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
             atomicOr(reinterpret_cast<unsigned long long *>(&hsx[s]), 1ull << obit[e]);
         }
         __syncthreads();
-        for (int k = threadIdx.x; k < LH; k += VOX_BLOCK) {
+        for (int k = threadIdx.x; k < LH; k += BS) {
             if (hk[k] != VOX_EMPTY) atomicOr(bits + hk[k], (unsigned long long)hsx[k]);
             hk[k] = VOX_EMPTY; hc01[k] = 0; if constexpr (!ORG) hc23[k] = 0; hsx[k] = 0; hsy[k] = 0; hsz[k] = 0; hn[k] = 0;      // an empty table for the passes that follow
         }
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_insert(VoxFrame f0, const V
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     VOXT(7);
-    if ((int)threadIdx.x < passes) bcount[threadIdx.x] = min(VOX_BLOCK, max(0, bcnt - (int)threadIdx.x * VOX_BLOCK));      // the block's segments, filled in order
+    if ((int)threadIdx.x < passes * SEGS) bcount[threadIdx.x] = min(VOX_BLOCK, max(0, bcnt - (int)threadIdx.x * VOX_BLOCK));      // the block's segments, filled in order
 }
 
 // general ordering path only: the row histogram of a flagged frame, from its claim lists.  grid (insert blocks, frames)

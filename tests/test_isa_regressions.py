@@ -140,14 +140,14 @@ def test_persistent_list_kernel_keeps_its_co_residency_budget(device_asm):
 def test_voxel_insert_keeps_six_tile_blocks_per_cu(device_asm):
     """k_voxel_insert (row f-1, round 6): a frame alone is 1,200 tile blocks that must all be resident at once (the launch is one block
     lifetime long), and batches are bound by block lifetime x occupancy -- the tile instance stays under 160 KB / 6 of LDS, the list instance
-    (1,024-entry table) under 160 KB / 2, no scratch in either; the scan and finalize launches use no fence (buffer_wbl2 / buffer_inv).
+    (1,024 threads, 2,048-entry table) within the 160 KB of a CU, no scratch in either; the scan and finalize launches use no fence (buffer_wbl2 / buffer_inv).
     Parity: tests/test_voxel.py."""
     meta = _meta(device_asm)
     tile = [n for n in meta if "k_voxel_insertILb1" in n]
     lst = [n for n in meta if "k_voxel_insertILb0" in n]
     assert len(tile) == 1 and len(lst) == 1, (tile, lst)
     assert int(meta[tile[0]]["group_segment_fixed_size"]) <= 160 * 1024 // 6, meta[tile[0]]["group_segment_fixed_size"]
-    assert int(meta[lst[0]]["group_segment_fixed_size"]) <= 160 * 1024 // 2, meta[lst[0]]["group_segment_fixed_size"]
+    assert int(meta[lst[0]]["group_segment_fixed_size"]) <= 160 * 1024, meta[lst[0]]["group_segment_fixed_size"]
     for n in tile + lst + [m for m in meta if "k_voxel_scan" in m or "k_voxel_finalize" in m]:
         assert int(meta[n]["private_segment_fixed_size"]) == 0 and int(meta[n]["vgpr_spill_count"]) == 0, (n, meta[n])
         assert int(meta[n]["vgpr_count"]) <= 64, (n, meta[n]["vgpr_count"])
