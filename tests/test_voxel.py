@@ -237,6 +237,33 @@ def test_hip_voxel_grid_dense_and_general_ordering_paths(gpu_lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("size", [(1280, 960), (200, 150)])
+def test_hip_voxel_grid_other_frame_sizes_and_list_blocks(gpu_lib, size):
+    """The list insert's blocks take 2 (one or two lists) or 4 (batches) runs of 1,024 records and own whole segments of the claim lists; the
+    organized insert cuts ragged 16x16 tiles.  A config-5 sized frame and one whose sides are no multiples of 16, as organized frames and as
+    PCD-form lists (invalid pixels dropped, lengths that are no multiples of 1,024), single calls and a batch of five: the oracle's bits."""
+    import torch
+    from slam3d_gx_amd import capi
+    pr, c = _cloud(51, *size)
+    lst = np.ascontiguousarray(c[np.isfinite(c[:, 2])])
+    cut = np.ascontiguousarray(lst[: len(lst) - 777])
+    with capi.IcpHandle(capi.default_params(pr.intr, max_batch=1)) as h:
+        for cloud in (c, lst, cut, lst[:1023], lst[:1025]):
+            got = h.voxel_grid(cloud)
+            want = O.voxel_grid(cloud)
+            assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)), len(cloud)
+        clouds = [lst, cut, lst[:5000], lst[:1], lst[: len(lst) // 2]]
+        ds = [torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0") for x in clouds]
+        outs = [torch.zeros_like(d) for d in ds]
+        ms = h.voxel_grid_batch_device([d.data_ptr() for d in ds], [len(x) for x in clouds], [o.data_ptr() for o in outs], 0.03, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for x, o, m in zip(clouds, outs, ms):
+            want = O.voxel_grid(x)
+            assert m == want.shape[0] and np.array_equal(o[:m].cpu().numpy().view(np.uint32), want.view(np.uint32)), len(x)
+        assert h.voxel_grid_path_counts()[1] == 0
+
+
+@pytest.mark.gpu
 def test_hip_voxel_grid_device_on_a_caller_stream_is_stream_ordered(gpu_lib):
     """With a caller's stream the call returns as soon as the count is known (host-mapped, written by the scan kernel);
     the records are ready in stream order.  Back-to-back calls reuse the table (self-cleaning) while the previous
