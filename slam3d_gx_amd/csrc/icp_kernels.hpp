@@ -2035,8 +2035,9 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                     const int q = __builtin_ctz(m);
                     m &= m - 1u;
                     const float4 *__restrict__ cand = st + (q >> 2) * STAGE_REC + (q & 3) * QSTRIDE;
+                    const int nq = __float_as_int(st[(q >> 2) * STAGE_REC + 4 * QSTRIDE + 2 * (q & 3)].w);     // the quadrant's live slots come first (k_frame_tiles)
 #pragma unroll 1
-                    for (int i = 0; i < 16; i += 4) {
+                    for (int i = 0; i < nq; i += 4) {
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const float4 c4 = cand[i + u];
@@ -2056,9 +2057,10 @@ __global__ __launch_bounds__(64 * NN_WAVES) __attribute__((amdgpu_waves_per_eu(W
                     const int q = __builtin_ctz(m);
                     m &= m - 1u;
                     const float4 *__restrict__ cand = st + (q >> 2) * STAGE_REC + (q & 3) * QSTRIDE;
-                    // the padding slots of a quadrant hold (+inf, +inf, +inf): d2 = +inf never wins
+                    const int nq = __float_as_int(st[(q >> 2) * STAGE_REC + 4 * QSTRIDE + 2 * (q & 3)].w);     // the quadrant's live slots come first (k_frame_tiles)
+                    // the padding slots of a quadrant hold (+inf, +inf, +inf): d2 = +inf never wins (the last group of four may reach into them)
 #pragma unroll 1
-                    for (int i = 0; i < 16; i += 4) {
+                    for (int i = 0; i < nq; i += 4) {
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
                             const float4 c4 = cand[i + u];
