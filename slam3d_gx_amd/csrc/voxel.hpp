@@ -5,18 +5,18 @@
 // oracle/voxel_oracle.c is the CPU twin.  The centroids come from integer fixed-point sums (2^-20 m) and
 // integer colour sums, so the atomics below give the same bits whatever order they land in.
 //
-//   k_voxel_insert   one thread per point: 64-bit voxel key (iz,iy,ix) -> open-addressing hash table in HBM
-//                    (two-line slots, see VoxSlot: atomicCAS on the key; the block that claims a slot stores its sums
-//                    with plain writes, blocks that find it claimed add theirs atomically into the key's own line).
-//                    The lane that claims a slot also lists it -- per block, through an LDS counter -- and bumps the
-//                    histogram of the (iz, iy) rows: no pass over the table is ever needed.
-//   k_voxel_scan1/2 / k_voxel_scatter   counting sort of the listed slots by row (iz, iy are the most significant fields)
-//   k_voxel_rank     output order = ascending key, like PCL's sorted linear voxel index: rank = start of the
-//                    rows a block touches + number of smaller keys among them (LDS-tiled compares), centroid
-//                    written at that rank; the slot is reset as it is read.
-// The table is SELF-CLEANING: every call leaves every slot empty and the histogram zero (round 1 cleared 52 MB of
-// table per call and scanned its 2^20 slots for the occupied ones: 0.4 % of the HBM roofline).  No host round trip
-// until the final count.
+//   k_voxel_insert   one thread per point: 64-bit voxel key (iz,iy,ix); runs of equal keys summed in the wave, then in a block-local LDS
+//                    table, then ONE update of the open-addressing table in HBM per (block, voxel) (two-line slots, see VoxSlot: atomicCAS
+//                    on the key; the block that claims a slot stores its sums with plain writes, blocks that find it claimed add theirs
+//                    atomically into the key's own line).  The lane that claims a slot lists it (per block, through an LDS counter) and
+//                    sets the voxel's BIT in the occupancy bitmap of its (iz, iy) row -- ORed per block in LDS first.
+//   k_voxel_scan<true>   row popcounts -> row starts (prefix inside blocks of 1,024 rows + block totals); occupied rows copied aside, bitmap cleared.
+//   k_voxel_finalize     output order = ascending key, like PCL's sorted linear voxel index: rank = start of the voxel's row + occupied
+//                    bits below its own; centroid written at that rank; the slot is reset as it is read; the count goes to host-mapped memory.
+//   general path (a frame with a voxel outside the bitmap's key range -- flagged on the device, run by the host in the same call):
+//   k_voxel_hist / k_voxel_scan<false> / k_voxel_scatter / k_voxel_rank: counting sort of the listed slots by row, rank by key compares.
+// The tables are SELF-CLEANING: every call leaves every slot empty, the bitmap and the histogram zero (round 1 cleared 52 MB of
+// table per call and scanned its 2^20 slots for the occupied ones: 0.4 % of the HBM roofline).  No host round trip until the final count.
 #pragma once
 
 #include <hip/hip_runtime.h>
