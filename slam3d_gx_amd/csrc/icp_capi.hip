@@ -1713,8 +1713,16 @@ static int voxel_grid_impl(slam3d_icp_handle *h, int B, const VoxFrame *frames, 
     if (org) hipLaunchKernelGGL(k_voxel_insert<true>, dim3(nins, B), dim3(VOX_BLOCK), 0, s, frames[0], d_frames, h->p.width, h->p.height, 1.0f / leaf, zmin, zmax, L, passes);
     else hipLaunchKernelGGL(k_voxel_insert<false>, dim3(nins, B), dim3(VOX_LIST_BLOCK), 0, s, frames[0], d_frames, h->p.width, h->p.height, 1.0f / leaf, zmin, zmax, L, passes);
     for (int b = 0; b < B; ++b) ((volatile int *)h->pin_vox_m)[b] = -1;
-    hipLaunchKernelGGL(k_voxel_scan<true>, dim3(VOX_SCAN_BLOCKS, B), dim3(1024), 0, s, L);
-    hipLaunchKernelGGL(k_voxel_finalize, dim3(nblk, B), dim3(VOX_BLOCK), 0, s, frames[0], d_frames, L, nins, passes * segs);
+    // the slabs PassThrough lets through (vox_key's arithmetic: floorf(z * inv_leaf), monotone in z) -> the scan blocks that can hold a bit
+    int sb0 = 0, sb1 = VOX_SCAN_BLOCKS;
+    {
+        const float inv_leaf = 1.0f / leaf;
+        const float lo = floorf(zmin * inv_leaf), hi = floorf(zmax * inv_leaf);
+        if (lo == lo && lo > -1.0e6f) sb0 = std::min(VOX_SCAN_BLOCKS - 1, std::max(0, ((int)lo + (int)zbias) * VOX_BY / 1024));
+        if (hi == hi && hi < 1.0e6f) sb1 = std::max(sb0 + 1, std::min(VOX_SCAN_BLOCKS, ((int)hi + (int)zbias) * VOX_BY / 1024 + 1));
+    }
+    hipLaunchKernelGGL(k_voxel_scan<true>, dim3(sb1 - sb0, B), dim3(1024), 0, s, L, sb0);
+    hipLaunchKernelGGL(k_voxel_finalize, dim3(nblk, B), dim3(VOX_BLOCK), 0, s, frames[0], d_frames, L, nins, passes * segs, sb0, sb1);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->vox_done, s));
     h->vox_done_valid = true;
@@ -1723,7 +1731,7 @@ static int voxel_grid_impl(slam3d_icp_handle *h, int B, const VoxFrame *frames, 
     auto general_path = [&]() -> int {
         for (int b = 0; b < B; ++b) if (((volatile int *)h->pin_vox_m)[b] == -2) ((volatile int *)h->pin_vox_m)[b] = -1;
         hipLaunchKernelGGL(k_voxel_hist, dim3(nblk, B), dim3(VOX_BLOCK), 0, s, L);
-        hipLaunchKernelGGL(k_voxel_scan<false>, dim3(VOX_SCAN_BLOCKS, B), dim3(1024), 0, s, L);
+        hipLaunchKernelGGL(k_voxel_scan<false>, dim3(VOX_SCAN_BLOCKS, B), dim3(1024), 0, s, L, 0);
         hipLaunchKernelGGL(k_voxel_scatter, dim3(nblk, B), dim3(VOX_BLOCK), 0, s, L);
         hipLaunchKernelGGL(k_voxel_rank, dim3(nblk, B), dim3(VOX_BLOCK), 0, s, frames[0], d_frames, L);
         HIPCHK(h, hipGetLastError());

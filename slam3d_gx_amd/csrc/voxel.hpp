@@ -395,8 +395,10 @@ __device__ __forceinline__ VoxHist vox_hist_of(const VoxLayout &L, int fb)
 // grid (VOX_SCAN_BLOCKS, frames).  <BITS>: a row's count is the popcount of its bitmap words; occupied rows are copied to `rowbits` (what
 // k_voxel_finalize reads) and cleared in place -- the bitmap is empty again when the launch ends; a flagged frame reports -2 instead of its
 // count (the host then runs the general path, whose scan is the <false> instance, on it).  <false> only works on flagged frames.
+// <true> runs on the scan blocks [sb0, sb0 + gridDim.x) only: PassThrough keeps z inside [zmin, zmax], so the host knows which slabs of the row
+// table can hold a bit at all (z in [0, 7 m] at a 3 cm leaf: 59 of the 128 blocks) -- the rest of the bitmap is neither read nor counted.
 template <bool BITS>
-__global__ __launch_bounds__(1024) void k_voxel_scan(VoxLayout L)
+__global__ __launch_bounds__(1024) void k_voxel_scan(VoxLayout L, int sb0)
 {
     if (!BITS && !L.flags[blockIdx.y]) return;
     const VoxHist vh = vox_hist_of(L, blockIdx.y);
@@ -404,7 +406,8 @@ __global__ __launch_bounds__(1024) void k_voxel_scan(VoxLayout L)
         *__restrict__ boff = vh.boff, *__restrict__ ticket = vh.ticket, *__restrict__ m_host = L.m_host + blockIdx.y;
     __shared__ int wtot[16];
     __shared__ int last_sh;
-    const int i = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int sblk = (int)blockIdx.x + sb0;
+    const int i = sblk * 1024 + threadIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int v;
     if constexpr (BITS) {
         uint4 *__restrict__ rb = reinterpret_cast<uint4 *>(L.bits + ((size_t)blockIdx.y * VOX_BINS + i) * VOX_BW);
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(1024) void k_voxel_scan(VoxLayout L)
     start[i] = before + incl - v;                      // exclusive prefix inside the block
     if constexpr (!BITS) cursor[i] = 0;
     if constexpr (BITS) {       // the dense path stops here: k_voxel_finalize sums the block totals itself (no ticket, no last-block pass on the critical path)
-        if (threadIdx.x == 1023) btot[blockIdx.x] = before + incl;
+        if (threadIdx.x == 1023) btot[sblk] = before + incl;
         return;
     }
     if (threadIdx.x == 1023) {
@@ -549,7 +552,7 @@ __device__ __forceinline__ void vox_emit(VoxSlot *q, float4 *__restrict__ out, i
 // Workgroups go to the XCDs round robin, and a list block fills its first segments only: taken in list order, the busy segments of blocks
 // with 16 segments each would all sit on XCDs 0 and 1 (measured: 3x the launch time).  So workgroup g takes segment g / nins of insert block
 // g % nins: every block's first segment, then every block's second, ...
-__global__ __launch_bounds__(VOX_BLOCK) void k_voxel_finalize(VoxFrame fr0, const VoxFrame *__restrict__ frames, VoxLayout L, int nins, int passes)
+__global__ __launch_bounds__(VOX_BLOCK) void k_voxel_finalize(VoxFrame fr0, const VoxFrame *__restrict__ frames, VoxLayout L, int nins, int passes, int sb0, int sb1 /* the scan blocks that ran */)
 {
     const int fb = blockIdx.y;
     const int seg = ((int)blockIdx.x % nins) * passes + (int)blockIdx.x / nins;
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(VOX_BLOCK) void k_voxel_finalize(VoxFrame fr0, cons
     static_assert(VOX_SCAN_BLOCKS == 128, "two scan blocks per lane");
     const VoxHist vh = vox_hist_of(L, fb);
     const int lane = threadIdx.x & 63;
-    const int t0 = vh.btot[2 * lane], t1 = vh.btot[2 * lane + 1];
+    const int t0 = (2 * lane >= sb0 && 2 * lane < sb1) ? vh.btot[2 * lane] : 0, t1 = (2 * lane + 1 >= sb0 && 2 * lane + 1 < sb1) ? vh.btot[2 * lane + 1] : 0;
     const int flagged = L.flags[fb];
     const int nb = L.bcount[(size_t)fb * (L.blk_stride + 1) + 1 + seg];
     int inc = t0 + t1;
