@@ -1407,7 +1407,7 @@ def voxel_icp_leg(args, torch, capi, synth, local_rank, vh, d1, d2, want_cpu):
                                "roofline": {"bound": "hbm", "achieved": alg / dtb / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": alg / dtb / 1e9 / HBM_PEAK_GBPS,
                                             "algorithmic_bytes_per_step": alg, "note": "records in + records out, 64 clouds per launch sequence"}}
     res["note"] = ("the reference's operating point: readimage's voxel clouds (16,034 / 14,758 points) aligned as unorganized point lists, svd estimator, "
-                   "full scan on the bf16 matrix cores; parity: tests/test_unorganized.py")
+                   "ONE persistent launch per run (csrc/list_icp.hpp: Morton-cell tiles, exact tile-pruned search, grid barrier); parity: tests/test_unorganized.py")
     return res
 
 
@@ -1627,7 +1627,7 @@ def extra_legs(args, torch, dist, capi, synth, local_rank, est, handles, pools, 
             out["plane_normals"]["real_pair"] = real_legs(Est(capi, "plane_gate", est.coarse))
     # ---- (ii-c2) round 5: ICP at the reference's ACTUAL operating point: readimage's cloud -- the frame's records
     # through PassThrough + VoxelGrid(0.03): 16,034 / 14,758 points for the reference's data/exp1 frames -- aligned as UNORGANIZED
-    # clouds (height == 1 handle: full scan on the bf16 matrix cores, svd estimator), and the batched voxel grid
+    # clouds (height == 1 handle: the persistent list kernel, svd estimator), and the batched voxel grid
     if d1 is not None and (args.width, args.height) == (640, 480):
         try:
             out["voxel_icp"] = voxel_icp_leg(args, torch, capi, synth, local_rank, handles[0], d1, d2, "cpu_baseline" in out)
