@@ -1679,7 +1679,7 @@ static int voxel_grid_impl(slam3d_icp_handle *h, int B, const VoxFrame *frames, 
     if (nmax == 0) return SLAM3D_OK;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     // The handle's tables (hash slots, histogram, claim lists) serve one call at a time.  With a caller's stream a call returns
-    // as soon as the count is known, its scatter and rank launches still queued: whatever stream the NEXT call runs on first
+    // as soon as the count is known, the rest of its finalize launch still running: whatever stream the NEXT call runs on first
     // waits for the end of those launches (two streams raced on the tables).
     if (!h->vox_done) HIPCHK(h, hipEventCreateWithFlags(&h->vox_done, hipEventDisableTiming));
     if (h->vox_done_valid) HIPCHK(h, hipStreamWaitEvent(s, h->vox_done, 0));
@@ -1743,7 +1743,7 @@ static int voxel_grid_impl(slam3d_icp_handle *h, int B, const VoxFrame *frames, 
     bool flagged = false;
     if (stream) {
         // A caller's stream: the records are ready IN STREAM ORDER, and the call returns as soon as the counts are known --
-        // k_voxel_scan writes them into host-mapped memory while the scatter and rank launches are still queued behind it.
+        // the first workgroup of k_voxel_finalize writes them into host-mapped memory while the others still emit records.
         for (int b = 0; b < B; ++b) {
             int m = -1;
             for (unsigned spins = 1; (m = ((volatile int *)h->pin_vox_m)[b]) == -1; ++spins) {
@@ -1759,7 +1759,7 @@ static int voxel_grid_impl(slam3d_icp_handle *h, int B, const VoxFrame *frames, 
             flagged = flagged || m == -2;
         }
     } else {
-        HIPCHK(h, hipStreamSynchronize(s));      // the voxel counts are in host-mapped memory by now (written by k_voxel_scan)
+        HIPCHK(h, hipStreamSynchronize(s));      // the voxel counts are in host-mapped memory by now (written by k_voxel_finalize)
         for (int b = 0; b < B; ++b) { n_out[b] = ((volatile int *)h->pin_vox_m)[b]; flagged = flagged || n_out[b] == -2; }
     }
     if (pass == 0) ++(flagged ? h->vox_calls_general : h->vox_calls_dense);
