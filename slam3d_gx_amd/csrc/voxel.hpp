@@ -238,7 +238,7 @@ __global__ __launch_bounds__(ORG ? VOX_BLOCK : VOX_LIST_BLOCK) void k_voxel_inse
     };
     // level 3: one global update per (block, voxel) in the table, then the table is empty again.  The occupied entries are compacted first, so
     // that each has a thread of its own and the block pays one round of returning-atomic latency per 256 of them.
-    auto flush = [&]() __attribute__((always_inline)) {
+    auto flush = [&](bool last) __attribute__((always_inline)) {
         for (int k = threadIdx.x; k < LH; k += BS)
             if (hk[k] != VOX_EMPTY) occ[atomicAdd(&nocc, 1)] = k;
         __syncthreads();
@@ -301,8 +301,9 @@ __global__ __launch_bounds__(ORG ? VOX_BLOCK : VOX_LIST_BLOCK) void k_voxel_inse
         __syncthreads();
         for (int k = threadIdx.x; k < LH; k += BS) {
             if (hk[k] != VOX_EMPTY) atomicOr(bits + hk[k], (unsigned long long)hsx[k]);
-            hk[k] = VOX_EMPTY; hc01[k] = 0; if constexpr (!ORG) hc23[k] = 0; hsx[k] = 0; hsy[k] = 0; hsz[k] = 0; hn[k] = 0;      // an empty table for the passes that follow
+            if (!last) { hk[k] = VOX_EMPTY; hc01[k] = 0; if constexpr (!ORG) hc23[k] = 0; hsx[k] = 0; hsy[k] = 0; hsz[k] = 0; hn[k] = 0; }      // an empty table for the runs that follow
         }
+        if (last) return;
         if (threadIdx.x == 0) { nocc = 0; nkeys = 0; }
         __syncthreads();
     };
@@ -359,9 +360,9 @@ __global__ __launch_bounds__(ORG ? VOX_BLOCK : VOX_LIST_BLOCK) void k_voxel_inse
         __syncthreads();
         VOXT(3);
         // the next run may bring 256 new keys: the table must not fill up (load <= 3/4), so it is emptied early when more than half is taken
-        if (!ORG && pass + 1 < passes && nkeys > LH / 2) flush();
+        if (!ORG && pass + 1 < passes && nkeys > LH / 2) flush(false);
     }
-    flush();
+    flush(true);                                                    // (bcnt is final behind the barriers inside)
     VOXT(6);
 #ifdef VOX_DBG
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
