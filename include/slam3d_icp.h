@@ -110,7 +110,11 @@ typedef struct slam3d_icp_params {
  * and hands to the plane extraction (:158).  Views may then carry any width <= params.width (height 1); records beyond a view are
  * invalid.  No camera model is assumed (fx .. cy unused; |x|, |y| <= z for the range check), there are no image windows or tiles:
  * the estimator is SLAM3D_EST_SVD or SLAM3D_EST_PLANE with SLAM3D_PLANE_ONLY (SLAM3D_E_INVALID otherwise) and SLAM3D_NN_AUTO selects
- * the full scan on the matrix cores.  Spec S4c's coarse iterations take the points whose index i satisfies (i / 8) mod 4 == 0. */
+ * one persistent launch per run (round 6: Morton-cell tiles, exact tile-pruned search; SLAM3D_NN_MFMA16 / _MFMA / _VALU keep the full scans).
+ * Spec S4c's coarse iterations take the points whose index i satisfies (i / 8) mod 4 == 0.  The persistent launch needs all its blocks
+ * resident (at most four such runs in flight per device and process): should a grid barrier not open within
+ * about two seconds -- another process's persistent work on the device -- the run is given up, fetch / align return SLAM3D_E_HIP and the
+ * pairs carry the failure convention (identity, SLAM3D_DEGENERATE); nothing hangs, the handle stays usable. */
 /* a borrowed view of an organized cloud: `data` points at width*height records of
  * `stride_bytes` each whose first 12 bytes are float x,y,z (pcl::PointXYZRGBA is 32 B,
  * src/GraphicEnd.h:71-72; a packed float4 cloud is 16 B).  Invalid = NaN or z <= 0. */

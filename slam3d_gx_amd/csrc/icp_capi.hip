@@ -67,6 +67,7 @@ struct slam3d_icp_handle {
     // plane segmentation (f-2): allocated on first use
     SegState *seg_state = nullptr, *pin_seg = nullptr;
     SegScratch *seg_scratch = nullptr;     // the persistent segmentation launch's accumulators (two frames)
+    int ls_test_stall_it = -1;                    // SLAM3D_LIST_TEST_STALL=<iteration>: developer hook of the test of the list kernel's barrier watchdog (list_icp.hpp, LS_ABORT)
     bool seg_persist = false;              // SLAM3D_SEG_PERSIST=1: developer knob, one persistent launch per pass (plane_seg.hpp: bit-identical, measured SLOWER -- 263 vs 139 us per frame)
     int *seg_labels = nullptr;
     const float4 **seg_ptrs = nullptr;
@@ -461,6 +462,7 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     if (getenv("SLAM3D_HEAD_SOLVE")) h->head_solve = atoi(getenv("SLAM3D_HEAD_SOLVE"));
     if (getenv("SLAM3D_CERT")) h->cert_on = atoi(getenv("SLAM3D_CERT")) != 0;
     if (getenv("SLAM3D_SEG_PERSIST")) h->seg_persist = atoi(getenv("SLAM3D_SEG_PERSIST")) != 0;
+    if (getenv("SLAM3D_LIST_TEST_STALL")) h->ls_test_stall_it = atoi(getenv("SLAM3D_LIST_TEST_STALL"));
     A(dalloc(h->slot_rec, (size_t)h->maxB * tg.nslots)); A(dalloc(h->tile_cum, (size_t)h->maxB * tg.ntiles));
     A(dalloc(h->sums, (size_t)h->maxB * NRAW + 8)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
     A(dalloc(h->trace_T, (size_t)h->maxB * (iters + 1) * 16)); A(dalloc(h->trace_S, (size_t)h->maxB * iters * NSUMS));
@@ -1161,7 +1163,7 @@ static int enqueue_iterations(slam3d_icp_handle *h, int B, hipStream_t s, int it
         const bool gated = is_p2p(h) && (h->g.resid2 > 0.0f || h->g.min_ncos > 0.0f || h->g.pair_gate);
         if (h->profiling) { HIPCHK(h, hipEventRecord(h->ev[1], s)); HIPCHK(h, hipEventRecord(h->ev[3], s)); }
         auto launch = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(G, B), dim3(64 * LS_WAVES), 0, s, h->d_pairs, h->g, iters, n_coarse, h->nsets, h->ls_npad, h->Tcur, h->trace_T,
+            hipLaunchKernelGGL(kern, dim3(G, B), dim3(64 * LS_WAVES), 0, s, h->d_pairs, h->g, iters, n_coarse | ((h->ls_test_stall_it + 1) << 16), h->nsets, h->ls_npad, h->Tcur, h->trace_T,
                                h->trace_S, h->flags, h->acc, h->ticket, h->ticket + h->maxB, h->ls_match, h->corr, h->cd2, h->want_corr_trace ? h->corr_trace : nullptr,
                                h->maxB, h->tg.nslots, h->d_res, h->dev_runs, h->ls_dbg);
         };
@@ -1311,9 +1313,15 @@ extern "C" int slam3d_icp_fetch_results(slam3d_icp_handle *h, int32_t B, slam3d_
         // wait for THIS run only (its end event), not for whatever else the caller queued on the stream since:
         // two handles can then alternate on one stream and the host never leaves the GPU idle between runs
         HIPCHK(h, hipEventSynchronize(h->ev[2]));
+        bool gave_up = false;
         for (int b = 0; b < B; ++b) {
             const double *r = h->pin_res + (size_t)b * RES_REC;
             finish_result(h->p, r, r + 16, (int)r[45], (int)r[46], (int)r[47], out + b);
+            gave_up = gave_up || (((int)r[45]) & 4) != 0;
+        }
+        if (gave_up) {      // (list_icp.hpp, LS_ABORT: the pairs concerned carry SLAM3D_DEGENERATE and the identity)
+            h->err = "point-list ICP: a grid barrier of the persistent launch timed out (its blocks were not all resident: another process on the device?); the run was given up";
+            return SLAM3D_E_HIP;
         }
         return SLAM3D_OK;
     }

@@ -281,12 +281,30 @@ __device__ __forceinline__ void ls_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+constexpr unsigned int LS_BARRIER_POLLS = 1500000u;         // ticket polls (a memory round trip + s_sleep each, ~1.5 us) a block spends at a grid barrier before it gives the run up
+constexpr unsigned int LS_ABORT = 0x40000000u;              // bit of the barrier ticket (arrivals stay below 2^13): the run was given up, every barrier is open
+// the wait of the grid barrier, out of line (the gated instance of the kernel has no register to spare: inlined, this loop cost it two
+// spills): wave-uniform -- lane 0 loads, the value is broadcast -- so the poll counter lives in an SGPR
+__device__ __noinline__ void ls_wait_ticket(unsigned int *ticket, unsigned int want)
+{
+    const int lane = threadIdx.x & 63;
+    for (unsigned int polls = 0u;; ++polls) {
+        unsigned int seen = 0u;
+        if (lane == 0) seen = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned int)__builtin_amdgcn_readfirstlane((int)seen) >= want) break;
+        if (polls > LS_BARRIER_POLLS) {
+            if (lane == 0) __hip_atomic_fetch_or(ticket, LS_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
 constexpr int LS_LDS_TILES = 384;                       // target tiles whose boxes (32 B) and table entries (8 B) fit the block's LDS budget
 constexpr int LS_CAND = 32;                             // candidate tiles a wave lists before it scans them
 
 template <int EST, bool GATED, bool DBG = false>
 __global__ __launch_bounds__(64 * LS_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_list_icp(
-    const PairPtrs *__restrict__ pairs, Geometry g, int iters, int n_coarse, int nsets, int N,
+    const PairPtrs *__restrict__ pairs, Geometry g, int iters, int n_coarse_and_hook /* coarse iterations | (1 + iteration whose barrier block 0 of pair 0 never reaches: the watchdog's test hook, 0 = none) << 16 -- the gated instance has no register left for another argument */, int nsets, int N,
     double *__restrict__ Tcur, double *__restrict__ trace_T, double *__restrict__ trace_S, int *__restrict__ flags,
     long long *__restrict__ acc, unsigned int *__restrict__ ticket, unsigned int *__restrict__ claim /* [B], zero at launch */, float4 *__restrict__ prev /* [B][N]: previous match (x, y, z, index) by sorted source position */,
     int *__restrict__ corr, float *__restrict__ cd2, int *__restrict__ corr_trace /* nullable: [iters][maxB][nslots] */, int maxB, int nslots,
@@ -339,7 +357,7 @@ __global__ __launch_bounds__(64 * LS_WAVES) __attribute__((amdgpu_waves_per_eu(4
     };
     __syncthreads();
     for (int it = 0; it < iters; ++it) {
-        const bool coarse = it < n_coarse;
+        const bool coarse = it < (n_coarse_and_hook & 0xffff);
         long long ph_prev = 0;
         const bool stamp = DBG && dbg && b == 0 && tid == 0;          // SLAM3D_LIST_DEBUG: thread 0 of EVERY block books its phases
         if (stamp) for (int k = 0; k < 12; ++k) ph[k] = 0;
@@ -536,12 +554,16 @@ __global__ __launch_bounds__(64 * LS_WAVES) __attribute__((amdgpu_waves_per_eu(4
             // to be written back or invalidated: __threadfence() here is buffer_wbl2 + buffer_inv on gfx950, an L2 flush per block and
             // iteration that turned every later read of the (read-only) target into a miss.  The totals are read with device-scope loads.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) {
-                __hip_atomic_fetch_add(ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned int want = (unsigned int)(it + 1) * (unsigned int)G;
-                if (stamp) { const long long now_ = (long long)wall_clock64(); ph[5] += now_ - ph_prev; ph_prev = now_; }
-                while (__hip_atomic_load(ticket + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(1);
-            }
+            if (lane == 0 && !(it + 1 == (n_coarse_and_hook >> 16) && b == 0 && blockIdx.x == 0)) __hip_atomic_fetch_add(ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int want = (unsigned int)(it + 1) * (unsigned int)G;
+            if (stamp) { const long long now_ = (long long)wall_clock64(); ph[5] += now_ - ph_prev; ph_prev = now_; }
+            // WATCHDOG.  The barrier needs every block of the launch resident; the launch is sized so that this holds for four launches
+            // of one process, but nothing on the device can promise it against OTHER processes' persistent work.
+            // A block that has polled LS_BARRIER_POLLS times (about two seconds) raises LS_ABORT in the ticket word itself: every waiter (and every later
+            // barrier) then passes at once, the launch runs to its end on garbage, and block 0 reports flag 4 -- the host returns
+            // SLAM3D_E_HIP with an identity pose instead of hanging the device.  The loop is wave-uniform (lane 0 loads, the value is
+            // broadcast), so its counter lives in an SGPR: the kernel has no VGPR to spare.
+            ls_wait_ticket(ticket + b, want);
         }
         ls_barrier();
         if (stamp) { const long long now_ = (long long)wall_clock64(); ph[6] += now_ - ph_prev; ph_prev = now_; }
@@ -588,6 +610,7 @@ __global__ __launch_bounds__(64 * LS_WAVES) __attribute__((amdgpu_waves_per_eu(4
         }
         if (rc == 2) flag |= 1;
         if (rc == 0) flag |= 2;            // no update in this iteration: never a silent "ok"
+        if (last && blockIdx.x == 0 && tid == 0 && (__hip_atomic_load(ticket + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & LS_ABORT)) flag |= 4;      // the run was given up at a barrier
         if (blockIdx.x == 0) {
             if (tid < 16) trace_T[((size_t)b * (iters + 1) + it + 1) * 16 + tid] = Tsh[tid];
             if (last) {
