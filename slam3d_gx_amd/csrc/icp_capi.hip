@@ -1917,6 +1917,7 @@ extern "C" int slam3d_segment_planes_device(slam3d_icp_handle *h, int32_t B, con
     HIPCHK(h, hipStreamSynchronize(s));
     for (int b = 0; b < B; ++b) {
         const SegState &st = h->pin_seg[b];
+        if (st.n_valid < 0) { h->err = "plane segmentation: a grid barrier of the persistent launch (SLAM3D_SEG_PERSIST) timed out; the pass was given up"; return SLAM3D_E_HIP; }
         nplanes[b] = st.nplanes;
         for (int r = 0; r < sp->max_planes; ++r) {
             slam3d_plane &o = planes[(size_t)b * sp->max_planes + r];

@@ -563,11 +563,9 @@ __global__ __launch_bounds__(SEG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
         ls_barrier();
         if (w == 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (all of a block's global atomics are issued by wave 0: they have been performed)
-            if (lane == 0) {
-                epoch += 1;
-                __hip_atomic_fetch_add(&x.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                while (__hip_atomic_load(&x.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch * (unsigned int)G) __builtin_amdgcn_s_sleep(1);
-            }
+            epoch += 1;
+            if (lane == 0) __hip_atomic_fetch_add(&x.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ls_wait_ticket(&x.ticket, epoch * (unsigned int)G);       // (list_icp.hpp: bounded -- after ~2 s the abort bit opens every barrier; the end of the kernel reports it)
         }
         ls_barrier();
     };
@@ -734,7 +732,8 @@ __global__ __launch_bounds__(SEG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)
     if (rec && b == 0) printf("seg phases us: load %.1f bar %.1f | hyp %.1f count %.1f bar %.1f | mom %.1f bar %.1f | refine %.1f label %.1f bar %.1f\n", tph[0]*.01, tph[1]*.01, tph[2]*.01, tph[3]*.01, tph[4]*.01, tph[5]*.01, tph[6]*.01, tph[7]*.01, tph[8]*.01, tph[9]*.01);
 #endif
     if (rec) {
-        s.n_valid = n_valid;
+        // (a barrier that timed out -- the blocks were not all resident -- left garbage everywhere: the state says so, the host reader refuses it)
+        s.n_valid = (__hip_atomic_load(&x.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & LS_ABORT) ? -1 : n_valid;
         s.rs[0] = c; s.rs[1] = c;
         s.lab_count[0] = 0; s.lab_count[1] = 0;
         if (!c.done) s.lab_count[(sp.max_planes - 1) & 1] = last_got;      // (the loop ran its last round to the end: its labelled count is still to be booked)
