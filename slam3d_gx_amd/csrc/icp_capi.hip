@@ -2263,3 +2263,7 @@ extern "C" int slam3d_icp_dense_run(slam3d_icp_handle *h, slam3d_comm *comm, con
 #ifdef VOX_DBG
 extern "C" int slam3d_debug_vox_phases(long long *out, int n_ll) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(s3d::g_vox_dbg), sizeof(long long) * (size_t)n_ll); }
 #endif
+
+#ifdef SEGC_DBG
+extern "C" int slam3d_debug_segc_phases(long long *out, int n_ll) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(s3d::g_segc_dbg), sizeof(long long) * (size_t)n_ll); }
+#endif

@@ -203,6 +203,12 @@ __global__ __launch_bounds__(64) void k_seg_hyp(const float4 *const *__restrict_
     s.hyp[h] = seg_make_hyp(clouds[b], labels + (size_t)b * N, N, sp, r, h);
 }
 
+#ifdef SEGC_DBG
+__device__ long long g_segc_dbg[3][1200 * 8];
+#define SEGCT(k) do { if (threadIdx.x == 0 && blockIdx.y == 0 && r < 3) g_segc_dbg[r][((int)blockIdx.z * (int)gridDim.x + (int)blockIdx.x) * 8 + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define SEGCT(k) do { } while (0)
+#endif
 template <bool FUSED, int PTS>
 __global__ __launch_bounds__(SEG_BLOCK) void k_seg_count(const float4 *const *__restrict__ clouds, const int *__restrict__ labels,
                                                          SegState *__restrict__ st, int N, SegParams sp, int r)
@@ -216,6 +222,7 @@ __global__ __launch_bounds__(SEG_BLOCK) void k_seg_count(const float4 *const *__
     const int h0 = blockIdx.z * SEG_HGROUP, h1 = min(H, h0 + SEG_HGROUP);
     __shared__ SegHyp hy_sh[SEG_HGROUP];
     __shared__ int bc[SEG_H];
+    SEGCT(0);
     // this thread's points first: their loads are in flight while the head below draws the hypotheses (dependent trips of its own)
     float4 q[PTS];
     bool live[PTS];
@@ -247,8 +254,10 @@ __global__ __launch_bounds__(SEG_BLOCK) void k_seg_count(const float4 *const *__
         if (s.rs[(r + 1) & 1].done) return;                  // (k_seg_hyp ran before this launch)
         if (threadIdx.x < SEG_HGROUP) hy_sh[threadIdx.x] = s.hyp[h0 + threadIdx.x];
     }
+    SEGCT(1);
     if (threadIdx.x < SEG_H) bc[threadIdx.x] = 0;
     __syncthreads();
+    SEGCT(2);
     // lane l < SEG_HGROUP holds hypothesis h0 + l; the loop broadcasts it with v_readlane (no dependent scalar loads)
     SegHyp mh = hy_sh[lane < SEG_HGROUP ? lane : 0];
     if (lane >= SEG_HGROUP) mh.ok = 0;
@@ -264,9 +273,15 @@ __global__ __launch_bounds__(SEG_BLOCK) void k_seg_count(const float4 *const *__
         for (int k = 0; k < PTS; ++k) cc += __popcll(__ballot(live[k] && seg_inlier(nx, ny, nz, dd, t2, q[k])));
         if (lane == l) mine = cc;
     }
+    SEGCT(3);
     if (mine) atomicAdd(&bc[h0 + lane], mine);            // (mine != 0 only in lanes < SEG_HGROUP)
     __syncthreads();
+    SEGCT(4);
     if (threadIdx.x < SEG_H && bc[threadIdx.x]) atomicAdd(&s.counts[r & 1][blockIdx.x % SEG_CR][threadIdx.x], bc[threadIdx.x]);
+#ifdef SEGC_DBG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    SEGCT(5);
 }
 
 // P2 tail + P3: every block finds the best hypothesis (max count, smallest h on ties), block 0 records it, then
