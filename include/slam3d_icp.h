@@ -414,8 +414,10 @@ int slam3d_icp_dense_run_with(slam3d_icp_handle *h, int32_t rank, int32_t world,
                               const double *T_init, slam3d_icp_result *out);
 /* Test hook of the failure protocol above: iteration `dense_fail_at` of THIS handle's dense runs behaves as if it could not be
  * enqueued (SLAM3D_E_HIP on this rank, SLAM3D_E_COMM on its peers); -2: the failure happens before the first iteration; 1000 + k: behind
- * iteration k's exchange (the peers' iteration k is then complete); -1 (the default) = off.  An explicit call on a handle, not an
- * environment variable: nothing a production process inherits can switch it on. */
+ * iteration k's exchange (the peers' iteration k is then complete); -1 (the default) = off.  2000 + k: the hook of the point-list kernel's
+ * barrier watchdog instead -- in this handle's list runs one block never reaches the grid barrier of iteration k, the run is given up after
+ * about two seconds (SLAM3D_E_HIP, see the note on unorganized clouds above).  An explicit call on a handle, not an environment variable:
+ * nothing a production process inherits can switch it on. */
 int slam3d_icp_set_fault_injection(slam3d_icp_handle *h, int32_t dense_fail_at);
 
 /* BASELINE configs 3/4: pairs are independent, the only exchange is the gather of the SE(3) pose records. */

@@ -67,7 +67,7 @@ struct slam3d_icp_handle {
     // plane segmentation (f-2): allocated on first use
     SegState *seg_state = nullptr, *pin_seg = nullptr;
     SegScratch *seg_scratch = nullptr;     // the persistent segmentation launch's accumulators (two frames)
-    int ls_test_stall_it = -1;                    // SLAM3D_LIST_TEST_STALL=<iteration>: developer hook of the test of the list kernel's barrier watchdog (list_icp.hpp, LS_ABORT)
+    int ls_test_stall_it = -1;                    // slam3d_icp_set_fault_injection(h, 2000 + k): block 0 of pair 0 never reaches the barrier of iteration k (test of the list kernel's watchdog, list_icp.hpp LS_ABORT)
     bool seg_persist = false;              // SLAM3D_SEG_PERSIST=1: developer knob, one persistent launch per pass (plane_seg.hpp: bit-identical, measured SLOWER -- 263 vs 139 us per frame)
     int *seg_labels = nullptr;
     const float4 **seg_ptrs = nullptr;
@@ -462,7 +462,6 @@ extern "C" int slam3d_icp_create(const slam3d_icp_params *p, slam3d_icp_handle *
     if (getenv("SLAM3D_HEAD_SOLVE")) h->head_solve = atoi(getenv("SLAM3D_HEAD_SOLVE"));
     if (getenv("SLAM3D_CERT")) h->cert_on = atoi(getenv("SLAM3D_CERT")) != 0;
     if (getenv("SLAM3D_SEG_PERSIST")) h->seg_persist = atoi(getenv("SLAM3D_SEG_PERSIST")) != 0;
-    if (getenv("SLAM3D_LIST_TEST_STALL")) h->ls_test_stall_it = atoi(getenv("SLAM3D_LIST_TEST_STALL"));
     A(dalloc(h->slot_rec, (size_t)h->maxB * tg.nslots)); A(dalloc(h->tile_cum, (size_t)h->maxB * tg.ntiles));
     A(dalloc(h->sums, (size_t)h->maxB * NRAW + 8)); A(dalloc(h->Tcur, (size_t)h->maxB * 16));
     A(dalloc(h->trace_T, (size_t)h->maxB * (iters + 1) * 16)); A(dalloc(h->trace_S, (size_t)h->maxB * iters * NSUMS));
@@ -2224,6 +2223,8 @@ static int dense_run_impl(slam3d_icp_handle *h, int rank, int world, const Dense
 extern "C" int slam3d_icp_set_fault_injection(slam3d_icp_handle *h, int32_t dense_fail_at)
 {
     if (!h) return SLAM3D_E_INVALID;
+    if (dense_fail_at >= 2000 && dense_fail_at < 2256) { h->ls_test_stall_it = dense_fail_at - 2000; return SLAM3D_OK; }      // the point-list watchdog's hook
+    h->ls_test_stall_it = -1;
     h->dense_fail_at = dense_fail_at;
     return SLAM3D_OK;
 }

@@ -272,11 +272,11 @@ def test_four_list_runs_in_flight_on_one_device(gpu_lib):
 
 
 @pytest.mark.gpu
-def test_list_kernel_watchdog_gives_a_stalled_run_up(gpu_lib, monkeypatch):
+def test_list_kernel_watchdog_gives_a_stalled_run_up(gpu_lib):
     """The persistent list launch meets its blocks at a grid barrier: if they are not all resident (another process's persistent work on
     the device) the barrier would never open.  A block that has polled for about two seconds raises an abort bit in the ticket word:
     every barrier opens, the launch runs to its end, the host returns SLAM3D_E_HIP with the failure convention (identity, status != OK)
-    instead of hanging.  SLAM3D_LIST_TEST_STALL makes block 0 skip one arrival; a handle created afterwards runs normally."""
+    instead of hanging.  slam3d_icp_set_fault_injection(h, 2000 + k) makes block 0 skip one arrival; the handle runs normally afterwards."""
     import time
     from slam3d_gx_amd import capi
     v1, _ = kinect_voxel_clouds()
@@ -284,14 +284,13 @@ def test_list_kernel_watchdog_gives_a_stalled_run_up(gpu_lib, monkeypatch):
     src = np.ascontiguousarray(pad(v1[:n], n)); tgt = np.ascontiguousarray(pad(v1[:n], n))
     intr = synth.Intrinsics(width=n, height=1)
     Ti = synth.pose_from_seed(5, 1.0, 0.01)
-    monkeypatch.setenv("SLAM3D_LIST_TEST_STALL", "3")
     with capi.IcpHandle(capi.default_params(intr, iterations=8, estimator=capi.EST_SVD)) as h:
+        h.set_fault_injection(2003)                      # one block never reaches the barrier of iteration 3
         t0 = time.time()
         with pytest.raises(capi.Slam3dError) as e:
             h.align(src, tgt, Ti)
         assert "barrier" in str(e.value) and time.time() - t0 < 30.0
-    monkeypatch.delenv("SLAM3D_LIST_TEST_STALL")
-    with capi.IcpHandle(capi.default_params(intr, iterations=8, estimator=capi.EST_SVD)) as h:
+        h.set_fault_injection(-1)                        # the same handle, hook off: the run is the oracle's again
         r = h.align(src, tgt, Ti)
         ro = O.icp(pad(v1[:n], n), pad(v1[:n], n), O.params(intr, iterations=8, estimator=1, nn_method=1), T_init=Ti)
         assert r["status"] == ro["status"] and np.array_equal(np.asarray(r["T"]).reshape(4, 4), ro["T"])
