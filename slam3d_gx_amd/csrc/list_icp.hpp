@@ -435,7 +435,12 @@ __global__ __launch_bounds__(64 * LS_WAVES) __attribute__((amdgpu_waves_per_eu(4
                 // its load is in flight): the points of tiles k + 1 and k + 2 arrive while tile k is scanned out of the wave's 1 KB LDS stage
                 auto issue = [&](int kk, ls_f4 &r, int &n_) __attribute__((always_inline)) {
                     const int t_ = __builtin_amdgcn_readfirstlane(s_cand[w][kk < nc ? kk : 0]);     // (past the end: the first tile again, count 0)
-                    const int2 td = lds_boxes ? s_tile[t_] : make_int2(ttileg[t_].x, ttileg[t_].y);
+                    // (beyond LS_LDS_TILES the table entry comes through the SCALAR cache: a vector load here -- what hipcc made of it even on the LDS
+                    //  branch's join -- was followed by s_waitcnt vmcnt(0), which also drained the two tile loads in flight.  Measured after the fix:
+                    //  the same 29 us per iteration -- a tile's cost is its 64 candidates at one wave per SIMD (tools/ubench_pk.hip: 40 cycles per
+                    //  candidate alone on a SIMD, 21 with four waves), not its load)
+                    const ls_i2 tdc = lds_boxes ? ls_i2{ 0, 0 } : ((ls_cptri2)pp.ls_ttile)[t_];
+                    const int2 td = lds_boxes ? s_tile[t_] : make_int2(tdc.x, tdc.y);
                     n_ = kk < nc ? __builtin_amdgcn_readfirstlane(td.y) : 0;
                     ls_issue(r, tpts + (td.x + lane));            // all 64 lanes: behind a short tile lie the next tile's points or the padding
                 };
